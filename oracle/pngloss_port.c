@@ -1,0 +1,393 @@
+/*
+ * pngloss_port.c -- CPU ORACLE (test infrastructure only; see pngloss_port.h for the rules).
+ *
+ * Restatement of the reference's per-scanline optimiser, written from the semantics, not
+ * from the reference text.  Structure per row y:
+ *
+ *   pre   : nothing (E0 holds the incoming Sierra error for row y)
+ *   chain : for each of the 5 candidate filters, a strictly serial walk over x that only carries
+ *             left pixel, rem(x-1), thr(x-2) and the running symbol histogram
+ *           and records, per pixel, the chosen byte and the int16 quantisation error ("diff16")
+ *   post  : (vectorisable over x) derivative error metric, libpng heuristic filter, entropy cost
+ *   commit: winner's bytes -> image, winner's diff16 -> next two error rows, winner's histogram -> state
+ *
+ * Algebra used here and in the HIP kernels, each proven against the real reference by tests/test_oracle.py:
+ *   (1) reference: predicted +-= 256 so that orig-predicted in [-128,127]   (optimize_state.c:175-182)
+ *       here     : osym = sext8(orig - pred),  pred' = orig - osym,  filtered = here - pred' = osym + err
+ *   (2) reference: three-way clamp of [min,max] to reconstructable bytes    (optimize_state.c:195-210)
+ *       here     : min = med3(min, lo, hi), max = med3(max, lo, hi) with lo = -pred', hi = 255 - pred'
+ *   (3) reference: ascending scan with replace-rules                         (optimize_state.c:212-244)
+ *       here     : lexicographic arg-max of (H[v], O_f[v], v==osym, -v)
+ *   (4) reference: ulog2(UINTMAX_MAX / freq) by shifting                     (optimize_state.c:338,565-572)
+ *       here     : 33 + clz32(freq)
+ *   (5) reference: 10 "+=" into three int16 error rows per pixel            (optimize_state.c:445-467)
+ *       here     : rem/thr carried in registers along the chain, the eight next-row terms summed after the row
+ *                  from the stored diff16 (int16 wrap is additive, so the order does not matter)
+ *   (6) reference: three optimize_state copies + original_frequency x3       (pngloss_image.c:172-189)
+ *       here     : original_frequency once; candidates write into their own scratch, commit by copy of the winner
+ */
+#include "pngloss_port.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { F_NONE = 0, F_SUB, F_UP, F_AVG, F_PAETH, F_COUNT };
+
+static const unsigned char png_filter_flag[F_COUNT] = { 0x08, 0x10, 0x20, 0x40, 0x80 };
+
+/* ------------------------------------------------------------------ small pure helpers */
+
+static inline int paeth(int above, int diag, int left)
+{
+    int p = above - diag, pd = left - diag;
+    int pl = p < 0 ? -p : p;             /* distance to left  */
+    int pa = pd < 0 ? -pd : pd;          /* distance to above */
+    int pg = (p + pd) < 0 ? -(p + pd) : (p + pd);
+    if (pl <= pa && pl <= pg) return left;
+    return pa <= pg ? above : diag;
+}
+
+static inline int predict(int f, int above, int diag, int left)
+{
+    switch (f) {
+    case F_SUB:   return left;
+    case F_UP:    return above;
+    case F_AVG:   return (above + left) >> 1;
+    case F_PAETH: return paeth(above, diag, left);
+    default:      return 0;
+    }
+}
+
+static inline int sext8(int v)  { return (int)(int8_t)(uint8_t)(v & 0xff); }
+static inline int sext16(int v) { return (int)(int16_t)(uint16_t)(v & 0xffff); }
+static inline int med3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* which of the four error planes a pixel channel uses (color_delta.c:4-41, optimize_state.c:167-171) */
+static inline int plane_of(uint32_t bpp, uint32_t c) { return (bpp == 2 && c == 1) ? 3 : (int)c; }
+/* how many of the four expanded delta lanes carry this channel (gray is replicated into r,g,b) */
+static inline int weight_of(uint32_t bpp, uint32_t c) { return (bpp <= 2 && c == 0) ? 3 : 1; }
+
+unsigned port_symbol_cost(uint32_t freq)
+{
+    /* bit length of floor((2^64-1)/freq) == 64 - floor(log2 freq) for 1 <= freq < 2^32 */
+    return freq ? 33u + (unsigned)__builtin_clz(freq) : 0u;
+}
+
+void port_sierra_split(int diff16, long bleed, int parts[5])
+{
+    long d = (long)diff16 / bleed;       /* C division truncates toward zero */
+    long t = d / 16;  d -= 4 * t;
+    long h = d / 8;   d -= 2 * h;
+    long f = (d * 2) / 9; d -= 2 * f;
+    long v = d / 2;   d -= v;
+    parts[0] = (int)t; parts[1] = (int)h; parts[2] = (int)f; parts[3] = (int)v; parts[4] = (int)d;
+}
+
+/* ------------------------------------------------------------------ fully parallel pieces */
+
+void port_classify(const unsigned char *const *rows, uint32_t width, uint32_t height, int *grayscale, int *opaque)
+{
+    int g = 1, o = 1;
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            const unsigned char *p = rows[y] + (size_t)x * 4;
+            g &= (p[0] == p[1]) & (p[1] == p[2]);
+            o &= (p[3] == 255);
+        }
+    *grayscale = g;
+    *opaque = o;
+}
+
+void port_orig_histograms(const unsigned char *pix, uint32_t width, uint32_t height, uint32_t bpp, uint32_t out[5][256])
+{
+    memset(out, 0, sizeof(uint32_t) * 5 * 256);
+    const size_t stride = (size_t)width * bpp;
+    for (uint32_t y = 0; y < height; y++) {
+        const unsigned char *row = pix + y * stride;
+        const unsigned char *up = y ? row - stride : NULL;
+        for (size_t i = 0; i < stride; i++) {
+            int here = row[i];
+            int left = i >= bpp ? row[i - bpp] : 0;
+            int above = up ? up[i] : 0;
+            int diag = (up && i >= bpp) ? up[i - bpp] : 0;
+            for (int f = 0; f < F_COUNT; f++)
+                out[f][(here - predict(f, above, diag, left)) & 255]++;
+        }
+    }
+}
+
+int port_adaptive_filter(const unsigned char *above_row, const unsigned char *row, uint32_t width, uint32_t bpp)
+{
+    uint32_t sum[F_COUNT] = { 0, 0, 0, 0, 0 };
+    const size_t n = (size_t)width * bpp;
+    for (size_t i = 0; i < n; i++) {
+        int here = row[i];
+        int left = i >= bpp ? row[i - bpp] : 0;
+        int above = above_row ? above_row[i] : 0;
+        int diag = (above_row && i >= bpp) ? above_row[i - bpp] : 0;
+        for (int f = 0; f < F_COUNT; f++) {
+            int b = (here - predict(f, above, diag, left)) & 255;
+            sum[f] += (uint32_t)(b < 128 ? b : 256 - b);
+        }
+    }
+    int best = 0;
+    for (int f = 1; f < F_COUNT; f++)
+        if (sum[f] < sum[best]) best = f;      /* strict: first minimum in order none,sub,up,avg,paeth */
+    return best;
+}
+
+/* ------------------------------------------------------------------ the serial chain */
+
+typedef struct {
+    unsigned char *bytes;   /* [W*bpp]  candidate row                               */
+    int16_t *diff16;        /* [W*4]    quantisation error per error plane, int16   */
+    uint32_t hist[256];     /* running symbol histogram after this candidate's row  */
+    uint64_t cost;
+} candidate;
+
+typedef struct {
+    uint32_t W, H, bpp;
+    unsigned char *pix;       /* packed image: rows < y already optimised, rows >= y original */
+    unsigned char *old_above; /* original row y-1 */
+    int16_t *E0, *E1;         /* [(W)*4] incoming error for rows y and y+1 (x-major, 4 planes) */
+    uint32_t hist[256];
+    uint32_t orig_hist[5][256];
+} engine;
+
+static inline int better(uint32_t h, uint32_t o, int flag, uint32_t bh, uint32_t bo, int bflag)
+{
+    if (h != bh) return h > bh;
+    if (o != bo) return o > bo;
+    return flag > bflag;        /* equal keys: the later (larger) v only wins if it is the original symbol */
+}
+
+static void run_chain(const engine *e, uint32_t y, int f, unsigned s, long bleed, candidate *cd)
+{
+    const uint32_t W = e->W, bpp = e->bpp;
+    const size_t stride = (size_t)W * bpp;
+    const unsigned char *orig = e->pix + (size_t)y * stride;
+    const unsigned char *nabove = y ? orig - stride : NULL;
+    const uint32_t *O = e->orig_hist[f];
+    uint32_t *Hs = cd->hist;
+    const int q = (int)s + 1;
+    const bool has_alpha = (bpp % 2) == 0;
+
+    memcpy(Hs, e->hist, sizeof(e->hist));
+    int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
+
+    for (uint32_t x = 0; x < W; x++) {
+        int d16[4] = { 0, 0, 0, 0 };
+        const bool transparent = has_alpha && orig[(size_t)x * bpp + bpp - 1] == 0;
+        for (uint32_t c = 0; c < bpp; c++) {
+            const size_t o = (size_t)x * bpp + c;
+            const int pl = plane_of(bpp, c);
+            const int ov = orig[o];
+            const int above = nabove ? nabove[o] : 0;
+            const int diag = (nabove && x) ? nabove[o - bpp] : 0;
+            const int left = x ? cd->bytes[o - bpp] : 0;
+            const int pred = predict(f, above, diag, left);
+            int back, sym;
+            if (transparent && c == bpp - 1) {
+                back = 0;                      /* keep fully transparent pixels fully transparent */
+                sym = (0 - pred) & 255;
+                d16[pl] = 0;
+            } else {
+                const int err = sext16(e->E0[(size_t)x * 4 + pl] + rem[pl] + thr_prev[pl]);
+                const int osym = sext8(ov - pred);
+                const int predc = ov - osym;
+                const int filt = osym + err;
+                int vmin, vmax;
+                if (filt < 0) { vmax = -((-filt) - ((-filt) % q)); vmin = vmax - (int)s; }
+                else          { vmin = filt - (filt % q);          vmax = vmin + (int)s; }
+                const int lo = -predc, hi = 255 - predc;
+                vmin = med3(vmin, lo, hi);
+                vmax = med3(vmax, lo, hi);
+                int best = vmin;
+                uint32_t bh = Hs[vmin & 255], bo = O[vmin & 255];
+                int bflag = (vmin == osym);
+                for (int v = vmin + 1; v <= vmax; v++) {
+                    uint32_t h = Hs[v & 255], oo = O[v & 255];
+                    int fl = (v == osym);
+                    if (better(h, oo, fl, bh, bo, bflag)) { best = v; bh = h; bo = oo; bflag = fl; }
+                }
+                back = best + predc;
+                if (back < 0 || back > 255) { fprintf(stderr, "port: reconstruction %d out of range\n", back); abort(); }
+                sym = best & 255;
+                d16[pl] = sext16(filt - best);   /* == (int16)(here - back) */
+            }
+            cd->bytes[o] = (unsigned char)back;
+            Hs[sym]++;
+        }
+        /* replicated gray lanes 1,2 and the unused alpha lane are never read back; only real planes are kept */
+        for (int pl = 0; pl < 4; pl++) {
+            cd->diff16[(size_t)x * 4 + pl] = (int16_t)d16[pl];
+            int parts[5];
+            port_sierra_split(d16[pl], bleed, parts);
+            thr_prev[pl] = thr_cur[pl];
+            thr_cur[pl] = parts[1];
+            rem[pl] = parts[4];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ per-row post pass */
+
+static uint64_t derivative_error(const engine *e, uint32_t y, const candidate *cd)
+{
+    const uint32_t W = e->W, bpp = e->bpp;
+    const size_t stride = (size_t)W * bpp;
+    const unsigned char *orig = e->pix + (size_t)y * stride;
+    const unsigned char *nabove = y ? orig - stride : NULL;
+    const unsigned char *oabove = y ? e->old_above : NULL;
+    uint64_t total = 0;
+    for (uint32_t x = 0; x < W; x++)
+        for (uint32_t c = 0; c < bpp; c++) {
+            const size_t o = (size_t)x * bpp + c;
+            const int ov = orig[o], back = cd->bytes[o];
+            const int na = nabove ? nabove[o] : 0, oa = oabove ? oabove[o] : 0;
+            const int nd = (nabove && x) ? nabove[o - bpp] : 0, od = (oabove && x) ? oabove[o - bpp] : 0;
+            const int nl = x ? cd->bytes[o - bpp] : 0, ol = x ? orig[o - bpp] : 0;
+            const int da = (oa - ov) - (na - back);
+            const int dd = (od - ov) - (nd - back);
+            const int dl = (ol - ov) - (nl - back);
+            total += (uint64_t)weight_of(bpp, c) * (uint64_t)(da * da + dd * dd + dl * dl);
+        }
+    return total;
+}
+
+static uint32_t entropy_cost(const engine *e, uint32_t y, int f, const candidate *cd)
+{
+    const uint32_t W = e->W, bpp = e->bpp;
+    const size_t stride = (size_t)W * bpp;
+    const unsigned char *nabove = y ? e->pix + (size_t)(y - 1) * stride : NULL;
+    uint32_t total = 0;
+    for (size_t i = 0; i < stride; i++) {
+        int left = i >= bpp ? cd->bytes[i - bpp] : 0;
+        int above = nabove ? nabove[i] : 0;
+        int diag = (nabove && i >= bpp) ? nabove[i - bpp] : 0;
+        total += port_symbol_cost(cd->hist[(cd->bytes[i] - predict(f, above, diag, left)) & 255]);
+    }
+    return total;
+}
+
+static void commit_error_rows(engine *e, const candidate *win, long bleed)
+{
+    /* row+1 target x gets t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2); row+2 target x gets t(x+1)+h(x)+t(x-1) */
+    const uint32_t W = e->W;
+    for (uint32_t x = 0; x < W; x++)
+        for (int pl = 0; pl < 4; pl++) {
+            int c1 = 0, c2 = 0;
+            for (int dx = -2; dx <= 2; dx++) {
+                long sx = (long)x + dx;
+                if (sx < 0 || sx >= (long)W) continue;
+                int parts[5];
+                port_sierra_split(win->diff16[(size_t)sx * 4 + pl], bleed, parts);
+                int ad = dx < 0 ? -dx : dx;
+                c1 += ad == 2 ? parts[0] : (ad == 1 ? parts[2] : parts[3]);
+                if (ad <= 1) c2 += ad == 1 ? parts[0] : parts[1];
+            }
+            e->E0[(size_t)x * 4 + pl] = (int16_t)sext16(e->E1[(size_t)x * 4 + pl] + c1);
+            e->E1[(size_t)x * 4 + pl] = (int16_t)sext16(c2);
+        }
+}
+
+/* ------------------------------------------------------------------ image driver */
+
+int port_optimize_packed(unsigned char *pix, uint32_t width, uint32_t height, uint32_t bpp,
+                         unsigned char *row_filters, unsigned strength, long bleed, port_trace *trace)
+{
+    if (!width || !height) return 0;
+    const size_t stride = (size_t)width * bpp;
+    engine e;
+    memset(&e, 0, sizeof e);
+    e.W = width; e.H = height; e.bpp = bpp; e.pix = pix;
+    e.old_above = calloc(stride, 1);
+    e.E0 = calloc((size_t)width * 4, sizeof(int16_t));
+    e.E1 = calloc((size_t)width * 4, sizeof(int16_t));
+    candidate cand[F_COUNT];
+    int ok = e.old_above && e.E0 && e.E1;
+    for (int f = 0; f < F_COUNT; f++) {
+        cand[f].bytes = calloc(stride, 1);
+        cand[f].diff16 = calloc((size_t)width * 4, sizeof(int16_t));
+        ok = ok && cand[f].bytes && cand[f].diff16;
+    }
+    if (ok) {
+        port_orig_histograms(pix, width, height, bpp, e.orig_hist);
+        for (uint32_t y = 0; y < height; y++) {
+            const bool adaptive = !row_filters || y == 0;   /* PNG: first row is always filtered adaptively */
+            const unsigned char *nabove = y ? pix + (size_t)(y - 1) * stride : NULL;
+            unsigned s = strength;
+            int winner = -1;
+            uint64_t best_cost = UINT64_MAX;
+            uint64_t costs[F_COUNT];
+            for (;;) {
+                for (int f = 0; f < F_COUNT; f++) {
+                    run_chain(&e, y, f, s, bleed, &cand[f]);
+                    if (adaptive && port_adaptive_filter(nabove, cand[f].bytes, width, bpp) != f) {
+                        cand[f].cost = UINT64_MAX;
+                    } else {
+                        cand[f].cost = derivative_error(&e, y, &cand[f]) / 128 + entropy_cost(&e, y, f, &cand[f]);
+                    }
+                    costs[f] = cand[f].cost;
+                    if (cand[f].cost < best_cost) { best_cost = cand[f].cost; winner = f; }
+                }
+                if (winner >= 0) break;
+                if (s == 0) { fprintf(stderr, "port: no acceptable filter at row %u\n", y); abort(); }
+                s--;
+            }
+            if (trace) {
+                if (trace->cost) memcpy(trace->cost + (size_t)y * F_COUNT, costs, sizeof costs);
+                if (trace->strength_used) trace->strength_used[y] = (uint8_t)s;
+                if (trace->winner) trace->winner[y] = (uint8_t)winner;
+            }
+            memcpy(e.old_above, pix + (size_t)y * stride, stride);
+            memcpy(pix + (size_t)y * stride, cand[winner].bytes, stride);
+            memcpy(e.hist, cand[winner].hist, sizeof e.hist);
+            commit_error_rows(&e, &cand[winner], bleed);
+            if (row_filters) row_filters[y] = png_filter_flag[winner];
+        }
+        if (trace && trace->final_hist) memcpy(trace->final_hist, e.hist, sizeof e.hist);
+    }
+    for (int f = 0; f < F_COUNT; f++) { free(cand[f].bytes); free(cand[f].diff16); }
+    free(e.old_above); free(e.E0); free(e.E1);
+    return ok ? 0 : 17;
+}
+
+int port_optimize_with_rows(unsigned char **rows, uint32_t width, uint32_t height, unsigned char *row_filters,
+                            bool verbose, uint_fast8_t quantization_strength, int_fast16_t bleed_divider)
+{
+    (void)verbose;
+    if (!width || !height) return 0;
+    int gray, opaque;
+    port_classify((const unsigned char *const *)rows, width, height, &gray, &opaque);
+    const uint32_t bpp = gray ? (opaque ? 1 : 2) : (opaque ? 3 : 4);
+    unsigned char *pix = malloc((size_t)width * height * bpp);
+    if (!pix) return 17;
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            const unsigned char *s = rows[y] + (size_t)x * 4;
+            unsigned char *d = pix + ((size_t)y * width + x) * bpp;
+            switch (bpp) {
+            case 1: d[0] = s[1]; break;
+            case 2: d[0] = s[1]; d[1] = s[3]; break;
+            case 3: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; break;
+            default: memcpy(d, s, 4); break;
+            }
+        }
+    int rc = port_optimize_packed(pix, width, height, bpp, row_filters, quantization_strength, bleed_divider, NULL);
+    if (rc == 0)
+        for (uint32_t y = 0; y < height; y++)
+            for (uint32_t x = 0; x < width; x++) {
+                unsigned char *d = rows[y] + (size_t)x * 4;
+                const unsigned char *s = pix + ((size_t)y * width + x) * bpp;
+                switch (bpp) {
+                case 1: d[0] = d[1] = d[2] = s[0]; d[3] = 255; break;
+                case 2: d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; break;
+                case 3: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; break;
+                default: memcpy(d, s, 4); break;
+                }
+            }
+    free(pix);
+    return rc;
+}
