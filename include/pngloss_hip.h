@@ -1,0 +1,133 @@
+/*
+ * pngloss_hip.h -- C ABI of the MI355X (gfx950) implementation of pngloss's filter+quantise hot path.
+ *
+ * libpngloss_hip.so is a drop-in for the ONE seam the reference has on this path:
+ *
+ *     pngloss_file_internal()  --calls-->  optimize_with_rows()        /root/reference/src/pngloss.c:266
+ *                                                                      /root/reference/src/pngloss_image.h:21-25
+ *
+ * Section 1 re-exports that seam (and its two legacy siblings) with the reference's exact names, argument meaning,
+ * ownership rules and return codes, so that relinking pngloss.c against this library instead of
+ * pngloss_image.c/optimize_state.c/color_delta.c changes nothing but the speed.  Section 2 is the device-resident /
+ * batched extension the reference does not have (its per-file loop, pngloss.c:173, is sequential).
+ *
+ * Plain C, plain pointers and sizes; no HIP or torch types appear in any signature (streams are passed as void*).
+ * There is NO CPU fallback behind these entry points: if the HIP runtime, a gfx950 device or the kernels are
+ * unavailable they fail loudly (message on stderr + PNGLOSS_HIP_ERROR), they never silently compute on the host.
+ */
+#ifndef PNGLOSS_HIP_H
+#define PNGLOSS_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes: the subset of the reference's pngloss_error (rwpng.h:23-38) this path can produce ---------- */
+#ifndef PNGLOSS_ERROR_CODES
+#define PNGLOSS_ERROR_CODES
+#define PNGLOSS_SUCCESS             0   /* SUCCESS              rwpng.h:24 */
+#define PNGLOSS_OUT_OF_MEMORY_ERROR 17  /* OUT_OF_MEMORY_ERROR  rwpng.h:30 (host or device allocation failed) */
+#define PNGLOSS_INVALID_ARGUMENT    4   /* INVALID_ARGUMENT     rwpng.h:27 (bleed outside 1..32767 etc.; the CLI
+                                           validates this at pngloss.c:123-131, the library re-checks) */
+#define PNGLOSS_HIP_ERROR           64  /* new: HIP runtime / device / kernel failure (no reference equivalent) */
+#define PNGLOSS_INTERNAL_ABORT      65  /* new: the invariant the reference abort()s on (optimize_state.c:216-219,
+                                           245-248; pngloss_image.c:268-271) was violated on the device */
+#endif
+
+/* =====================================================================================================
+ * 1. Drop-in seam (host pointers).  Replaces /root/reference/src/pngloss_image.h:14-29.
+ * ===================================================================================================== */
+
+/* pngloss_image.h:7-11 -- packed image with 1..4 bytes per pixel, rows need not be contiguous. */
+typedef struct {
+    unsigned char **rows;
+    uint32_t width, height;
+    uint_fast8_t bytes_per_pixel;
+} pngloss_image;
+
+/* Replaces optimize_with_rows(), pngloss_image.h:21-25 / pngloss_image.c:52-156.
+ *   rows          height pointers to width*4 bytes of RGBA8 each, caller-owned, rewritten IN PLACE
+ *   row_filters   caller-allocated height bytes or NULL.  Non-NULL: receives libpng filter FLAG values
+ *                 0x08,0x10,0x20,0x40,0x80 (PNG_FILTER_NONE..PAETH, pngloss_image.c:290-306) and only row 0 is
+ *                 forced to libpng's heuristic filter.  NULL: every row is (pngloss_image.c:210), no IDs returned.
+ *   verbose       prints "compression complete" / "used N unique symbols" to stderr like pngloss_image.c:309-325
+ *                 (the 10 Hz spinner of :214-237 is host-side cosmetics and is not reproduced)
+ *   quantization_strength 0..255, bleed_divider 1..32767 (pngloss.c:123-131)
+ * Returns PNGLOSS_SUCCESS or an error above.  Output bytes and filter IDs are bit-identical to the reference. */
+int optimize_with_rows(unsigned char **rows, uint32_t width, uint32_t height, unsigned char *row_filters,
+                       bool verbose, uint_fast8_t quantization_strength, int_fast16_t bleed_divider);
+
+/* Replaces optimize_with_stride(), pngloss_image.h:17-20 / pngloss_image.c:40-50 (row_filters = NULL mode). */
+void optimize_with_stride(unsigned char *pixels, uint32_t width, uint32_t height, uint32_t stride,
+                          bool verbose, uint_fast8_t quantization_strength, int_fast16_t bleed_divider);
+
+/* Replaces optimizeForAverageFilter(), pngloss_image.h:14-16 / pngloss_image.c:29-38 (RGBA, bleed fixed at 2). */
+void optimizeForAverageFilter(unsigned char pixels[], int width, int height, int quantization);
+
+/* Replaces optimize_image(), pngloss_image.h:26-29 / pngloss_image.c:159-333: the lower seam on an already packed
+ * 1/2/3/4 bytes-per-pixel image (no gray/alpha detection). */
+int optimize_image(pngloss_image *image, unsigned char *row_filters, bool verbose,
+                   uint_fast8_t quantization_strength, int_fast16_t bleed_divider);
+
+/* =====================================================================================================
+ * 2. Device-resident, batched extension (new; the natural batching point is pngloss.c:173).
+ * ===================================================================================================== */
+
+typedef struct pngloss_hip_ctx pngloss_hip_ctx;
+
+/* One RGBA8 image resident in device memory. */
+typedef struct {
+    void    *d_rgba;         /* device pointer, width*height*4 bytes, rows contiguous; rewritten in place       */
+    void    *d_row_filters;  /* device pointer to height bytes, or NULL (=> all rows adaptive, no IDs)           */
+    uint32_t width, height;
+} pngloss_hip_image_desc;
+
+/* Per-image result record (host memory, filled after the stream has been synchronised by _finish). */
+typedef struct {
+    int32_t  status;            /* PNGLOSS_SUCCESS / PNGLOSS_INTERNAL_ABORT                                        */
+    uint32_t bytes_per_pixel;   /* 1 gray, 2 gray+alpha, 3 rgb, 4 rgba -- what pngloss_image.c:64-96 detects       */
+    uint32_t unique_symbols;    /* non-zero bins of the final histogram (pngloss_image.c:311-325)                  */
+    uint32_t retried_rows;      /* rows that needed the strength-decrement retry (pngloss_image.c:266-274)         */
+} pngloss_hip_result;
+
+/* Number of HIP devices visible, or a negative PNGLOSS_HIP_ERROR-style code if the runtime is unusable. */
+int pngloss_hip_device_count(void);
+
+/* Create / destroy a context bound to one device (device < 0: the current device).  NULL on failure. */
+pngloss_hip_ctx *pngloss_hip_create(int device);
+void pngloss_hip_destroy(pngloss_hip_ctx *ctx);
+
+/* Enqueue the whole hot path for n device-resident images on `stream` (a hipStream_t passed as void*, NULL = the
+ * default stream).  Images are independent and run concurrently (one workgroup per image in the row engine).
+ * Asynchronous: returns after enqueueing; call pngloss_hip_finish() to synchronise and collect results. */
+int pngloss_hip_optimize_batch_async(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n,
+                                     unsigned quantization_strength, long bleed_divider, void *stream);
+
+/* Wait for the last enqueued batch, copy back its n result records (results may be NULL). */
+int pngloss_hip_finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n);
+
+/* Convenience: async + finish. */
+int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n,
+                               unsigned quantization_strength, long bleed_divider, void *stream,
+                               pngloss_hip_result *results);
+
+/* Duration in milliseconds of the row-engine kernel of the last finished batch, measured with hipEvents recorded
+ * on the launch stream immediately around that kernel (what bench.py's roofline block reports).  < 0 if none. */
+double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx);
+/* Same for the whole enqueued pipeline (classify + histograms + repack + engine + unpack). */
+double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx);
+
+/* Final 256-bin symbol histogram of image `index` of the last finished batch (host buffer of 256 uint32). */
+int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *hist256);
+
+/* Library / device identification string (static storage). */
+const char *pngloss_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNGLOSS_HIP_H */

@@ -231,6 +231,98 @@ static void run_chain(const engine *e, uint32_t y, int f, unsigned s, long bleed
     }
 }
 
+/* ------------------------------------------------------------------ GPU-shaped variant of the chain
+ *
+ * port_set_chain_variant(1) switches run_chain to the formulation the HIP row engine uses, so that the algorithm
+ * itself (not only its CPU-friendly restatement) is checked against the real reference on the CPU:
+ *   - the secondary key is the 8-bit RANK of original_frequency, folded with "is the original symbol" and the
+ *     candidate index into one word (key2), arg-maxed after the primary key (running frequency);
+ *   - the channels of a pixel are evaluated SPECULATIVELY against the histogram as it was before the pixel, then
+ *     repaired in channel order by re-evaluating only the bins the earlier channels incremented.
+ */
+static int g_chain_variant = 0;
+void port_set_chain_variant(int v) { g_chain_variant = v; }
+
+static inline uint32_t key2(uint32_t rank, int jj, int josym)
+{
+    return ((rank << 9) | ((jj == josym) ? 256u : 0u) | (uint32_t)(255 - jj)) + 1u;
+}
+
+static void run_chain_spec(const engine *e, uint32_t y, int f, unsigned s, long bleed, candidate *cd)
+{
+    const uint32_t W = e->W, bpp = e->bpp;
+    const size_t stride = (size_t)W * bpp;
+    const unsigned char *orig = e->pix + (size_t)y * stride;
+    const unsigned char *nabove = y ? orig - stride : NULL;
+    const uint32_t *O = e->orig_hist[f];
+    uint32_t rank[256];
+    for (int b = 0; b < 256; b++) { uint32_t r = 0; for (int k = 0; k < 256; k++) r += O[k] < O[b]; rank[b] = r; }
+    uint32_t *Hs = cd->hist;
+    const int q = (int)s + 1;
+    const bool has_alpha = (bpp % 2) == 0;
+    memcpy(Hs, e->hist, sizeof(e->hist));
+    int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
+
+    for (uint32_t x = 0; x < W; x++) {
+        int vmin[4], span[4], josym[4], predc[4], filt[4], tr[4], jwin[4];
+        uint32_t Hwin[4], K[4], Rwin[4];
+        const bool transparent = has_alpha && orig[(size_t)x * bpp + bpp - 1] == 0;
+        for (uint32_t c = 0; c < bpp; c++) {           /* "all four DPP rows at once": only pre-pixel state is read */
+            const size_t o = (size_t)x * bpp + c;
+            const int pl = plane_of(bpp, c);
+            const int ov = orig[o];
+            const int above = nabove ? nabove[o] : 0;
+            const int diag = (nabove && x) ? nabove[o - bpp] : 0;
+            const int left = x ? cd->bytes[o - bpp] : 0;
+            const int pred = predict(f, above, diag, left);
+            const int osym = sext8(ov - pred);
+            predc[c] = ov - osym;
+            const int err = sext16(e->E0[(size_t)x * 4 + pl] + rem[pl] + thr_prev[pl]);
+            filt[c] = osym + err;
+            const int af = filt[c] < 0 ? -filt[c] : filt[c];
+            const int base = (af / q) * q;
+            int lo_v = filt[c] < 0 ? -base - (int)s : base, hi_v = lo_v + (int)s;
+            const int lo = -predc[c], hi = lo + 255;
+            lo_v = med3(lo_v, lo, hi); hi_v = med3(hi_v, lo, hi);
+            tr[c] = transparent && c == bpp - 1;
+            if (tr[c]) { lo_v = hi_v = -pred; predc[c] = pred; }
+            vmin[c] = lo_v; span[c] = hi_v - lo_v; josym[c] = osym - lo_v;
+            uint32_t m = 0;
+            for (int jj = 0; jj <= span[c]; jj++) { uint32_t h = Hs[(lo_v + jj) & 255]; if (h > m) m = h; }
+            uint32_t kk = 0;
+            for (int jj = 0; jj <= span[c]; jj++) {
+                int b = (lo_v + jj) & 255;
+                if (Hs[b] == m) { uint32_t k2 = key2(rank[b], jj, josym[c]); if (k2 > kk) kk = k2; }
+            }
+            Hwin[c] = m; K[c] = kk;
+            jwin[c] = 255 - (int)((kk - 1u) & 255u); Rwin[c] = (kk - 1u) >> 9;
+        }
+        for (uint32_t cp = 0; cp + 1 < bpp; cp++) {    /* exact repair, in channel order */
+            const uint32_t sb = (uint32_t)(vmin[cp] + jwin[cp]) & 255u, sH = Hwin[cp] + 1u, sR = Rwin[cp];
+            for (uint32_t c = cp + 1; c < bpp; c++) {
+                const int jj2 = ((int)sb - vmin[c]) & 255;
+                const uint32_t K2 = key2(sR, jj2, josym[c]);
+                if (jj2 <= span[c] && (sH > Hwin[c] || (sH == Hwin[c] && K2 > K[c]))) {
+                    Hwin[c] = sH; K[c] = K2; jwin[c] = jj2; Rwin[c] = sR;
+                }
+            }
+        }
+        int d16[4] = { 0, 0, 0, 0 };
+        for (uint32_t c = 0; c < bpp; c++) {
+            const int vwin = vmin[c] + jwin[c];
+            cd->bytes[(size_t)x * bpp + c] = (unsigned char)(vwin + predc[c]);
+            d16[plane_of(bpp, c)] = tr[c] ? 0 : sext16(filt[c] - vwin);
+            Hs[vwin & 255]++;
+        }
+        for (int pl = 0; pl < 4; pl++) {
+            cd->diff16[(size_t)x * 4 + pl] = (int16_t)d16[pl];
+            int parts[5];
+            port_sierra_split(d16[pl], bleed, parts);
+            thr_prev[pl] = thr_cur[pl]; thr_cur[pl] = parts[1]; rem[pl] = parts[4];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ per-row post pass */
 
 static uint64_t derivative_error(const engine *e, uint32_t y, const candidate *cd)
@@ -323,7 +415,8 @@ int port_optimize_packed(unsigned char *pix, uint32_t width, uint32_t height, ui
             uint64_t costs[F_COUNT];
             for (;;) {
                 for (int f = 0; f < F_COUNT; f++) {
-                    run_chain(&e, y, f, s, bleed, &cand[f]);
+                    if (g_chain_variant) run_chain_spec(&e, y, f, s, bleed, &cand[f]);
+                    else run_chain(&e, y, f, s, bleed, &cand[f]);
                     if (adaptive && port_adaptive_filter(nabove, cand[f].bytes, width, bpp) != f) {
                         cand[f].cost = UINT64_MAX;
                     } else {

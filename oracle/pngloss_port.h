@@ -53,6 +53,10 @@ int  port_adaptive_filter(const unsigned char *above /*nullable*/, const unsigne
 void port_sierra_split(int diff16, long bleed, int parts[5]);
 unsigned port_symbol_cost(uint32_t freq);
 
+/* 0 (default): straightforward chain.  1: the speculative-channels + rank-key formulation of the HIP row engine
+ * (same results, proven by tests/test_oracle.py); process-global, test use only. */
+void port_set_chain_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+/*
+ * pl_device.h -- shared device-side definitions for the gfx950 pngloss hot path (internal, not part of the C ABI).
+ *
+ * Working layout ("slots"): every pixel is one 32-bit word in HBM, channel c of the packed image in byte c.
+ *   4 B/px class (rgba)       : the caller's RGBA8 buffer as is
+ *   3 B/px class (rgb)        : (r,g,b,0)   -- alpha byte parked at 0, restored to 255 by the unpack kernel
+ *   2 B/px class (gray+alpha) : (g,a,0,0)
+ *   1 B/px class (gray)       : (g,0,0,0)
+ * so the row engine always moves whole dwords (coalesced 256 B per wave load) and the four channel rows of a wave
+ * pick their byte with one v_bfe.  This replaces the malloc+repack of /root/reference/src/pngloss_image.c:81-124.
+ */
+#ifndef PL_DEVICE_H
+#define PL_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PL_NFILT 5
+#define PL_NSYM 256
+#define PL_ENGINE_THREADS (PL_NFILT * 64)
+
+/* class flag bits produced by the classify kernel */
+#define PL_FLAG_GRAY 1u
+#define PL_FLAG_OPAQUE 2u
+
+/* Everything the kernels need to know about one image of the batch.  Lives in device memory. */
+struct PlJob {
+    uint32_t *img;        /* slots image, width*height words, in place over the caller's RGBA8 buffer            */
+    uint8_t *row_filters; /* device, height bytes, or nullptr                                                    */
+    uint32_t width, height;
+    uint32_t forced_bpp;  /* 0 = detect (optimize_with_rows); 1..4 = caller says so (optimize_image seam)         */
+    /* per-image workspace */
+    uint32_t *flags;      /* [1]  PL_FLAG_* (AND-reduced)                                                        */
+    uint32_t *orig_hist;  /* [5][256] original_frequency (optimize_state.c:66-83)                                */
+    uint32_t *orig_rank;  /* [5][256] order/equality preserving 8-bit rank of orig_hist[f][*]                    */
+    uint4 *cand;          /* [5][width] per candidate, per pixel, per channel: byte | (diff16 << 8)              */
+    uint2 *err0;          /* [width] 4 x int16 incoming Sierra error for the current row  (color_error row 0)    */
+    uint2 *err1;          /* [width] same for the next row                                 (color_error row 1)    */
+    uint32_t *old_above;  /* [width] original (pre-optimisation) previous row = last_row_pixels                  */
+    uint32_t *final_hist; /* [256]                                                                               */
+    int32_t *result;      /* [4] status, bpp, unique symbols, retried rows                                       */
+};
+
+__device__ __forceinline__ uint32_t pl_bpp_from_flags(uint32_t fl)
+{
+    const bool g = fl & PL_FLAG_GRAY, o = fl & PL_FLAG_OPAQUE;
+    return g ? (o ? 1u : 2u) : (o ? 3u : 4u);
+}
+
+__device__ __forceinline__ uint32_t pl_job_bpp(const PlJob &j)
+{
+    return j.forced_bpp ? j.forced_bpp : pl_bpp_from_flags(*j.flags);
+}
+
+/* PNG predictors (optimize_state.c:575-613).  All operands 0..255. */
+__device__ __forceinline__ int pl_paeth(int above, int diag, int left)
+{
+    const int p = above - diag, pd = left - diag;
+    const int pl = abs(p), pa = abs(pd), pg = abs(p + pd);
+    return (pl <= pa && pl <= pg) ? left : (pa <= pg ? above : diag);
+}
+
+template <int F>
+__device__ __forceinline__ int pl_predict(int above, int diag, int left)
+{
+    if (F == 1) return left;
+    if (F == 2) return above;
+    if (F == 3) return (above + left) >> 1;
+    if (F == 4) return pl_paeth(above, diag, left);
+    return 0;
+}
+
+__device__ __forceinline__ int pl_predict_rt(int f, int above, int diag, int left)
+{
+    switch (f) {
+    case 1: return left;
+    case 2: return above;
+    case 3: return (above + left) >> 1;
+    case 4: return pl_paeth(above, diag, left);
+    default: return 0;
+    }
+}
+
+__device__ __forceinline__ int pl_sext8(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
+__device__ __forceinline__ int pl_sext16(int v) { return __builtin_amdgcn_sbfe(v, 0, 16); }
+__device__ __forceinline__ int pl_med3(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+/* Exact truncating division of a small signed integer (|n| < 2^17) by a positive constant d <= 32767 using the
+ * float reciprocal rd = nextafterf(1.0f/d, +inf): trunc(n * rd) == trunc(n / d).  Proof sketch and exhaustive
+ * check: tests/test_host_logic.py::test_float_reciprocal_division. */
+__device__ __forceinline__ float pl_truncdiv_f(float n, float rd) { return truncf(n * rd); }
+
+/* Sierra split of one error lane (optimize_state.c:397-401,445-467), all in exact small-integer float arithmetic.
+ * in : diff16 (already int16-wrapped), rbleed = recip of bleed_divider, r29 = 2*nextafterf(1/9,+inf)
+ * out: t "twos", h "threes", f "fours", v "five", rem (what stays for x+1) */
+struct PlSplit { float t, h, f, v, rem; };
+__device__ __forceinline__ PlSplit pl_sierra_split(int diff16, float rbleed, float r29)
+{
+    PlSplit s;
+    float d = truncf((float)diff16 * rbleed);
+    s.t = truncf(d * 0.0625f);   d = fmaf(s.t, -4.0f, d);
+    s.h = truncf(d * 0.125f);    d = fmaf(s.h, -2.0f, d);
+    s.f = truncf(d * r29);       d = fmaf(s.f, -2.0f, d);
+    s.v = truncf(d * 0.5f);      s.rem = d - s.v;
+    return s;
+}
+
+/* which channel feeds error plane p (color_delta.c:4-41 expand + optimize_state.c:167-171): -1 = plane unused */
+__device__ __forceinline__ int pl_channel_of_plane(uint32_t bpp, int p)
+{
+    if (bpp == 2) return p == 0 ? 0 : (p == 3 ? 1 : -1);
+    return p < (int)bpp ? p : -1;
+}
+__device__ __forceinline__ int pl_plane_of_channel(uint32_t bpp, int c) { return (bpp == 2 && c == 1) ? 3 : c; }
+
+/* launchers implemented in pl_prepost.hip / pl_engine.hip (host side) */
+struct PlEngineParams {
+    int strength;
+    float rq;       /* nextafterf(1/(strength+1), +inf) */
+    float rbleed;   /* nextafterf(1/bleed, +inf)        */
+    float r29;      /* 2*nextafterf(1/9, +inf)          */
+};
+
+hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
+hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream);
+hipError_t pl_launch_finish(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
+
+#endif

@@ -1,0 +1,368 @@
+/*
+ * pl_host.hip -- the thin C-ABI shim of libpngloss_hip.so (see include/pngloss_hip.h for the contract).
+ *
+ * Host side only: context + workspace management, job tables, stream/event plumbing, and the host-pointer
+ * drop-in entry points that replace /root/reference/src/pngloss_image.c:29-156.  No arithmetic of the hot path is
+ * done here and there is no CPU fallback: without a usable HIP device every entry point fails loudly.
+ */
+#include "../../include/pngloss_hip.h"
+#include "pl_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#define PL_CHECK(expr)                                                                                           \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            std::fprintf(stderr, "pngloss_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                                              \
+            return e_ == hipErrorOutOfMemory ? PNGLOSS_OUT_OF_MEMORY_ERROR : PNGLOSS_HIP_ERROR;                  \
+        }                                                                                                        \
+    } while (0)
+
+struct pngloss_hip_ctx {
+    int device = 0;
+    /* one device arena, regrown on demand, carved per batch */
+    char *d_ws = nullptr;
+    size_t ws_bytes = 0;
+    std::vector<PlJob> h_jobs;
+    size_t n_last = 0;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; /* total start, engine start, engine stop, total stop */
+    double engine_ms = -1.0, total_ms = -1.0;
+    bool pending = false;
+};
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+    size_t jobs, flags, orig_hist, orig_rank, cand, err0, err1, old_above, final_hist, result, total;
+};
+
+/* per-image workspace: everything the engine keeps outside the image itself */
+WsLayout image_ws(uint32_t width)
+{
+    WsLayout l{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    l.flags = take(sizeof(uint32_t));
+    l.orig_hist = take(sizeof(uint32_t) * PL_NFILT * PL_NSYM);
+    l.orig_rank = take(sizeof(uint32_t) * PL_NFILT * PL_NSYM);
+    l.cand = take(sizeof(uint4) * PL_NFILT * (size_t)width);
+    l.err0 = take(sizeof(uint2) * (size_t)width);
+    l.err1 = take(sizeof(uint2) * (size_t)width);
+    l.old_above = take(sizeof(uint32_t) * (size_t)width);
+    l.final_hist = take(sizeof(uint32_t) * PL_NSYM);
+    l.result = take(sizeof(int32_t) * 4);
+    l.total = o;
+    return l;
+}
+
+float recip_up_host(long d)
+{
+    /* one ulp above the correctly rounded reciprocal: > 1/d, and far inside the exactness margin (pl_device.h) */
+    float r = 1.0f / (float)d;
+    r = std::nextafterf(r, 2.0f);
+    return r;
+}
+
+int ensure_ws(pngloss_hip_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return PNGLOSS_SUCCESS;
+    if (ctx->d_ws) PL_CHECK(hipFree(ctx->d_ws));
+    ctx->d_ws = nullptr;
+    ctx->ws_bytes = 0;
+    size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    PL_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_ws), want));
+    ctx->ws_bytes = want;
+    return PNGLOSS_SUCCESS;
+}
+
+int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n, const uint32_t *forced_bpp,
+            unsigned strength, long bleed, hipStream_t stream)
+{
+    if (!ctx) return PNGLOSS_INVALID_ARGUMENT;
+    if (strength > 255 || bleed < 1 || bleed > 32767) {
+        std::fprintf(stderr, "pngloss_hip: strength must be 0..255 and bleed 1..32767 (got %u, %ld)\n", strength, bleed);
+        return PNGLOSS_INVALID_ARGUMENT;
+    }
+    if (ctx->pending) {
+        std::fprintf(stderr, "pngloss_hip: previous batch not finished; call pngloss_hip_finish first\n");
+        return PNGLOSS_INVALID_ARGUMENT;
+    }
+    PL_CHECK(hipSetDevice(ctx->device));
+    ctx->h_jobs.clear();
+    ctx->n_last = 0;
+    /* drop empty images (the reference's loops simply do nothing for them) */
+    std::vector<size_t> offs;
+    size_t total = align_up(sizeof(PlJob) * (n ? n : 1), 256);
+    for (size_t i = 0; i < n; i++) {
+        if (!images[i].d_rgba && images[i].width && images[i].height) return PNGLOSS_INVALID_ARGUMENT;
+        offs.push_back(total);
+        total += image_ws(images[i].width ? images[i].width : 1).total;
+    }
+    int rc = ensure_ws(ctx, total);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) {
+        const WsLayout l = image_ws(images[i].width ? images[i].width : 1);
+        char *b = ctx->d_ws + offs[i];
+        PlJob j{};
+        j.img = static_cast<uint32_t *>(images[i].d_rgba);
+        j.row_filters = static_cast<uint8_t *>(images[i].d_row_filters);
+        j.width = images[i].width;
+        j.height = (images[i].width == 0) ? 0 : images[i].height;
+        j.forced_bpp = forced_bpp ? forced_bpp[i] : 0;
+        j.flags = reinterpret_cast<uint32_t *>(b + l.flags);
+        j.orig_hist = reinterpret_cast<uint32_t *>(b + l.orig_hist);
+        j.orig_rank = reinterpret_cast<uint32_t *>(b + l.orig_rank);
+        j.cand = reinterpret_cast<uint4 *>(b + l.cand);
+        j.err0 = reinterpret_cast<uint2 *>(b + l.err0);
+        j.err1 = reinterpret_cast<uint2 *>(b + l.err1);
+        j.old_above = reinterpret_cast<uint32_t *>(b + l.old_above);
+        j.final_hist = reinterpret_cast<uint32_t *>(b + l.final_hist);
+        j.result = reinterpret_cast<int32_t *>(b + l.result);
+        ctx->h_jobs.push_back(j);
+    }
+    if (!n) return PNGLOSS_SUCCESS;
+    PlJob *d_jobs = reinterpret_cast<PlJob *>(ctx->d_ws);
+    PL_CHECK(hipMemcpyAsync(d_jobs, ctx->h_jobs.data(), sizeof(PlJob) * n, hipMemcpyHostToDevice, stream));
+
+    PlEngineParams prm{};
+    prm.strength = (int)strength;
+    prm.rq = recip_up_host((long)strength + 1);
+    prm.rbleed = recip_up_host(bleed);
+    prm.r29 = 2.0f * recip_up_host(9);
+
+    PL_CHECK(hipEventRecord(ctx->ev[0], stream));
+    PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));
+    PL_CHECK(hipEventRecord(ctx->ev[1], stream));
+    PL_CHECK(pl_launch_engine(d_jobs, n, prm, stream));
+    PL_CHECK(hipEventRecord(ctx->ev[2], stream));
+    PL_CHECK(pl_launch_finish(d_jobs, ctx->h_jobs.data(), n, stream));
+    PL_CHECK(hipEventRecord(ctx->ev[3], stream));
+    ctx->n_last = n;
+    ctx->last_stream = stream;
+    ctx->pending = true;
+    return PNGLOSS_SUCCESS;
+}
+
+int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
+{
+    if (!ctx) return PNGLOSS_INVALID_ARGUMENT;
+    if (!ctx->pending) {
+        if (results)
+            for (size_t i = 0; i < n; i++) results[i] = pngloss_hip_result{ 0, 0, 0, 0 };
+        return PNGLOSS_SUCCESS;
+    }
+    PL_CHECK(hipSetDevice(ctx->device));
+    PL_CHECK(hipEventSynchronize(ctx->ev[3]));
+    ctx->pending = false;
+    float ms = 0.f;
+    PL_CHECK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    ctx->engine_ms = ms;
+    PL_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
+    ctx->total_ms = ms;
+    int worst = PNGLOSS_SUCCESS;
+    for (size_t i = 0; i < ctx->n_last; i++) {
+        int32_t r[4] = { 0, 0, 0, 0 };
+        PL_CHECK(hipMemcpy(r, ctx->h_jobs[i].result, sizeof r, hipMemcpyDeviceToHost));
+        if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3] };
+        if (r[0]) {
+            std::fprintf(stderr, "pngloss_hip: image %zu: no acceptable filter row (device status %d)\n", i, r[0]);
+            worst = PNGLOSS_INTERNAL_ABORT;
+        }
+    }
+    return worst;
+}
+
+/* ---- process-wide context for the host-pointer drop-in seam ------------------------------------------------ */
+std::mutex g_mu;
+pngloss_hip_ctx *g_ctx = nullptr;
+
+pngloss_hip_ctx *global_ctx()
+{
+    if (!g_ctx) g_ctx = pngloss_hip_create(-1);
+    return g_ctx;
+}
+
+/* Upload a packed bpp-byte image as "slots" words, run, download.  rows[] may be non-contiguous. */
+int run_host_image(unsigned char **rows, uint32_t width, uint32_t height, uint32_t src_bpp, uint32_t forced_bpp,
+                   unsigned char *row_filters, bool verbose, unsigned strength, long bleed)
+{
+    if (!width || !height) return PNGLOSS_SUCCESS;
+    std::lock_guard<std::mutex> lock(g_mu);
+    pngloss_hip_ctx *ctx = global_ctx();
+    if (!ctx) {
+        std::fprintf(stderr, "pngloss_hip: no usable HIP device -- refusing to fall back to a CPU path\n");
+        return PNGLOSS_HIP_ERROR;
+    }
+    const size_t npx = (size_t)width * height;
+    std::vector<uint32_t> staging;
+    try { staging.resize(npx); } catch (const std::bad_alloc &) { return PNGLOSS_OUT_OF_MEMORY_ERROR; }
+    for (uint32_t y = 0; y < height; y++) {
+        const unsigned char *s = rows[y];
+        uint32_t *d = staging.data() + (size_t)y * width;
+        if (src_bpp == 4) std::memcpy(d, s, (size_t)width * 4);
+        else
+            for (uint32_t x = 0; x < width; x++) {
+                uint32_t w = 0;
+                for (uint32_t c = 0; c < src_bpp; c++) w |= (uint32_t)s[(size_t)x * src_bpp + c] << (8 * c);
+                d[x] = w;
+            }
+    }
+    void *d_img = nullptr, *d_filt = nullptr;
+    PL_CHECK(hipSetDevice(ctx->device));
+    PL_CHECK(hipMalloc(&d_img, npx * 4));
+    if (row_filters) {
+        hipError_t e = hipMalloc(&d_filt, height);
+        if (e != hipSuccess) { (void)hipFree(d_img); return PNGLOSS_OUT_OF_MEMORY_ERROR; }
+    }
+    int rc = PNGLOSS_SUCCESS;
+    pngloss_hip_result res{};
+    do {
+        if (hipMemcpy(d_img, staging.data(), npx * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
+        pngloss_hip_image_desc desc{ d_img, d_filt, width, height };
+        rc = enqueue(ctx, &desc, 1, forced_bpp ? &forced_bpp : nullptr, strength, bleed, nullptr);
+        if (rc) break;
+        rc = finish(ctx, &res, 1);
+        if (rc) break;
+        if (hipMemcpy(staging.data(), d_img, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
+        if (row_filters && hipMemcpy(row_filters, d_filt, height, hipMemcpyDeviceToHost) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
+    } while (0);
+    (void)hipFree(d_img);
+    if (d_filt) (void)hipFree(d_filt);
+    if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: device transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
+    if (rc) return rc;
+    for (uint32_t y = 0; y < height; y++) {
+        unsigned char *d = rows[y];
+        const uint32_t *s = staging.data() + (size_t)y * width;
+        if (src_bpp == 4) std::memcpy(d, s, (size_t)width * 4);
+        else
+            for (uint32_t x = 0; x < width; x++)
+                for (uint32_t c = 0; c < src_bpp; c++) d[(size_t)x * src_bpp + c] = (unsigned char)(s[x] >> (8 * c));
+    }
+    if (verbose) {
+        /* pngloss_image.c:309-325 */
+        std::fputs("\x1B[\x01G  compression complete\n", stderr);
+        std::fprintf(stderr, "  used %u unique symbols\n", res.unique_symbols);
+    }
+    return PNGLOSS_SUCCESS;
+}
+
+} // namespace
+
+/* ================================================================================================ C ABI */
+
+extern "C" {
+
+int pngloss_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -PNGLOSS_HIP_ERROR;
+    return n;
+}
+
+pngloss_hip_ctx *pngloss_hip_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        std::fprintf(stderr, "pngloss_hip: no HIP device available\n");
+        return nullptr;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= n) {
+        std::fprintf(stderr, "pngloss_hip: device %d out of range (%d visible)\n", device, n);
+        return nullptr;
+    }
+    pngloss_hip_ctx *ctx = new (std::nothrow) pngloss_hip_ctx;
+    if (!ctx) return nullptr;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return nullptr; }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { pngloss_hip_destroy(ctx); return nullptr; }
+    return ctx;
+}
+
+void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->pending) (void)hipEventSynchronize(ctx->ev[3]);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    delete ctx;
+}
+
+int pngloss_hip_optimize_batch_async(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n,
+                                     unsigned quantization_strength, long bleed_divider, void *stream)
+{
+    return enqueue(ctx, images, n, nullptr, quantization_strength, bleed_divider, static_cast<hipStream_t>(stream));
+}
+
+int pngloss_hip_finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n) { return finish(ctx, results, n); }
+
+int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n,
+                               unsigned quantization_strength, long bleed_divider, void *stream,
+                               pngloss_hip_result *results)
+{
+    int rc = enqueue(ctx, images, n, nullptr, quantization_strength, bleed_divider, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    return finish(ctx, results, n);
+}
+
+double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->engine_ms : -1.0; }
+double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->total_ms : -1.0; }
+
+int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *hist256)
+{
+    if (!ctx || !hist256 || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
+    PL_CHECK(hipSetDevice(ctx->device));
+    PL_CHECK(hipMemcpy(hist256, ctx->h_jobs[index].final_hist, sizeof(uint32_t) * PL_NSYM, hipMemcpyDeviceToHost));
+    return PNGLOSS_SUCCESS;
+}
+
+const char *pngloss_hip_version(void) { return "pngloss_hip 0.1 (gfx950 row engine v1; seam: pngloss_image.h:14-29)"; }
+
+/* ---- the reference's seam ------------------------------------------------------------------------------- */
+
+int optimize_with_rows(unsigned char **rows, uint32_t width, uint32_t height, unsigned char *row_filters,
+                       bool verbose, uint_fast8_t quantization_strength, int_fast16_t bleed_divider)
+{
+    return run_host_image(rows, width, height, 4, 0, row_filters, verbose, quantization_strength, bleed_divider);
+}
+
+void optimize_with_stride(unsigned char *pixels, uint32_t width, uint32_t height, uint32_t stride, bool verbose,
+                          uint_fast8_t quantization_strength, int_fast16_t bleed_divider)
+{
+    std::vector<unsigned char *> rows(height);
+    for (uint32_t i = 0; i < height; i++) rows[i] = pixels + (size_t)i * stride;
+    (void)optimize_with_rows(rows.data(), width, height, nullptr, verbose, quantization_strength, bleed_divider);
+}
+
+void optimizeForAverageFilter(unsigned char pixels[], int width, int height, int quantization)
+{
+    /* pngloss_image.c:29-38: RGBA, stride 4*w, bleed divider fixed at 2 */
+    optimize_with_stride(pixels, (uint32_t)width, (uint32_t)height, (uint32_t)width * 4u, false,
+                         (uint_fast8_t)quantization, 2);
+}
+
+int optimize_image(pngloss_image *image, unsigned char *row_filters, bool verbose, uint_fast8_t quantization_strength,
+                   int_fast16_t bleed_divider)
+{
+    if (!image || image->bytes_per_pixel < 1 || image->bytes_per_pixel > 4) return PNGLOSS_INVALID_ARGUMENT;
+    const uint32_t bpp = (uint32_t)image->bytes_per_pixel;
+    return run_host_image(image->rows, image->width, image->height, bpp, bpp, row_filters, verbose,
+                          quantization_strength, bleed_divider);
+}
+
+} /* extern "C" */

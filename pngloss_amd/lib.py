@@ -1,0 +1,226 @@
+"""ctypes mirror of include/pngloss_hip.h (the drop-in seam of /root/reference/src/pngloss_image.h:14-29)."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_ROOT = os.path.dirname(_HERE)
+
+#: libpng filter flag values written to row_filters (pngloss_image.c:290-306): none, sub, up, average, paeth
+PNG_FILTER_FLAGS = (0x08, 0x10, 0x20, 0x40, 0x80)
+
+PNGLOSS_SUCCESS = 0
+PNGLOSS_INVALID_ARGUMENT = 4
+PNGLOSS_OUT_OF_MEMORY_ERROR = 17
+PNGLOSS_HIP_ERROR = 64
+PNGLOSS_INTERNAL_ABORT = 65
+
+_lock = threading.Lock()
+_hip = None
+_synth = None
+
+
+class PnglossImage(C.Structure):
+    _fields_ = [("rows", C.POINTER(C.c_void_p)), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("bytes_per_pixel", C.c_uint8)]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("d_rgba", C.c_void_p), ("d_row_filters", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("bytes_per_pixel", C.c_uint32), ("unique_symbols", C.c_uint32),
+                ("retried_rows", C.c_uint32)]
+
+
+def build(verbose: bool = False) -> None:
+    """Compile libpngloss_hip.so (hipcc, gfx950) and libpngloss_synth.so (gcc) in-tree."""
+    r = subprocess.run(["make", "-C", _CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building pngloss_amd/csrc failed")
+
+
+def _load(name):
+    path = os.path.join(_CSRC, name)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+    return C.CDLL(path)
+
+
+def synth_lib():
+    global _synth
+    with _lock:
+        if _synth is None:
+            lib = _load("libpngloss_synth.so")
+            lib.pngloss_synth_rgba.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64]
+            lib.pngloss_synth_rgba.restype = None
+            lib.pngloss_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
+            lib.pngloss_fnv1a64.restype = C.c_uint64
+            lib.pngloss_fnv1a64_seed.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+            lib.pngloss_fnv1a64_seed.restype = C.c_uint64
+            _synth = lib
+        return _synth
+
+
+#: every symbol include/pngloss_hip.h declares (tests/test_abi.py checks the .so exports each of them)
+ABI_SYMBOLS = (
+    "optimize_with_rows", "optimize_with_stride", "optimizeForAverageFilter", "optimize_image",
+    "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
+    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
+    "pngloss_hip_last_histogram", "pngloss_hip_version",
+)
+
+
+def hip_lib():
+    global _hip
+    with _lock:
+        if _hip is None:
+            lib = _load("libpngloss_hip.so")
+            rows_t = C.POINTER(C.c_void_p)
+            lib.optimize_with_rows.argtypes = [rows_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
+            lib.optimize_with_rows.restype = C.c_int
+            lib.optimize_with_stride.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_bool, C.c_uint8, C.c_long]
+            lib.optimize_with_stride.restype = None
+            lib.optimizeForAverageFilter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+            lib.optimizeForAverageFilter.restype = None
+            lib.optimize_image.argtypes = [C.POINTER(PnglossImage), C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
+            lib.optimize_image.restype = C.c_int
+            lib.pngloss_hip_device_count.restype = C.c_int
+            lib.pngloss_hip_create.argtypes = [C.c_int]
+            lib.pngloss_hip_create.restype = C.c_void_p
+            lib.pngloss_hip_destroy.argtypes = [C.c_void_p]
+            lib.pngloss_hip_destroy.restype = None
+            lib.pngloss_hip_optimize_batch_async.argtypes = [C.c_void_p, C.POINTER(ImageDesc), C.c_size_t, C.c_uint, C.c_long, C.c_void_p]
+            lib.pngloss_hip_optimize_batch_async.restype = C.c_int
+            lib.pngloss_hip_finish.argtypes = [C.c_void_p, C.POINTER(Result), C.c_size_t]
+            lib.pngloss_hip_finish.restype = C.c_int
+            lib.pngloss_hip_optimize_batch.argtypes = [C.c_void_p, C.POINTER(ImageDesc), C.c_size_t, C.c_uint, C.c_long, C.c_void_p, C.POINTER(Result)]
+            lib.pngloss_hip_optimize_batch.restype = C.c_int
+            lib.pngloss_hip_last_engine_ms.argtypes = [C.c_void_p]
+            lib.pngloss_hip_last_engine_ms.restype = C.c_double
+            lib.pngloss_hip_last_total_ms.argtypes = [C.c_void_p]
+            lib.pngloss_hip_last_total_ms.restype = C.c_double
+            lib.pngloss_hip_last_histogram.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+            lib.pngloss_hip_last_histogram.restype = C.c_int
+            lib.pngloss_hip_version.restype = C.c_char_p
+            _hip = lib
+        return _hip
+
+
+def _check(rc, what):
+    if rc != PNGLOSS_SUCCESS:
+        raise RuntimeError(f"{what} failed with pngloss_error {rc}")
+
+
+def _row_pointers(arr: np.ndarray):
+    h = arr.shape[0]
+    stride = arr.strides[0]
+    base = arr.ctypes.data
+    return (C.c_void_p * h)(*[base + y * stride for y in range(h)])
+
+
+# ---- host-pointer seam, same names as the reference ---------------------------------------------------------
+
+def optimize_with_rows(rgba: np.ndarray, strength: int = 19, bleed: int = 2, want_filters: bool = True, verbose: bool = False):
+    """optimize_with_rows (pngloss_image.h:21-25) on an (H, W, 4) uint8 array.  Returns (rgba_out, row_filters|None)."""
+    assert rgba.dtype == np.uint8 and rgba.ndim == 3 and rgba.shape[2] == 4
+    out = np.ascontiguousarray(rgba).copy()
+    h, w = out.shape[:2]
+    filt = np.zeros(h, np.uint8) if want_filters else None
+    rows = _row_pointers(out) if h else (C.c_void_p * 1)()
+    rc = hip_lib().optimize_with_rows(rows, w, h, filt.ctypes.data_as(C.c_void_p) if want_filters else None, verbose, strength, bleed)
+    _check(rc, "optimize_with_rows")
+    return out, filt
+
+
+def optimize_with_stride(rgba: np.ndarray, strength: int = 19, bleed: int = 2):
+    """optimize_with_stride (pngloss_image.h:17-20): contiguous buffer + stride, row_filters = NULL mode."""
+    out = np.ascontiguousarray(rgba).copy()
+    h, w = out.shape[:2]
+    hip_lib().optimize_with_stride(out.ctypes.data_as(C.c_void_p), w, h, out.strides[0], False, strength, bleed)
+    return out
+
+
+def optimize_for_average_filter(rgba: np.ndarray, strength: int):
+    """optimizeForAverageFilter (pngloss_image.h:14-16)."""
+    out = np.ascontiguousarray(rgba).copy()
+    h, w = out.shape[:2]
+    hip_lib().optimizeForAverageFilter(out.ctypes.data_as(C.c_void_p), w, h, strength)
+    return out
+
+
+def optimize_image(packed: np.ndarray, strength: int = 19, bleed: int = 2, want_filters: bool = True):
+    """optimize_image (pngloss_image.h:26-29) on an (H, W, bpp) packed uint8 array, bpp 1..4."""
+    assert packed.dtype == np.uint8 and packed.ndim == 3 and 1 <= packed.shape[2] <= 4
+    out = np.ascontiguousarray(packed).copy()
+    h, w, bpp = out.shape
+    filt = np.zeros(h, np.uint8) if want_filters else None
+    rows = _row_pointers(out) if h else (C.c_void_p * 1)()
+    img = PnglossImage(C.cast(rows, C.POINTER(C.c_void_p)), w, h, bpp)
+    rc = hip_lib().optimize_image(C.byref(img), filt.ctypes.data_as(C.c_void_p) if want_filters else None, False, strength, bleed)
+    _check(rc, "optimize_image")
+    return out, filt
+
+
+# ---- device-resident batch extension ------------------------------------------------------------------------
+
+class HipContext:
+    """pngloss_hip_ctx wrapper: device-resident batches (pointers come from torch tensors / hipMalloc)."""
+
+    def __init__(self, device: int = -1):
+        self._lib = hip_lib()
+        self._ctx = self._lib.pngloss_hip_create(device)
+        if not self._ctx:
+            raise RuntimeError("pngloss_hip_create failed: no usable HIP device (there is no CPU fallback)")
+
+    def close(self):
+        if self._ctx:
+            self._lib.pngloss_hip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enqueue(self, images, strength=19, bleed=2, stream=0):
+        """images: sequence of (d_rgba_ptr, d_filters_ptr_or_0, width, height). Asynchronous."""
+        n = len(images)
+        descs = (ImageDesc * max(n, 1))()
+        for i, (p, f, w, h) in enumerate(images):
+            descs[i] = ImageDesc(p, f or None, w, h)
+        _check(self._lib.pngloss_hip_optimize_batch_async(self._ctx, descs, n, strength, bleed, stream or None), "enqueue")
+        self._n = n
+
+    def finish(self):
+        n = getattr(self, "_n", 0)
+        res = (Result * max(n, 1))()
+        _check(self._lib.pngloss_hip_finish(self._ctx, res, n), "finish")
+        return [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols, retried_rows=r.retried_rows) for r in res[:n]]
+
+    def run(self, images, strength=19, bleed=2, stream=0):
+        self.enqueue(images, strength, bleed, stream)
+        return self.finish()
+
+    @property
+    def engine_ms(self):
+        return self._lib.pngloss_hip_last_engine_ms(self._ctx)
+
+    @property
+    def total_ms(self):
+        return self._lib.pngloss_hip_last_total_ms(self._ctx)
+
+    def histogram(self, index=0):
+        h = np.zeros(256, np.uint32)
+        _check(self._lib.pngloss_hip_last_histogram(self._ctx, index, h.ctypes.data_as(C.c_void_p)), "histogram")
+        return h
