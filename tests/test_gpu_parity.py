@@ -1,0 +1,209 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of libpngloss_hip.so, against
+  (a) the committed golden fixtures produced by the real reference,
+  (b) the CPU oracle on seeded inputs,
+  (c) the reference digests of the full-size BASELINE.json configurations, and size-independent properties.
+Bar: bit-exact pixels and filter IDs (integer/byte work, no tolerance)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pngloss_amd as P
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def test_extension_is_loaded_and_sees_the_gpu():
+    lib = P.hip_lib()
+    assert lib.pngloss_hip_device_count() >= 1
+    assert b"gfx950" in lib.pngloss_hip_version()
+
+
+@pytest.mark.parametrize("case", U.SYNTH_CASES, ids=U.case_key)
+def test_golden_synthetic(case):
+    w, h, m, s, b, fr, filt = case
+    g = U.load_npz("synth_cases.npz")
+    out, f = P.optimize_with_rows(P.synth_rgba(w, h, m, fr), s, b, want_filters=filt)
+    assert np.array_equal(out, g[U.case_key(case) + "/out"])
+    if filt:
+        assert np.array_equal(f, g[U.case_key(case) + "/filters"])
+
+
+@pytest.mark.parametrize("name", ["rose", "david", "tux"])
+def test_golden_suite_images(name):
+    g = U.load_npz("suite_small.npz")
+    out, f = P.optimize_with_rows(g[name + "/in"], 19, 2)
+    assert np.array_equal(out, g[name + "/out"])
+    assert np.array_equal(f, g[name + "/filters"])
+
+
+def test_seeded_inputs_against_oracle():
+    for img, s, b, filt in U.seeded_cases(seed=7, n=48):
+        o1, f1 = U.run_port(img, s, b, filt)
+        o2, f2 = P.optimize_with_rows(img, s, b, want_filters=filt)
+        assert np.array_equal(o1, o2), (img.shape, s, b, filt)
+        if filt:
+            assert np.array_equal(f1, f2), (img.shape, s, b, filt)
+
+
+@pytest.mark.parametrize("strength", [0, 1, 15, 16, 19, 20, 31, 32, 33, 40, 63, 64, 85, 127, 128, 255])
+def test_every_candidate_count_path(strength):
+    """s<=15: one candidate per lane, s<=31: two, above: the generic sweep -- each against the oracle, every class."""
+    for mode in (0, 1, 3, 4, 5):
+        img = P.synth_rgba(70, 10, mode, strength)
+        o1, f1 = U.run_port(img, strength, 2)
+        o2, f2 = P.optimize_with_rows(img, strength, 2)
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (strength, mode)
+
+
+@pytest.mark.parametrize("bleed", [1, 2, 3, 7, 8, 100, 32767])
+def test_bleed_dividers(bleed):
+    for mode in (0, 1, 5):
+        img = P.synth_rgba(66, 12, mode, bleed)
+        o1, f1 = U.run_port(img, 40, bleed)
+        o2, f2 = P.optimize_with_rows(img, 40, bleed)
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (bleed, mode)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 1), (1, 7), (63, 2), (64, 2), (65, 3), (128, 2), (129, 2), (300, 1)])
+def test_edge_shapes_both_modes(shape):
+    w, h = shape
+    for mode in (1, 0, 3, 4, 5):
+        for filt in (True, False):
+            img = P.synth_rgba(w, h, mode, 0)
+            o1, f1 = U.run_port(img, 19, 2, filt)
+            o2, f2 = P.optimize_with_rows(img, 19, 2, want_filters=filt)
+            assert np.array_equal(o1, o2), (shape, mode, filt)
+            if filt:
+                assert np.array_equal(f1, f2), (shape, mode, filt)
+
+
+def test_empty_image_is_a_no_op():
+    out, f = P.optimize_with_rows(np.zeros((0, 0, 4), np.uint8), 19, 2)
+    assert out.size == 0 and f.size == 0
+    out, f = P.optimize_with_rows(np.zeros((3, 0, 4), np.uint8), 19, 2)
+    assert out.shape == (3, 0, 4)
+
+
+def test_strength_zero_identity_and_determinism():
+    for mode in range(6):
+        img = P.synth_rgba(200, 40, mode, 9)
+        out, f = P.optimize_with_rows(img, 0, 2)
+        assert np.array_equal(out, img)
+    img = P.synth_rgba(333, 77, 0, 4)
+    a = P.optimize_with_rows(img, 19, 2)
+    b = P.optimize_with_rows(img, 19, 2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_legacy_entry_points():
+    """optimize_with_stride / optimizeForAverageFilter (pngloss_image.c:29-50): row_filters = NULL mode."""
+    img = P.synth_rgba(90, 30, 0, 1)
+    want, _ = U.run_port(img, 25, 2, filters=False)
+    assert np.array_equal(P.optimize_for_average_filter(img, 25), want)
+    want8, _ = U.run_port(img, 25, 8, filters=False)
+    assert np.array_equal(P.optimize_with_stride(img, 25, 8), want8)
+
+
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+def test_optimize_image_lower_seam(bpp):
+    """optimize_image (pngloss_image.h:26-29) on packed data, no gray/alpha detection: e.g. an RGB image whose
+    pixels happen to be gray must still be treated as 3 B/px."""
+    rng = np.random.default_rng(bpp)
+    packed = rng.integers(0, 256, (14, 37, bpp), dtype=np.uint8)
+    if bpp in (2, 4):
+        packed[rng.random((14, 37)) < 0.2, bpp - 1] = 0
+    if bpp == 3:
+        packed[...] = packed[..., :1]
+    o1, f1 = U.run_port_packed(packed, 19, 2)
+    o2, f2 = P.optimize_image(packed, 19, 2)
+    assert np.array_equal(o1, o2) and np.array_equal(f1, f2)
+    o1, _ = U.run_port_packed(packed, 19, 2, filters=False)
+    o2, _ = P.optimize_image(packed, 19, 2, want_filters=False)
+    assert np.array_equal(o1, o2)
+
+
+def test_invalid_arguments_are_rejected():
+    img = P.synth_rgba(8, 8, 0, 0)
+    with pytest.raises(RuntimeError):
+        P.optimize_with_rows(img, 19, 0)
+    with pytest.raises(RuntimeError):
+        P.optimize_with_rows(img, 19, 40000)
+
+
+def test_device_resident_batch_of_mixed_images(torch_cuda):
+    """The batched extension: 9 images of all classes and sizes in one launch, device pointers from torch."""
+    torch = torch_cuda
+    specs = [(64, 48, 0), (70, 46, 2), (180, 215, 4), (33, 9, 3), (265, 31, 5), (1, 1, 1), (129, 65, 1), (5, 1, 0), (96, 64, 4)]
+    imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+    dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+    filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") for a in imgs]
+    ctx = P.HipContext()
+    res = ctx.run([(d.data_ptr(), f.data_ptr(), a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)], 19, 2,
+                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want_bpp = {0: 4, 1: 4, 2: 3, 3: 2, 4: 1, 5: 4}
+    for i, (a, d, f, r) in enumerate(zip(imgs, dev, filt, res)):
+        o1, f1 = U.run_port(a, 19, 2)
+        assert np.array_equal(d.cpu().numpy(), o1), specs[i]
+        assert np.array_equal(f.cpu().numpy(), f1), specs[i]
+        assert r["status"] == 0 and r["bpp"] == want_bpp[specs[i][2]]
+        # final histogram: one symbol per channel byte, and the unique-symbol count of pngloss_image.c:311-325
+        h, w = a.shape[:2]
+        hist = ctx.histogram(i)
+        assert int(hist.sum()) == w * h * r["bpp"]
+        assert int((hist != 0).sum()) == r["unique_symbols"]
+    assert ctx.engine_ms > 0 and ctx.total_ms >= ctx.engine_ms
+    ctx.close()
+
+
+def test_batch_histogram_matches_oracle(torch_cuda):
+    torch = torch_cuda
+    a = P.synth_rgba(150, 40, 2, 3)
+    d = torch.from_numpy(a.copy()).cuda()
+    f = torch.zeros(40, dtype=torch.uint8, device="cuda")
+    ctx = P.HipContext()
+    ctx.run([(d.data_ptr(), f.data_ptr(), 150, 40)], 30, 2)
+    _, _, hist = U.run_port_packed(np.ascontiguousarray(a[..., :3]), 30, 2, trace=True)
+    assert np.array_equal(ctx.histogram(0), hist)
+    ctx.close()
+
+
+def test_reference_digests_1080p_frames():
+    for e in U.load_digests()["synthetic"]:
+        if (e["width"], e["height"]) != (1920, 1080):
+            continue
+        out, f = P.optimize_with_rows(P.synth_rgba(1920, 1080, 0, e["frame"]), 19, 2)
+        assert "%016x" % P.fnv1a64(out, P.SURVEY_FNV_BASIS) == e["out"], e
+        assert "%016x" % P.fnv1a64(f, P.SURVEY_FNV_BASIS) == e["filters"], e
+
+
+def test_reference_digest_headline_4096(torch_cuda):
+    """BASELINE.json configs[1]: 4096x4096 synthetic RGBA8, s=19, b=2 -- digests measured on the real reference."""
+    e = [e for e in U.load_digests()["synthetic"] if e["width"] == 4096][0]
+    img = P.synth_rgba(4096, 4096, 0, 0)
+    assert "%016x" % P.fnv1a64(img, P.SURVEY_FNV_BASIS) == e["in"]
+    out, f = P.optimize_with_rows(img, 19, 2)
+    assert "%016x" % P.fnv1a64(out, P.SURVEY_FNV_BASIS) == e["out"]
+    assert "%016x" % P.fnv1a64(f, P.SURVEY_FNV_BASIS) == e["filters"]
+    # size-independent properties at full size: only the five legal filter flags, alpha never leaves [224,255]
+    assert set(np.unique(f)) <= set(P.PNG_FILTER_FLAGS)
+    assert int(np.abs(out.astype(np.int16) - img.astype(np.int16)).max()) <= 2 * 19 + 8
+
+
+def test_suite_class_digests_via_synthetic_stand_ins():
+    """BASELINE.json configs[2] (the 11 suite PNGs) cannot travel as files; their three small members are golden
+    fixtures above, and every byte-per-pixel class is covered at suite-like sizes against the oracle here."""
+    for (w, h, m) in [(512, 512, 4), (755, 503, 2), (800, 600, 5), (512, 480, 3)]:
+        img = P.synth_rgba(w, h, m, 1)
+        o1, f1 = U.run_port(img, 19, 2)
+        o2, f2 = P.optimize_with_rows(img, 19, 2)
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m)

@@ -1,0 +1,136 @@
+"""Shared helpers for the tests: ctypes access to the CPU oracle (tests may use oracle/, the product may not)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+_ROWS_SIG = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
+
+
+class PortTrace(C.Structure):
+    _fields_ = [("cost", C.c_void_p), ("strength_used", C.c_void_p), ("winner", C.c_void_p), ("final_hist", C.c_void_p)]
+
+
+_port = None
+_ref = None
+
+
+def port():
+    global _port
+    if _port is None:
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "libpngloss_port.so"))
+        lib.port_optimize_with_rows.argtypes = _ROWS_SIG
+        lib.port_optimize_with_rows.restype = C.c_int
+        lib.port_optimize_packed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint, C.c_long, C.POINTER(PortTrace)]
+        lib.port_optimize_packed.restype = C.c_int
+        lib.port_orig_histograms.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.port_adaptive_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.port_adaptive_filter.restype = C.c_int
+        lib.port_sierra_split.argtypes = [C.c_int, C.c_long, C.POINTER(C.c_int * 5)]
+        lib.port_symbol_cost.argtypes = [C.c_uint32]
+        lib.port_symbol_cost.restype = C.c_uint
+        lib.port_set_chain_variant.argtypes = [C.c_int]
+        _port = lib
+    return _port
+
+
+def ref():
+    """The REAL reference hot path (oracle/_ref, built from /root/reference by oracle/Makefile) or None."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libpngloss_ref.so")
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        lib.optimize_with_rows.argtypes = _ROWS_SIG
+        lib.optimize_with_rows.restype = C.c_int
+        _ref = lib
+    return _ref
+
+
+def _run_rows(fn, img, s, b, filters=True):
+    img = np.ascontiguousarray(img)
+    h, w, _ = img.shape
+    out = img.copy()
+    f = np.zeros(h, np.uint8)
+    rows = (C.c_void_p * max(h, 1))(*[out.ctypes.data + y * w * 4 for y in range(h)])
+    rc = fn(rows, w, h, f.ctypes.data if filters else None, False, s, b)
+    assert rc == 0
+    return out, (f if filters else None)
+
+
+def run_port(img, s=19, b=2, filters=True, variant=0):
+    port().port_set_chain_variant(variant)
+    try:
+        return _run_rows(port().port_optimize_with_rows, img, s, b, filters)
+    finally:
+        port().port_set_chain_variant(0)
+
+
+def run_ref(img, s=19, b=2, filters=True):
+    return _run_rows(ref().optimize_with_rows, img, s, b, filters)
+
+
+def run_port_packed(packed, s=19, b=2, filters=True, trace=False):
+    """port_optimize_packed on an (H, W, bpp) array; returns out, filters, (final_hist if trace)."""
+    out = np.ascontiguousarray(packed).copy()
+    h, w, bpp = out.shape
+    f = np.zeros(h, np.uint8)
+    hist = np.zeros(256, np.uint32)
+    tr = PortTrace(None, None, None, hist.ctypes.data)
+    rc = port().port_optimize_packed(out.ctypes.data, w, h, bpp, f.ctypes.data if filters else None, s, b, C.byref(tr) if trace else None)
+    assert rc == 0
+    return (out, (f if filters else None), hist) if trace else (out, (f if filters else None))
+
+
+# (width, height, mode, strength, bleed, frame, want_filters) -- must match tests/golden/make_golden.py:SYNTH_CASES
+SYNTH_CASES = (
+    [(64, 48, m, 19, 2, 0, True) for m in range(6)]
+    + [(64, 48, 0, s, b, 0, True) for (s, b) in [(0, 2), (20, 1), (40, 2), (85, 8), (255, 1), (19, 32767)]]
+    + [(64, 48, m, s, b, 0, True) for m in (1, 5) for (s, b) in [(40, 2), (85, 8)]]
+    + [(w, h, 1, 19, 2, 0, True) for (w, h) in [(1, 1), (2, 3), (5, 1), (1, 7)]]
+    + [(96, 64, m, 19, 2, 3, False) for m in (0, 3, 4, 5)]
+    + [(130, 9, m, 19, 2, 1, True) for m in (0, 2, 3, 4)]
+)
+
+
+def case_key(c):
+    return "w%d_h%d_m%d_s%d_b%d_f%d_%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "ids" if c[6] else "null")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def load_digests():
+    with open(os.path.join(GOLDEN, "digests.json")) as fh:
+        return json.load(fh)
+
+
+def seeded_cases(seed=7, n=24):
+    """Random RGBA images covering all four byte-per-pixel classes, transparency, extreme strengths and bleeds."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w = int(rng.integers(1, 150))
+        h = int(rng.integers(1, 24))
+        s = int(rng.choice([0, 1, 7, 15, 16, 19, 31, 32, 40, 85, 200, 255]))
+        b = int(rng.choice([1, 2, 3, 8, 100, 32767]))
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        kind = i % 6
+        if kind == 1:
+            img[..., 3] = 255
+        elif kind == 2:
+            img[..., 0] = img[..., 1]; img[..., 2] = img[..., 1]
+        elif kind == 3:
+            img[..., 0] = img[..., 1]; img[..., 2] = img[..., 1]; img[..., 3] = 255
+        elif kind == 4:
+            img[..., 3] = np.where(rng.random((h, w)) < 0.3, 0, img[..., 3])
+        elif kind == 5:
+            img = (img // 86 * 127).astype(np.uint8)   # few distinct values: lots of saturated 0/254 runs and ties
+        out.append((img, s, b, bool(i % 3)))
+    return out
