@@ -38,7 +38,8 @@ struct PlJob {
     uint2 *err1;          /* [width] same for the next row                                 (color_error row 1)    */
     uint32_t *old_above;  /* [width] original (pre-optimisation) previous row = last_row_pixels                  */
     uint32_t *final_hist; /* [256]                                                                               */
-    int32_t *result;      /* [4] status, bpp, unique symbols, retried rows                                       */
+    int32_t *result;      /* [16] status, bpp, unique symbols, retried rows, repaired pixels (wave 0), -,-,-,
+                             [8..11] chain kilo-cycles per chain wave, [12..15] repaired pixels per chain wave          */
 };
 
 __device__ __forceinline__ uint32_t pl_bpp_from_flags(uint32_t fl)

@@ -28,6 +28,10 @@
  */
 #include "pl_device.h"
 
+#ifndef PL_ABLATE
+#define PL_ABLATE 0   /* timing experiments only (tools/ablate.sh): >0 removes pieces of the chain, results become wrong */
+#endif
+
 namespace {
 
 /* ---- DPP helpers (wave64, 16-lane rows) ---------------------------------------------------------------- */
@@ -72,33 +76,90 @@ __device__ __forceinline__ uint32_t key2(uint32_t rank, int jj, int josym)
     return ((rank << 9) | ((jj == josym) ? 256u : 0u) | (uint32_t)(255 - jj)) + 1u;
 }
 
+/* LDS pointers keep their address space across the (non-inlined) per-filter chain functions, so the compiler emits
+ * ds_* instead of flat_* accesses */
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x2 lds_uint2;
+typedef __attribute__((address_space(3))) u32x4 lds_uint4;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+#define PL_TBL_N (PL_NSYM + 64)   /* 256 bins + 64 per-lane dummy slots */
+
 struct RowCtx {
-    const uint32_t *row;      /* original row y (slots)                    */
-    const uint32_t *nabove;   /* optimised row y-1 or nullptr              */
-    const uint2 *err0;        /* incoming error for row y                  */
-    uint32_t *out;            /* this candidate's cand[] as words: [x][4]  */
-    uint2 *tbl;               /* this candidate's {H, rank}[256] in LDS    */
-    uint2 (*rec)[4];          /* this candidate's [64][4] chunk records    */
+    const uint32_t *row;      /* original row y (slots)                                  */
+    const uint32_t *nabove;   /* optimised row y-1 or nullptr                            */
+    const uint2 *err0;        /* incoming error for row y                                */
+    uint4 *cand;              /* cand[5][W]: per candidate, per pixel: 4 x (byte | diff16<<8) */
+    lds_uint2 *tbl;           /* tbl[5][PL_TBL_N] {H, rank<<9} in LDS                    */
+    lds_uint4 *rec;           /* this WAVE's chunk records: [64][4][2]                   */
+    lds_u32 *lut;             /* Sierra split table: [diff+256] -> rem | thr<<16, |diff|<=255 */
     uint32_t W, y, bpp;
     int s;
     float rq, rbleed, r29;
+    uint32_t slow;            /* out: pixels that took the exact-repair slow path        */
 };
 
-/* ---------------------------------------------------------------------------------------------------------
- * The serial chain for one candidate filter F over one row.  NCT = candidates per lane known at compile time
- * (1: s<=15, 2: s<=31) or 0 for the generic two-sweep loop.
- * --------------------------------------------------------------------------------------------------------- */
-template <int F, int NCT>
-__device__ __forceinline__ void chain_row(const RowCtx &k, const int lane)
+__device__ __forceinline__ int med3_i32(int v, int lo, int hi)
 {
-    const int c = lane >> 4, jl = lane & 15;
-    const uint32_t bpp = k.bpp, W = k.W;
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
+/* max over an aligned group of GL (16 or 8) lanes, result in every lane of the group */
+template <int GL>
+__device__ __forceinline__ uint32_t groupmax_u32(uint32_t v)
+{
+    if (GL == 16) return rowmax_u32(v);
+    v = max(v, dpp_u32<0xB1>(v));    /* quad_perm [1,0,3,2] */
+    v = max(v, dpp_u32<0x4E>(v));    /* quad_perm [2,3,0,1] */
+    v = max(v, dpp_u32<0x141>(v));   /* row_half_mirror     */
+    return v;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * The serial chain of one wave over one row.
+ *   MODE 1,3,4  one candidate filter (sub, average, paeth): 16 lanes per channel
+ *   MODE 5      TWO candidate filters whose prediction does not depend on the left neighbour (none = half 0, up =
+ *               half 1 of every 16-lane DPP row): 8 lanes per (channel, filter).  Five chains on four SIMDs would
+ *               make two waves share a SIMD, and the younger of two DPP-heavy waves on one SIMD runs at half rate
+ *               (profiles/r01_ubench_simd_sharing.txt) -- so the two cheapest chains share one wave instead.
+ *   NCT  candidates per lane known at compile time (1..4) or 0 for the generic two-sweep loop
+ *   TR   the image class has alpha (2 or 4 B/px): honour optimize_state.c:158-164 for fully transparent pixels
+ *   WRAP false when every incoming error of this row is <= 8000 in magnitude (decided by the commit pass): then no
+ *        intermediate can leave int16 (DESIGN.md "int16 wrap") and the sign-extensions are dropped
+ * Per pixel (all channels at once): band -> candidates -> gather -> 2 DPP arg-max reductions, speculative w.r.t. the
+ * histogram bumps of the earlier channels of the same pixel; a 1-pass test (one ds_bpermute) proves the speculation
+ * harmless -- the common case -- or sends the pixel down the exact sequential repair.
+ * --------------------------------------------------------------------------------------------------------- */
+template <int MODE, int NCT, bool TR, bool WRAP>
+__device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
+{
+    constexpr bool PAIR = MODE == 5;
+    constexpr int GL = PAIR ? 8 : 16;                     /* lanes per (channel[, filter]) group */
+    const int c = lane >> 4, jl = lane & (GL - 1);
+    const int half = PAIR ? (lane >> 3) & 1 : 0;
+    const int filt_id = PAIR ? 2 * half : MODE;           /* which candidate filter this lane works for */
+    const uint32_t bpp = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.bpp);
+    const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.W);
+    const uint32_t *const row = k.row, *const nabove = k.nabove;
+    const uint2 *const err0 = k.err0;
+    uint32_t *const outp = reinterpret_cast<uint32_t *>(k.cand + (size_t)filt_id * W);
     const bool active = (uint32_t)c < bpp;
-    const bool has_alpha = (bpp & 1u) == 0;
-    const int s = k.s, q = s + 1;
-    const int nc = NCT ? NCT : (q + 15) >> 4;
+    const int s = __builtin_amdgcn_readfirstlane(k.s), q = s + 1;
+    const int nc = NCT ? NCT : (q + GL - 1) / GL;
     const float rq = k.rq, rbleed = k.rbleed, r29 = k.r29;
-    uint2 *const T = k.tbl;
+    lds_uint2 *const T = k.tbl + filt_id * PL_TBL_N;
+    lds_uint4 *const R = k.rec;
+    lds_u32 *const LUT = k.lut;
+    /* lane constants */
+    const bool upd = active && jl == 0;                 /* the one lane per group that bumps the histogram        */
+    const uint32_t inc = upd ? 1u : 0u;
+    const int dummy = PL_NSYM + lane;
+    const bool chk = active && jl < c && jl < 3;        /* lane (c, k<c) checks channel k's bump against channel c */
+    const int chk_src = (16 * jl + 8 * half) * 4;       /* ds_bpermute byte address of a lane of group (k=jl)      */
+    uint32_t slow = 0;
 
     int left = 0, rem = 0, thr_prev = 0, thr_cur = 0;
 
@@ -107,18 +168,28 @@ __device__ __forceinline__ void chain_row(const RowCtx &k, const int lane)
         {
             const uint32_t xl = x0 + lane;
             const bool ok = xl < W;
-            const uint32_t o = ok ? k.row[xl] : 0u;
-            const uint32_t a = (ok && k.nabove) ? k.nabove[xl] : 0u;
-            const uint32_t d = (ok && k.nabove && xl) ? k.nabove[xl - 1] : 0u;
-            const uint2 e = ok ? k.err0[xl] : make_uint2(0u, 0u);
-            const bool alpha0 = has_alpha && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+            const uint32_t o = ok ? row[xl] : 0u;
+            const uint32_t a = (ok && nabove) ? nabove[xl] : 0u;
+            const uint32_t d = (ok && nabove && xl) ? nabove[xl - 1] : 0u;
+            const uint2 e = ok ? err0[xl] : make_uint2(0u, 0u);
+            const bool alpha0 = TR && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                 const int p = pl_plane_of_channel(bpp, cc);
-                const uint32_t ev = p < 2 ? (e.x >> (16 * p)) : (e.y >> (16 * (p - 2)));
-                uint32_t w0 = ((o >> (8 * cc)) & 255u) | (((a >> (8 * cc)) & 255u) << 8) | (((d >> (8 * cc)) & 255u) << 16);
-                if (alpha0 && (uint32_t)cc == bpp - 1u) w0 |= 1u << 24;
-                k.rec[lane][cc] = make_uint2(w0, (uint32_t)pl_sext16((int)ev));
+                const int e0 = pl_sext16((int)(p < 2 ? (e.x >> (16 * p)) : (e.y >> (16 * (p - 2)))));
+                const int orig = (o >> (8 * cc)) & 255, above = (a >> (8 * cc)) & 255, diag = (d >> (8 * cc)) & 255;
+                const uint32_t trbit = (alpha0 && (uint32_t)cc == bpp - 1u) ? (1u << 16) : 0u;
+                if (PAIR) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int pred = h ? above : 0;
+                        const int osym = pl_sext8(orig - pred);
+                        R[(lane * 4 + cc) * 2 + h] = (u32x4){ (uint32_t)osym, (uint32_t)(osym - orig), (uint32_t)pred | trbit,
+                                                              (uint32_t)(WRAP ? e0 : osym + e0) };
+                    }
+                } else {
+                    R[(lane * 4 + cc) * 2] = (u32x4){ (uint32_t)orig, (uint32_t)above, (uint32_t)diag | trbit, (uint32_t)e0 };
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -126,102 +197,174 @@ __device__ __forceinline__ void chain_row(const RowCtx &k, const int lane)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         const int n = (int)min(64u, W - x0);
-        uint2 r = k.rec[0][c];
-        for (int i = 0; i < n; i++) {
-            const uint2 rn = k.rec[(i + 1) & 63][c];   /* prefetch the next pixel's record */
-            const int orig = r.x & 255, above = (r.x >> 8) & 255, diag = (r.x >> 16) & 255;
-            const bool tr = has_alpha && (r.x >> 24);
+        u32x4 r = R[c * 2 + half];
+        for (int g = 0; g < n; g += GL) {
+        const int m = min(GL, n - g);
+        uint32_t cap = 0;
+        for (int ii = 0; ii < m; ii++) {
+            const int i = g + ii;
+            const u32x4 rn = R[(((i + 1) & 63) * 4 + c) * 2 + half];   /* prefetch the next pixel's record */
 
-            /* ---- uniform per channel row: optimize_state.c:157-210 ---- */
-            const int pred = pl_predict<F>(above, diag, left);
-            const int osym = pl_sext8(orig - pred);
-            int predc = orig - osym;
-            const int err = pl_sext16((int)r.y + rem + thr_prev);
-            const int filt = osym + err;
-            const int af = abs(filt);
-            const int base = (int)((float)af * rq) * q;
-            int vmin = filt < 0 ? -base - s : base;
+            /* ---- uniform per group: optimize_state.c:157-210 ---- */
+            int osym, lo, predraw, filt;
+            if (PAIR) {
+                osym = (int)r.x; lo = (int)r.y; predraw = (int)(r.z & 0xffffu);
+                filt = WRAP ? osym + pl_sext16((int)r.w + rem + thr_prev) : (int)r.w + rem + thr_prev;
+            } else {
+                const int orig = (int)r.x;
+                predraw = pl_predict<MODE>((int)r.y, (int)(r.z & 0xffffu), left);
+                osym = pl_sext8(orig - predraw);
+                lo = osym - orig;                       /* = -(re-centred prediction), optimize_state.c:175-182 */
+                int err = (int)r.w + rem + thr_prev;
+                if (WRAP) err = pl_sext16(err);
+                filt = osym + err;
+            }
+            const int tq = (int)((float)filt * rq);     /* trunc(filt / q), exact (pl_device.h) */
+            int vmin = __mul24(tq, q) - ((filt >> 31) & s);
             int vmax = vmin + s;
-            const int lo = -predc, hi = lo + 255;
-            vmin = pl_med3(vmin, lo, hi);
-            vmax = pl_med3(vmax, lo, hi);
-            if (tr) { vmin = -pred; vmax = -pred; predc = pred; }   /* optimize_state.c:158-164 */
+            const int hi = lo + 255;
+            vmin = med3_i32(vmin, lo, hi);
+            vmax = med3_i32(vmax, lo, hi);
+            bool tr = false;
+            if (TR) {
+                tr = (r.z >> 16) != 0;                  /* optimize_state.c:158-164 */
+                vmin = tr ? -predraw : vmin;
+                vmax = tr ? -predraw : vmax;
+                lo = tr ? -predraw : lo;
+            }
             const int span = vmax - vmin, josym = osym - vmin;
 
-            /* ---- candidates: gather and two-level arg-max (optimize_state.c:212-244) ---- */
+            /* ---- candidates: gather and two-level arg-max (optimize_state.c:212-244).  Lanes beyond the band
+             *      re-evaluate its last member, which cannot change a max or an arg-max. ---- */
             uint32_t Hwin, K;
-            if (NCT == 1) {
-                const uint2 e0 = T[(vmin + jl) & 255];
-                const bool v0 = jl <= span;
-                Hwin = rowmax_u32(v0 ? e0.x : 0u);
-                K = rowmax_u32((v0 && e0.x == Hwin) ? key2(e0.y, jl, josym) : 0u);
-            } else if (NCT == 2) {
-                const uint2 e0 = T[(vmin + jl) & 255];
-                const uint2 e1 = T[(vmin + jl + 16) & 255];
-                const bool v0 = jl <= span, v1 = jl + 16 <= span;
-                Hwin = rowmax_u32(max(v0 ? e0.x : 0u, v1 ? e1.x : 0u));
-                const uint32_t k0 = (v0 && e0.x == Hwin) ? key2(e0.y, jl, josym) : 0u;
-                const uint32_t k1 = (v1 && e1.x == Hwin) ? key2(e1.y, jl + 16, josym) : 0u;
-                K = rowmax_u32(max(k0, k1));
-            } else {
-                uint32_t m = 0;
-                for (int t = 0; t < nc; t++) {
-                    const int jj = jl + 16 * t;
-                    const uint32_t h = T[(vmin + jj) & 255].x;
-                    m = max(m, jj <= span ? h : 0u);
-                }
-                Hwin = rowmax_u32(m);
-                uint32_t kk = 0;
-                for (int t = 0; t < nc; t++) {
-                    const int jj = jl + 16 * t;
-                    const uint2 e = T[(vmin + jj) & 255];
-                    kk = max(kk, (jj <= span && e.x == Hwin) ? key2(e.y, jj, josym) : 0u);
-                }
-                K = rowmax_u32(kk);
-            }
-            int jwin = 255 - (int)((K - 1u) & 255u);
-            uint32_t Rwin = (K - 1u) >> 9;
-
-            /* ---- exact repair of the channel coupling: channel cp chose bin sb and bumped it to sH ---- */
+            if (NCT) {
+                int jj[NCT ? NCT : 1];
+                u32x2 e[NCT ? NCT : 1];
+                uint32_t kk[NCT ? NCT : 1];
 #pragma unroll
-            for (int cp = 0; cp < 3; cp++) {
-                if ((uint32_t)cp + 1u < bpp) {
-                    const int binp = (vmin + jwin) & 255;
-                    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane(binp, 16 * cp);
-                    const uint32_t sH = (uint32_t)__builtin_amdgcn_readlane((int)Hwin, 16 * cp) + 1u;
-                    const uint32_t sR = (uint32_t)__builtin_amdgcn_readlane((int)Rwin, 16 * cp);
-                    const int jj2 = ((int)sb - vmin) & 255;
-                    const uint32_t K2 = key2(sR, jj2, josym);
-                    const bool better = (c > cp) && (jj2 <= span) && (sH > Hwin || (sH == Hwin && K2 > K));
-                    if (better) { Hwin = sH; K = K2; jwin = jj2; Rwin = sR; }
+                for (int t = 0; t < NCT; t++) {
+                    jj[t] = min(jl + GL * t, span);
+                    e[t] = PL_ABLATE >= 5 ? (u32x2){ (uint32_t)jj[t], 0u } : T[(vmin + jj[t]) & 255];
                 }
+                uint32_t hm = e[0].x;
+#pragma unroll
+                for (int t = 0; t < NCT; t++) {
+                    kk[t] = e[t].y + ((jj[t] == josym) ? 256u : 0u) + (uint32_t)(256 - jj[t]);
+                    hm = max(hm, e[t].x);
+                }
+                Hwin = PL_ABLATE >= 4 ? hm : groupmax_u32<GL>(hm);
+                uint32_t km = 0;
+#pragma unroll
+                for (int t = 0; t < NCT; t++) km = max(km, e[t].x == Hwin ? kk[t] : 0u);
+                K = PL_ABLATE >= 3 ? (km | 1u) : groupmax_u32<GL>(km);
+            } else {
+                uint32_t hm = 0;
+                for (int t = 0; t < nc; t++) hm = max(hm, T[(vmin + min(jl + GL * t, span)) & 255].x);
+                Hwin = groupmax_u32<GL>(hm);
+                uint32_t km = 0;
+                for (int t = 0; t < nc; t++) {
+                    const int j2 = min(jl + GL * t, span);
+                    const u32x2 e = T[(vmin + j2) & 255];
+                    km = max(km, e.x == Hwin ? e.y + ((j2 == josym) ? 256u : 0u) + (uint32_t)(256 - j2) : 0u);
+                }
+                K = groupmax_u32<GL>(km);
             }
+            int jwin = (int)((0u - K) & 255u);          /* K-1 = rank<<9 | flag<<8 | 255-j */
+            int vwin = vmin + jwin;
 
-            /* ---- reconstruct, carry the in-row Sierra terms (optimize_state.c:251-260,455,467) ---- */
-            const int vwin = vmin + jwin;
-            const int back = vwin + predc;
-            const int diff = tr ? 0 : pl_sext16(filt - vwin);
-            const PlSplit sp = pl_sierra_split(diff, rbleed, r29);
-            thr_prev = thr_cur;
-            thr_cur = (int)sp.h;
-            rem = (int)sp.rem;
-            left = back;
-            if (jl == 0 && active) {
-                atomicAdd(&T[vwin & 255].x, 1u);
-                k.out[(size_t)(x0 + i) * 4 + c] = (uint32_t)(back & 255) | ((uint32_t)(diff & 0xffff) << 8);
+            /* ---- did an earlier channel of this pixel bump a bin of my band that is not my winner?
+             *      lane (c, k) fetches channel k's (speculative) winner; the answer is only needed after the
+             *      tail below has been computed speculatively, which hides the ds_bpermute latency ---- */
+            const int sv = PL_ABLATE >= 1 ? vwin : __builtin_amdgcn_ds_bpermute(chk_src, vwin);
+
+            /* ---- reconstruct (optimize_state.c:251-260); the Sierra terms that stay in this row (:455,467) come
+             *      from a 511-entry LDS table of the split, fetched alongside the ds_bpermute above ---- */
+            int back = vwin - lo;
+            int diff = filt - vwin;
+            if (WRAP) diff = pl_sext16(diff);
+            if (TR) diff = tr ? 0 : diff;
+            const uint32_t le = PL_ABLATE >= 2 ? 0u : LUT[(diff + 256) & 511];
+            int remv, thrv;
+
+            const int tt = (sv - vmin) & 255;
+            const bool bad = PL_ABLATE >= 1 ? false : ((chk && tt <= span && tt != jwin) | (active && (uint32_t)(diff + 255) > 510u));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+                /* exact repair in channel order: channel cp chose bin sb and bumped it to sH */
+                slow++;
+                uint32_t Rwin = (K - 1u) >> 9;
+#pragma unroll
+                for (int cp = 0; cp < 3; cp++) {
+                    if ((uint32_t)cp + 1u < bpp) {
+                        int sb; uint32_t sH, sR;
+                        if (PAIR) {
+                            const int b0 = __builtin_amdgcn_readlane(vwin, 16 * cp), b1 = __builtin_amdgcn_readlane(vwin, 16 * cp + 8);
+                            const int h0 = __builtin_amdgcn_readlane((int)Hwin, 16 * cp), h1 = __builtin_amdgcn_readlane((int)Hwin, 16 * cp + 8);
+                            const int r0 = __builtin_amdgcn_readlane((int)Rwin, 16 * cp), r1 = __builtin_amdgcn_readlane((int)Rwin, 16 * cp + 8);
+                            sb = half ? b1 : b0; sH = (uint32_t)(half ? h1 : h0) + 1u; sR = (uint32_t)(half ? r1 : r0);
+                        } else {
+                            sb = __builtin_amdgcn_readlane(vwin, 16 * cp);
+                            sH = (uint32_t)__builtin_amdgcn_readlane((int)Hwin, 16 * cp) + 1u;
+                            sR = (uint32_t)__builtin_amdgcn_readlane((int)Rwin, 16 * cp);
+                        }
+                        const int jj2 = (sb - vmin) & 255;
+                        const uint32_t K2 = (sR << 9) + ((jj2 == josym) ? 256u : 0u) + (uint32_t)(256 - jj2);
+                        const bool better = (c > cp) & (jj2 <= span) & ((sH > Hwin) | ((sH == Hwin) & (K2 > K)));
+                        Hwin = better ? sH : Hwin;
+                        K = better ? K2 : K;
+                        jwin = better ? jj2 : jwin;
+                        Rwin = better ? sR : Rwin;
+                        vwin = vmin + jwin;
+                    }
+                }
+                back = vwin - lo;
+                diff = filt - vwin;
+                if (WRAP) diff = pl_sext16(diff);
+                if (TR) diff = tr ? 0 : diff;
+                const PlSplit sp = pl_sierra_split(diff, rbleed, r29);
+                remv = (int)sp.rem;
+                thrv = (int)sp.h;
+            } else {
+                remv = pl_sext16((int)le);
+                thrv = (int)le >> 16;
             }
+            thr_prev = thr_cur;
+            thr_cur = thrv;
+            rem = remv;
+            left = back;
+            /* histogram bump without touching EXEC: non-owner lanes add 0 to a private dummy slot */
+            if (PL_ABLATE < 6) __hip_atomic_fetch_add((lds_u32 *)&T[upd ? (vwin & 255) : dummy], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            /* output capture: lane jl of the group keeps pixel ii; stored GL pixels at a time */
+            const uint32_t packed = (uint32_t)back | ((uint32_t)diff << 8);
+            cap = (jl == ii) ? packed : cap;
             r = rn;
         }
+        if (active && jl < m) outp[(size_t)(x0 + g + jl) * 4 + c] = cap;
+        }
     }
+    k.slow = slow;
 }
 
-template <int F>
-__device__ __forceinline__ void chain_dispatch(const RowCtx &k, int lane)
+template <int MODE, bool TR, bool WRAP>
+__device__ __forceinline__ void chain_dispatch_nc(RowCtx &k, int lane)
 {
     const int q = k.s + 1;
-    if (q <= 16) chain_row<F, 1>(k, lane);
-    else if (q <= 32) chain_row<F, 2>(k, lane);
-    else chain_row<F, 0>(k, lane);
+    const int per_lane = (q + (MODE == 5 ? 7 : 15)) / (MODE == 5 ? 8 : 16);
+    if (per_lane <= 1) chain_row<MODE, 1, TR, WRAP>(k, lane);
+    else if (per_lane == 2) chain_row<MODE, 2, TR, WRAP>(k, lane);
+    else if (MODE == 5 && per_lane == 3) chain_row<MODE, 3, TR, WRAP>(k, lane);
+    else if (MODE == 5 && per_lane == 4) chain_row<MODE, 4, TR, WRAP>(k, lane);
+    else chain_row<MODE, 0, TR, WRAP>(k, lane);
+}
+
+template <int MODE>
+__device__ __noinline__ void chain_dispatch(RowCtx &k, int lane, bool wrap)
+{
+    const bool tr = (k.bpp & 1u) == 0;
+    if (wrap) {
+        /* rare (needs |error| > 8000): one careful variant is enough */
+        chain_row<MODE, 0, true, true>(k, lane);
+    } else if (tr) chain_dispatch_nc<MODE, true, false>(k, lane);
+    else chain_dispatch_nc<MODE, false, false>(k, lane);
 }
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -294,9 +437,11 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 
 __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs, PlEngineParams prm)
 {
-    __shared__ uint2 tbl[PL_NFILT][PL_NSYM];     /* {running symbol_frequency, rank(original_frequency)} per candidate */
+    __shared__ uint2 tbl[PL_NFILT][PL_NSYM + 64]; /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
     __shared__ uint32_t Hc[PL_NSYM];             /* committed symbol_frequency                                        */
-    __shared__ uint2 rec[PL_NFILT][64][4];       /* per-candidate chunk records                                       */
+    __shared__ uint4 rec[4][64][4][2];           /* per chain-wave chunk records (two filters in the paired wave)      */
+    __shared__ uint32_t split_lut[512];          /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255     */
+    __shared__ uint32_t big_err;                 /* some |incoming error| of the coming row exceeds 8000 (see WRAP)    */
     __shared__ unsigned long long costs[PL_NFILT];
 
     const PlJob j = jobs[blockIdx.x];
@@ -308,39 +453,56 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
 
     for (int i = tid; i < PL_NSYM; i += PL_ENGINE_THREADS) Hc[i] = 0;
     for (int i = tid; i < PL_NFILT * PL_NSYM; i += PL_ENGINE_THREADS)
-        tbl[i >> 8][i & 255] = make_uint2(0u, j.orig_rank[i]);
+        tbl[i >> 8][i & 255] = make_uint2(0u, j.orig_rank[i] << 9);
+    for (int i = tid; i < PL_NFILT * 64; i += PL_ENGINE_THREADS) tbl[i >> 6][PL_NSYM + (i & 63)] = make_uint2(0u, 0u);
+    for (int i = tid; i < 512; i += PL_ENGINE_THREADS) {
+        const PlSplit sp = pl_sierra_split(i - 256, prm.rbleed, r29);
+        split_lut[i] = ((uint32_t)(int)sp.rem & 0xffffu) | ((uint32_t)(int)sp.h << 16);
+    }
+    if (tid == 0) big_err = 0;
     __syncthreads();
 
-    uint32_t retried = 0;
+    uint32_t retried = 0, slow_px = 0;
+    unsigned long long chain_cycles = 0;
     int status = 0;
     for (uint32_t y = 0; y < H && !status; y++) {
         const bool adaptive = !j.row_filters || y == 0;   /* pngloss_image.c:210 */
         int s = prm.strength;
         int winner = -1;
+        const bool wrap = big_err != 0;
         for (;;) {
             /* every candidate starts from the committed histogram (optimize_state_copy, pngloss_image.c:240) */
             for (int b = lane; b < PL_NSYM; b += 64) tbl[wave][b].x = Hc[b];
-            RowCtx k;
-            k.row = j.img + (size_t)y * W;
-            k.nabove = y ? k.row - W : nullptr;
-            k.err0 = j.err0;
-            k.out = reinterpret_cast<uint32_t *>(j.cand + (size_t)wave * W);
-            k.tbl = tbl[wave];
-            k.rec = rec[wave];
-            k.W = W; k.y = y; k.bpp = bpp; k.s = s;
-            k.rq = recip_up(s + 1); k.rbleed = prm.rbleed; k.r29 = r29;
-            switch (wave) {
-            case 0: chain_dispatch<0>(k, lane); break;
-            case 1: chain_dispatch<1>(k, lane); break;
-            case 2: chain_dispatch<2>(k, lane); break;
-            case 3: chain_dispatch<3>(k, lane); break;
-            default: chain_dispatch<4>(k, lane); break;
+            __syncthreads();
+            /* chain phase: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
+             * waves 1..3 run sub, average, paeth; wave 4 only takes part in the data-parallel passes */
+            if (wave < 4) {
+                RowCtx k;
+                k.row = j.img + (size_t)y * W;
+                k.nabove = y ? k.row - W : nullptr;
+                k.err0 = j.err0;
+                k.cand = j.cand;
+                k.tbl = (lds_uint2 *)&tbl[0][0];
+                k.rec = (lds_uint4 *)&rec[wave][0][0][0];
+                k.lut = (lds_u32 *)&split_lut[0];
+                k.W = W; k.y = y; k.bpp = bpp; k.s = s;
+                k.rq = recip_up(s + 1); k.rbleed = prm.rbleed; k.r29 = r29;
+                k.slow = 0;
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                switch (wave) {
+                case 0: chain_dispatch<5>(k, lane, wrap); break;
+                case 1: chain_dispatch<1>(k, lane, wrap); break;
+                case 2: chain_dispatch<3>(k, lane, wrap); break;
+                default: chain_dispatch<4>(k, lane, wrap); break;
+                }
+                chain_cycles += __builtin_readcyclecounter() - t0;
+                slow_px += k.slow;
             }
-            /* the post pass reads what this wave's own lanes stored: drain them (same CU, same L1) */
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint64_t cst = post_pass(j, y, bpp, wave, tbl[wave], adaptive, lane);
-            if (lane == 0) costs[wave] = cst;
+            __syncthreads();   /* candidate rows (global, same CU) and histograms (LDS) complete and visible */
+            /* post pass: one wave per candidate */
+            const int pf = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2)));
+            const uint64_t cst = post_pass(j, y, bpp, pf, tbl[pf], adaptive, lane);
+            if (lane == 0) costs[pf] = cst;
             __syncthreads();
             uint64_t best = ~0ull;
 #pragma unroll
@@ -357,6 +519,9 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         if (status) break;
 
         /* ---- commit (pngloss_image.c:277-308), parallel over x ---- */
+        if (tid == 0) big_err = 0;
+        __syncthreads();
+        bool big = false;
         const uint4 *cd = j.cand + (size_t)winner * W;
         uint32_t *rowp = j.img + (size_t)y * W;
         const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
@@ -382,11 +547,13 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                     c2 = p1.t + z0.h + m1.t;
                 }
                 n0[p] = (uint32_t)((int)e1p + (int)c1) & 0xffffu;   /* int16 wrap-on-store */
+                big |= abs(pl_sext16((int)n0[p])) > 8000;
                 n1[p] = (uint32_t)((int)c2) & 0xffffu;
             }
             j.err0[x] = make_uint2(n0[0] | (n0[1] << 16), n0[2] | (n0[3] << 16));
             j.err1[x] = make_uint2(n1[0] | (n1[1] << 16), n1[2] | (n1[3] << 16));
         }
+        if (big) big_err = 1;
         for (int b = tid; b < PL_NSYM; b += PL_ENGINE_THREADS) Hc[b] = tbl[winner][b].x;
         if (tid == 0 && j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);   /* PNG_FILTER_* flags */
         __syncthreads();
@@ -403,11 +570,17 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
     if (nz) atomicAdd(&uniq, nz);
     __syncthreads();
+    /* diagnostics: per chain wave, cycles spent in the serial chain (>>10) and pixels that needed the exact repair */
+    if (lane == 0 && wave < 4) {
+        j.result[8 + wave] = (int32_t)(chain_cycles >> 10);
+        j.result[12 + wave] = (int32_t)slow_px;
+    }
     if (tid == 0) {
         j.result[0] = status;
         j.result[1] = (int32_t)bpp;
         j.result[2] = (int32_t)uniq;
         j.result[3] = (int32_t)retried;
+        j.result[4] = (int32_t)slow_px;   /* wave 0's (none+up chains) count of pixels that needed the exact channel repair */
     }
 }
 

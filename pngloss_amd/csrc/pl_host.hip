@@ -61,7 +61,7 @@ WsLayout image_ws(uint32_t width)
     l.err1 = take(sizeof(uint2) * (size_t)width);
     l.old_above = take(sizeof(uint32_t) * (size_t)width);
     l.final_hist = take(sizeof(uint32_t) * PL_NSYM);
-    l.result = take(sizeof(int32_t) * 4);
+    l.result = take(sizeof(int32_t) * 16);
     l.total = o;
     return l;
 }
@@ -159,7 +159,7 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
     if (!ctx) return PNGLOSS_INVALID_ARGUMENT;
     if (!ctx->pending) {
         if (results)
-            for (size_t i = 0; i < n; i++) results[i] = pngloss_hip_result{ 0, 0, 0, 0 };
+            for (size_t i = 0; i < n; i++) results[i] = pngloss_hip_result{ 0, 0, 0, 0, 0 };
         return PNGLOSS_SUCCESS;
     }
     PL_CHECK(hipSetDevice(ctx->device));
@@ -172,9 +172,12 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
     ctx->total_ms = ms;
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < ctx->n_last; i++) {
-        int32_t r[4] = { 0, 0, 0, 0 };
+        int32_t r[16] = { 0 };
         PL_CHECK(hipMemcpy(r, ctx->h_jobs[i].result, sizeof r, hipMemcpyDeviceToHost));
-        if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3] };
+        if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4] };
+        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+            std::fprintf(stderr, "pngloss_hip: image %zu: chain kcycles per wave %d %d %d %d, repaired pixels %d %d %d %d, engine %.3f ms\n", i,
+                         r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15], ctx->engine_ms);
         if (r[0]) {
             std::fprintf(stderr, "pngloss_hip: image %zu: no acceptable filter row (device status %d)\n", i, r[0]);
             worst = PNGLOSS_INTERNAL_ABORT;
@@ -331,7 +334,7 @@ int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *his
     return PNGLOSS_SUCCESS;
 }
 
-const char *pngloss_hip_version(void) { return "pngloss_hip 0.1 (gfx950 row engine v1; seam: pngloss_image.h:14-29)"; }
+const char *pngloss_hip_version(void) { return "pngloss_hip 0.1 (gfx950 row engine v2; seam: pngloss_image.h:14-29)"; }
 
 /* ---- the reference's seam ------------------------------------------------------------------------------- */
 

@@ -35,7 +35,7 @@ class ImageDesc(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("bytes_per_pixel", C.c_uint32), ("unique_symbols", C.c_uint32),
-                ("retried_rows", C.c_uint32)]
+                ("retried_rows", C.c_uint32), ("repaired_pixels", C.c_uint32)]
 
 
 def build(verbose: bool = False) -> None:
@@ -84,7 +84,7 @@ def hip_lib():
     global _hip
     with _lock:
         if _hip is None:
-            lib = _load("libpngloss_hip.so")
+            lib = _load(os.environ.get("PNGLOSS_HIP_LIBNAME", "libpngloss_hip.so"))
             rows_t = C.POINTER(C.c_void_p)
             lib.optimize_with_rows.argtypes = [rows_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
             lib.optimize_with_rows.restype = C.c_int
@@ -206,7 +206,7 @@ class HipContext:
         n = getattr(self, "_n", 0)
         res = (Result * max(n, 1))()
         _check(self._lib.pngloss_hip_finish(self._ctx, res, n), "finish")
-        return [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols, retried_rows=r.retried_rows) for r in res[:n]]
+        return [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols, retried_rows=r.retried_rows, repaired_pixels=r.repaired_pixels) for r in res[:n]]
 
     def run(self, images, strength=19, bleed=2, stream=0):
         self.enqueue(images, strength, bleed, stream)
