@@ -28,6 +28,9 @@
  */
 #include "pl_device.h"
 
+#ifndef PL_SEGPROF
+#define PL_SEGPROF 0   /* timing experiments only: s_memtime stamps inside the chain loop (perturbs it) */
+#endif
 #ifndef PL_ABLATE
 #define PL_ABLATE 0   /* timing experiments only (tools/ablate.sh): >0 removes pieces of the chain, results become wrong */
 #endif
@@ -83,6 +86,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x2 lds_uint2;
 typedef __attribute__((address_space(3))) u32x4 lds_uint4;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+/* pointers loaded from the job table are generic; accesses through them would be FLAT instructions, which count in
+ * lgkmcnt and make every wait for an LDS result also wait for outstanding global stores.  Name the address space. */
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+typedef __attribute__((address_space(1))) const uint32_t glb_cu32;
+typedef __attribute__((address_space(1))) const u32x2 glb_cu32x2;
 
 #define PL_TBL_N (PL_NSYM + 64)   /* 256 bins + 64 per-lane dummy slots */
 
@@ -98,6 +106,7 @@ struct RowCtx {
     int s;
     float rq, rbleed, r29;
     uint32_t slow;            /* out: pixels that took the exact-repair slow path        */
+    unsigned long long seg[4];/* out (PL_SEGPROF): cycles in head+gather | reductions | check | tail */
 };
 
 __device__ __forceinline__ int med3_i32(int v, int lo, int hi)
@@ -143,9 +152,9 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
     const int filt_id = PAIR ? 2 * half : MODE;           /* which candidate filter this lane works for */
     const uint32_t bpp = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.bpp);
     const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.W);
-    const uint32_t *const row = k.row, *const nabove = k.nabove;
-    const uint2 *const err0 = k.err0;
-    uint32_t *const outp = reinterpret_cast<uint32_t *>(k.cand + (size_t)filt_id * W);
+    glb_cu32 *const row = (glb_cu32 *)k.row, *const nabove = (glb_cu32 *)k.nabove;
+    glb_cu32x2 *const err0 = (glb_cu32x2 *)k.err0;
+    glb_u32 *const outp = (glb_u32 *)(k.cand + (size_t)filt_id * W);
     const bool active = (uint32_t)c < bpp;
     const int s = __builtin_amdgcn_readfirstlane(k.s), q = s + 1;
     const int nc = NCT ? NCT : (q + GL - 1) / GL;
@@ -158,8 +167,14 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
     const uint32_t inc = upd ? 1u : 0u;
     const int dummy = PL_NSYM + lane;
     const bool chk = active && jl < c && jl < 3;        /* lane (c, k<c) checks channel k's bump against channel c */
+    /* the same facts as sign/bit masks, so that the per-pixel test stays in the VALU: a VALU-written lane mask that
+     * is read by the SALU costs ~16-28 cycles on gfx950 (profiles/r01_ubench_mask_traffic.txt) */
+    const int nochk_neg = chk ? 0 : (int)0x80000000;    /* forces "no conflict" in lanes that do not check            */
+    const int inact_neg = active ? 0 : (int)0x80000000; /* forces "in range" in lanes of unused channel rows          */
+    const int upd_and = upd ? 255 : 0, upd_or = upd ? 0 : dummy;
     const int chk_src = (16 * jl + 8 * half) * 4;       /* ds_bpermute byte address of a lane of group (k=jl)      */
     uint32_t slow = 0;
+    unsigned long long seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0, tprev = PL_SEGPROF ? __builtin_readcyclecounter() : 0;
 
     int left = 0, rem = 0, thr_prev = 0, thr_cur = 0;
 
@@ -171,7 +186,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             const uint32_t o = ok ? row[xl] : 0u;
             const uint32_t a = (ok && nabove) ? nabove[xl] : 0u;
             const uint32_t d = (ok && nabove && xl) ? nabove[xl - 1] : 0u;
-            const uint2 e = ok ? err0[xl] : make_uint2(0u, 0u);
+            const u32x2 e = ok ? err0[xl] : (u32x2){ 0u, 0u };
             const bool alpha0 = TR && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
@@ -201,9 +216,12 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         for (int g = 0; g < n; g += GL) {
         const int m = min(GL, n - g);
         uint32_t cap = 0;
+#pragma unroll 2
         for (int ii = 0; ii < m; ii++) {
             const int i = g + ii;
             const u32x4 rn = R[(((i + 1) & 63) * 4 + c) * 2 + half];   /* prefetch the next pixel's record */
+            unsigned long long tA = 0, tC = 0, tD = 0, tE = 0;
+            if (PL_SEGPROF) { tA = __builtin_readcyclecounter(); seg3 += tA - tprev; }
 
             /* ---- uniform per group: optimize_state.c:157-210 ---- */
             int osym, lo, predraw, filt;
@@ -252,6 +270,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
                     kk[t] = e[t].y + ((jj[t] == josym) ? 256u : 0u) + (uint32_t)(256 - jj[t]);
                     hm = max(hm, e[t].x);
                 }
+                if (PL_SEGPROF) { asm volatile("" : "+v"(hm)); tC = __builtin_readcyclecounter(); seg0 += tC - tA; }
                 Hwin = PL_ABLATE >= 4 ? hm : groupmax_u32<GL>(hm);
                 uint32_t km = 0;
 #pragma unroll
@@ -269,6 +288,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
                 }
                 K = groupmax_u32<GL>(km);
             }
+            if (PL_SEGPROF) { asm volatile("" : "+v"(K)); tD = __builtin_readcyclecounter(); seg1 += tD - tC; }
             int jwin = (int)((0u - K) & 255u);          /* K-1 = rank<<9 | flag<<8 | 255-j */
             int vwin = vmin + jwin;
 
@@ -283,11 +303,18 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             int diff = filt - vwin;
             if (WRAP) diff = pl_sext16(diff);
             if (TR) diff = tr ? 0 : diff;
-            const uint32_t le = PL_ABLATE >= 2 ? 0u : LUT[(diff + 256) & 511];
+            uint32_t le = PL_ABLATE >= 2 ? 0u : LUT[(diff + 256) & 511];
             int remv, thrv;
+            /* both LDS results are consumed here: keeps the table read ahead of the branch (one wait for the two) */
+            int sv2 = sv;
+            asm volatile("" : "+v"(le), "+v"(sv2));
 
-            const int tt = (sv - vmin) & 255;
-            const bool bad = PL_ABLATE >= 1 ? false : ((chk && tt <= span && tt != jwin) | (active && (uint32_t)(diff + 255) > 510u));
+            /* bad  <=>  (checking lane: channel k's winner lies in my band and is not my winner) or |diff| > 255.
+             * z >= 0 <=> conflict, w >= 0 <=> table index out of range; one compare, one branch. */
+            const int tt = (sv2 - vmin) & 255;
+            const int z = ((tt != jwin) ? span - tt : -1) | nochk_neg;
+            const int w = (max(diff, -diff) - 256) | inact_neg;
+            const bool bad = PL_ABLATE >= 1 ? false : ((z & w) >= 0);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
                 /* exact repair in channel order: channel cp chose bin sb and bumped it to sH */
                 slow++;
@@ -327,12 +354,13 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
                 remv = pl_sext16((int)le);
                 thrv = (int)le >> 16;
             }
+            if (PL_SEGPROF) { asm volatile("" : "+v"(remv), "+v"(thrv)); tE = __builtin_readcyclecounter(); seg2 += tE - tD; tprev = tE; }
             thr_prev = thr_cur;
             thr_cur = thrv;
             rem = remv;
             left = back;
             /* histogram bump without touching EXEC: non-owner lanes add 0 to a private dummy slot */
-            if (PL_ABLATE < 6) __hip_atomic_fetch_add((lds_u32 *)&T[upd ? (vwin & 255) : dummy], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (PL_ABLATE < 6) __hip_atomic_fetch_add((lds_u32 *)&T[(vwin & upd_and) | upd_or], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             /* output capture: lane jl of the group keeps pixel ii; stored GL pixels at a time */
             const uint32_t packed = (uint32_t)back | ((uint32_t)diff << 8);
             cap = (jl == ii) ? packed : cap;
@@ -342,6 +370,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         }
     }
     k.slow = slow;
+    k.seg[0] = seg0; k.seg[1] = seg1; k.seg[2] = seg2; k.seg[3] = seg3;
 }
 
 template <int MODE, bool TR, bool WRAP>
@@ -463,7 +492,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0;
-    unsigned long long chain_cycles = 0;
+    unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
     int status = 0;
     for (uint32_t y = 0; y < H && !status; y++) {
         const bool adaptive = !j.row_filters || y == 0;   /* pngloss_image.c:210 */
@@ -497,6 +526,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 }
                 chain_cycles += __builtin_readcyclecounter() - t0;
                 slow_px += k.slow;
+                if (PL_SEGPROF) for (int q = 0; q < 4; q++) segs[q] += k.seg[q];
             }
             __syncthreads();   /* candidate rows (global, same CU) and histograms (LDS) complete and visible */
             /* post pass: one wave per candidate */
@@ -574,6 +604,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     if (lane == 0 && wave < 4) {
         j.result[8 + wave] = (int32_t)(chain_cycles >> 10);
         j.result[12 + wave] = (int32_t)slow_px;
+        if (PL_SEGPROF) for (int q = 0; q < 4; q++) j.result[16 + wave * 4 + q] = (int32_t)(segs[q] >> 10);
     }
     if (tid == 0) {
         j.result[0] = status;

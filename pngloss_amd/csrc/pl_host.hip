@@ -61,7 +61,7 @@ WsLayout image_ws(uint32_t width)
     l.err1 = take(sizeof(uint2) * (size_t)width);
     l.old_above = take(sizeof(uint32_t) * (size_t)width);
     l.final_hist = take(sizeof(uint32_t) * PL_NSYM);
-    l.result = take(sizeof(int32_t) * 16);
+    l.result = take(sizeof(int32_t) * 32);
     l.total = o;
     return l;
 }
@@ -172,12 +172,16 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
     ctx->total_ms = ms;
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < ctx->n_last; i++) {
-        int32_t r[16] = { 0 };
+        int32_t r[32] = { 0 };
         PL_CHECK(hipMemcpy(r, ctx->h_jobs[i].result, sizeof r, hipMemcpyDeviceToHost));
         if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4] };
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
             std::fprintf(stderr, "pngloss_hip: image %zu: chain kcycles per wave %d %d %d %d, repaired pixels %d %d %d %d, engine %.3f ms\n", i,
                          r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15], ctx->engine_ms);
+        if (std::getenv("PNGLOSS_HIP_DEBUG") && r[16])
+            for (int w = 0; w < 4; w++)
+                std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,
+                             r[16 + 4 * w], r[17 + 4 * w], r[18 + 4 * w], r[19 + 4 * w]);
         if (r[0]) {
             std::fprintf(stderr, "pngloss_hip: image %zu: no acceptable filter row (device status %d)\n", i, r[0]);
             worst = PNGLOSS_INTERNAL_ABORT;
