@@ -1,0 +1,82 @@
+"""GPU drop-in test: the reference's UNMODIFIED command-line program (pngloss.c, pngloss_opts.c, rwpng.c compiled in
+place by oracle/Makefile) linked against libpngloss_hip.so instead of its own hot-path sources must write exactly the
+files the all-reference build writes -- same pixels, same per-row filter bytes, same PNG bytes (both use the same libpng).
+Covers BASELINE.json configs[0] (suite/david.png through the CLI) and the web front-end contract
+(`pngloss -sN -bN --strip -`, website/pnglossapi.go:543-556)."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+REF_CLI = os.path.join(U.ROOT, "oracle", "_ref", "pngloss_ref_cli")
+HIP_CLI = os.path.join(U.ROOT, "oracle", "_ref", "pngloss_hip_cli")
+needs_cli = pytest.mark.skipif(not (os.path.exists(REF_CLI) and os.path.exists(HIP_CLI)),
+                               reason="oracle/_ref CLI builds absent (they are built where /root/reference exists)")
+
+
+def _write_png(path, rgba):
+    from PIL import Image
+    Image.fromarray(rgba, "RGBA").save(path)
+
+
+def _idat_filter_bytes(png_bytes, width, height):
+    """Filter type byte of every scanline + colour type, straight from the PNG stream."""
+    pos, idat, ctype, depth = 8, b"", None, None
+    while pos < len(png_bytes):
+        n = int.from_bytes(png_bytes[pos:pos + 4], "big")
+        kind = png_bytes[pos + 4:pos + 8]
+        data = png_bytes[pos + 8:pos + 8 + n]
+        if kind == b"IHDR":
+            depth, ctype = data[8], data[9]
+        if kind == b"IDAT":
+            idat += data
+        pos += 12 + n
+    raw = zlib.decompress(idat)
+    channels = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
+    stride = 1 + width * channels * depth // 8
+    return bytes(raw[y * stride] for y in range(height)), ctype
+
+
+@needs_cli
+@pytest.mark.parametrize("name", ["david", "rose", "tux"])
+def test_reference_cli_on_our_library_writes_identical_files(tmp_path, name):
+    g = U.load_npz("suite_small.npz")
+    src = str(tmp_path / f"{name}.png")
+    _write_png(src, g[name + "/in"])
+    outs = {}
+    for tag, exe in (("ref", REF_CLI), ("hip", HIP_CLI)):
+        out = str(tmp_path / f"{name}-{tag}.png")
+        r = subprocess.run([exe, "-f", "-s", "19", "-b", "2", "-o", out, src], capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-500:]
+        outs[tag] = open(out, "rb").read()
+    assert outs["hip"] == outs["ref"]
+    # and the file really carries the golden pixels and the golden per-row filter choices
+    from PIL import Image
+    import io
+    h, w = g[name + "/in"].shape[:2]
+    decoded = np.array(Image.open(io.BytesIO(outs["hip"])).convert("RGBA"))
+    assert np.array_equal(decoded, g[name + "/out"])
+    filt, _ = _idat_filter_bytes(outs["hip"], w, h)
+    want = bytes({0x08: 0, 0x10: 1, 0x20: 2, 0x40: 3, 0x80: 4}[int(v)] for v in g[name + "/filters"])
+    assert filt[1:] == want[1:]          # row 0 is written with PNG_ALL_FILTERS by rwpng.c:488-490 ...
+    assert filt[0] == want[0]            # ... and libpng's heuristic picks what adaptive_filter_for_rows predicted
+
+
+@needs_cli
+def test_web_frontend_contract_stdin_stdout(tmp_path):
+    import pngloss_amd as P
+    src = str(tmp_path / "in.png")
+    _write_png(src, P.synth_rgba(120, 50, 5, 2))
+    data = open(src, "rb").read()
+    res = {}
+    for tag, exe in (("ref", REF_CLI), ("hip", HIP_CLI)):
+        r = subprocess.run([exe, "-s20", "-b2", "--strip", "-"], input=data, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-500:]
+        res[tag] = r.stdout
+    assert res["hip"] == res["ref"] and res["hip"][:8] == b"\x89PNG\r\n\x1a\n"
