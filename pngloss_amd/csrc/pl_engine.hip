@@ -216,7 +216,6 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         for (int g = 0; g < n; g += GL) {
         const int m = min(GL, n - g);
         uint32_t cap = 0;
-#pragma unroll 2
         for (int ii = 0; ii < m; ii++) {
             const int i = g + ii;
             const u32x4 rn = R[(((i + 1) & 63) * 4 + c) * 2 + half];   /* prefetch the next pixel's record */
@@ -378,11 +377,15 @@ __device__ __forceinline__ void chain_dispatch_nc(RowCtx &k, int lane)
 {
     const int q = k.s + 1;
     const int per_lane = (q + (MODE == 5 ? 7 : 15)) / (MODE == 5 ? 8 : 16);
-    if (per_lane <= 1) chain_row<MODE, 1, TR, WRAP>(k, lane);
-    else if (per_lane == 2) chain_row<MODE, 2, TR, WRAP>(k, lane);
-    else if (MODE == 5 && per_lane == 3) chain_row<MODE, 3, TR, WRAP>(k, lane);
-    else if (MODE == 5 && per_lane == 4) chain_row<MODE, 4, TR, WRAP>(k, lane);
-    else chain_row<MODE, 0, TR, WRAP>(k, lane);
+    switch (per_lane) {
+    case 1: chain_row<MODE, 1, TR, WRAP>(k, lane); break;   /* s <= 15 (paired wave: s <= 7)  */
+    case 2: chain_row<MODE, 2, TR, WRAP>(k, lane); break;   /* s <= 31 (<= 15)                */
+    case 3: chain_row<MODE, 3, TR, WRAP>(k, lane); break;   /* s <= 47 (<= 23): the default s=19 pairs here */
+    case 4: chain_row<MODE, 4, TR, WRAP>(k, lane); break;   /* s <= 63 (<= 31)                */
+    case 5: chain_row<MODE, 5, TR, WRAP>(k, lane); break;
+    case 6: chain_row<MODE, 6, TR, WRAP>(k, lane); break;   /* s <= 95 (<= 47)                */
+    default: chain_row<MODE, 0, TR, WRAP>(k, lane); break;  /* generic two-sweep loop         */
+    }
 }
 
 template <int MODE>
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
 {
     __shared__ uint2 tbl[PL_NFILT][PL_NSYM + 64]; /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
     __shared__ uint32_t Hc[PL_NSYM];             /* committed symbol_frequency                                        */
-    __shared__ uint4 rec[4][64][4][2];           /* per chain-wave chunk records (two filters in the paired wave)      */
+    __shared__ uint4 rec[PL_NFILT][64][4][2];    /* per chain-wave chunk records (two filters in the paired wave)      */
     __shared__ uint32_t split_lut[512];          /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255     */
     __shared__ uint32_t big_err;                 /* some |incoming error| of the coming row exceeds 8000 (see WRAP)    */
     __shared__ unsigned long long costs[PL_NFILT];
@@ -505,7 +508,10 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             __syncthreads();
             /* chain phase: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
              * waves 1..3 run sub, average, paeth; wave 4 only takes part in the data-parallel passes */
-            if (wave < 4) {
+            /* wide bands (s > 47) would need > 6 candidates per lane in the paired wave: there the five chains run as
+             * five waves instead (wave 4 = 'up'), accepting that two of them share a SIMD */
+            const bool paired = s + 1 <= 48;
+            if (wave < 4 || !paired) {
                 RowCtx k;
                 k.row = j.img + (size_t)y * W;
                 k.nabove = y ? k.row - W : nullptr;
@@ -519,10 +525,11 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 k.slow = 0;
                 const unsigned long long t0 = __builtin_readcyclecounter();
                 switch (wave) {
-                case 0: chain_dispatch<5>(k, lane, wrap); break;
+                case 0: if (paired) chain_dispatch<5>(k, lane, wrap); else chain_dispatch<0>(k, lane, wrap); break;
                 case 1: chain_dispatch<1>(k, lane, wrap); break;
                 case 2: chain_dispatch<3>(k, lane, wrap); break;
-                default: chain_dispatch<4>(k, lane, wrap); break;
+                case 3: chain_dispatch<4>(k, lane, wrap); break;
+                default: chain_dispatch<2>(k, lane, wrap); break;
                 }
                 chain_cycles += __builtin_readcyclecounter() - t0;
                 slow_px += k.slow;
