@@ -117,6 +117,18 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
                                unsigned quantization_strength, long bleed_divider, void *stream,
                                pngloss_hip_result *results);
 
+/* The same for images in HOST memory (the batch form of optimize_with_rows: this is what a multi-file CLI loop calls
+ * instead of pngloss.c:173-208's one-file-at-a-time loop).  rgba: width*height*4 contiguous bytes, rewritten in place;
+ * row_filters: height bytes or NULL.  Uploads, runs one batch, downloads; synchronous. */
+typedef struct {
+    unsigned char *rgba;
+    unsigned char *row_filters;
+    uint32_t width, height;
+} pngloss_hip_host_image;
+
+int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                    unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results);
+
 /* Duration in milliseconds of the row-engine kernel of the last finished batch, measured with hipEvents recorded
  * on the launch stream immediately around that kernel (what bench.py's roofline block reports).  < 0 if none. */
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx);

@@ -1,0 +1,432 @@
+/*
+ * pngloss.c -- `pngloss [options] -- pngfile [pngfile ...]` on an MI355X.
+ *
+ * Same command line, messages and exit codes as the reference tool (/root/reference/src/pngloss.c:28-165 usage and
+ * argument checks, src/pngloss_opts.c:22-135 option table), but the per-file loop of pngloss_main_internal
+ * (pngloss.c:168-223), which handles one file at a time, is replaced by a three-stage batch:
+ *
+ *     decode all inputs (libpng, worker threads)  ->  ONE batched call into libpngloss_hip.so  ->  encode (threads)
+ *
+ * so that a GPU with 256 compute units works on up to 256 images at once (one workgroup per image).  Files are
+ * processed in windows so that memory stays bounded.  Per-file semantics are unchanged: output naming (--ext / -o),
+ * the overwrite rule, temp-file + atomic rename, --skip-if-larger, --strip, stdin/stdout with "-", and the exit code
+ * is the error of the last failing file.  Verbose messages are buffered per file and printed in file order.
+ */
+#include <getopt.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "../../include/pngloss_hip.h"
+#include "rwpng.h"
+
+#define PNGLOSS_VERSION "1.0.1-mi355x"
+#define WINDOW_FILES 256                 /* images per GPU batch (one workgroup each)              */
+
+struct options {
+    const char *extension, *output_path;
+    char *const *files;
+    unsigned long strength, bleed;
+    unsigned num_files;
+    bool from_stdin, to_stdout, force, skip_if_larger, strip, help, version, missing, verbose;
+};
+
+static const char usage_text[] =
+    "usage:  pngloss [options] -- pngfile [pngfile ...]\n"
+    "        pngloss [options] - >stdout <stdin\n\n"
+    "options:\n"
+    "  -s, --strength 19 how much quality to sacrifice, from 0 to 100 (default 19)\n"
+    "  -b, --bleed 2     bleed divider, from 1 (full dithering) to 32767 (none)\n"
+    "  -f, --force       overwrite existing output files\n"
+    "  -o, --output file destination file path to use instead of --ext\n"
+    "  -v, --verbose     print status messages\n"
+    "  -q, --quiet       don't print status messages (default, overrides -v)\n"
+    "  -V, --version     print version number\n"
+    "  --skip-if-larger  only save converted files if they're smaller than original\n"
+    "  --ext new.png     set custom suffix/extension for output filenames\n"
+    "  --strip           remove optional metadata (default on Mac)\n"
+    "\n"
+    "Lossily compresses PNGs by using more compressible colors that are close enough to the\n"
+    "original values; the filter+quantise pass runs on the GPU (all files of a call as one batch).\n"
+    "Output names end in \"-loss.png\" or your --ext; with \"-\" the image goes stdin -> stdout.\n"
+    "Existing outputs are skipped unless --force is given.\n";
+
+/* ------------------------------------------------------------------------------------------- options */
+
+enum { OPT_EXT = 256, OPT_NO_FORCE, OPT_SKIP_LARGER, OPT_STRIP };
+
+static bool parse_number(const char *text, unsigned long *out)
+{
+    char *end;
+    unsigned long v = strtoul(text, &end, 10);
+    if (end == text || *end) return false;
+    *out = v;
+    return true;
+}
+
+static pngloss_error parse_options(int argc, char **argv, struct options *o)
+{
+    static const struct option table[] = {
+        { "strength", required_argument, NULL, 's' }, { "bleed", required_argument, NULL, 'b' },
+        { "force", no_argument, NULL, 'f' },          { "no-force", no_argument, NULL, OPT_NO_FORCE },
+        { "output", required_argument, NULL, 'o' },   { "ext", required_argument, NULL, OPT_EXT },
+        { "verbose", no_argument, NULL, 'v' },        { "quiet", no_argument, NULL, 'q' },
+        { "skip-if-larger", no_argument, NULL, OPT_SKIP_LARGER }, { "strip", no_argument, NULL, OPT_STRIP },
+        { "version", no_argument, NULL, 'V' },        { "help", no_argument, NULL, 'h' },
+        { NULL, 0, NULL, 0 },
+    };
+    for (int c; (c = getopt_long(argc, argv, "vqfo:Vhs:b:", table, NULL)) != -1;) {
+        switch (c) {
+        case 'v': o->verbose = true; break;
+        case 'q': o->verbose = false; break;
+        case 'f': o->force = true; break;
+        case OPT_NO_FORCE: o->force = false; break;
+        case OPT_EXT: o->extension = optarg; break;
+        case OPT_SKIP_LARGER: o->skip_if_larger = true; break;
+        case OPT_STRIP: o->strip = true; break;
+        case 'h': o->help = true; break;
+        case 'V': o->version = true; break;
+        case 'o':
+            if (o->output_path) { fputs("--output option can be used only once\n", stderr); return INVALID_ARGUMENT; }
+            if (strcmp(optarg, "-") == 0) o->to_stdout = true;
+            else o->output_path = optarg;
+            break;
+        case 's':
+            if (!parse_number(optarg, &o->strength)) { fputs("-s, --strength requires a numeric argument\n", stderr); return INVALID_ARGUMENT; }
+            break;
+        case 'b':
+            if (!parse_number(optarg, &o->bleed)) { fputs("-b, --bleed requires a numeric argument\n", stderr); return INVALID_ARGUMENT; }
+            break;
+        default: return INVALID_ARGUMENT;
+        }
+    }
+    if (optind < argc) {
+        int first = optind;
+        if (first == argc - 1 && strcmp(argv[first], "-") == 0) {   /* lone "-": stdin -> stdout (or -> --output) */
+            o->from_stdin = true;
+            o->to_stdout = !o->output_path;
+        }
+        o->num_files = (unsigned)(argc - first);
+        o->files = argv + first;
+    } else if (optind <= 1) {
+        o->missing = true;
+    }
+    return SUCCESS;
+}
+
+static void print_version_banner(FILE *f)
+{
+    fprintf(f, "pngloss, %s, filter+quantise path on AMD MI355X (%s).\n", PNGLOSS_VERSION, pngloss_hip_version());
+    rwpng_version_info(f);
+    fputs("\n", f);
+}
+
+/* ------------------------------------------------------------------------------------------- per-file job */
+
+struct job {
+    const char *in_name;      /* "stdin" for the pipe */
+    char *out_name;           /* malloc'ed unless it aliases options.output_path */
+    bool own_out_name;
+    pngloss_error status;
+    png24_image in, out;
+    unsigned char *filters;
+    char *log;                /* buffered stderr text */
+    size_t log_len;
+    pngloss_hip_result gpu;
+};
+
+static void say(struct job *j, const char *fmt, ...)
+{
+    char line[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    if (n <= 0) return;
+    if ((size_t)n >= sizeof line) n = (int)sizeof line - 1;
+    char *grown = realloc(j->log, j->log_len + (size_t)n + 1);
+    if (!grown) return;
+    memcpy(grown + j->log_len, line, (size_t)n + 1);
+    j->log = grown;
+    j->log_len += (size_t)n;
+}
+
+static void flush_log(struct job *j)
+{
+    if (j->log) fputs(j->log, stderr);
+    free(j->log);
+    j->log = NULL;
+    j->log_len = 0;
+}
+
+static const char *leaf(const char *path)
+{
+    const char *s = strrchr(path, '/');
+    return s ? s + 1 : path;
+}
+
+static char *with_extension(const char *name, const char *ext)
+{
+    size_t n = strlen(name);
+    char *out = malloc(n + strlen(ext) + 1);
+    if (!out) return NULL;
+    memcpy(out, name, n + 1);
+    if (n > 4 && (memcmp(out + n - 4, ".png", 4) == 0 || memcmp(out + n - 4, ".PNG", 4) == 0)) n -= 4;
+    strcpy(out + n, ext);
+    return out;
+}
+
+static bool exists(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (f) fclose(f);
+    return f != NULL;
+}
+
+/* stage 1: open + decode + private output copy (pngloss.c:433-484 of the reference) */
+static void decode_job(struct job *j, const struct options *o)
+{
+    if (j->status != SUCCESS) return;
+    if (o->verbose) say(j, "%s:\n", j->in_name);
+    FILE *f = o->from_stdin ? stdin : fopen(j->in_name, "rb");
+    if (!f) {
+        say(j, "  error: cannot open %s for reading\n", j->in_name);
+        j->status = READ_ERROR;
+        return;
+    }
+    pngloss_error rc = rwpng_read_image24(f, &j->in, o->strip, o->verbose);
+    if (!o->from_stdin) fclose(f);
+    if (rc != SUCCESS) {
+        say(j, "  error: cannot decode image %s\n", o->from_stdin ? "from stdin" : leaf(j->in_name));
+        j->status = rc;
+        return;
+    }
+    if (o->verbose) {
+        say(j, "  read %luKB file\n", (unsigned long)((j->in.file_size + 500UL) / 1000UL));
+        if (j->in.input_color == RWPNG_SRGB) say(j, "  passing sRGB tag from the input\n");
+        else if (j->in.gamma != 0.45455) say(j, "  converted image from gamma %2.1f to gamma 2.2\n", 1.0 / j->in.gamma);
+    }
+    const size_t W = j->in.width, H = j->in.height;
+    j->out.width = j->in.width;
+    j->out.height = j->in.height;
+    j->out.gamma = j->in.gamma;
+    j->out.output_color = j->in.output_color;
+    const size_t bytes = W * H * 4;
+    j->out.rgba_data = malloc(bytes > 0 ? bytes : 1);
+    j->out.row_pointers = malloc((H ? H : 1) * sizeof(unsigned char *));
+    j->filters = malloc(H ? H : 1);
+    if (!j->out.rgba_data || !j->out.row_pointers || !j->filters) { j->status = OUT_OF_MEMORY_ERROR; return; }
+    for (size_t y = 0; y < H; y++) {
+        j->out.row_pointers[y] = j->out.rgba_data + y * W * 4;
+        memcpy(j->out.row_pointers[y], j->in.row_pointers[y], W * 4);
+    }
+}
+
+/* stage 3: encode to "<out>.tmp", rename over the destination (pngloss.c:379-431 of the reference) */
+static pngloss_error encode_to(struct job *j, png24_image *img, unsigned char *filters, const struct options *o)
+{
+    FILE *f;
+    char *tmp = NULL;
+    if (o->to_stdout) {
+        f = stdout;
+        if (o->verbose) say(j, "  writing compressed image to stdout\n");
+    } else {
+        tmp = malloc(strlen(j->out_name) + 5);
+        if (!tmp) return OUT_OF_MEMORY_ERROR;
+        sprintf(tmp, "%s.tmp", j->out_name);
+        f = fopen(tmp, "wb");
+        if (!f) {
+            say(j, "  error: cannot open '%s' for writing\n", tmp);
+            free(tmp);
+            return CANT_WRITE_ERROR;
+        }
+        if (o->verbose) say(j, "  writing compressed image as %s\n", leaf(j->out_name));
+    }
+    pngloss_error rc = rwpng_write_image24(f, img, filters);
+    if (!o->to_stdout) {
+        fclose(f);
+        if (rc == SUCCESS && rename(tmp, j->out_name) != 0) rc = CANT_WRITE_ERROR;
+        if (rc != SUCCESS) unlink(tmp);
+    }
+    free(tmp);
+    if (rc != SUCCESS && rc != TOO_LARGE_FILE)
+        say(j, "  error: failed writing image to %s (%d)\n", o->to_stdout ? "stdout" : j->out_name, (int)rc);
+    return rc;
+}
+
+static void encode_job(struct job *j, const struct options *o)
+{
+    if (j->status != SUCCESS) return;
+    if (o->verbose) say(j, "  compression complete\n  used %u unique symbols\n", j->gpu.unique_symbols);
+    if (o->skip_if_larger) j->out.maximum_file_size = j->in.file_size - 1;
+    j->out.chunks = j->in.chunks;          /* metadata travels to the output */
+    j->in.chunks = NULL;
+    pngloss_error rc = encode_to(j, &j->out, j->filters, o);
+    if (o->verbose) {
+        if (rc == SUCCESS) {
+            say(j, "  wrote %luKB file (%.1f%% of original)\n", (unsigned long)((j->out.file_size + 500UL) / 1000UL),
+                100.0f * (float)j->out.file_size / (float)j->in.file_size);
+            if (j->out.metadata_size > 0) say(j, "  copied %dKB of additional PNG metadata\n", (int)(j->out.metadata_size + 500) / 1000);
+        } else if (rc == TOO_LARGE_FILE) {
+            say(j, "  file exceeded maximum size of %luKB\n", (unsigned long)((j->out.maximum_file_size + 500UL) / 1000UL));
+        }
+    }
+    if (o->to_stdout && (rc == TOO_LARGE_FILE || rc == TOO_LOW_QUALITY)) {
+        /* never leave a pipe empty: fall back to the decoded original */
+        pngloss_error again = encode_to(j, &j->in, NULL, o);
+        if (again != SUCCESS) rc = again;
+    }
+    j->status = rc;
+}
+
+/* ------------------------------------------------------------------------------------------- tiny parallel-for */
+
+struct crew { struct job *jobs; size_t n, next; const struct options *o; void (*work)(struct job *, const struct options *); pthread_mutex_t mu; };
+
+static void *crew_member(void *arg)
+{
+    struct crew *c = arg;
+    for (;;) {
+        pthread_mutex_lock(&c->mu);
+        size_t i = c->next++;
+        pthread_mutex_unlock(&c->mu);
+        if (i >= c->n) return NULL;
+        c->work(&c->jobs[i], c->o);
+    }
+}
+
+static void for_each_job(struct job *jobs, size_t n, const struct options *o, void (*work)(struct job *, const struct options *))
+{
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    size_t threads = cores > 1 ? (size_t)cores : 1;
+    if (threads > n) threads = n;
+    if (threads > 64) threads = 64;
+    if (o->from_stdin || o->to_stdout) threads = 1;
+    struct crew c = { jobs, n, 0, o, work, PTHREAD_MUTEX_INITIALIZER };
+    if (threads <= 1) { crew_member(&c); return; }
+    pthread_t tid[64];
+    size_t started = 0;
+    for (; started < threads; started++)
+        if (pthread_create(&tid[started], NULL, crew_member, &c) != 0) break;
+    if (!started) crew_member(&c);
+    for (size_t t = 0; t < started; t++) pthread_join(tid[t], NULL);
+}
+
+/* ------------------------------------------------------------------------------------------- the batch driver */
+
+static pngloss_error run_window(struct job *jobs, size_t n, const struct options *o, pngloss_hip_ctx **ctx)
+{
+    for_each_job(jobs, n, o, decode_job);
+
+    /* stage 2: every decoded image of the window in one GPU batch */
+    pngloss_hip_host_image *imgs = calloc(n ? n : 1, sizeof *imgs);
+    pngloss_hip_result *res = calloc(n ? n : 1, sizeof *res);
+    size_t *who = calloc(n ? n : 1, sizeof *who), m = 0;
+    if (!imgs || !res || !who) { free(imgs); free(res); free(who); return OUT_OF_MEMORY_ERROR; }
+    for (size_t i = 0; i < n; i++)
+        if (jobs[i].status == SUCCESS) {
+            imgs[m] = (pngloss_hip_host_image){ jobs[i].out.rgba_data, jobs[i].filters, jobs[i].out.width, jobs[i].out.height };
+            who[m++] = i;
+        }
+    if (m) {
+        if (!*ctx) *ctx = pngloss_hip_create(-1);
+        int rc = *ctx ? pngloss_hip_optimize_batch_host(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res) : PNGLOSS_HIP_ERROR;
+        for (size_t k = 0; k < m; k++) {
+            jobs[who[k]].gpu = res[k];
+            if (rc != PNGLOSS_SUCCESS) {
+                /* unlike the reference (pngloss.c:266 ignores the return value) a failed optimisation is an error:
+                 * there is no CPU path to fall back to, and writing an unoptimised file silently would be wrong */
+                say(&jobs[who[k]], "  error: GPU optimisation failed (%d)\n", rc);
+                jobs[who[k]].status = (pngloss_error)rc;
+            }
+        }
+    }
+    free(imgs); free(res); free(who);
+
+    for_each_job(jobs, n, o, encode_job);
+    return SUCCESS;
+}
+
+int main(int argc, char **argv)
+{
+    struct options o;
+    memset(&o, 0, sizeof o);
+    o.strength = 19;
+    o.bleed = 2;
+    pngloss_error rc = parse_options(argc, argv, &o);
+    if (rc != SUCCESS) return rc;
+    if (o.version) { puts(PNGLOSS_VERSION); return SUCCESS; }
+    if (o.missing) { print_version_banner(stderr); fputs(usage_text, stderr); return MISSING_ARGUMENT; }
+    if (o.help) { print_version_banner(stdout); fputs(usage_text, stdout); return SUCCESS; }
+    if (o.strength > 255) { fputs("Must specify a strength in the range 0-255.\n", stderr); return INVALID_ARGUMENT; }
+    if (o.bleed < 1 || o.bleed > 32767) { fputs("Must specify a bleed divider in the range 1-32767.\n", stderr); return INVALID_ARGUMENT; }
+    if (o.extension && o.output_path) { fputs("--ext and --output options can't be used at the same time\n", stderr); return INVALID_ARGUMENT; }
+    if (!o.extension) o.extension = "-loss.png";
+    if (o.output_path && o.num_files != 1) {
+        fputs("  error: Only one input file is allowed when --output is used. This error also happens when filenames with spaces are not in quotes.\n", stderr);
+        return INVALID_ARGUMENT;
+    }
+    if (o.to_stdout && !o.from_stdin && o.num_files != 1) {
+        fputs("  error: Only one input file is allowed when using the special output path \"-\" to write to stdout. This error also happens when filenames with spaces are not in quotes.\n", stderr);
+        return INVALID_ARGUMENT;
+    }
+    if (!o.num_files && !o.from_stdin) {
+        fputs("No input files specified.\n", stderr);
+        if (o.verbose) print_version_banner(stderr);
+        fputs(usage_text, stderr);
+        return MISSING_ARGUMENT;
+    }
+
+    const size_t total = o.num_files;
+    struct job *jobs = calloc(total ? total : 1, sizeof *jobs);
+    if (!jobs) return OUT_OF_MEMORY_ERROR;
+    for (size_t i = 0; i < total; i++) {
+        struct job *j = &jobs[i];
+        j->in_name = o.from_stdin ? "stdin" : o.files[i];
+        if (!o.to_stdout) {
+            if (o.output_path) j->out_name = (char *)o.output_path;
+            else { j->out_name = with_extension(j->in_name, o.extension); j->own_out_name = true; }
+            if (!j->out_name) j->status = OUT_OF_MEMORY_ERROR;
+            else if (!o.force && exists(j->out_name)) {
+                say(j, "  error: '%s' exists; not overwriting\n", j->out_name);
+                j->status = NOT_OVERWRITING_ERROR;
+            }
+        }
+    }
+
+    pngloss_hip_ctx *ctx = NULL;
+    pngloss_error latest = SUCCESS;
+    unsigned errors = 0, skipped = 0;
+    for (size_t start = 0; start < total;) {
+        /* a window: up to WINDOW_FILES files decoded, optimised as one GPU batch, encoded */
+        size_t n = total - start < WINDOW_FILES ? total - start : WINDOW_FILES;
+        run_window(jobs + start, n, &o, &ctx);
+        for (size_t i = start; i < start + n; i++) {
+            struct job *j = &jobs[i];
+            flush_log(j);
+            if (j->status != SUCCESS) {
+                latest = j->status;
+                if (j->status == TOO_LOW_QUALITY || j->status == TOO_LARGE_FILE) skipped++;
+                else errors++;
+            }
+            rwpng_free_image24(&j->in);
+            rwpng_free_image24(&j->out);
+            free(j->filters);
+            if (j->own_out_name) free(j->out_name);
+        }
+        start += n;
+    }
+    if (ctx) pngloss_hip_destroy(ctx);
+    if (o.verbose) {
+        const unsigned files = (unsigned)total;
+        if (errors) fprintf(stderr, "There were errors compressing %d file%s out of a total of %d file%s.\n", errors, errors == 1 ? "" : "s", files, files == 1 ? "" : "s");
+        if (skipped) fprintf(stderr, "Skipped %d file%s out of a total of %d file%s.\n", skipped, skipped == 1 ? "" : "s", files, files == 1 ? "" : "s");
+        if (!skipped && !errors) fprintf(stderr, "Compressed %d image%s.\n", files, files == 1 ? "" : "s");
+    }
+    free(jobs);
+    return latest;
+}

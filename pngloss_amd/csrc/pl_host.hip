@@ -327,6 +327,44 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
     return finish(ctx, results, n);
 }
 
+int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                    unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results)
+{
+    if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
+    PL_CHECK(hipSetDevice(ctx->device));
+    /* one device arena for the whole batch: [image 0 | filters 0 | image 1 | ...], 256-byte aligned pieces */
+    std::vector<size_t> img_off(n), flt_off(n);
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t px = (size_t)images[i].width * images[i].height;
+        if (px && !images[i].rgba) return PNGLOSS_INVALID_ARGUMENT;
+        img_off[i] = total; total = align_up(total + px * 4, 256);
+        flt_off[i] = total; total = align_up(total + (images[i].row_filters ? images[i].height : 0), 256);
+    }
+    char *arena = nullptr;
+    if (total) PL_CHECK(hipMalloc(reinterpret_cast<void **>(&arena), total));
+    int rc = PNGLOSS_SUCCESS;
+    std::vector<pngloss_hip_image_desc> descs(n);
+    for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
+        const size_t px = (size_t)images[i].width * images[i].height;
+        descs[i] = pngloss_hip_image_desc{ px ? arena + img_off[i] : nullptr,
+                                           (px && images[i].row_filters) ? arena + flt_off[i] : nullptr, images[i].width, images[i].height };
+        if (px && hipMemcpy(arena + img_off[i], images[i].rgba, px * 4, hipMemcpyHostToDevice) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    }
+    if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, nullptr);
+    if (rc == PNGLOSS_SUCCESS) rc = finish(ctx, results, n);
+    for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
+        const size_t px = (size_t)images[i].width * images[i].height;
+        if (!px) continue;
+        if (hipMemcpy(images[i].rgba, arena + img_off[i], px * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+        if (images[i].row_filters &&
+            hipMemcpy(images[i].row_filters, arena + flt_off[i], images[i].height, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    }
+    if (arena) (void)hipFree(arena);
+    if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->engine_ms : -1.0; }
 double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->total_ms : -1.0; }
 

@@ -33,6 +33,10 @@ class ImageDesc(C.Structure):
     _fields_ = [("d_rgba", C.c_void_p), ("d_row_filters", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class HostImage(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("row_filters", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("bytes_per_pixel", C.c_uint32), ("unique_symbols", C.c_uint32),
                 ("retried_rows", C.c_uint32), ("repaired_pixels", C.c_uint32)]
@@ -75,7 +79,7 @@ def synth_lib():
 ABI_SYMBOLS = (
     "optimize_with_rows", "optimize_with_stride", "optimizeForAverageFilter", "optimize_image",
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
-    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
+    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
     "pngloss_hip_last_histogram", "pngloss_hip_version",
 )
 
@@ -105,6 +109,8 @@ def hip_lib():
             lib.pngloss_hip_finish.restype = C.c_int
             lib.pngloss_hip_optimize_batch.argtypes = [C.c_void_p, C.POINTER(ImageDesc), C.c_size_t, C.c_uint, C.c_long, C.c_void_p, C.POINTER(Result)]
             lib.pngloss_hip_optimize_batch.restype = C.c_int
+            lib.pngloss_hip_optimize_batch_host.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result)]
+            lib.pngloss_hip_optimize_batch_host.restype = C.c_int
             lib.pngloss_hip_last_engine_ms.argtypes = [C.c_void_p]
             lib.pngloss_hip_last_engine_ms.restype = C.c_double
             lib.pngloss_hip_last_total_ms.argtypes = [C.c_void_p]
@@ -211,6 +217,18 @@ class HipContext:
     def run(self, images, strength=19, bleed=2, stream=0):
         self.enqueue(images, strength, bleed, stream)
         return self.finish()
+
+    def run_host(self, arrays, strength=19, bleed=2, want_filters=True):
+        """pngloss_hip_optimize_batch_host on a list of (H, W, 4) uint8 arrays.  Returns (outs, filters, results)."""
+        outs = [np.ascontiguousarray(a).copy() for a in arrays]
+        filts = [np.zeros(a.shape[0], np.uint8) if want_filters else None for a in outs]
+        n = len(outs)
+        imgs = (HostImage * max(n, 1))()
+        for i, (a, f) in enumerate(zip(outs, filts)):
+            imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
+        res = (Result * max(n, 1))()
+        _check(self._lib.pngloss_hip_optimize_batch_host(self._ctx, imgs, n, strength, bleed, res), "optimize_batch_host")
+        return outs, filts, [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols) for r in res[:n]]
 
     @property
     def engine_ms(self):

@@ -1,0 +1,37 @@
+/* tests/c/rwpng_copy.c -- test driver for the rwpng surface: decode a PNG to RGBA8 and write it back with a given
+ * per-row filter policy, WITHOUT touching the pixels.  Compiled twice by tests/test_cli_host.py: against our
+ * pngloss_amd/cli/rwpng.c and (where /root/reference exists) against the reference's rwpng.c; both must emit the same
+ * bytes.   usage: rwpng_copy in.png out.png policy strip      policy: -1 = NULL filters, 0..4 = that filter on every row,
+ * 5 = rows cycle none,sub,up,avg,paeth */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "rwpng.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) return 1;
+    const int policy = atoi(argv[3]);
+    const bool strip = atoi(argv[4]) != 0;
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) return 2;
+    png24_image img;
+    memset(&img, 0, sizeof img);
+    pngloss_error rc = rwpng_read_image24(in, &img, strip, false);
+    fclose(in);
+    if (rc) return (int)rc;
+    unsigned char *filters = NULL;
+    static const unsigned char flag[5] = { 0x08, 0x10, 0x20, 0x40, 0x80 };
+    if (policy >= 0) {
+        filters = malloc(img.height ? img.height : 1);
+        for (uint32_t y = 0; y < img.height; y++) filters[y] = flag[policy == 5 ? y % 5 : policy];
+    }
+    FILE *out = fopen(argv[2], "wb");
+    if (!out) return 3;
+    rc = rwpng_write_image24(out, &img, filters);
+    fclose(out);
+    printf("%u %u %zu %zu %d %.5f\n", img.width, img.height, img.file_size, img.metadata_size, (int)img.output_color, img.gamma);
+    free(filters);
+    rwpng_free_image24(&img);
+    return (int)rc;
+}
