@@ -124,6 +124,7 @@ struct PlEngineParams {
 
 hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream);
+int pl_engine_occupancy(void);   /* workgroups of the row engine per CU according to the HIP occupancy query */
 hipError_t pl_launch_finish(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 
 #endif

@@ -93,6 +93,7 @@ typedef __attribute__((address_space(1))) const uint32_t glb_cu32;
 typedef __attribute__((address_space(1))) const u32x2 glb_cu32x2;
 
 #define PL_TBL_N (PL_NSYM + 64)   /* 256 bins + 64 per-lane dummy slots */
+#define PL_CHUNK 32                /* pixels per vector pre-phase; small so that several workgroups fit one CU's LDS */
 
 struct RowCtx {
     const uint32_t *row;      /* original row y (slots)                                  */
@@ -100,7 +101,7 @@ struct RowCtx {
     const uint2 *err0;        /* incoming error for row y                                */
     uint4 *cand;              /* cand[5][W]: per candidate, per pixel: 4 x (byte | diff16<<8) */
     lds_uint2 *tbl;           /* tbl[5][PL_TBL_N] {H, rank<<9} in LDS                    */
-    lds_uint4 *rec;           /* this WAVE's chunk records: [64][4][2]                   */
+    lds_uint4 *rec;           /* this WAVE's chunk records: [PL_CHUNK][4][1 or 2]         */
     lds_u32 *lut;             /* Sierra split table: [diff+256] -> rem | thr<<16, |diff|<=255 */
     uint32_t W, y, bpp;
     int s;
@@ -178,9 +179,10 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
 
     int left = 0, rem = 0, thr_prev = 0, thr_cur = 0;
 
-    for (uint32_t x0 = 0; x0 < W; x0 += 64) {
+    constexpr int RS = PAIR ? 2 : 1;                    /* records per (pixel, channel) */
+    for (uint32_t x0 = 0; x0 < W; x0 += PL_CHUNK) {
         /* ---- vector pre-phase: lane = pixel x0+lane; everything that does not depend on the chain ---- */
-        {
+        if (lane < PL_CHUNK) {
             const uint32_t xl = x0 + lane;
             const bool ok = xl < W;
             const uint32_t o = ok ? row[xl] : 0u;
@@ -199,11 +201,11 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
                     for (int h = 0; h < 2; h++) {
                         const int pred = h ? above : 0;
                         const int osym = pl_sext8(orig - pred);
-                        R[(lane * 4 + cc) * 2 + h] = (u32x4){ (uint32_t)osym, (uint32_t)(osym - orig), (uint32_t)pred | trbit,
+                        R[(lane * 4 + cc) * RS + h] = (u32x4){ (uint32_t)osym, (uint32_t)(osym - orig), (uint32_t)pred | trbit,
                                                               (uint32_t)(WRAP ? e0 : osym + e0) };
                     }
                 } else {
-                    R[(lane * 4 + cc) * 2] = (u32x4){ (uint32_t)orig, (uint32_t)above, (uint32_t)diag | trbit, (uint32_t)e0 };
+                    R[(lane * 4 + cc) * RS] = (u32x4){ (uint32_t)orig, (uint32_t)above, (uint32_t)diag | trbit, (uint32_t)e0 };
                 }
             }
         }
@@ -211,14 +213,14 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const int n = (int)min(64u, W - x0);
-        u32x4 r = R[c * 2 + half];
+        const int n = (int)min((uint32_t)PL_CHUNK, W - x0);
+        u32x4 r = R[c * RS + half];
         for (int g = 0; g < n; g += GL) {
         const int m = min(GL, n - g);
         uint32_t cap = 0;
         for (int ii = 0; ii < m; ii++) {
             const int i = g + ii;
-            const u32x4 rn = R[(((i + 1) & 63) * 4 + c) * 2 + half];   /* prefetch the next pixel's record */
+            const u32x4 rn = R[(((i + 1) & (PL_CHUNK - 1)) * 4 + c) * RS + half];   /* prefetch the next pixel's record */
             unsigned long long tA = 0, tC = 0, tD = 0, tE = 0;
             if (PL_SEGPROF) { tA = __builtin_readcyclecounter(); seg3 += tA - tprev; }
 
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
 {
     __shared__ uint2 tbl[PL_NFILT][PL_NSYM + 64]; /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
     __shared__ uint32_t Hc[PL_NSYM];             /* committed symbol_frequency                                        */
-    __shared__ uint4 rec[PL_NFILT][64][4][2];    /* per chain-wave chunk records (two filters in the paired wave)      */
+    __shared__ uint4 rec[PL_CHUNK * 4 * (2 + 4)]; /* chunk records: wave 0 gets room for two filters, waves 1..4 for one   */
     __shared__ uint32_t split_lut[512];          /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255     */
     __shared__ uint32_t big_err;                 /* some |incoming error| of the coming row exceeds 8000 (see WRAP)    */
     __shared__ unsigned long long costs[PL_NFILT];
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 k.err0 = j.err0;
                 k.cand = j.cand;
                 k.tbl = (lds_uint2 *)&tbl[0][0];
-                k.rec = (lds_uint4 *)&rec[wave][0][0][0];
+                k.rec = (lds_uint4 *)&rec[wave == 0 ? 0 : PL_CHUNK * 4 * (1 + wave)];
                 k.lut = (lds_u32 *)&split_lut[0];
                 k.W = W; k.y = y; k.bpp = bpp; k.s = s;
                 k.rq = recip_up(s + 1); k.rbleed = prm.rbleed; k.r29 = r29;
@@ -620,6 +622,13 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         j.result[3] = (int32_t)retried;
         j.result[4] = (int32_t)slow_px;   /* wave 0's (none+up chains) count of pixels that needed the exact channel repair */
     }
+}
+
+int pl_engine_occupancy(void)
+{
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pl_engine, PL_ENGINE_THREADS, 0) != hipSuccess) return -1;
+    return n;
 }
 
 hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream)

@@ -170,6 +170,7 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
     ctx->engine_ms = ms;
     PL_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
     ctx->total_ms = ms;
+    if (std::getenv("PNGLOSS_HIP_DEBUG")) std::fprintf(stderr, "pngloss_hip: row engine occupancy query: %d workgroups per CU\n", pl_engine_occupancy());
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < ctx->n_last; i++) {
         int32_t r[32] = { 0 };
