@@ -120,6 +120,8 @@ struct PlEngineParams {
     float rq;       /* nextafterf(1/(strength+1), +inf) */
     float rbleed;   /* nextafterf(1/bleed, +inf)        */
     float r29;      /* 2*nextafterf(1/9, +inf)          */
+    int force_careful; /* test hook: always run the chain variant with explicit int16 wrap handling (normally only
+                          rows whose incoming |error| exceeds 8000 use it) */
 };
 
 hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);

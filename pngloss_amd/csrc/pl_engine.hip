@@ -189,7 +189,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             const uint32_t a = (ok && nabove) ? nabove[xl] : 0u;
             const uint32_t d = (ok && nabove && xl) ? nabove[xl - 1] : 0u;
             const u32x2 e = ok ? err0[xl] : (u32x2){ 0u, 0u };
-            const bool alpha0 = TR && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+            const bool alpha0 = TR && (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;   /* only 2 and 4 B/px have alpha */
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                 const int p = pl_plane_of_channel(bpp, cc);
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         const bool adaptive = !j.row_filters || y == 0;   /* pngloss_image.c:210 */
         int s = prm.strength;
         int winner = -1;
-        const bool wrap = big_err != 0;
+        const bool wrap = big_err != 0 || prm.force_careful;
         for (;;) {
             /* every candidate starts from the committed histogram (optimize_state_copy, pngloss_image.c:240) */
             for (int b = lane; b < PL_NSYM; b += 64) tbl[wave][b].x = Hc[b];

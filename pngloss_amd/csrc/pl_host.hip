@@ -140,6 +140,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     prm.rq = recip_up_host((long)strength + 1);
     prm.rbleed = recip_up_host(bleed);
     prm.r29 = 2.0f * recip_up_host(9);
+    prm.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;   /* test hook, see pl_device.h */
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
     PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));

@@ -54,7 +54,7 @@ def test_seeded_inputs_against_oracle():
             assert np.array_equal(f1, f2), (img.shape, s, b, filt)
 
 
-@pytest.mark.parametrize("strength", [0, 1, 15, 16, 19, 20, 31, 32, 33, 40, 63, 64, 85, 127, 128, 255])
+@pytest.mark.parametrize("strength", [0, 1, 7, 8, 15, 16, 19, 20, 23, 24, 31, 32, 33, 40, 47, 48, 63, 64, 79, 80, 85, 95, 96, 127, 128, 255])
 def test_every_candidate_count_path(strength):
     """s<=15: one candidate per lane, s<=31: two, above: the generic sweep -- each against the oracle, every class."""
     for mode in (0, 1, 3, 4, 5):
@@ -165,6 +165,30 @@ def test_device_resident_batch_of_mixed_images(torch_cuda):
     ctx.close()
 
 
+def test_strength_retry_rows_are_reported(torch_cuda):
+    """pngloss_image.c:266-274: smooth gray input needs the strength-decrement retry on the adaptive first row; with
+    row_filters == NULL every row is adaptive and many rows retry.  The HIP path must agree with the oracle's trace."""
+    import ctypes as C
+    torch = torch_cuda
+    img = P.synth_rgba(96, 64, 4, 0)
+    h, w = img.shape[:2]
+    packed = np.ascontiguousarray(img[..., 1:2])
+    for want_filters in (True, False):
+        out = packed.copy()
+        f = np.zeros(h, np.uint8)
+        su = np.zeros(h, np.uint8)
+        tr = U.PortTrace(None, su.ctypes.data, None, None)
+        assert U.port().port_optimize_packed(out.ctypes.data, w, h, 1, f.ctypes.data if want_filters else None, 19, 2, C.byref(tr)) == 0
+        want_retried = int((su < 19).sum())
+        d = torch.from_numpy(img.copy()).cuda()
+        df = torch.zeros(h, dtype=torch.uint8, device="cuda")
+        ctx = P.HipContext()
+        res = ctx.run([(d.data_ptr(), df.data_ptr() if want_filters else 0, w, h)], 19, 2)
+        assert res[0]["retried_rows"] == want_retried and want_retried >= 1
+        assert np.array_equal(d.cpu().numpy()[..., 1:2], out)
+        ctx.close()
+
+
 def test_batch_histogram_matches_oracle(torch_cuda):
     torch = torch_cuda
     a = P.synth_rgba(150, 40, 2, 3)
@@ -207,3 +231,25 @@ def test_suite_class_digests_via_synthetic_stand_ins():
         o1, f1 = U.run_port(img, 19, 2)
         o2, f2 = P.optimize_with_rows(img, 19, 2)
         assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m)
+
+
+def test_careful_int16_wrap_variant_of_the_chain():
+    """Rows whose incoming Sierra error exceeds 8000 switch the chain to a variant with explicit int16 sign
+    extensions (DESIGN.md 4.6).  Natural images never get there, so a test hook forces that variant for every row;
+    it must give the same bytes.  Run in a subprocess because the hook is read from the environment per batch."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, pngloss_amd as P\n"
+        "from tests import util as U\n"
+        "for m in range(6):\n"
+        "    for (s, b) in [(19, 2), (40, 1), (85, 8), (7, 3)]:\n"
+        "        img = P.synth_rgba(150, 20, m, s)\n"
+        "        o1, f1 = U.run_port(img, s, b)\n"
+        "        o2, f2 = P.optimize_with_rows(img, s, b)\n"
+        "        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (m, s, b)\n"
+        "print('careful ok')\n")
+    env = dict(os.environ, PNGLOSS_HIP_FORCE_CAREFUL="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=U.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "careful ok" in r.stdout, r.stderr[-1500:]
