@@ -146,6 +146,11 @@ def main():
         value = world * px * args.steps / elapsed_max / 1e6
         eng_ms = sum(r["engine_ms"] for r in records) / len(records)
         achieved = ALGO_BYTES_PER_PIXEL * px / (eng_ms * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch from the last committed rocprofv3 PMC passes (tools/pmc_to_json.py)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "Mpixels/s (filter+quantise path), 4096x4096 RGBA8 s=19; bit-exact vs ref",
             "value": round(value, 4), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,10 +162,11 @@ def main():
                        "images_per_gpu": 1, "parallelism": f"image-parallel x{world}, no data-path collective"},
             "bit_exact_vs_reference_digest": bool(bit_exact),
             "roofline": {"bound": "hbm", "kernel": "pl_engine", "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "engine_ms_per_launch": round(eng_ms, 3),
                          "note": "dominant kernel is bound by the serial per-pixel dependency chain (DESIGN.md), "
-                                 "not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx per launch"},
+                                 "not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB per launch; traffic = "
+                                 "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(frame)
