@@ -136,7 +136,11 @@ def main():
     filt_last = filt[nrun - 1].cpu().numpy()
     rec = [dict(index=rank, out="%016x" % P.fnv1a64(out_last, P.SURVEY_FNV_BASIS),
                 filters="%016x" % P.fnv1a64(filt_last, P.SURVEY_FNV_BASIS), engine_ms=sum(engine_ms) / len(engine_ms))]
-    records = S.gather_records(rec)
+    try:
+        records = S.gather_records(rec)
+    except Exception as exc:          # never lose the measurement to a failed record gather
+        print(f"bench.py: record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
+        records = rec if rank == 0 else rec
 
     if rank == 0:
         golden = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))

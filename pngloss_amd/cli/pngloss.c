@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "../../include/pngloss_hip.h"
@@ -318,9 +319,19 @@ static void for_each_job(struct job *jobs, size_t n, const struct options *o, vo
 
 /* ------------------------------------------------------------------------------------------- the batch driver */
 
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static pngloss_error run_window(struct job *jobs, size_t n, const struct options *o, pngloss_hip_ctx **ctx)
 {
+    const bool timing = getenv("PNGLOSS_TIMING") != NULL;
+    const double t0 = now_s();
     for_each_job(jobs, n, o, decode_job);
+    const double t1 = now_s();
 
     /* stage 2: every decoded image of the window in one GPU batch */
     pngloss_hip_host_image *imgs = calloc(n ? n : 1, sizeof *imgs);
@@ -346,8 +357,10 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
         }
     }
     free(imgs); free(res); free(who);
+    const double t2 = now_s();
 
     for_each_job(jobs, n, o, encode_job);
+    if (timing) fprintf(stderr, "  [timing] %zu files: decode %.2f s, gpu batch %.2f s, encode %.2f s\n", n, t1 - t0, t2 - t1, now_s() - t2);
     return SUCCESS;
 }
 

@@ -1,0 +1,30 @@
+"""End-to-end command line comparison on the GPU box: the reference tool (one file at a time, single thread) vs
+pngloss_amd/cli/pngloss (decode threads -> one GPU batch -> encode threads) on the same PNG files."""
+import os, subprocess, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pngloss_amd as P
+from PIL import Image
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "pngloss_ref_cli")
+OURS = os.path.join(ROOT, "pngloss_amd", "cli", "pngloss")
+n, W, H = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 1280, 720
+with tempfile.TemporaryDirectory() as d:
+    files = []
+    for i in range(n):
+        p = os.path.join(d, f"f{i:03d}.png")
+        Image.fromarray(P.synth_rgba(W, H, 0, i), "RGBA").save(p, compress_level=1)
+        files.append(p)
+    t = time.perf_counter()
+    r = subprocess.run([OURS, "-f", "--ext", "-ours.png"] + files, capture_output=True, text=True, env=dict(os.environ, PNGLOSS_TIMING="1")); print(r.stderr.strip())
+    t_ours = time.perf_counter() - t
+    assert r.returncode == 0, r.stderr[-500:]
+    nref = min(n, 4)
+    t = time.perf_counter()
+    for p in files[:nref]:
+        rr = subprocess.run([REF, "-f", "--ext", "-ref.png", p], capture_output=True)
+        assert rr.returncode == 0
+    t_ref = (time.perf_counter() - t) / nref * n
+    same = all(open(p[:-4] + "-ours.png", "rb").read() == open(p[:-4] + "-ref.png", "rb").read() for p in files[:nref])
+    print(f"{n} files {W}x{H}: ours {t_ours:.2f} s ({n*W*H/t_ours/1e6:.1f} Mpx/s end to end), reference tool {t_ref:.1f} s extrapolated from {nref} files "
+          f"({n*W*H/t_ref/1e6:.2f} Mpx/s); identical output files: {same}")
