@@ -173,7 +173,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
     const int nochk_neg = chk ? 0 : (int)0x80000000;    /* forces "no conflict" in lanes that do not check            */
     const int inact_neg = active ? 0 : (int)0x80000000; /* forces "in range" in lanes of unused channel rows          */
     const int upd_and = upd ? 255 : 0, upd_or = upd ? 0 : dummy;
-    const int chk_src = (16 * jl + 8 * half) * 4;       /* ds_bpermute byte address of a lane of group (k=jl)      */
+    const bool sel0 = jl == 0, sel1 = jl == 1;          /* which earlier channel this lane checks                  */
     uint32_t slow = 0;
     unsigned long long seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0, tprev = PL_SEGPROF ? __builtin_readcyclecounter() : 0;
 
@@ -296,7 +296,19 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             /* ---- did an earlier channel of this pixel bump a bin of my band that is not my winner?
              *      lane (c, k) fetches channel k's (speculative) winner; the answer is only needed after the
              *      tail below has been computed speculatively, which hides the ds_bpermute latency ---- */
-            const int sv = PL_ABLATE >= 1 ? vwin : __builtin_amdgcn_ds_bpermute(chk_src, vwin);
+            /* (readlane broadcasts + lane-constant selects: no LDS round trip on the critical path; the split-table read
+             *  issued below overlaps with this arithmetic) */
+            int sv;
+            if (PL_ABLATE >= 1) sv = vwin;
+            else if (PAIR) {
+                const int a0 = __builtin_amdgcn_readlane(vwin, 0), a1 = __builtin_amdgcn_readlane(vwin, 16), a2 = __builtin_amdgcn_readlane(vwin, 32);
+                const int b0 = __builtin_amdgcn_readlane(vwin, 8), b1 = __builtin_amdgcn_readlane(vwin, 24), b2 = __builtin_amdgcn_readlane(vwin, 40);
+                const int sa = sel0 ? a0 : (sel1 ? a1 : a2), sb = sel0 ? b0 : (sel1 ? b1 : b2);
+                sv = half ? sb : sa;
+            } else {
+                const int a0 = __builtin_amdgcn_readlane(vwin, 0), a1 = __builtin_amdgcn_readlane(vwin, 16), a2 = __builtin_amdgcn_readlane(vwin, 32);
+                sv = sel0 ? a0 : (sel1 ? a1 : a2);
+            }
 
             /* ---- reconstruct (optimize_state.c:251-260); the Sierra terms that stay in this row (:455,467) come
              *      from a 511-entry LDS table of the split, fetched alongside the ds_bpermute above ---- */
@@ -306,9 +318,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             if (TR) diff = tr ? 0 : diff;
             uint32_t le = PL_ABLATE >= 2 ? 0u : LUT[(diff + 256) & 511];
             int remv, thrv;
-            /* both LDS results are consumed here: keeps the table read ahead of the branch (one wait for the two) */
             int sv2 = sv;
-            asm volatile("" : "+v"(le), "+v"(sv2));
 
             /* bad  <=>  (checking lane: channel k's winner lies in my band and is not my winner) or |diff| > 255.
              * z >= 0 <=> conflict, w >= 0 <=> table index out of range; one compare, one branch. */

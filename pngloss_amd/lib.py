@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -88,6 +89,14 @@ def hip_lib():
     global _hip
     with _lock:
         if _hip is None:
+            # PyTorch-ROCm wheels bundle their own libamdhip64; whichever copy is loaded first serves the whole process.
+            # Loading /opt/rocm's copy first (through our .so) and torch's afterwards leaves torch without devices, so
+            # when torch is installed let it load first.  The C library itself has no torch dependency.
+            if "torch" not in sys.modules and os.environ.get("PNGLOSS_NO_TORCH_PRELOAD") is None:
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             lib = _load(os.environ.get("PNGLOSS_HIP_LIBNAME", "libpngloss_hip.so"))
             rows_t = C.POINTER(C.c_void_p)
             lib.optimize_with_rows.argtypes = [rows_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]

@@ -1,0 +1,71 @@
+"""Randomised parity campaign on the GPU box: HIP path (C ABI) vs the CPU oracle over random shapes, contents, strengths
+and bleed dividers, both row_filters modes, plus the device batch API with mixed images.  usage: gpu_fuzz.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pngloss_amd as P
+from tests import util as U
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+
+
+def make(rng):
+    w = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 129, 257, int(rng.integers(1, 400))]))
+    h = int(rng.integers(1, 30))
+    kind = int(rng.integers(0, 9))
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    elif kind == 1:      # smooth gradients + small noise
+        x = np.linspace(0, 255, w)[None, :, None]; y = np.linspace(0, 255, h)[:, None, None]
+        img = np.clip((x * rng.random(4) + y * rng.random(4)) / 2 + rng.integers(0, 6, (h, w, 4)), 0, 255).astype(np.uint8)
+    elif kind == 2:      # saturated: lots of 0 and 255
+        img = (rng.integers(0, 2, (h, w, 4)) * 255).astype(np.uint8)
+    elif kind == 3:      # near-white with noise (clamping at 255)
+        img = (255 - rng.integers(0, 12, (h, w, 4))).astype(np.uint8)
+    elif kind == 4:      # near-black
+        img = rng.integers(0, 12, (h, w, 4), dtype=np.uint8)
+    elif kind == 5:      # few distinct values -> many histogram ties
+        img = (rng.integers(0, 3, (h, w, 4)) * 100 + 20).astype(np.uint8)
+    elif kind == 6:      # constant
+        img = np.full((h, w, 4), int(rng.integers(0, 256)), np.uint8)
+    elif kind == 7:      # blocks
+        img = np.repeat(np.repeat(rng.integers(0, 256, ((h + 3) // 4, (w + 3) // 4, 4), dtype=np.uint8), 4, 0), 4, 1)[:h, :w]
+    else:                # stripes
+        img = np.zeros((h, w, 4), np.uint8); img[:, ::2] = rng.integers(0, 256, 4); img[:, 1::2] = rng.integers(0, 256, 4)
+    img = np.ascontiguousarray(img)
+    cls = int(rng.integers(0, 6))
+    if cls == 1: img[..., 3] = 255
+    elif cls == 2: img[..., 0] = img[..., 1]; img[..., 2] = img[..., 1]
+    elif cls == 3: img[..., 0] = img[..., 1]; img[..., 2] = img[..., 1]; img[..., 3] = 255
+    elif cls == 4: img[..., 3] = np.where(rng.random((h, w)) < 0.4, 0, img[..., 3])
+    s = int(rng.choice([0, 1, 2, 5, 7, 8, 15, 16, 19, 20, 23, 24, 31, 32, 40, 47, 48, 63, 64, 85, 100, 127, 200, 255, int(rng.integers(0, 256))]))
+    b = int(rng.choice([1, 2, 3, 4, 8, 16, 100, 1000, 32767, int(rng.integers(1, 32768))]))
+    return img, s, b, bool(rng.integers(0, 3))
+
+
+t0 = time.time(); n = 0; bad = 0
+ctx = P.HipContext()
+import torch
+while time.time() - t0 < budget:
+    if n % 10 == 9:     # device batch of 5 mixed images
+        items = [make(rng) for _ in range(5)]
+        s, b = items[0][1], items[0][2]
+        dev = [torch.from_numpy(it[0].copy()).cuda() for it in items]
+        flt = [torch.zeros(it[0].shape[0], dtype=torch.uint8, device="cuda") for it in items]
+        ctx.run([(d.data_ptr(), f.data_ptr(), it[0].shape[1], it[0].shape[0]) for d, f, it in zip(dev, flt, items)], s, b)
+        for d, f, it in zip(dev, flt, items):
+            o1, f1 = U.run_port(it[0], s, b)
+            if not (np.array_equal(o1, d.cpu().numpy()) and np.array_equal(f1, f.cpu().numpy())):
+                bad += 1; print("BATCH MISMATCH", it[0].shape, s, b, flush=True)
+    else:
+        img, s, b, filt = make(rng)
+        o1, f1 = U.run_port(img, s, b, filt)
+        o2, f2 = P.optimize_with_rows(img, s, b, want_filters=filt)
+        if not (np.array_equal(o1, o2) and (not filt or np.array_equal(f1, f2))):
+            bad += 1
+            np.save(f"gpurun_out/fuzz_fail_{n}.npy", img)
+            print("MISMATCH", n, img.shape, s, b, filt, int((o1 != o2).sum()), flush=True)
+    n += 1
+print(f"fuzz: {n} cases in {time.time() - t0:.0f} s, {bad} mismatches")
+sys.exit(1 if bad else 0)
