@@ -1,11 +1,11 @@
 /*
- * rwpng.c -- libpng glue for the pngloss CLI: decode any PNG to RGBA8, encode RGBA8 with caller-chosen row filters.
+ * png_bridge.c -- libpng glue for the pngloss CLI: decode any PNG to RGBA8, encode RGBA8 with caller-chosen row filters.
  *
  * Written for this project; it performs the same sequence of libpng operations as the reference's rwpng.c
  * (/root/reference/src/rwpng.c:179-400 read, :444-637 write) so that, given the same libpng/zlib, the files it writes
  * are byte-identical to the reference's -- that equality is what tests/test_gpu_cli.py checks.
  */
-#include "rwpng.h"
+#include "png_bridge.h"
 
 #include <limits.h>
 #include <png.h>

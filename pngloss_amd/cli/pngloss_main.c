@@ -1,5 +1,5 @@
 /*
- * pngloss.c -- `pngloss [options] -- pngfile [pngfile ...]` on an MI355X.
+ * pngloss_main.c -- `pngloss [options] -- pngfile [pngfile ...]` on an MI355X.
  *
  * Same command line, messages and exit codes as the reference tool (/root/reference/src/pngloss.c:28-165 usage and
  * argument checks, src/pngloss_opts.c:22-135 option table), but the per-file loop of pngloss_main_internal
@@ -23,7 +23,7 @@
 #include <unistd.h>
 
 #include "../../include/pngloss_hip.h"
-#include "rwpng.h"
+#include "png_bridge.h"
 
 #define PNGLOSS_VERSION "1.0.1-mi355x"
 #define WINDOW_FILES 256                 /* images per GPU batch (one workgroup each)              */

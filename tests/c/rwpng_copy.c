@@ -6,7 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "rwpng.h"
+#include "png_bridge.h"
 
 int main(int argc, char **argv)
 {

@@ -25,7 +25,7 @@ def drivers(tmp_path_factory):
     d = tmp_path_factory.mktemp("rwpng")
     ours = str(d / "copy_ours")
     subprocess.run(["gcc", "-O1", "-std=gnu11", "-w", "-I" + PNG_INC, "-I" + CLI, "-o", ours,
-                    os.path.join(U.ROOT, "tests", "c", "rwpng_copy.c"), os.path.join(CLI, "rwpng.c"), PNG_LIB, "-lz", "-lm"], check=True)
+                    os.path.join(U.ROOT, "tests", "c", "rwpng_copy.c"), os.path.join(CLI, "png_bridge.c"), PNG_LIB, "-lz", "-lm"], check=True)
     ref = None
     if os.path.exists(os.path.join(REF_SRC, "rwpng.c")):
         ref = str(d / "copy_ref")
