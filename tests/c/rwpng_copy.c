@@ -6,7 +6,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "png_bridge.h"
+#ifndef RWPNG_HEADER
+#define RWPNG_HEADER "png_bridge.h"   /* ours; the reference build passes -DRWPNG_HEADER='"rwpng.h"' */
+#endif
+#include RWPNG_HEADER
 
 int main(int argc, char **argv)
 {

@@ -29,7 +29,7 @@ def drivers(tmp_path_factory):
     ref = None
     if os.path.exists(os.path.join(REF_SRC, "rwpng.c")):
         ref = str(d / "copy_ref")
-        subprocess.run(["gcc", "-O1", "-std=gnu11", "-w", "-I" + PNG_INC, "-I" + REF_SRC, "-o", ref,
+        subprocess.run(["gcc", "-O1", "-std=gnu11", "-w", '-DRWPNG_HEADER="rwpng.h"', "-I" + PNG_INC, "-I" + REF_SRC, "-o", ref,
                         os.path.join(U.ROOT, "tests", "c", "rwpng_copy.c"), os.path.join(REF_SRC, "rwpng.c"), PNG_LIB, "-lz", "-lm"], check=True)
     return ours, ref, d
 
