@@ -28,6 +28,8 @@
  */
 #include "pl_device.h"
 
+#include <type_traits>
+
 #ifndef PL_SEGPROF
 #define PL_SEGPROF 0   /* timing experiments only: s_memtime stamps inside the chain loop (perturbs it) */
 #endif
@@ -110,6 +112,13 @@ struct RowCtx {
     unsigned long long seg[4];/* out (PL_SEGPROF): cycles in head+gather | reductions | check | tail */
 };
 
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));   /* |a - b| */
+    return r;
+}
+
 __device__ __forceinline__ int med3_i32(int v, int lo, int hi)
 {
     int r;
@@ -182,6 +191,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
     constexpr int RS = PAIR ? 2 : 1;                    /* records per (pixel, channel) */
     for (uint32_t x0 = 0; x0 < W; x0 += PL_CHUNK) {
         /* ---- vector pre-phase: lane = pixel x0+lane; everything that does not depend on the chain ---- */
+        bool chunk_has_transparent = false;
         if (lane < PL_CHUNK) {
             const uint32_t xl = x0 + lane;
             const bool ok = xl < W;
@@ -190,6 +200,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             const uint32_t d = (ok && nabove && xl) ? nabove[xl - 1] : 0u;
             const u32x2 e = ok ? err0[xl] : (u32x2){ 0u, 0u };
             const bool alpha0 = TR && (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;   /* only 2 and 4 B/px have alpha */
+            chunk_has_transparent = alpha0;
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                 const int p = pl_plane_of_channel(bpp, cc);
@@ -214,6 +225,10 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         const int n = (int)min((uint32_t)PL_CHUNK, W - x0);
+        /* the serial part of the chunk, compiled twice: with and without the fully-transparent-pixel handling, chosen per
+         * chunk (most chunks of most images have no alpha == 0 pixel, and the handling costs ~6 issue slots per pixel) */
+        auto serial_part = [&](auto trx_tag) {
+        constexpr bool TRX = decltype(trx_tag)::value;
         u32x4 r = R[c * RS + half];
         for (int g = 0; g < n; g += GL) {
         const int m = min(GL, n - g);
@@ -231,7 +246,14 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
                 filt = WRAP ? osym + pl_sext16((int)r.w + rem + thr_prev) : (int)r.w + rem + thr_prev;
             } else {
                 const int orig = (int)r.x;
-                predraw = pl_predict<MODE>((int)r.y, (int)(r.z & 0xffffu), left);
+                if (MODE == 4) {
+                    /* Paeth with three v_sad_u32 (|a-b|+0) instead of sub/neg/max triplets */
+                    const uint32_t ab = r.y, dg = r.z & 0xffffu, lf = (uint32_t)left;
+                    const uint32_t dl = sad_u32(ab, dg), da = sad_u32(lf, dg), dd = sad_u32(lf + ab, dg + dg);
+                    predraw = (dl <= da && dl <= dd) ? left : (da <= dd ? (int)ab : (int)dg);
+                } else {
+                    predraw = pl_predict<MODE>((int)r.y, (int)(r.z & 0xffffu), left);
+                }
                 osym = pl_sext8(orig - predraw);
                 lo = osym - orig;                       /* = -(re-centred prediction), optimize_state.c:175-182 */
                 int err = (int)r.w + rem + thr_prev;
@@ -245,7 +267,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             vmin = med3_i32(vmin, lo, hi);
             vmax = med3_i32(vmax, lo, hi);
             bool tr = false;
-            if (TR) {
+            if (TRX) {
                 tr = (r.z >> 16) != 0;                  /* optimize_state.c:158-164 */
                 vmin = tr ? -predraw : vmin;
                 vmax = tr ? -predraw : vmax;
@@ -293,11 +315,15 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             int jwin = (int)((0u - K) & 255u);          /* K-1 = rank<<9 | flag<<8 | 255-j */
             int vwin = vmin + jwin;
 
+            /* histogram bump, issued NOW with the speculative winner so that the LDS atomic retires behind the check
+             * below instead of in front of the next pixel's record wait; the rare repair path moves it.  EXEC is not
+             * touched: non-owner lanes add 0 to a private dummy slot. */
+            const int bump_idx = (vwin & upd_and) | upd_or;
+            if (PL_ABLATE < 6) __hip_atomic_fetch_add((lds_u32 *)&T[bump_idx], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
             /* ---- did an earlier channel of this pixel bump a bin of my band that is not my winner?
-             *      lane (c, k) fetches channel k's (speculative) winner; the answer is only needed after the
-             *      tail below has been computed speculatively, which hides the ds_bpermute latency ---- */
-            /* (readlane broadcasts + lane-constant selects: no LDS round trip on the critical path; the split-table read
-             *  issued below overlaps with this arithmetic) */
+             *      lane (c, k) looks at channel k's (speculative) winner: readlane broadcasts + lane-constant selects,
+             *      no LDS round trip; the split-table read issued below overlaps with this arithmetic ---- */
             int sv;
             if (PL_ABLATE >= 1) sv = vwin;
             else if (PAIR) {
@@ -315,7 +341,7 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             int back = vwin - lo;
             int diff = filt - vwin;
             if (WRAP) diff = pl_sext16(diff);
-            if (TR) diff = tr ? 0 : diff;
+            if (TRX) diff = tr ? 0 : diff;
             uint32_t le = PL_ABLATE >= 2 ? 0u : LUT[(diff + 256) & 511];
             int remv, thrv;
             int sv2 = sv;
@@ -326,6 +352,9 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             const int z = ((tt != jwin) ? span - tt : -1) | nochk_neg;
             const int w = (max(diff, -diff) - 256) | inact_neg;
             const bool bad = PL_ABLATE >= 1 ? false : ((z & w) >= 0);
+            /* consume the split-table entry HERE: otherwise the compiler sinks its ds_read below the branch, where the
+             * whole LDS latency lands on the critical path; issued ~15 slots ago it has (nearly) arrived by now */
+            asm volatile("" : "+v"(le));
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
                 /* exact repair in channel order: channel cp chose bin sb and bumped it to sH */
                 slow++;
@@ -354,10 +383,13 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
                         vwin = vmin + jwin;
                     }
                 }
+                /* move the speculative bump to the repaired winner (no-op where nothing changed) */
+                __hip_atomic_fetch_add((lds_u32 *)&T[bump_idx], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add((lds_u32 *)&T[(vwin & upd_and) | upd_or], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 back = vwin - lo;
                 diff = filt - vwin;
                 if (WRAP) diff = pl_sext16(diff);
-                if (TR) diff = tr ? 0 : diff;
+                if (TRX) diff = tr ? 0 : diff;
                 const PlSplit sp = pl_sierra_split(diff, rbleed, r29);
                 remv = (int)sp.rem;
                 thrv = (int)sp.h;
@@ -370,8 +402,6 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             thr_cur = thrv;
             rem = remv;
             left = back;
-            /* histogram bump without touching EXEC: non-owner lanes add 0 to a private dummy slot */
-            if (PL_ABLATE < 6) __hip_atomic_fetch_add((lds_u32 *)&T[(vwin & upd_and) | upd_or], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             /* output capture: lane jl of the group keeps pixel ii; stored GL pixels at a time */
             const uint32_t packed = (uint32_t)back | ((uint32_t)diff << 8);
             cap = (jl == ii) ? packed : cap;
@@ -379,6 +409,9 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         }
         if (active && jl < m) outp[(size_t)(x0 + g + jl) * 4 + c] = cap;
         }
+        };
+        if (TR && __builtin_amdgcn_ballot_w64(chunk_has_transparent) != 0) serial_part(std::true_type{});
+        else serial_part(std::false_type{});
     }
     k.slow = slow;
     k.seg[0] = seg0; k.seg[1] = seg1; k.seg[2] = seg2; k.seg[3] = seg3;
