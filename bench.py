@@ -91,14 +91,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK in the environment) always go through RCCL, also for one rank, so that the
+    # N=1 launch the driver does exercises exactly the code path of N=2,4,8
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     # ---- inputs resident in HBM before the timed region: one pristine copy per step (the path works in place) ----
@@ -127,7 +131,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
 
@@ -177,8 +181,8 @@ def main():
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
