@@ -119,6 +119,15 @@ def main():
         assert res[0]["status"] == 0 and res[0]["bpp"] == 4
         return ctx.engine_ms, ctx.total_ms
 
+    # PCIe legs, reported separately and never part of `value` (inputs are resident before the timed region)
+    pinned = torch.from_numpy(frame).pin_memory()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    scratch = torch.empty_like(src)
+    ev[0].record(); scratch.copy_(pinned, non_blocking=True); ev[1].record(); pinned.copy_(scratch, non_blocking=True); ev[2].record()
+    torch.cuda.synchronize()
+    h2d_ms, d2h_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    del scratch
+
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -176,6 +185,9 @@ def main():
                                  "not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB per launch; traffic = "
                                  "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
         }
+        line["transfers"] = {"h2d_ms": round(h2d_ms, 3), "d2h_ms": round(d2h_ms, 3), "bytes_each_way": W * H * 4,
+                             "note": "pinned 64 MiB frame over PCIe, outside the timed region; with both legs one step "
+                                     "would take %.1f ms" % (elapsed_max / args.steps * 1e3 + h2d_ms + d2h_ms)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(frame)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)

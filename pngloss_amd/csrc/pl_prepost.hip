@@ -59,10 +59,20 @@ __global__ __launch_bounds__(kThreads) void pl_classify(const PlJob *jobs)
         gray &= (r == g) & (g == b);
         opaque &= (a == 255u);
     }
+    /* one atomic per WORKGROUP at most (8192 same-address atomics, one per wave, used to cost 80 us of a 100 us kernel),
+     * and none at all once the flag word already says "neither gray nor opaque" */
+    __shared__ uint32_t wg_clear;
+    if (threadIdx.x == 0) wg_clear = 0;
+    __syncthreads();
     const bool all_gray = __all(gray), all_opaque = __all(opaque);
     if ((threadIdx.x & 63) == 0) {
-        uint32_t clear = (all_gray ? 0u : PL_FLAG_GRAY) | (all_opaque ? 0u : PL_FLAG_OPAQUE);
-        if (clear) atomicAnd(j.flags, ~clear);
+        const uint32_t clear = (all_gray ? 0u : PL_FLAG_GRAY) | (all_opaque ? 0u : PL_FLAG_OPAQUE);
+        if (clear) atomicOr(&wg_clear, clear);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_clear) {
+        const uint32_t now = __hip_atomic_load(j.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (now & wg_clear) atomicAnd(j.flags, ~wg_clear);
     }
 }
 
@@ -108,11 +118,15 @@ __global__ __launch_bounds__(kThreads) void pl_unpack(const PlJob *jobs)
  * bin per workgroup at the end. */
 __global__ __launch_bounds__(kThreads) void pl_hist(const PlJob *jobs)
 {
-    __shared__ uint32_t h[PL_NFILT * PL_NSYM];
+    /* natural images put most residuals into a handful of bins, so the 64 lanes of a wave keep hitting the same LDS
+     * word; kRep lane-interleaved replicas cut that serialisation kRep-fold (replica = lane & (kRep-1)) */
+    constexpr int kRep = 8;
+    __shared__ uint32_t h[kRep][PL_NFILT * PL_NSYM];
     const PlJob j = jobs[blockIdx.y];
     const uint32_t bpp = pl_job_bpp(j);
-    for (uint32_t i = threadIdx.x; i < PL_NFILT * PL_NSYM; i += kThreads) h[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kRep * PL_NFILT * PL_NSYM; i += kThreads) (&h[0][0])[i] = 0;
     __syncthreads();
+    uint32_t *const mine = h[threadIdx.x & (kRep - 1)];
     const uint32_t W = j.width;
     const size_t n = (size_t)W * j.height;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
@@ -125,16 +139,20 @@ __global__ __launch_bounds__(kThreads) void pl_hist(const PlJob *jobs)
         for (uint32_t c = 0; c < bpp; c++) {
             const int hv = (here >> (8 * c)) & 255, lv = (left >> (8 * c)) & 255;
             const int av = (above >> (8 * c)) & 255, dv = (diag >> (8 * c)) & 255;
-            atomicAdd(&h[0 * PL_NSYM + (hv & 255)], 1u);
-            atomicAdd(&h[1 * PL_NSYM + ((hv - lv) & 255)], 1u);
-            atomicAdd(&h[2 * PL_NSYM + ((hv - av) & 255)], 1u);
-            atomicAdd(&h[3 * PL_NSYM + ((hv - ((av + lv) >> 1)) & 255)], 1u);
-            atomicAdd(&h[4 * PL_NSYM + ((hv - pl_paeth(av, dv, lv)) & 255)], 1u);
+            atomicAdd(&mine[0 * PL_NSYM + (hv & 255)], 1u);
+            atomicAdd(&mine[1 * PL_NSYM + ((hv - lv) & 255)], 1u);
+            atomicAdd(&mine[2 * PL_NSYM + ((hv - av) & 255)], 1u);
+            atomicAdd(&mine[3 * PL_NSYM + ((hv - ((av + lv) >> 1)) & 255)], 1u);
+            atomicAdd(&mine[4 * PL_NSYM + ((hv - pl_paeth(av, dv, lv)) & 255)], 1u);
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < PL_NFILT * PL_NSYM; i += kThreads)
-        if (h[i]) atomicAdd(&j.orig_hist[i], h[i]);
+    for (uint32_t i = threadIdx.x; i < PL_NFILT * PL_NSYM; i += kThreads) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < kRep; r++) v += h[r][i];
+        if (v) atomicAdd(&j.orig_hist[i], v);
+    }
 }
 
 /* rank[f][b] = #{ b' : orig_hist[f][b'] < orig_hist[f][b] }  (0..255): a < b  <=>  rank(a) < rank(b), and
