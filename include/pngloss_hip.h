@@ -129,6 +129,27 @@ typedef struct {
 int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
                                     unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results);
 
+/* As above, and additionally returns, per image, the FILTERED SCANLINES a PNG encoder deflates -- the first piece of
+ * the PNG write side done on the device (replaces libpng's png_write_row filtering inside rwpng_write_image24,
+ * /root/reference/src/rwpng.c:477-501,558-609): the colour type is re-detected from the optimised pixels, gray images
+ * are repacked, row 0 (every row when row_filters is NULL) takes libpng's heuristic filter, the others the filter the
+ * optimiser chose.  The host then only deflates and frames chunks (pngloss_amd/cli/png_stream_writer.c).
+ *   filter_types  caller-allocated height bytes, receives the PNG filter type 0..4 of every scanline
+ *   scanlines     caller-allocated height*pitch bytes, receives width*channels filtered bytes per row
+ *   pitch         in: bytes between rows of `scanlines`, >= width*4
+ *   color_type    out: 0 gray, 4 gray+alpha, 2 RGB, 6 RGBA (8 bits per sample)
+ * Entries whose buffers are NULL are skipped. */
+typedef struct {
+    unsigned char *filter_types;
+    unsigned char *scanlines;
+    size_t pitch;
+    int color_type;
+} pngloss_hip_scanlines;
+
+int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                         unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
+                                         pngloss_hip_scanlines *scanlines);
+
 /* Duration in milliseconds of the row-engine kernel of the last finished batch, measured with hipEvents recorded
  * on the launch stream immediately around that kernel (what bench.py's roofline block reports).  < 0 if none. */
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx);

@@ -7,6 +7,9 @@
  *
  *     decode all inputs (libpng, worker threads)  ->  ONE batched call into libpngloss_hip.so  ->  encode (threads)
  *
+ * The GPU call also returns the filtered scanlines of every image (colour type re-detected, per-row filters applied),
+ * so the encode stage only deflates and frames chunks (png_stream_writer.c) -- libpng is used for decoding only.
+ *
  * so that a GPU with 256 compute units works on up to 256 images at once (one workgroup per image).  Files are
  * processed in windows so that memory stays bounded.  Per-file semantics are unchanged: output naming (--ext / -o),
  * the overwrite rule, temp-file + atomic rename, --skip-if-larger, --strip, stdin/stdout with "-", and the exit code
@@ -24,6 +27,7 @@
 
 #include "../../include/pngloss_hip.h"
 #include "png_bridge.h"
+#include "png_stream_writer.h"
 
 #define PNGLOSS_VERSION "1.0.1-mi355x"
 #define WINDOW_FILES 256                 /* images per GPU batch (one workgroup each)              */
@@ -135,6 +139,8 @@ struct job {
     pngloss_error status;
     png24_image in, out;
     unsigned char *filters;
+    unsigned char *line_types, *lines;   /* filtered scanlines from the GPU: type byte per row, width*4-pitched rows */
+    int color_type;
     char *log;                /* buffered stderr text */
     size_t log_len;
     pngloss_hip_result gpu;
@@ -220,7 +226,9 @@ static void decode_job(struct job *j, const struct options *o)
     j->out.rgba_data = malloc(bytes > 0 ? bytes : 1);
     j->out.row_pointers = malloc((H ? H : 1) * sizeof(unsigned char *));
     j->filters = malloc(H ? H : 1);
-    if (!j->out.rgba_data || !j->out.row_pointers || !j->filters) { j->status = OUT_OF_MEMORY_ERROR; return; }
+    j->line_types = malloc(H ? H : 1);
+    j->lines = malloc(bytes > 0 ? bytes : 1);
+    if (!j->out.rgba_data || !j->out.row_pointers || !j->filters || !j->line_types || !j->lines) { j->status = OUT_OF_MEMORY_ERROR; return; }
     for (size_t y = 0; y < H; y++) {
         j->out.row_pointers[y] = j->out.rgba_data + y * W * 4;
         memcpy(j->out.row_pointers[y], j->in.row_pointers[y], W * 4);
@@ -247,7 +255,16 @@ static pngloss_error encode_to(struct job *j, png24_image *img, unsigned char *f
         }
         if (o->verbose) say(j, "  writing compressed image as %s\n", leaf(j->out_name));
     }
-    pngloss_error rc = rwpng_write_image24(f, img, filters);
+    pngloss_error rc;
+    if (filters) {
+        /* the optimised image: scanlines were filtered on the GPU, only deflate + chunk framing happen here */
+        const png_stream_image si = { img->width, img->height, j->color_type, j->line_types, j->lines, (size_t)img->width * 4, img->gamma,
+                                      img->output_color != RWPNG_GAMA_ONLY && img->output_color != RWPNG_NONE, img->output_color == RWPNG_SRGB,
+                                      img->chunks, img->maximum_file_size };
+        rc = png_stream_write(f, &si, &img->file_size, &img->metadata_size);
+    } else {
+        rc = rwpng_write_image24(f, img, NULL);     /* the untouched original (pipe fallback): plain libpng */
+    }
     if (!o->to_stdout) {
         fclose(f);
         if (rc == SUCCESS && rename(tmp, j->out_name) != 0) rc = CANT_WRITE_ERROR;
@@ -335,19 +352,22 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
 
     /* stage 2: every decoded image of the window in one GPU batch */
     pngloss_hip_host_image *imgs = calloc(n ? n : 1, sizeof *imgs);
+    pngloss_hip_scanlines *lines = calloc(n ? n : 1, sizeof *lines);
     pngloss_hip_result *res = calloc(n ? n : 1, sizeof *res);
     size_t *who = calloc(n ? n : 1, sizeof *who), m = 0;
-    if (!imgs || !res || !who) { free(imgs); free(res); free(who); return OUT_OF_MEMORY_ERROR; }
+    if (!imgs || !lines || !res || !who) { free(imgs); free(lines); free(res); free(who); return OUT_OF_MEMORY_ERROR; }
     for (size_t i = 0; i < n; i++)
         if (jobs[i].status == SUCCESS) {
             imgs[m] = (pngloss_hip_host_image){ jobs[i].out.rgba_data, jobs[i].filters, jobs[i].out.width, jobs[i].out.height };
+            lines[m] = (pngloss_hip_scanlines){ jobs[i].line_types, jobs[i].lines, (size_t)jobs[i].out.width * 4, -1 };
             who[m++] = i;
         }
     if (m) {
         if (!*ctx) *ctx = pngloss_hip_create(-1);
-        int rc = *ctx ? pngloss_hip_optimize_batch_host(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res) : PNGLOSS_HIP_ERROR;
+        int rc = *ctx ? pngloss_hip_optimize_batch_host_emit(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res, lines) : PNGLOSS_HIP_ERROR;
         for (size_t k = 0; k < m; k++) {
             jobs[who[k]].gpu = res[k];
+            jobs[who[k]].color_type = lines[k].color_type;
             if (rc != PNGLOSS_SUCCESS) {
                 /* unlike the reference (pngloss.c:266 ignores the return value) a failed optimisation is an error:
                  * there is no CPU path to fall back to, and writing an unoptimised file silently would be wrong */
@@ -356,7 +376,7 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
             }
         }
     }
-    free(imgs); free(res); free(who);
+    free(imgs); free(lines); free(res); free(who);
     const double t2 = now_s();
 
     for_each_job(jobs, n, o, encode_job);
@@ -429,6 +449,8 @@ int main(int argc, char **argv)
             rwpng_free_image24(&j->in);
             rwpng_free_image24(&j->out);
             free(j->filters);
+            free(j->line_types);
+            free(j->lines);
             if (j->own_out_name) free(j->out_name);
         }
         start += n;

@@ -38,6 +38,12 @@ struct PlJob {
     uint2 *err1;          /* [width] same for the next row                                 (color_error row 1)    */
     uint32_t *old_above;  /* [width] original (pre-optimisation) previous row = last_row_pixels                  */
     uint32_t *final_hist; /* [256]                                                                               */
+    uint8_t *row_ids;     /* [height] winning filter 0..4 of every row (always written, also when row_filters is null) */
+    uint32_t *out_flags;  /* [1]  PL_FLAG_* of the OPTIMISED image (what the PNG writer side detects, rwpng.c:558-573)  */
+    uint8_t *emit_ids;    /* [height] or null: PNG filter type actually used per scanline of the emitted stream         */
+    uint8_t *emit_rows;   /* [height][emit_pitch] or null: filtered scanline bytes in the output colour type             */
+    uint32_t emit_pitch;  /* bytes between emitted rows (multiple of 16, >= width*4)                                     */
+    uint32_t emit_adaptive_all; /* 1: every row takes libpng's heuristic filter (row_filters == NULL mode), 0: only row 0 */
     int32_t *result;      /* [16] status, bpp, unique symbols, retried rows, repaired pixels (wave 0), -,-,-,
                              [8..11] chain kilo-cycles per chain wave, [12..15] repaired pixels per chain wave          */
 };
@@ -128,5 +134,6 @@ hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n,
 hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream);
 int pl_engine_occupancy(void);   /* workgroups of the row engine per CU according to the HIP occupancy query */
 hipError_t pl_launch_finish(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
+hipError_t pl_launch_emit(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 
 #endif

@@ -638,6 +638,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         if (big) big_err = 1;
         for (int b = tid; b < PL_NSYM; b += PL_ENGINE_THREADS) Hc[b] = tbl[winner][b].x;
         if (tid == 0 && j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);   /* PNG_FILTER_* flags */
+        if (tid == 0) j.row_ids[y] = (uint8_t)winner;
         __syncthreads();
     }
 

@@ -44,11 +44,11 @@ namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-    size_t jobs, flags, orig_hist, orig_rank, cand, err0, err1, old_above, final_hist, result, total;
+    size_t jobs, flags, orig_hist, orig_rank, cand, err0, err1, old_above, final_hist, result, row_ids, out_flags, total;
 };
 
 /* per-image workspace: everything the engine keeps outside the image itself */
-WsLayout image_ws(uint32_t width)
+WsLayout image_ws(uint32_t width, uint32_t height)
 {
     WsLayout l{};
     size_t o = 0;
@@ -62,6 +62,8 @@ WsLayout image_ws(uint32_t width)
     l.old_above = take(sizeof(uint32_t) * (size_t)width);
     l.final_hist = take(sizeof(uint32_t) * PL_NSYM);
     l.result = take(sizeof(int32_t) * 32);
+    l.row_ids = take(height ? height : 1);
+    l.out_flags = take(sizeof(uint32_t));
     l.total = o;
     return l;
 }
@@ -86,8 +88,10 @@ int ensure_ws(pngloss_hip_ctx *ctx, size_t bytes)
     return PNGLOSS_SUCCESS;
 }
 
+struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
+
 int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n, const uint32_t *forced_bpp,
-            unsigned strength, long bleed, hipStream_t stream)
+            unsigned strength, long bleed, hipStream_t stream, const EmitTarget *emits = nullptr)
 {
     if (!ctx) return PNGLOSS_INVALID_ARGUMENT;
     if (strength > 255 || bleed < 1 || bleed > 32767) {
@@ -107,12 +111,12 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     for (size_t i = 0; i < n; i++) {
         if (!images[i].d_rgba && images[i].width && images[i].height) return PNGLOSS_INVALID_ARGUMENT;
         offs.push_back(total);
-        total += image_ws(images[i].width ? images[i].width : 1).total;
+        total += image_ws(images[i].width ? images[i].width : 1, images[i].height).total;
     }
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
     for (size_t i = 0; i < n; i++) {
-        const WsLayout l = image_ws(images[i].width ? images[i].width : 1);
+        const WsLayout l = image_ws(images[i].width ? images[i].width : 1, images[i].height);
         char *b = ctx->d_ws + offs[i];
         PlJob j{};
         j.img = static_cast<uint32_t *>(images[i].d_rgba);
@@ -129,6 +133,14 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         j.old_above = reinterpret_cast<uint32_t *>(b + l.old_above);
         j.final_hist = reinterpret_cast<uint32_t *>(b + l.final_hist);
         j.result = reinterpret_cast<int32_t *>(b + l.result);
+        j.row_ids = reinterpret_cast<uint8_t *>(b + l.row_ids);
+        j.out_flags = reinterpret_cast<uint32_t *>(b + l.out_flags);
+        if (emits && emits[i].d_rows) {
+            j.emit_ids = static_cast<uint8_t *>(emits[i].d_ids);
+            j.emit_rows = static_cast<uint8_t *>(emits[i].d_rows);
+            j.emit_pitch = emits[i].pitch;
+            j.emit_adaptive_all = images[i].d_row_filters ? 0u : 1u;
+        }
         ctx->h_jobs.push_back(j);
     }
     if (!n) return PNGLOSS_SUCCESS;
@@ -148,6 +160,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     PL_CHECK(pl_launch_engine(d_jobs, n, prm, stream));
     PL_CHECK(hipEventRecord(ctx->ev[2], stream));
     PL_CHECK(pl_launch_finish(d_jobs, ctx->h_jobs.data(), n, stream));
+    PL_CHECK(pl_launch_emit(d_jobs, ctx->h_jobs.data(), n, stream));
     PL_CHECK(hipEventRecord(ctx->ev[3], stream));
     ctx->n_last = n;
     ctx->last_stream = stream;
@@ -329,19 +342,26 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
     return finish(ctx, results, n);
 }
 
-int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
-                                    unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results)
+static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n, unsigned quantization_strength,
+                      long bleed_divider, pngloss_hip_result *results, pngloss_hip_scanlines *lines)
 {
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
-    /* one device arena for the whole batch: [image 0 | filters 0 | image 1 | ...], 256-byte aligned pieces */
-    std::vector<size_t> img_off(n), flt_off(n);
+    /* one device arena for the whole batch: [image | filter flags | emitted ids | emitted rows] per image, 256-B aligned */
+    std::vector<size_t> img_off(n), flt_off(n), ids_off(n), rows_off(n);
+    std::vector<EmitTarget> emits(n);
     size_t total = 0;
     for (size_t i = 0; i < n; i++) {
         const size_t px = (size_t)images[i].width * images[i].height;
         if (px && !images[i].rgba) return PNGLOSS_INVALID_ARGUMENT;
         img_off[i] = total; total = align_up(total + px * 4, 256);
         flt_off[i] = total; total = align_up(total + (images[i].row_filters ? images[i].height : 0), 256);
+        const bool want = lines && lines[i].scanlines && lines[i].filter_types && px;
+        const uint32_t pitch = want ? (uint32_t)align_up((size_t)images[i].width * 4, 16) : 0;
+        if (want && lines[i].pitch < (size_t)images[i].width * 4) return PNGLOSS_INVALID_ARGUMENT;
+        ids_off[i] = total; total = align_up(total + (want ? images[i].height : 0), 256);
+        rows_off[i] = total; total = align_up(total + (size_t)pitch * (want ? images[i].height : 0), 256);
+        emits[i].pitch = pitch;
     }
     char *arena = nullptr;
     if (total) PL_CHECK(hipMalloc(reinterpret_cast<void **>(&arena), total));
@@ -351,9 +371,11 @@ int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host
         const size_t px = (size_t)images[i].width * images[i].height;
         descs[i] = pngloss_hip_image_desc{ px ? arena + img_off[i] : nullptr,
                                            (px && images[i].row_filters) ? arena + flt_off[i] : nullptr, images[i].width, images[i].height };
+        emits[i].d_ids = emits[i].pitch ? arena + ids_off[i] : nullptr;
+        emits[i].d_rows = emits[i].pitch ? arena + rows_off[i] : nullptr;
         if (px && hipMemcpy(arena + img_off[i], images[i].rgba, px * 4, hipMemcpyHostToDevice) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     }
-    if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, nullptr);
+    if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, nullptr, emits.data());
     if (rc == PNGLOSS_SUCCESS) rc = finish(ctx, results, n);
     for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
         const size_t px = (size_t)images[i].width * images[i].height;
@@ -361,10 +383,33 @@ int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host
         if (hipMemcpy(images[i].rgba, arena + img_off[i], px * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
         if (images[i].row_filters &&
             hipMemcpy(images[i].row_filters, arena + flt_off[i], images[i].height, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+        if (emits[i].pitch) {
+            uint32_t fl = 0;
+            if (hipMemcpy(&fl, ctx->h_jobs[i].out_flags, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            const bool g = fl & PL_FLAG_GRAY, o = fl & PL_FLAG_OPAQUE;
+            lines[i].color_type = g ? (o ? 0 : 4) : (o ? 2 : 6);
+            const size_t rowbytes = (size_t)images[i].width * (g ? (o ? 1 : 2) : (o ? 3 : 4));
+            if (hipMemcpy(lines[i].filter_types, emits[i].d_ids, images[i].height, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            if (hipMemcpy2D(lines[i].scanlines, lines[i].pitch, emits[i].d_rows, emits[i].pitch, rowbytes, images[i].height,
+                            hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+        }
     }
     if (arena) (void)hipFree(arena);
     if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
     return rc;
+}
+
+int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                    unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results)
+{
+    return batch_host(ctx, images, n, quantization_strength, bleed_divider, results, nullptr);
+}
+
+int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                         unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
+                                         pngloss_hip_scanlines *scanlines)
+{
+    return batch_host(ctx, images, n, quantization_strength, bleed_divider, results, scanlines);
 }
 
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->engine_ms : -1.0; }

@@ -38,6 +38,10 @@ class HostImage(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("row_filters", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class Scanlines(C.Structure):
+    _fields_ = [("filter_types", C.c_void_p), ("scanlines", C.c_void_p), ("pitch", C.c_size_t), ("color_type", C.c_int)]
+
+
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("bytes_per_pixel", C.c_uint32), ("unique_symbols", C.c_uint32),
                 ("retried_rows", C.c_uint32), ("repaired_pixels", C.c_uint32)]
@@ -80,7 +84,7 @@ def synth_lib():
 ABI_SYMBOLS = (
     "optimize_with_rows", "optimize_with_stride", "optimizeForAverageFilter", "optimize_image",
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
-    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
+    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
     "pngloss_hip_last_histogram", "pngloss_hip_version",
 )
 
@@ -120,6 +124,8 @@ def hip_lib():
             lib.pngloss_hip_optimize_batch.restype = C.c_int
             lib.pngloss_hip_optimize_batch_host.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result)]
             lib.pngloss_hip_optimize_batch_host.restype = C.c_int
+            lib.pngloss_hip_optimize_batch_host_emit.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result), C.POINTER(Scanlines)]
+            lib.pngloss_hip_optimize_batch_host_emit.restype = C.c_int
             lib.pngloss_hip_last_engine_ms.argtypes = [C.c_void_p]
             lib.pngloss_hip_last_engine_ms.restype = C.c_double
             lib.pngloss_hip_last_total_ms.argtypes = [C.c_void_p]
@@ -238,6 +244,24 @@ class HipContext:
         res = (Result * max(n, 1))()
         _check(self._lib.pngloss_hip_optimize_batch_host(self._ctx, imgs, n, strength, bleed, res), "optimize_batch_host")
         return outs, filts, [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols) for r in res[:n]]
+
+    def run_host_emit(self, arrays, strength=19, bleed=2, want_filters=True):
+        """pngloss_hip_optimize_batch_host_emit: like run_host, plus per image (color_type, filter_types[H], scanlines[H, W*ch])."""
+        outs = [np.ascontiguousarray(a).copy() for a in arrays]
+        filts = [np.zeros(a.shape[0], np.uint8) if want_filters else None for a in outs]
+        n = len(outs)
+        imgs = (HostImage * max(n, 1))()
+        lines = (Scanlines * max(n, 1))()
+        ids = [np.zeros(a.shape[0], np.uint8) for a in outs]
+        rows = [np.zeros((a.shape[0], a.shape[1] * 4), np.uint8) for a in outs]
+        for i, (a, f) in enumerate(zip(outs, filts)):
+            imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
+            lines[i] = Scanlines(ids[i].ctypes.data, rows[i].ctypes.data, a.shape[1] * 4, -1)
+        res = (Result * max(n, 1))()
+        _check(self._lib.pngloss_hip_optimize_batch_host_emit(self._ctx, imgs, n, strength, bleed, res, lines), "optimize_batch_host_emit")
+        chans = {0: 1, 4: 2, 2: 3, 6: 4}
+        emitted = [(lines[i].color_type, ids[i], rows[i][:, : outs[i].shape[1] * chans[lines[i].color_type]].copy()) for i in range(n)]
+        return outs, filts, emitted
 
     @property
     def engine_ms(self):

@@ -253,3 +253,24 @@ def test_careful_int16_wrap_variant_of_the_chain():
     env = dict(os.environ, PNGLOSS_HIP_FORCE_CAREFUL="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=U.ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "careful ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_emitted_png_scanlines(torch_cuda):
+    """Write side, device part: colour type of the optimised pixels, per-row PNG filter types (heuristic on row 0 /
+    on every row in NULL mode, the optimiser's choice elsewhere) and the filtered bytes -- against a numpy restatement
+    applied to the ORACLE's output, for every class, ragged widths and both row_filters modes."""
+    specs = [(64, 48, 0), (70, 46, 2), (33, 77, 4), (96, 20, 3), (120, 50, 5), (1, 1, 1), (5, 3, 0), (257, 9, 2), (130, 40, 1), (31, 31, 4)]
+    imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+    # an RGB image whose optimised version happens to be ... still RGB, plus a constant image (gray output from "rgba" input)
+    imgs.append(np.full((9, 40, 4), 200, np.uint8))
+    ctx = P.HipContext()
+    for want_filters in (True, False):
+        outs, filts, emitted = ctx.run_host_emit(imgs, 19, 2, want_filters=want_filters)
+        for a, o, f, (ctype, ids, rows) in zip(imgs, outs, filts, emitted):
+            o1, f1 = U.run_port(a, 19, 2, want_filters)
+            assert np.array_equal(o, o1)
+            want_ct, want_ids, want_rows = U.png_scanlines_reference(o1, f1 if want_filters else None)
+            assert ctype == want_ct, (a.shape, ctype, want_ct)
+            assert np.array_equal(ids, want_ids), (a.shape, want_filters)
+            assert np.array_equal(rows, want_rows), (a.shape, want_filters)
+    ctx.close()

@@ -134,3 +134,43 @@ def seeded_cases(seed=7, n=24):
             img = (img // 86 * 127).astype(np.uint8)   # few distinct values: lots of saturated 0/254 runs and ties
         out.append((img, s, b, bool(i % 3)))
     return out
+
+
+def png_scanlines_reference(rgba_out, filter_flags):
+    """What a PNG encoder must deflate for the optimised image: (color_type, filter type per row, filtered rows).
+    numpy restatement of the writer side of the reference (rwpng.c:558-609 colour type + gray repack, :477-501
+    per-row filters, row 0 -- or every row when filter_flags is None -- by libpng's minimum-sum heuristic)."""
+    img = np.asarray(rgba_out)
+    h, w = img.shape[:2]
+    gray = bool((img[..., 0] == img[..., 1]).all() and (img[..., 1] == img[..., 2]).all())
+    opaque = bool((img[..., 3] == 255).all())
+    if gray:
+        raw = img[..., 1:2] if opaque else img[..., [1, 3]]
+        ctype = 0 if opaque else 4
+    else:
+        raw = img[..., :3] if opaque else img
+        ctype = 2 if opaque else 6
+    ch = raw.shape[2]
+    raw = raw.reshape(h, w * ch).astype(np.int32)
+    zeros = np.zeros(w * ch, np.int32)
+    ids = np.zeros(h, np.uint8)
+    rows = np.zeros((h, w * ch), np.uint8)
+    flag_to_id = {0x08: 0, 0x10: 1, 0x20: 2, 0x40: 3, 0x80: 4}
+    for y in range(h):
+        cur = raw[y]
+        up = raw[y - 1] if y else zeros
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]]) if w * ch > ch else np.zeros(w * ch, np.int32)
+        diag = np.concatenate([np.zeros(ch, np.int32), up[:-ch]]) if w * ch > ch else np.zeros(w * ch, np.int32)
+        p = left + up - diag
+        pa, pb, pc = np.abs(p - left), np.abs(p - up), np.abs(p - diag)
+        paeth = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, diag))
+        preds = [zeros, left, up, (left + up) >> 1, paeth]
+        res = [((cur - q) & 255) for q in preds]
+        if filter_flags is None or y == 0:
+            sums = [int(np.where(r < 128, r, 256 - r).sum()) for r in res]
+            f = sums.index(min(sums))
+        else:
+            f = flag_to_id[int(filter_flags[y])]
+        ids[y] = f
+        rows[y] = res[f].astype(np.uint8)
+    return ctype, ids, rows
