@@ -2,10 +2,10 @@
 pngloss_amd/cli/pngloss (decode threads -> one GPU batch -> encode threads) on the same PNG files."""
 import os, subprocess, sys, tempfile, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pngloss_amd as P
 from PIL import Image
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref", "pngloss_ref_cli")
 OURS = os.path.join(ROOT, "pngloss_amd", "cli", "pngloss")
 n, W, H = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 1280, 720

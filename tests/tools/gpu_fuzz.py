@@ -2,7 +2,7 @@
 and bleed dividers, both row_filters modes, plus the device batch API with mixed images.  usage: gpu_fuzz.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pngloss_amd as P
 from tests import util as U
 

@@ -1,5 +1,5 @@
 """Quick GPU bring-up check (not a test): HIP path vs the CPU oracle on seeded inputs + first timings.
-Run on the GPU box:  python tools/gpu_quick.py [--big]"""
+Run on the GPU box:  python tests/tools/gpu_quick.py [--big]"""
 import ctypes as C
 import os
 import sys
@@ -7,10 +7,10 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pngloss_amd as P  # noqa: E402
 
-port = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libpngloss_port.so"))
+port = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "libpngloss_port.so"))
 port.port_optimize_with_rows.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
 port.port_optimize_with_rows.restype = C.c_int
 
