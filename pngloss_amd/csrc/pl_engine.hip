@@ -233,7 +233,9 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         for (int g = 0; g < n; g += GL) {
         const int m = min(GL, n - g);
         uint32_t cap = 0;
-        for (int ii = 0; ii < m; ii++) {
+        /* one pixel step; called twice per loop iteration (manual 2x unroll: halves the loop-control and back-edge cost
+         * and lets the record registers alternate instead of being copied) */
+        auto pixel = [&](const int ii) {
             const int i = g + ii;
             const u32x4 rn = R[(((i + 1) & (PL_CHUNK - 1)) * 4 + c) * RS + half];   /* prefetch the next pixel's record */
             unsigned long long tA = 0, tC = 0, tD = 0, tE = 0;
@@ -406,7 +408,10 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             const uint32_t packed = (uint32_t)back | ((uint32_t)diff << 8);
             cap = (jl == ii) ? packed : cap;
             r = rn;
-        }
+        };
+        int ii = 0;
+        for (; ii + 1 < m; ii += 2) { pixel(ii); pixel(ii + 1); }
+        if (ii < m) pixel(ii);
         if (active && jl < m) outp[(size_t)(x0 + g + jl) * 4 + c] = cap;
         }
         };
