@@ -150,6 +150,30 @@ int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip
                                          unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
                                          pngloss_hip_scanlines *scanlines);
 
+/* Same again, but the device also DEFLATES the scanlines: per image the caller gets the complete zlib stream of the
+ * PNG's IDAT data (what /root/reference/src/rwpng.c:477-637 obtains from libpng + zlib level 9 on the CPU, and where
+ * the reference tool spends its time once the hot path is fast).  The stream inflates to exactly the scanlines the
+ * _emit call returns -- so the decoded PNG is identical -- but it is not the byte sequence zlib would write:
+ * the encoder is the GPU one of pngloss_amd/csrc/pl_deflate_core.h (multi-level match search, 256 KiB blocks that each
+ * end byte-aligned).  On the files of the reference's suite its output is 0-3 % smaller than zlib level 9 / Z_FILTERED.
+ * `data` must have room for pngloss_hip_zlib_bound(width, height) bytes; `size` = 0 for an empty image. */
+typedef struct {
+    unsigned char *data;      /* in: caller's buffer; out: zlib stream (header 78 DA ... Adler-32) */
+    size_t capacity;          /* in */
+    size_t size;              /* out */
+    int color_type;           /* out: 0, 2, 4 or 6 */
+    uint32_t blocks[3];       /* out: deflate blocks written as stored / fixed / dynamic */
+} pngloss_hip_zstream;
+
+size_t pngloss_hip_zlib_bound(uint32_t width, uint32_t height);
+
+int pngloss_hip_optimize_batch_host_zlib(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                         unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
+                                         pngloss_hip_zstream *streams);
+
+/* Milliseconds the last _zlib call spent in the deflate stage (device work + the block-size round trip). */
+double pngloss_hip_last_deflate_ms(const pngloss_hip_ctx *ctx);
+
 /* Duration in milliseconds of the row-engine kernel of the last finished batch, measured with hipEvents recorded
  * on the launch stream immediately around that kernel (what bench.py's roofline block reports).  < 0 if none. */
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx);

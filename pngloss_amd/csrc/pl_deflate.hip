@@ -1,0 +1,260 @@
+/*
+ * pl_deflate.hip -- zlib streams of the emitted scanlines, made on the GPU (the deflate half of
+ * /root/reference/src/rwpng.c:477-637, which libpng/zlib level 9 does on one CPU core and which is ~97 % of the tool's
+ * time once the row engine runs on the device).
+ *
+ * The algorithm lives in pl_deflate_core.h (also compiled for the CPU by tests/c/deflate_host.cpp, which checks it
+ * against zlib's inflate).  Here: the kernels that run it, and the host sequencing for a batch of images.
+ *
+ *   dfl_pack      scanlines (filter id + filtered bytes per row) of every image  ->  one contiguous byte stream
+ *   per level:    dfl_keys -> radix sort of (key, position) -> dfl_rank -> dfl_match      (all position-parallel)
+ *   dfl_encode    one wave per deflate block: parse, Huffman codes, bits; block outputs are byte-aligned
+ *   dfl_gather    compacts the block outputs into one buffer per image
+ *
+ * Positions are 32-bit: a call handles at most DFL_MAX_STREAM bytes of scanlines at a time (the caller's images are
+ * processed in groups).  Everything is HBM-resident; the only host round trip is the table of block sizes.
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "pl_deflate.h"
+#include "pl_deflate_core.h"
+
+namespace {
+
+constexpr uint32_t kThreads = 256;
+constexpr uint32_t kLevels[] = { 128, 32, 12, 6 };          /* key lengths, longest first (see dfl_search_level) */
+constexpr int kNumLevels = sizeof(kLevels) / sizeof(kLevels[0]);
+
+struct DflImageDev {
+    const uint8_t *ids;      /* filter type per row */
+    const uint8_t *rows;     /* filtered bytes, `pitch` apart */
+    uint32_t pitch, rowbytes;
+};
+
+__global__ __launch_bounds__(kThreads) void dfl_pack(const dfl_block_desc *desc, const DflImageDev *img, uint8_t *s)
+{
+    const dfl_block_desc d = desc[blockIdx.y];
+    const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
+    if (p >= d.end) return;
+    const DflImageDev im = img[d.image];
+    const uint32_t stride = im.rowbytes + 1u, o = p - d.img_begin;
+    const uint32_t y = o / stride, x = o - y * stride;
+    s[p] = x ? im.rows[(size_t)y * im.pitch + (x - 1u)] : im.ids[y];
+}
+
+__global__ __launch_bounds__(kThreads) void dfl_keys(const dfl_block_desc *desc, const uint8_t *s, uint32_t nbytes,
+                                                     uint64_t *key, uint32_t *val)
+{
+    const dfl_block_desc d = desc[blockIdx.y];
+    const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
+    if (p >= d.end) return;
+    key[p] = dfl_sort_key(s, p, d.img_end, nbytes);
+    val[p] = p;
+}
+
+__global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, uint32_t n, uint32_t *rank)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) rank[sorted[i]] = i;
+}
+
+__global__ __launch_bounds__(kThreads) void dfl_match(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *sorted,
+                                                      const uint64_t *skey, const uint32_t *rank, uint32_t max_chain,
+                                                      int first, uint32_t *match)
+{
+    const dfl_block_desc d = desc[blockIdx.y];
+    const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
+    if (p >= d.end) return;
+    match[p] = dfl_search_level(s, d.img_begin, d.img_end, p, sorted, skey, rank, max_chain, first ? 0u : match[p]);
+}
+
+__global__ __launch_bounds__(64) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match,
+                                                 dfl_params prm, uint32_t *tok, uint8_t *arena, dfl_block_result *result)
+{
+    __shared__ dfl_work work;
+    __shared__ dfl_block_result res;
+    const dfl_block_desc d = desc[blockIdx.x];
+    uint8_t *out = arena + d.out_offset;
+    /* the bit writer ORs nothing, it stores whole words; no need to clear `out` */
+    uint32_t a;
+    uint64_t b64;
+    dfl_adler_partial(s, d.begin, d.end, threadIdx.x, 64, &a, &b64);
+    unsigned long long b = b64;
+    for (int off = 32; off; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if (threadIdx.x == 0) {
+        res = dfl_encode_block(s, match, &d, &prm, tok + d.begin, out, &work);
+        res.adler_a = a;
+        res.adler_b = b;
+        result[blockIdx.x] = res;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void dfl_gather(const dfl_block_desc *desc, const dfl_block_result *result,
+                                                       const uint32_t *dest, const uint8_t *arena, uint8_t *compact)
+{
+    const dfl_block_desc d = desc[blockIdx.x];
+    const uint32_t n = result[blockIdx.x].bytes;
+    const uint8_t *src = arena + d.out_offset;
+    uint8_t *dst = compact + dest[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) dst[i] = src[i];
+}
+
+#define DFL_CHECK(expr)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            std::fprintf(stderr, "pngloss_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));                        \
+            rc = e_;                                                                                                   \
+            goto done;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+
+template <class T> hipError_t dev_alloc(T **p, size_t count) { return hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)); }
+
+/* one group of images whose streams fit 32-bit positions */
+hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm, hipStream_t stream)
+{
+    hipError_t rc = hipSuccess;
+    std::vector<dfl_block_desc> desc;
+    std::vector<DflImageDev> dev_img(n);
+    std::vector<uint32_t> first_block(n + 1, 0);
+    uint32_t total = 0, arena_bytes = 0, max_block = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t len = (imgs[i].rowbytes + 1u) * imgs[i].height;
+        dev_img[i] = DflImageDev{ imgs[i].d_filter_types, imgs[i].d_scanlines, imgs[i].pitch, imgs[i].rowbytes };
+        first_block[i] = (uint32_t)desc.size();
+        for (uint32_t b0 = 0; b0 < len; b0 += prm.block_bytes) {
+            const uint32_t bl = std::min(prm.block_bytes, len - b0);
+            desc.push_back(dfl_block_desc{ total + b0, total + b0 + bl, total, total + len, (uint32_t)i, arena_bytes, dfl_block_bound(bl), 0 });
+            arena_bytes += dfl_block_bound(bl);
+            max_block = std::max(max_block, bl);
+        }
+        total += len;
+    }
+    first_block[n] = (uint32_t)desc.size();
+    const uint32_t nblocks = (uint32_t)desc.size();
+    for (size_t i = 0; i < n; i++) imgs[i].out_size = 0;
+    if (!nblocks) return hipSuccess;
+
+    uint8_t *d_s = nullptr, *d_arena = nullptr, *d_compact = nullptr, *d_temp = nullptr;
+    uint64_t *d_key[2] = { nullptr, nullptr };
+    uint32_t *d_val[2] = { nullptr, nullptr }, *d_rank = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
+    dfl_block_desc *d_desc = nullptr;
+    dfl_block_result *d_result = nullptr;
+    DflImageDev *d_img = nullptr;
+    size_t temp_bytes = 0;
+    std::vector<dfl_block_result> result(nblocks);
+    std::vector<uint32_t> dest(nblocks);
+    std::vector<uint32_t> img_off(n + 1, 0);
+    const dim3 pos_grid((max_block + kThreads - 1) / kThreads, nblocks);
+
+    DFL_CHECK(dev_alloc(&d_s, (size_t)total + 512));              /* slack: the key/compare loads may run past the end */
+    DFL_CHECK(dev_alloc(&d_key[0], total));
+    DFL_CHECK(dev_alloc(&d_key[1], total));
+    DFL_CHECK(dev_alloc(&d_val[0], total));
+    DFL_CHECK(dev_alloc(&d_val[1], total));
+    DFL_CHECK(dev_alloc(&d_rank, total));
+    DFL_CHECK(dev_alloc(&d_match, total));
+    DFL_CHECK(dev_alloc(&d_tok, total));
+    DFL_CHECK(dev_alloc(&d_arena, arena_bytes));
+    DFL_CHECK(dev_alloc(&d_desc, nblocks));
+    DFL_CHECK(dev_alloc(&d_result, nblocks));
+    DFL_CHECK(dev_alloc(&d_dest, nblocks));
+    DFL_CHECK(dev_alloc(&d_img, n));
+    DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
+    DFL_CHECK(dev_alloc(&d_temp, temp_bytes));
+    DFL_CHECK(hipMemsetAsync(d_s + total, 0, 512, stream));
+    DFL_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(dfl_block_desc) * nblocks, hipMemcpyHostToDevice, stream));
+    DFL_CHECK(hipMemcpyAsync(d_img, dev_img.data(), sizeof(DflImageDev) * n, hipMemcpyHostToDevice, stream));
+
+    dfl_pack<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_img, d_s);
+    for (int lv = 0; lv < kNumLevels; lv++) {
+        dfl_keys<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, kLevels[lv], d_key[0], d_val[0]);
+        DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
+        dfl_rank<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], total, d_rank);
+        dfl_match<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_val[1], d_key[1], d_rank, prm.max_chain, lv == 0, d_match);
+    }
+    dfl_encode<<<nblocks, 64, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_arena, d_result);
+    DFL_CHECK(hipGetLastError());
+    DFL_CHECK(hipMemcpyAsync(result.data(), d_result, sizeof(dfl_block_result) * nblocks, hipMemcpyDeviceToHost, stream));
+    DFL_CHECK(hipStreamSynchronize(stream));
+
+    {   /* compact layout: image i's blocks back to back at img_off[i] */
+        uint32_t cursor = 0;
+        for (size_t i = 0; i < n; i++) {
+            img_off[i] = cursor;
+            for (uint32_t b = first_block[i]; b < first_block[i + 1]; b++) { dest[b] = cursor; cursor += result[b].bytes; }
+        }
+        img_off[n] = cursor;
+        DFL_CHECK(dev_alloc(&d_compact, (size_t)cursor + 16));
+        DFL_CHECK(hipMemcpyAsync(d_dest, dest.data(), sizeof(uint32_t) * nblocks, hipMemcpyHostToDevice, stream));
+        dfl_gather<<<nblocks, kThreads, 0, stream>>>(d_desc, d_result, d_dest, d_arena, d_compact);
+        DFL_CHECK(hipGetLastError());
+        DFL_CHECK(hipStreamSynchronize(stream));
+    }
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t body = img_off[i + 1] - img_off[i];
+        if (first_block[i] == first_block[i + 1]) continue;               /* empty image: no stream */
+        const size_t need = (size_t)DFL_ZLIB_HEAD_BYTES + body + DFL_ZLIB_TAIL_BYTES;
+        if (!imgs[i].out || imgs[i].out_capacity < need) { rc = hipErrorInvalidValue; goto done; }
+        unsigned char *o = imgs[i].out;
+        o[0] = 0x78; o[1] = 0xda;                                          /* deflate, 32 KiB window, "maximum compression" */
+        DFL_CHECK(hipMemcpy(o + 2, d_compact + img_off[i], body, hipMemcpyDeviceToHost));
+        uint32_t adler = 1;
+        uint32_t kinds[3] = { 0, 0, 0 };
+        for (uint32_t b = first_block[i]; b < first_block[i + 1]; b++) {
+            adler = dfl_adler_fold(adler, result[b].adler_a, result[b].adler_b, desc[b].end - desc[b].begin);
+            kinds[result[b].kind < 3 ? result[b].kind : 0]++;
+        }
+        unsigned char *t = o + 2 + body;
+        t[0] = 0x03; t[1] = 0x00;                                          /* final block: empty, fixed codes */
+        t[2] = (unsigned char)(adler >> 24); t[3] = (unsigned char)(adler >> 16); t[4] = (unsigned char)(adler >> 8); t[5] = (unsigned char)adler;
+        imgs[i].out_size = need;
+        imgs[i].blocks_stored = kinds[0]; imgs[i].blocks_fixed = kinds[1]; imgs[i].blocks_dynamic = kinds[2];
+    }
+done:
+    (void)hipFree(d_s); (void)hipFree(d_key[0]); (void)hipFree(d_key[1]); (void)hipFree(d_val[0]); (void)hipFree(d_val[1]);
+    (void)hipFree(d_rank); (void)hipFree(d_match); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
+    (void)hipFree(d_result); (void)hipFree(d_dest); (void)hipFree(d_img); (void)hipFree(d_temp); (void)hipFree(d_compact);
+    return rc;
+}
+
+} // namespace
+
+size_t pl_deflate_bound(uint32_t width, uint32_t height)
+{
+    const size_t len = ((size_t)width * 4 + 1) * height;
+    const size_t blocks = len / PL_DEFLATE_BLOCK_BYTES + 1;
+    return DFL_ZLIB_HEAD_BYTES + DFL_ZLIB_TAIL_BYTES + len + blocks * (5 * (PL_DEFLATE_BLOCK_BYTES / 65535 + 1) + 80);
+}
+
+hipError_t pl_deflate_images(pl_deflate_image *imgs, size_t n, hipStream_t stream)
+{
+    dfl_params prm = { PL_DEFLATE_MAX_CHAIN, DFL_KEY_BYTES, PL_DEFLATE_BLOCK_BYTES };
+    if (const char *e = std::getenv("PNGLOSS_HIP_DEFLATE_CHAIN")) prm.max_chain = (uint32_t)std::max(1, std::atoi(e));
+    size_t i = 0;
+    while (i < n) {
+        uint64_t bytes = 0;
+        size_t j = i;
+        while (j < n) {
+            const uint64_t len = ((uint64_t)imgs[j].rowbytes + 1u) * imgs[j].height;
+            if (len > PL_DEFLATE_MAX_STREAM) return hipErrorInvalidValue;   /* one image beyond 32-bit positions */
+            if (j > i && bytes + len > PL_DEFLATE_MAX_STREAM) break;
+            bytes += len;
+            ++j;
+        }
+        const hipError_t rc = deflate_group(imgs + i, j - i, prm, stream);
+        if (rc != hipSuccess) return rc;
+        i = j;
+    }
+    return hipSuccess;
+}

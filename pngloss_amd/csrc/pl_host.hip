@@ -7,7 +7,9 @@
  */
 #include "../../include/pngloss_hip.h"
 #include "pl_device.h"
+#include "pl_deflate.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +37,7 @@ struct pngloss_hip_ctx {
     size_t n_last = 0;
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; /* total start, engine start, engine stop, total stop */
-    double engine_ms = -1.0, total_ms = -1.0;
+    double engine_ms = -1.0, total_ms = -1.0, deflate_ms = -1.0;
     bool pending = false;
 };
 
@@ -343,7 +345,8 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
 }
 
 static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n, unsigned quantization_strength,
-                      long bleed_divider, pngloss_hip_result *results, pngloss_hip_scanlines *lines)
+                      long bleed_divider, pngloss_hip_result *results, pngloss_hip_scanlines *lines,
+                      pngloss_hip_zstream *zs = nullptr)
 {
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
@@ -356,9 +359,9 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         if (px && !images[i].rgba) return PNGLOSS_INVALID_ARGUMENT;
         img_off[i] = total; total = align_up(total + px * 4, 256);
         flt_off[i] = total; total = align_up(total + (images[i].row_filters ? images[i].height : 0), 256);
-        const bool want = lines && lines[i].scanlines && lines[i].filter_types && px;
+        const bool want = ((lines && lines[i].scanlines && lines[i].filter_types) || (zs && zs[i].data)) && px;
         const uint32_t pitch = want ? (uint32_t)align_up((size_t)images[i].width * 4, 16) : 0;
-        if (want && lines[i].pitch < (size_t)images[i].width * 4) return PNGLOSS_INVALID_ARGUMENT;
+        if (want && lines && lines[i].pitch < (size_t)images[i].width * 4) return PNGLOSS_INVALID_ARGUMENT;
         ids_off[i] = total; total = align_up(total + (want ? images[i].height : 0), 256);
         rows_off[i] = total; total = align_up(total + (size_t)pitch * (want ? images[i].height : 0), 256);
         emits[i].pitch = pitch;
@@ -383,7 +386,7 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         if (hipMemcpy(images[i].rgba, arena + img_off[i], px * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
         if (images[i].row_filters &&
             hipMemcpy(images[i].row_filters, arena + flt_off[i], images[i].height, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
-        if (emits[i].pitch) {
+        if (emits[i].pitch && lines) {
             uint32_t fl = 0;
             if (hipMemcpy(&fl, ctx->h_jobs[i].out_flags, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
             const bool g = fl & PL_FLAG_GRAY, o = fl & PL_FLAG_OPAQUE;
@@ -393,6 +396,41 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
             if (hipMemcpy2D(lines[i].scanlines, lines[i].pitch, emits[i].d_rows, emits[i].pitch, rowbytes, images[i].height,
                             hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
         }
+    }
+    if (zs && rc == PNGLOSS_SUCCESS) {
+        /* the colour type decides the scanline length, so it is fetched before the deflate stage is laid out */
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<pl_deflate_image> dz;
+        std::vector<size_t> who;
+        for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
+            zs[i].size = 0; zs[i].color_type = 6; zs[i].blocks[0] = zs[i].blocks[1] = zs[i].blocks[2] = 0;
+            if (!emits[i].pitch) continue;
+            uint32_t fl = 0;
+            if (hipMemcpy(&fl, ctx->h_jobs[i].out_flags, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
+            const bool g = fl & PL_FLAG_GRAY, o = fl & PL_FLAG_OPAQUE;
+            zs[i].color_type = g ? (o ? 0 : 4) : (o ? 2 : 6);
+            pl_deflate_image d{};
+            d.d_filter_types = static_cast<const uint8_t *>(emits[i].d_ids);
+            d.d_scanlines = static_cast<const uint8_t *>(emits[i].d_rows);
+            d.pitch = emits[i].pitch;
+            d.rowbytes = images[i].width * (g ? (o ? 1u : 2u) : (o ? 3u : 4u));
+            d.height = images[i].height;
+            d.out = zs[i].data;
+            d.out_capacity = zs[i].capacity;
+            dz.push_back(d);
+            who.push_back(i);
+        }
+        if (rc == PNGLOSS_SUCCESS && !dz.empty()) {
+            const hipError_t e = pl_deflate_images(dz.data(), dz.size(), nullptr);
+            if (e == hipErrorInvalidValue) rc = PNGLOSS_INVALID_ARGUMENT;
+            else if (e == hipErrorOutOfMemory) rc = PNGLOSS_OUT_OF_MEMORY_ERROR;
+            else if (e != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            for (size_t k = 0; k < dz.size() && rc == PNGLOSS_SUCCESS; k++) {
+                zs[who[k]].size = dz[k].out_size;
+                zs[who[k]].blocks[0] = dz[k].blocks_stored; zs[who[k]].blocks[1] = dz[k].blocks_fixed; zs[who[k]].blocks[2] = dz[k].blocks_dynamic;
+            }
+        }
+        ctx->deflate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     if (arena) (void)hipFree(arena);
     if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
@@ -411,6 +449,17 @@ int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip
 {
     return batch_host(ctx, images, n, quantization_strength, bleed_divider, results, scanlines);
 }
+
+int pngloss_hip_optimize_batch_host_zlib(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
+                                         unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
+                                         pngloss_hip_zstream *streams)
+{
+    if (!streams && n) return PNGLOSS_INVALID_ARGUMENT;
+    return batch_host(ctx, images, n, quantization_strength, bleed_divider, results, nullptr, streams);
+}
+
+size_t pngloss_hip_zlib_bound(uint32_t width, uint32_t height) { return pl_deflate_bound(width, height); }
+double pngloss_hip_last_deflate_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->deflate_ms : -1.0; }
 
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->engine_ms : -1.0; }
 double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->total_ms : -1.0; }

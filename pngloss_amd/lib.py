@@ -42,6 +42,11 @@ class Scanlines(C.Structure):
     _fields_ = [("filter_types", C.c_void_p), ("scanlines", C.c_void_p), ("pitch", C.c_size_t), ("color_type", C.c_int)]
 
 
+class ZStream(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("capacity", C.c_size_t), ("size", C.c_size_t), ("color_type", C.c_int),
+                ("blocks", C.c_uint32 * 3)]
+
+
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("bytes_per_pixel", C.c_uint32), ("unique_symbols", C.c_uint32),
                 ("retried_rows", C.c_uint32), ("repaired_pixels", C.c_uint32)]
@@ -84,7 +89,8 @@ def synth_lib():
 ABI_SYMBOLS = (
     "optimize_with_rows", "optimize_with_stride", "optimizeForAverageFilter", "optimize_image",
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
-    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
+    "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit",
+    "pngloss_hip_optimize_batch_host_zlib", "pngloss_hip_zlib_bound", "pngloss_hip_last_deflate_ms", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
     "pngloss_hip_last_histogram", "pngloss_hip_version",
 )
 
@@ -126,6 +132,12 @@ def hip_lib():
             lib.pngloss_hip_optimize_batch_host.restype = C.c_int
             lib.pngloss_hip_optimize_batch_host_emit.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result), C.POINTER(Scanlines)]
             lib.pngloss_hip_optimize_batch_host_emit.restype = C.c_int
+            lib.pngloss_hip_optimize_batch_host_zlib.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result), C.POINTER(ZStream)]
+            lib.pngloss_hip_optimize_batch_host_zlib.restype = C.c_int
+            lib.pngloss_hip_zlib_bound.argtypes = [C.c_uint32, C.c_uint32]
+            lib.pngloss_hip_zlib_bound.restype = C.c_size_t
+            lib.pngloss_hip_last_deflate_ms.argtypes = [C.c_void_p]
+            lib.pngloss_hip_last_deflate_ms.restype = C.c_double
             lib.pngloss_hip_last_engine_ms.argtypes = [C.c_void_p]
             lib.pngloss_hip_last_engine_ms.restype = C.c_double
             lib.pngloss_hip_last_total_ms.argtypes = [C.c_void_p]
@@ -262,6 +274,26 @@ class HipContext:
         chans = {0: 1, 4: 2, 2: 3, 6: 4}
         emitted = [(lines[i].color_type, ids[i], rows[i][:, : outs[i].shape[1] * chans[lines[i].color_type]].copy()) for i in range(n)]
         return outs, filts, emitted
+
+    def run_host_zlib(self, arrays, strength=19, bleed=2, want_filters=True):
+        """pngloss_hip_optimize_batch_host_zlib: like run_host, plus per image (color_type, zlib stream bytes, blocks)."""
+        outs = [np.ascontiguousarray(a).copy() for a in arrays]
+        filts = [np.zeros(a.shape[0], np.uint8) if want_filters else None for a in outs]
+        n = len(outs)
+        imgs = (HostImage * max(n, 1))()
+        zs = (ZStream * max(n, 1))()
+        bufs = [np.zeros(self._lib.pngloss_hip_zlib_bound(a.shape[1], a.shape[0]), np.uint8) for a in outs]
+        for i, (a, f) in enumerate(zip(outs, filts)):
+            imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
+            zs[i] = ZStream(bufs[i].ctypes.data, bufs[i].size, 0, -1, (C.c_uint32 * 3)(0, 0, 0))
+        res = (Result * max(n, 1))()
+        _check(self._lib.pngloss_hip_optimize_batch_host_zlib(self._ctx, imgs, n, strength, bleed, res, zs), "optimize_batch_host_zlib")
+        streams = [(zs[i].color_type, bufs[i][: zs[i].size].tobytes(), tuple(zs[i].blocks)) for i in range(n)]
+        return outs, filts, streams
+
+    @property
+    def deflate_ms(self):
+        return self._lib.pngloss_hip_last_deflate_ms(self._ctx)
 
     @property
     def engine_ms(self):

@@ -1,0 +1,103 @@
+/*
+ * deflate_host.cpp -- test driver: runs pngloss_amd/csrc/pl_deflate_core.h (the code the GPU kernels execute) serially
+ * on the CPU so that the bitstream logic can be checked against zlib's inflate where there is no GPU.
+ *
+ *   size_t dfl_host_zlib(in, n, out, cap, max_chain, min_len, block_bytes, stats[4])   -> zlib stream, 0 on overflow
+ *   built with -DDFL_MAIN: deflate_host FILE [max_chain min_len block_bytes]  prints sizes next to zlib level 9
+ */
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include <zlib.h>
+
+#include "../../pngloss_amd/csrc/pl_deflate_core.h"
+
+static uint32_t g_levels[8] = { 0 };
+extern "C" void dfl_host_set_levels(const uint32_t *lv, int n) { for (int i = 0; i < 8; i++) g_levels[i] = i < n ? lv[i] : 0; }
+
+extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, uint32_t max_chain,
+                                uint32_t min_len, uint32_t block_bytes, uint32_t *stats)
+{
+    dfl_params prm = { max_chain, min_len, block_bytes };
+    std::vector<uint64_t> key(n), skey(n);
+    std::vector<uint32_t> sorted(n), rank(n), match(n, 0u), tok(block_bytes ? block_bytes : 1);
+    static const uint32_t default_levels[] = { 6, 0 };
+    const uint32_t *levels = g_levels[0] ? g_levels : default_levels;
+    for (int lv = 0; levels[lv]; lv++) {
+        for (uint32_t p = 0; p < n; p++) key[p] = dfl_sort_key(in, p, n, levels[lv]);
+        std::iota(sorted.begin(), sorted.end(), 0u);
+        std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        for (uint32_t i = 0; i < n; i++) { rank[sorted[i]] = i; skey[i] = key[sorted[i]]; }
+        for (uint32_t p = 0; p < n; p++)
+            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), skey.data(), rank.data(), max_chain, match[p]);
+    }
+
+    size_t pos = 0;
+    if (cap < 8) return 0;
+    out[pos++] = 0x78; out[pos++] = 0xda;
+    uint32_t adler = 1;
+    dfl_work work;
+    std::vector<uint8_t> buf(dfl_block_bound(block_bytes) + 16);
+    if (stats) std::memset(stats, 0, 4 * sizeof(uint32_t));
+    for (uint32_t b0 = 0; b0 < n; b0 += block_bytes) {
+        dfl_block_desc d = { b0, std::min(n, b0 + block_bytes), 0, n, 0, 0, (uint32_t)buf.size(), 0 };
+        std::memset(buf.data(), 0, buf.size());
+        dfl_block_result r = dfl_encode_block(in, match.data(), &d, &prm, tok.data(), buf.data(), &work);
+        dfl_adler_partial(in, d.begin, d.end, 0, 1, &r.adler_a, &r.adler_b);
+        if (pos + r.bytes + 6 > cap) return 0;
+        std::memcpy(out + pos, buf.data(), r.bytes);
+        pos += r.bytes;
+        adler = dfl_adler_fold(adler, r.adler_a, r.adler_b, d.end - d.begin);
+        if (stats) { stats[r.kind]++; stats[3] += r.tokens; }
+    }
+    out[pos++] = 0x03; out[pos++] = 0x00;
+    out[pos++] = (uint8_t)(adler >> 24); out[pos++] = (uint8_t)(adler >> 16); out[pos++] = (uint8_t)(adler >> 8); out[pos++] = (uint8_t)adler;
+    return pos;
+}
+
+#ifdef DFL_MAIN
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: %s FILE [max_chain min_len block_bytes]\n", argv[0]); return 2; }
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) { std::perror(argv[1]); return 2; }
+    std::vector<uint8_t> in;
+    uint8_t tmp[65536];
+    size_t got;
+    while ((got = std::fread(tmp, 1, sizeof tmp, f)) > 0) in.insert(in.end(), tmp, tmp + got);
+    std::fclose(f);
+    const uint32_t max_chain = argc > 2 ? std::atoi(argv[2]) : 256, min_len = argc > 3 ? std::atoi(argv[3]) : 3,
+                   block = argc > 4 ? std::atoi(argv[4]) : 262144;
+    for (int i = 5; i < argc && i < 12; i++) g_levels[i - 5] = std::atoi(argv[i]);
+    std::vector<uint8_t> out(in.size() + in.size() / 8 + 1024);
+    uint32_t stats[4];
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t z = dfl_host_zlib(in.data(), (uint32_t)in.size(), out.data(), out.size(), max_chain, min_len, block, stats);
+    auto t1 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> back(in.size() + 16);
+    uLongf blen = back.size();
+    const int rc = uncompress(back.data(), &blen, out.data(), z);
+    const bool ok = rc == Z_OK && blen == in.size() && !std::memcmp(back.data(), in.data(), in.size());
+    /* zlib exactly as libpng drives it for the reference */
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, 9, Z_DEFLATED, 15, 9, Z_FILTERED);
+    std::vector<uint8_t> ref(deflateBound(&zs, in.size()));
+    zs.next_in = in.data(); zs.avail_in = (uInt)in.size(); zs.next_out = ref.data(); zs.avail_out = (uInt)ref.size();
+    auto t2 = std::chrono::steady_clock::now();
+    deflate(&zs, Z_FINISH);
+    auto t3 = std::chrono::steady_clock::now();
+    const size_t zref = zs.total_out;
+    deflateEnd(&zs);
+    std::printf("%s: in %zu  ours %zu (%s, stored/fixed/dyn %u/%u/%u, %u tokens, %.2fs)  zlib9f %zu (%.2fs)  ratio ours/zlib %.4f\n",
+                argv[1], in.size(), z, ok ? "roundtrip ok" : "ROUNDTRIP FAILED", stats[0], stats[1], stats[2], stats[3],
+                std::chrono::duration<double>(t1 - t0).count(), zref, std::chrono::duration<double>(t3 - t2).count(),
+                zref ? (double)z / zref : 0.0);
+    return ok ? 0 : 1;
+}
+#endif
