@@ -6,8 +6,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define PL_DEFLATE_BLOCK_BYTES 262144u          /* input bytes per deflate block */
-#define PL_DEFLATE_MAX_CHAIN   64u              /* candidates examined per position and search level */
+#include "pl_deflate_core.h"
+
+#define PL_DEFLATE_BLOCK_BYTES DFL_DEFAULT_BLOCK_BYTES
+#define PL_DEFLATE_MAX_CHAIN   DFL_DEFAULT_MAX_CHAIN
 #define PL_DEFLATE_MAX_STREAM  (1ull << 30)     /* scanline bytes handled per group (32-bit positions, ~40 B/position of workspace) */
 
 typedef struct {

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr uint32_t kThreads = 256;
-constexpr uint32_t kLevels[] = { 128, 32, 12, 6 };          /* key lengths, longest first (see dfl_search_level) */
+constexpr uint32_t kLevels[] = DFL_DEFAULT_LEVELS;            /* key lengths, longest first (see dfl_search_level) */
 constexpr int kNumLevels = sizeof(kLevels) / sizeof(kLevels[0]);
 
 struct DflImageDev {

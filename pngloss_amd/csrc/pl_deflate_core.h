@@ -36,6 +36,11 @@
                                           are not worth coding in filtered image data (zlib's Z_FILTERED rule) */
 #define DFL_TAIL_KEY   (1ull << 48)    /* sort key of positions that have no complete key inside their image */
 #define DFL_KEY_BITS   49
+/* encoder settings of the product (pl_deflate.hip) -- the CPU test driver uses the same ones, so that its output is
+ * byte-identical to the GPU's */
+#define DFL_DEFAULT_LEVELS      { 128u, 32u, 12u, 6u }     /* key lengths of the search levels, longest first */
+#define DFL_DEFAULT_MAX_CHAIN   64u                        /* candidates examined per position and level */
+#define DFL_DEFAULT_BLOCK_BYTES 262144u                    /* input bytes per deflate block */
 #define DFL_NUM_LL     288
 #define DFL_NUM_D      32              /* 30 used + 2 so that the tables have a round size */
 #define DFL_NUM_CL     19

@@ -272,7 +272,7 @@ class HipContext:
         res = (Result * max(n, 1))()
         _check(self._lib.pngloss_hip_optimize_batch_host_emit(self._ctx, imgs, n, strength, bleed, res, lines), "optimize_batch_host_emit")
         chans = {0: 1, 4: 2, 2: 3, 6: 4}
-        emitted = [(lines[i].color_type, ids[i], rows[i][:, : outs[i].shape[1] * chans[lines[i].color_type]].copy()) for i in range(n)]
+        emitted = [(lines[i].color_type, ids[i], rows[i][:, : outs[i].shape[1] * chans.get(lines[i].color_type, 4)].copy()) for i in range(n)]
         return outs, filts, emitted
 
     def run_host_zlib(self, arrays, strength=19, bleed=2, want_filters=True):

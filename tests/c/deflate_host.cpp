@@ -26,8 +26,11 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
     dfl_params prm = { max_chain, min_len, block_bytes };
     std::vector<uint64_t> key(n), skey(n);
     std::vector<uint32_t> sorted(n), rank(n), match(n, 0u), tok(block_bytes ? block_bytes : 1);
-    static const uint32_t default_levels[] = { 6, 0 };
+    static const uint32_t default_levels[] = { 128u, 32u, 12u, 6u, 0u };    /* DFL_DEFAULT_LEVELS, zero-terminated */
+    static const uint32_t check_levels[] = DFL_DEFAULT_LEVELS;
+    static_assert(sizeof(check_levels) == 4 * sizeof(uint32_t), "update default_levels");
     const uint32_t *levels = g_levels[0] ? g_levels : default_levels;
+    for (int k = 0; k < 4; k++) if (default_levels[k] != check_levels[k]) return 0;
     for (int lv = 0; levels[lv]; lv++) {
         for (uint32_t p = 0; p < n; p++) key[p] = dfl_sort_key(in, p, n, levels[lv]);
         std::iota(sorted.begin(), sorted.end(), 0u);

@@ -174,3 +174,41 @@ def png_scanlines_reference(rgba_out, filter_flags):
         ids[y] = f
         rows[y] = res[f].astype(np.uint8)
     return ctype, ids, rows
+
+
+# ---- CPU run of the GPU deflate core (tests/c/deflate_host.cpp) -------------------------------------------------
+_dfl = None
+
+
+def deflate_host_lib():
+    """tests/c/deflate_host.cpp built into a shared object (cached per process)."""
+    global _dfl
+    if _dfl is None:
+        import subprocess
+        import tempfile
+        so = os.path.join(tempfile.mkdtemp(prefix="dfl_host_"), "libdeflate_host.so")
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "c", "deflate_host.cpp"), "-lz"], check=True)
+        lib = C.CDLL(so)
+        lib.dfl_host_zlib.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.dfl_host_zlib.restype = C.c_size_t
+        _dfl = lib
+    return _dfl
+
+
+def deflate_host(data, max_chain=64, min_len=6, block_bytes=262144):
+    """zlib stream of `data` from the CPU run of pl_deflate_core.h; returns (bytes, stats[stored, fixed, dynamic, tokens])."""
+    lib = deflate_host_lib()
+    src = np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(0, np.uint8)
+    out = np.zeros(len(data) + len(data) // 4 + 4096, np.uint8)
+    stats = np.zeros(4, np.uint32)
+    n = lib.dfl_host_zlib(src.ctypes.data if len(data) else None, len(data), out.ctypes.data, out.size, max_chain, min_len,
+                          block_bytes, stats.ctypes.data)
+    assert n > 0
+    return out[:n].tobytes(), stats
+
+
+def zlib9_filtered(data):
+    """zlib the way libpng drives it for the reference's writer: level 9, memLevel 9, Z_FILTERED, 32 KiB window"""
+    import zlib
+    c = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_FILTERED)
+    return c.compress(data) + c.flush()
