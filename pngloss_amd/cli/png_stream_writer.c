@@ -87,6 +87,49 @@ static void fix_cmf(unsigned char *z, size_t data_size)
     z[1] = (unsigned char)tmp;
 }
 
+/* IDAT the way libpng writes it: one zlib stream over [filter byte, filtered row] x height, cut into 8192-byte chunks */
+static pngloss_error put_idat_zlib(sink *sp, const png_stream_image *im, size_t rowbytes, size_t data_size)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, 9, Z_DEFLATED, window_bits_for(data_size), 9, Z_FILTERED) != Z_OK) return LIBPNG_INIT_ERROR;
+    unsigned char *buf = malloc(IDAT_SLICE);
+    if (!buf) { deflateEnd(&z); return OUT_OF_MEMORY_ERROR; }
+    z.next_out = buf;
+    z.avail_out = IDAT_SLICE;
+    bool first = true;
+    pngloss_error rc = SUCCESS;
+    for (uint32_t y = 0; y <= im->height && rc == SUCCESS; y++) {
+        const bool last = y == im->height;
+        /* each row goes in as two pieces (type byte, bytes); deflate's output does not depend on how input is sliced */
+        for (int piece = 0; piece < (last ? 1 : 2) && rc == SUCCESS; piece++) {
+            unsigned char type_byte;
+            if (!last) {
+                if (piece == 0) { type_byte = im->filter_ids[y]; z.next_in = &type_byte; z.avail_in = 1; }
+                else { z.next_in = (Bytef *)(im->rows + (size_t)y * im->pitch); z.avail_in = (uInt)rowbytes; }
+            }
+            for (;;) {
+                const int zr = deflate(&z, last ? Z_FINISH : Z_NO_FLUSH);
+                if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { rc = LIBPNG_INIT_ERROR; break; }
+                if (z.avail_out == 0 || zr == Z_STREAM_END) {
+                    const size_t n = IDAT_SLICE - z.avail_out;
+                    if (n) {
+                        if (first) { fix_cmf(buf, data_size); first = false; }
+                        put_chunk(sp, "IDAT", buf, n);
+                    }
+                    z.next_out = buf;
+                    z.avail_out = IDAT_SLICE;
+                }
+                if (zr == Z_STREAM_END) break;
+                if (!last && z.avail_in == 0) break;
+            }
+        }
+    }
+    deflateEnd(&z);
+    free(buf);
+    return rc;
+}
+
 pngloss_error png_stream_write(FILE *out, const png_stream_image *im, size_t *bytes_written, size_t *metadata_bytes)
 {
     static const unsigned char signature[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
@@ -114,45 +157,15 @@ pngloss_error png_stream_write(FILE *out, const png_stream_image *im, size_t *by
     put_passthrough(&s, im->chunks, PNG_STREAM_HAVE_IHDR, &meta);
     put_passthrough(&s, im->chunks, PNG_STREAM_HAVE_PLTE, &meta);
 
-    /* ---- IDAT: one zlib stream over [filter byte, filtered row] x height, cut into 8192-byte chunks ---- */
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (deflateInit2(&z, 9, Z_DEFLATED, window_bits_for(data_size), 9, Z_FILTERED) != Z_OK) return LIBPNG_INIT_ERROR;
-    unsigned char *buf = malloc(IDAT_SLICE);
-    if (!buf) { deflateEnd(&z); return OUT_OF_MEMORY_ERROR; }
-    z.next_out = buf;
-    z.avail_out = IDAT_SLICE;
-    bool first = true;
-    pngloss_error rc = SUCCESS;
-    for (uint32_t y = 0; y <= im->height && rc == SUCCESS; y++) {
-        const bool last = y == im->height;
-        /* each row goes in as two pieces (type byte, bytes); deflate's output does not depend on how input is sliced */
-        for (int piece = 0; piece < (last ? 1 : 2) && rc == SUCCESS; piece++) {
-            unsigned char type_byte;
-            if (!last) {
-                if (piece == 0) { type_byte = im->filter_ids[y]; z.next_in = &type_byte; z.avail_in = 1; }
-                else { z.next_in = (Bytef *)(im->rows + (size_t)y * im->pitch); z.avail_in = (uInt)rowbytes; }
-            }
-            for (;;) {
-                const int zr = deflate(&z, last ? Z_FINISH : Z_NO_FLUSH);
-                if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { rc = LIBPNG_INIT_ERROR; break; }
-                if (z.avail_out == 0 || zr == Z_STREAM_END) {
-                    const size_t n = IDAT_SLICE - z.avail_out;
-                    if (n) {
-                        if (first) { fix_cmf(buf, data_size); first = false; }
-                        put_chunk(&s, "IDAT", buf, n);
-                    }
-                    z.next_out = buf;
-                    z.avail_out = IDAT_SLICE;
-                }
-                if (zr == Z_STREAM_END) break;
-                if (!last && z.avail_in == 0) break;
-            }
-        }
+    if (im->zdata) {
+        /* ---- IDAT from a zlib stream that was compressed on the GPU: framing only (a chunk holds < 2^31 bytes) ---- */
+        const size_t slice = (size_t)1 << 30;
+        for (size_t off = 0; off < im->zsize; off += slice)
+            put_chunk(&s, "IDAT", im->zdata + off, im->zsize - off < slice ? im->zsize - off : slice);
+    } else {
+        const pngloss_error rc = put_idat_zlib(&s, im, rowbytes, data_size);
+        if (rc != SUCCESS) return rc;
     }
-    deflateEnd(&z);
-    free(buf);
-    if (rc != SUCCESS) return rc;
 
     put_passthrough(&s, im->chunks, PNG_STREAM_AFTER_IDAT, &meta);
     put_chunk(&s, "IEND", NULL, 0);

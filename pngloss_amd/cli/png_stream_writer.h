@@ -23,6 +23,8 @@ typedef struct {
     bool tag_gamma, tag_srgb;          /* what rwpng.c:508-516 of the reference derives from output_color       */
     const struct rwpng_chunk *chunks;  /* ancillary chunks to pass through (list order = write order)           */
     size_t maximum_file_size;          /* 0 = unlimited, else TOO_LARGE_FILE beyond it                          */
+    const unsigned char *zdata;        /* optional: the finished zlib stream of the scanlines (GPU deflate); then    */
+    size_t zsize;                      /* filter_ids/rows are not read and no zlib runs here                          */
 } png_stream_image;
 
 pngloss_error png_stream_write(FILE *out, const png_stream_image *image, size_t *bytes_written, size_t *metadata_bytes);

@@ -38,6 +38,7 @@ struct options {
     unsigned long strength, bleed;
     unsigned num_files;
     bool from_stdin, to_stdout, force, skip_if_larger, strip, help, version, missing, verbose;
+    bool gpu_deflate;          /* --gpu-deflate: IDAT data compressed on the device instead of by zlib level 9 */
 };
 
 static const char usage_text[] =
@@ -54,6 +55,8 @@ static const char usage_text[] =
     "  --skip-if-larger  only save converted files if they're smaller than original\n"
     "  --ext new.png     set custom suffix/extension for output filenames\n"
     "  --strip           remove optional metadata (default on Mac)\n"
+    "  --gpu-deflate     compress the image data on the GPU too (not zlib's bytes, same pixels,\n"
+    "                    files as small as or smaller than zlib level 9, much faster)\n"
     "\n"
     "Lossily compresses PNGs by using more compressible colors that are close enough to the\n"
     "original values; the filter+quantise pass runs on the GPU (all files of a call as one batch).\n"
@@ -62,7 +65,7 @@ static const char usage_text[] =
 
 /* ------------------------------------------------------------------------------------------- options */
 
-enum { OPT_EXT = 256, OPT_NO_FORCE, OPT_SKIP_LARGER, OPT_STRIP };
+enum { OPT_EXT = 256, OPT_NO_FORCE, OPT_SKIP_LARGER, OPT_STRIP, OPT_GPU_DEFLATE };
 
 static bool parse_number(const char *text, unsigned long *out)
 {
@@ -82,6 +85,7 @@ static pngloss_error parse_options(int argc, char **argv, struct options *o)
         { "verbose", no_argument, NULL, 'v' },        { "quiet", no_argument, NULL, 'q' },
         { "skip-if-larger", no_argument, NULL, OPT_SKIP_LARGER }, { "strip", no_argument, NULL, OPT_STRIP },
         { "version", no_argument, NULL, 'V' },        { "help", no_argument, NULL, 'h' },
+        { "gpu-deflate", no_argument, NULL, OPT_GPU_DEFLATE },
         { NULL, 0, NULL, 0 },
     };
     for (int c; (c = getopt_long(argc, argv, "vqfo:Vhs:b:", table, NULL)) != -1;) {
@@ -93,6 +97,7 @@ static pngloss_error parse_options(int argc, char **argv, struct options *o)
         case OPT_EXT: o->extension = optarg; break;
         case OPT_SKIP_LARGER: o->skip_if_larger = true; break;
         case OPT_STRIP: o->strip = true; break;
+        case OPT_GPU_DEFLATE: o->gpu_deflate = true; break;
         case 'h': o->help = true; break;
         case 'V': o->version = true; break;
         case 'o':
@@ -140,6 +145,7 @@ struct job {
     png24_image in, out;
     unsigned char *filters;
     unsigned char *line_types, *lines;   /* filtered scanlines from the GPU: type byte per row, width*4-pitched rows */
+    size_t zsize;                        /* --gpu-deflate: `lines` holds the finished zlib stream of zsize bytes instead */
     int color_type;
     char *log;                /* buffered stderr text */
     size_t log_len;
@@ -227,7 +233,7 @@ static void decode_job(struct job *j, const struct options *o)
     j->out.row_pointers = malloc((H ? H : 1) * sizeof(unsigned char *));
     j->filters = malloc(H ? H : 1);
     j->line_types = malloc(H ? H : 1);
-    j->lines = malloc(bytes > 0 ? bytes : 1);
+    j->lines = malloc(o->gpu_deflate ? pngloss_hip_zlib_bound((uint32_t)W, (uint32_t)H) : (bytes > 0 ? bytes : 1));
     if (!j->out.rgba_data || !j->out.row_pointers || !j->filters || !j->line_types || !j->lines) { j->status = OUT_OF_MEMORY_ERROR; return; }
     for (size_t y = 0; y < H; y++) {
         j->out.row_pointers[y] = j->out.rgba_data + y * W * 4;
@@ -260,7 +266,7 @@ static pngloss_error encode_to(struct job *j, png24_image *img, unsigned char *f
         /* the optimised image: scanlines were filtered on the GPU, only deflate + chunk framing happen here */
         const png_stream_image si = { img->width, img->height, j->color_type, j->line_types, j->lines, (size_t)img->width * 4, img->gamma,
                                       img->output_color != RWPNG_GAMA_ONLY && img->output_color != RWPNG_NONE, img->output_color == RWPNG_SRGB,
-                                      img->chunks, img->maximum_file_size };
+                                      img->chunks, img->maximum_file_size, o->gpu_deflate ? j->lines : NULL, o->gpu_deflate ? j->zsize : 0 };
         rc = png_stream_write(f, &si, &img->file_size, &img->metadata_size);
     } else {
         rc = rwpng_write_image24(f, img, NULL);     /* the untouched original (pipe fallback): plain libpng */
@@ -353,21 +359,26 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
     /* stage 2: every decoded image of the window in one GPU batch */
     pngloss_hip_host_image *imgs = calloc(n ? n : 1, sizeof *imgs);
     pngloss_hip_scanlines *lines = calloc(n ? n : 1, sizeof *lines);
+    pngloss_hip_zstream *zs = calloc(n ? n : 1, sizeof *zs);
     pngloss_hip_result *res = calloc(n ? n : 1, sizeof *res);
     size_t *who = calloc(n ? n : 1, sizeof *who), m = 0;
-    if (!imgs || !lines || !res || !who) { free(imgs); free(lines); free(res); free(who); return OUT_OF_MEMORY_ERROR; }
+    if (!imgs || !lines || !zs || !res || !who) { free(imgs); free(lines); free(zs); free(res); free(who); return OUT_OF_MEMORY_ERROR; }
     for (size_t i = 0; i < n; i++)
         if (jobs[i].status == SUCCESS) {
             imgs[m] = (pngloss_hip_host_image){ jobs[i].out.rgba_data, jobs[i].filters, jobs[i].out.width, jobs[i].out.height };
             lines[m] = (pngloss_hip_scanlines){ jobs[i].line_types, jobs[i].lines, (size_t)jobs[i].out.width * 4, -1 };
+            zs[m] = (pngloss_hip_zstream){ jobs[i].lines, pngloss_hip_zlib_bound(jobs[i].out.width, jobs[i].out.height), 0, -1, { 0, 0, 0 } };
             who[m++] = i;
         }
     if (m) {
         if (!*ctx) *ctx = pngloss_hip_create(-1);
-        int rc = *ctx ? pngloss_hip_optimize_batch_host_emit(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res, lines) : PNGLOSS_HIP_ERROR;
+        int rc = !*ctx ? PNGLOSS_HIP_ERROR
+               : o->gpu_deflate ? pngloss_hip_optimize_batch_host_zlib(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res, zs)
+                                : pngloss_hip_optimize_batch_host_emit(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res, lines);
         for (size_t k = 0; k < m; k++) {
             jobs[who[k]].gpu = res[k];
-            jobs[who[k]].color_type = lines[k].color_type;
+            jobs[who[k]].color_type = o->gpu_deflate ? zs[k].color_type : lines[k].color_type;
+            jobs[who[k]].zsize = zs[k].size;
             if (rc != PNGLOSS_SUCCESS) {
                 /* unlike the reference (pngloss.c:266 ignores the return value) a failed optimisation is an error:
                  * there is no CPU path to fall back to, and writing an unoptimised file silently would be wrong */
@@ -376,7 +387,7 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
             }
         }
     }
-    free(imgs); free(lines); free(res); free(who);
+    free(imgs); free(lines); free(zs); free(res); free(who);
     const double t2 = now_s();
 
     for_each_job(jobs, n, o, encode_job);

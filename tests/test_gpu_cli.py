@@ -132,3 +132,41 @@ def test_batch_cli_pipe_ext_and_skip_if_larger(tmp_path):
     b = subprocess.run([REF_CLI, "-f", "-s", "0", "--skip-if-larger", "-o", str(tmp_path / "o2.png"), str(noise)], capture_output=True, timeout=300)
     assert a.returncode == b.returncode
     assert (tmp_path / "o1.png").exists() == (tmp_path / "o2.png").exists()
+
+
+@needs_our_cli
+def test_batch_cli_gpu_deflate_same_pixels_same_filters_not_larger(tmp_path):
+    """--gpu-deflate: the IDAT bytes are not zlib's, everything a decoder sees is what the reference tool wrote:
+    pixels, colour type, per-row filter bytes, ancillary chunks; and the files are not larger."""
+    import io
+    from PIL import Image
+    import pngloss_amd as P
+    g = U.load_npz("suite_small.npz")
+    inputs = {"david": g["david/in"], "rose": g["rose/in"], "tux": g["tux/in"]}
+    for i, (w, h, m) in enumerate([(640, 360, 0), (130, 9, 2), (96, 64, 3), (33, 77, 4), (320, 200, 5), (1, 1, 1), (700, 300, 1)]):
+        inputs[f"synth{i}"] = P.synth_rgba(w, h, m, i)
+    a_dir, b_dir = tmp_path / "zlib", tmp_path / "gpu"
+    a_dir.mkdir(); b_dir.mkdir()
+    for name, arr in inputs.items():
+        _write_png(str(a_dir / f"{name}.png"), arr)
+        _write_png(str(b_dir / f"{name}.png"), arr)
+    names = sorted(inputs)
+    ra = subprocess.run([OUR_CLI, "-s", "19", "-b", "2"] + [str(a_dir / f"{n}.png") for n in names], capture_output=True, text=True, timeout=600)
+    rb = subprocess.run([OUR_CLI, "--gpu-deflate", "-v", "-s", "19", "-b", "2"] + [str(b_dir / f"{n}.png") for n in names], capture_output=True, text=True, timeout=600)
+    assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr[-400:], rb.stderr[-400:])
+    total_a = total_b = 0
+    for n in names:
+        a = (a_dir / f"{n}-loss.png").read_bytes()
+        b = (b_dir / f"{n}-loss.png").read_bytes()
+        h, w = inputs[n].shape[:2]
+        assert np.array_equal(np.array(Image.open(io.BytesIO(a)).convert("RGBA")), np.array(Image.open(io.BytesIO(b)).convert("RGBA"))), n
+        assert _idat_filter_bytes(a, w, h) == _idat_filter_bytes(b, w, h), n
+        assert a[:33] == b[:33]                                       # signature + IHDR
+        total_a += len(a); total_b += len(b)
+    assert total_b <= 1.005 * total_a
+    # the pipe contract holds with the option as well
+    data = (a_dir / "synth4.png").read_bytes()
+    p1 = subprocess.run([OUR_CLI, "-s20", "-b2", "--strip", "-"], input=data, capture_output=True, timeout=300)
+    p2 = subprocess.run([OUR_CLI, "--gpu-deflate", "-s20", "-b2", "--strip", "-"], input=data, capture_output=True, timeout=300)
+    assert p1.returncode == p2.returncode == 0
+    assert np.array_equal(np.array(Image.open(io.BytesIO(p1.stdout)).convert("RGBA")), np.array(Image.open(io.BytesIO(p2.stdout)).convert("RGBA")))

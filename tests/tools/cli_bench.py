@@ -19,6 +19,15 @@ with tempfile.TemporaryDirectory() as d:
     r = subprocess.run([OURS, "-f", "--ext", "-ours.png"] + files, capture_output=True, text=True, env=dict(os.environ, PNGLOSS_TIMING="1")); print(r.stderr.strip())
     t_ours = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-500:]
+    t = time.perf_counter()
+    r = subprocess.run([OURS, "-f", "--gpu-deflate", "--ext", "-gpu.png"] + files, capture_output=True, text=True, env=dict(os.environ, PNGLOSS_TIMING="1")); print(r.stderr.strip())
+    t_gpu = time.perf_counter() - t
+    assert r.returncode == 0, r.stderr[-500:]
+    size_ours = sum(os.path.getsize(p[:-4] + "-ours.png") for p in files)
+    size_gpu = sum(os.path.getsize(p[:-4] + "-gpu.png") for p in files)
+    same_px = all(np.array_equal(np.array(Image.open(p[:-4] + "-ours.png")), np.array(Image.open(p[:-4] + "-gpu.png"))) for p in files[:4])
+    print(f"{n} files {W}x{H} with --gpu-deflate: {t_gpu:.2f} s ({n*W*H/t_gpu/1e6:.1f} Mpx/s end to end); total size {size_gpu} B vs zlib-9 {size_ours} B "
+          f"({size_gpu/size_ours:.4f}); same decoded pixels: {same_px}")
     nref = min(n, 4)
     t = time.perf_counter()
     for p in files[:nref]:
