@@ -58,20 +58,26 @@ __global__ __launch_bounds__(kThreads) void dfl_keys(const dfl_block_desc *desc,
     val[p] = p;
 }
 
-__global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, uint32_t n, uint32_t *rank)
+/* rank[p] = index of p in the sorted order; flag[i] = i where a new key group starts (else 0): an inclusive max-scan
+ * of flag[] then gives every entry the index of the first entry of its group */
+__global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, const uint64_t *skey, uint32_t n,
+                                                     uint32_t *rank, uint32_t *flag)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i < n) rank[sorted[i]] = i;
+    if (i >= n) return;
+    rank[sorted[i]] = i;
+    flag[i] = (i && skey[i] != skey[i - 1]) ? i : 0u;
 }
 
 __global__ __launch_bounds__(kThreads) void dfl_match(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *sorted,
-                                                      const uint64_t *skey, const uint32_t *rank, uint32_t max_chain,
+                                                      const uint32_t *group_start, const uint32_t *rank, uint32_t max_chain,
                                                       int first, uint32_t *match)
 {
     const dfl_block_desc d = desc[blockIdx.y];
     const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
     if (p >= d.end) return;
-    match[p] = dfl_search_level(s, d.img_begin, d.img_end, p, sorted, skey, rank, max_chain, first ? 0u : match[p]);
+    const uint32_t r = rank[p];
+    match[p] = dfl_search_level(s, d.img_begin, d.img_end, p, sorted, r, group_start[r], max_chain, first ? 0u : match[p]);
 }
 
 __global__ __launch_bounds__(64) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match,
@@ -151,7 +157,8 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     dfl_block_desc *d_desc = nullptr;
     dfl_block_result *d_result = nullptr;
     DflImageDev *d_img = nullptr;
-    size_t temp_bytes = 0;
+    size_t temp_bytes = 0, scan_bytes = 0;
+    uint32_t *d_flag = nullptr, *d_gstart = nullptr;
     std::vector<dfl_block_result> result(nblocks);
     std::vector<uint32_t> dest(nblocks);
     std::vector<uint32_t> img_off(n + 1, 0);
@@ -171,6 +178,10 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     DFL_CHECK(dev_alloc(&d_dest, nblocks));
     DFL_CHECK(dev_alloc(&d_img, n));
     DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
+    d_flag = d_val[0];                                             /* both are free between the sort and the next level's keys */
+    d_gstart = reinterpret_cast<uint32_t *>(d_key[0]);
+    DFL_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
+    temp_bytes = std::max(temp_bytes, scan_bytes);
     DFL_CHECK(dev_alloc(&d_temp, temp_bytes));
     DFL_CHECK(hipMemsetAsync(d_s + total, 0, 512, stream));
     DFL_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(dfl_block_desc) * nblocks, hipMemcpyHostToDevice, stream));
@@ -180,8 +191,9 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     for (int lv = 0; lv < kNumLevels; lv++) {
         dfl_keys<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, kLevels[lv], d_key[0], d_val[0]);
         DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
-        dfl_rank<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], total, d_rank);
-        dfl_match<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_val[1], d_key[1], d_rank, prm.max_chain, lv == 0, d_match);
+        dfl_rank<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], d_key[1], total, d_rank, d_flag);
+        DFL_CHECK(hipcub::DeviceScan::InclusiveScan(d_temp, temp_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
+        dfl_match<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_val[1], d_gstart, d_rank, prm.max_chain, lv == 0, d_match);
     }
     dfl_encode<<<nblocks, 64, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_arena, d_result);
     DFL_CHECK(hipGetLastError());

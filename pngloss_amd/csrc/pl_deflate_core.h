@@ -117,15 +117,14 @@ DFL_HD uint64_t dfl_sort_key(const uint8_t *s, uint32_t p, uint32_t img_end, uin
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. longest match of position p.  One search level = positions stably sorted by dfl_sort_key: `sorted` holds the
- * positions, `skey` their keys in the same order, `rank[p]` is p's index.  Walking down from rank[p]-1 visits earlier
- * positions that start with the same bytes, nearest first; the walk ends at the first entry with another key, outside
- * the 32 KiB window or outside the image.  Of equally long matches the nearest is kept (cheapest distance code).
+ * positions, `r` is p's index in it and `group_start` the index of the first entry with p's key.  Walking down from
+ * r-1 visits earlier positions that start with the same bytes, nearest first; the walk ends at the start of the group,
+ * outside the 32 KiB window or outside the image.  Of equally long matches the nearest is kept (cheapest distance code).
  * Levels with longer keys find the long matches that hide deep in the six-byte groups of near-constant image data;
  * `best` (a match record or 0) is carried from level to level.
  * ------------------------------------------------------------------------------------------------------------- */
 DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t img_end, uint32_t p,
-                                 const uint32_t *sorted, const uint64_t *skey, const uint32_t *rank,
-                                 uint32_t max_chain, uint32_t best)
+                                 const uint32_t *sorted, uint32_t r, uint32_t group_start, uint32_t max_chain, uint32_t best)
 {
     const uint32_t room = img_end - p;
     if (room < DFL_KEY_BYTES) return best;
@@ -133,12 +132,9 @@ DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t 
     const uint8_t *b = s + p;
     uint32_t best_len = best ? DFL_TOK_LEN(best) : DFL_KEY_BYTES - 1, best_dist = best ? DFL_TOK_DIST(best) : 0;
     if (best_len >= max_len) return best;
-    uint32_t r = rank[p];
-    const uint64_t key = skey[r];
-    for (uint32_t chain = max_chain; chain && r; --chain) {
-        --r;
-        const uint32_t q = sorted[r];
-        if (skey[r] != key || q < img_begin || p - q > DFL_WINDOW) break;
+    for (uint32_t chain = max_chain; chain && r > group_start; --chain) {
+        const uint32_t q = sorted[--r];
+        if (q < img_begin || p - q > DFL_WINDOW) break;
         const uint8_t *a = s + q;
         if (a[best_len] != b[best_len]) continue;                                /* cannot beat the best: skip */
         uint32_t len = 0;

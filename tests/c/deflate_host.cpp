@@ -25,7 +25,7 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
 {
     dfl_params prm = { max_chain, min_len, block_bytes };
     std::vector<uint64_t> key(n), skey(n);
-    std::vector<uint32_t> sorted(n), rank(n), match(n, 0u), tok(block_bytes ? block_bytes : 1);
+    std::vector<uint32_t> sorted(n), rank(n), gstart(n), match(n, 0u), tok(block_bytes ? block_bytes : 1);
     static const uint32_t default_levels[] = { 128u, 32u, 12u, 6u, 0u };    /* DFL_DEFAULT_LEVELS, zero-terminated */
     static const uint32_t check_levels[] = DFL_DEFAULT_LEVELS;
     static_assert(sizeof(check_levels) == 4 * sizeof(uint32_t), "update default_levels");
@@ -35,9 +35,13 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
         for (uint32_t p = 0; p < n; p++) key[p] = dfl_sort_key(in, p, n, levels[lv]);
         std::iota(sorted.begin(), sorted.end(), 0u);
         std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-        for (uint32_t i = 0; i < n; i++) { rank[sorted[i]] = i; skey[i] = key[sorted[i]]; }
+        for (uint32_t i = 0; i < n; i++) {
+            rank[sorted[i]] = i;
+            skey[i] = key[sorted[i]];
+            gstart[i] = (i && skey[i] == skey[i - 1]) ? gstart[i - 1] : i;
+        }
         for (uint32_t p = 0; p < n; p++)
-            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), skey.data(), rank.data(), max_chain, match[p]);
+            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), rank[p], gstart[rank[p]], max_chain, match[p]);
     }
 
     size_t pos = 0;
