@@ -8,7 +8,7 @@
  *
  *   dfl_pack      scanlines (filter id + filtered bytes per row) of every image  ->  one contiguous byte stream
  *   per level:    dfl_keys -> radix sort of (key, position) -> dfl_rank -> dfl_match      (all position-parallel)
- *   dfl_encode    one wave per deflate block: parse, Huffman codes, bits; block outputs are byte-aligned
+ *   dfl_encode    one workgroup per deflate block (pl_deflate_coop.h): parse, Huffman codes, bits; byte-aligned outputs
  *   dfl_gather    compacts the block outputs into one buffer per image
  *
  * Positions are 32-bit: a call handles at most DFL_MAX_STREAM bytes of scanlines at a time (the caller's images are
@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "pl_deflate.h"
-#include "pl_deflate_core.h"
+#include "pl_deflate_coop.h"
 
 namespace {
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void dfl_pack(const dfl_block_desc *desc,
 }
 
 __global__ __launch_bounds__(kThreads) void dfl_keys(const dfl_block_desc *desc, const uint8_t *s, uint32_t nbytes,
-                                                     uint64_t *key, uint32_t *val)
+                                                     uint32_t *key, uint32_t *val)
 {
     const dfl_block_desc d = desc[blockIdx.y];
     const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void dfl_keys(const dfl_block_desc *desc,
 
 /* rank[p] = index of p in the sorted order; flag[i] = i where a new key group starts (else 0): an inclusive max-scan
  * of flag[] then gives every entry the index of the first entry of its group */
-__global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, const uint64_t *skey, uint32_t n,
+__global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, const uint32_t *skey, uint32_t n,
                                                      uint32_t *rank, uint32_t *flag)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -71,37 +71,26 @@ __global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, con
 
 __global__ __launch_bounds__(kThreads) void dfl_match(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *sorted,
                                                       const uint32_t *group_start, const uint32_t *rank, uint32_t max_chain,
-                                                      int first, uint32_t *match)
+                                                      uint32_t longer_key_bytes, uint32_t *match)
 {
     const dfl_block_desc d = desc[blockIdx.y];
     const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
     if (p >= d.end) return;
     const uint32_t r = rank[p];
-    match[p] = dfl_search_level(s, d.img_begin, d.img_end, p, sorted, r, group_start[r], max_chain, first ? 0u : match[p]);
+    match[p] = dfl_search_level(s, d.img_begin, d.img_end, p, sorted, r, group_start[r], max_chain, longer_key_bytes,
+                                longer_key_bytes ? match[p] : 0u);
 }
 
-__global__ __launch_bounds__(64) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match,
-                                                 dfl_params prm, uint32_t *tok, uint8_t *arena, dfl_block_result *result)
+/* one 256-thread workgroup per deflate block: pl_deflate_coop.h; `arena` must be zero (the bits are OR-ed in) */
+__global__ __launch_bounds__(kThreads) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match,
+                                                       dfl_params prm, uint32_t *tok, uint32_t *litsum, uint8_t *arena,
+                                                       dfl_block_result *result)
 {
-    __shared__ dfl_work work;
-    __shared__ dfl_block_result res;
+    __shared__ dfl_coop shared;
     const dfl_block_desc d = desc[blockIdx.x];
-    uint8_t *out = arena + d.out_offset;
-    /* the bit writer ORs nothing, it stores whole words; no need to clear `out` */
-    uint32_t a;
-    uint64_t b64;
-    dfl_adler_partial(s, d.begin, d.end, threadIdx.x, 64, &a, &b64);
-    unsigned long long b = b64;
-    for (int off = 32; off; off >>= 1) {
-        a += __shfl_down(a, off);
-        b += __shfl_down(b, off);
-    }
-    if (threadIdx.x == 0) {
-        res = dfl_encode_block(s, match, &d, &prm, tok + d.begin, out, &work);
-        res.adler_a = a;
-        res.adler_b = b;
-        result[blockIdx.x] = res;
-    }
+    dfl_team team = { threadIdx.x, kThreads, nullptr, nullptr };
+    const dfl_block_result res = dfl_encode_block_coop(&team, s, match, &d, &prm, tok + d.begin, litsum, arena + d.out_offset, &shared);
+    if (threadIdx.x == 0) result[blockIdx.x] = res;
 }
 
 __global__ __launch_bounds__(kThreads) void dfl_gather(const dfl_block_desc *desc, const dfl_block_result *result,
@@ -152,7 +141,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     if (!nblocks) return hipSuccess;
 
     uint8_t *d_s = nullptr, *d_arena = nullptr, *d_compact = nullptr, *d_temp = nullptr;
-    uint64_t *d_key[2] = { nullptr, nullptr };
+    uint32_t *d_key[2] = { nullptr, nullptr };
     uint32_t *d_val[2] = { nullptr, nullptr }, *d_rank = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
     dfl_block_desc *d_desc = nullptr;
     dfl_block_result *d_result = nullptr;
@@ -179,7 +168,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     DFL_CHECK(dev_alloc(&d_img, n));
     DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
     d_flag = d_val[0];                                             /* both are free between the sort and the next level's keys */
-    d_gstart = reinterpret_cast<uint32_t *>(d_key[0]);
+    d_gstart = d_key[0];
     DFL_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
     temp_bytes = std::max(temp_bytes, scan_bytes);
     DFL_CHECK(dev_alloc(&d_temp, temp_bytes));
@@ -193,9 +182,10 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
         DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
         dfl_rank<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], d_key[1], total, d_rank, d_flag);
         DFL_CHECK(hipcub::DeviceScan::InclusiveScan(d_temp, temp_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
-        dfl_match<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_val[1], d_gstart, d_rank, prm.max_chain, lv == 0, d_match);
+        dfl_match<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_val[1], d_gstart, d_rank, prm.max_chain, lv ? kLevels[lv - 1] : 0u, d_match);
     }
-    dfl_encode<<<nblocks, 64, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_arena, d_result);
+    DFL_CHECK(hipMemsetAsync(d_arena, 0, arena_bytes, stream));
+    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_rank /* free now: literal price sums */, d_arena, d_result);
     DFL_CHECK(hipGetLastError());
     DFL_CHECK(hipMemcpyAsync(result.data(), d_result, sizeof(dfl_block_result) * nblocks, hipMemcpyDeviceToHost, stream));
     DFL_CHECK(hipStreamSynchronize(stream));

@@ -34,11 +34,11 @@
 #define DFL_MAX_MATCH  258u
 #define DFL_KEY_BYTES  6u              /* positions are grouped by their first six bytes: matches shorter than that
                                           are not worth coding in filtered image data (zlib's Z_FILTERED rule) */
-#define DFL_TAIL_KEY   (1ull << 48)    /* sort key of positions that have no complete key inside their image */
-#define DFL_KEY_BITS   49
+#define DFL_TAIL_KEY   0xffffffffu     /* sort key of positions that have no complete key inside their image */
+#define DFL_KEY_BITS   32
 /* encoder settings of the product (pl_deflate.hip) -- the CPU test driver uses the same ones, so that its output is
  * byte-identical to the GPU's */
-#define DFL_DEFAULT_LEVELS      { 128u, 32u, 12u, 6u }     /* key lengths of the search levels, longest first */
+#define DFL_DEFAULT_LEVELS      { 128u, 64u, 32u, 16u, 12u, 8u, 6u }   /* key lengths of the search levels, longest first */
 #define DFL_DEFAULT_MAX_CHAIN   64u                        /* candidates examined per position and level */
 #define DFL_DEFAULT_BLOCK_BYTES 262144u                    /* input bytes per deflate block */
 #define DFL_NUM_LL     288
@@ -101,18 +101,27 @@ DFL_HD uint64_t dfl_key_at(const uint8_t *p)
     return (uint64_t)dfl_load32(p) | ((uint64_t)hi << 32);
 }
 
-/* Sort key of position p at a search level that groups positions by their first `nbytes` bytes: the bytes themselves
- * for the six-byte level, a 64-bit hash of them for the longer ones (collisions only cost a wasted comparison). */
-DFL_HD uint64_t dfl_sort_key(const uint8_t *s, uint32_t p, uint32_t img_end, uint32_t nbytes)
+/* Sort key of position p at a search level that groups positions by their first `nbytes` bytes: a 32-bit hash of
+ * them.  A collision merges two groups, which only costs wasted comparisons (every candidate is verified byte by
+ * byte); positions too close to the end of their image for a full key share one catch-all group. */
+DFL_HD uint32_t dfl_sort_key(const uint8_t *s, uint32_t p, uint32_t img_end, uint32_t nbytes)
 {
-    if (p + nbytes > img_end) return DFL_TAIL_KEY | p;           /* unique: a group of one */
-    if (nbytes == DFL_KEY_BYTES) return dfl_key_at(s + p);
+    if (p + nbytes > img_end) return DFL_TAIL_KEY;
+    if (nbytes == DFL_KEY_BYTES) {
+        const uint64_t k = dfl_key_at(s + p) * 0x9e3779b97f4a7c15ull;
+        return (uint32_t)(k >> 32);
+    }
     uint64_t h = 0x9e3779b97f4a7c15ull;
-    for (uint32_t i = 0; i + 4 <= nbytes; i += 4) {
+    uint32_t i = 0;
+    for (; i + 4 <= nbytes; i += 4) {
         h = (h ^ dfl_load32(s + p + i)) * 0xff51afd7ed558ccdull;
         h ^= h >> 29;
     }
-    return h & (DFL_TAIL_KEY - 1);                                /* the sort looks at DFL_KEY_BITS bits */
+    for (; i < nbytes; i++) {
+        h = (h ^ s[p + i]) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    return (uint32_t)(h >> 32);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -121,10 +130,12 @@ DFL_HD uint64_t dfl_sort_key(const uint8_t *s, uint32_t p, uint32_t img_end, uin
  * r-1 visits earlier positions that start with the same bytes, nearest first; the walk ends at the start of the group,
  * outside the 32 KiB window or outside the image.  Of equally long matches the nearest is kept (cheapest distance code).
  * Levels with longer keys find the long matches that hide deep in the six-byte groups of near-constant image data;
- * `best` (a match record or 0) is carried from level to level.
+ * `best` (a match record or 0) is carried from level to level, `longer_key_bytes` is the key length of the level
+ * before this one (0 for the first).
  * ------------------------------------------------------------------------------------------------------------- */
 DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t img_end, uint32_t p,
-                                 const uint32_t *sorted, uint32_t r, uint32_t group_start, uint32_t max_chain, uint32_t best)
+                                 const uint32_t *sorted, uint32_t r, uint32_t group_start, uint32_t max_chain,
+                                 uint32_t longer_key_bytes, uint32_t best)
 {
     const uint32_t room = img_end - p;
     if (room < DFL_KEY_BYTES) return best;
@@ -132,6 +143,10 @@ DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t 
     const uint8_t *b = s + p;
     uint32_t best_len = best ? DFL_TOK_LEN(best) : DFL_KEY_BYTES - 1, best_dist = best ? DFL_TOK_DIST(best) : 0;
     if (best_len >= max_len) return best;
+    /* A candidate that beats a match of >= longer_key_bytes shares that many bytes with p, so it is in p's group of
+     * the previous (longer-key) level; being among the nearest max_chain here it was among the nearest there and has
+     * been examined already: this level cannot improve the match. */
+    if (longer_key_bytes && best_len >= longer_key_bytes) return best;
     for (uint32_t chain = max_chain; chain && r > group_start; --chain) {
         const uint32_t q = sorted[--r];
         if (q < img_begin || p - q > DFL_WINDOW) break;
@@ -222,6 +237,74 @@ DFL_HD uint32_t dfl_parse_block(const uint8_t *s, const uint32_t *match, uint32_
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * 3a'. second parse, by price.  Filtered image data has very cheap literals (a handful of small values), so a short
+ * match at a long distance can cost more bits than the literals it replaces -- the classic weakness of choosing by
+ * length.  With the code lengths of the first parse as prices, a match is used only if it is cheaper than its bytes
+ * as literals, and the lazy step compares the SAVINGS of the match here and of the match at the next position.
+ * litsum[p] = price of the bytes [begin, p] as literals (inclusive prefix sums, filled in by dfl_literal_prices).
+ * ------------------------------------------------------------------------------------------------------------- */
+#define DFL_UNSEEN_PRICE 12u           /* bits charged for a symbol the first parse never used */
+
+DFL_HD void dfl_literal_prices(const uint8_t *s, uint32_t begin, uint32_t end, const dfl_work *w, uint32_t *litsum)
+{
+    uint32_t acc = 0;
+    for (uint32_t p = begin; p < end; p++) {
+        const uint32_t l = w->len_ll[s[p]];
+        acc += l ? l : DFL_UNSEEN_PRICE;
+        litsum[p] = acc;
+    }
+}
+
+DFL_HD int32_t dfl_saving(uint32_t m, uint32_t p, uint32_t begin, const dfl_work *w, const uint32_t *litsum)
+{
+    if (!m) return -1;
+    uint32_t sym, eb, ex, price;
+    const uint32_t len = DFL_TOK_LEN(m);
+    dfl_len_symbol(len, &sym, &eb, &ex);
+    price = (w->len_ll[sym] ? w->len_ll[sym] : DFL_UNSEEN_PRICE) + eb;
+    dfl_dist_symbol(DFL_TOK_DIST(m), &sym, &eb, &ex);
+    price += (w->len_d[sym] ? w->len_d[sym] : DFL_UNSEEN_PRICE) + eb;
+    const uint32_t lits = litsum[p + len - 1] - (p > begin ? litsum[p - 1] : 0u);
+    return (int32_t)lits - (int32_t)price;
+}
+
+DFL_HD uint32_t dfl_parse_block_priced(const uint8_t *s, const uint32_t *match, uint32_t begin, uint32_t end,
+                                       uint32_t min_len, uint32_t *tok, dfl_work *w, const uint32_t *litsum)
+{
+    uint32_t n = 0, p = begin;
+    uint32_t cur = p < end ? dfl_clip(match[p], p, end, min_len) : 0;
+    int32_t cur_saving = dfl_saving(cur, p, begin, w, litsum);
+    while (p < end) {
+        if (cur_saving > 0) {
+            const uint32_t nxt = p + 1 < end ? dfl_clip(match[p + 1], p + 1, end, min_len) : 0;
+            const int32_t nxt_saving = dfl_saving(nxt, p + 1, begin, w, litsum);
+            if (nxt_saving > cur_saving) {                             /* defer: literal now, the better match next */
+                w->freq_ll[s[p]]++;
+                tok[n++] = s[p];
+                ++p;
+                cur = nxt;
+                cur_saving = nxt_saving;
+                continue;
+            }
+            uint32_t sym, eb, ex;
+            dfl_len_symbol(DFL_TOK_LEN(cur), &sym, &eb, &ex);
+            w->freq_ll[sym]++;
+            dfl_dist_symbol(DFL_TOK_DIST(cur), &sym, &eb, &ex);
+            w->freq_d[sym]++;
+            tok[n++] = cur;
+            p += DFL_TOK_LEN(cur);
+        } else {
+            w->freq_ll[s[p]]++;
+            tok[n++] = s[p];
+            ++p;
+        }
+        cur = p < end ? dfl_clip(match[p], p, end, min_len) : 0;
+        cur_saving = dfl_saving(cur, p, begin, w, litsum);
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
  * 3b. length-limited Huffman code for `n` symbols: sort by frequency, two-queue Huffman merge, clamp depths to
  * `limit` and repair the Kraft sum, hand the lengths out by rank, then canonical codes (stored bit-reversed, the
  * order deflate sends them in).  At least two symbols get a code so that a decoder always sees a complete tree.
@@ -233,23 +316,10 @@ DFL_HD uint32_t dfl_bitrev(uint32_t v, uint32_t bits)
     return r;
 }
 
-DFL_HD void dfl_build_code(uint32_t *freq, uint32_t n, uint32_t limit, uint8_t *len, uint16_t *code, dfl_work *w)
+/* everything after the sort: w->order[0 .. used) holds the coded symbols by ascending (frequency, symbol) */
+DFL_HD void dfl_build_code_sorted(const uint32_t *freq, uint32_t n, uint32_t used, uint32_t limit, uint8_t *len,
+                                  uint16_t *code, dfl_work *w)
 {
-    uint32_t used = 0;
-    for (uint32_t i = 0; i < n; i++) { len[i] = 0; code[i] = 0; if (freq[i]) w->order[used++] = (uint16_t)i; }
-    for (uint32_t i = 0; used < 2 && i < n; i++)            /* force two coded symbols */
-        if (!freq[i]) { freq[i] = 1; w->order[used++] = (uint16_t)i; }
-    /* sort ascending by (freq, symbol): insertion sort over <= 288 entries, mostly small */
-    for (uint32_t i = 1; i < used; i++) {
-        const uint16_t v = w->order[i];
-        const uint32_t fv = freq[v];
-        uint32_t j = i;
-        while (j && (freq[w->order[j - 1]] > fv || (freq[w->order[j - 1]] == fv && w->order[j - 1] > v))) {
-            w->order[j] = w->order[j - 1];
-            --j;
-        }
-        w->order[j] = v;
-    }
     /* leaves 0..used-1 (sorted), internal nodes used..2*used-2 created in non-decreasing weight order */
     for (uint32_t i = 0; i < used; i++) w->weight[i] = freq[w->order[i]];
     uint32_t leaf = 0, inode = used, next = used;
@@ -294,6 +364,26 @@ DFL_HD void dfl_build_code(uint32_t *freq, uint32_t n, uint32_t limit, uint8_t *
     for (uint32_t l = 1; l <= limit; l++) { c = (c + count[l - 1]) << 1; next_code[l] = c; }
     for (uint32_t i = 0; i < n; i++)
         if (len[i]) code[i] = (uint16_t)dfl_bitrev(next_code[len[i]]++, len[i]);
+}
+
+DFL_HD void dfl_build_code(uint32_t *freq, uint32_t n, uint32_t limit, uint8_t *len, uint16_t *code, dfl_work *w)
+{
+    uint32_t used = 0;
+    for (uint32_t i = 0; i < n; i++) { len[i] = 0; code[i] = 0; if (freq[i]) w->order[used++] = (uint16_t)i; }
+    for (uint32_t i = 0; used < 2 && i < n; i++)            /* force two coded symbols */
+        if (!freq[i]) { freq[i] = 1; w->order[used++] = (uint16_t)i; }
+    /* sort ascending by (freq, symbol): insertion sort over <= 288 entries */
+    for (uint32_t i = 1; i < used; i++) {
+        const uint16_t v = w->order[i];
+        const uint32_t fv = freq[v];
+        uint32_t j = i;
+        while (j && (freq[w->order[j - 1]] > fv || (freq[w->order[j - 1]] == fv && w->order[j - 1] > v))) {
+            w->order[j] = w->order[j - 1];
+            --j;
+        }
+        w->order[j] = v;
+    }
+    dfl_build_code_sorted(freq, n, used, limit, len, code, w);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -368,7 +458,7 @@ DFL_HD void dfl_canonical(const uint8_t *len, uint32_t n, uint16_t *code)
  * this block, with room for the stored form (input + 5 bytes per 65535 + 16).  Returns the result record.
  * ------------------------------------------------------------------------------------------------------------- */
 DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match, const dfl_block_desc *d,
-                                         const dfl_params *prm, uint32_t *tok, uint8_t *out, dfl_work *w)
+                                         const dfl_params *prm, uint32_t *tok, uint32_t *litsum, uint8_t *out, dfl_work *w)
 {
     static const uint8_t cl_order[DFL_NUM_CL] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
     dfl_block_result res;
@@ -380,7 +470,16 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
     res.adler_a = 0;                 /* filled in by the caller (dfl_adler_partial, lane-parallel on the device) */
     res.adler_b = 0;
 
-    const uint32_t ntok = dfl_parse_block(s, match, d->begin, d->end, prm->min_len, tok, w);
+    uint32_t ntok = dfl_parse_block(s, match, d->begin, d->end, prm->min_len, tok, w);
+    if (litsum && ntok < L) {                                    /* there are matches: price them and parse again */
+        w->freq_ll[256] = 1;
+        dfl_build_code(w->freq_ll, 286, 15, w->len_ll, w->code_ll, w);
+        dfl_build_code(w->freq_d, 30, 15, w->len_d, w->code_d, w);
+        dfl_literal_prices(s, d->begin, d->end, w, litsum);
+        for (uint32_t i = 0; i < DFL_NUM_LL; i++) w->freq_ll[i] = 0;
+        for (uint32_t i = 0; i < DFL_NUM_D; i++) w->freq_d[i] = 0;
+        ntok = dfl_parse_block_priced(s, match, d->begin, d->end, prm->min_len, tok, w, litsum);
+    }
     w->freq_ll[256] = 1;
     res.tokens = ntok;
 

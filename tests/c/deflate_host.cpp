@@ -15,22 +15,54 @@
 
 #include <zlib.h>
 
-#include "../../pngloss_amd/csrc/pl_deflate_core.h"
+#include <pthread.h>
+#include <thread>
 
-static uint32_t g_levels[8] = { 0 };
-extern "C" void dfl_host_set_levels(const uint32_t *lv, int n) { for (int i = 0; i < 8; i++) g_levels[i] = i < n ? lv[i] : 0; }
+#define DFL_COOP_MAX_BLOCK (1u << 22)          /* the tests also use blocks larger than the product's 256 KiB */
+#include "../../pngloss_amd/csrc/pl_deflate_coop.h"
+
+static uint32_t g_levels[12] = { 0 };
+static int g_priced = 1;
+static int g_team = 0;              /* 0: one-thread dfl_encode_block; N >= 1: dfl_encode_block_coop with a team of N threads */
+extern "C" void dfl_host_set_team(int n) { g_team = n; }
+
+static void barrier_wait(void *b) { pthread_barrier_wait(static_cast<pthread_barrier_t *>(b)); }
+
+static dfl_block_result encode_with_team(int nthreads, const uint8_t *in, const uint32_t *match, const dfl_block_desc *d,
+                                         const dfl_params *prm, uint32_t *tok, uint32_t *litsum, uint8_t *out)
+{
+    static dfl_coop shared;                      /* the team's "LDS" */
+    dfl_block_result res{};
+    if (nthreads == 1) {
+        dfl_team t = { 0, 1, nullptr, nullptr };
+        return dfl_encode_block_coop(&t, in, match, d, prm, tok, litsum, out, &shared);
+    }
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, (unsigned)nthreads);
+    std::vector<std::thread> th;
+    for (int i = 0; i < nthreads; i++)
+        th.emplace_back([&, i] {
+            dfl_team t = { (uint32_t)i, (uint32_t)nthreads, barrier_wait, &bar };
+            const dfl_block_result r = dfl_encode_block_coop(&t, in, match, d, prm, tok, litsum, out, &shared);
+            if (i == 0) res = r;
+        });
+    for (auto &x : th) x.join();
+    pthread_barrier_destroy(&bar);
+    return res;
+}
+extern "C" void dfl_host_set_priced(int on) { g_priced = on; }
+extern "C" void dfl_host_set_levels(const uint32_t *lv, int n) { for (int i = 0; i < 11; i++) g_levels[i] = i < n ? lv[i] : 0; }
 
 extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, uint32_t max_chain,
                                 uint32_t min_len, uint32_t block_bytes, uint32_t *stats)
 {
     dfl_params prm = { max_chain, min_len, block_bytes };
-    std::vector<uint64_t> key(n), skey(n);
+    std::vector<uint32_t> key(n), skey(n);
     std::vector<uint32_t> sorted(n), rank(n), gstart(n), match(n, 0u), tok(block_bytes ? block_bytes : 1);
-    static const uint32_t default_levels[] = { 128u, 32u, 12u, 6u, 0u };    /* DFL_DEFAULT_LEVELS, zero-terminated */
-    static const uint32_t check_levels[] = DFL_DEFAULT_LEVELS;
-    static_assert(sizeof(check_levels) == 4 * sizeof(uint32_t), "update default_levels");
+    static const uint32_t product_levels[] = DFL_DEFAULT_LEVELS;
+    uint32_t default_levels[9] = { 0 };                              /* zero-terminated copy */
+    for (size_t k = 0; k < sizeof product_levels / sizeof product_levels[0] && k < 8; k++) default_levels[k] = product_levels[k];
     const uint32_t *levels = g_levels[0] ? g_levels : default_levels;
-    for (int k = 0; k < 4; k++) if (default_levels[k] != check_levels[k]) return 0;
     for (int lv = 0; levels[lv]; lv++) {
         for (uint32_t p = 0; p < n; p++) key[p] = dfl_sort_key(in, p, n, levels[lv]);
         std::iota(sorted.begin(), sorted.end(), 0u);
@@ -41,7 +73,7 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
             gstart[i] = (i && skey[i] == skey[i - 1]) ? gstart[i - 1] : i;
         }
         for (uint32_t p = 0; p < n; p++)
-            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), rank[p], gstart[rank[p]], max_chain, match[p]);
+            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), rank[p], gstart[rank[p]], max_chain, lv ? levels[lv - 1] : 0u, match[p]);
     }
 
     size_t pos = 0;
@@ -50,12 +82,18 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
     uint32_t adler = 1;
     dfl_work work;
     std::vector<uint8_t> buf(dfl_block_bound(block_bytes) + 16);
+    std::vector<uint32_t> litsum(n + 1);
     if (stats) std::memset(stats, 0, 4 * sizeof(uint32_t));
     for (uint32_t b0 = 0; b0 < n; b0 += block_bytes) {
         dfl_block_desc d = { b0, std::min(n, b0 + block_bytes), 0, n, 0, 0, (uint32_t)buf.size(), 0 };
         std::memset(buf.data(), 0, buf.size());
-        dfl_block_result r = dfl_encode_block(in, match.data(), &d, &prm, tok.data(), buf.data(), &work);
-        dfl_adler_partial(in, d.begin, d.end, 0, 1, &r.adler_a, &r.adler_b);
+        dfl_block_result r;
+        if (g_team > 0) {
+            r = encode_with_team(g_team, in, match.data(), &d, &prm, tok.data(), g_priced ? litsum.data() : nullptr, buf.data());
+        } else {
+            r = dfl_encode_block(in, match.data(), &d, &prm, tok.data(), g_priced ? litsum.data() : nullptr, buf.data(), &work);
+            dfl_adler_partial(in, d.begin, d.end, 0, 1, &r.adler_a, &r.adler_b);
+        }
         if (pos + r.bytes + 6 > cap) return 0;
         std::memcpy(out + pos, buf.data(), r.bytes);
         pos += r.bytes;
@@ -80,7 +118,9 @@ int main(int argc, char **argv)
     std::fclose(f);
     const uint32_t max_chain = argc > 2 ? std::atoi(argv[2]) : 256, min_len = argc > 3 ? std::atoi(argv[3]) : 3,
                    block = argc > 4 ? std::atoi(argv[4]) : 262144;
-    for (int i = 5; i < argc && i < 12; i++) g_levels[i - 5] = std::atoi(argv[i]);
+    if (std::getenv("DFL_UNPRICED")) g_priced = 0;
+    if (std::getenv("DFL_TEAM")) g_team = std::atoi(std::getenv("DFL_TEAM"));
+    for (int i = 5; i < argc && i < 16; i++) g_levels[i - 5] = std::atoi(argv[i]);
     std::vector<uint8_t> out(in.size() + in.size() / 8 + 1024);
     uint32_t stats[4];
     auto t0 = std::chrono::steady_clock::now();

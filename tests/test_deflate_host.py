@@ -96,3 +96,21 @@ def test_size_vs_zlib9_on_a_larger_frame(host):
     z, _ = deflate(host, data)
     assert zlib.decompress(z) == data
     assert len(z) <= 1.005 * len(zlib9f(data))
+
+
+def test_team_encoder_is_byte_identical_to_the_one_thread_encoder(host):
+    """pl_deflate_coop.h (the workgroup version: speculative chunk parse + merge, rank sort, OR-ed bit runs) against the
+    plain statement of the algorithm, for team sizes that give chunks of 32 positions up to the whole block."""
+    import pngloss_amd as P
+    rng = np.random.default_rng(6)
+    cases = [scanline_stream(P.synth_rgba(200, 120, m, 1)) for m in (0, 1, 2, 5)]
+    cases += [b"", b"x", bytes(1000), rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(),
+              (b"abcdefgh" * 50 + rng.integers(0, 3, 300, dtype=np.uint8).tobytes()) * 40]
+    for data in cases:
+        for block in (1500, 262144):
+            want, wstats = U.deflate_host(data, block_bytes=block, team=0)
+            assert zlib.decompress(want) == data
+            for team in (1, 3, 16, 64):
+                got, gstats = U.deflate_host(data, block_bytes=block, team=team)
+                assert got == want, (len(data), block, team)
+                assert np.array_equal(gstats, wstats)

@@ -187,17 +187,21 @@ def deflate_host_lib():
         import subprocess
         import tempfile
         so = os.path.join(tempfile.mkdtemp(prefix="dfl_host_"), "libdeflate_host.so")
-        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "c", "deflate_host.cpp"), "-lz"], check=True)
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "c", "deflate_host.cpp"), "-lz", "-lpthread"], check=True)
         lib = C.CDLL(so)
         lib.dfl_host_zlib.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.dfl_host_zlib.restype = C.c_size_t
+        lib.dfl_host_set_team.argtypes = [C.c_int]
         _dfl = lib
     return _dfl
 
 
-def deflate_host(data, max_chain=64, min_len=6, block_bytes=262144):
-    """zlib stream of `data` from the CPU run of pl_deflate_core.h; returns (bytes, stats[stored, fixed, dynamic, tokens])."""
+def deflate_host(data, max_chain=64, min_len=6, block_bytes=262144, team=0):
+    """zlib stream of `data` from the CPU run of the encoder; returns (bytes, stats[stored, fixed, dynamic, tokens]).
+    team=0: the one-thread dfl_encode_block (pl_deflate_core.h); team=N: dfl_encode_block_coop (pl_deflate_coop.h, what
+    the GPU runs) with a team of N host threads."""
     lib = deflate_host_lib()
+    lib.dfl_host_set_team(team)
     src = np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(0, np.uint8)
     out = np.zeros(len(data) + len(data) // 4 + 4096, np.uint8)
     stats = np.zeros(4, np.uint32)
