@@ -155,7 +155,7 @@ int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip
  * the reference tool spends its time once the hot path is fast).  The stream inflates to exactly the scanlines the
  * _emit call returns -- so the decoded PNG is identical -- but it is not the byte sequence zlib would write:
  * the encoder is the GPU one of pngloss_amd/csrc/pl_deflate_core.h (multi-level match search, 256 KiB blocks that each
- * end byte-aligned).  On the files of the reference's suite its output is 0-3 % smaller than zlib level 9 / Z_FILTERED.
+ * end byte-aligned).  On the files of the reference's suite its output is 1-5 % smaller than zlib level 9 / Z_FILTERED.
  * `data` must have room for pngloss_hip_zlib_bound(width, height) bytes; `size` = 0 for an empty image. */
 typedef struct {
     unsigned char *data;      /* in: caller's buffer; out: zlib stream (header 78 DA ... Adler-32) */
