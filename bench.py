@@ -196,6 +196,19 @@ def main():
                              "note": "pinned 64 MiB frame over PCIe, outside the timed region; with both legs one step "
                                      "would take %.1f ms" % (elapsed_max / args.steps * 1e3 + h2d_ms + d2h_ms)}
         if world == 1 and not args.no_cpu_baseline:
+            # the write side of the same frame, outside the timed region: scanline filtering + deflate on
+            # the device; reported next to the headline, never part of `value`
+            try:
+                t_ws = time.perf_counter()
+                _, _, streams = ctx.run_host_zlib([frame], STRENGTH, BLEED)
+                ctype, zbytes, blocks = streams[0]
+                line["write_side"] = {"gpu_deflate_ms": round(ctx.deflate_ms, 2), "zlib_stream_bytes": len(zbytes),
+                                      "scanline_bytes": (W * {0: 1, 4: 2, 2: 3, 6: 4}[ctype] + 1) * H,
+                                      "host_call_ms": round((time.perf_counter() - t_ws) * 1e3, 1),
+                                      "note": "pngloss_hip_optimize_batch_host_zlib on the same frame from host memory: upload + "
+                                              "hot path + scanline filtering + GPU deflate + download of the zlib stream"}
+            except Exception as exc:          # informational only
+                line["write_side"] = {"error": repr(exc)}
             line["cpu_baseline"] = cpu_baseline(frame)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)
         print(json.dumps(line), flush=True)

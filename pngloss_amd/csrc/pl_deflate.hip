@@ -7,7 +7,7 @@
  * against zlib's inflate).  Here: the kernels that run it, and the host sequencing for a batch of images.
  *
  *   dfl_pack      scanlines (filter id + filtered bytes per row) of every image  ->  one contiguous byte stream
- *   per level:    dfl_keys -> radix sort of (key, position) -> dfl_rank -> dfl_match      (all position-parallel)
+ *   per level:    dfl_keys -> radix sort of (key, position) -> dfl_flags + max-scan -> dfl_match   (all position-parallel)
  *   dfl_encode    one workgroup per deflate block (pl_deflate_coop.h): parse, Huffman codes, bits; byte-aligned outputs
  *   dfl_gather    compacts the block outputs into one buffer per image
  *
@@ -18,6 +18,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -58,27 +59,34 @@ __global__ __launch_bounds__(kThreads) void dfl_keys(const dfl_block_desc *desc,
     val[p] = p;
 }
 
-/* rank[p] = index of p in the sorted order; flag[i] = i where a new key group starts (else 0): an inclusive max-scan
- * of flag[] then gives every entry the index of the first entry of its group */
-__global__ __launch_bounds__(kThreads) void dfl_rank(const uint32_t *sorted, const uint32_t *skey, uint32_t n,
-                                                     uint32_t *rank, uint32_t *flag)
+/* flag[i] = i where a new key group starts in the sorted order (else 0): an inclusive max-scan of flag[] then gives
+ * every entry the index of the first entry of its group */
+__global__ __launch_bounds__(kThreads) void dfl_flags(const uint32_t *skey, uint32_t n, uint32_t *flag)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) flag[i] = (i && skey[i] != skey[i - 1]) ? i : 0u;
+}
+
+/* One search level, one thread per entry of the SORTED order: neighbouring threads are positions with the same
+ * context (similar chain lengths, shared candidate lists), no inverse permutation is needed, and the positions that the
+ * exact skip rule exempts from this level (most of them, in compressible data) leave after one load. */
+__global__ __launch_bounds__(kThreads) void dfl_match(const uint32_t *sorted, const uint32_t *group_start, uint32_t n,
+                                                      const uint8_t *s, const uint32_t *img_begin, uint32_t nimg,
+                                                      uint32_t max_chain, uint32_t longer_key_bytes, uint32_t *match)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
-    rank[sorted[i]] = i;
-    flag[i] = (i && skey[i] != skey[i - 1]) ? i : 0u;
-}
-
-__global__ __launch_bounds__(kThreads) void dfl_match(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *sorted,
-                                                      const uint32_t *group_start, const uint32_t *rank, uint32_t max_chain,
-                                                      uint32_t longer_key_bytes, uint32_t *match)
-{
-    const dfl_block_desc d = desc[blockIdx.y];
-    const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
-    if (p >= d.end) return;
-    const uint32_t r = rank[p];
-    match[p] = dfl_search_level(s, d.img_begin, d.img_end, p, sorted, r, group_start[r], max_chain, longer_key_bytes,
-                                longer_key_bytes ? match[p] : 0u);
+    const uint32_t p = sorted[i];
+    const uint32_t best = longer_key_bytes ? match[p] : 0u;
+    if (best && DFL_TOK_LEN(best) >= longer_key_bytes) return;
+    uint32_t lo = 0, hi = nimg;                 /* image of p: img_begin[lo] <= p < img_begin[lo + 1] */
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (img_begin[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint32_t m = dfl_search_level(s, img_begin[lo], img_begin[lo + 1], p, sorted, i, group_start[i], max_chain,
+                                        longer_key_bytes, best);
+    if (m != best || !longer_key_bytes) match[p] = m;
 }
 
 /* one 256-thread workgroup per deflate block: pl_deflate_coop.h; `arena` must be zero (the bits are OR-ed in) */
@@ -142,7 +150,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
 
     uint8_t *d_s = nullptr, *d_arena = nullptr, *d_compact = nullptr, *d_temp = nullptr;
     uint32_t *d_key[2] = { nullptr, nullptr };
-    uint32_t *d_val[2] = { nullptr, nullptr }, *d_rank = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
+    uint32_t *d_val[2] = { nullptr, nullptr }, *d_litsum = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
     dfl_block_desc *d_desc = nullptr;
     dfl_block_result *d_result = nullptr;
     DflImageDev *d_img = nullptr;
@@ -150,15 +158,20 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     uint32_t *d_flag = nullptr, *d_gstart = nullptr;
     std::vector<dfl_block_result> result(nblocks);
     std::vector<uint32_t> dest(nblocks);
-    std::vector<uint32_t> img_off(n + 1, 0);
+    std::vector<uint32_t> img_off(n + 1, 0), img_begin;
+    uint32_t *d_img_begin = nullptr;
     const dim3 pos_grid((max_block + kThreads - 1) / kThreads, nblocks);
 
+    const bool debug = std::getenv("PNGLOSS_HIP_DEBUG") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    double ms_alloc = 0, ms_kernels = 0, ms_gather = 0, ms_copy = 0;
     DFL_CHECK(dev_alloc(&d_s, (size_t)total + 512));              /* slack: the key/compare loads may run past the end */
     DFL_CHECK(dev_alloc(&d_key[0], total));
     DFL_CHECK(dev_alloc(&d_key[1], total));
     DFL_CHECK(dev_alloc(&d_val[0], total));
     DFL_CHECK(dev_alloc(&d_val[1], total));
-    DFL_CHECK(dev_alloc(&d_rank, total));
+    DFL_CHECK(dev_alloc(&d_litsum, total));               /* literal price sums of the second parse */
     DFL_CHECK(dev_alloc(&d_match, total));
     DFL_CHECK(dev_alloc(&d_tok, total));
     DFL_CHECK(dev_alloc(&d_arena, arena_bytes));
@@ -166,29 +179,39 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     DFL_CHECK(dev_alloc(&d_result, nblocks));
     DFL_CHECK(dev_alloc(&d_dest, nblocks));
     DFL_CHECK(dev_alloc(&d_img, n));
+    DFL_CHECK(dev_alloc(&d_img_begin, n + 1));
     DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
     d_flag = d_val[0];                                             /* both are free between the sort and the next level's keys */
     d_gstart = d_key[0];
     DFL_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
     temp_bytes = std::max(temp_bytes, scan_bytes);
     DFL_CHECK(dev_alloc(&d_temp, temp_bytes));
+    ms_alloc = ms_since(t_begin);
     DFL_CHECK(hipMemsetAsync(d_s + total, 0, 512, stream));
     DFL_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(dfl_block_desc) * nblocks, hipMemcpyHostToDevice, stream));
     DFL_CHECK(hipMemcpyAsync(d_img, dev_img.data(), sizeof(DflImageDev) * n, hipMemcpyHostToDevice, stream));
+    {   /* start of every image in the stream (+ the end), for the sorted-order kernels */
+        uint32_t at = 0;
+        for (size_t i = 0; i < n; i++) { img_begin.push_back(at); at += (imgs[i].rowbytes + 1u) * imgs[i].height; }
+        img_begin.push_back(at);
+        DFL_CHECK(hipMemcpyAsync(d_img_begin, img_begin.data(), sizeof(uint32_t) * (n + 1), hipMemcpyHostToDevice, stream));
+    }
 
     dfl_pack<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_img, d_s);
     for (int lv = 0; lv < kNumLevels; lv++) {
         dfl_keys<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, kLevels[lv], d_key[0], d_val[0]);
         DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
-        dfl_rank<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], d_key[1], total, d_rank, d_flag);
+        dfl_flags<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_key[1], total, d_flag);
         DFL_CHECK(hipcub::DeviceScan::InclusiveScan(d_temp, temp_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
-        dfl_match<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_val[1], d_gstart, d_rank, prm.max_chain, lv ? kLevels[lv - 1] : 0u, d_match);
+        dfl_match<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], d_gstart, total, d_s, d_img_begin, (uint32_t)n,
+                                                                                  prm.max_chain, lv ? kLevels[lv - 1] : 0u, d_match);
     }
     DFL_CHECK(hipMemsetAsync(d_arena, 0, arena_bytes, stream));
-    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_rank /* free now: literal price sums */, d_arena, d_result);
+    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_litsum, d_arena, d_result);
     DFL_CHECK(hipGetLastError());
     DFL_CHECK(hipMemcpyAsync(result.data(), d_result, sizeof(dfl_block_result) * nblocks, hipMemcpyDeviceToHost, stream));
     DFL_CHECK(hipStreamSynchronize(stream));
+    ms_kernels = ms_since(t_begin) - ms_alloc;
 
     {   /* compact layout: image i's blocks back to back at img_off[i] */
         uint32_t cursor = 0;
@@ -202,6 +225,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
         dfl_gather<<<nblocks, kThreads, 0, stream>>>(d_desc, d_result, d_dest, d_arena, d_compact);
         DFL_CHECK(hipGetLastError());
         DFL_CHECK(hipStreamSynchronize(stream));
+        ms_gather = ms_since(t_begin) - ms_alloc - ms_kernels;
     }
     for (size_t i = 0; i < n; i++) {
         const uint32_t body = img_off[i + 1] - img_off[i];
@@ -223,10 +247,16 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
         imgs[i].out_size = need;
         imgs[i].blocks_stored = kinds[0]; imgs[i].blocks_fixed = kinds[1]; imgs[i].blocks_dynamic = kinds[2];
     }
+    ms_copy = ms_since(t_begin) - ms_alloc - ms_kernels - ms_gather;
 done:
     (void)hipFree(d_s); (void)hipFree(d_key[0]); (void)hipFree(d_key[1]); (void)hipFree(d_val[0]); (void)hipFree(d_val[1]);
-    (void)hipFree(d_rank); (void)hipFree(d_match); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
+    (void)hipFree(d_litsum); (void)hipFree(d_match); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
     (void)hipFree(d_result); (void)hipFree(d_dest); (void)hipFree(d_img); (void)hipFree(d_temp); (void)hipFree(d_compact);
+    (void)hipFree(d_img_begin);
+    if (debug)
+        std::fprintf(stderr, "pngloss_hip deflate: %zu images, %u bytes, %u blocks: alloc %.2f ms, kernels %.2f ms, gather %.2f ms, "
+                             "download %.2f ms, free %.2f ms\n", n, total, nblocks, ms_alloc, ms_kernels, ms_gather, ms_copy,
+                     ms_since(t_begin) - ms_alloc - ms_kernels - ms_gather - ms_copy);
     return rc;
 }
 
