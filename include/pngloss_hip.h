@@ -156,7 +156,9 @@ int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip
  * _emit call returns -- so the decoded PNG is identical -- but it is not the byte sequence zlib would write:
  * the encoder is the GPU one of pngloss_amd/csrc/pl_deflate_core.h (multi-level match search, 256 KiB blocks that each
  * end byte-aligned).  On the files of the reference's suite its output is 1-5 % smaller than zlib level 9 / Z_FILTERED.
- * `data` must have room for pngloss_hip_zlib_bound(width, height) bytes; `size` = 0 for an empty image. */
+ * `data` must have room for pngloss_hip_zlib_bound(width, height) bytes; `size` = 0 for an empty image.  One image may
+ * have at most 1 GiB of scanlines ((4*width+1)*height; positions are 32-bit on the device): larger ones make the call
+ * return PNGLOSS_INVALID_ARGUMENT -- use the _emit form and a CPU deflate for those. */
 typedef struct {
     unsigned char *data;      /* in: caller's buffer; out: zlib stream (header 78 DA ... Adler-32) */
     size_t capacity;          /* in */

@@ -370,6 +370,19 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
             zs[m] = (pngloss_hip_zstream){ jobs[i].lines, pngloss_hip_zlib_bound(jobs[i].out.width, jobs[i].out.height), 0, -1, { 0, 0, 0 } };
             who[m++] = i;
         }
+    if (m && o->gpu_deflate)
+        for (size_t k = 0; k < m; k++)
+            if (((uint64_t)imgs[k].width * 4 + 1) * imgs[k].height > ((uint64_t)1 << 30)) {
+                /* the device encoder addresses one image's scanlines with 32-bit positions (include/pngloss_hip.h) */
+                say(&jobs[who[k]], "  error: image too large for --gpu-deflate (more than 1 GiB of scanlines); run it without the option\n");
+                jobs[who[k]].status = INVALID_ARGUMENT;
+            }
+    if (m && o->gpu_deflate) {                       /* drop the refused ones from the batch */
+        size_t keep = 0;
+        for (size_t k = 0; k < m; k++)
+            if (jobs[who[k]].status == SUCCESS) { imgs[keep] = imgs[k]; lines[keep] = lines[k]; zs[keep] = zs[k]; who[keep++] = who[k]; }
+        m = keep;
+    }
     if (m) {
         if (!*ctx) *ctx = pngloss_hip_create(-1);
         int rc = !*ctx ? PNGLOSS_HIP_ERROR
