@@ -91,13 +91,13 @@ __global__ __launch_bounds__(kThreads) void dfl_match(const uint32_t *sorted, co
 
 /* one 256-thread workgroup per deflate block: pl_deflate_coop.h; `arena` must be zero (the bits are OR-ed in) */
 __global__ __launch_bounds__(kThreads) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match,
-                                                       dfl_params prm, uint32_t *tok, uint32_t *litsum, uint8_t *arena,
+                                                       dfl_params prm, uint32_t *tok, uint32_t *choice, uint8_t *arena,
                                                        dfl_block_result *result)
 {
     __shared__ dfl_coop shared;
     const dfl_block_desc d = desc[blockIdx.x];
     dfl_team team = { threadIdx.x, kThreads, nullptr, nullptr };
-    const dfl_block_result res = dfl_encode_block_coop(&team, s, match, &d, &prm, tok + d.begin, litsum, arena + d.out_offset, &shared);
+    const dfl_block_result res = dfl_encode_block_coop(&team, s, match, &d, &prm, tok + d.begin, choice, arena + d.out_offset, &shared);
     if (threadIdx.x == 0) result[blockIdx.x] = res;
 }
 
@@ -150,7 +150,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
 
     uint8_t *d_s = nullptr, *d_arena = nullptr, *d_compact = nullptr, *d_temp = nullptr;
     uint32_t *d_key[2] = { nullptr, nullptr };
-    uint32_t *d_val[2] = { nullptr, nullptr }, *d_litsum = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
+    uint32_t *d_val[2] = { nullptr, nullptr }, *d_choice = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
     dfl_block_desc *d_desc = nullptr;
     dfl_block_result *d_result = nullptr;
     DflImageDev *d_img = nullptr;
@@ -171,7 +171,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     DFL_CHECK(dev_alloc(&d_key[1], total));
     DFL_CHECK(dev_alloc(&d_val[0], total));
     DFL_CHECK(dev_alloc(&d_val[1], total));
-    DFL_CHECK(dev_alloc(&d_litsum, total));               /* literal price sums of the second parse */
+    DFL_CHECK(dev_alloc(&d_choice, total));               /* token choices of the optimal parse */
     DFL_CHECK(dev_alloc(&d_match, total));
     DFL_CHECK(dev_alloc(&d_tok, total));
     DFL_CHECK(dev_alloc(&d_arena, arena_bytes));
@@ -207,7 +207,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
                                                                                   prm.max_chain, lv ? kLevels[lv - 1] : 0u, d_match);
     }
     DFL_CHECK(hipMemsetAsync(d_arena, 0, arena_bytes, stream));
-    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_litsum, d_arena, d_result);
+    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_choice, d_arena, d_result);
     DFL_CHECK(hipGetLastError());
     DFL_CHECK(hipMemcpyAsync(result.data(), d_result, sizeof(dfl_block_result) * nblocks, hipMemcpyDeviceToHost, stream));
     DFL_CHECK(hipStreamSynchronize(stream));
@@ -250,7 +250,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     ms_copy = ms_since(t_begin) - ms_alloc - ms_kernels - ms_gather;
 done:
     (void)hipFree(d_s); (void)hipFree(d_key[0]); (void)hipFree(d_key[1]); (void)hipFree(d_val[0]); (void)hipFree(d_val[1]);
-    (void)hipFree(d_litsum); (void)hipFree(d_match); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
+    (void)hipFree(d_choice); (void)hipFree(d_match); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
     (void)hipFree(d_result); (void)hipFree(d_dest); (void)hipFree(d_img); (void)hipFree(d_temp); (void)hipFree(d_compact);
     (void)hipFree(d_img_begin);
     if (debug)

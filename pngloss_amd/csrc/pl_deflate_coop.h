@@ -11,7 +11,9 @@
  *              true orbit across chunk borders -- it only has to walk until it lands on a position the chunk's owner
  *              visited too (the two walks coincide from there on; they merge within a few tokens, the way Huffman
  *              decoding self-synchronises) -- and patches the bitmap.  Tokens are then produced from the bitmap by
- *              all threads, compacted by a scan, histograms through shared-memory atomics.
+ *              all threads, compacted by a scan, histograms through shared-memory atomics.  The same machinery
+ *              serves the parse by length and the optimal parse (whose chunks of the shortest-path pass go one per
+ *              thread).
  *   codes      symbols are rank-sorted in parallel; the Huffman merge itself (<= 286 symbols) is one thread.
  *   bits       tokens are dealt to the threads in equal runs, a scan of their bit counts gives every run its bit
  *              offset, and each thread writes its run with atomic ORs into the zero-initialised output.
@@ -35,6 +37,11 @@ typedef struct {
     void *sync_arg;
 } dfl_team;
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DFL_PHASE_PROF)
+#define DFL_PROF(k) do { if (t->tid == 0) { const unsigned long long now_ = wall_clock64(); dfl_prof_acc[k] += now_ - dfl_prof_last; dfl_prof_last = now_; } } while (0)
+#else
+#define DFL_PROF(k) do { } while (0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DFL_SYNC(t) __syncthreads()
 #define DFL_SHARED_ADD(p, v) atomicAdd((p), (v))
@@ -48,7 +55,10 @@ typedef struct {
 typedef struct {
     dfl_work w;
     uint16_t sorted[DFL_NUM_LL];                       /* symbols by (frequency, symbol) */
-    uint32_t bitmap[DFL_COOP_MAX_BLOCK / 32];          /* bit p-begin set: a token starts at p */
+    union {                                             /* never live at the same time */
+        uint32_t bitmap[DFL_COOP_MAX_BLOCK / 32];      /* parse: bit p-begin set: a token starts at p */
+        uint16_t ring[DFL_DP_RING * DFL_COOP_MAX_THREADS];   /* optimal parse: the threads' cost windows, interleaved */
+    } u;
     uint32_t exit_pos[DFL_COOP_MAX_THREADS];           /* where a thread's walk left its chunk */
     uint32_t part[DFL_COOP_MAX_THREADS + 1];           /* scan scratch */
     uint64_t part64[DFL_COOP_MAX_THREADS];
@@ -57,18 +67,15 @@ typedef struct {
     dfl_block_result res;
 } dfl_coop;
 
-/* the token that starts at p: by length (litsum == NULL, the rule of dfl_parse_block) or by price
- * (dfl_parse_block_priced) */
-DFL_HD uint32_t dfl_decide(const uint8_t *s, const uint32_t *match, uint32_t p, uint32_t begin, uint32_t end,
-                           uint32_t min_len, const dfl_work *w, const uint32_t *litsum)
+/* the token that starts at p: the optimal parse's choice, or (choice == NULL) by length, the rule of dfl_parse_block */
+DFL_HD uint32_t dfl_decide(const uint8_t *s, const uint32_t *match, uint32_t p, uint32_t end, uint32_t min_len,
+                           const uint32_t *choice)
 {
+    if (choice) return choice[p];
     const uint32_t cur = dfl_clip(match[p], p, end, min_len);
     if (!cur) return s[p];
     const uint32_t nxt = p + 1 < end ? dfl_clip(match[p + 1], p + 1, end, min_len) : 0;
-    if (!litsum) return (nxt && DFL_TOK_LEN(nxt) > DFL_TOK_LEN(cur)) ? (uint32_t)s[p] : cur;
-    const int32_t cs = dfl_saving(cur, p, begin, w, litsum);
-    if (cs <= 0) return s[p];
-    return dfl_saving(nxt, p + 1, begin, w, litsum) > cs ? (uint32_t)s[p] : cur;
+    return (nxt && DFL_TOK_LEN(nxt) > DFL_TOK_LEN(cur)) ? (uint32_t)s[p] : cur;
 }
 
 DFL_HD uint32_t dfl_token_span(uint32_t t) { return DFL_IS_MATCH(t) ? DFL_TOK_LEN(t) : 1u; }
@@ -105,7 +112,7 @@ DFL_HD uint32_t dfl_chunk_size(uint32_t L, uint32_t nthreads)
 
 /* cooperative parse of the block; tokens to tok[], histograms into sh->w (must be zero), returns the token count */
 DFL_HD uint32_t dfl_parse_coop(const dfl_team *t, const uint8_t *s, const uint32_t *match, uint32_t begin, uint32_t end,
-                               uint32_t min_len, uint32_t *tok, const uint32_t *litsum, dfl_coop *sh)
+                               uint32_t min_len, uint32_t *tok, const uint32_t *choice, dfl_coop *sh)
 {
     const uint32_t L = end - begin, CH = dfl_chunk_size(L, t->nthreads);
     const uint32_t cs = t->tid * CH < L ? t->tid * CH : L, ce = cs + CH < L ? cs + CH : L;
@@ -113,12 +120,12 @@ DFL_HD uint32_t dfl_parse_coop(const dfl_team *t, const uint8_t *s, const uint32
     const uint32_t nwords = (L + 31u) >> 5;
     const uint32_t w0 = t->tid * (CH >> 5) < nwords ? t->tid * (CH >> 5) : nwords;
     const uint32_t w1 = w0 + (CH >> 5) < nwords ? w0 + (CH >> 5) : nwords;
-    for (uint32_t wd = w0; wd < w1; wd++) sh->bitmap[wd] = 0;
+    for (uint32_t wd = w0; wd < w1; wd++) sh->u.bitmap[wd] = 0;
     /* 1. walk through the own chunk as if it started on a token boundary */
     uint32_t p = cs;
     while (p < ce) {
-        sh->bitmap[p >> 5] |= 1u << (p & 31u);
-        p += dfl_token_span(dfl_decide(s, match, begin + p, begin, end, min_len, &sh->w, litsum));
+        sh->u.bitmap[p >> 5] |= 1u << (p & 31u);
+        p += dfl_token_span(dfl_decide(s, match, begin + p, end, min_len, choice));
     }
     sh->exit_pos[t->tid] = p;
     DFL_SYNC(t);
@@ -129,16 +136,16 @@ DFL_HD uint32_t dfl_parse_coop(const dfl_team *t, const uint8_t *s, const uint32
             const uint32_t ks = k * CH;
             if (ks >= L) break;
             const uint32_t ke = ks + CH < L ? ks + CH : L;
-            if (e >= ke) { dfl_bitmap_clear(sh->bitmap, ks, ke); continue; }      /* a match jumped over the chunk */
+            if (e >= ke) { dfl_bitmap_clear(sh->u.bitmap, ks, ke); continue; }      /* a match jumped over the chunk */
             if (e == ks) { e = sh->exit_pos[k]; continue; }                        /* the guess was right */
-            dfl_bitmap_clear(sh->bitmap, ks, e);
+            dfl_bitmap_clear(sh->u.bitmap, ks, e);
             uint32_t q = e;
             for (;;) {
                 if (q >= ke) { e = q; break; }                                     /* never met the owner's walk */
-                if (sh->bitmap[q >> 5] & (1u << (q & 31u))) { e = sh->exit_pos[k]; break; }   /* merged */
-                const uint32_t nq = q + dfl_token_span(dfl_decide(s, match, begin + q, begin, end, min_len, &sh->w, litsum));
-                sh->bitmap[q >> 5] |= 1u << (q & 31u);
-                dfl_bitmap_clear(sh->bitmap, q + 1, nq < ke ? nq : ke);
+                if (sh->u.bitmap[q >> 5] & (1u << (q & 31u))) { e = sh->exit_pos[k]; break; }   /* merged */
+                const uint32_t nq = q + dfl_token_span(dfl_decide(s, match, begin + q, end, min_len, choice));
+                sh->u.bitmap[q >> 5] |= 1u << (q & 31u);
+                dfl_bitmap_clear(sh->u.bitmap, q + 1, nq < ke ? nq : ke);
                 q = nq;
             }
         }
@@ -146,16 +153,16 @@ DFL_HD uint32_t dfl_parse_coop(const dfl_team *t, const uint8_t *s, const uint32
     DFL_SYNC(t);
     /* 3. tokens from the bitmap */
     uint32_t cnt = 0;
-    for (uint32_t wd = w0; wd < w1; wd++) cnt += (uint32_t)__builtin_popcount(sh->bitmap[wd]);
+    for (uint32_t wd = w0; wd < w1; wd++) cnt += (uint32_t)__builtin_popcount(sh->u.bitmap[wd]);
     sh->part[t->tid] = cnt;
     dfl_team_scan(t, sh);
     uint32_t k = sh->part[t->tid];
     for (uint32_t wd = w0; wd < w1; wd++) {
-        uint32_t bits = sh->bitmap[wd];
+        uint32_t bits = sh->u.bitmap[wd];
         while (bits) {
             const uint32_t q = (wd << 5) + (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1u;
-            const uint32_t tk = dfl_decide(s, match, begin + q, begin, end, min_len, &sh->w, litsum);
+            const uint32_t tk = dfl_decide(s, match, begin + q, end, min_len, choice);
             tok[k++] = tk;
             if (DFL_IS_MATCH(tk)) {
                 uint32_t sym, eb, ex;
@@ -238,16 +245,19 @@ DFL_HD uint32_t dfl_token_bits(uint32_t tk, const dfl_work *w)
 
 /* ---------------------------------------------------------------------------------------------------------------
  * The block.  All threads of the team call this with the same arguments; `out` must be zero-initialised, 4-byte
- * aligned and dfl_block_bound(L) long; `litsum` is per-position scratch (NULL: single parse by length).  The result
+ * aligned and dfl_block_bound(L) long; `choice` is per-position scratch (NULL: single parse by length).  The result
  * is returned to every thread.
  * ------------------------------------------------------------------------------------------------------------- */
 DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *s, const uint32_t *match,
                                               const dfl_block_desc *d, const dfl_params *prm, uint32_t *tok,
-                                              uint32_t *litsum, uint8_t *out, dfl_coop *sh)
+                                              uint32_t *choice, uint8_t *out, dfl_coop *sh)
 {
     static const uint8_t cl_order[DFL_NUM_CL] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
     dfl_work *w = &sh->w;
     const uint32_t L = d->end - d->begin;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DFL_PHASE_PROF)
+    unsigned long long dfl_prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dfl_prof_last = wall_clock64();
+#endif
 
     /* Adler-32 partial sums */
     {
@@ -270,30 +280,29 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
     }
     DFL_SYNC(t);
 
+    DFL_PROF(0);
     uint32_t ntok = dfl_parse_coop(t, s, match, d->begin, d->end, prm->min_len, tok, NULL, sh);
-    if (litsum && ntok < L) {
-        if (t->tid == 0) w->freq_ll[256] = 1;
-        DFL_SYNC(t);
-        dfl_build_code_coop(t, w->freq_ll, 286, 15, w->len_ll, w->code_ll, sh);
-        dfl_build_code_coop(t, w->freq_d, 30, 15, w->len_d, w->code_d, sh);
-        /* literal prices: inclusive prefix sums over the block, chunk-wise */
-        const uint32_t CH = dfl_chunk_size(L, t->nthreads);
-        const uint32_t cs = t->tid * CH < L ? t->tid * CH : L, ce = cs + CH < L ? cs + CH : L;
-        uint32_t acc = 0;
-        for (uint32_t p = cs; p < ce; p++) { const uint32_t l = w->len_ll[s[d->begin + p]]; acc += l ? l : DFL_UNSEEN_PRICE; }
-        sh->part[t->tid] = acc;
-        dfl_team_scan(t, sh);
-        acc = sh->part[t->tid];
-        for (uint32_t p = cs; p < ce; p++) {
-            const uint32_t l = w->len_ll[s[d->begin + p]];
-            acc += l ? l : DFL_UNSEEN_PRICE;
-            litsum[d->begin + p] = acc;
+    DFL_PROF(1);
+    if (choice && ntok < L) {
+        for (int it = 0; it < DFL_DP_ITERATIONS; it++) {
+            if (t->tid == 0) w->freq_ll[256] = 1;
+            DFL_SYNC(t);
+            dfl_build_code_coop(t, w->freq_ll, 286, 15, w->len_ll, w->code_ll, sh);
+            dfl_build_code_coop(t, w->freq_d, 30, 15, w->len_d, w->code_d, sh);
+            dfl_length_prices(w, t->tid, t->nthreads);
+            DFL_SYNC(t);
+            DFL_PROF(2);
+            for (uint32_t c = t->tid; c * DFL_DP_CHUNK < L; c += t->nthreads)
+                dfl_dp_chunk(s, match, d->begin, d->end, prm->min_len, c, w, choice, &sh->u.ring[t->tid], t->nthreads);
+            for (uint32_t i = t->tid; i < DFL_NUM_LL; i += t->nthreads) w->freq_ll[i] = 0;
+            for (uint32_t i = t->tid; i < DFL_NUM_D; i += t->nthreads) w->freq_d[i] = 0;
+            DFL_SYNC(t);
+            DFL_PROF(3);
+            ntok = dfl_parse_coop(t, s, match, d->begin, d->end, prm->min_len, tok, choice, sh);
+            DFL_PROF(4);
         }
-        for (uint32_t i = t->tid; i < DFL_NUM_LL; i += t->nthreads) w->freq_ll[i] = 0;
-        for (uint32_t i = t->tid; i < DFL_NUM_D; i += t->nthreads) w->freq_d[i] = 0;
-        DFL_SYNC(t);
-        ntok = dfl_parse_coop(t, s, match, d->begin, d->end, prm->min_len, tok, litsum, sh);
     }
+    DFL_PROF(5);
 
     if (t->tid == 0) {
         w->freq_ll[256] = 1;
@@ -365,6 +374,7 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         return sh->res;
     }
 
+    DFL_PROF(6);
     /* header by thread 0, tokens by everyone */
     if (t->tid == 0) {
         dfl_orbits bw;
@@ -410,6 +420,7 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         }
         dfl_or_finish(&bw);
     }
+    DFL_PROF(7);
     if (t->tid == 0) {
         dfl_orbits bw;
         uint32_t at = sh->header_bits + sh->part[t->nthreads];
@@ -423,6 +434,11 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         dfl_or_put(&bw, 0xffffu, 16);
         dfl_or_finish(&bw);
         sh->res.bytes = (at + pad) / 8u + 4u;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DFL_PHASE_PROF)
+        DFL_PROF(7);
+        if (d->begin == 0) printf("phases (100 MHz ticks): init+adler %llu parse0 %llu | codes %llu dp %llu parse %llu | - %llu plan %llu emit %llu\n",
+                                  dfl_prof_acc[0], dfl_prof_acc[1], dfl_prof_acc[2], dfl_prof_acc[3], dfl_prof_acc[4], dfl_prof_acc[5], dfl_prof_acc[6], dfl_prof_acc[7]);
+#endif
     }
     DFL_SYNC(t);
     return sh->res;

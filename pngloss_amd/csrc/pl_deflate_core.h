@@ -85,6 +85,7 @@ typedef struct {
     uint8_t  depth[2 * DFL_NUM_LL];
     uint8_t  cl_sym[DFL_NUM_LL + DFL_NUM_D];    /* run-length coded code lengths: symbol 0..18 ... */
     uint8_t  cl_arg[DFL_NUM_LL + DFL_NUM_D];    /* ... and its repeat argument */
+    uint16_t lenprice[DFL_MAX_MATCH + 2];       /* price in bits of a match of each length (optimal parse) */
 } dfl_work;
 
 DFL_HD uint32_t dfl_load32(const uint8_t *p)
@@ -237,69 +238,129 @@ DFL_HD uint32_t dfl_parse_block(const uint8_t *s, const uint32_t *match, uint32_
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
- * 3a'. second parse, by price.  Filtered image data has very cheap literals (a handful of small values), so a short
- * match at a long distance can cost more bits than the literals it replaces -- the classic weakness of choosing by
- * length.  With the code lengths of the first parse as prices, a match is used only if it is cheaper than its bytes
- * as literals, and the lazy step compares the SAVINGS of the match here and of the match at the next position.
- * litsum[p] = price of the bytes [begin, p] as literals (inclusive prefix sums, filled in by dfl_literal_prices).
+ * 3a'. optimal parse.  Filtered image data has very cheap literals (a handful of small values) and a few very long
+ * matches, so choosing by length (lazy matching) wastes bits: a short match far away can cost more than the literals it
+ * replaces, and cutting a match short can let a much better one start.  With the code lengths of the previous parse as
+ * prices, the cheapest tokenisation is a shortest path: cost[i] = min(price(literal) + cost[i+1],
+ * price(len l, dist) + cost[i+l] for l up to the longest match at i), evaluated backwards.
+ *
+ * To make that parallel the block is cut into chunks of DFL_DP_CHUNK positions and every chunk runs its own backward
+ * pass, started DFL_DP_OVERLAP positions beyond its end from a neutral terminal condition (costs falling gently with
+ * distance, at the per-byte price of a maximal match, so that no phase is preferred inside long runs).  The choices
+ * depend only on cost differences and those forget the terminal condition within a few tokens; what a chunk keeps are
+ * the choices for its own positions.  The chunking is part of the algorithm's definition (it does not depend on how
+ * many threads work on the block), so every implementation produces the same tokens.
+ * choice[p] = the token to use IF a token starts at p; the tokens of the block are the orbit of `begin`.
  * ------------------------------------------------------------------------------------------------------------- */
-#define DFL_UNSEEN_PRICE 12u           /* bits charged for a symbol the first parse never used */
+#define DFL_UNSEEN_PRICE  12u          /* bits charged for a symbol the previous parse never used */
+#define DFL_DP_CHUNK      1024u
+#define DFL_DP_OVERLAP    512u
+#define DFL_DP_NEAR       8u           /* lengths just below the longest that are always tried */
+#define DFL_DP_ITERATIONS 3            /* parse by length, then this many optimal parses, each priced by the one before */
+#define DFL_DP_RING       264u         /* >= 258 + 1, the furthest cost a position looks at */
 
-DFL_HD void dfl_literal_prices(const uint8_t *s, uint32_t begin, uint32_t end, const dfl_work *w, uint32_t *litsum)
+/* price in bits of every match length under the current lit/len code */
+DFL_HD void dfl_length_prices(dfl_work *w, uint32_t first, uint32_t step)
 {
-    uint32_t acc = 0;
-    for (uint32_t p = begin; p < end; p++) {
-        const uint32_t l = w->len_ll[s[p]];
-        acc += l ? l : DFL_UNSEEN_PRICE;
-        litsum[p] = acc;
+    for (uint32_t l = DFL_MIN_MATCH + first; l <= DFL_MAX_MATCH; l += step) {
+        uint32_t sym, eb, ex;
+        dfl_len_symbol(l, &sym, &eb, &ex);
+        w->lenprice[l] = (uint16_t)((w->len_ll[sym] ? w->len_ll[sym] : DFL_UNSEEN_PRICE) + eb);
     }
 }
 
-DFL_HD int32_t dfl_saving(uint32_t m, uint32_t p, uint32_t begin, const dfl_work *w, const uint32_t *litsum)
+/* top of the length code below the one that expresses l (RFC 1951 3.2.5) */
+DFL_HD uint32_t dfl_prev_code_top(uint32_t l)
 {
-    if (!m) return -1;
-    uint32_t sym, eb, ex, price;
-    const uint32_t len = DFL_TOK_LEN(m);
-    dfl_len_symbol(len, &sym, &eb, &ex);
-    price = (w->len_ll[sym] ? w->len_ll[sym] : DFL_UNSEEN_PRICE) + eb;
-    dfl_dist_symbol(DFL_TOK_DIST(m), &sym, &eb, &ex);
-    price += (w->len_d[sym] ? w->len_d[sym] : DFL_UNSEEN_PRICE) + eb;
-    const uint32_t lits = litsum[p + len - 1] - (p > begin ? litsum[p - 1] : 0u);
-    return (int32_t)lits - (int32_t)price;
+    const uint32_t v = l - 3u;
+    uint32_t base;
+    if (v < 8u) base = l;
+    else if (l == 258u) base = 258u;
+    else { const uint32_t eb = dfl_log2(v) - 2u; base = ((v >> eb) << eb) + 3u; }
+    return base - 1u;
 }
 
-DFL_HD uint32_t dfl_parse_block_priced(const uint8_t *s, const uint32_t *match, uint32_t begin, uint32_t end,
-                                       uint32_t min_len, uint32_t *tok, dfl_work *w, const uint32_t *litsum)
+/* `ring` holds the cost window: cost[i] lives in ring[(i % DFL_DP_RING) * stride] as a 16-bit number (a run is at most
+ * DFL_DP_CHUNK + DFL_DP_OVERLAP + 258 positions of at most 15 bits each above a terminal level of 1024).  On the
+ * device the rings of a workgroup's threads are interleaved in LDS (stride = number of threads). */
+DFL_HD void dfl_dp_chunk(const uint8_t *s, const uint32_t *match, uint32_t begin, uint32_t end, uint32_t min_len,
+                         uint32_t chunk, const dfl_work *w, uint32_t *choice, uint16_t *ring, uint32_t stride)
 {
-    uint32_t n = 0, p = begin;
-    uint32_t cur = p < end ? dfl_clip(match[p], p, end, min_len) : 0;
-    int32_t cur_saving = dfl_saving(cur, p, begin, w, litsum);
-    while (p < end) {
-        if (cur_saving > 0) {
-            const uint32_t nxt = p + 1 < end ? dfl_clip(match[p + 1], p + 1, end, min_len) : 0;
-            const int32_t nxt_saving = dfl_saving(nxt, p + 1, begin, w, litsum);
-            if (nxt_saving > cur_saving) {                             /* defer: literal now, the better match next */
-                w->freq_ll[s[p]]++;
-                tok[n++] = s[p];
-                ++p;
-                cur = nxt;
-                cur_saving = nxt_saving;
-                continue;
+    const uint32_t L = end - begin, c0 = chunk * DFL_DP_CHUNK;
+    if (c0 >= L) return;
+    const uint32_t c1 = c0 + DFL_DP_CHUNK < L ? c0 + DFL_DP_CHUNK : L;
+    const uint32_t top = c1 + DFL_DP_OVERLAP < L ? c1 + DFL_DP_OVERLAP : L;
+    const uint32_t limit = top == L ? L : (top + DFL_MAX_MATCH < L ? top + DFL_MAX_MATCH : L);
+    const uint32_t slope_q8 = ((uint32_t)w->lenprice[DFL_MAX_MATCH] << 8) / DFL_MAX_MATCH;
+    for (uint32_t k = 0; top + k <= limit; k++)
+        ring[((top + k) % DFL_DP_RING) * stride] = (uint16_t)(top == L ? 0u : 1024u - ((k * slope_q8) >> 8));
+    uint32_t next_cost = ring[(top % DFL_DP_RING) * stride];       /* cost[i + 1], kept in a register */
+    uint32_t slot = top % DFL_DP_RING;                             /* ring slot of position i, kept incrementally */
+    for (uint32_t hi = top; hi > c0;) {
+        /* the inputs of the next eight positions do not depend on the costs: fetch them together */
+        enum { TILE = 8 };
+        const uint32_t n = hi - c0 < (uint32_t)TILE ? hi - c0 : (uint32_t)TILE;
+        uint32_t mm[TILE];
+        uint8_t bb[TILE];
+        for (uint32_t k = 0; k < (uint32_t)TILE; k++) {
+            const uint32_t p = begin + hi - 1u - (k < n ? k : n - 1u);
+            mm[k] = match[p];
+            bb[k] = s[p];
+        }
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t i = hi - 1u - k, p = begin + i;
+            slot = slot ? slot - 1u : DFL_DP_RING - 1u;
+            const uint32_t lit = w->len_ll[bb[k]] ? w->len_ll[bb[k]] : DFL_UNSEEN_PRICE;
+            uint32_t best = lit + next_cost, best_len = 0;
+            const uint32_t m = dfl_clip(mm[k], p, end, min_len);
+            if (m) {
+                uint32_t len = DFL_TOK_LEN(m);
+                if (len > limit - i) len = limit - i;
+                uint32_t sym, eb, ex;
+                dfl_dist_symbol(DFL_TOK_DIST(m), &sym, &eb, &ex);
+                const uint32_t dist_price = (w->len_d[sym] ? w->len_d[sym] : DFL_UNSEEN_PRICE) + eb;
+                /* candidates: the DFL_DP_NEAR lengths just below the longest, then one per length code -- the longest
+                 * length the code can express (within a code the price is the same and the cost to go almost never
+                 * rises with distance): <= 37 instead of <= 253, for 0.1 % of size */
+                for (uint32_t j = 1; j <= DFL_DP_NEAR && len >= min_len + j; j++) {
+                    const uint32_t l = len - j;
+                    const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
+                    const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
+                    if (c < best) { best = c; best_len = l; }
+                }
+                for (uint32_t l = len; l >= min_len; l = dfl_prev_code_top(l)) {
+                    const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
+                    const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
+                    if (c < best) { best = c; best_len = l; }
+                }
             }
+            if (i < c1) choice[p] = best_len ? DFL_MAKE_MATCH(best_len, DFL_TOK_DIST(m)) : (uint32_t)bb[k];
+            ring[slot * stride] = (uint16_t)best;
+            next_cost = best;
+        }
+        hi -= n;
+    }
+}
+
+/* tokens of the block from the choices: the orbit of `begin` */
+DFL_HD uint32_t dfl_parse_block_chosen(const uint8_t *s, const uint32_t *choice, uint32_t begin, uint32_t end,
+                                       uint32_t *tok, dfl_work *w)
+{
+    uint32_t n = 0;
+    for (uint32_t p = begin; p < end;) {
+        const uint32_t t = choice[p];
+        if (DFL_IS_MATCH(t)) {
             uint32_t sym, eb, ex;
-            dfl_len_symbol(DFL_TOK_LEN(cur), &sym, &eb, &ex);
+            dfl_len_symbol(DFL_TOK_LEN(t), &sym, &eb, &ex);
             w->freq_ll[sym]++;
-            dfl_dist_symbol(DFL_TOK_DIST(cur), &sym, &eb, &ex);
+            dfl_dist_symbol(DFL_TOK_DIST(t), &sym, &eb, &ex);
             w->freq_d[sym]++;
-            tok[n++] = cur;
-            p += DFL_TOK_LEN(cur);
+            p += DFL_TOK_LEN(t);
         } else {
-            w->freq_ll[s[p]]++;
-            tok[n++] = s[p];
+            w->freq_ll[t]++;
             ++p;
         }
-        cur = p < end ? dfl_clip(match[p], p, end, min_len) : 0;
-        cur_saving = dfl_saving(cur, p, begin, w, litsum);
+        tok[n++] = t;
     }
     return n;
 }
@@ -458,7 +519,7 @@ DFL_HD void dfl_canonical(const uint8_t *len, uint32_t n, uint16_t *code)
  * this block, with room for the stored form (input + 5 bytes per 65535 + 16).  Returns the result record.
  * ------------------------------------------------------------------------------------------------------------- */
 DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match, const dfl_block_desc *d,
-                                         const dfl_params *prm, uint32_t *tok, uint32_t *litsum, uint8_t *out, dfl_work *w)
+                                         const dfl_params *prm, uint32_t *tok, uint32_t *choice, uint8_t *out, dfl_work *w)
 {
     static const uint8_t cl_order[DFL_NUM_CL] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
     dfl_block_result res;
@@ -471,14 +532,18 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
     res.adler_b = 0;
 
     uint32_t ntok = dfl_parse_block(s, match, d->begin, d->end, prm->min_len, tok, w);
-    if (litsum && ntok < L) {                                    /* there are matches: price them and parse again */
-        w->freq_ll[256] = 1;
-        dfl_build_code(w->freq_ll, 286, 15, w->len_ll, w->code_ll, w);
-        dfl_build_code(w->freq_d, 30, 15, w->len_d, w->code_d, w);
-        dfl_literal_prices(s, d->begin, d->end, w, litsum);
-        for (uint32_t i = 0; i < DFL_NUM_LL; i++) w->freq_ll[i] = 0;
-        for (uint32_t i = 0; i < DFL_NUM_D; i++) w->freq_d[i] = 0;
-        ntok = dfl_parse_block_priced(s, match, d->begin, d->end, prm->min_len, tok, w, litsum);
+    if (choice && ntok < L) {                                    /* there are matches: price them and parse again */
+        uint16_t ring[DFL_DP_RING];
+        for (int it = 0; it < DFL_DP_ITERATIONS; it++) {
+            w->freq_ll[256] = 1;
+            dfl_build_code(w->freq_ll, 286, 15, w->len_ll, w->code_ll, w);
+            dfl_build_code(w->freq_d, 30, 15, w->len_d, w->code_d, w);
+            dfl_length_prices(w, 0, 1);
+            for (uint32_t c = 0; c * DFL_DP_CHUNK < L; c++) dfl_dp_chunk(s, match, d->begin, d->end, prm->min_len, c, w, choice, ring, 1);
+            for (uint32_t i = 0; i < DFL_NUM_LL; i++) w->freq_ll[i] = 0;
+            for (uint32_t i = 0; i < DFL_NUM_D; i++) w->freq_d[i] = 0;
+            ntok = dfl_parse_block_chosen(s, choice, d->begin, d->end, tok, w);
+        }
     }
     w->freq_ll[256] = 1;
     res.tokens = ntok;

@@ -22,20 +22,20 @@
 #include "../../pngloss_amd/csrc/pl_deflate_coop.h"
 
 static uint32_t g_levels[12] = { 0 };
-static int g_priced = 1;
+static int g_optimal = 1;
 static int g_team = 0;              /* 0: one-thread dfl_encode_block; N >= 1: dfl_encode_block_coop with a team of N threads */
 extern "C" void dfl_host_set_team(int n) { g_team = n; }
 
 static void barrier_wait(void *b) { pthread_barrier_wait(static_cast<pthread_barrier_t *>(b)); }
 
 static dfl_block_result encode_with_team(int nthreads, const uint8_t *in, const uint32_t *match, const dfl_block_desc *d,
-                                         const dfl_params *prm, uint32_t *tok, uint32_t *litsum, uint8_t *out)
+                                         const dfl_params *prm, uint32_t *tok, uint32_t *choice, uint8_t *out)
 {
     static dfl_coop shared;                      /* the team's "LDS" */
     dfl_block_result res{};
     if (nthreads == 1) {
         dfl_team t = { 0, 1, nullptr, nullptr };
-        return dfl_encode_block_coop(&t, in, match, d, prm, tok, litsum, out, &shared);
+        return dfl_encode_block_coop(&t, in, match, d, prm, tok, choice, out, &shared);
     }
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, nullptr, (unsigned)nthreads);
@@ -43,14 +43,14 @@ static dfl_block_result encode_with_team(int nthreads, const uint8_t *in, const 
     for (int i = 0; i < nthreads; i++)
         th.emplace_back([&, i] {
             dfl_team t = { (uint32_t)i, (uint32_t)nthreads, barrier_wait, &bar };
-            const dfl_block_result r = dfl_encode_block_coop(&t, in, match, d, prm, tok, litsum, out, &shared);
+            const dfl_block_result r = dfl_encode_block_coop(&t, in, match, d, prm, tok, choice, out, &shared);
             if (i == 0) res = r;
         });
     for (auto &x : th) x.join();
     pthread_barrier_destroy(&bar);
     return res;
 }
-extern "C" void dfl_host_set_priced(int on) { g_priced = on; }
+extern "C" void dfl_host_set_optimal(int on) { g_optimal = on; }
 extern "C" void dfl_host_set_levels(const uint32_t *lv, int n) { for (int i = 0; i < 11; i++) g_levels[i] = i < n ? lv[i] : 0; }
 
 extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, uint32_t max_chain,
@@ -82,16 +82,16 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
     uint32_t adler = 1;
     dfl_work work;
     std::vector<uint8_t> buf(dfl_block_bound(block_bytes) + 16);
-    std::vector<uint32_t> litsum(n + 1);
+    std::vector<uint32_t> choice(n + 1);
     if (stats) std::memset(stats, 0, 4 * sizeof(uint32_t));
     for (uint32_t b0 = 0; b0 < n; b0 += block_bytes) {
         dfl_block_desc d = { b0, std::min(n, b0 + block_bytes), 0, n, 0, 0, (uint32_t)buf.size(), 0 };
         std::memset(buf.data(), 0, buf.size());
         dfl_block_result r;
         if (g_team > 0) {
-            r = encode_with_team(g_team, in, match.data(), &d, &prm, tok.data(), g_priced ? litsum.data() : nullptr, buf.data());
+            r = encode_with_team(g_team, in, match.data(), &d, &prm, tok.data(), g_optimal ? choice.data() : nullptr, buf.data());
         } else {
-            r = dfl_encode_block(in, match.data(), &d, &prm, tok.data(), g_priced ? litsum.data() : nullptr, buf.data(), &work);
+            r = dfl_encode_block(in, match.data(), &d, &prm, tok.data(), g_optimal ? choice.data() : nullptr, buf.data(), &work);
             dfl_adler_partial(in, d.begin, d.end, 0, 1, &r.adler_a, &r.adler_b);
         }
         if (pos + r.bytes + 6 > cap) return 0;
@@ -118,7 +118,7 @@ int main(int argc, char **argv)
     std::fclose(f);
     const uint32_t max_chain = argc > 2 ? std::atoi(argv[2]) : 256, min_len = argc > 3 ? std::atoi(argv[3]) : 3,
                    block = argc > 4 ? std::atoi(argv[4]) : 262144;
-    if (std::getenv("DFL_UNPRICED")) g_priced = 0;
+    if (std::getenv("DFL_LAZY_ONLY")) g_optimal = 0;
     if (std::getenv("DFL_TEAM")) g_team = std::atoi(std::getenv("DFL_TEAM"));
     for (int i = 5; i < argc && i < 16; i++) g_levels[i - 5] = std::atoi(argv[i]);
     std::vector<uint8_t> out(in.size() + in.size() / 8 + 1024);
