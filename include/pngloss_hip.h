@@ -154,8 +154,9 @@ int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip
  * PNG's IDAT data (what /root/reference/src/rwpng.c:477-637 obtains from libpng + zlib level 9 on the CPU, and where
  * the reference tool spends its time once the hot path is fast).  The stream inflates to exactly the scanlines the
  * _emit call returns -- so the decoded PNG is identical -- but it is not the byte sequence zlib would write:
- * the encoder is the GPU one of pngloss_amd/csrc/pl_deflate_core.h (multi-level match search, 256 KiB blocks that each
- * end byte-aligned).  On the files of the reference's suite its output is 1-5 % smaller than zlib level 9 / Z_FILTERED.
+ * the encoder is the GPU one of pngloss_amd/csrc/pl_deflate_core.h (multi-level match search, optimal parse, 256 KiB
+ * blocks that each end byte-aligned).  On the files of the reference's suite its output is 6-10 % smaller than zlib
+ * level 9 / Z_FILTERED.
  * `data` must have room for pngloss_hip_zlib_bound(width, height) bytes; `size` = 0 for an empty image.  One image may
  * have at most 1 GiB of scanlines ((4*width+1)*height; positions are 32-bit on the device): larger ones make the call
  * return PNGLOSS_INVALID_ARGUMENT -- use the _emit form and a CPU deflate for those. */

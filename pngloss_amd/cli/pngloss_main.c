@@ -56,7 +56,7 @@ static const char usage_text[] =
     "  --ext new.png     set custom suffix/extension for output filenames\n"
     "  --strip           remove optional metadata (default on Mac)\n"
     "  --gpu-deflate     compress the image data on the GPU too (not zlib's bytes, same pixels,\n"
-    "                    files as small as or smaller than zlib level 9, much faster)\n"
+    "                    files several percent smaller than with zlib level 9, much faster)\n"
     "\n"
     "Lossily compresses PNGs by using more compressible colors that are close enough to the\n"
     "original values; the filter+quantise pass runs on the GPU (all files of a call as one batch).\n"

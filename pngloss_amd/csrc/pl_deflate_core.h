@@ -255,7 +255,8 @@ DFL_HD uint32_t dfl_parse_block(const uint8_t *s, const uint32_t *match, uint32_
 #define DFL_UNSEEN_PRICE  12u          /* bits charged for a symbol the previous parse never used */
 #define DFL_DP_CHUNK      1024u
 #define DFL_DP_OVERLAP    512u
-#define DFL_DP_NEAR       8u           /* lengths just below the longest that are always tried */
+#define DFL_DP_NEAR       4u           /* lengths just below the longest that are always tried */
+#define DFL_DP_TOPS       5u           /* then the longest length of this many length codes, from the match's own downwards */
 #define DFL_DP_ITERATIONS 3            /* parse by length, then this many optimal parses, each priced by the one before */
 #define DFL_DP_RING       264u         /* >= 258 + 1, the furthest cost a position looks at */
 
@@ -296,49 +297,44 @@ DFL_HD void dfl_dp_chunk(const uint8_t *s, const uint32_t *match, uint32_t begin
         ring[((top + k) % DFL_DP_RING) * stride] = (uint16_t)(top == L ? 0u : 1024u - ((k * slope_q8) >> 8));
     uint32_t next_cost = ring[(top % DFL_DP_RING) * stride];       /* cost[i + 1], kept in a register */
     uint32_t slot = top % DFL_DP_RING;                             /* ring slot of position i, kept incrementally */
-    for (uint32_t hi = top; hi > c0;) {
-        /* the inputs of the next eight positions do not depend on the costs: fetch them together */
-        enum { TILE = 8 };
-        const uint32_t n = hi - c0 < (uint32_t)TILE ? hi - c0 : (uint32_t)TILE;
-        uint32_t mm[TILE];
-        uint8_t bb[TILE];
-        for (uint32_t k = 0; k < (uint32_t)TILE; k++) {
-            const uint32_t p = begin + hi - 1u - (k < n ? k : n - 1u);
-            mm[k] = match[p];
-            bb[k] = s[p];
-        }
-        for (uint32_t k = 0; k < n; k++) {
-            const uint32_t i = hi - 1u - k, p = begin + i;
-            slot = slot ? slot - 1u : DFL_DP_RING - 1u;
-            const uint32_t lit = w->len_ll[bb[k]] ? w->len_ll[bb[k]] : DFL_UNSEEN_PRICE;
-            uint32_t best = lit + next_cost, best_len = 0;
-            const uint32_t m = dfl_clip(mm[k], p, end, min_len);
-            if (m) {
-                uint32_t len = DFL_TOK_LEN(m);
-                if (len > limit - i) len = limit - i;
-                uint32_t sym, eb, ex;
-                dfl_dist_symbol(DFL_TOK_DIST(m), &sym, &eb, &ex);
-                const uint32_t dist_price = (w->len_d[sym] ? w->len_d[sym] : DFL_UNSEEN_PRICE) + eb;
-                /* candidates: the DFL_DP_NEAR lengths just below the longest, then one per length code -- the longest
-                 * length the code can express (within a code the price is the same and the cost to go almost never
-                 * rises with distance): <= 37 instead of <= 253, for 0.1 % of size */
-                for (uint32_t j = 1; j <= DFL_DP_NEAR && len >= min_len + j; j++) {
-                    const uint32_t l = len - j;
-                    const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
-                    const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
-                    if (c < best) { best = c; best_len = l; }
-                }
-                for (uint32_t l = len; l >= min_len; l = dfl_prev_code_top(l)) {
-                    const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
-                    const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
-                    if (c < best) { best = c; best_len = l; }
-                }
+    /* the inputs of a position do not depend on the costs: they are fetched two positions ahead */
+    uint32_t m_a = match[begin + top - 1u], m_b = top >= c0 + 2u ? match[begin + top - 2u] : 0u;
+    uint32_t b_a = s[begin + top - 1u], b_b = top >= c0 + 2u ? s[begin + top - 2u] : 0u;
+    for (uint32_t i = top; i-- > c0;) {
+        const uint32_t p = begin + i;
+        const uint32_t raw = m_a, byte = b_a;
+        m_a = m_b; b_a = b_b;
+        if (i >= c0 + 2u) { m_b = match[p - 2u]; b_b = s[p - 2u]; }
+        slot = slot ? slot - 1u : DFL_DP_RING - 1u;
+        const uint32_t lit = w->len_ll[byte] ? w->len_ll[byte] : DFL_UNSEEN_PRICE;
+        uint32_t best = lit + next_cost, best_len = 0;
+        const uint32_t m = dfl_clip(raw, p, end, min_len);
+        if (m) {
+            uint32_t len = DFL_TOK_LEN(m);
+            if (len > limit - i) len = limit - i;
+            uint32_t sym, eb, ex;
+            dfl_dist_symbol(DFL_TOK_DIST(m), &sym, &eb, &ex);
+            const uint32_t dist_price = (w->len_d[sym] ? w->len_d[sym] : DFL_UNSEEN_PRICE) + eb;
+            /* candidates: the DFL_DP_NEAR lengths just below the longest, then one per length code -- the longest
+             * length the code can express (within a code the price is the same and the cost to go almost never
+             * rises with distance) -- for the DFL_DP_TOPS codes from the match's own downwards: <= 9 candidates
+             * instead of <= 253, for 0.2 % of size (cutting a match to less than a quarter almost never pays) */
+            for (uint32_t j = 1; j <= DFL_DP_NEAR && len >= min_len + j; j++) {
+                const uint32_t l = len - j;
+                const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
+                const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
+                if (c < best) { best = c; best_len = l; }
             }
-            if (i < c1) choice[p] = best_len ? DFL_MAKE_MATCH(best_len, DFL_TOK_DIST(m)) : (uint32_t)bb[k];
-            ring[slot * stride] = (uint16_t)best;
-            next_cost = best;
+            uint32_t tops = 0;
+            for (uint32_t l = len; l >= min_len && tops < DFL_DP_TOPS; l = dfl_prev_code_top(l), tops++) {
+                const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
+                const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
+                if (c < best) { best = c; best_len = l; }
+            }
         }
-        hi -= n;
+        if (i < c1) choice[p] = best_len ? DFL_MAKE_MATCH(best_len, DFL_TOK_DIST(m)) : byte;
+        ring[slot * stride] = (uint16_t)best;
+        next_cost = best;
     }
 }
 
