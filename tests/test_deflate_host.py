@@ -95,7 +95,7 @@ def test_size_vs_zlib9_on_a_larger_frame(host):
     data = scanline_stream(P.synth_rgba(512, 384, 0, 0))
     z, _ = deflate(host, data)
     assert zlib.decompress(z) == data
-    assert len(z) <= 1.005 * len(zlib9f(data))
+    assert len(z) <= 0.95 * len(zlib9f(data))                         # measured 0.93: the optimal parse at work
 
 
 def test_team_encoder_is_byte_identical_to_the_one_thread_encoder(host):

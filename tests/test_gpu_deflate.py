@@ -70,7 +70,7 @@ def test_multi_block_images_adaptive_mode_and_strengths(ctx):
     data = stream_of(emitted[0])
     ctype, z, blocks = streams[0]
     assert zlib.decompress(z) == data and sum(blocks) == -(-len(data) // 262144)
-    assert len(z) <= 1.002 * len(U.zlib9_filtered(data))           # measured: 0.4 % smaller than zlib level 9
+    assert len(z) <= 0.95 * len(U.zlib9_filtered(data))            # measured: 6.1 % smaller than zlib level 9
     small = [P.synth_rgba(320, 200, 0, 1)]
     for s, b, wf in [(0, 2, True), (40, 2, True), (255, 1, True), (19, 2, False)]:
         emitted, streams = run_both(ctx, small, s, b, wf)
