@@ -204,7 +204,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
         dfl_flags<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_key[1], total, d_flag);
         DFL_CHECK(hipcub::DeviceScan::InclusiveScan(d_temp, temp_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
         dfl_match<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], d_gstart, total, d_s, d_img_begin, (uint32_t)n,
-                                                                                  prm.max_chain, lv ? kLevels[lv - 1] : 0u, d_match);
+                                                                                  dfl_level_chain(prm.max_chain, kLevels[lv]), lv ? kLevels[lv - 1] : 0u, d_match);
     }
     DFL_CHECK(hipMemsetAsync(d_arena, 0, arena_bytes, stream));
     dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_choice, d_arena, d_result);
