@@ -49,6 +49,15 @@ __global__ __launch_bounds__(kThreads) void dfl_pack(const dfl_block_desc *desc,
     s[p] = x ? im.rows[(size_t)y * im.pitch + (x - 1u)] : im.ids[y];
 }
 
+/* second record per position: the longest match at distance 1..8 (dfl_near_match) */
+__global__ __launch_bounds__(kThreads) void dfl_near(const dfl_block_desc *desc, const uint8_t *s, uint32_t *near)
+{
+    const dfl_block_desc d = desc[blockIdx.y];
+    const uint32_t p = d.begin + blockIdx.x * kThreads + threadIdx.x;
+    if (p >= d.end) return;
+    near[p] = dfl_near_match(s, d.img_begin, d.img_end, p);
+}
+
 __global__ __launch_bounds__(kThreads) void dfl_keys(const dfl_block_desc *desc, const uint8_t *s, uint32_t nbytes,
                                                      uint32_t *key, uint32_t *val)
 {
@@ -90,14 +99,14 @@ __global__ __launch_bounds__(kThreads) void dfl_match(const uint32_t *sorted, co
 }
 
 /* one 256-thread workgroup per deflate block: pl_deflate_coop.h; `arena` must be zero (the bits are OR-ed in) */
-__global__ __launch_bounds__(kThreads) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match,
+__global__ __launch_bounds__(kThreads) void dfl_encode(const dfl_block_desc *desc, const uint8_t *s, const uint32_t *match, const uint32_t *near,
                                                        dfl_params prm, uint32_t *tok, uint32_t *choice, uint8_t *arena,
                                                        dfl_block_result *result)
 {
     __shared__ dfl_coop shared;
     const dfl_block_desc d = desc[blockIdx.x];
     dfl_team team = { threadIdx.x, kThreads, nullptr, nullptr };
-    const dfl_block_result res = dfl_encode_block_coop(&team, s, match, &d, &prm, tok + d.begin, choice, arena + d.out_offset, &shared);
+    const dfl_block_result res = dfl_encode_block_coop(&team, s, match, near, &d, &prm, tok + d.begin, choice, arena + d.out_offset, &shared);
     if (threadIdx.x == 0) result[blockIdx.x] = res;
 }
 
@@ -150,7 +159,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
 
     uint8_t *d_s = nullptr, *d_arena = nullptr, *d_compact = nullptr, *d_temp = nullptr;
     uint32_t *d_key[2] = { nullptr, nullptr };
-    uint32_t *d_val[2] = { nullptr, nullptr }, *d_choice = nullptr, *d_match = nullptr, *d_tok = nullptr, *d_dest = nullptr;
+    uint32_t *d_val[2] = { nullptr, nullptr }, *d_choice = nullptr, *d_match = nullptr, *d_near = nullptr, *d_tok = nullptr, *d_dest = nullptr;
     dfl_block_desc *d_desc = nullptr;
     dfl_block_result *d_result = nullptr;
     DflImageDev *d_img = nullptr;
@@ -173,6 +182,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     DFL_CHECK(dev_alloc(&d_val[1], total));
     DFL_CHECK(dev_alloc(&d_choice, total));               /* token choices of the optimal parse */
     DFL_CHECK(dev_alloc(&d_match, total));
+    DFL_CHECK(dev_alloc(&d_near, total));
     DFL_CHECK(dev_alloc(&d_tok, total));
     DFL_CHECK(dev_alloc(&d_arena, arena_bytes));
     DFL_CHECK(dev_alloc(&d_desc, nblocks));
@@ -198,6 +208,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     }
 
     dfl_pack<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_img, d_s);
+    dfl_near<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, d_near);
     for (int lv = 0; lv < kNumLevels; lv++) {
         dfl_keys<<<pos_grid, kThreads, 0, stream>>>(d_desc, d_s, kLevels[lv], d_key[0], d_val[0]);
         DFL_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], total, 0, DFL_KEY_BITS, stream));
@@ -207,7 +218,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
                                                                                   dfl_level_chain(prm.max_chain, kLevels[lv]), lv ? kLevels[lv - 1] : 0u, d_match);
     }
     DFL_CHECK(hipMemsetAsync(d_arena, 0, arena_bytes, stream));
-    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, prm, d_tok, d_choice, d_arena, d_result);
+    dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, d_near, prm, d_tok, d_choice, d_arena, d_result);
     DFL_CHECK(hipGetLastError());
     DFL_CHECK(hipMemcpyAsync(result.data(), d_result, sizeof(dfl_block_result) * nblocks, hipMemcpyDeviceToHost, stream));
     DFL_CHECK(hipStreamSynchronize(stream));
@@ -250,7 +261,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
     ms_copy = ms_since(t_begin) - ms_alloc - ms_kernels - ms_gather;
 done:
     (void)hipFree(d_s); (void)hipFree(d_key[0]); (void)hipFree(d_key[1]); (void)hipFree(d_val[0]); (void)hipFree(d_val[1]);
-    (void)hipFree(d_choice); (void)hipFree(d_match); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
+    (void)hipFree(d_choice); (void)hipFree(d_match); (void)hipFree(d_near); (void)hipFree(d_tok); (void)hipFree(d_arena); (void)hipFree(d_desc);
     (void)hipFree(d_result); (void)hipFree(d_dest); (void)hipFree(d_img); (void)hipFree(d_temp); (void)hipFree(d_compact);
     (void)hipFree(d_img_begin);
     if (debug)

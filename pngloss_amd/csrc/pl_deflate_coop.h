@@ -248,7 +248,7 @@ DFL_HD uint32_t dfl_token_bits(uint32_t tk, const dfl_work *w)
  * aligned and dfl_block_bound(L) long; `choice` is per-position scratch (NULL: single parse by length).  The result
  * is returned to every thread.
  * ------------------------------------------------------------------------------------------------------------- */
-DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *s, const uint32_t *match,
+DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *s, const uint32_t *match, const uint32_t *near,
                                               const dfl_block_desc *d, const dfl_params *prm, uint32_t *tok,
                                               uint32_t *choice, uint8_t *out, dfl_coop *sh)
 {
@@ -293,7 +293,7 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
             DFL_SYNC(t);
             DFL_PROF(2);
             for (uint32_t c = t->tid; c * DFL_DP_CHUNK < L; c += t->nthreads)
-                dfl_dp_chunk(s, match, d->begin, d->end, prm->min_len, c, w, choice, &sh->u.ring[t->tid], t->nthreads);
+                dfl_dp_chunk(s, match, near, d->begin, d->end, prm->min_len, c, w, choice, &sh->u.ring[t->tid], t->nthreads);
             for (uint32_t i = t->tid; i < DFL_NUM_LL; i += t->nthreads) w->freq_ll[i] = 0;
             for (uint32_t i = t->tid; i < DFL_NUM_D; i += t->nthreads) w->freq_d[i] = 0;
             DFL_SYNC(t);

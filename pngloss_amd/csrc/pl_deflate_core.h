@@ -175,6 +175,34 @@ DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t 
     return best_dist ? DFL_MAKE_MATCH(best_len, best_dist) : 0u;
 }
 
+/* The longest match among the DFL_NEAR_DIST nearest positions (distance 1..8: the previous bytes of the same channel,
+ * the previous pixel).  These have the cheapest distance codes, no extra bits up to distance 4, so the optimal parse
+ * often prefers one of them to the longest match, which may lie 30 KB away; they are kept as a second record per
+ * position (0.6 % of size on the reference's suite).  Of equally long ones the nearest wins. */
+#define DFL_NEAR_DIST 8u
+
+DFL_HD uint32_t dfl_near_match(const uint8_t *s, uint32_t img_begin, uint32_t img_end, uint32_t p)
+{
+    const uint32_t room = img_end - p;
+    if (room < DFL_KEY_BYTES) return 0;
+    const uint32_t max_len = room < DFL_MAX_MATCH ? room : DFL_MAX_MATCH;
+    const uint8_t *b = s + p;
+    uint32_t best_len = DFL_KEY_BYTES - 1, best_dist = 0;
+    for (uint32_t dist = 1; dist <= DFL_NEAR_DIST && dist <= p - img_begin; dist++) {
+        const uint8_t *a = b - dist;
+        if (a[0] != b[0] || a[best_len] != b[best_len]) continue;
+        uint32_t len = 0;
+        while (len + 4 <= max_len && dfl_load32(a + len) == dfl_load32(b + len)) len += 4;
+        while (len < max_len && a[len] == b[len]) ++len;
+        if (len > best_len) {
+            best_len = len;
+            best_dist = dist;
+            if (len >= max_len) break;
+        }
+    }
+    return best_dist ? DFL_MAKE_MATCH(best_len, best_dist) : 0u;
+}
+
 /* ---------------------------------------------------------------------------------------------------------------
  * symbol mapping (RFC 1951 section 3.2.5), computed instead of tabulated
  * ------------------------------------------------------------------------------------------------------------- */
@@ -252,7 +280,8 @@ DFL_HD uint32_t dfl_parse_block(const uint8_t *s, const uint32_t *match, uint32_
  * matches, so choosing by length (lazy matching) wastes bits: a short match far away can cost more than the literals it
  * replaces, and cutting a match short can let a much better one start.  With the code lengths of the previous parse as
  * prices, the cheapest tokenisation is a shortest path: cost[i] = min(price(literal) + cost[i+1],
- * price(len l, dist) + cost[i+l] for l up to the longest match at i), evaluated backwards.
+ * price(len l, dist) + cost[i+l] for l up to the longest match at i -- or up to the longest NEAR match at i, the second
+ * record of a position), evaluated backwards.
  *
  * To make that parallel the block is cut into chunks of DFL_DP_CHUNK positions and every chunk runs its own backward
  * pass, started DFL_DP_OVERLAP positions beyond its end from a neutral terminal condition (costs falling gently with
@@ -294,8 +323,8 @@ DFL_HD uint32_t dfl_prev_code_top(uint32_t l)
 /* `ring` holds the cost window: cost[i] lives in ring[(i % DFL_DP_RING) * stride] as a 16-bit number (a run is at most
  * DFL_DP_CHUNK + DFL_DP_OVERLAP + 258 positions of at most 15 bits each above a terminal level of 1024).  On the
  * device the rings of a workgroup's threads are interleaved in LDS (stride = number of threads). */
-DFL_HD void dfl_dp_chunk(const uint8_t *s, const uint32_t *match, uint32_t begin, uint32_t end, uint32_t min_len,
-                         uint32_t chunk, const dfl_work *w, uint32_t *choice, uint16_t *ring, uint32_t stride)
+DFL_HD void dfl_dp_chunk(const uint8_t *s, const uint32_t *match, const uint32_t *near, uint32_t begin, uint32_t end,
+                         uint32_t min_len, uint32_t chunk, const dfl_work *w, uint32_t *choice, uint16_t *ring, uint32_t stride)
 {
     const uint32_t L = end - begin, c0 = chunk * DFL_DP_CHUNK;
     if (c0 >= L) return;
@@ -308,18 +337,23 @@ DFL_HD void dfl_dp_chunk(const uint8_t *s, const uint32_t *match, uint32_t begin
     uint32_t next_cost = ring[(top % DFL_DP_RING) * stride];       /* cost[i + 1], kept in a register */
     uint32_t slot = top % DFL_DP_RING;                             /* ring slot of position i, kept incrementally */
     /* the inputs of a position do not depend on the costs: they are fetched two positions ahead */
-    uint32_t m_a = match[begin + top - 1u], m_b = top >= c0 + 2u ? match[begin + top - 2u] : 0u;
-    uint32_t b_a = s[begin + top - 1u], b_b = top >= c0 + 2u ? s[begin + top - 2u] : 0u;
+    const bool two = top >= c0 + 2u;
+    uint32_t m_a = match[begin + top - 1u], m_b = two ? match[begin + top - 2u] : 0u;
+    uint32_t n_a = near[begin + top - 1u], n_b = two ? near[begin + top - 2u] : 0u;
+    uint32_t b_a = s[begin + top - 1u], b_b = two ? s[begin + top - 2u] : 0u;
     for (uint32_t i = top; i-- > c0;) {
         const uint32_t p = begin + i;
-        const uint32_t raw = m_a, byte = b_a;
-        m_a = m_b; b_a = b_b;
-        if (i >= c0 + 2u) { m_b = match[p - 2u]; b_b = s[p - 2u]; }
+        const uint32_t byte = b_a;
+        uint32_t rec[2] = { dfl_clip(m_a, p, end, min_len), dfl_clip(n_a, p, end, min_len) };
+        m_a = m_b; n_a = n_b; b_a = b_b;
+        if (i >= c0 + 2u) { m_b = match[p - 2u]; n_b = near[p - 2u]; b_b = s[p - 2u]; }
         slot = slot ? slot - 1u : DFL_DP_RING - 1u;
         const uint32_t lit = w->len_ll[byte] ? w->len_ll[byte] : DFL_UNSEEN_PRICE;
-        uint32_t best = lit + next_cost, best_len = 0;
-        const uint32_t m = dfl_clip(raw, p, end, min_len);
-        if (m) {
+        uint32_t best = lit + next_cost, best_tok = byte;
+        if (rec[1] && rec[0] && DFL_TOK_DIST(rec[1]) == DFL_TOK_DIST(rec[0])) rec[1] = 0;    /* the same match, or a prefix of it */
+        for (uint32_t r = 0; r < 2; r++) {
+            const uint32_t m = rec[r];
+            if (!m) continue;
             uint32_t len = DFL_TOK_LEN(m);
             if (len > limit - i) len = limit - i;
             uint32_t sym, eb, ex;
@@ -333,16 +367,16 @@ DFL_HD void dfl_dp_chunk(const uint8_t *s, const uint32_t *match, uint32_t begin
                 const uint32_t l = len - j;
                 const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
                 const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
-                if (c < best) { best = c; best_len = l; }
+                if (c < best) { best = c; best_tok = DFL_MAKE_MATCH(l, DFL_TOK_DIST(m)); }
             }
             uint32_t tops = 0;
             for (uint32_t l = len; l >= min_len && tops < DFL_DP_TOPS; l = dfl_prev_code_top(l), tops++) {
                 const uint32_t at = slot + l < DFL_DP_RING ? slot + l : slot + l - DFL_DP_RING;
                 const uint32_t c = w->lenprice[l] + dist_price + ring[at * stride];
-                if (c < best) { best = c; best_len = l; }
+                if (c < best) { best = c; best_tok = DFL_MAKE_MATCH(l, DFL_TOK_DIST(m)); }
             }
         }
-        if (i < c1) choice[p] = best_len ? DFL_MAKE_MATCH(best_len, DFL_TOK_DIST(m)) : byte;
+        if (i < c1) choice[p] = best_tok;
         ring[slot * stride] = (uint16_t)best;
         next_cost = best;
     }
@@ -524,7 +558,7 @@ DFL_HD void dfl_canonical(const uint8_t *len, uint32_t n, uint16_t *code)
  * 3c. one whole block: parse, code, choose the representation, write.  `out` must be 4-byte aligned, zero-offset for
  * this block, with room for the stored form (input + 5 bytes per 65535 + 16).  Returns the result record.
  * ------------------------------------------------------------------------------------------------------------- */
-DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match, const dfl_block_desc *d,
+DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match, const uint32_t *near, const dfl_block_desc *d,
                                          const dfl_params *prm, uint32_t *tok, uint32_t *choice, uint8_t *out, dfl_work *w)
 {
     static const uint8_t cl_order[DFL_NUM_CL] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
@@ -545,7 +579,7 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
             dfl_build_code(w->freq_ll, 286, 15, w->len_ll, w->code_ll, w);
             dfl_build_code(w->freq_d, 30, 15, w->len_d, w->code_d, w);
             dfl_length_prices(w, 0, 1);
-            for (uint32_t c = 0; c * DFL_DP_CHUNK < L; c++) dfl_dp_chunk(s, match, d->begin, d->end, prm->min_len, c, w, choice, ring, 1);
+            for (uint32_t c = 0; c * DFL_DP_CHUNK < L; c++) dfl_dp_chunk(s, match, near, d->begin, d->end, prm->min_len, c, w, choice, ring, 1);
             for (uint32_t i = 0; i < DFL_NUM_LL; i++) w->freq_ll[i] = 0;
             for (uint32_t i = 0; i < DFL_NUM_D; i++) w->freq_d[i] = 0;
             ntok = dfl_parse_block_chosen(s, choice, d->begin, d->end, tok, w);

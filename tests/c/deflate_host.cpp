@@ -28,14 +28,14 @@ extern "C" void dfl_host_set_team(int n) { g_team = n; }
 
 static void barrier_wait(void *b) { pthread_barrier_wait(static_cast<pthread_barrier_t *>(b)); }
 
-static dfl_block_result encode_with_team(int nthreads, const uint8_t *in, const uint32_t *match, const dfl_block_desc *d,
+static dfl_block_result encode_with_team(int nthreads, const uint8_t *in, const uint32_t *match, const uint32_t *near, const dfl_block_desc *d,
                                          const dfl_params *prm, uint32_t *tok, uint32_t *choice, uint8_t *out)
 {
     static dfl_coop shared;                      /* the team's "LDS" */
     dfl_block_result res{};
     if (nthreads == 1) {
         dfl_team t = { 0, 1, nullptr, nullptr };
-        return dfl_encode_block_coop(&t, in, match, d, prm, tok, choice, out, &shared);
+        return dfl_encode_block_coop(&t, in, match, near, d, prm, tok, choice, out, &shared);
     }
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, nullptr, (unsigned)nthreads);
@@ -43,7 +43,7 @@ static dfl_block_result encode_with_team(int nthreads, const uint8_t *in, const 
     for (int i = 0; i < nthreads; i++)
         th.emplace_back([&, i] {
             dfl_team t = { (uint32_t)i, (uint32_t)nthreads, barrier_wait, &bar };
-            const dfl_block_result r = dfl_encode_block_coop(&t, in, match, d, prm, tok, choice, out, &shared);
+            const dfl_block_result r = dfl_encode_block_coop(&t, in, match, near, d, prm, tok, choice, out, &shared);
             if (i == 0) res = r;
         });
     for (auto &x : th) x.join();
@@ -76,6 +76,9 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
             match[p] = dfl_search_level(in, 0, n, p, sorted.data(), rank[p], gstart[rank[p]], dfl_level_chain(max_chain, levels[lv]), lv ? levels[lv - 1] : 0u, match[p]);
     }
 
+    std::vector<uint32_t> near(n);
+    for (uint32_t p = 0; p < n; p++) near[p] = dfl_near_match(in, 0, n, p);
+
     size_t pos = 0;
     if (cap < 8) return 0;
     out[pos++] = 0x78; out[pos++] = 0xda;
@@ -89,9 +92,9 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
         std::memset(buf.data(), 0, buf.size());
         dfl_block_result r;
         if (g_team > 0) {
-            r = encode_with_team(g_team, in, match.data(), &d, &prm, tok.data(), g_optimal ? choice.data() : nullptr, buf.data());
+            r = encode_with_team(g_team, in, match.data(), near.data(), &d, &prm, tok.data(), g_optimal ? choice.data() : nullptr, buf.data());
         } else {
-            r = dfl_encode_block(in, match.data(), &d, &prm, tok.data(), g_optimal ? choice.data() : nullptr, buf.data(), &work);
+            r = dfl_encode_block(in, match.data(), near.data(), &d, &prm, tok.data(), g_optimal ? choice.data() : nullptr, buf.data(), &work);
             dfl_adler_partial(in, d.begin, d.end, 0, 1, &r.adler_a, &r.adler_b);
         }
         if (pos + r.bytes + 6 > cap) return 0;
