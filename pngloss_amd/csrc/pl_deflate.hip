@@ -284,6 +284,9 @@ hipError_t pl_deflate_images(pl_deflate_image *imgs, size_t n, hipStream_t strea
 {
     dfl_params prm = { PL_DEFLATE_MAX_CHAIN, DFL_KEY_BYTES, PL_DEFLATE_BLOCK_BYTES };
     if (const char *e = std::getenv("PNGLOSS_HIP_DEFLATE_CHAIN")) prm.max_chain = (uint32_t)std::max(1, std::atoi(e));
+    /* images are processed in groups of at most `group_bytes` of scanlines (test hook: a small value forces many groups) */
+    uint64_t group_bytes = PL_DEFLATE_MAX_STREAM;
+    if (const char *e = std::getenv("PNGLOSS_HIP_DEFLATE_GROUP_BYTES")) group_bytes = std::min<uint64_t>(PL_DEFLATE_MAX_STREAM, std::max(1ll, std::atoll(e)));
     size_t i = 0;
     while (i < n) {
         uint64_t bytes = 0;
@@ -291,7 +294,7 @@ hipError_t pl_deflate_images(pl_deflate_image *imgs, size_t n, hipStream_t strea
         while (j < n) {
             const uint64_t len = ((uint64_t)imgs[j].rowbytes + 1u) * imgs[j].height;
             if (len > PL_DEFLATE_MAX_STREAM) return hipErrorInvalidValue;   /* one image beyond 32-bit positions */
-            if (j > i && bytes + len > PL_DEFLATE_MAX_STREAM) break;
+            if (j > i && bytes + len > group_bytes) break;
             bytes += len;
             ++j;
         }

@@ -95,3 +95,28 @@ def test_mixed_batch_matches_single_image_calls(ctx):
     for a, got in zip(arrays, batch):
         _, single = run_both(ctx, [a])
         assert single[0] == got
+
+
+def test_batches_split_into_several_groups(tmp_path):
+    """A call handles at most 1 GiB of scanlines at a time and walks through larger batches in groups; a small group
+    size (test hook PNGLOSS_HIP_DEFLATE_GROUP_BYTES) makes that path run with a handful of images."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, zlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import pngloss_amd as P\n"
+        "from tests import util as U\n"
+        "ctx = P.HipContext(0)\n"
+        "arrays = [P.synth_rgba(w, h, m, 9) for (w, h, m) in [(300, 200, 0), (64, 64, 1), (500, 400, 2), (31, 17, 3), (400, 300, 5), (200, 100, 0), (128, 128, 4)]]\n"
+        "outs, filts, emitted = ctx.run_host_emit(arrays)\n"
+        "outs2, filts2, streams = ctx.run_host_zlib(arrays)\n"
+        "for e, (ctype, z, blocks) in zip(emitted, streams):\n"
+        "    data = np.concatenate([e[1][:, None], e[2]], axis=1).tobytes()\n"
+        "    assert ctype == e[0] and zlib.decompress(z) == data and z == U.deflate_host(data)[0]\n"
+        "print('groups ok')\n" % U.ROOT)
+    env = dict(os.environ, PNGLOSS_HIP_DEFLATE_GROUP_BYTES="300000", PNGLOSS_HIP_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "groups ok" in r.stdout, r.stderr[-800:]
+    assert r.stderr.count("pngloss_hip deflate:") >= 4          # the seven images went through several groups
