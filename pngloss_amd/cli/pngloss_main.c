@@ -30,7 +30,8 @@
 #include "png_stream_writer.h"
 
 #define PNGLOSS_VERSION "1.0.1-mi355x"
-#define WINDOW_FILES 256                 /* images per GPU batch (one workgroup each)              */
+#define WINDOW_FILES window_files()      /* images per GPU batch (one workgroup each): 256, or $PNGLOSS_WINDOW_FILES */
+static size_t window_files(void);
 
 struct options {
     const char *extension, *output_path;
@@ -349,12 +350,43 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static pngloss_error run_window(struct job *jobs, size_t n, const struct options *o, pngloss_hip_ctx **ctx)
+static size_t window_files(void)
+{
+    const char *e = getenv("PNGLOSS_WINDOW_FILES");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (size_t)v : 256;
+}
+
+/* stage 1 of a window, possibly running in the background while the previous window is on the GPU */
+struct decode_ahead { struct job *jobs; size_t n; const struct options *o; pthread_t thread; bool running; double seconds; };
+
+static void *decode_ahead_main(void *arg)
+{
+    struct decode_ahead *d = arg;
+    const double t0 = now_s();
+    for_each_job(d->jobs, d->n, d->o, decode_job);
+    d->seconds = now_s() - t0;
+    return NULL;
+}
+
+static void decode_ahead_start(struct decode_ahead *d, struct job *jobs, size_t n, const struct options *o)
+{
+    d->jobs = jobs; d->n = n; d->o = o; d->seconds = 0;
+    d->running = n && pthread_create(&d->thread, NULL, decode_ahead_main, d) == 0;
+    if (n && !d->running) decode_ahead_main(d);              /* no thread: decode right here */
+}
+
+static void decode_ahead_wait(struct decode_ahead *d)
+{
+    if (d->running) pthread_join(d->thread, NULL);
+    d->running = false;
+}
+
+/* stages 2 and 3 of a window whose files are decoded already */
+static pngloss_error run_window(struct job *jobs, size_t n, const struct options *o, pngloss_hip_ctx **ctx, double decode_seconds)
 {
     const bool timing = getenv("PNGLOSS_TIMING") != NULL;
-    const double t0 = now_s();
-    for_each_job(jobs, n, o, decode_job);
-    const double t1 = now_s();
+    const double t1 = now_s(), t0 = t1 - decode_seconds;
 
     /* stage 2: every decoded image of the window in one GPU batch */
     pngloss_hip_host_image *imgs = calloc(n ? n : 1, sizeof *imgs);
@@ -458,10 +490,18 @@ int main(int argc, char **argv)
     pngloss_hip_ctx *ctx = NULL;
     pngloss_error latest = SUCCESS;
     unsigned errors = 0, skipped = 0;
+    /* windows of up to WINDOW_FILES files: decoded (threads), optimised as ONE GPU batch, encoded (threads).  The next
+     * window is decoded in the background while the current one is on the GPU (pngloss.c:173 is a sequential loop). */
+    struct decode_ahead ahead;
+    memset(&ahead, 0, sizeof ahead);
+    decode_ahead_start(&ahead, jobs, total < WINDOW_FILES ? total : WINDOW_FILES, &o);
     for (size_t start = 0; start < total;) {
-        /* a window: up to WINDOW_FILES files decoded, optimised as one GPU batch, encoded */
         size_t n = total - start < WINDOW_FILES ? total - start : WINDOW_FILES;
-        run_window(jobs + start, n, &o, &ctx);
+        decode_ahead_wait(&ahead);
+        const double decode_seconds = ahead.seconds;
+        const size_t next = start + n, next_n = total - next < WINDOW_FILES ? total - next : WINDOW_FILES;
+        if (next < total) decode_ahead_start(&ahead, jobs + next, next_n, &o);
+        run_window(jobs + start, n, &o, &ctx, decode_seconds);
         for (size_t i = start; i < start + n; i++) {
             struct job *j = &jobs[i];
             flush_log(j);

@@ -170,3 +170,31 @@ def test_batch_cli_gpu_deflate_same_pixels_same_filters_not_larger(tmp_path):
     p2 = subprocess.run([OUR_CLI, "--gpu-deflate", "-s20", "-b2", "--strip", "-"], input=data, capture_output=True, timeout=300)
     assert p1.returncode == p2.returncode == 0
     assert np.array_equal(np.array(Image.open(io.BytesIO(p1.stdout)).convert("RGBA")), np.array(Image.open(io.BytesIO(p2.stdout)).convert("RGBA")))
+
+
+@needs_our_cli
+def test_batch_cli_windows_are_pipelined_without_changing_the_outputs(tmp_path):
+    """Many files = several GPU batches (windows); the next window is decoded while the current one is on the GPU.
+    A window of 3 files (test hook PNGLOSS_WINDOW_FILES) must write exactly what one big window writes, with the
+    per-file messages still in command line order."""
+    import pngloss_amd as P
+    a_dir, b_dir = tmp_path / "one", tmp_path / "many"
+    a_dir.mkdir(); b_dir.mkdir()
+    names = []
+    for i, (w, h, m) in enumerate([(64, 48, 0), (130, 9, 2), (96, 64, 3), (33, 77, 4), (120, 50, 5), (80, 80, 1), (257, 3, 0), (50, 50, 2)]):
+        arr = P.synth_rgba(w, h, m, i)
+        for d in (a_dir, b_dir):
+            _write_png(str(d / f"f{i}.png"), arr)
+        names.append(f"f{i}")
+    bad = "missing.png"                                   # a failing file in the middle keeps its place and exit code
+    order = names[:4] + [None] + names[4:]
+    runs = {}
+    for d, env in ((a_dir, {}), (b_dir, {"PNGLOSS_WINDOW_FILES": "3"})):
+        args = [str(d / (f"{n}.png" if n else bad)) for n in order]
+        runs[d] = subprocess.run([OUR_CLI, "-v", "--gpu-deflate"] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert runs[d].returncode == 2, runs[d].stderr[-500:]
+    for n in names:
+        assert (a_dir / f"{n}-loss.png").read_bytes() == (b_dir / f"{n}-loss.png").read_bytes(), n
+    for r in runs.values():
+        pos = [r.stderr.index(f"{n}.png:") for n in names[:4]] + [r.stderr.index("missing.png")] + [r.stderr.index(f"{n}.png:") for n in names[4:]]
+        assert pos == sorted(pos)
