@@ -15,6 +15,14 @@ with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, f"f{i:03d}.png")
         Image.fromarray(P.synth_rgba(W, H, 0, i), "RGBA").save(p, compress_level=1)
         files.append(p)
+    if os.environ.get("CLI_BENCH_GPU_ONLY"):
+        # large jobs: only the all-GPU path (several windows of 256 files, decode of the next one overlapped)
+        t = time.perf_counter()
+        r = subprocess.run([OURS, "-f", "--gpu-deflate", "--ext", "-gpu.png"] + files, capture_output=True, text=True, env=dict(os.environ, PNGLOSS_TIMING="1")); print(r.stderr.strip())
+        t_gpu = time.perf_counter() - t
+        assert r.returncode == 0, r.stderr[-500:]
+        print(f"{n} files {W}x{H} with --gpu-deflate: {t_gpu:.2f} s ({n*W*H/t_gpu/1e6:.1f} Mpx/s end to end)")
+        sys.exit(0)
     t = time.perf_counter()
     r = subprocess.run([OURS, "-f", "--ext", "-ours.png"] + files, capture_output=True, text=True, env=dict(os.environ, PNGLOSS_TIMING="1")); print(r.stderr.strip())
     t_ours = time.perf_counter() - t
