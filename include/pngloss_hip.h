@@ -166,7 +166,11 @@ typedef struct {
     size_t size;              /* out */
     int color_type;           /* out: 0, 2, 4 or 6 */
     uint32_t blocks[3];       /* out: deflate blocks written as stored / fixed / dynamic */
+    uint32_t flags;           /* in: PNGLOSS_HIP_Z_* */
 } pngloss_hip_zstream;
+
+/* the caller only wants the stream: the optimised pixels (and row_filters) are not copied back to the host image */
+#define PNGLOSS_HIP_Z_STREAM_ONLY 1u
 
 size_t pngloss_hip_zlib_bound(uint32_t width, uint32_t height);
 

@@ -399,7 +399,8 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
         if (jobs[i].status == SUCCESS) {
             imgs[m] = (pngloss_hip_host_image){ jobs[i].out.rgba_data, jobs[i].filters, jobs[i].out.width, jobs[i].out.height };
             lines[m] = (pngloss_hip_scanlines){ jobs[i].line_types, jobs[i].lines, (size_t)jobs[i].out.width * 4, -1 };
-            zs[m] = (pngloss_hip_zstream){ jobs[i].lines, pngloss_hip_zlib_bound(jobs[i].out.width, jobs[i].out.height), 0, -1, { 0, 0, 0 } };
+            zs[m] = (pngloss_hip_zstream){ jobs[i].lines, pngloss_hip_zlib_bound(jobs[i].out.width, jobs[i].out.height), 0, -1, { 0, 0, 0 },
+                                            PNGLOSS_HIP_Z_STREAM_ONLY };     /* the file is written from the stream alone */
             who[m++] = i;
         }
     if (m && o->gpu_deflate)

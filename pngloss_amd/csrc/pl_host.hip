@@ -383,6 +383,8 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
     for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
         const size_t px = (size_t)images[i].width * images[i].height;
         if (!px) continue;
+        const bool stream_only = zs && zs[i].data && (zs[i].flags & PNGLOSS_HIP_Z_STREAM_ONLY);
+        if (stream_only) continue;
         if (hipMemcpy(images[i].rgba, arena + img_off[i], px * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
         if (images[i].row_filters &&
             hipMemcpy(images[i].row_filters, arena + flt_off[i], images[i].height, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;

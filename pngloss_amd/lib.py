@@ -44,7 +44,7 @@ class Scanlines(C.Structure):
 
 class ZStream(C.Structure):
     _fields_ = [("data", C.c_void_p), ("capacity", C.c_size_t), ("size", C.c_size_t), ("color_type", C.c_int),
-                ("blocks", C.c_uint32 * 3)]
+                ("blocks", C.c_uint32 * 3), ("flags", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -275,8 +275,9 @@ class HipContext:
         emitted = [(lines[i].color_type, ids[i], rows[i][:, : outs[i].shape[1] * chans.get(lines[i].color_type, 4)].copy()) for i in range(n)]
         return outs, filts, emitted
 
-    def run_host_zlib(self, arrays, strength=19, bleed=2, want_filters=True):
-        """pngloss_hip_optimize_batch_host_zlib: like run_host, plus per image (color_type, zlib stream bytes, blocks)."""
+    def run_host_zlib(self, arrays, strength=19, bleed=2, want_filters=True, stream_only=False):
+        """pngloss_hip_optimize_batch_host_zlib: like run_host, plus per image (color_type, zlib stream bytes, blocks).
+        stream_only: PNGLOSS_HIP_Z_STREAM_ONLY -- the returned pixel arrays are then the unmodified inputs."""
         outs = [np.ascontiguousarray(a).copy() for a in arrays]
         filts = [np.zeros(a.shape[0], np.uint8) if want_filters else None for a in outs]
         n = len(outs)
@@ -285,7 +286,7 @@ class HipContext:
         bufs = [np.zeros(self._lib.pngloss_hip_zlib_bound(a.shape[1], a.shape[0]), np.uint8) for a in outs]
         for i, (a, f) in enumerate(zip(outs, filts)):
             imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
-            zs[i] = ZStream(bufs[i].ctypes.data, bufs[i].size, 0, -1, (C.c_uint32 * 3)(0, 0, 0))
+            zs[i] = ZStream(bufs[i].ctypes.data, bufs[i].size, 0, -1, (C.c_uint32 * 3)(0, 0, 0), 1 if stream_only else 0)
         res = (Result * max(n, 1))()
         _check(self._lib.pngloss_hip_optimize_batch_host_zlib(self._ctx, imgs, n, strength, bleed, res, zs), "optimize_batch_host_zlib")
         streams = [(zs[i].color_type, bufs[i][: zs[i].size].tobytes(), tuple(zs[i].blocks)) for i in range(n)]

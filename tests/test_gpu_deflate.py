@@ -120,3 +120,11 @@ def test_batches_split_into_several_groups(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "groups ok" in r.stdout, r.stderr[-800:]
     assert r.stderr.count("pngloss_hip deflate:") >= 4          # the seven images went through several groups
+
+
+def test_stream_only_leaves_the_host_pixels_alone(ctx):
+    a = P.synth_rgba(300, 200, 0, 4)
+    outs, filts, streams = ctx.run_host_zlib([a], stream_only=True)
+    assert np.array_equal(outs[0], a) and not filts[0].any()           # nothing was copied back ...
+    _, _, full = ctx.run_host_zlib([a])
+    assert streams[0] == full[0]                                       # ... and the stream is the same
