@@ -232,7 +232,6 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
         u32x4 r = R[c * RS + half];
         for (int g = 0; g < n; g += GL) {
         const int m = min(GL, n - g);
-        uint32_t cap = 0;
         /* one pixel step; called twice per loop iteration (manual 2x unroll: halves the loop-control and back-edge cost
          * and lets the record registers alternate instead of being copied) */
         auto pixel = [&](const int ii) {
@@ -404,15 +403,16 @@ __device__ __forceinline__ void chain_row(RowCtx &k, const int lane)
             thr_cur = thrv;
             rem = remv;
             left = back;
-            /* output capture: lane jl of the group keeps pixel ii; stored GL pixels at a time */
+            /* output capture: the pixel's record is dead once `r` holds it, so its first word takes the result (one
+             * ds_write, all lanes of the group the same word); lane jl picks up pixel g+jl when the group is done */
             const uint32_t packed = (uint32_t)back | ((uint32_t)diff << 8);
-            cap = (jl == ii) ? packed : cap;
+            *(lds_u32 *)&R[((i & (PL_CHUNK - 1)) * 4 + c) * RS + half] = packed;
             r = rn;
         };
         int ii = 0;
         for (; ii + 1 < m; ii += 2) { pixel(ii); pixel(ii + 1); }
         if (ii < m) pixel(ii);
-        if (active && jl < m) outp[(size_t)(x0 + g + jl) * 4 + c] = cap;
+        if (active && jl < m) outp[(size_t)(x0 + g + jl) * 4 + c] = *(lds_u32 *)&R[(((g + jl) & (PL_CHUNK - 1)) * 4 + c) * RS + half];
         }
         };
         if (TR && __builtin_amdgcn_ballot_w64(chunk_has_transparent) != 0) serial_part(std::true_type{});
