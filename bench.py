@@ -182,11 +182,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "engine_ms_per_launch": round(eng_ms, 3),
                          "chain_bound": {"ns_per_pixel_step": round(eng_ms * 1e6 / px, 1),
-                                         "static_issue_slots_per_pixel_step": 205,
+                                         "static_issue_slots_per_pixel_step": 200,
                                          "note": "secondary, honest bound (SURVEY 8d): W*H pixel steps in series per image; "
-                                                 "~170 instructions + ~45 wait states per step (ISA count), a lone wave issues "
+                                                 "~165 instructions + ~40 wait states per step (ISA count), a lone wave issues "
                                                  "one 4-byte instruction per 4.2 cycles and one 8-byte one per 5.0 (profiles/"
-                                                 "r01_ubench_*), so ~740 cycles = ~350 ns per step at ~2.1 GHz is the floor of "
+                                                 "r01_ubench_*), so ~720 cycles = ~340 ns per step at ~2.1 GHz is the floor of "
                                                  "this formulation"},
                          "note": "dominant kernel is bound by the serial per-pixel dependency chain (DESIGN.md), "
                                  "not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB per launch; traffic = "

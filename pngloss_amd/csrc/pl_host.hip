@@ -474,7 +474,7 @@ int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *his
     return PNGLOSS_SUCCESS;
 }
 
-const char *pngloss_hip_version(void) { return "pngloss_hip 0.1 (gfx950 row engine v4; seam: pngloss_image.h:14-29)"; }
+const char *pngloss_hip_version(void) { return "pngloss_hip 0.1 (gfx950 row engine v5; seam: pngloss_image.h:14-29)"; }
 
 /* ---- the reference's seam ------------------------------------------------------------------------------- */
 
