@@ -146,7 +146,8 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
         first_block[i] = (uint32_t)desc.size();
         for (uint32_t b0 = 0; b0 < len; b0 += prm.block_bytes) {
             const uint32_t bl = std::min(prm.block_bytes, len - b0);
-            desc.push_back(dfl_block_desc{ total + b0, total + b0 + bl, total, total + len, (uint32_t)i, arena_bytes, dfl_block_bound(bl), 0 });
+            desc.push_back(dfl_block_desc{ total + b0, total + b0 + bl, total, total + len, (uint32_t)i, arena_bytes, dfl_block_bound(bl),
+                                           b0 + bl == len ? 1u : 0u });
             arena_bytes += dfl_block_bound(bl);
             max_block = std::max(max_block, bl);
         }
@@ -252,9 +253,8 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
             adler = dfl_adler_fold(adler, result[b].adler_a, result[b].adler_b, desc[b].end - desc[b].begin);
             kinds[result[b].kind < 3 ? result[b].kind : 0]++;
         }
-        unsigned char *t = o + 2 + body;
-        t[0] = 0x03; t[1] = 0x00;                                          /* final block: empty, fixed codes */
-        t[2] = (unsigned char)(adler >> 24); t[3] = (unsigned char)(adler >> 16); t[4] = (unsigned char)(adler >> 8); t[5] = (unsigned char)adler;
+        unsigned char *t = o + 2 + body;                                   /* the last block carried BFINAL */
+        t[0] = (unsigned char)(adler >> 24); t[1] = (unsigned char)(adler >> 16); t[2] = (unsigned char)(adler >> 8); t[3] = (unsigned char)adler;
         imgs[i].out_size = need;
         imgs[i].blocks_stored = kinds[0]; imgs[i].blocks_fixed = kinds[1]; imgs[i].blocks_dynamic = kinds[2];
     }

@@ -345,7 +345,7 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         }
         const uint64_t dyn_bits = header + sh->extra_bits + body;
         const uint32_t chunks = L ? (L + 65534u) / 65535u : 1u;
-        const uint64_t stored_bits = 8ull * ((uint64_t)L + 5ull * chunks), sync_bits = 8ull * 5;
+        const uint64_t stored_bits = 8ull * ((uint64_t)L + 5ull * chunks), sync_bits = d->last ? 0u : 8ull * 5;
         sh->hclen = hclen;
         if (stored_bits <= sh->fixed_bits + sync_bits && stored_bits <= dyn_bits + sync_bits) sh->kind = 0;
         else if (sh->fixed_bits <= dyn_bits) sh->kind = 1;
@@ -366,7 +366,7 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         for (uint32_t c = t->tid; c < chunks; c += t->nthreads) {
             const uint32_t off = c * 65535u, len = L - off > 65535u ? 65535u : L - off;
             uint8_t *h = out + (size_t)c * 65540u;
-            h[0] = 0; h[1] = (uint8_t)len; h[2] = (uint8_t)(len >> 8); h[3] = (uint8_t)~len; h[4] = (uint8_t)(~len >> 8);
+            h[0] = (d->last && c + 1 == chunks) ? 1 : 0; h[1] = (uint8_t)len; h[2] = (uint8_t)(len >> 8); h[3] = (uint8_t)~len; h[4] = (uint8_t)(~len >> 8);
         }
         for (uint32_t i = t->tid; i < L; i += t->nthreads) out[(size_t)(i / 65535u) * 65540u + 5u + i % 65535u] = s[d->begin + i];
         if (t->tid == 0) sh->res.bytes = L + 5u * chunks;
@@ -380,9 +380,9 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         dfl_orbits bw;
         dfl_or_init(&bw, out, 0);
         if (sh->kind == 1) {
-            dfl_or_put(&bw, 0u | (1u << 1), 3);
+            dfl_or_put(&bw, d->last | (1u << 1), 3);
         } else {
-            dfl_or_put(&bw, 0u | (2u << 1), 3);
+            dfl_or_put(&bw, d->last | (2u << 1), 3);
             dfl_or_put(&bw, sh->hlit - 257u, 5);
             dfl_or_put(&bw, sh->hdist - 1u, 5);
             dfl_or_put(&bw, sh->hclen - 4u, 4);
@@ -426,14 +426,20 @@ DFL_HD dfl_block_result dfl_encode_block_coop(const dfl_team *t, const uint8_t *
         uint32_t at = sh->header_bits + sh->part[t->nthreads];
         dfl_or_init(&bw, out, at);
         dfl_or_put(&bw, w->code_ll[256], w->len_ll[256]);
-        dfl_or_put(&bw, 0, 3);                                     /* empty stored block: the sync marker */
-        at += w->len_ll[256] + 3u;
-        const uint32_t pad = (8u - (at & 7u)) & 7u;
-        dfl_or_put(&bw, 0, pad);
-        dfl_or_put(&bw, 0x0000u, 16);
-        dfl_or_put(&bw, 0xffffu, 16);
-        dfl_or_finish(&bw);
-        sh->res.bytes = (at + pad) / 8u + 4u;
+        at += w->len_ll[256];
+        if (d->last) {                                             /* the stream ends here */
+            dfl_or_finish(&bw);
+            sh->res.bytes = (at + 7u) / 8u;
+        } else {
+            dfl_or_put(&bw, 0, 3);                                 /* empty stored block: the sync marker */
+            at += 3u;
+            const uint32_t pad = (8u - (at & 7u)) & 7u;
+            dfl_or_put(&bw, 0, pad);
+            dfl_or_put(&bw, 0x0000u, 16);
+            dfl_or_put(&bw, 0xffffu, 16);
+            dfl_or_finish(&bw);
+            sh->res.bytes = (at + pad) / 8u + 4u;
+        }
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DFL_PHASE_PROF)
         DFL_PROF(7);
         if (d->begin == 0) printf("phases (100 MHz ticks): init+adler %llu parse0 %llu | codes %llu dp %llu parse %llu | - %llu plan %llu emit %llu\n",

@@ -10,8 +10,8 @@
  *   3. blocks       the stream is cut into deflate blocks of DFL_BLOCK input bytes; one wave per block parses
  *                   (lazy matching over the precomputed matches), builds the two length-limited Huffman codes,
  *                   picks stored / fixed / dynamic by exact size, and writes the bits.  Every block ends on a byte
- *                   boundary (empty stored block, the classic sync marker), so blocks are independent and their
- *                   outputs are simply concatenated.
+ *                   boundary (empty stored block, the classic sync marker; the image's last block carries BFINAL
+ *                   instead), so blocks are independent and their outputs are simply concatenated.
  *
  * The functions here are __host__ __device__: pl_deflate.hip runs them on the GPU; tests/c/deflate_host.cpp runs the
  * very same code serially on the CPU and checks it against zlib's inflate, which is how the bitstream logic is
@@ -63,7 +63,7 @@ typedef struct {
     uint32_t image;          /* index of the image in the batch */
     uint32_t out_offset;     /* where this block's bytes go in the block-output arena */
     uint32_t out_capacity;
-    uint32_t pad;
+    uint32_t last;           /* 1: the image's last block -- it carries BFINAL and no sync marker follows it */
 } dfl_block_desc;
 
 typedef struct {
@@ -627,7 +627,7 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
 
     const uint32_t chunks = L ? (L + 65534u) / 65535u : 1u;
     const uint64_t stored_bits = 8ull * ((uint64_t)L + 5ull * chunks);
-    const uint64_t sync_bits = 8ull * 5;                         /* upper bound of the closing sync marker */
+    const uint64_t sync_bits = d->last ? 0u : 8ull * 5;          /* upper bound of the closing sync marker */
 
     dfl_bits bw;
     bw.out = out; bw.pos = 0; bw.acc = 0; bw.nbits = 0;
@@ -636,7 +636,7 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
         uint32_t off = 0;
         for (uint32_t c = 0; c < chunks; c++) {
             const uint32_t len = L - off > 65535u ? 65535u : L - off;
-            out[bw.pos++] = 0;                                   /* BFINAL 0, BTYPE 00, padding */
+            out[bw.pos++] = (d->last && c + 1 == chunks) ? 1 : 0;   /* BFINAL, BTYPE 00, padding */
             out[bw.pos++] = (uint8_t)len; out[bw.pos++] = (uint8_t)(len >> 8);
             out[bw.pos++] = (uint8_t)~len; out[bw.pos++] = (uint8_t)(~len >> 8);
             for (uint32_t i = 0; i < len; i++) out[bw.pos++] = s[d->begin + off + i];
@@ -650,10 +650,10 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
         dfl_fixed_lengths(w->len_ll, w->len_d);
         dfl_canonical(w->len_ll, DFL_NUM_LL, w->code_ll);
         dfl_canonical(w->len_d, DFL_NUM_D, w->code_d);
-        dfl_put(&bw, 0u | (1u << 1), 3);                          /* BFINAL 0, BTYPE 01 */
+        dfl_put(&bw, d->last | (1u << 1), 3);                     /* BFINAL, BTYPE 01 */
     } else {
         res.kind = 2;
-        dfl_put(&bw, 0u | (2u << 1), 3);                          /* BFINAL 0, BTYPE 10 */
+        dfl_put(&bw, d->last | (2u << 1), 3);                     /* BFINAL, BTYPE 10 */
         dfl_put(&bw, hlit - 257u, 5);
         dfl_put(&bw, hdist - 1u, 5);
         dfl_put(&bw, hclen - 4u, 4);
@@ -679,10 +679,14 @@ DFL_HD dfl_block_result dfl_encode_block(const uint8_t *s, const uint32_t *match
         }
     }
     dfl_put(&bw, w->code_ll[256], w->len_ll[256]);
-    /* sync marker: empty stored block, which byte-aligns the stream */
-    dfl_put(&bw, 0, 3);
-    dfl_flush_to_byte(&bw);
-    out[bw.pos++] = 0; out[bw.pos++] = 0; out[bw.pos++] = 0xff; out[bw.pos++] = 0xff;
+    if (d->last) {
+        dfl_flush_to_byte(&bw);                                  /* the stream ends here */
+    } else {
+        /* sync marker: empty stored block, which byte-aligns the stream */
+        dfl_put(&bw, 0, 3);
+        dfl_flush_to_byte(&bw);
+        out[bw.pos++] = 0; out[bw.pos++] = 0; out[bw.pos++] = 0xff; out[bw.pos++] = 0xff;
+    }
     res.bytes = bw.pos;
     return res;
 }
@@ -717,8 +721,8 @@ DFL_HD uint32_t dfl_adler_fold(uint32_t adler, uint32_t a, uint64_t b, uint32_t 
     return (uint32_t)(s2 << 16 | s1);
 }
 
-/* zlib framing around the concatenated blocks: 78 DA | blocks | final empty fixed block (03 00) | Adler-32 (BE) */
+/* zlib framing around the concatenated blocks: 78 DA | blocks (the last one carries BFINAL) | Adler-32 (BE) */
 #define DFL_ZLIB_HEAD_BYTES 2u
-#define DFL_ZLIB_TAIL_BYTES 6u
+#define DFL_ZLIB_TAIL_BYTES 4u
 
 #endif

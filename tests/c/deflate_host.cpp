@@ -88,7 +88,7 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
     std::vector<uint32_t> choice(n + 1);
     if (stats) std::memset(stats, 0, 4 * sizeof(uint32_t));
     for (uint32_t b0 = 0; b0 < n; b0 += block_bytes) {
-        dfl_block_desc d = { b0, std::min(n, b0 + block_bytes), 0, n, 0, 0, (uint32_t)buf.size(), 0 };
+        dfl_block_desc d = { b0, std::min(n, b0 + block_bytes), 0, n, 0, 0, (uint32_t)buf.size(), b0 + block_bytes >= n ? 1u : 0u };
         std::memset(buf.data(), 0, buf.size());
         dfl_block_result r;
         if (g_team > 0) {
@@ -103,7 +103,7 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
         adler = dfl_adler_fold(adler, r.adler_a, r.adler_b, d.end - d.begin);
         if (stats) { stats[r.kind]++; stats[3] += r.tokens; }
     }
-    out[pos++] = 0x03; out[pos++] = 0x00;
+    if (n == 0) { out[pos++] = 0x03; out[pos++] = 0x00; }      /* no block at all: an empty final one (the product never deflates an empty image) */
     out[pos++] = (uint8_t)(adler >> 24); out[pos++] = (uint8_t)(adler >> 16); out[pos++] = (uint8_t)(adler >> 8); out[pos++] = (uint8_t)adler;
     return pos;
 }
