@@ -38,7 +38,7 @@
 #define DFL_KEY_BITS   32
 /* encoder settings of the product (pl_deflate.hip) -- the CPU test driver uses the same ones, so that its output is
  * byte-identical to the GPU's */
-#define DFL_DEFAULT_LEVELS      { 128u, 64u, 32u, 16u, 12u, 8u, 6u }   /* key lengths of the search levels, longest first */
+#define DFL_DEFAULT_LEVELS      { 128u, 64u, 32u, 20u, 12u, 8u, 6u }   /* key lengths of the search levels, longest first */
 #define DFL_DEFAULT_MAX_CHAIN   64u                        /* candidates examined per position and level */
 #define DFL_DEFAULT_BLOCK_BYTES 262144u                    /* input bytes per deflate block */
 #define DFL_NUM_LL     288
