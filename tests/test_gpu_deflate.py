@@ -128,3 +128,19 @@ def test_stream_only_leaves_the_host_pixels_alone(ctx):
     assert np.array_equal(outs[0], a) and not filts[0].any()           # nothing was copied back ...
     _, _, full = ctx.run_host_zlib([a])
     assert streams[0] == full[0]                                       # ... and the stream is the same
+
+
+def test_too_small_a_buffer_is_refused(ctx):
+    """capacity < what the stream needs: PNGLOSS_INVALID_ARGUMENT (4), nothing written past the buffer"""
+    import ctypes as C
+    from pngloss_amd import lib as L
+    a = np.ascontiguousarray(np.random.default_rng(8).integers(0, 256, (64, 64, 4), dtype=np.uint8))
+    filt = np.zeros(64, np.uint8)
+    buf = np.full(512, 0xAB, np.uint8)                      # a 64x64 noise image needs ~16 KB
+    imgs = (L.HostImage * 1)(L.HostImage(a.ctypes.data, filt.ctypes.data, 64, 64))
+    zs = (L.ZStream * 1)(L.ZStream(buf.ctypes.data, 256, 0, -1, (C.c_uint32 * 3)(0, 0, 0), 0))
+    res = (L.Result * 1)()
+    rc = ctx._lib.pngloss_hip_optimize_batch_host_zlib(ctx._ctx, imgs, 1, 0, 2, res, zs)
+    assert rc == 4 and zs[0].size == 0
+    assert (buf[256:] == 0xAB).all()
+    assert ctx._lib.pngloss_hip_zlib_bound(64, 64) >= 64 * (64 * 4 + 1) + 11
