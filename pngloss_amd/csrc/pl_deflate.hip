@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void dfl_flags(const uint32_t *skey, uint
  * exact skip rule exempts from this level (most of them, in compressible data) leave after one load. */
 __global__ __launch_bounds__(kThreads) void dfl_match(const uint32_t *sorted, const uint32_t *group_start, uint32_t n,
                                                       const uint8_t *s, const uint32_t *img_begin, uint32_t nimg,
-                                                      uint32_t max_chain, uint32_t longer_key_bytes, uint32_t *match)
+                                                      uint32_t max_chain, uint32_t key_bytes, uint32_t longer_key_bytes, uint32_t *match)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void dfl_match(const uint32_t *sorted, co
         if (img_begin[mid] <= p) lo = mid; else hi = mid;
     }
     const uint32_t m = dfl_search_level(s, img_begin[lo], img_begin[lo + 1], p, sorted, i, group_start[i], max_chain,
-                                        longer_key_bytes, best);
+                                        key_bytes, longer_key_bytes, best);
     if (m != best || !longer_key_bytes) match[p] = m;
 }
 
@@ -216,7 +216,7 @@ hipError_t deflate_group(pl_deflate_image *imgs, size_t n, const dfl_params &prm
         dfl_flags<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_key[1], total, d_flag);
         DFL_CHECK(hipcub::DeviceScan::InclusiveScan(d_temp, temp_bytes, d_flag, d_gstart, hipcub::Max(), total, stream));
         dfl_match<<<(total + kThreads - 1) / kThreads, kThreads, 0, stream>>>(d_val[1], d_gstart, total, d_s, d_img_begin, (uint32_t)n,
-                                                                                  dfl_level_chain(prm.max_chain, kLevels[lv]), lv ? kLevels[lv - 1] : 0u, d_match);
+                                                                                  dfl_level_chain(prm.max_chain, kLevels[lv]), kLevels[lv], lv ? kLevels[lv - 1] : 0u, d_match);
     }
     DFL_CHECK(hipMemsetAsync(d_arena, 0, arena_bytes, stream));
     dfl_encode<<<nblocks, kThreads, 0, stream>>>(d_desc, d_s, d_match, d_near, prm, d_tok, d_choice, d_arena, d_result);

@@ -146,7 +146,7 @@ DFL_HD uint32_t dfl_sort_key(const uint8_t *s, uint32_t p, uint32_t img_end, uin
  * ------------------------------------------------------------------------------------------------------------- */
 DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t img_end, uint32_t p,
                                  const uint32_t *sorted, uint32_t r, uint32_t group_start, uint32_t max_chain,
-                                 uint32_t longer_key_bytes, uint32_t best)
+                                 uint32_t key_bytes, uint32_t longer_key_bytes, uint32_t best)
 {
     const uint32_t room = img_end - p;
     if (room < DFL_KEY_BYTES) return best;
@@ -163,9 +163,19 @@ DFL_HD uint32_t dfl_search_level(const uint8_t *s, uint32_t img_begin, uint32_t 
         if (q < img_begin || p - q > DFL_WINDOW) break;
         const uint8_t *a = s + q;
         if (a[best_len] != b[best_len]) continue;                                /* cannot beat the best: skip */
-        uint32_t len = 0;
+        /* members of the group share their first key_bytes bytes (up to a hash collision), so the comparison starts
+         * behind them; only a candidate that would win gets its prefix verified, and a collision is then measured
+         * from the start -- the result is the one a comparison from byte 0 gives, with most of the bytes skipped */
+        const uint32_t start = key_bytes < max_len ? key_bytes : 0u;
+        uint32_t len = start;
         while (len + 4 <= max_len && dfl_load32(a + len) == dfl_load32(b + len)) len += 4;
         while (len < max_len && a[len] == b[len]) ++len;
+        if (len > best_len && start) {
+            uint32_t pre = 0;
+            while (pre + 4 <= start && dfl_load32(a + pre) == dfl_load32(b + pre)) pre += 4;
+            while (pre < start && a[pre] == b[pre]) ++pre;
+            if (pre < start) len = pre;
+        }
         if (len > best_len) {
             best_len = len;
             best_dist = p - q;

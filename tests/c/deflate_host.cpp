@@ -73,7 +73,7 @@ extern "C" size_t dfl_host_zlib(const uint8_t *in, uint32_t n, uint8_t *out, siz
             gstart[i] = (i && skey[i] == skey[i - 1]) ? gstart[i - 1] : i;
         }
         for (uint32_t p = 0; p < n; p++)
-            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), rank[p], gstart[rank[p]], dfl_level_chain(max_chain, levels[lv]), lv ? levels[lv - 1] : 0u, match[p]);
+            match[p] = dfl_search_level(in, 0, n, p, sorted.data(), rank[p], gstart[rank[p]], dfl_level_chain(max_chain, levels[lv]), levels[lv], lv ? levels[lv - 1] : 0u, match[p]);
     }
 
     std::vector<uint32_t> near(n);
