@@ -323,6 +323,181 @@ static void run_chain_spec(const engine *e, uint32_t y, int f, unsigned s, long 
     }
 }
 
+/* ------------------------------------------------------------------ "band leader" variant of the chain (variant 2)
+ *
+ * The formulation of the round-2 HIP row engine (pl_engine.hip, chain_lead), proven here on the CPU first.
+ * Observation: without the clamp the candidate set of a channel is one of a FIXED partition of v-space into bands
+ * [tq, tq+s] (filt >= 0) and [-tq-s, -tq] (filt < 0) (optimize_state.c:186-193), and the choice inside a band is the
+ * lexicographic arg-max of (H[v], O_f[v], v==osym, -v) (:212-244).  Keep, per "near" band (one that lies inside
+ * |v| <= 127, so that no histogram bin belongs to two tracked bands except bin 0), its LEADER L = argmax (H, O_f, -v)
+ * and whether that maximum of (H, O_f) is unique.  Then:
+ *   - a pixel channel whose band is near, whose band maximum is unique and whose leader can be reconstructed
+ *     (lo <= L <= hi, the clamp of :195-210) chooses exactly L: the clamped range is a subset of the band that
+ *     contains the band's unique maximum, and "v == osym" only breaks (H, O_f) ties, of which there are none;
+ *   - bumping a unique leader leaves every band's leader and uniqueness unchanged (bin 0 is the one bin that sits
+ *     in two near bands, [0,s] and [-s,0]: a band whose leader is 0 only counts as usable while 0 also leads the
+ *     other one or the other one is unusable), so the four channels of a pixel decouple and NO per-pixel gather,
+ *     reduction or channel repair is needed -- one table lookup per channel;
+ *   - anything else (far band, tie at the top, leader clamped away, a forced transparent-alpha symbol that is not
+ *     its band's leader) takes the exact sequential evaluation and then rebuilds the bands its bumps touched.
+ * port_lead_stats() reports how often each case occurs (the GPU engine's speed is the fast fraction).
+ */
+typedef struct { int L; int usable; int uniq; } band_state;
+static unsigned long long g_lead_stats[8 * 6];   /* [0..7] all chains, [8+8f..] chain f */
+#define LSTAT(i) do { g_lead_stats[i]++; g_lead_stats[8 + 8 * g_lead_f + (i)]++; } while (0)
+static int g_lead_f;
+static unsigned long long g_lead_stats_unused[1];   /* pixels, fast, slow:far, slow:tie/unusable, slow:clamp, slow:forced, rebuilds, rows */
+void port_lead_stats(unsigned long long out[48], int reset)
+{
+    if (out) memcpy(out, g_lead_stats, sizeof g_lead_stats);
+    if (reset) memset(g_lead_stats, 0, sizeof g_lead_stats);
+}
+
+/* band id: 0..NB-1 = positive bands t, NB..2NB-1 = negative bands t */
+static void band_scan(const uint32_t *Hs, const uint32_t *O, int q, int s, int NB, int id, band_state *b)
+{
+    const int neg = id >= NB, t = neg ? id - NB : id;
+    const int v0 = neg ? -t * q - s : t * q;
+    int L = v0; uint32_t bh = Hs[v0 & 255], bo = O[v0 & 255]; int uniq = 1;
+    for (int v = v0 + 1; v <= v0 + s; v++) {
+        const uint32_t h = Hs[v & 255], o = O[v & 255];
+        if (h > bh || (h == bh && o > bo)) { L = v; bh = h; bo = o; uniq = 1; }
+        else if (h == bh && o == bo) uniq = 0;
+    }
+    b->L = L; b->uniq = uniq; b->usable = uniq;
+}
+static void band_pair_fixup(band_state *B, int NB)
+{
+    /* bin 0 sits in positive band 0 and negative band 0 */
+    band_state *p = &B[0], *n = &B[NB];
+    p->usable = p->uniq; n->usable = n->uniq;
+    if (p->L == 0 && n->L != 0) p->usable = p->uniq && !n->usable;
+    else if (n->L == 0 && p->L != 0) n->usable = n->uniq && !p->usable;
+}
+static void band_rebuild_for_bin(const uint32_t *Hs, const uint32_t *O, int q, int s, int NB, band_state *B, int bin)
+{
+    const int lim = NB * q;            /* near v: |v| < lim */
+    if (bin == 0) {
+        if (NB) { band_scan(Hs, O, q, s, NB, 0, &B[0]); band_scan(Hs, O, q, s, NB, NB, &B[NB]); band_pair_fixup(B, NB); LSTAT(6); LSTAT(6); }
+        return;
+    }
+    if (bin < lim) {
+        const int id = bin / q; band_scan(Hs, O, q, s, NB, id, &B[id]); LSTAT(6);
+        if (id == 0) band_pair_fixup(B, NB);
+    }
+    if (256 - bin < lim) {
+        const int id = NB + (256 - bin) / q; band_scan(Hs, O, q, s, NB, id, &B[id]); LSTAT(6);
+        if (id == NB) band_pair_fixup(B, NB);
+    }
+}
+
+static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long bleed, candidate *cd)
+{
+    const uint32_t W = e->W, bpp = e->bpp;
+    const size_t stride = (size_t)W * bpp;
+    const unsigned char *orig = e->pix + (size_t)y * stride;
+    const unsigned char *nabove = y ? orig - stride : NULL;
+    const uint32_t *O = e->orig_hist[f];
+    uint32_t *Hs = cd->hist;
+    const int q = (int)s + 1;
+    const int NB = 128 / q, lim = NB * q;
+    const bool has_alpha = (bpp % 2) == 0;
+    band_state B[2 * 128 + 2];
+    memcpy(Hs, e->hist, sizeof(e->hist));
+    for (int id = 0; id < 2 * NB; id++) band_scan(Hs, O, q, (int)s, NB, id, &B[id]);
+    if (NB) band_pair_fixup(B, NB);
+    g_lead_f = f;
+    LSTAT(7);
+    int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
+
+    for (uint32_t x = 0; x < W; x++) {
+        int d16[4] = { 0, 0, 0, 0 };
+        const bool transparent = has_alpha && orig[(size_t)x * bpp + bpp - 1] == 0;
+        int pred[4], osym[4], filt[4], lo[4], vfast[4], tr[4];
+        int why = 0;
+        /* fast attempt: every channel looks only at the band states as they were before the pixel */
+        for (uint32_t c = 0; c < bpp; c++) {
+            const size_t o = (size_t)x * bpp + c;
+            const int pl = plane_of(bpp, c);
+            const int ov = orig[o];
+            const int above = nabove ? nabove[o] : 0;
+            const int diag = (nabove && x) ? nabove[o - bpp] : 0;
+            const int left = x ? cd->bytes[o - bpp] : 0;
+            pred[c] = predict(f, above, diag, left);
+            tr[c] = transparent && c == bpp - 1;
+            osym[c] = sext8(ov - pred[c]);
+            lo[c] = osym[c] - ov;
+            const int err = sext16(e->E0[(size_t)x * 4 + pl] + rem[pl] + thr_prev[pl]);
+            filt[c] = osym[c] + err;
+            if (tr[c]) {
+                /* forced symbol (0 - pred) mod 256 (optimize_state.c:158-164): harmless iff its bin is in no near band or
+                 * it is the leader of a usable near band */
+                const int bin = (0 - pred[c]) & 255;
+                int v = -1000;
+                if (bin < lim) v = bin; else if (256 - bin < lim) v = bin - 256;
+                if (v != -1000) {
+                    const int id = v >= 0 ? v / q : NB + (-v) / q;
+                    if (!(B[id].usable && B[id].L == v)) why = why ? why : 5;
+                }
+                vfast[c] = -pred[c];
+                lo[c] = -pred[c];
+                continue;
+            }
+            const int fl = filt[c];
+            if (fl >= lim || fl <= -lim) { why = why ? why : 2; continue; }
+            const int id = fl >= 0 ? fl / q : NB + (-fl) / q;
+            if (!B[id].usable) { why = why ? why : 3; continue; }
+            const int L = B[id].L;
+            if (L < lo[c] || L > lo[c] + 255) { why = why ? why : 4; continue; }
+            vfast[c] = L;
+        }
+        LSTAT(0);
+        if (!why) {
+            LSTAT(1);
+            for (uint32_t c = 0; c < bpp; c++) {
+                const int pl = plane_of(bpp, c);
+                cd->bytes[(size_t)x * bpp + c] = (unsigned char)(vfast[c] - lo[c]);
+                d16[pl] = tr[c] ? 0 : sext16(filt[c] - vfast[c]);
+                Hs[vfast[c] & 255]++;
+            }
+        } else {
+            LSTAT(why);
+            /* exact sequential evaluation (the reference's own order), then rebuild what the bumps touched */
+            for (uint32_t c = 0; c < bpp; c++) {
+                const int pl = plane_of(bpp, c);
+                int best;
+                if (tr[c]) { best = -pred[c]; d16[pl] = 0; }
+                else {
+                    const int fl = filt[c];
+                    int vmin, vmax;
+                    if (fl < 0) { vmax = -((-fl) - ((-fl) % q)); vmin = vmax - (int)s; }
+                    else        { vmin = fl - (fl % q);          vmax = vmin + (int)s; }
+                    vmin = med3(vmin, lo[c], lo[c] + 255);
+                    vmax = med3(vmax, lo[c], lo[c] + 255);
+                    best = vmin;
+                    uint32_t bh = Hs[vmin & 255], bo = O[vmin & 255];
+                    int bflag = (vmin == osym[c]);
+                    for (int v = vmin + 1; v <= vmax; v++) {
+                        uint32_t h = Hs[v & 255], oo = O[v & 255];
+                        int fg = (v == osym[c]);
+                        if (better(h, oo, fg, bh, bo, bflag)) { best = v; bh = h; bo = oo; bflag = fg; }
+                    }
+                    d16[pl] = sext16(fl - best);
+                }
+                cd->bytes[(size_t)x * bpp + c] = (unsigned char)(best - lo[c]);
+                Hs[best & 255]++;
+                band_rebuild_for_bin(Hs, O, q, (int)s, NB, B, best & 255);
+            }
+        }
+        for (int pl = 0; pl < 4; pl++) {
+            cd->diff16[(size_t)x * 4 + pl] = (int16_t)d16[pl];
+            int parts[5];
+            port_sierra_split(d16[pl], bleed, parts);
+            thr_prev[pl] = thr_cur[pl]; thr_cur[pl] = parts[1]; rem[pl] = parts[4];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ per-row post pass */
 
 static uint64_t derivative_error(const engine *e, uint32_t y, const candidate *cd)
@@ -415,7 +590,8 @@ int port_optimize_packed(unsigned char *pix, uint32_t width, uint32_t height, ui
             uint64_t costs[F_COUNT];
             for (;;) {
                 for (int f = 0; f < F_COUNT; f++) {
-                    if (g_chain_variant) run_chain_spec(&e, y, f, s, bleed, &cand[f]);
+                    if (g_chain_variant == 2) run_chain_lead(&e, y, f, s, bleed, &cand[f]);
+                    else if (g_chain_variant) run_chain_spec(&e, y, f, s, bleed, &cand[f]);
                     else run_chain(&e, y, f, s, bleed, &cand[f]);
                     if (adaptive && port_adaptive_filter(nabove, cand[f].bytes, width, bpp) != f) {
                         cand[f].cost = UINT64_MAX;

@@ -449,6 +449,483 @@ __device__ __noinline__ void chain_dispatch(RowCtx &k, int lane, bool wrap)
     else chain_dispatch_nc<MODE, false, false>(k, lane);
 }
 
+/* =========================================================================================================
+ * Round 2: the BAND-LEADER chain (chain_lead).  Proven on the CPU first: oracle/pngloss_port.c:run_chain_lead.
+ *
+ * Without the clamp, the candidate set of a channel is one member of a FIXED partition of v-space into bands
+ * [tq, tq+s] (filt >= 0) / [-tq-s, -tq] (filt < 0) (optimize_state.c:186-193) and the choice inside it is the arg-max
+ * of (H[v], O_f[v], v==osym, -v) (:212-244).  Per "near" band (inside |v| <= 127, so that only bin 0 sits in two
+ * tracked bands) the chain keeps the band's LEADER L = argmax (H, O_f, -v) and whether that maximum of (H, O_f) is
+ * unique, folded into a decision table indexed by filt:  T[filt] = { 8*L | 8*rem(filt-L) << 16, 8*thr(filt-L) }.
+ * A channel whose band is usable and whose leader is reconstructable (lo <= L <= hi, the clamp of :195-210) chooses
+ * exactly L, and bumping a unique leader changes no band's leader: the four channels of a pixel decouple, the
+ * histogram is not read at all on this path (its bumps are applied later, 64 pixels per instruction), and one pixel
+ * step is ONE dependent LDS lookup plus a handful of adds -- instead of a gather, two DPP reductions and a coupling
+ * check.  Everything is kept scaled by 8 (the byte size of a table entry) so that filt IS the table address.
+ * A pixel whose table entry is unusable (tie at the top, far band, leader clamped away, forced transparent-alpha
+ * symbol that is not its band's leader) shows up as a reconstructed byte outside [0,255]; it is detected per group of
+ * PL_LGROUP pixels, and the first such pixel is redone by the exact gather/arg-max/repair step of round 1, after
+ * which the bands its bumps touched are rescanned and their table entries rewritten.
+ * Preconditions (else the row runs the round-1 chain): q <= 128 and every incoming Sierra error of the row
+ * |E0| <= 88, which bounds |filt| <= 252 -- so table addresses need no clamp.
+ * ========================================================================================================= */
+#define PL_LT_N 512                 /* decision-table entries per chain: filt in [-256, 255] */
+#define PL_LT_BADV 0x4000           /* 8*v marker of an unusable entry: reconstructs to a byte far outside 0..255 */
+#define PL_LCHUNK 64                /* pixels per vector phase */
+#define PL_LGROUP 16                /* pixels per speculative group */
+#define PL_E0_LEAD_MAX 88           /* rows with larger incoming |error| take the round-1 chain */
+
+struct LeadCtx {
+    const uint32_t *row, *nabove;
+    const uint2 *err0;
+    uint4 *cand;              /* this chain's candidate row cand[f][W] */
+    lds_uint2 *tbl;           /* this chain's {H, rank<<9}[PL_TBL_N] */
+    lds_uint2 *T;             /* this chain's decision table [PL_LT_N] */
+    lds_u32 *bs;              /* this chain's band states [256]: L+256 | uniq<<9 | usable<<10 */
+    lds_uint4 *crec;          /* chain records of the chunk: [PL_LCHUNK][4][RW] */
+    lds_uint2 *out;           /* results of the chunk: [(2 + PL_LCHUNK)][4] {8*byte (checked), 8*diff + TB} */
+    lds_u32 *lut;             /* Sierra split table [diff+256] -> rem | thr<<16 */
+    uint32_t W, bpp;
+    int s;
+    float rq;
+    uint32_t slow;            /* out: pixels redone exactly */
+    uint32_t rebuilds;        /* out: band rescans */
+};
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* first value of band id (0..NB-1 positive bands t, NB..2NB-1 negative bands t) */
+__device__ __forceinline__ int band_v0(int id, int NB, int q, int s)
+{
+    return id >= NB ? -(id - NB) * q - s : id * q;
+}
+
+/* one table entry from a band state */
+__device__ __forceinline__ u32x2 lead_entry(uint32_t st, int filt, lds_u32 *LUT)
+{
+    if (!(st & 1024u)) return (u32x2){ (uint32_t)PL_LT_BADV, 0u };
+    const int L = (int)(st & 511u) - 256;
+    const uint32_t le = LUT[(filt - L + 256) & 511];
+    const int rem = pl_sext16((int)le), thr = (int)le >> 16;
+    return (u32x2){ ((uint32_t)(L * 8) & 0xffffu) | ((uint32_t)(rem * 8) << 16), (uint32_t)(thr * 8) };
+}
+
+/* bin 0 sits in positive band 0 and negative band 0: a band led by 0 is only usable while 0 also leads the other
+ * one, or the other one is unusable (oracle: band_pair_fixup) */
+__device__ __forceinline__ void lead_zero_pair(lds_u32 *bs, int NB)
+{
+    uint32_t p = bs[0], n = bs[NB];
+    const int Lp = (int)(p & 511u) - 256, Ln = (int)(n & 511u) - 256;
+    bool up = (p >> 9) & 1u, un = (n >> 9) & 1u;
+    if (Lp == 0 && Ln != 0) up = up && !un;
+    else if (Ln == 0 && Lp != 0) un = un && !up;
+    bs[0] = (p & 1023u) | (up ? 1024u : 0u);
+    bs[NB] = (n & 1023u) | (un ? 1024u : 0u);
+}
+
+/* whole-table rebuild from the chain's histogram (row start / new strength): lane = band, then lane = entry */
+__device__ __noinline__ void lead_build_table(LeadCtx &k, int lane)
+{
+    const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
+    lds_uint2 *const H = k.tbl;
+    for (int id = lane; id < 2 * NB; id += 64) {
+        const int v0 = band_v0(id, NB, q, s);
+        u32x2 e = H[v0 & 255];
+        int L = v0; uint32_t bh = e.x, br = e.y; bool uniq = true;
+        for (int j = 1; j <= s; j++) {
+            e = H[(v0 + j) & 255];
+            if (e.x > bh || (e.x == bh && e.y > br)) { L = v0 + j; bh = e.x; br = e.y; uniq = true; }
+            else if (e.x == bh && e.y == br) uniq = false;
+        }
+        k.bs[id] = (uint32_t)(L + 256) | (uniq ? 1536u : 0u);
+    }
+    wave_lds_sync();
+    if (lane == 0 && NB) lead_zero_pair(k.bs, NB);
+    wave_lds_sync();
+    for (int idx = lane; idx < PL_LT_N; idx += 64) {
+        const int filt = idx - 256, af = abs(filt);
+        u32x2 ent = (u32x2){ (uint32_t)PL_LT_BADV, 0u };
+        if (af < lim) {
+            const int t = (int)((float)af * k.rq);
+            ent = lead_entry(k.bs[filt >= 0 ? t : NB + t], filt, k.lut);
+        }
+        k.T[idx] = ent;
+    }
+    wave_lds_sync();
+}
+
+/* rescan of the near bands that contain the bins the four channels of a slow pixel just bumped; row c of the wave
+ * (16 lanes) works for channel c's bin.  Rewrites the affected table entries. */
+__device__ __noinline__ void lead_rescan(LeadCtx &k, int lane, int bin, bool rowactive)
+{
+    const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
+    const int jl = lane & 15;
+    lds_uint2 *const H = k.tbl;
+    const int nc = (q + 15) >> 4;
+    bool zero_touched = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        bool has; int id;
+        if (pass == 0) { has = rowactive && bin < lim; id = (int)((float)bin * k.rq); }
+        else { has = rowactive && NB && (bin == 0 || 256 - bin < lim); id = NB + (bin ? (int)((float)(256 - bin) * k.rq) : 0); }
+        if (__builtin_amdgcn_ballot_w64(has) == 0) continue;
+        if (!has) id = 0;
+        const int v0 = band_v0(id, NB, q, s);
+        uint32_t hm = 0;
+        for (int t = 0; t < nc; t++) hm = max(hm, H[(v0 + min(jl + 16 * t, s)) & 255].x);
+        const uint32_t Hmax = rowmax_u32(hm);
+        uint32_t km = 0;
+        for (int t = 0; t < nc; t++) {
+            const int j = min(jl + 16 * t, s);
+            const u32x2 e = H[(v0 + j) & 255];
+            km = max(km, e.x == Hmax ? (e.y >> 1) + (uint32_t)(255 - j) + 1u : 0u);    /* rank<<8 | 255-j, +1 */
+        }
+        const uint32_t K = rowmax_u32(km) - 1u;
+        const int jL = 255 - (int)(K & 255u);
+        const uint32_t rL = K >> 8;
+        uint32_t dup = 0;
+        for (int t = 0; t < nc; t++) {
+            const int j = jl + 16 * t;
+            if (j <= s && j != jL) {
+                const u32x2 e = H[(v0 + j) & 255];
+                dup |= (e.x == Hmax && (e.y >> 9) == rL) ? 1u : 0u;
+            }
+        }
+        dup = rowmax_u32(dup);
+        if (has && jl == 0) k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 1536u);
+        zero_touched |= has && (id == 0 || id == NB);
+        k.rebuilds += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has && jl == 0));
+        wave_lds_sync();
+        if (__builtin_amdgcn_ballot_w64(zero_touched) != 0) {
+            if (lane == 0) lead_zero_pair(k.bs, NB);
+            wave_lds_sync();
+        }
+        /* entries of the rescanned band */
+        if (has) {
+            const uint32_t st = k.bs[id];
+            const bool neg = id >= NB;
+            for (int t = 0; t < nc; t++) {
+                const int j = jl + 16 * t;
+                if (j <= s) {
+                    const int filt = v0 + j;
+                    if (!(neg && filt == 0)) k.T[filt + 256] = lead_entry(st, filt, k.lut);
+                }
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(zero_touched) != 0) {
+        /* the usability of BOTH zero bands may have changed: rewrite their entries (filt -s..s) */
+        for (int f2 = lane - s; f2 <= s; f2 += 64)
+            k.T[f2 + 256] = lead_entry(k.bs[f2 >= 0 ? 0 : NB], f2, k.lut);
+    }
+    wave_lds_sync();
+}
+
+/* per-lane state of the speculative fast path (only lanes 0,16,32,48 -- one per channel -- run it) */
+struct LeadState {
+    uint32_t e0;     /* previous pixel's entry word 0: 8*v (low 16, signed) | 8*rem << 16 */
+    int h1;          /* 8*thr of the previous pixel  (entry word 1) */
+    int h2;          /* 8*thr of the pixel before it               */
+    int lo8;         /* 8*lo of the previous pixel: byte*8 = 8*v - lo8 */
+    int addr;        /* table address the previous pixel looked up (8*filt + TB) */
+    uint32_t mul;    /* 1, or 4096 when the previous pixel's channel was a forced transparent alpha */
+    int bad;         /* OR of the checked 8*byte values of the group */
+};
+
+/* the exact evaluation of ONE pixel, all channels at once in 16-lane rows: gather, two DPP arg-max reductions and
+ * the sequential repair of the histogram coupling between the channels -- the round-1 pixel step (chain_row) with
+ * the generic candidate loop.  Bumps the histogram.  o,a,d,ex,ey: the pixel's raw words (uniform). */
+template <int MODE>
+__device__ __noinline__ void lead_exact_pixel(LeadCtx &k, int lane, uint32_t o, uint32_t a, uint32_t d, uint32_t ex, uint32_t ey,
+                                              int left, int rem, int thr_prev, int &back_out, int &diff_out, int &bin_out)
+{
+    const int c = lane >> 4, jl = lane & 15;
+    const uint32_t bpp = k.bpp;
+    const bool active = (uint32_t)c < bpp;
+    const int s = k.s, q = s + 1, nc = (q + 15) >> 4;
+    lds_uint2 *const T = k.tbl;
+    const int p = pl_plane_of_channel(bpp, c);
+    const int e0 = pl_sext16((int)(p < 2 ? (ex >> (16 * p)) : (ey >> (16 * (p - 2)))));
+    const int orig = (o >> (8 * c)) & 255, above = (a >> (8 * c)) & 255, diag = (d >> (8 * c)) & 255;
+    const bool tr = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u && (uint32_t)c == bpp - 1u;
+    const int predraw = pl_predict<MODE>(above, diag, left);
+    const int osym = pl_sext8(orig - predraw);
+    int lo = osym - orig;
+    const int filt = osym + e0 + rem + thr_prev;
+    const int tq = (int)((float)filt * k.rq);
+    int vmin = tq * q - ((filt >> 31) & s);
+    int vmax = vmin + s;
+    const int hi = lo + 255;
+    vmin = med3_i32(vmin, lo, hi);
+    vmax = med3_i32(vmax, lo, hi);
+    if (tr) { vmin = -predraw; vmax = -predraw; lo = -predraw; }
+    const int span = vmax - vmin, josym = osym - vmin;
+    uint32_t hm = 0;
+    for (int t = 0; t < nc; t++) hm = max(hm, T[(vmin + min(jl + 16 * t, span)) & 255].x);
+    uint32_t Hwin = rowmax_u32(hm);
+    uint32_t km = 0;
+    for (int t = 0; t < nc; t++) {
+        const int j2 = min(jl + 16 * t, span);
+        const u32x2 e = T[(vmin + j2) & 255];
+        km = max(km, e.x == Hwin ? e.y + ((j2 == josym) ? 256u : 0u) + (uint32_t)(256 - j2) : 0u);
+    }
+    uint32_t K = rowmax_u32(km);
+    int jwin = (int)((0u - K) & 255u);
+    int vwin = vmin + jwin;
+    uint32_t Rwin = (K - 1u) >> 9;
+#pragma unroll
+    for (int cp = 0; cp < 3; cp++) {
+        if ((uint32_t)cp + 1u < bpp) {
+            const int sb = __builtin_amdgcn_readlane(vwin, 16 * cp);
+            const uint32_t sH = (uint32_t)__builtin_amdgcn_readlane((int)Hwin, 16 * cp) + 1u;
+            const uint32_t sR = (uint32_t)__builtin_amdgcn_readlane((int)Rwin, 16 * cp);
+            const int jj2 = (sb - vmin) & 255;
+            const uint32_t K2 = (sR << 9) + ((jj2 == josym) ? 256u : 0u) + (uint32_t)(256 - jj2);
+            const bool better = (c > cp) & (jj2 <= span) & ((sH > Hwin) | ((sH == Hwin) & (K2 > K)));
+            Hwin = better ? sH : Hwin;
+            K = better ? K2 : K;
+            jwin = better ? jj2 : jwin;
+            Rwin = better ? sR : Rwin;
+            vwin = vmin + jwin;
+        }
+    }
+    if (active && jl == 0) __hip_atomic_fetch_add((lds_u32 *)&T[vwin & 255], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    back_out = vwin - lo;
+    diff_out = tr ? 0 : filt - vwin;
+    bin_out = vwin & 255;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * One row of one candidate filter, band-leader formulation.  MODE = filter (0 none, 1 sub, 2 up, 3 average, 4 paeth).
+ * Chain records (written by the vector pre-phase, lane = pixel; everything scaled by 8, TB = byte address of T[256]):
+ *   none/up : { 8*osym + 8*e0 + TB, 8*lo, forced address (TB + 8*sext8(-pred)), tr }
+ *   sub     : { 8*orig, 8*e0 + TB, tr, - }
+ *   average : { orig, 8*e0 + TB, 8*above, tr }
+ *   paeth   : { 8*diag, 8*above, 16*diag, 8*|above-diag| } { 8*(orig-above), 8*(orig-diag), 8*orig, 8*e0 + TB | tr in bit 31.. see code }
+ * --------------------------------------------------------------------------------------------------------- */
+template <int MODE, bool TR>
+__device__ __forceinline__ void chain_lead(LeadCtx &k, const int lane)
+{
+    constexpr int RW = MODE == 4 ? 2 : 1;
+    const int c = lane >> 4, jl = lane & 15;
+    const uint32_t bpp = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.bpp);
+    const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.W);
+    glb_cu32 *const row = (glb_cu32 *)k.row, *const nabove = (glb_cu32 *)k.nabove;
+    glb_cu32x2 *const err0 = (glb_cu32x2 *)k.err0;
+    const bool active = (uint32_t)c < bpp;
+    lds_uint2 *const H = k.tbl;
+    lds_uint4 *const R = k.crec;
+    lds_uint2 *const OUT = k.out;
+    lds_u32 *const LUT = k.lut;
+    const int TB = (int)(uint32_t)(uintptr_t)(k.T + 256);
+    const bool chainlane = active && jl == 0;
+    const bool has_alpha = (bpp & 1u) == 0u;
+
+    /* out ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
+    if (lane < 8) OUT[lane] = (u32x2){ 0u, (uint32_t)TB };
+    LeadState st;
+    st.e0 = 0u; st.h1 = 0; st.h2 = 0; st.lo8 = 0; st.addr = TB; st.mul = 1u; st.bad = 0;
+    uint32_t slow = 0;
+
+    /* prefetch of the first chunk's raw words (lane = pixel) */
+    uint32_t no = 0, na = 0, nd = 0; u32x2 ne = (u32x2){ 0u, 0u };
+    {
+        const uint32_t xl = lane;
+        if (xl < W) {
+            no = row[xl];
+            if (nabove) { na = nabove[xl]; nd = xl ? nabove[xl - 1] : 0u; }
+            ne = err0[xl];
+        }
+    }
+    for (uint32_t x0 = 0; x0 < W; x0 += PL_LCHUNK) {
+        const int n = (int)min((uint32_t)PL_LCHUNK, W - x0);
+        const uint32_t o = no, a = na, d = nd; const u32x2 e = ne;
+        {   /* issue the next chunk's loads now; they land while the serial part runs */
+            const uint32_t xl = x0 + PL_LCHUNK + lane;
+            no = 0; na = 0; nd = 0; ne = (u32x2){ 0u, 0u };
+            if (xl < W) {
+                no = row[xl];
+                if (nabove) { na = nabove[xl]; nd = nabove[xl - 1]; }
+                ne = err0[xl];
+            }
+        }
+        /* ---- vector pre-phase: lane = pixel ---- */
+        const bool alpha0 = TR && lane < n && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+        const bool chunk_tr = TR && __builtin_amdgcn_ballot_w64(alpha0) != 0;
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const int p = pl_plane_of_channel(bpp, cc);
+            const int e0 = pl_sext16((int)(p < 2 ? (e.x >> (16 * p)) : (e.y >> (16 * (p - 2)))));
+            const int orig = (o >> (8 * cc)) & 255, above = (a >> (8 * cc)) & 255, diag = (d >> (8 * cc)) & 255;
+            const uint32_t trf = (alpha0 && (uint32_t)cc == bpp - 1u) ? 1u : 0u;
+            const int e0tb = e0 * 8 + TB;
+            if (MODE == 0 || MODE == 2) {
+                const int pred = MODE == 2 ? above : 0;
+                const int osym = pl_sext8(orig - pred);
+                R[lane * 4 + cc] = (u32x4){ (uint32_t)(osym * 8 + e0tb), (uint32_t)((osym - orig) * 8),
+                                            (uint32_t)(pl_sext8(-pred) * 8 + TB), trf };
+            } else if (MODE == 1) {
+                R[lane * 4 + cc] = (u32x4){ (uint32_t)(orig * 8), (uint32_t)e0tb, trf, 0u };
+            } else if (MODE == 3) {
+                R[lane * 4 + cc] = (u32x4){ (uint32_t)orig, (uint32_t)e0tb, (uint32_t)(above * 8), trf };
+            } else {
+                R[(lane * 4 + cc) * 2] = (u32x4){ (uint32_t)(diag * 8), (uint32_t)(above * 8), (uint32_t)(diag * 16), (uint32_t)(abs(above - diag) * 8) };
+                R[(lane * 4 + cc) * 2 + 1] = (u32x4){ (uint32_t)((orig - above) * 8), (uint32_t)((orig - diag) * 8), (uint32_t)(orig * 8) | (trf << 31), (uint32_t)e0tb };
+            }
+        }
+        wave_lds_sync();
+
+        /* ---- serial part: speculative groups ---- */
+        auto serial = [&](auto trx_tag) {
+            constexpr bool TRX = decltype(trx_tag)::value;
+            int pos = 0, flushed = 0;
+            /* histogram bumps of the pixels [from, to) of the chunk, lane = pixel */
+            auto flush = [&](int from, int to) {
+                if (lane >= from && lane < to) {
+                    for (uint32_t cc = 0; cc < bpp; cc++) {
+                        const int back = (int)OUT[(lane + 2) * 4 + cc].x >> 3;
+                        const int left = (int)OUT[(lane + 1) * 4 + cc].x >> 3;
+                        const int sym = (back - pl_predict<MODE>((a >> (8 * cc)) & 255, (d >> (8 * cc)) & 255, left)) & 255;
+                        __hip_atomic_fetch_add((lds_u32 *)&H[sym], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            };
+            while (pos < n) {
+                const int gend = min(n, (pos & ~(PL_LGROUP - 1)) + PL_LGROUP);
+                if (chainlane) {
+                    LeadState t = st;
+                    t.bad = 0;
+#pragma unroll 4
+                    for (int i = pos; i < gend; i++) {
+                        const int v8p = pl_sext16((int)t.e0), rem8p = (int)t.e0 >> 16;
+                        int back8p = v8p - t.lo8;
+                        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);   /* forced symbol: any mismatch -> out of range */
+                        int addr, lo8; uint32_t trf;
+                        if (MODE == 0 || MODE == 2) {
+                            const u32x4 r = R[i * 4 + c];
+                            addr = (int)r.x + t.h2 + rem8p;
+                            lo8 = (int)r.y;
+                            trf = r.w;
+                            if (TRX) { addr = trf ? (int)r.z : addr; lo8 = trf ? (int)r.z - TB : lo8; }
+                        } else if (MODE == 1) {
+                            const u32x4 r = R[i * 4 + c];
+                            const int osym8 = __builtin_amdgcn_sbfe((int)r.x - back8p, 0, 11);
+                            addr = osym8 + (int)r.y + t.h2 + rem8p;
+                            lo8 = osym8 - (int)r.x;
+                            trf = r.z;
+                            if (TRX) { const int f8 = __builtin_amdgcn_sbfe(-back8p, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+                        } else if (MODE == 3) {
+                            const u32x4 r = R[i * 4 + c];
+                            const int pred = (int)__builtin_amdgcn_ubfe((uint32_t)(back8p + (int)r.z), 4, 8);
+                            const int osym = __builtin_amdgcn_sbfe((int)r.x - pred, 0, 8);
+                            addr = (osym << 3) + ((int)r.y + t.h2 + rem8p);
+                            lo8 = (osym - (int)r.x) << 3;
+                            trf = r.w;
+                            if (TRX) { const int f8 = pl_sext8(-pred) << 3; addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+                        } else {
+                            const u32x4 r0 = R[(i * 4 + c) * 2], r1 = R[(i * 4 + c) * 2 + 1];
+                            const uint32_t pa = sad_u32((uint32_t)back8p, r0.x);
+                            const uint32_t pg = sad_u32((uint32_t)back8p + r0.y, r0.z);
+                            const uint32_t m3 = min(min(r0.w, pa), pg);
+                            const int orig8 = TRX ? (int)(r1.z & 0x7fffffffu) : (int)r1.z;
+                            const int inner = (m3 == pa) ? (int)r1.x : (int)r1.y;
+                            const int t1 = (m3 == r0.w) ? orig8 - back8p : inner;
+                            const int osym8 = __builtin_amdgcn_sbfe(t1, 0, 11);
+                            addr = osym8 + (int)r1.w + t.h2 + rem8p;
+                            lo8 = osym8 - orig8;
+                            trf = TRX ? r1.z >> 31 : 0u;
+                            if (TRX) { const int f8 = __builtin_amdgcn_sbfe(t1 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+                        }
+                        const u32x2 en = *(lds_uint2 *)(uintptr_t)(uint32_t)addr;
+                        OUT[(i + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
+                        t.bad |= back8p;
+                        t.h2 = t.h1; t.h1 = (int)en.y; t.e0 = en.x; t.lo8 = lo8; t.addr = addr;
+                        if (TRX) t.mul = trf ? 4096u : 1u;
+                    }
+                    {   /* the group's last pixel: check it too (its record is written again, identically, by the next step) */
+                        const int v8p = pl_sext16((int)t.e0);
+                        int back8p = v8p - t.lo8;
+                        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);
+                        OUT[(gend + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
+                        t.bad |= back8p;
+                    }
+                    st = t;
+                }
+                const bool failed = chainlane && ((uint32_t)st.bad & ~2047u) != 0u;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(failed) == 0, 1)) { pos = gend; continue; }
+                /* ---- first pixel of the group whose reconstruction left 0..255: redo it exactly ---- */
+                wave_lds_sync();
+                const int g0 = pos;
+                const bool flag = active && g0 + jl < gend && (OUT[(g0 + jl + 2) * 4 + c].x & ~2047u) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+                const uint32_t m16 = (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
+                const int ix = g0 + (int)__builtin_ctz(m16);
+                flush(flushed, ix);
+                wave_lds_sync();
+                /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
+                const uint32_t le1 = LUT[((((int)OUT[(ix + 1) * 4 + c].y - TB) >> 3) + 256) & 511];
+                const uint32_t le2 = LUT[((((int)OUT[(ix + 0) * 4 + c].y - TB) >> 3) + 256) & 511];
+                const int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
+                int back, diff, bin;
+                lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin);
+                slow++;
+                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8), (uint32_t)(diff * 8 + TB) };
+                wave_lds_sync();
+                lead_rescan(k, lane, bin, active);
+                /* resume behind it */
+                if (chainlane) {
+                    const uint32_t le0 = LUT[(diff + 256) & 511];
+                    st.e0 = ((uint32_t)(back * 8) & 0xffffu) | ((uint32_t)(pl_sext16((int)le0) * 8) << 16);
+                    st.lo8 = 0;
+                    st.h1 = ((int)le0 >> 16) * 8;
+                    st.h2 = ((int)le1 >> 16) * 8;
+                    st.addr = diff * 8 + TB + back * 8;
+                    st.mul = 1u;
+                    st.bad = 0;
+                }
+                flushed = ix + 1;
+                pos = ix + 1;
+            }
+            /* the last pixel's record is in place (group epilogue).  Bumps of what is left, then the candidate row. */
+            wave_lds_sync();
+            flush(flushed, n);
+        };
+        if (TR && chunk_tr) serial(std::true_type{});
+        else serial(std::false_type{});
+        /* ---- vector post-phase: candidate row (byte | diff16 << 8 per channel), lane = pixel ---- */
+        if (lane < n) {
+            uint32_t w[4] = { 0u, 0u, 0u, 0u };
+            for (uint32_t cc = 0; cc < bpp; cc++) {
+                const u32x2 r = OUT[(lane + 2) * 4 + cc];
+                w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(((int)r.y - TB) >> 3) << 8);
+            }
+            ((__attribute__((address_space(1))) u32x4 *)k.cand)[x0 + lane] = (u32x4){ w[0], w[1], w[2], w[3] };
+        }
+        /* the chunk's last two results become slots 0,1 of the next chunk */
+        u32x2 keep = (u32x2){ 0u, 0u };
+        if (lane < 8) keep = OUT[n * 4 + lane];
+        wave_lds_sync();
+        if (lane < 8) OUT[lane] = keep;
+        if (chainlane) { /* the pending record of the last pixel now lives in slot 1: nothing to fix, addresses are per step */ }
+        wave_lds_sync();
+    }
+    k.slow = slow;
+}
+
+template <int MODE>
+__device__ __noinline__ void chain_lead_dispatch(LeadCtx &k, int lane)
+{
+    if ((k.bpp & 1u) == 0) chain_lead<MODE, true>(k, lane);
+    else chain_lead<MODE, false>(k, lane);
+}
+
 /* ---------------------------------------------------------------------------------------------------------
  * Per-candidate post pass, parallel over x (lane = pixel): derivative error (optimize_state.c:265-287),
  * libpng's heuristic filter (optimize_state.c:492-562) and entropy cost (optimize_state.c:326-342).
@@ -517,14 +994,39 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 
 } // namespace
 
+/* LDS layout of pl_engine (bytes) */
+#define PL_SM_TBL 0
+#define PL_SM_HC (PL_SM_TBL + PL_NFILT * (PL_NSYM + 64) * 8)
+#define PL_SM_LUT (PL_SM_HC + PL_NSYM * 4)
+#define PL_SM_COSTS (PL_SM_LUT + 512 * 4)
+#define PL_SM_FLAGS (PL_SM_COSTS + 64)
+#define PL_SM_UNION (PL_SM_FLAGS + 64)
+#define PL_SM_LEGACY_BYTES (PL_CHUNK * 4 * (2 + 4) * 16)
+#define PL_SM_L_BS (PL_NFILT * PL_LT_N * 8)
+#define PL_SM_L_REC (PL_SM_L_BS + PL_NFILT * 256 * 4)
+#define PL_SM_L_REC_WAVE (PL_LCHUNK * 4 * 16)                 /* per chain; the paeth chain takes two */
+#define PL_SM_L_OUT (PL_SM_L_REC + (PL_NFILT + 1) * PL_SM_L_REC_WAVE)
+#define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2) * 4 * 8)
+#define PL_SM_LEAD_BYTES (PL_SM_L_OUT + PL_NFILT * PL_SM_L_OUT_WAVE)
+#define PL_SM_TOTAL (PL_SM_UNION + (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES))
+
 __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs, PlEngineParams prm)
 {
-    __shared__ uint2 tbl[PL_NFILT][PL_NSYM + 64]; /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
-    __shared__ uint32_t Hc[PL_NSYM];             /* committed symbol_frequency                                        */
-    __shared__ uint4 rec[PL_CHUNK * 4 * (2 + 4)]; /* chunk records: wave 0 gets room for two filters, waves 1..4 for one   */
-    __shared__ uint32_t split_lut[512];          /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255     */
-    __shared__ uint32_t big_err;                 /* some |incoming error| of the coming row exceeds 8000 (see WRAP)    */
-    __shared__ unsigned long long costs[PL_NFILT];
+    /* LDS carve-up (dynamic: the band-leader tables push the total past the 64 KB static limit; gfx950 has 160 KB) */
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2 (*const tbl)[PL_NSYM + 64] = (uint2 (*)[PL_NSYM + 64])(smem + PL_SM_TBL);   /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
+    uint32_t *const Hc = (uint32_t *)(smem + PL_SM_HC);                               /* committed symbol_frequency */
+    uint32_t *const split_lut = (uint32_t *)(smem + PL_SM_LUT);                       /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255 */
+    unsigned long long *const costs = (unsigned long long *)(smem + PL_SM_COSTS);
+    uint32_t &big_err = *(uint32_t *)(smem + PL_SM_FLAGS);                            /* some |incoming error| of the coming row exceeds 8000 (see WRAP) */
+    uint32_t &big_lead = *(uint32_t *)(smem + PL_SM_FLAGS + 4);                       /* ... exceeds PL_E0_LEAD_MAX: the row takes the round-1 chain */
+    uint32_t &uniq = *(uint32_t *)(smem + PL_SM_FLAGS + 8);
+    uint4 *const rec = (uint4 *)(smem + PL_SM_UNION);                                 /* round-1 chain: chunk records (wave 0 two filters, waves 1..4 one) */
+    /* band-leader chain (same region): decision tables, band states, chain records, result rings */
+    uint2 *const ltab = (uint2 *)(smem + PL_SM_UNION);
+    uint32_t *const lbs = (uint32_t *)(smem + PL_SM_UNION + PL_SM_L_BS);
+    unsigned char *const lrec = smem + PL_SM_UNION + PL_SM_L_REC;
+    uint2 *const lout = (uint2 *)(smem + PL_SM_UNION + PL_SM_L_OUT);
 
     const PlJob j = jobs[blockIdx.x];
     const uint32_t W = j.width, H = j.height;
@@ -541,10 +1043,10 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         const PlSplit sp = pl_sierra_split(i - 256, prm.rbleed, r29);
         split_lut[i] = ((uint32_t)(int)sp.rem & 0xffffu) | ((uint32_t)(int)sp.h << 16);
     }
-    if (tid == 0) big_err = 0;
+    if (tid == 0) { big_err = 0; big_lead = 0; }
     __syncthreads();
 
-    uint32_t retried = 0, slow_px = 0;
+    uint32_t retried = 0, slow_px = 0, lead_rows = 0, lead_rebuilds = 0;
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
     int status = 0;
     for (uint32_t y = 0; y < H && !status; y++) {
@@ -556,11 +1058,44 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             /* every candidate starts from the committed histogram (optimize_state_copy, pngloss_image.c:240) */
             for (int b = lane; b < PL_NSYM; b += 64) tbl[wave][b].x = Hc[b];
             __syncthreads();
-            /* chain phase: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
+            /* chain phase.  Band-leader chains (round 2): five waves, one per candidate filter -- their fast path has
+             * no DPP, and plain VALU/LDS waves sharing a SIMD do not slow each other (profiles/r01_ubench_simd_sharing.txt).
+             * Rows that do not meet its preconditions take the round-1 chains below. */
+            const bool lead = prm.engine_mode != 1 && s + 1 <= 128 && !wrap && big_lead == 0;
+            const int lead_f = wave == 0 ? 2 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 0)));   /* up | sub | average | paeth | none */
+            const bool paired = s + 1 <= 48;
+            if (lead) {
+                LeadCtx k;
+                k.row = j.img + (size_t)y * W;
+                k.nabove = y ? k.row - W : nullptr;
+                k.err0 = j.err0;
+                k.cand = j.cand + (size_t)lead_f * W;
+                k.tbl = (lds_uint2 *)&tbl[lead_f][0];
+                k.T = (lds_uint2 *)(ltab + lead_f * PL_LT_N);
+                k.bs = (lds_u32 *)(lbs + lead_f * 256);
+                k.crec = (lds_uint4 *)(lrec + (lead_f == 4 ? PL_NFILT - 1 : (lead_f > 2 ? lead_f - 1 : lead_f)) * PL_SM_L_REC_WAVE);   /* none, sub, up, average, paeth(x2) */
+                k.out = (lds_uint2 *)(lout + lead_f * (PL_SM_L_OUT_WAVE / 8));
+                k.lut = (lds_u32 *)&split_lut[0];
+                k.W = W; k.bpp = bpp; k.s = s; k.rq = recip_up(s + 1);
+                k.slow = 0; k.rebuilds = 0;
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                lead_build_table(k, lane);
+                switch (lead_f) {
+                case 0: chain_lead_dispatch<0>(k, lane); break;
+                case 1: chain_lead_dispatch<1>(k, lane); break;
+                case 2: chain_lead_dispatch<2>(k, lane); break;
+                case 3: chain_lead_dispatch<3>(k, lane); break;
+                default: chain_lead_dispatch<4>(k, lane); break;
+                }
+                chain_cycles += __builtin_readcyclecounter() - t0;
+                slow_px += k.slow;
+                lead_rebuilds += k.rebuilds;
+                lead_rows++;
+            } else
+            /* round-1 chains: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
              * waves 1..3 run sub, average, paeth; wave 4 only takes part in the data-parallel passes */
             /* wide bands (s > 47) would need > 6 candidates per lane in the paired wave: there the five chains run as
              * five waves instead (wave 4 = 'up'), accepting that two of them share a SIMD */
-            const bool paired = s + 1 <= 48;
             if (wave < 4 || !paired) {
                 RowCtx k;
                 k.row = j.img + (size_t)y * W;
@@ -587,7 +1122,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             }
             __syncthreads();   /* candidate rows (global, same CU) and histograms (LDS) complete and visible */
             /* post pass: one wave per candidate */
-            const int pf = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2)));
+            const int pf = lead ? lead_f : (wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2))));
             const uint64_t cst = post_pass(j, y, bpp, pf, tbl[pf], adaptive, lane);
             if (lane == 0) costs[pf] = cst;
             __syncthreads();
@@ -606,9 +1141,9 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         if (status) break;
 
         /* ---- commit (pngloss_image.c:277-308), parallel over x ---- */
-        if (tid == 0) big_err = 0;
+        if (tid == 0) { big_err = 0; big_lead = 0; }
         __syncthreads();
-        bool big = false;
+        bool big = false, bigl = false;
         const uint4 *cd = j.cand + (size_t)winner * W;
         uint32_t *rowp = j.img + (size_t)y * W;
         const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
@@ -635,12 +1170,14 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 }
                 n0[p] = (uint32_t)((int)e1p + (int)c1) & 0xffffu;   /* int16 wrap-on-store */
                 big |= abs(pl_sext16((int)n0[p])) > 8000;
+                bigl |= abs(pl_sext16((int)n0[p])) > PL_E0_LEAD_MAX;
                 n1[p] = (uint32_t)((int)c2) & 0xffffu;
             }
             j.err0[x] = make_uint2(n0[0] | (n0[1] << 16), n0[2] | (n0[3] << 16));
             j.err1[x] = make_uint2(n1[0] | (n1[1] << 16), n1[2] | (n1[3] << 16));
         }
         if (big) big_err = 1;
+        if (bigl) big_lead = 1;
         for (int b = tid; b < PL_NSYM; b += PL_ENGINE_THREADS) Hc[b] = tbl[winner][b].x;
         if (tid == 0 && j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);   /* PNG_FILTER_* flags */
         if (tid == 0) j.row_ids[y] = (uint8_t)winner;
@@ -653,7 +1190,6 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         j.final_hist[b] = Hc[b];
         nz += Hc[b] != 0;
     }
-    __shared__ uint32_t uniq;
     if (tid == 0) uniq = 0;
     __syncthreads();
     if (nz) atomicAdd(&uniq, nz);
@@ -664,25 +1200,39 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         j.result[12 + wave] = (int32_t)slow_px;
         if (PL_SEGPROF) for (int q = 0; q < 4; q++) j.result[16 + wave * 4 + q] = (int32_t)(segs[q] >> 10);
     }
+    if (lane == 0 && wave == 4) {
+        j.result[24] = (int32_t)(chain_cycles >> 10);
+        j.result[25] = (int32_t)slow_px;
+        j.result[26] = (int32_t)lead_rebuilds;
+    }
     if (tid == 0) {
         j.result[0] = status;
         j.result[1] = (int32_t)bpp;
         j.result[2] = (int32_t)uniq;
         j.result[3] = (int32_t)retried;
-        j.result[4] = (int32_t)slow_px;   /* wave 0's (none+up chains) count of pixels that needed the exact channel repair */
+        j.result[4] = (int32_t)slow_px;   /* wave 0's count of pixels that needed the exact channel repair / exact redo */
+        j.result[5] = (int32_t)lead_rows;  /* row attempts that ran the band-leader chains */
+        j.result[6] = (int32_t)lead_rebuilds;
     }
 }
 
 int pl_engine_occupancy(void)
 {
     int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pl_engine, PL_ENGINE_THREADS, 0) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)pl_engine, hipFuncAttributeMaxDynamicSharedMemorySize, PL_SM_TOTAL) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pl_engine, PL_ENGINE_THREADS, PL_SM_TOTAL) != hipSuccess) return -1;
     return n;
 }
 
 hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream)
 {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(pl_engine, dim3((unsigned)n), dim3(PL_ENGINE_THREADS), 0, stream, d_jobs, prm);
+    static bool attr_set = false;   /* per process; the attribute belongs to the function */
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void *)pl_engine, hipFuncAttributeMaxDynamicSharedMemorySize, PL_SM_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pl_engine, dim3((unsigned)n), dim3(PL_ENGINE_THREADS), PL_SM_TOTAL, stream, d_jobs, prm);
     return hipGetLastError();
 }

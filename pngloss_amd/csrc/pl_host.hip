@@ -155,6 +155,10 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     prm.rbleed = recip_up_host(bleed);
     prm.r29 = 2.0f * recip_up_host(9);
     prm.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;   /* test hook, see pl_device.h */
+    {
+        const char *em = std::getenv("PNGLOSS_HIP_ENGINE");                     /* test hook: "legacy" = round-1 chains only */
+        prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : 0;
+    }
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
     PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));
@@ -195,6 +199,9 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
             std::fprintf(stderr, "pngloss_hip: image %zu: chain kcycles per wave %d %d %d %d, repaired pixels %d %d %d %d, engine %.3f ms\n", i,
                          r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15], ctx->engine_ms);
+        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+            std::fprintf(stderr, "pngloss_hip: image %zu: band-leader row attempts %d, wave 4 kcycles %d, exact redos %d, band rescans (wave 0 / 4) %d %d\n", i,
+                         r[5], r[24], r[25], r[6], r[26]);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[16])
             for (int w = 0; w < 4; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,
