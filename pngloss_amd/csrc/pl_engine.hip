@@ -94,7 +94,7 @@ typedef __attribute__((address_space(1))) uint32_t glb_u32;
 typedef __attribute__((address_space(1))) const uint32_t glb_cu32;
 typedef __attribute__((address_space(1))) const u32x2 glb_cu32x2;
 
-#define PL_TBL_N (PL_NSYM + 64)   /* 256 bins + 64 per-lane dummy slots */
+#define PL_TBL_N 512               /* 256 bins + 64 per-lane dummy slots, padded so that every table is 4 KB aligned */
 #define PL_CHUNK 32                /* pixels per vector pre-phase; small so that several workgroups fit one CU's LDS */
 
 struct RowCtx {
@@ -490,6 +490,7 @@ struct LeadCtx {
     float rq;
     uint32_t slow;            /* out: pixels redone exactly */
     uint32_t rebuilds;        /* out: band rescans */
+    unsigned long long cyc[4]; /* out (diagnostics): cycles in vector phases | fast groups | exact redo | rescan */
 };
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -529,7 +530,7 @@ __device__ __forceinline__ void lead_zero_pair(lds_u32 *bs, int NB)
 }
 
 /* whole-table rebuild from the chain's histogram (row start / new strength): lane = band, then lane = entry */
-__device__ __noinline__ void lead_build_table(LeadCtx &k, int lane)
+__device__ __forceinline__ void lead_build_table(const LeadCtx &k, int lane)
 {
     const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
     lds_uint2 *const H = k.tbl;
@@ -561,7 +562,7 @@ __device__ __noinline__ void lead_build_table(LeadCtx &k, int lane)
 
 /* rescan of the near bands that contain the bins the four channels of a slow pixel just bumped; row c of the wave
  * (16 lanes) works for channel c's bin.  Rewrites the affected table entries. */
-__device__ __noinline__ void lead_rescan(LeadCtx &k, int lane, int bin, bool rowactive)
+__device__ __forceinline__ void lead_rescan(LeadCtx &k, int lane, int bin, bool rowactive)
 {
     const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
     const int jl = lane & 15;
@@ -637,12 +638,16 @@ struct LeadState {
     int bad;         /* OR of the checked 8*byte values of the group */
 };
 
+#include "pl_lead_asm.h"
+
 /* the exact evaluation of ONE pixel, all channels at once in 16-lane rows: gather, two DPP arg-max reductions and
  * the sequential repair of the histogram coupling between the channels -- the round-1 pixel step (chain_row) with
- * the generic candidate loop.  Bumps the histogram.  o,a,d,ex,ey: the pixel's raw words (uniform). */
+ * the generic candidate loop.  Bumps the histogram.  o,a,d,ex,ey: the pixel's raw words (uniform).
+ * Hout/Rout: the winner's frequency BEFORE its bump and its rank (for the rescan test). */
 template <int MODE>
-__device__ __noinline__ void lead_exact_pixel(LeadCtx &k, int lane, uint32_t o, uint32_t a, uint32_t d, uint32_t ex, uint32_t ey,
-                                              int left, int rem, int thr_prev, int &back_out, int &diff_out, int &bin_out)
+__device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uint32_t o, uint32_t a, uint32_t d, uint32_t ex, uint32_t ey,
+                                                 int left, int rem, int thr_prev, int &back_out, int &diff_out, int &bin_out,
+                                                 uint32_t &Hout, uint32_t &Rout)
 {
     const int c = lane >> 4, jl = lane & 15;
     const uint32_t bpp = k.bpp;
@@ -698,6 +703,130 @@ __device__ __noinline__ void lead_exact_pixel(LeadCtx &k, int lane, uint32_t o, 
     back_out = vwin - lo;
     diff_out = tr ? 0 : filt - vwin;
     bin_out = vwin & 255;
+    Hout = Hwin;
+    Rout = Rwin;
+}
+
+/* After the exact pixel bumped `bin` (new frequency Hnew, rank R), does any near band that contains the bin have to
+ * be rescanned?  Not if the bin still is strictly below the band's leader in (H, rank), or is the leader of a band
+ * whose maximum was unique already: then neither the leader nor the uniqueness changed.  Lane 0 of the row looks at
+ * the positive-v band, lane 1 at the negative-v band. */
+__device__ __forceinline__ bool lead_needs_rescan(const LeadCtx &k, int lane, int bin, bool rowactive, uint32_t Hnew, uint32_t R)
+{
+    const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
+    const int jl = lane & 15;
+    bool has = false; int id = 0, v = 0;
+    if (jl == 0) { has = rowactive && bin < lim; id = (int)((float)bin * k.rq); v = bin; }
+    else if (jl == 1) { has = rowactive && NB && (bin == 0 || 256 - bin < lim); id = NB + (bin ? (int)((float)(256 - bin) * k.rq) : 0); v = bin ? bin - 256 : 0; }
+    bool need = false;
+    if (has) {
+        const uint32_t st = k.bs[id];
+        const int L = (int)(st & 511u) - 256;
+        const u32x2 e = k.tbl[L & 255];
+        need = L == v ? !(st & 512u) : (Hnew > e.x || (Hnew == e.x && (R << 9) >= e.y));
+    }
+    return __builtin_amdgcn_ballot_w64(need) != 0;
+}
+
+/* The speculative run of one channel lane over the pixels [pos, end) of the chunk.  On entry st describes pixel pos-1,
+ * whose result record is in place.  Writes the result record {8*byte, 8*diff + TB} of every pixel it passes and returns
+ * how many pixels of the chunk now have one; `bad` tells that some byte it produced lies outside 0..255 (= a table
+ * entry was unusable or a leader clamped away; everything behind the first such pixel is garbage, and memory-safe).
+ * The hand-scheduled loop notices that with a lag of up to two iterations; the first bad pixel is then among the
+ * last nine records.  The histogram is NOT touched here: bumps are applied 64 pixels at a time by the caller. */
+template <int MODE, bool TRX>
+__device__ __forceinline__ int lead_fast_run(LeadState &st, lds_uint4 *R, lds_uint2 *OUT, const int c, const int TB,
+                                             const int pos, const int end, bool &bad)
+{
+    constexpr int RW = MODE == 4 ? 2 : 1;
+    LeadState t = st;
+    int ret = end;
+    bad = false;
+    u32x4 ra0 = R[(pos * 4 + c) * RW], ra1 = RW == 2 ? R[(pos * 4 + c) * RW + 1] : ra0;
+    u32x4 rb0 = R[((pos + 1) * 4 + c) * RW], rb1 = RW == 2 ? R[((pos + 1) * 4 + c) * RW + 1] : rb0;
+    u32x4 rc0 = rb0, rc1 = rb1;
+    /* one pixel in C++ (run head and tail, chunks with transparent pixels): look up pixel i (record r0/r1), write the
+     * record of pixel i-1, fetch record i+2 into rn0/rn1; true = pixel i-1 is bad */
+    auto step = [&](const int i, const u32x4 r0, const u32x4 r1, u32x4 &rn0, u32x4 &rn1) -> bool {
+        const int v8p = pl_sext16((int)t.e0), rem8p = (int)t.e0 >> 16;
+        int back8p = v8p - t.lo8;
+        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);   /* forced symbol: any mismatch -> out of range */
+        int addr, lo8; uint32_t trf = 0;
+        if (MODE == 0 || MODE == 2) {
+            addr = (int)r0.x + t.h2 + rem8p;
+            lo8 = (int)r0.y;
+            if (TRX) { trf = r0.w; addr = trf ? (int)r0.z : addr; lo8 = trf ? (int)r0.z - TB : lo8; }
+        } else if (MODE == 1) {
+            const int osym8 = __builtin_amdgcn_sbfe((int)r0.x - back8p, 0, 11);
+            addr = osym8 + ((int)r0.y + t.h2 + rem8p);
+            lo8 = osym8 - (int)r0.x;
+            if (TRX) { trf = r0.z; const int f8 = __builtin_amdgcn_sbfe(-back8p, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+        } else if (MODE == 3) {
+            const int pred = (int)__builtin_amdgcn_ubfe((uint32_t)(back8p + (int)r0.z), 4, 8);
+            const int osym = __builtin_amdgcn_sbfe((int)r0.x - pred, 0, 8);
+            addr = (osym << 3) + ((int)r0.y + t.h2 + rem8p);
+            lo8 = (osym - (int)r0.x) << 3;
+            if (TRX) { trf = r0.w; const int f8 = pl_sext8(-pred) << 3; addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+        } else {
+            /* Paeth without compares: key = distance << 14 | priority << 12 | (8*(orig - candidate) + 2048); the minimum
+             * key is the predictor the reference picks (left, then above, then upper-left on ties, optimize_state.c:600-613)
+             * and its low 11 bits are 8*osym already */
+            const uint32_t pa = sad_u32((uint32_t)back8p, r0.x);
+            const uint32_t pg = sad_u32((uint32_t)back8p + r0.y, r0.z);
+            const uint32_t kA = (pa << 14) | r1.x, kD = (pg << 14) | r1.y, kL = r0.w - (uint32_t)back8p;
+            const uint32_t m3 = min(min(kL, kA), kD);
+            const int orig8 = TRX ? (int)(r1.z & 0x7fffffffu) : (int)r1.z;
+            const int osym8 = __builtin_amdgcn_sbfe((int)m3, 0, 11);
+            addr = osym8 + ((int)r1.w + t.h2 + rem8p);
+            lo8 = osym8 - orig8;
+            if (TRX) { trf = r1.z >> 31; const int f8 = __builtin_amdgcn_sbfe(osym8 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+        }
+        const u32x2 en = *(lds_uint2 *)(uintptr_t)(uint32_t)addr;
+        OUT[(i + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
+        rn0 = R[((i + 2) * 4 + c) * RW];
+        if (RW == 2) rn1 = R[((i + 2) * 4 + c) * RW + 1];
+        const bool b = __builtin_amdgcn_ballot_w64((uint32_t)back8p > 2047u) != 0;
+        t.h2 = t.h1; t.lo8 = lo8; t.addr = addr;
+        if (TRX) t.mul = trf ? 4096u : 1u;
+        t.h1 = (int)en.y; t.e0 = en.x;
+        return b;
+    };
+    int i = pos;
+    (void)step(i, ra0, ra1, rc0, rc1);                       /* rewrites the (good) record of pixel pos-1 */
+    i++;
+    ra0 = rb0; ra1 = rb1; rb0 = rc0; rb1 = rc1;              /* a = record of pixel i, b = i+1 */
+    if (!TRX && i + 4 <= end) {
+        /* the hand-scheduled loop (pl_lead_asm.h): whole groups of four pixels */
+        const int iters0 = (end - i) >> 2;
+        int iters = iters0;
+        const uint32_t rptr = (uint32_t)(uintptr_t)&R[(i * 4 + c) * RW], optr = (uint32_t)(uintptr_t)&OUT[(i + 1) * 4 + c];
+        uint32_t acc;
+        if (MODE == 0 || MODE == 2) acc = lead_asm_noneup(t, rptr, optr, iters, ra0, rb0);
+        else if (MODE == 1) acc = lead_asm_sub(t, rptr, optr, iters, ra0, rb0);
+        else if (MODE == 3) acc = lead_asm_avg(t, rptr, optr, iters, ra0, rb0);
+        else acc = lead_asm_paeth(t, rptr, optr, iters, ra0, rb0, ra1, rb1);
+        i += 4 * (iters0 - iters);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(acc > 2047u) != 0, 0)) { bad = true; ret = i; goto lead_run_done; }
+    }
+    for (; i < end; i++) {
+        if (__builtin_expect(step(i, ra0, ra1, rc0, rc1), 0)) { bad = true; ret = i; goto lead_run_done; }
+        ra0 = rb0; ra1 = rb1; rb0 = rc0; rb1 = rc1;
+    }
+    {
+        /* the last pixel of the run: its record, and the state as if it had come from a committed pixel */
+        const int v8p = pl_sext16((int)t.e0);
+        int back8p = v8p - t.lo8;
+        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);
+        OUT[(end + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
+        if (__builtin_amdgcn_ballot_w64((uint32_t)back8p > 2047u) != 0) bad = true;
+        t.e0 = ((uint32_t)back8p & 0xffffu) | (t.e0 & 0xffff0000u);
+        t.addr = t.addr - v8p + back8p;
+        t.lo8 = 0;
+        t.mul = 1u;
+    }
+lead_run_done:
+    st = t;
+    return ret;
 }
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -705,32 +834,32 @@ __device__ __noinline__ void lead_exact_pixel(LeadCtx &k, int lane, uint32_t o, 
  * Chain records (written by the vector pre-phase, lane = pixel; everything scaled by 8, TB = byte address of T[256]):
  *   none/up : { 8*osym + 8*e0 + TB, 8*lo, forced address (TB + 8*sext8(-pred)), tr }
  *   sub     : { 8*orig, 8*e0 + TB, tr, - }
- *   average : { orig, 8*e0 + TB, 8*above, tr }
- *   paeth   : { 8*diag, 8*above, 16*diag, 8*|above-diag| } { 8*(orig-above), 8*(orig-diag), 8*orig, 8*e0 + TB | tr in bit 31.. see code }
+ *   average : { orig, 8*e0 + TB, 8*above, -8*orig (tr in chunks that hold a transparent pixel) }
+ *   paeth   : { 8*diag, 8*above, 16*diag, (8*|above-diag| << 14) + 8*orig + 2048 }
+ *             { (1<<12) + 8*(orig-above) + 2048, (2<<12) + 8*(orig-diag) + 2048, 8*orig | tr<<31, 8*e0 + TB }
  * --------------------------------------------------------------------------------------------------------- */
 template <int MODE, bool TR>
-__device__ __forceinline__ void chain_lead(LeadCtx &k, const int lane)
+__device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 {
-    constexpr int RW = MODE == 4 ? 2 : 1;
+    LeadCtx k = kref;     /* a register copy: kref lives in the caller's frame, and every field is read many times */
     const int c = lane >> 4, jl = lane & 15;
     const uint32_t bpp = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.bpp);
     const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.W);
     glb_cu32 *const row = (glb_cu32 *)k.row, *const nabove = (glb_cu32 *)k.nabove;
     glb_cu32x2 *const err0 = (glb_cu32x2 *)k.err0;
     const bool active = (uint32_t)c < bpp;
-    lds_uint2 *const H = k.tbl;
     lds_uint4 *const R = k.crec;
     lds_uint2 *const OUT = k.out;
     lds_u32 *const LUT = k.lut;
     const int TB = (int)(uint32_t)(uintptr_t)(k.T + 256);
     const bool chainlane = active && jl == 0;
-    const bool has_alpha = (bpp & 1u) == 0u;
 
-    /* out ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
+    /* result ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
     if (lane < 8) OUT[lane] = (u32x2){ 0u, (uint32_t)TB };
     LeadState st;
     st.e0 = 0u; st.h1 = 0; st.h2 = 0; st.lo8 = 0; st.addr = TB; st.mul = 1u; st.bad = 0;
     uint32_t slow = 0;
+    unsigned long long cyc_vec = 0, cyc_fast = 0, cyc_exact = 0, cyc_rescan = 0;
 
     /* prefetch of the first chunk's raw words (lane = pixel) */
     uint32_t no = 0, na = 0, nd = 0; u32x2 ne = (u32x2){ 0u, 0u };
@@ -754,6 +883,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &k, const int lane)
                 ne = err0[xl];
             }
         }
+        const unsigned long long tv0 = __builtin_readcyclecounter();
         /* ---- vector pre-phase: lane = pixel ---- */
         const bool alpha0 = TR && lane < n && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
         const bool chunk_tr = TR && __builtin_amdgcn_ballot_w64(alpha0) != 0;
@@ -772,139 +902,95 @@ __device__ __forceinline__ void chain_lead(LeadCtx &k, const int lane)
             } else if (MODE == 1) {
                 R[lane * 4 + cc] = (u32x4){ (uint32_t)(orig * 8), (uint32_t)e0tb, trf, 0u };
             } else if (MODE == 3) {
-                R[lane * 4 + cc] = (u32x4){ (uint32_t)orig, (uint32_t)e0tb, (uint32_t)(above * 8), trf };
+                R[lane * 4 + cc] = (u32x4){ (uint32_t)orig, (uint32_t)e0tb, (uint32_t)(above * 8), chunk_tr ? trf : (uint32_t)(-8 * orig) };
             } else {
-                R[(lane * 4 + cc) * 2] = (u32x4){ (uint32_t)(diag * 8), (uint32_t)(above * 8), (uint32_t)(diag * 16), (uint32_t)(abs(above - diag) * 8) };
-                R[(lane * 4 + cc) * 2 + 1] = (u32x4){ (uint32_t)((orig - above) * 8), (uint32_t)((orig - diag) * 8), (uint32_t)(orig * 8) | (trf << 31), (uint32_t)e0tb };
+                R[(lane * 4 + cc) * 2] = (u32x4){ (uint32_t)(diag * 8), (uint32_t)(above * 8), (uint32_t)(diag * 16),
+                                                  ((uint32_t)(abs(above - diag) * 8) << 14) + (uint32_t)(orig * 8 + 2048) };
+                R[(lane * 4 + cc) * 2 + 1] = (u32x4){ (1u << 12) + (uint32_t)((orig - above) * 8 + 2048), (2u << 12) + (uint32_t)((orig - diag) * 8 + 2048),
+                                                      (uint32_t)(orig * 8) | (trf << 31), (uint32_t)e0tb };
             }
         }
         wave_lds_sync();
+        cyc_vec += __builtin_readcyclecounter() - tv0;
 
-        /* ---- serial part: speculative groups ---- */
-        auto serial = [&](auto trx_tag) {
-            constexpr bool TRX = decltype(trx_tag)::value;
-            int pos = 0, flushed = 0;
-            /* histogram bumps of the pixels [from, to) of the chunk, lane = pixel */
-            auto flush = [&](int from, int to) {
-                if (lane >= from && lane < to) {
-                    for (uint32_t cc = 0; cc < bpp; cc++) {
-                        const int back = (int)OUT[(lane + 2) * 4 + cc].x >> 3;
-                        const int left = (int)OUT[(lane + 1) * 4 + cc].x >> 3;
+        /* ---- serial part ---- */
+        int pos = 0, flushed = 0;
+        /* histogram bumps of the pixels [from, to) of the chunk, lane = pixel */
+        auto flush = [&](int from, int to) {
+            if (lane >= from && lane < to) {
+                u32x2 rr[4], rl[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) { rr[cc] = OUT[(lane + 2) * 4 + cc]; rl[cc] = OUT[(lane + 1) * 4 + cc]; }
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    if ((uint32_t)cc < bpp) {
+                        const int back = (int)rr[cc].x >> 3, left = (int)rl[cc].x >> 3;
                         const int sym = (back - pl_predict<MODE>((a >> (8 * cc)) & 255, (d >> (8 * cc)) & 255, left)) & 255;
-                        __hip_atomic_fetch_add((lds_u32 *)&H[sym], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add((lds_u32 *)&k.tbl[sym], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-            };
-            while (pos < n) {
-                const int gend = min(n, (pos & ~(PL_LGROUP - 1)) + PL_LGROUP);
-                if (chainlane) {
-                    LeadState t = st;
-                    t.bad = 0;
-#pragma unroll 4
-                    for (int i = pos; i < gend; i++) {
-                        const int v8p = pl_sext16((int)t.e0), rem8p = (int)t.e0 >> 16;
-                        int back8p = v8p - t.lo8;
-                        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);   /* forced symbol: any mismatch -> out of range */
-                        int addr, lo8; uint32_t trf;
-                        if (MODE == 0 || MODE == 2) {
-                            const u32x4 r = R[i * 4 + c];
-                            addr = (int)r.x + t.h2 + rem8p;
-                            lo8 = (int)r.y;
-                            trf = r.w;
-                            if (TRX) { addr = trf ? (int)r.z : addr; lo8 = trf ? (int)r.z - TB : lo8; }
-                        } else if (MODE == 1) {
-                            const u32x4 r = R[i * 4 + c];
-                            const int osym8 = __builtin_amdgcn_sbfe((int)r.x - back8p, 0, 11);
-                            addr = osym8 + (int)r.y + t.h2 + rem8p;
-                            lo8 = osym8 - (int)r.x;
-                            trf = r.z;
-                            if (TRX) { const int f8 = __builtin_amdgcn_sbfe(-back8p, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
-                        } else if (MODE == 3) {
-                            const u32x4 r = R[i * 4 + c];
-                            const int pred = (int)__builtin_amdgcn_ubfe((uint32_t)(back8p + (int)r.z), 4, 8);
-                            const int osym = __builtin_amdgcn_sbfe((int)r.x - pred, 0, 8);
-                            addr = (osym << 3) + ((int)r.y + t.h2 + rem8p);
-                            lo8 = (osym - (int)r.x) << 3;
-                            trf = r.w;
-                            if (TRX) { const int f8 = pl_sext8(-pred) << 3; addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
-                        } else {
-                            const u32x4 r0 = R[(i * 4 + c) * 2], r1 = R[(i * 4 + c) * 2 + 1];
-                            const uint32_t pa = sad_u32((uint32_t)back8p, r0.x);
-                            const uint32_t pg = sad_u32((uint32_t)back8p + r0.y, r0.z);
-                            const uint32_t m3 = min(min(r0.w, pa), pg);
-                            const int orig8 = TRX ? (int)(r1.z & 0x7fffffffu) : (int)r1.z;
-                            const int inner = (m3 == pa) ? (int)r1.x : (int)r1.y;
-                            const int t1 = (m3 == r0.w) ? orig8 - back8p : inner;
-                            const int osym8 = __builtin_amdgcn_sbfe(t1, 0, 11);
-                            addr = osym8 + (int)r1.w + t.h2 + rem8p;
-                            lo8 = osym8 - orig8;
-                            trf = TRX ? r1.z >> 31 : 0u;
-                            if (TRX) { const int f8 = __builtin_amdgcn_sbfe(t1 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
-                        }
-                        const u32x2 en = *(lds_uint2 *)(uintptr_t)(uint32_t)addr;
-                        OUT[(i + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
-                        t.bad |= back8p;
-                        t.h2 = t.h1; t.h1 = (int)en.y; t.e0 = en.x; t.lo8 = lo8; t.addr = addr;
-                        if (TRX) t.mul = trf ? 4096u : 1u;
-                    }
-                    {   /* the group's last pixel: check it too (its record is written again, identically, by the next step) */
-                        const int v8p = pl_sext16((int)t.e0);
-                        int back8p = v8p - t.lo8;
-                        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);
-                        OUT[(gend + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
-                        t.bad |= back8p;
-                    }
-                    st = t;
-                }
-                const bool failed = chainlane && ((uint32_t)st.bad & ~2047u) != 0u;
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(failed) == 0, 1)) { pos = gend; continue; }
-                /* ---- first pixel of the group whose reconstruction left 0..255: redo it exactly ---- */
-                wave_lds_sync();
-                const int g0 = pos;
-                const bool flag = active && g0 + jl < gend && (OUT[(g0 + jl + 2) * 4 + c].x & ~2047u) != 0u;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
-                const uint32_t m16 = (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
-                const int ix = g0 + (int)__builtin_ctz(m16);
-                flush(flushed, ix);
-                wave_lds_sync();
-                /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
-                const uint32_t le1 = LUT[((((int)OUT[(ix + 1) * 4 + c].y - TB) >> 3) + 256) & 511];
-                const uint32_t le2 = LUT[((((int)OUT[(ix + 0) * 4 + c].y - TB) >> 3) + 256) & 511];
-                const int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
-                int back, diff, bin;
-                lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
-                                       (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
-                                       (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin);
-                slow++;
-                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8), (uint32_t)(diff * 8 + TB) };
-                wave_lds_sync();
-                lead_rescan(k, lane, bin, active);
-                /* resume behind it */
-                if (chainlane) {
-                    const uint32_t le0 = LUT[(diff + 256) & 511];
-                    st.e0 = ((uint32_t)(back * 8) & 0xffffu) | ((uint32_t)(pl_sext16((int)le0) * 8) << 16);
-                    st.lo8 = 0;
-                    st.h1 = ((int)le0 >> 16) * 8;
-                    st.h2 = ((int)le1 >> 16) * 8;
-                    st.addr = diff * 8 + TB + back * 8;
-                    st.mul = 1u;
-                    st.bad = 0;
-                }
-                flushed = ix + 1;
-                pos = ix + 1;
             }
-            /* the last pixel's record is in place (group epilogue).  Bumps of what is left, then the candidate row. */
-            wave_lds_sync();
-            flush(flushed, n);
         };
-        if (TR && chunk_tr) serial(std::true_type{});
-        else serial(std::false_type{});
+        while (pos < n) {
+            const unsigned long long tf0 = __builtin_readcyclecounter();
+            int cur = n; bool bad = false;
+            if (chainlane) {
+                if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(st, R, OUT, c, TB, pos, n, bad);
+                else cur = lead_fast_run<MODE, false>(st, R, OUT, c, TB, pos, n, bad);
+            }
+            cur = __builtin_amdgcn_readfirstlane(cur);    /* lane 0 is channel 0's chain lane: always active */
+            const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
+            const unsigned long long tf1 = __builtin_readcyclecounter();
+            cyc_fast += tf1 - tf0;
+            if (__builtin_expect(!anybad, 1)) break;
+            /* ---- the first pixel whose reconstruction left 0..255 is among the last 16 records: redo it exactly ---- */
+            wave_lds_sync();
+            const int w0 = cur - 16 + jl;
+            const bool flag = active && w0 >= pos && (OUT[(max(w0, 0) + 2) * 4 + c].x > 2047u);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+            const uint32_t m16 = (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
+            const int ix = cur - 16 + (int)__builtin_ctz(m16);
+            flush(flushed, ix);
+            wave_lds_sync();
+            /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
+            const uint32_t le1 = LUT[((((int)OUT[(ix + 1) * 4 + c].y - TB) >> 3) + 256) & 511];
+            const uint32_t le2 = LUT[((((int)OUT[(ix + 0) * 4 + c].y - TB) >> 3) + 256) & 511];
+            const int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
+            int back, diff, bin; uint32_t Hw, Rw;
+            lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
+                                   (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
+                                   (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
+            slow++;
+            if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8), (uint32_t)(diff * 8 + TB) };
+            wave_lds_sync();
+            const unsigned long long tf2 = __builtin_readcyclecounter();
+            cyc_exact += tf2 - tf1;
+            if (lead_needs_rescan(k, lane, bin, active, Hw + 1u, Rw)) lead_rescan(k, lane, bin, active);
+            /* resume behind it */
+            if (chainlane) {
+                const uint32_t le0 = LUT[(diff + 256) & 511];
+                st.e0 = ((uint32_t)(back * 8) & 0xffffu) | ((uint32_t)(pl_sext16((int)le0) * 8) << 16);
+                st.lo8 = 0;
+                st.h1 = ((int)le0 >> 16) * 8;
+                st.h2 = ((int)le1 >> 16) * 8;
+                st.addr = diff * 8 + TB + back * 8;
+                st.mul = 1u;
+            }
+            flushed = ix + 1;
+            pos = ix + 1;
+            cyc_rescan += __builtin_readcyclecounter() - tf2;
+        }
+        wave_lds_sync();
+        flush(flushed, n);
+        wave_lds_sync();
+        const unsigned long long tv1 = __builtin_readcyclecounter();
         /* ---- vector post-phase: candidate row (byte | diff16 << 8 per channel), lane = pixel ---- */
         if (lane < n) {
             uint32_t w[4] = { 0u, 0u, 0u, 0u };
-            for (uint32_t cc = 0; cc < bpp; cc++) {
+#pragma unroll
+            for (uint32_t cc = 0; cc < 4; cc++) {
                 const u32x2 r = OUT[(lane + 2) * 4 + cc];
-                w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(((int)r.y - TB) >> 3) << 8);
+                if (cc < bpp) w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(((int)r.y - TB) >> 3) << 8);
             }
             ((__attribute__((address_space(1))) u32x4 *)k.cand)[x0 + lane] = (u32x4){ w[0], w[1], w[2], w[3] };
         }
@@ -913,10 +999,12 @@ __device__ __forceinline__ void chain_lead(LeadCtx &k, const int lane)
         if (lane < 8) keep = OUT[n * 4 + lane];
         wave_lds_sync();
         if (lane < 8) OUT[lane] = keep;
-        if (chainlane) { /* the pending record of the last pixel now lives in slot 1: nothing to fix, addresses are per step */ }
         wave_lds_sync();
+        cyc_vec += __builtin_readcyclecounter() - tv1;
     }
-    k.slow = slow;
+    kref.slow = slow;
+    kref.rebuilds = k.rebuilds;
+    kref.cyc[0] = cyc_vec; kref.cyc[1] = cyc_fast; kref.cyc[2] = cyc_exact; kref.cyc[3] = cyc_rescan;
 }
 
 template <int MODE>
@@ -996,7 +1084,7 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 
 /* LDS layout of pl_engine (bytes) */
 #define PL_SM_TBL 0
-#define PL_SM_HC (PL_SM_TBL + PL_NFILT * (PL_NSYM + 64) * 8)
+#define PL_SM_HC (PL_SM_TBL + PL_NFILT * PL_TBL_N * 8)
 #define PL_SM_LUT (PL_SM_HC + PL_NSYM * 4)
 #define PL_SM_COSTS (PL_SM_LUT + 512 * 4)
 #define PL_SM_FLAGS (PL_SM_COSTS + 64)
@@ -1008,13 +1096,15 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_L_OUT (PL_SM_L_REC + (PL_NFILT + 1) * PL_SM_L_REC_WAVE)
 #define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2) * 4 * 8)
 #define PL_SM_LEAD_BYTES (PL_SM_L_OUT + PL_NFILT * PL_SM_L_OUT_WAVE)
-#define PL_SM_TOTAL (PL_SM_UNION + (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES))
+#define PL_SM_TOTAL (4096 + PL_SM_UNION + (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES))
 
 __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs, PlEngineParams prm)
 {
     /* LDS carve-up (dynamic: the band-leader tables push the total past the 64 KB static limit; gfx950 has 160 KB) */
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint2 (*const tbl)[PL_NSYM + 64] = (uint2 (*)[PL_NSYM + 64])(smem + PL_SM_TBL);   /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    /* the histogram tables sit 4 KB aligned (the band-leader chain ORs the bin offset into the table address) */
+    unsigned char *const smem = smem_raw + ((4096u - ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw & 4095u)) & 4095u);
+    uint2 (*const tbl)[PL_TBL_N] = (uint2 (*)[PL_TBL_N])(smem + PL_SM_TBL);   /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
     uint32_t *const Hc = (uint32_t *)(smem + PL_SM_HC);                               /* committed symbol_frequency */
     uint32_t *const split_lut = (uint32_t *)(smem + PL_SM_LUT);                       /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255 */
     unsigned long long *const costs = (unsigned long long *)(smem + PL_SM_COSTS);
@@ -1047,6 +1137,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0, lead_rows = 0, lead_rebuilds = 0;
+    unsigned long long lead_cyc[5] = { 0, 0, 0, 0, 0 };   /* diagnostics: vector | fast | exact | rescan | table build */
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
     int status = 0;
     for (uint32_t y = 0; y < H && !status; y++) {
@@ -1073,13 +1164,14 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 k.tbl = (lds_uint2 *)&tbl[lead_f][0];
                 k.T = (lds_uint2 *)(ltab + lead_f * PL_LT_N);
                 k.bs = (lds_u32 *)(lbs + lead_f * 256);
-                k.crec = (lds_uint4 *)(lrec + (lead_f == 4 ? PL_NFILT - 1 : (lead_f > 2 ? lead_f - 1 : lead_f)) * PL_SM_L_REC_WAVE);   /* none, sub, up, average, paeth(x2) */
+                k.crec = (lds_uint4 *)(lrec + lead_f * PL_SM_L_REC_WAVE);   /* none, sub, up, average, paeth (two slots) */
                 k.out = (lds_uint2 *)(lout + lead_f * (PL_SM_L_OUT_WAVE / 8));
                 k.lut = (lds_u32 *)&split_lut[0];
                 k.W = W; k.bpp = bpp; k.s = s; k.rq = recip_up(s + 1);
                 k.slow = 0; k.rebuilds = 0;
                 const unsigned long long t0 = __builtin_readcyclecounter();
                 lead_build_table(k, lane);
+                const unsigned long long tb1 = __builtin_readcyclecounter();
                 switch (lead_f) {
                 case 0: chain_lead_dispatch<0>(k, lane); break;
                 case 1: chain_lead_dispatch<1>(k, lane); break;
@@ -1091,6 +1183,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 slow_px += k.slow;
                 lead_rebuilds += k.rebuilds;
                 lead_rows++;
+                for (int qq = 0; qq < 4; qq++) lead_cyc[qq] += k.cyc[qq];
+                lead_cyc[4] += tb1 - t0;
             } else
             /* round-1 chains: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
              * waves 1..3 run sub, average, paeth; wave 4 only takes part in the data-parallel passes */
@@ -1199,6 +1293,9 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         j.result[8 + wave] = (int32_t)(chain_cycles >> 10);
         j.result[12 + wave] = (int32_t)slow_px;
         if (PL_SEGPROF) for (int q = 0; q < 4; q++) j.result[16 + wave * 4 + q] = (int32_t)(segs[q] >> 10);
+    }
+    if (lane == 0) {
+        for (int qq = 0; qq < 5; qq++) j.result[32 + wave * 5 + qq] = (int32_t)(lead_cyc[qq] >> 10);
     }
     if (lane == 0 && wave == 4) {
         j.result[24] = (int32_t)(chain_cycles >> 10);

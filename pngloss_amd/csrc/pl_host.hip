@@ -63,7 +63,7 @@ WsLayout image_ws(uint32_t width, uint32_t height)
     l.err1 = take(sizeof(uint2) * (size_t)width);
     l.old_above = take(sizeof(uint32_t) * (size_t)width);
     l.final_hist = take(sizeof(uint32_t) * PL_NSYM);
-    l.result = take(sizeof(int32_t) * 32);
+    l.result = take(sizeof(int32_t) * 64);
     l.row_ids = take(height ? height : 1);
     l.out_flags = take(sizeof(uint32_t));
     l.total = o;
@@ -193,7 +193,7 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
     if (std::getenv("PNGLOSS_HIP_DEBUG")) std::fprintf(stderr, "pngloss_hip: row engine occupancy query: %d workgroups per CU\n", pl_engine_occupancy());
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < ctx->n_last; i++) {
-        int32_t r[32] = { 0 };
+        int32_t r[64] = { 0 };
         PL_CHECK(hipMemcpy(r, ctx->h_jobs[i].result, sizeof r, hipMemcpyDeviceToHost));
         if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4] };
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
@@ -202,6 +202,11 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
             std::fprintf(stderr, "pngloss_hip: image %zu: band-leader row attempts %d, wave 4 kcycles %d, exact redos %d, band rescans (wave 0 / 4) %d %d\n", i,
                          r[5], r[24], r[25], r[6], r[26]);
+        if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
+            for (int w = 0; w < 5; w++)
+                std::fprintf(stderr, "pngloss_hip:   wave %d (%s) kcycles: vector %d  fast groups %d  exact redo %d  rescan %d  table build %d\n", w,
+                             w == 0 ? "up" : (w == 1 ? "sub" : (w == 2 ? "average" : (w == 3 ? "paeth" : "none"))),
+                             r[32 + 5 * w], r[33 + 5 * w], r[34 + 5 * w], r[35 + 5 * w], r[36 + 5 * w]);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[16])
             for (int w = 0; w < 4; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generates pngloss_amd/csrc/pl_lead_asm.h: the hand-scheduled gfx950 inner loops of the band-leader chains
+(pl_engine.hip, lead_fast_run).  One asm statement = a 4x unrolled loop over pixels; all rotating values (table
+entries, records, addresses) live in fixed VGPRs v200.. so that the rotation costs no moves.
+
+Per pixel step k (pixel i+k), with E[j] = table entry pairs, Q[j] = record quads, A[j] = looked-up addresses:
+  critical  s_waitcnt lgkmcnt(3)          entry of pixel i+k-1 has arrived (3 younger LDS ops may be in flight)
+            ...filter specific...          8*byte of the previous pixel -> prediction -> 8*osym -> table address
+            ds_read_b64 E[k], A            THE lookup
+  shadow    v_cmp / s_cbranch_vccnz        previous pixel reconstructs outside 0..255 -> leave (almost never)
+            v_and_or + ds_add_u32          histogram bump of the previous pixel (table address HB | (8v & 0x7f8))
+            v_sub_sdwa + ds_write_b64      result record of the previous pixel {8*byte, 8*diff + TB}
+            ds_read_b128 Q[k+2]            record of pixel i+k+2
+            ...                            8*lo of this pixel, pre-added address parts of the next
+Usage: python tools/gen_lead_asm.py > pngloss_amd/csrc/pl_lead_asm.h
+"""
+import os
+ABL = int(os.environ.get("PL_LEAD_ABLATE", "0"))   # timing experiments only (tools/lead_ablate.sh): >0 drops pieces, results become wrong
+E = [(200, 201), (202, 203), (204, 205), (206, 207)]
+A = [208, 209]
+LO = 210
+PRE = 211
+BACK, DTB = 212, 213
+T0, BADACC, OSYM, T1, T2, T3 = 214, 215, 216, 217, 218, 219
+Q = [220, 224, 228, 232]       # quads (paeth: second quads at 240..)
+Q2 = [240, 244, 248, 252]
+RPTR, OPTR, ONE, VHB = 236, 237, 238, 239
+SDWA_W0 = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+SDWA_W1 = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+SDWA_S1W0 = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+
+
+def v(n):
+    return f"v{n}"
+
+
+def vr(lo, n):
+    return f"v[{lo}:{lo + n - 1}]"
+
+
+def step(mode, k):
+    """mode: 'nu' (none/up), 'sub', 'avg', 'pae'"""
+    ep = E[(k + 3) % 4]          # entry of the previous pixel
+    e2 = E[(k + 2) % 4]          # entry of the pixel before it (its .y = thr for this pixel)
+    en = E[k]
+    an, ap = A[k % 2], A[(k + 1) % 2]
+    q, qprev, qnext, qpre = Q[k], Q[(k + 3) % 4], Q[(k + 1) % 4], Q[(k + 2) % 4]
+    rw = 2 if mode == "pae" else 1
+    L = []
+    # the record of pixel i+k+2 first: issued while the wave waits for the previous lookup anyway, and -- being older
+    # than this step's lookup -- guaranteed complete behind the NEXT step's s_waitcnt, which is where it is first used
+    L.append(f"ds_read_b128 {vr(qpre, 4)}, {v(RPTR)} offset:{(k + 2) * 64 * rw}")
+    if mode == "pae":
+        L.append(f"ds_read_b128 {vr(Q2[(k + 2) % 4], 4)}, {v(RPTR)} offset:{(k + 2) * 64 * rw + 16}")
+    L.append("s_waitcnt lgkmcnt(%d)" % (3 if mode == "pae" else 2))
+    if mode == "nu":
+        # record: x = 8*osym + 8*e0 + TB, y = 8*lo.  PRE = x + thr(i-2) was added in the previous step's shadow
+        L.append(f"v_add_u32_sdwa {v(an)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
+        L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
+        L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(qprev + 1)} {SDWA_W0}")
+    elif mode == "sub":
+        # record: x = 8*orig, y = 8*e0 + TB
+        L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(LO)} {SDWA_W0}")
+        L.append(f"v_sub_u32_e32 {v(T0)}, {v(q)}, {v(BACK)}")
+        L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 11")
+        L.append(f"v_add_u32_sdwa {v(T0)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
+        L.append(f"v_add_u32_e32 {v(an)}, {v(T0)}, {v(OSYM)}")
+        L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
+    elif mode == "avg":
+        # record: x = orig, y = 8*e0 + TB, z = 8*above, w = -8*orig
+        L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(LO)} {SDWA_W0}")
+        L.append(f"v_add_u32_e32 {v(T0)}, {v(BACK)}, {v(q + 2)}")
+        L.append(f"v_bfe_u32 {v(T0)}, {v(T0)}, 4, 8")
+        L.append(f"v_sub_u32_e32 {v(T0)}, {v(q)}, {v(T0)}")
+        L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 8")
+        L.append(f"v_add_u32_sdwa {v(T0)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
+        L.append(f"v_lshl_add_u32 {v(an)}, {v(OSYM)}, 3, {v(T0)}")
+        L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
+    else:
+        # records: q  = { 8*diag, 8*above, 16*diag, (8*|above-diag| << 14) + 8*orig + 2048 }
+        #          q2 = { (1<<12) + 8*(orig-above) + 2048, (2<<12) + 8*(orig-diag) + 2048, 8*orig, 8*e0 + TB }
+        q2 = Q2[k]
+        L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(LO)} {SDWA_W0}")
+        L.append(f"v_sad_u32 {v(T0)}, {v(BACK)}, {v(q)}, 0")
+        L.append(f"v_add_u32_e32 {v(T1)}, {v(BACK)}, {v(q + 1)}")
+        L.append(f"v_sad_u32 {v(T1)}, {v(T1)}, {v(q + 2)}, 0")
+        L.append(f"v_lshl_or_b32 {v(T0)}, {v(T0)}, 14, {v(q2)}")
+        L.append(f"v_lshl_or_b32 {v(T1)}, {v(T1)}, 14, {v(q2 + 1)}")
+        L.append(f"v_sub_u32_e32 {v(T2)}, {v(q + 3)}, {v(BACK)}")
+        L.append(f"v_min3_u32 {v(T0)}, {v(T2)}, {v(T0)}, {v(T1)}")
+        L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 11")
+        L.append(f"v_add_u32_sdwa {v(T0)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
+        L.append(f"v_add_u32_e32 {v(an)}, {v(T0)}, {v(OSYM)}")
+        L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
+    # ---- shadow ----
+    L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
+    L.append(f"v_sub_u32_sdwa {v(DTB)}, {v(ap)}, sext({v(ep[0])}) {SDWA_S1W0}")
+    L.append(f"ds_write_b64 {v(OPTR)}, {vr(BACK, 2)} offset:{32 * k}")
+    # thr of the next pixel = entry of the previous pixel .y ; pre-add it to the next record's address part
+    if mode == "nu":
+        L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext)}, {v(ep[1])}")
+    elif mode == "sub":
+        L.append(f"v_sub_u32_e32 {v(LO)}, {v(OSYM)}, {v(q)}")
+        L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext + 1)}, {v(ep[1])}")
+    elif mode == "avg":
+        L.append(f"v_lshl_add_u32 {v(LO)}, {v(OSYM)}, 3, {v(q + 3)}")
+        L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext + 1)}, {v(ep[1])}")
+    else:
+        L.append(f"v_sub_u32_e32 {v(LO)}, {v(OSYM)}, {v(Q2[k] + 2)}")
+        L.append(f"v_add_u32_e32 {v(PRE)}, {v(Q2[(k + 1) % 4] + 3)}, {v(ep[1])}")
+    return L
+
+
+def gen(mode):
+    rw = 2 if mode == "pae" else 1
+    body = []
+    body.append("1:")
+    # the validity test lags: vcc <- any byte so far outside 0..255, tested at the END of the iteration (a scalar branch
+    # right behind the v_cmp that feeds it costs ~100 cycles, profiles/r02_lead_ablation.txt)
+    if ABL < 2:
+        body.append(f"v_cmp_lt_u32_e32 vcc, %[c2047], {v(BADACC)}")
+    for k in range(4):
+        body += step(mode, k)
+    body.append(f"v_add_u32_e32 {v(RPTR)}, {hex(256 * rw)}, {v(RPTR)}")
+    body.append(f"v_add_u32_e32 {v(OPTR)}, 0x80, {v(OPTR)}")
+    body.append("s_sub_u32 %[cnt], %[cnt], 1")
+    if ABL < 1:
+        body.append("s_cbranch_vccnz 99f")
+    body.append("s_cmp_lg_u32 %[cnt], 0")
+    body.append("s_cbranch_scc1 1b")
+    body.append("99:")
+    body.append("s_waitcnt lgkmcnt(0)")
+    return body
+
+
+def emit(mode, name):
+    rw = 2 if mode == "pae" else 1
+    out = []
+    out.append(f"/* {name}: see tools/gen_lead_asm.py */")
+    args = "LeadState &st, const uint32_t rptr, const uint32_t optr, int &iters, u32x4 &qa, u32x4 &qb"
+    if rw == 2:
+        args += ", u32x4 &qx, u32x4 &qy"
+    out.append(f"__device__ __forceinline__ uint32_t {name}({args})")
+    out.append("{")
+    out.append("    uint32_t bad = 0;")
+    out.append("    uint32_t e0 = st.e0; int h1 = st.h1, h2 = st.h2, lo8 = st.lo8, addr = st.addr, cnt = iters;")
+    pre_in = {"nu": Q[0], "sub": Q[0] + 1, "avg": Q[0] + 1, "pae": Q2[0] + 3}[mode]
+    lines = []
+    # move inputs into the fixed registers
+    mv = [(BADACC, "0"), (E[3][0], "%[e0]"), (E[3][1], "%[h1]"), (E[2][1], "%[h2]"), (A[1], "%[addr]"), (RPTR, "%[rptr]"), (OPTR, "%[optr]")]
+    for dst, src in mv:
+        lines.append(f"v_mov_b32_e32 {v(dst)}, {src}")
+    for j in range(4):
+        lines.append(f"v_mov_b32_e32 {v(Q[0] + j)}, %[qa{j}]")
+        lines.append(f"v_mov_b32_e32 {v(Q[1] + j)}, %[qb{j}]")
+        if rw == 2:
+            lines.append(f"v_mov_b32_e32 {v(Q2[0] + j)}, %[qc{j}]")
+            lines.append(f"v_mov_b32_e32 {v(Q2[1] + j)}, %[qd{j}]")
+    if mode == "nu":
+        lines.append(f"v_mov_b32_e32 {v(Q[3] + 1)}, %[lo8]")        # 8*lo of the previous pixel sits in its record
+    else:
+        lines.append(f"v_mov_b32_e32 {v(LO)}, %[lo8]")
+    lines.append(f"v_add_u32_e32 {v(PRE)}, {v(pre_in)}, {v(E[2][1])}")
+    lines += gen(mode)
+    # outputs
+    lines.append(f"v_mov_b32_e32 %[bad], {v(BADACC)}")
+    lines.append(f"v_mov_b32_e32 %[e0], {v(E[3][0])}")
+    lines.append(f"v_mov_b32_e32 %[h1], {v(E[3][1])}")
+    lines.append(f"v_mov_b32_e32 %[h2], {v(E[2][1])}")
+    lines.append(f"v_mov_b32_e32 %[addr], {v(A[1])}")
+    lines.append(f"v_mov_b32_e32 %[lo8], {v(Q[3] + 1 if mode == 'nu' else LO)}")
+    for j in range(4):
+        lines.append(f"v_mov_b32_e32 %[qa{j}], {v(Q[0] + j)}")
+        lines.append(f"v_mov_b32_e32 %[qb{j}], {v(Q[1] + j)}")
+        if rw == 2:
+            lines.append(f"v_mov_b32_e32 %[qc{j}], {v(Q2[0] + j)}")
+            lines.append(f"v_mov_b32_e32 %[qd{j}], {v(Q2[1] + j)}")
+    out.append("    uint32_t " + ", ".join([f"qa{j} = qa[{j}], qb{j} = qb[{j}]" for j in range(4)]) + ";")
+    if rw == 2:
+        out.append("    uint32_t " + ", ".join([f"qc{j} = qx[{j}], qd{j} = qy[{j}]" for j in range(4)]) + ";")
+    out.append("    asm volatile(")
+    for ln in lines:
+        out.append(f'        "{ln}\\n"')
+    outs = ['[bad] "=&v"(bad)', '[cnt] "+s"(cnt)', '[e0] "+v"(e0)', '[h1] "+v"(h1)', '[h2] "+v"(h2)', '[addr] "+v"(addr)', '[lo8] "+v"(lo8)']
+    for j in range(4):
+        outs += [f'[qa{j}] "+v"(qa{j})', f'[qb{j}] "+v"(qb{j})']
+        if rw == 2:
+            outs += [f'[qc{j}] "+v"(qc{j})', f'[qd{j}] "+v"(qd{j})']
+    ins = ['[rptr] "v"(rptr)', '[optr] "v"(optr)', '[c2047] "s"(2047u)']
+    hi = 256 if rw == 2 else 240
+    clob = ", ".join([f'"v{n}"' for n in range(200, hi)] + ['"vcc"', '"scc"', '"memory"'])
+    out.append("        : " + ", ".join(outs))
+    out.append("        : " + ", ".join(ins))
+    out.append("        : " + clob + ");")
+    out.append("    st.e0 = e0; st.h1 = h1; st.h2 = h2; st.lo8 = lo8; st.addr = addr;")
+    out.append("    " + " ".join([f"qa[{j}] = qa{j}; qb[{j}] = qb{j};" for j in range(4)]))
+    if rw == 2:
+        out.append("    " + " ".join([f"qx[{j}] = qc{j}; qy[{j}] = qd{j};" for j in range(4)]))
+    out.append("    iters = cnt;")
+    out.append("    return bad;")
+    out.append("}")
+    return "\n".join(out)
+
+
+print("/* GENERATED by tools/gen_lead_asm.py -- do not edit.  Hand-scheduled gfx950 inner loops of the band-leader chains. */")
+print("#ifndef PL_LEAD_ASM_H\n#define PL_LEAD_ASM_H\n")
+for m, n in [("nu", "lead_asm_noneup"), ("sub", "lead_asm_sub"), ("avg", "lead_asm_avg"), ("pae", "lead_asm_paeth")]:
+    print(emit(m, n))
+    print()
+print("#endif")
