@@ -242,6 +242,8 @@ static void run_chain(const engine *e, uint32_t y, int f, unsigned s, long bleed
  */
 static int g_chain_variant = 0;
 void port_set_chain_variant(int v) { g_chain_variant = v; }
+static int g_force_filter = -1;   /* debugging aid: >= 0 makes that candidate the winner of every row */
+void port_set_force_filter(int f) { g_force_filter = f; }
 
 static inline uint32_t key2(uint32_t rank, int jj, int josym)
 {
@@ -328,67 +330,140 @@ static void run_chain_spec(const engine *e, uint32_t y, int f, unsigned s, long 
  * The formulation of the round-2 HIP row engine (pl_engine.hip, chain_lead), proven here on the CPU first.
  * Observation: without the clamp the candidate set of a channel is one of a FIXED partition of v-space into bands
  * [tq, tq+s] (filt >= 0) and [-tq-s, -tq] (filt < 0) (optimize_state.c:186-193), and the choice inside a band is the
- * lexicographic arg-max of (H[v], O_f[v], v==osym, -v) (:212-244).  Keep, per "near" band (one that lies inside
- * |v| <= 127, so that no histogram bin belongs to two tracked bands except bin 0), its LEADER L = argmax (H, O_f, -v)
- * and whether that maximum of (H, O_f) is unique.  Then:
- *   - a pixel channel whose band is near, whose band maximum is unique and whose leader can be reconstructed
- *     (lo <= L <= hi, the clamp of :195-210) chooses exactly L: the clamped range is a subset of the band that
- *     contains the band's unique maximum, and "v == osym" only breaks (H, O_f) ties, of which there are none;
- *   - bumping a unique leader leaves every band's leader and uniqueness unchanged (bin 0 is the one bin that sits
- *     in two near bands, [0,s] and [-s,0]: a band whose leader is 0 only counts as usable while 0 also leads the
- *     other one or the other one is unusable), so the four channels of a pixel decouple and NO per-pixel gather,
- *     reduction or channel repair is needed -- one table lookup per channel;
- *   - anything else (far band, tie at the top, leader clamped away, a forced transparent-alpha symbol that is not
- *     its band's leader) takes the exact sequential evaluation and then rebuilds the bands its bumps touched.
+ * lexicographic arg-max of (H[v], O_f[v], v==osym, -v) (:212-244).  Keep, per tracked band, its LEADER
+ * L = argmax (H, O_f, -v) and whether that maximum of (H, O_f) is unique.  Then:
+ *   - a pixel channel whose band is usable and whose leader can be reconstructed (lo <= L <= hi, the clamp of
+ *     :195-210) chooses exactly L: the clamped range is a subset of the band that contains the band's unique maximum,
+ *     and "v == osym" only breaks (H, O_f) ties, of which there are none;
+ *   - bumping the leader of a usable band changes no usable band's state, so the four channels of a pixel decouple
+ *     and NO per-pixel gather, reduction or channel repair is needed -- one table lookup per channel;
+ *   - anything else takes the exact sequential evaluation and then rescans the bands its bumps touched.
+ * Bands of opposite sign OVERLAP in histogram bins (bin b is v = b in a positive band and v = b - 256 in a negative
+ * one), so "changes no usable band's state" needs a rule: two usable bands must never disagree about a shared bin,
+ *   conflict(A, B) = the leader bin of one lies in the other and is not the other's leader bin,
+ * and of two conflicting bands the one with the lower priority number 2t + (negative ? 1 : 0) stays usable.  A band
+ * demoted by a conflict also loses `ok`: its recorded state may go stale while the winner's leader keeps being bumped
+ * on the fast path, and only a rescan brings it back.
+ * Geometry.  Filters with a data dependent clamp (sub, up, average, paeth): bands t < 256/q, the clamp is checked per
+ * pixel.  Filter none: the prediction is 0, so the re-centred prediction is 0 (orig <= 127, "P pixels", v = byte) or 256
+ * (orig >= 128, "N pixels", v = byte - 256) and the clamp is static: positive bands are cut to [.., 255], negative ones to
+ * [-256, -1] (so v = 0 is not in the negative zero band), a P pixel with filt < 0 can only choose v = 0 and an N pixel
+ * with filt >= 0 only v = -1; these two are served by the zero bands when those are led by exactly that value.
  * port_lead_stats() reports how often each case occurs (the GPU engine's speed is the fast fraction).
  */
-typedef struct { int L; int usable; int uniq; } band_state;
-static unsigned long long g_lead_stats[8 * 6];   /* [0..7] all chains, [8+8f..] chain f */
+typedef struct { int L; int ok; int usable; } band_state;   /* ok: L is the unique (H,O) maximum AND the scan is fresh */
+static unsigned long long g_lead_stats[8 * 6];   /* [0..7] all chains, [8+8f..] chain f: pixels, fast, slow:untracked, slow:unusable, slow:clamp, slow:forced, scans, rows */
 #define LSTAT(i) do { g_lead_stats[i]++; g_lead_stats[8 + 8 * g_lead_f + (i)]++; } while (0)
 static int g_lead_f;
-static unsigned long long g_lead_stats_unused[1];   /* pixels, fast, slow:far, slow:tie/unusable, slow:clamp, slow:forced, rebuilds, rows */
 void port_lead_stats(unsigned long long out[48], int reset)
 {
     if (out) memcpy(out, g_lead_stats, sizeof g_lead_stats);
     if (reset) memset(g_lead_stats, 0, sizeof g_lead_stats);
 }
 
-/* band id: 0..NB-1 = positive bands t, NB..2NB-1 = negative bands t */
-static void band_scan(const uint32_t *Hs, const uint32_t *O, int q, int s, int NB, int id, band_state *b)
+typedef struct { int q, s, NP, none; const uint32_t *O; } band_geo;
+/* band ids: 0..NP-1 = positive bands t, NP..2NP-1 = negative bands t */
+static inline int band_lo(const band_geo *g, int id)
 {
-    const int neg = id >= NB, t = neg ? id - NB : id;
-    const int v0 = neg ? -t * q - s : t * q;
-    int L = v0; uint32_t bh = Hs[v0 & 255], bo = O[v0 & 255]; int uniq = 1;
-    for (int v = v0 + 1; v <= v0 + s; v++) {
-        const uint32_t h = Hs[v & 255], o = O[v & 255];
+    if (id < g->NP) return id * g->q;
+    const int t = id - g->NP, lo = -t * g->q - g->s;
+    return (g->none && lo < -256) ? -256 : lo;
+}
+static inline int band_hi(const band_geo *g, int id)
+{
+    if (id < g->NP) { const int hi = id * g->q + g->s; return (g->none && hi > 255) ? 255 : hi; }
+    const int t = id - g->NP;
+    return (g->none && t == 0) ? -1 : -t * g->q;
+}
+static inline int band_of_bin(const band_geo *g, int bin, int neg)   /* the band of that sign holding the bin, or -1 */
+{
+    if (!neg) { const int t = bin / g->q; return t < g->NP ? t : -1; }
+    int v;
+    if (bin) v = bin - 256; else if (g->none) v = -256; else return g->NP ? g->NP : -1;   /* general: v = 0 sits in negative band 0 too */
+    const int t = (-v) / g->q;
+    return t < g->NP ? g->NP + t : -1;
+}
+static inline int band_has_bin(const band_geo *g, int id, int bin)
+{
+    int v;
+    if (id < g->NP) v = bin;
+    else v = bin ? bin - 256 : (g->none ? -256 : 0);
+    return v >= band_lo(g, id) && v <= band_hi(g, id);
+}
+static void band_scan(const uint32_t *Hs, const band_geo *g, int id, band_state *b)
+{
+    const int v0 = band_lo(g, id), v1 = band_hi(g, id);
+    int L = v0; uint32_t bh = Hs[v0 & 255], bo = g->O[v0 & 255]; int uniq = 1;
+    for (int v = v0 + 1; v <= v1; v++) {
+        const uint32_t h = Hs[v & 255], o = g->O[v & 255];
         if (h > bh || (h == bh && o > bo)) { L = v; bh = h; bo = o; uniq = 1; }
         else if (h == bh && o == bo) uniq = 0;
     }
-    b->L = L; b->uniq = uniq; b->usable = uniq;
+    b->L = L; b->ok = uniq; b->usable = 0;
+    LSTAT(6);
 }
-static void band_pair_fixup(band_state *B, int NB)
+/* the (at most 2) bands of the other sign that share a bin with band id: those of its first and of its last bin */
+static int band_overlaps(const band_geo *g, int id, int out[2])
 {
-    /* bin 0 sits in positive band 0 and negative band 0 */
-    band_state *p = &B[0], *n = &B[NB];
-    p->usable = p->uniq; n->usable = n->uniq;
-    if (p->L == 0 && n->L != 0) p->usable = p->uniq && !n->usable;
-    else if (n->L == 0 && p->L != 0) n->usable = n->uniq && !p->usable;
+    int n = 0;
+    const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
+    for (int k = 0; k < 2; k++) {
+        const int o = band_of_bin(g, ends[k], id < g->NP);
+        if (o >= 0 && (n == 0 || out[0] != o)) out[n++] = o;
+    }
+    return n;
 }
-static void band_rebuild_for_bin(const uint32_t *Hs, const uint32_t *O, int q, int s, int NB, band_state *B, int bin)
+static inline int band_prio(const band_geo *g, int id) { return id >= g->NP ? 2 * (id - g->NP) + 1 : 2 * id; }
+static inline int band_conflict(const band_geo *g, const band_state *B, int a, int b)
 {
-    const int lim = NB * q;            /* near v: |v| < lim */
-    if (bin == 0) {
-        if (NB) { band_scan(Hs, O, q, s, NB, 0, &B[0]); band_scan(Hs, O, q, s, NB, NB, &B[NB]); band_pair_fixup(B, NB); LSTAT(6); LSTAT(6); }
-        return;
+    const int la = B[a].L & 255, lb = B[b].L & 255;
+    return (band_has_bin(g, a, lb) && lb != la) || (band_has_bin(g, b, la) && la != lb);
+}
+/* after band id was rescanned: decide its usability against its betters, then demote the lesser bands it now conflicts with */
+static void band_settle(const band_geo *g, band_state *B, int id)
+{
+    int ov[2];
+    const int n = band_overlaps(g, id, ov);
+    int usable = B[id].ok;
+    for (int j = 0; j < n && usable; j++)
+        if (band_prio(g, ov[j]) < band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, id, ov[j])) usable = 0;
+    B[id].usable = usable;
+    if (!usable) B[id].ok = 0;
+    if (usable)
+        for (int j = 0; j < n; j++)
+            if (band_prio(g, ov[j]) > band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, id, ov[j])) { B[ov[j]].usable = 0; B[ov[j]].ok = 0; }
+}
+static void band_rebuild_for_bin(const uint32_t *Hs, const band_geo *g, band_state *B, int bin)
+{
+    int ids[2], n = 0;
+    const int p = band_of_bin(g, bin, 0), m = band_of_bin(g, bin, 1);
+    if (p >= 0) ids[n++] = p;
+    if (m >= 0) ids[n++] = m;
+    if (n == 2 && band_prio(g, ids[1]) < band_prio(g, ids[0])) { int t = ids[0]; ids[0] = ids[1]; ids[1] = t; }
+    int need[2] = { 0, 0 };
+    const uint32_t hnew = Hs[bin], onew = g->O[bin];
+    for (int j = 0; j < n; j++) {
+        /* cheap test: a fresh band whose leader is not this bin and still beats it strictly keeps its state */
+        const band_state *b = &B[ids[j]];
+        const int lbin = b->L & 255;
+        need[j] = !b->ok || (lbin == bin ? 0 : (hnew > Hs[lbin] || (hnew == Hs[lbin] && onew >= g->O[lbin])));
     }
-    if (bin < lim) {
-        const int id = bin / q; band_scan(Hs, O, q, s, NB, id, &B[id]); LSTAT(6);
-        if (id == 0) band_pair_fixup(B, NB);
+    for (int j = 0; j < n; j++) if (need[j]) band_scan(Hs, g, ids[j], &B[ids[j]]);
+    for (int j = 0; j < n; j++) if (need[j]) band_settle(g, B, ids[j]);
+}
+/* the band a lookup with this filt lands in (-1: not tracked) and, for filter none's two one-value cases, the value it is forced to */
+static inline int band_of_lookup(const band_geo *g, int filt, int npixel, int *forced, int *fv)
+{
+    *forced = 0;
+    if (g->none) {
+        if (!npixel && filt < 0) { *forced = 1; *fv = 0; return g->NP ? 0 : -1; }
+        if (npixel && filt >= 0) { *forced = 1; *fv = -1; return g->NP ? g->NP : -1; }
     }
-    if (256 - bin < lim) {
-        const int id = NB + (256 - bin) / q; band_scan(Hs, O, q, s, NB, id, &B[id]); LSTAT(6);
-        if (id == NB) band_pair_fixup(B, NB);
-    }
+    const int t = (filt < 0 ? -filt : filt) / g->q;
+    if (t >= g->NP) return -1;
+    if (g->none && filt > 255) return -1;
+    if (g->none && filt < -256) return -1;
+    return filt < 0 ? g->NP + t : t;
 }
 
 static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long bleed, candidate *cd)
@@ -400,13 +475,15 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
     const uint32_t *O = e->orig_hist[f];
     uint32_t *Hs = cd->hist;
     const int q = (int)s + 1;
-    const int NB = 128 / q, lim = NB * q;
+    band_geo g = { q, (int)s, f == F_NONE ? (256 + q - 1) / q : 256 / q, f == F_NONE, O };
+    const int NP = g.NP;
     const bool has_alpha = (bpp % 2) == 0;
-    band_state B[2 * 128 + 2];
+    band_state B[2 * 256 + 2];
     memcpy(Hs, e->hist, sizeof(e->hist));
-    for (int id = 0; id < 2 * NB; id++) band_scan(Hs, O, q, (int)s, NB, id, &B[id]);
-    if (NB) band_pair_fixup(B, NB);
     g_lead_f = f;
+    for (int id = 0; id < 2 * NP; id++) band_scan(Hs, &g, id, &B[id]);
+    /* settle in priority order: positive t, negative t, positive t+1, ... */
+    for (int t = 0; t < NP; t++) { band_settle(&g, B, t); band_settle(&g, B, NP + t); }
     LSTAT(7);
     int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
 
@@ -429,25 +506,26 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             lo[c] = osym[c] - ov;
             const int err = sext16(e->E0[(size_t)x * 4 + pl] + rem[pl] + thr_prev[pl]);
             filt[c] = osym[c] + err;
+            int forced, fv = 0, id;
             if (tr[c]) {
-                /* forced symbol (0 - pred) mod 256 (optimize_state.c:158-164): harmless iff its bin is in no near band or
-                 * it is the leader of a usable near band */
-                const int bin = (0 - pred[c]) & 255;
-                int v = -1000;
-                if (bin < lim) v = bin; else if (256 - bin < lim) v = bin - 256;
-                if (v != -1000) {
-                    const int id = v >= 0 ? v / q : NB + (-v) / q;
-                    if (!(B[id].usable && B[id].L == v)) why = why ? why : 5;
-                }
+                /* forced symbol (0 - pred) mod 256 (optimize_state.c:158-164), looked up as v = sext8(-pred) (filter none:
+                 * pred = 0, a P pixel): fine iff that band is usable and led by exactly this v */
+                fv = sext8(-pred[c]);
+                id = band_of_lookup(&g, fv, 0, &forced, &fv);
+                forced = 1;
                 vfast[c] = -pred[c];
                 lo[c] = -pred[c];
-                continue;
+            } else {
+                id = band_of_lookup(&g, filt[c], ov >= 128, &forced, &fv);
             }
-            const int fl = filt[c];
-            if (fl >= lim || fl <= -lim) { why = why ? why : 2; continue; }
-            const int id = fl >= 0 ? fl / q : NB + (-fl) / q;
+            if (id < 0) { why = why ? why : 2; continue; }
             if (!B[id].usable) { why = why ? why : 3; continue; }
             const int L = B[id].L;
+            if (forced) {
+                if (L != fv) { why = why ? why : 5; continue; }
+                if (!tr[c]) vfast[c] = fv;
+                continue;
+            }
             if (L < lo[c] || L > lo[c] + 255) { why = why ? why : 4; continue; }
             vfast[c] = L;
         }
@@ -462,7 +540,7 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             }
         } else {
             LSTAT(why);
-            /* exact sequential evaluation (the reference's own order), then rebuild what the bumps touched */
+            /* exact sequential evaluation (the reference's own order), then rescan what the bumps touched */
             for (uint32_t c = 0; c < bpp; c++) {
                 const int pl = plane_of(bpp, c);
                 int best;
@@ -486,7 +564,7 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
                 }
                 cd->bytes[(size_t)x * bpp + c] = (unsigned char)(best - lo[c]);
                 Hs[best & 255]++;
-                band_rebuild_for_bin(Hs, O, q, (int)s, NB, B, best & 255);
+                band_rebuild_for_bin(Hs, &g, B, best & 255);
             }
         }
         for (int pl = 0; pl < 4; pl++) {
@@ -598,6 +676,7 @@ int port_optimize_packed(unsigned char *pix, uint32_t width, uint32_t height, ui
                     } else {
                         cand[f].cost = derivative_error(&e, y, &cand[f]) / 128 + entropy_cost(&e, y, f, &cand[f]);
                     }
+                    if (g_force_filter >= 0) cand[f].cost = f == g_force_filter ? 0 : UINT64_MAX;
                     costs[f] = cand[f].cost;
                     if (cand[f].cost < best_cost) { best_cost = cand[f].cost; winner = f; }
                 }

@@ -56,6 +56,8 @@ unsigned port_symbol_cost(uint32_t freq);
 /* 0 (default): straightforward chain.  1: the speculative-channels + rank-key formulation of the HIP row engine
  * (same results, proven by tests/test_oracle.py); process-global, test use only. */
 void port_set_chain_variant(int variant);
+/* debugging aid: f >= 0 makes candidate filter f the winner of every row (-1: normal) */
+void port_set_force_filter(int f);
 
 #ifdef __cplusplus
 }

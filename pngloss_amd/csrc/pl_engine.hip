@@ -481,7 +481,8 @@ struct LeadCtx {
     uint4 *cand;              /* this chain's candidate row cand[f][W] */
     lds_uint2 *tbl;           /* this chain's {H, rank<<9}[PL_TBL_N] */
     lds_uint2 *T;             /* this chain's decision table [PL_LT_N] */
-    lds_u32 *bs;              /* this chain's band states [256]: L+256 | uniq<<9 | usable<<10 */
+    lds_u32 *bs;              /* this chain's band states [512]: L+256 | ok<<9 | usable<<10 */
+    lds_u32 *work;            /* 32 words of scratch for the rescan */
     lds_uint4 *crec;          /* chain records of the chunk: [PL_LCHUNK][4][RW] */
     lds_uint2 *out;           /* results of the chunk: [(2 + PL_LCHUNK)][4] {8*byte (checked), 8*diff + TB} */
     lds_u32 *lut;             /* Sierra split table [diff+256] -> rem | thr<<16 */
@@ -500,89 +501,189 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* first value of band id (0..NB-1 positive bands t, NB..2NB-1 negative bands t) */
-__device__ __forceinline__ int band_v0(int id, int NB, int q, int s)
+/* ---- band geometry (oracle/pngloss_port.c: band_geo and friends) ------------------------------------------------
+ * ids 0..NP-1 = positive bands t, NP..2NP-1 = negative bands t.  Filters with a data dependent clamp: bands t < 256/q.
+ * Filter none (static clamp, see the oracle's comment): positive bands cut to [.., 255], negative ones to [-256, -1],
+ * two decision tables (P pixels: orig <= 127, N pixels: orig >= 128). */
+struct LeadGeo { int q, s, NP; bool none; float rq; };
+__device__ __forceinline__ LeadGeo lead_geo(int s, bool none, float rq)
 {
-    return id >= NB ? -(id - NB) * q - s : id * q;
+    LeadGeo g; g.q = s + 1; g.s = s; g.none = none; g.rq = rq;
+    g.NP = none ? (256 + s) / (s + 1) : 256 / (s + 1);
+    return g;
+}
+__device__ __forceinline__ int geo_div(const LeadGeo &g, int x) { return (int)((float)x * g.rq); }   /* x / q, 0 <= x <= 512 */
+__device__ __forceinline__ int band_lo(const LeadGeo &g, int id)
+{
+    if (id < g.NP) return id * g.q;
+    const int lo = -(id - g.NP) * g.q - g.s;
+    return (g.none && lo < -256) ? -256 : lo;
+}
+__device__ __forceinline__ int band_hi(const LeadGeo &g, int id)
+{
+    if (id < g.NP) { const int hi = id * g.q + g.s; return (g.none && hi > 255) ? 255 : hi; }
+    const int t = id - g.NP;
+    return (g.none && t == 0) ? -1 : -t * g.q;
+}
+__device__ __forceinline__ int band_of_bin(const LeadGeo &g, int bin, bool neg)   /* the band of that sign holding the bin, or -1 */
+{
+    if (!neg) { const int t = geo_div(g, bin); return t < g.NP ? t : -1; }
+    int v;
+    if (bin) v = bin - 256; else if (g.none) v = -256; else return g.NP ? g.NP : -1;   /* v = 0 sits in negative band 0 too */
+    const int t = geo_div(g, -v);
+    return t < g.NP ? g.NP + t : -1;
+}
+__device__ __forceinline__ bool band_has_bin(const LeadGeo &g, int id, int bin)
+{
+    const int v = id < g.NP ? bin : (bin ? bin - 256 : (g.none ? -256 : 0));
+    return v >= band_lo(g, id) && v <= band_hi(g, id);
+}
+__device__ __forceinline__ int band_prio(const LeadGeo &g, int id) { return id >= g.NP ? 2 * (id - g.NP) + 1 : 2 * id; }
+/* band states in LDS: L + 256 | ok << 9 | usable << 10   (ok: L is the unique (H, rank) maximum and the scan is fresh) */
+__device__ __forceinline__ bool band_conflict(const LeadGeo &g, uint32_t sa, uint32_t sb, int a, int b)
+{
+    const int la = ((int)(sa & 511u) - 256) & 255, lb = ((int)(sb & 511u) - 256) & 255;
+    return (band_has_bin(g, a, lb) && lb != la) || (band_has_bin(g, b, la) && la != lb);
+}
+/* usable(id) given the CURRENT usable bits of its (at most two) neighbours of the other sign */
+__device__ __forceinline__ bool band_usable_now(const LeadGeo &g, lds_u32 *bs, int id, uint32_t st)
+{
+    bool usable = (st >> 9) & 1u;
+    const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int o = band_of_bin(g, ends[e], id < g.NP);
+        if (o >= 0 && band_prio(g, o) < band_prio(g, id)) {
+            const uint32_t so = bs[o];
+            if ((so & 1024u) && band_conflict(g, st, so, id, o)) usable = false;
+        }
+    }
+    return usable;
 }
 
-/* one table entry from a band state */
-__device__ __forceinline__ u32x2 lead_entry(uint32_t st, int filt, lds_u32 *LUT)
+/* one decision-table entry.  tab 0: the table (filter none: of the P pixels), tab 1: filter none's N pixels */
+__device__ __forceinline__ u32x2 lead_entry_at(const LeadGeo &g, lds_u32 *bs, lds_u32 *LUT, int filt, int tab)
 {
-    if (!(st & 1024u)) return (u32x2){ (uint32_t)PL_LT_BADV, 0u };
+    const u32x2 badent = (u32x2){ (uint32_t)PL_LT_BADV, 0u };
+    int id; bool forced = false; int fv = 0;
+    const int af = abs(filt);
+    if (g.none && tab == 0 && filt < 0) { forced = true; fv = 0; id = g.NP ? 0 : -1; }
+    else if (g.none && tab == 1 && filt >= 0) { forced = true; fv = -1; id = g.NP ? g.NP : -1; }
+    else {
+        const int t = geo_div(g, af);
+        id = t < g.NP ? (filt < 0 ? g.NP + t : t) : -1;
+        if (g.none && (tab == 1) != (filt < 0)) id = -1;
+    }
+    if (id < 0) return badent;
+    const uint32_t st = bs[id];
+    if (!(st & 1024u)) return badent;
     const int L = (int)(st & 511u) - 256;
-    const uint32_t le = LUT[(filt - L + 256) & 511];
+    if (forced && L != fv) return badent;
+    const int diff = filt - L;
+    if (diff < -256 || diff > 255) return badent;
+    const uint32_t le = LUT[diff + 256];
     const int rem = pl_sext16((int)le), thr = (int)le >> 16;
     return (u32x2){ ((uint32_t)(L * 8) & 0xffffu) | ((uint32_t)(rem * 8) << 16), (uint32_t)(thr * 8) };
 }
 
-/* bin 0 sits in positive band 0 and negative band 0: a band led by 0 is only usable while 0 also leads the other
- * one, or the other one is unusable (oracle: band_pair_fixup) */
-__device__ __forceinline__ void lead_zero_pair(lds_u32 *bs, int NB)
+/* rewrite every table entry that depends on band id (all lanes of the wave cooperate) */
+__device__ __forceinline__ void lead_write_band_entries(const LeadCtx &k, const LeadGeo &g, int lane, int id)
 {
-    uint32_t p = bs[0], n = bs[NB];
-    const int Lp = (int)(p & 511u) - 256, Ln = (int)(n & 511u) - 256;
-    bool up = (p >> 9) & 1u, un = (n >> 9) & 1u;
-    if (Lp == 0 && Ln != 0) up = up && !un;
-    else if (Ln == 0 && Lp != 0) un = un && !up;
-    bs[0] = (p & 1023u) | (up ? 1024u : 0u);
-    bs[NB] = (n & 1023u) | (un ? 1024u : 0u);
+    const bool neg = id >= g.NP;
+    const int tab = (g.none && neg) ? 1 : 0;
+    lds_uint2 *const T = k.T + tab * PL_LT_N;
+    int flo = band_lo(g, id), fhi = band_hi(g, id);
+    if (!g.none && neg && fhi == 0) fhi = -1;             /* filt = 0 belongs to positive band 0 */
+    for (int f = flo + lane; f <= fhi; f += 64) T[f + 256] = lead_entry_at(g, k.bs, k.lut, f, tab);
+    if (g.none && (id == 0 || id == g.NP)) {
+        /* the one-value cases served by the zero bands: P pixels with filt < 0, N pixels with filt >= 0 */
+        const int base = id == 0 ? -256 : 0;
+        for (int f = base + lane; f < base + 256; f += 64) T[f + 256] = lead_entry_at(g, k.bs, k.lut, f, tab);
+    }
 }
 
-/* whole-table rebuild from the chain's histogram (row start / new strength): lane = band, then lane = entry */
-__device__ __forceinline__ void lead_build_table(const LeadCtx &k, int lane)
+/* scan of band id by one lane (row start) */
+__device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2 *H, int id)
 {
-    const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
-    lds_uint2 *const H = k.tbl;
-    for (int id = lane; id < 2 * NB; id += 64) {
-        const int v0 = band_v0(id, NB, q, s);
-        u32x2 e = H[v0 & 255];
-        int L = v0; uint32_t bh = e.x, br = e.y; bool uniq = true;
-        for (int j = 1; j <= s; j++) {
-            e = H[(v0 + j) & 255];
-            if (e.x > bh || (e.x == bh && e.y > br)) { L = v0 + j; bh = e.x; br = e.y; uniq = true; }
-            else if (e.x == bh && e.y == br) uniq = false;
-        }
-        k.bs[id] = (uint32_t)(L + 256) | (uniq ? 1536u : 0u);
+    const int v0 = band_lo(g, id), v1 = band_hi(g, id);
+    u32x2 e = H[v0 & 255];
+    int L = v0; uint32_t bh = e.x, br = e.y; bool uniq = true;
+    for (int v = v0 + 1; v <= v1; v++) {
+        e = H[v & 255];
+        if (e.x > bh || (e.x == bh && e.y > br)) { L = v; bh = e.x; br = e.y; uniq = true; }
+        else if (e.x == bh && e.y == br) uniq = false;
+    }
+    return (uint32_t)(L + 256) | (uniq ? 512u : 0u);
+}
+
+/* whole-table rebuild from the chain's histogram (row start / new strength) */
+__device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo &g, int lane)
+{
+    const int nb = 2 * g.NP;
+    for (int id = lane; id < nb; id += 64) {
+        const uint32_t st = lead_scan_serial(g, k.tbl, id);
+        k.bs[id] = st | ((st & 512u) << 1);               /* first guess: usable = ok */
     }
     wave_lds_sync();
-    if (lane == 0 && NB) lead_zero_pair(k.bs, NB);
-    wave_lds_sync();
-    for (int idx = lane; idx < PL_LT_N; idx += 64) {
-        const int filt = idx - 256, af = abs(filt);
-        u32x2 ent = (u32x2){ (uint32_t)PL_LT_BADV, 0u };
-        if (af < lim) {
-            const int t = (int)((float)af * k.rq);
-            ent = lead_entry(k.bs[filt >= 0 ? t : NB + t], filt, k.lut);
+    /* usable bits: the unique solution of  usable(A) = ok(A) and no usable band of higher priority conflicts with A.
+     * The priority order has short dependency chains, so a few parallel rounds reach the fixpoint. */
+    for (int round = 0; round < 64; round++) {
+        bool changed = false;
+        for (int id = lane; id < nb; id += 64) {
+            const uint32_t st = k.bs[id];
+            const bool u = band_usable_now(g, k.bs, id, st);
+            if (u != (bool)((st >> 10) & 1u)) changed = true;
+            k.bs[id] = (st & 1023u) | (u ? 1024u : 0u);
         }
-        k.T[idx] = ent;
+        wave_lds_sync();
+        if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
+    }
+    for (int id = lane; id < nb; id += 64) {
+        const uint32_t st = k.bs[id];
+        if (!(st & 1024u)) k.bs[id] = st & 511u;          /* demoted by a conflict: stale from now on */
+    }
+    wave_lds_sync();
+    const int ntab = g.none ? 2 : 1;
+    for (int idx = lane; idx < ntab * PL_LT_N; idx += 64) {
+        const int tab = idx >> 9, filt = (idx & 511) - 256;
+        k.T[idx] = lead_entry_at(g, k.bs, k.lut, filt, tab);
     }
     wave_lds_sync();
 }
 
-/* rescan of the near bands that contain the bins the four channels of a slow pixel just bumped; row c of the wave
- * (16 lanes) works for channel c's bin.  Rewrites the affected table entries. */
-__device__ __forceinline__ void lead_rescan(LeadCtx &k, int lane, int bin, bool rowactive)
+/* After a slow pixel: row c of the wave (16 lanes) looks after the bin its channel just bumped.  Bands (one per sign)
+ * that hold the bin are rescanned unless the cheap test proves their state unchanged (the bin is not the leader and
+ * still strictly below it in (H, rank), or it is the leader of a band that was ok); then one lane settles the usable
+ * bits of the rescanned bands in priority order and the table entries of every band that changed are rewritten. */
+__device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int lane, int bin, bool rowactive, lds_u32 *work)
 {
-    const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
-    const int jl = lane & 15;
+    const int jl = lane & 15, c = lane >> 4;
     lds_uint2 *const H = k.tbl;
-    const int nc = (q + 15) >> 4;
-    bool zero_touched = false;
+    const int nc = (g.q + 15) >> 4;
+    /* work[0..7] = ids of the bands that were rescanned (-1: none), slot 2c + sign */
+    if (lane < 8) work[lane] = 0xffffffffu;
+    wave_lds_sync();
+    bool any = false;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-        bool has; int id;
-        if (pass == 0) { has = rowactive && bin < lim; id = (int)((float)bin * k.rq); }
-        else { has = rowactive && NB && (bin == 0 || 256 - bin < lim); id = NB + (bin ? (int)((float)(256 - bin) * k.rq) : 0); }
-        if (__builtin_amdgcn_ballot_w64(has) == 0) continue;
-        if (!has) id = 0;
-        const int v0 = band_v0(id, NB, q, s);
+        const int id0 = rowactive ? band_of_bin(g, bin, pass == 1) : -1;
+        bool need = false;
+        if (id0 >= 0) {
+            const uint32_t st = k.bs[id0];
+            const int lbin = ((int)(st & 511u) - 256) & 255;
+            const u32x2 eb = H[bin], el = H[lbin];
+            need = !(st & 512u) || (lbin == bin ? false : (eb.x > el.x || (eb.x == el.x && eb.y >= el.y)));
+        }
+        if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+        any = true;
+        const int id = need ? id0 : 0;
+        const int v0 = band_lo(g, id), n1 = band_hi(g, id) - v0;     /* last index */
         uint32_t hm = 0;
-        for (int t = 0; t < nc; t++) hm = max(hm, H[(v0 + min(jl + 16 * t, s)) & 255].x);
+        for (int t = 0; t < nc; t++) hm = max(hm, H[(v0 + min(jl + 16 * t, n1)) & 255].x);
         const uint32_t Hmax = rowmax_u32(hm);
         uint32_t km = 0;
         for (int t = 0; t < nc; t++) {
-            const int j = min(jl + 16 * t, s);
+            const int j = min(jl + 16 * t, n1);
             const u32x2 e = H[(v0 + j) & 255];
             km = max(km, e.x == Hmax ? (e.y >> 1) + (uint32_t)(255 - j) + 1u : 0u);    /* rank<<8 | 255-j, +1 */
         }
@@ -592,38 +693,55 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, int lane, int bin, bool 
         uint32_t dup = 0;
         for (int t = 0; t < nc; t++) {
             const int j = jl + 16 * t;
-            if (j <= s && j != jL) {
+            if (j <= n1 && j != jL) {
                 const u32x2 e = H[(v0 + j) & 255];
                 dup |= (e.x == Hmax && (e.y >> 9) == rL) ? 1u : 0u;
             }
         }
         dup = rowmax_u32(dup);
-        if (has && jl == 0) k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 1536u);
-        zero_touched |= has && (id == 0 || id == NB);
-        k.rebuilds += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has && jl == 0));
-        wave_lds_sync();
-        if (__builtin_amdgcn_ballot_w64(zero_touched) != 0) {
-            if (lane == 0) lead_zero_pair(k.bs, NB);
-            wave_lds_sync();
+        if (need && jl == 0) {
+            k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 512u);      /* usable decided below */
+            work[2 * c + pass] = (uint32_t)id;
         }
-        /* entries of the rescanned band */
-        if (has) {
-            const uint32_t st = k.bs[id];
-            const bool neg = id >= NB;
-            for (int t = 0; t < nc; t++) {
-                const int j = jl + 16 * t;
-                if (j <= s) {
-                    const int filt = v0 + j;
-                    if (!(neg && filt == 0)) k.T[filt + 256] = lead_entry(st, filt, k.lut);
+        k.rebuilds += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(need && jl == 0));
+    }
+    if (!any) return;
+    wave_lds_sync();
+    /* settle, one lane, in priority order; work[8..] collects the bands whose entries must be rewritten, work[31] = count */
+    if (lane == 0) {
+        int ids[8], n = 0;
+        for (int j = 0; j < 8; j++) {
+            const int id = (int)work[j];
+            bool dupl = id < 0;
+            for (int m = 0; m < n; m++) dupl |= ids[m] == id;
+            if (!dupl) ids[n++] = id;
+        }
+        for (int a2 = 1; a2 < n; a2++)                       /* insertion sort by priority */
+            for (int b2 = a2; b2 > 0 && band_prio(g, ids[b2]) < band_prio(g, ids[b2 - 1]); b2--) { const int t = ids[b2]; ids[b2] = ids[b2 - 1]; ids[b2 - 1] = t; }
+        int nw = 0;
+        for (int m = 0; m < n; m++) {
+            const int id = ids[m];
+            uint32_t st = k.bs[id] & 1023u;
+            const bool usable = band_usable_now(g, k.bs, id, st);
+            st = usable ? (st | 1024u) : (st & 511u);
+            k.bs[id] = st;
+            work[8 + nw++] = (uint32_t)id;
+            if (usable) {
+                const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
+                for (int e = 0; e < 2; e++) {
+                    const int o = band_of_bin(g, ends[e], id < g.NP);
+                    if (o >= 0 && band_prio(g, o) > band_prio(g, id)) {
+                        const uint32_t so = k.bs[o];
+                        if ((so & 1024u) && band_conflict(g, st, so, id, o)) { k.bs[o] = so & 511u; work[8 + nw++] = (uint32_t)o; }
+                    }
                 }
             }
         }
+        work[31] = (uint32_t)nw;
     }
-    if (__builtin_amdgcn_ballot_w64(zero_touched) != 0) {
-        /* the usability of BOTH zero bands may have changed: rewrite their entries (filt -s..s) */
-        for (int f2 = lane - s; f2 <= s; f2 += 64)
-            k.T[f2 + 256] = lead_entry(k.bs[f2 >= 0 ? 0 : NB], f2, k.lut);
-    }
+    wave_lds_sync();
+    const int nw = (int)work[31];
+    for (int m = 0; m < nw; m++) lead_write_band_entries(k, g, lane, (int)work[8 + m]);
     wave_lds_sync();
 }
 
@@ -705,27 +823,6 @@ __device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uin
     bin_out = vwin & 255;
     Hout = Hwin;
     Rout = Rwin;
-}
-
-/* After the exact pixel bumped `bin` (new frequency Hnew, rank R), does any near band that contains the bin have to
- * be rescanned?  Not if the bin still is strictly below the band's leader in (H, rank), or is the leader of a band
- * whose maximum was unique already: then neither the leader nor the uniqueness changed.  Lane 0 of the row looks at
- * the positive-v band, lane 1 at the negative-v band. */
-__device__ __forceinline__ bool lead_needs_rescan(const LeadCtx &k, int lane, int bin, bool rowactive, uint32_t Hnew, uint32_t R)
-{
-    const int s = k.s, q = s + 1, NB = 128 / q, lim = NB * q;
-    const int jl = lane & 15;
-    bool has = false; int id = 0, v = 0;
-    if (jl == 0) { has = rowactive && bin < lim; id = (int)((float)bin * k.rq); v = bin; }
-    else if (jl == 1) { has = rowactive && NB && (bin == 0 || 256 - bin < lim); id = NB + (bin ? (int)((float)(256 - bin) * k.rq) : 0); v = bin ? bin - 256 : 0; }
-    bool need = false;
-    if (has) {
-        const uint32_t st = k.bs[id];
-        const int L = (int)(st & 511u) - 256;
-        const u32x2 e = k.tbl[L & 255];
-        need = L == v ? !(st & 512u) : (Hnew > e.x || (Hnew == e.x && (R << 9) >= e.y));
-    }
-    return __builtin_amdgcn_ballot_w64(need) != 0;
 }
 
 /* The speculative run of one channel lane over the pixels [pos, end) of the chunk.  On entry st describes pixel pos-1,
@@ -851,7 +948,8 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
     lds_uint4 *const R = k.crec;
     lds_uint2 *const OUT = k.out;
     lds_u32 *const LUT = k.lut;
-    const int TB = (int)(uint32_t)(uintptr_t)(k.T + 256);
+    const int TB = (int)(uint32_t)(uintptr_t)(k.T + 256);   /* filter none: of the P table; the N table sits 4 KB behind */
+    const LeadGeo geo = lead_geo(k.s, MODE == 0, k.rq);
     const bool chainlane = active && jl == 0;
 
     /* result ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
@@ -893,7 +991,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             const int e0 = pl_sext16((int)(p < 2 ? (e.x >> (16 * p)) : (e.y >> (16 * (p - 2)))));
             const int orig = (o >> (8 * cc)) & 255, above = (a >> (8 * cc)) & 255, diag = (d >> (8 * cc)) & 255;
             const uint32_t trf = (alpha0 && (uint32_t)cc == bpp - 1u) ? 1u : 0u;
-            const int e0tb = e0 * 8 + TB;
+            const int e0tb = e0 * 8 + TB + ((MODE == 0 && orig >= 128) ? PL_LT_N * 8 : 0);
             if (MODE == 0 || MODE == 2) {
                 const int pred = MODE == 2 ? above : 0;
                 const int osym = pl_sext8(orig - pred);
@@ -943,20 +1041,26 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             const unsigned long long tf1 = __builtin_readcyclecounter();
             cyc_fast += tf1 - tf0;
             if (__builtin_expect(!anybad, 1)) break;
-            /* ---- the first pixel whose reconstruction left 0..255 is among the last 16 records: redo it exactly ---- */
+            /* ---- the first pixel whose reconstruction left 0..255 is among the last records: redo it exactly ---- */
             wave_lds_sync();
-            const int w0 = cur - 16 + jl;
-            const bool flag = active && w0 >= pos && (OUT[(max(w0, 0) + 2) * 4 + c].x > 2047u);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
-            const uint32_t m16 = (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
-            const int ix = cur - 16 + (int)__builtin_ctz(m16);
+            /* (a record trails its lookup by one pixel, so the window behind a 16-pixel burst is 17 wide: look at 32) */
+            int ix;
+            {
+                const int w0 = cur - 32 + jl, w1 = cur - 16 + jl;
+                const bool f0 = active && w0 >= pos && (OUT[(max(w0, 0) + 2) * 4 + c].x > 2047u);
+                const bool f1 = active && w1 >= pos && (OUT[(max(w1, 0) + 2) * 4 + c].x > 2047u);
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
+                const uint32_t a16 = (uint32_t)((m0 | (m0 >> 16) | (m0 >> 32) | (m0 >> 48)) & 0xffffull);
+                const uint32_t b16 = (uint32_t)((m1 | (m1 >> 16) | (m1 >> 32) | (m1 >> 48)) & 0xffffull);
+                ix = a16 ? cur - 32 + (int)__builtin_ctz(a16) : cur - 16 + (int)__builtin_ctz(b16);
+            }
             flush(flushed, ix);
             wave_lds_sync();
             /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
-            const uint32_t le1 = LUT[((((int)OUT[(ix + 1) * 4 + c].y - TB) >> 3) + 256) & 511];
-            const uint32_t le2 = LUT[((((int)OUT[(ix + 0) * 4 + c].y - TB) >> 3) + 256) & 511];
+            const uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 1) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
+            const uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 0) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
             const int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
-            int back, diff, bin; uint32_t Hw, Rw;
+            int back, diff, bin; uint32_t Hw, Rw; (void)Hw; (void)Rw;
             lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
                                    (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
                                    (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
@@ -965,7 +1069,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             wave_lds_sync();
             const unsigned long long tf2 = __builtin_readcyclecounter();
             cyc_exact += tf2 - tf1;
-            if (lead_needs_rescan(k, lane, bin, active, Hw + 1u, Rw)) lead_rescan(k, lane, bin, active);
+            lead_rescan(k, geo, lane, bin, active, k.work);
             /* resume behind it */
             if (chainlane) {
                 const uint32_t le0 = LUT[(diff + 256) & 511];
@@ -990,7 +1094,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 #pragma unroll
             for (uint32_t cc = 0; cc < 4; cc++) {
                 const u32x2 r = OUT[(lane + 2) * 4 + cc];
-                if (cc < bpp) w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(((int)r.y - TB) >> 3) << 8);
+                if (cc < bpp) w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(__builtin_amdgcn_sbfe((int)r.y - TB, 0, 12) >> 3) << 8);
             }
             ((__attribute__((address_space(1))) u32x4 *)k.cand)[x0 + lane] = (u32x4){ w[0], w[1], w[2], w[3] };
         }
@@ -1090,8 +1194,9 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_FLAGS (PL_SM_COSTS + 64)
 #define PL_SM_UNION (PL_SM_FLAGS + 64)
 #define PL_SM_LEGACY_BYTES (PL_CHUNK * 4 * (2 + 4) * 16)
-#define PL_SM_L_BS (PL_NFILT * PL_LT_N * 8)
-#define PL_SM_L_REC (PL_SM_L_BS + PL_NFILT * 256 * 4)
+#define PL_SM_L_BS ((PL_NFILT + 1) * PL_LT_N * 8)             /* six decision tables: filter none has two */
+#define PL_SM_L_WORK (PL_SM_L_BS + PL_NFILT * 512 * 4)
+#define PL_SM_L_REC (PL_SM_L_WORK + PL_NFILT * 32 * 4)
 #define PL_SM_L_REC_WAVE (PL_LCHUNK * 4 * 16)                 /* per chain; the paeth chain takes two */
 #define PL_SM_L_OUT (PL_SM_L_REC + (PL_NFILT + 1) * PL_SM_L_REC_WAVE)
 #define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2) * 4 * 8)
@@ -1152,7 +1257,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             /* chain phase.  Band-leader chains (round 2): five waves, one per candidate filter -- their fast path has
              * no DPP, and plain VALU/LDS waves sharing a SIMD do not slow each other (profiles/r01_ubench_simd_sharing.txt).
              * Rows that do not meet its preconditions take the round-1 chains below. */
-            const bool lead = prm.engine_mode != 1 && s + 1 <= 128 && !wrap && big_lead == 0;
+            const bool lead = (prm.engine_mode & 15) != 1 && s + 1 <= 128 && !wrap && big_lead == 0;
             const int lead_f = wave == 0 ? 2 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 0)));   /* up | sub | average | paeth | none */
             const bool paired = s + 1 <= 48;
             if (lead) {
@@ -1162,15 +1267,16 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 k.err0 = j.err0;
                 k.cand = j.cand + (size_t)lead_f * W;
                 k.tbl = (lds_uint2 *)&tbl[lead_f][0];
-                k.T = (lds_uint2 *)(ltab + lead_f * PL_LT_N);
-                k.bs = (lds_u32 *)(lbs + lead_f * 256);
+                k.T = (lds_uint2 *)(ltab + (lead_f ? lead_f + 1 : 0) * PL_LT_N);   /* none: tables 0 (P pixels) and 1 (N pixels) */
+                k.bs = (lds_u32 *)(lbs + lead_f * 512);
+                k.work = (lds_u32 *)(smem + PL_SM_UNION + PL_SM_L_WORK) + lead_f * 32;
                 k.crec = (lds_uint4 *)(lrec + lead_f * PL_SM_L_REC_WAVE);   /* none, sub, up, average, paeth (two slots) */
                 k.out = (lds_uint2 *)(lout + lead_f * (PL_SM_L_OUT_WAVE / 8));
                 k.lut = (lds_u32 *)&split_lut[0];
                 k.W = W; k.bpp = bpp; k.s = s; k.rq = recip_up(s + 1);
                 k.slow = 0; k.rebuilds = 0;
                 const unsigned long long t0 = __builtin_readcyclecounter();
-                lead_build_table(k, lane);
+                lead_build_table(k, lead_geo(s, lead_f == 0, k.rq), lane);
                 const unsigned long long tb1 = __builtin_readcyclecounter();
                 switch (lead_f) {
                 case 0: chain_lead_dispatch<0>(k, lane); break;
@@ -1218,7 +1324,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             /* post pass: one wave per candidate */
             const int pf = lead ? lead_f : (wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2))));
             const uint64_t cst = post_pass(j, y, bpp, pf, tbl[pf], adaptive, lane);
-            if (lane == 0) costs[pf] = cst;
+            if (lane == 0) costs[pf] = prm.engine_mode >= 16 ? (pf == prm.engine_mode - 16 ? 0ull : ~0ull) : cst;   /* debugging aid: force one candidate */
             __syncthreads();
             uint64_t best = ~0ull;
 #pragma unroll

@@ -15,6 +15,7 @@ Per pixel step k (pixel i+k), with E[j] = table entry pairs, Q[j] = record quads
 Usage: python tools/gen_lead_asm.py > pngloss_amd/csrc/pl_lead_asm.h
 """
 import os
+BURST = 4
 ABL = int(os.environ.get("PL_LEAD_ABLATE", "0"))   # timing experiments only (tools/lead_ablate.sh): >0 drops pieces, results become wrong
 E = [(200, 201), (202, 203), (204, 205), (206, 207)]
 A = [208, 209]
@@ -114,20 +115,26 @@ def step(mode, k):
 def gen(mode):
     rw = 2 if mode == "pae" else 1
     body = []
+    # outer loop: bursts of BURST iterations (4 pixels each); the validity test -- any byte so far outside 0..255 -- sits
+    # between the bursts: a scalar branch on a VALU-written condition costs ~190 cycles on gfx950 even when the v_cmp is 40
+    # instructions old (profiles/r02_lead_ablation.txt), so it is paid once per 16 pixels, not per pixel or per iteration
+    body.append("2:")
+    body.append("s_min_u32 %[inner], %[cnt], " + str(BURST))
+    body.append("s_sub_u32 %[cnt], %[cnt], %[inner]")
     body.append("1:")
-    # the validity test lags: vcc <- any byte so far outside 0..255, tested at the END of the iteration (a scalar branch
-    # right behind the v_cmp that feeds it costs ~100 cycles, profiles/r02_lead_ablation.txt)
-    if ABL < 2:
-        body.append(f"v_cmp_lt_u32_e32 vcc, %[c2047], {v(BADACC)}")
     for k in range(4):
         body += step(mode, k)
     body.append(f"v_add_u32_e32 {v(RPTR)}, {hex(256 * rw)}, {v(RPTR)}")
     body.append(f"v_add_u32_e32 {v(OPTR)}, 0x80, {v(OPTR)}")
-    body.append("s_sub_u32 %[cnt], %[cnt], 1")
+    body.append("s_sub_u32 %[inner], %[inner], 1")
+    body.append("s_cmp_lg_u32 %[inner], 0")
+    body.append("s_cbranch_scc1 1b")
+    if ABL < 2:
+        body.append(f"v_cmp_lt_u32_e32 vcc, %[c2047], {v(BADACC)}")
     if ABL < 1:
         body.append("s_cbranch_vccnz 99f")
     body.append("s_cmp_lg_u32 %[cnt], 0")
-    body.append("s_cbranch_scc1 1b")
+    body.append("s_cbranch_scc1 2b")
     body.append("99:")
     body.append("s_waitcnt lgkmcnt(0)")
     return body
@@ -142,7 +149,7 @@ def emit(mode, name):
         args += ", u32x4 &qx, u32x4 &qy"
     out.append(f"__device__ __forceinline__ uint32_t {name}({args})")
     out.append("{")
-    out.append("    uint32_t bad = 0;")
+    out.append("    uint32_t bad = 0; int inner;")
     out.append("    uint32_t e0 = st.e0; int h1 = st.h1, h2 = st.h2, lo8 = st.lo8, addr = st.addr, cnt = iters;")
     pre_in = {"nu": Q[0], "sub": Q[0] + 1, "avg": Q[0] + 1, "pae": Q2[0] + 3}[mode]
     lines = []
@@ -181,7 +188,7 @@ def emit(mode, name):
     out.append("    asm volatile(")
     for ln in lines:
         out.append(f'        "{ln}\\n"')
-    outs = ['[bad] "=&v"(bad)', '[cnt] "+s"(cnt)', '[e0] "+v"(e0)', '[h1] "+v"(h1)', '[h2] "+v"(h2)', '[addr] "+v"(addr)', '[lo8] "+v"(lo8)']
+    outs = ['[bad] "=&v"(bad)', '[cnt] "+s"(cnt)', '[inner] "=&s"(inner)', '[e0] "+v"(e0)', '[h1] "+v"(h1)', '[h2] "+v"(h2)', '[addr] "+v"(addr)', '[lo8] "+v"(lo8)']
     for j in range(4):
         outs += [f'[qa{j}] "+v"(qa{j})', f'[qb{j}] "+v"(qb{j})']
         if rw == 2:
@@ -196,7 +203,7 @@ def emit(mode, name):
     out.append("    " + " ".join([f"qa[{j}] = qa{j}; qb[{j}] = qb{j};" for j in range(4)]))
     if rw == 2:
         out.append("    " + " ".join([f"qx[{j}] = qc{j}; qy[{j}] = qd{j};" for j in range(4)]))
-    out.append("    iters = cnt;")
+    out.append("    iters = cnt + inner;")
     out.append("    return bad;")
     out.append("}")
     return "\n".join(out)
