@@ -473,6 +473,7 @@ __device__ __noinline__ void chain_dispatch(RowCtx &k, int lane, bool wrap)
 #define PL_LT_BADV 0x4000           /* 8*v marker of an unusable entry: reconstructs to a byte far outside 0..255 */
 #define PL_LCHUNK 64                /* pixels per vector phase */
 #define PL_LGROUP 16                /* pixels per speculative group */
+#define PL_LREC_N (PL_LCHUNK + 8)   /* the hand-scheduled loop runs up to 4 pixels past the chunk and fetches 2 ahead */
 #define PL_E0_LEAD_MAX 88           /* rows with larger incoming |error| take the round-1 chain */
 
 struct LeadCtx {
@@ -491,7 +492,7 @@ struct LeadCtx {
     float rq;
     uint32_t slow;            /* out: pixels redone exactly */
     uint32_t rebuilds;        /* out: band rescans */
-    unsigned long long cyc[4]; /* out (diagnostics): cycles in vector phases | fast groups | exact redo | rescan */
+    unsigned long long cyc[6]; /* out (diagnostics): cycles in vector phases | fast groups | exact redo | rescan */
 };
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -567,8 +568,10 @@ __device__ __forceinline__ u32x2 lead_entry_at(const LeadGeo &g, lds_u32 *bs, ld
     const u32x2 badent = (u32x2){ (uint32_t)PL_LT_BADV, 0u };
     int id; bool forced = false; int fv = 0;
     const int af = abs(filt);
-    if (g.none && tab == 0 && filt < 0) { forced = true; fv = 0; id = g.NP ? 0 : -1; }
-    else if (g.none && tab == 1 && filt >= 0) { forced = true; fv = -1; id = g.NP ? g.NP : -1; }
+    /* the one-value cases of filter none are kept for |filt| < 64 only (beyond that: exact path), so that a change of a
+     * zero band rewrites 64 entries, not 256 */
+    if (g.none && tab == 0 && filt < 0) { forced = true; fv = 0; id = (g.NP && filt >= -64) ? 0 : -1; }
+    else if (g.none && tab == 1 && filt >= 0) { forced = true; fv = -1; id = (g.NP && filt < 64) ? g.NP : -1; }
     else {
         const int t = geo_div(g, af);
         id = t < g.NP ? (filt < 0 ? g.NP + t : t) : -1;
@@ -597,8 +600,8 @@ __device__ __forceinline__ void lead_write_band_entries(const LeadCtx &k, const 
     for (int f = flo + lane; f <= fhi; f += 64) T[f + 256] = lead_entry_at(g, k.bs, k.lut, f, tab);
     if (g.none && (id == 0 || id == g.NP)) {
         /* the one-value cases served by the zero bands: P pixels with filt < 0, N pixels with filt >= 0 */
-        const int base = id == 0 ? -256 : 0;
-        for (int f = base + lane; f < base + 256; f += 64) T[f + 256] = lead_entry_at(g, k.bs, k.lut, f, tab);
+        const int f = (id == 0 ? -64 : 0) + lane;
+        T[f + 256] = lead_entry_at(g, k.bs, k.lut, f, tab);
     }
 }
 
@@ -668,11 +671,19 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
     for (int pass = 0; pass < 2; pass++) {
         const int id0 = rowactive ? band_of_bin(g, bin, pass == 1) : -1;
         bool need = false;
+        uint32_t level = 0;
         if (id0 >= 0) {
             const uint32_t st = k.bs[id0];
             const int lbin = ((int)(st & 511u) - 256) & 255;
             const u32x2 eb = H[bin], el = H[lbin];
-            need = !(st & 512u) || (lbin == bin ? false : (eb.x > el.x || (eb.x == el.x && eb.y >= el.y)));
+            level = (st >> 16) & 7u;
+            if (!(st & 512u)) {
+                /* a band that is not ok (tie at the top, or demoted by a conflict) is rescanned when touched -- with an
+                 * exponential back-off while rescans keep finding it unusable: bits 11..15 count the touches to skip */
+                const uint32_t cool = (st >> 11) & 31u;
+                need = cool == 0;
+                if (cool && jl == 0) k.bs[id0] = st - (1u << 11);
+            } else need = lbin == bin ? false : (eb.x > el.x || (eb.x == el.x && eb.y >= el.y));
         }
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
         any = true;
@@ -700,7 +711,7 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
         }
         dup = rowmax_u32(dup);
         if (need && jl == 0) {
-            k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 512u);      /* usable decided below */
+            k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 512u) | (level << 16);      /* usable decided below */
             work[2 * c + pass] = (uint32_t)id;
         }
         k.rebuilds += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(need && jl == 0));
@@ -709,25 +720,28 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
     wave_lds_sync();
     /* settle, one lane, in priority order; work[8..] collects the bands whose entries must be rewritten, work[31] = count */
     if (lane == 0) {
-        int ids[8], n = 0;
-        for (int j = 0; j < 8; j++) {
-            const int id = (int)work[j];
-            bool dupl = id < 0;
-            for (int m = 0; m < n; m++) dupl |= ids[m] == id;
-            if (!dupl) ids[n++] = id;
-        }
-        for (int a2 = 1; a2 < n; a2++)                       /* insertion sort by priority */
-            for (int b2 = a2; b2 > 0 && band_prio(g, ids[b2]) < band_prio(g, ids[b2 - 1]); b2--) { const int t = ids[b2]; ids[b2] = ids[b2 - 1]; ids[b2 - 1] = t; }
+        int w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = (int)work[j];
         int nw = 0;
-        for (int m = 0; m < n; m++) {
-            const int id = ids[m];
-            uint32_t st = k.bs[id] & 1023u;
+#pragma unroll 1
+        for (int it = 0; it < 8; it++) {
+            int id = -1, bp = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int pj = w[j] >= 0 ? band_prio(g, w[j]) : 0x7fffffff; if (pj < bp) { bp = pj; id = w[j]; } }
+            if (id < 0) break;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (w[j] == id) w[j] = -1;
+            const uint32_t sraw = k.bs[id];
+            uint32_t st = sraw & 1023u;
             const bool usable = band_usable_now(g, k.bs, id, st);
-            st = usable ? (st | 1024u) : (st & 511u);
+            const uint32_t level = min(((sraw >> 16) & 7u) + 1u, 5u);
+            st = usable ? (st | 1024u) : ((st & 511u) | (level << 16) | (((1u << level) - 1u) << 11));
             k.bs[id] = st;
             work[8 + nw++] = (uint32_t)id;
             if (usable) {
                 const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
+#pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int o = band_of_bin(g, ends[e], id < g.NP);
                     if (o >= 0 && band_prio(g, o) > band_prio(g, id)) {
@@ -825,45 +839,71 @@ __device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uin
     Rout = Rwin;
 }
 
-/* The speculative run of one channel lane over the pixels [pos, end) of the chunk.  On entry st describes pixel pos-1,
- * whose result record is in place.  Writes the result record {8*byte, 8*diff + TB} of every pixel it passes and returns
+/* The speculative run of one channel lane over the pixels [pos, end) of the chunk.  The chain state in front of pixel
+ * pos is re-derived from the result records of pixels pos-1 and pos-2 (ring slots, so this also works across chunks and
+ * behind an exactly redone pixel).  Writes the result record {8*byte, 8*diff + TB} of every pixel it passes and returns
  * how many pixels of the chunk now have one; `bad` tells that some byte it produced lies outside 0..255 (= a table
  * entry was unusable or a leader clamped away; everything behind the first such pixel is garbage, and memory-safe).
- * The hand-scheduled loop notices that with a lag of up to two iterations; the first bad pixel is then among the
- * last nine records.  The histogram is NOT touched here: bumps are applied 64 pixels at a time by the caller. */
+ * The hand-scheduled loop runs whole groups of four, up to 4 pixels past `end` (neutral records there), and notices a
+ * bad byte with a lag of up to 17 pixels.  The histogram is NOT touched here: the caller applies the bumps 64 pixels
+ * at a time. */
 template <int MODE, bool TRX>
-__device__ __forceinline__ int lead_fast_run(LeadState &st, lds_uint4 *R, lds_uint2 *OUT, const int c, const int TB,
+__device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u32 *LUT, const int c, const int TB,
                                              const int pos, const int end, bool &bad)
 {
     constexpr int RW = MODE == 4 ? 2 : 1;
-    LeadState t = st;
-    int ret = end;
+    LeadState t;
+    {
+        const u32x2 r1 = OUT[(pos + 1) * 4 + c], r2 = OUT[pos * 4 + c];
+        const uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)r1.y - TB, 0, 12) >> 3) + 256) & 511];
+        const uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)r2.y - TB, 0, 12) >> 3) + 256) & 511];
+        t.e0 = (r1.x & 0xffffu) | ((uint32_t)(pl_sext16((int)le1) * 8) << 16);
+        t.h1 = ((int)le1 >> 16) * 8;
+        t.h2 = ((int)le2 >> 16) * 8;
+        t.lo8 = 0;
+        t.addr = (int)(r1.y + r1.x);
+        t.mul = 1u;
+        t.bad = 0;
+    }
     bad = false;
     u32x4 ra0 = R[(pos * 4 + c) * RW], ra1 = RW == 2 ? R[(pos * 4 + c) * RW + 1] : ra0;
     u32x4 rb0 = R[((pos + 1) * 4 + c) * RW], rb1 = RW == 2 ? R[((pos + 1) * 4 + c) * RW + 1] : rb0;
+    if (!TRX) {
+        /* the hand-scheduled loop (pl_lead_asm.h) */
+        const int iters0 = (end - pos + 4) >> 2;              /* ceil((end - pos + 1) / 4): the step of pixel `end` writes the record of end-1 */
+        int iters = iters0;
+        const uint32_t rptr = (uint32_t)(uintptr_t)&R[(pos * 4 + c) * RW], optr = (uint32_t)(uintptr_t)&OUT[(pos + 1) * 4 + c];
+        uint32_t acc;
+        if (MODE == 0 || MODE == 2) acc = lead_asm_noneup(t, rptr, optr, iters, ra0, rb0);
+        else if (MODE == 1) acc = lead_asm_sub(t, rptr, optr, iters, ra0, rb0);
+        else if (MODE == 3) acc = lead_asm_avg(t, rptr, optr, iters, ra0, rb0);
+        else acc = lead_asm_paeth(t, rptr, optr, iters, ra0, rb0, ra1, rb1);
+        bad = __builtin_amdgcn_ballot_w64(acc > 2047u) != 0;
+        return min(end, pos + 4 * (iters0 - iters) - 1);
+    }
+    /* chunks that hold a fully transparent pixel: plain C++ steps */
     u32x4 rc0 = rb0, rc1 = rb1;
-    /* one pixel in C++ (run head and tail, chunks with transparent pixels): look up pixel i (record r0/r1), write the
-     * record of pixel i-1, fetch record i+2 into rn0/rn1; true = pixel i-1 is bad */
+    /* look up pixel i (record r0/r1), write the record of pixel i-1, fetch record i+2 into rn0/rn1; true = pixel i-1 is bad */
     auto step = [&](const int i, const u32x4 r0, const u32x4 r1, u32x4 &rn0, u32x4 &rn1) -> bool {
         const int v8p = pl_sext16((int)t.e0), rem8p = (int)t.e0 >> 16;
         int back8p = v8p - t.lo8;
-        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);   /* forced symbol: any mismatch -> out of range */
+        back8p = (int)__umul24((uint32_t)back8p, t.mul);   /* forced symbol: any mismatch -> out of range */
         int addr, lo8; uint32_t trf = 0;
         if (MODE == 0 || MODE == 2) {
             addr = (int)r0.x + t.h2 + rem8p;
             lo8 = (int)r0.y;
-            if (TRX) { trf = r0.w; addr = trf ? (int)r0.z : addr; lo8 = trf ? (int)r0.z - TB : lo8; }
+            trf = r0.w; addr = trf ? (int)r0.z : addr; lo8 = trf ? (int)r0.z - TB : lo8;
         } else if (MODE == 1) {
             const int osym8 = __builtin_amdgcn_sbfe((int)r0.x - back8p, 0, 11);
             addr = osym8 + ((int)r0.y + t.h2 + rem8p);
             lo8 = osym8 - (int)r0.x;
-            if (TRX) { trf = r0.z; const int f8 = __builtin_amdgcn_sbfe(-back8p, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+            trf = r0.z; const int f8 = __builtin_amdgcn_sbfe(-back8p, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8;
         } else if (MODE == 3) {
             const int pred = (int)__builtin_amdgcn_ubfe((uint32_t)(back8p + (int)r0.z), 4, 8);
             const int osym = __builtin_amdgcn_sbfe((int)r0.x - pred, 0, 8);
             addr = (osym << 3) + ((int)r0.y + t.h2 + rem8p);
             lo8 = (osym - (int)r0.x) << 3;
-            if (TRX) { trf = r0.w; const int f8 = pl_sext8(-pred) << 3; addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+            trf = r0.w; const int f8 = pl_sext8(-pred) << 3; addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8;
         } else {
             /* Paeth without compares: key = distance << 14 | priority << 12 | (8*(orig - candidate) + 2048); the minimum
              * key is the predictor the reference picks (left, then above, then upper-left on ties, optimize_state.c:600-613)
@@ -872,11 +912,11 @@ __device__ __forceinline__ int lead_fast_run(LeadState &st, lds_uint4 *R, lds_ui
             const uint32_t pg = sad_u32((uint32_t)back8p + r0.y, r0.z);
             const uint32_t kA = (pa << 14) | r1.x, kD = (pg << 14) | r1.y, kL = r0.w - (uint32_t)back8p;
             const uint32_t m3 = min(min(kL, kA), kD);
-            const int orig8 = TRX ? (int)(r1.z & 0x7fffffffu) : (int)r1.z;
+            const int orig8 = (int)(r1.z & 0x7fffffffu);
             const int osym8 = __builtin_amdgcn_sbfe((int)m3, 0, 11);
             addr = osym8 + ((int)r1.w + t.h2 + rem8p);
             lo8 = osym8 - orig8;
-            if (TRX) { trf = r1.z >> 31; const int f8 = __builtin_amdgcn_sbfe(osym8 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8; }
+            trf = r1.z >> 31; const int f8 = __builtin_amdgcn_sbfe(osym8 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8;
         }
         const u32x2 en = *(lds_uint2 *)(uintptr_t)(uint32_t)addr;
         OUT[(i + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
@@ -884,46 +924,15 @@ __device__ __forceinline__ int lead_fast_run(LeadState &st, lds_uint4 *R, lds_ui
         if (RW == 2) rn1 = R[((i + 2) * 4 + c) * RW + 1];
         const bool b = __builtin_amdgcn_ballot_w64((uint32_t)back8p > 2047u) != 0;
         t.h2 = t.h1; t.lo8 = lo8; t.addr = addr;
-        if (TRX) t.mul = trf ? 4096u : 1u;
+        t.mul = trf ? 4096u : 1u;
         t.h1 = (int)en.y; t.e0 = en.x;
         return b;
     };
-    int i = pos;
-    (void)step(i, ra0, ra1, rc0, rc1);                       /* rewrites the (good) record of pixel pos-1 */
-    i++;
-    ra0 = rb0; ra1 = rb1; rb0 = rc0; rb1 = rc1;              /* a = record of pixel i, b = i+1 */
-    if (!TRX && i + 4 <= end) {
-        /* the hand-scheduled loop (pl_lead_asm.h): whole groups of four pixels */
-        const int iters0 = (end - i) >> 2;
-        int iters = iters0;
-        const uint32_t rptr = (uint32_t)(uintptr_t)&R[(i * 4 + c) * RW], optr = (uint32_t)(uintptr_t)&OUT[(i + 1) * 4 + c];
-        uint32_t acc;
-        if (MODE == 0 || MODE == 2) acc = lead_asm_noneup(t, rptr, optr, iters, ra0, rb0);
-        else if (MODE == 1) acc = lead_asm_sub(t, rptr, optr, iters, ra0, rb0);
-        else if (MODE == 3) acc = lead_asm_avg(t, rptr, optr, iters, ra0, rb0);
-        else acc = lead_asm_paeth(t, rptr, optr, iters, ra0, rb0, ra1, rb1);
-        i += 4 * (iters0 - iters);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(acc > 2047u) != 0, 0)) { bad = true; ret = i; goto lead_run_done; }
-    }
-    for (; i < end; i++) {
-        if (__builtin_expect(step(i, ra0, ra1, rc0, rc1), 0)) { bad = true; ret = i; goto lead_run_done; }
+    for (int i = pos; i <= end; i++) {                        /* the step of pixel `end` (a neutral record) writes the record of end-1 */
+        if (__builtin_expect(step(i, ra0, ra1, rc0, rc1), 0)) { bad = true; return i; }
         ra0 = rb0; ra1 = rb1; rb0 = rc0; rb1 = rc1;
     }
-    {
-        /* the last pixel of the run: its record, and the state as if it had come from a committed pixel */
-        const int v8p = pl_sext16((int)t.e0);
-        int back8p = v8p - t.lo8;
-        if (TRX) back8p = (int)__umul24((uint32_t)back8p, t.mul);
-        OUT[(end + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
-        if (__builtin_amdgcn_ballot_w64((uint32_t)back8p > 2047u) != 0) bad = true;
-        t.e0 = ((uint32_t)back8p & 0xffffu) | (t.e0 & 0xffff0000u);
-        t.addr = t.addr - v8p + back8p;
-        t.lo8 = 0;
-        t.mul = 1u;
-    }
-lead_run_done:
-    st = t;
-    return ret;
+    return end;
 }
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -954,10 +963,9 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 
     /* result ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
     if (lane < 8) OUT[lane] = (u32x2){ 0u, (uint32_t)TB };
-    LeadState st;
-    st.e0 = 0u; st.h1 = 0; st.h2 = 0; st.lo8 = 0; st.addr = TB; st.mul = 1u; st.bad = 0;
     uint32_t slow = 0;
-    unsigned long long cyc_vec = 0, cyc_fast = 0, cyc_exact = 0, cyc_rescan = 0;
+    unsigned long long cyc_vec = 0, cyc_fast = 0, cyc_exact = 0, cyc_rescan = 0, cyc_clean = 0;
+    uint32_t px_clean = 0;
 
     /* prefetch of the first chunk's raw words (lane = pixel) */
     uint32_t no = 0, na = 0, nd = 0; u32x2 ne = (u32x2){ 0u, 0u };
@@ -985,29 +993,34 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
         /* ---- vector pre-phase: lane = pixel ---- */
         const bool alpha0 = TR && lane < n && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
         const bool chunk_tr = TR && __builtin_amdgcn_ballot_w64(alpha0) != 0;
+        auto write_records = [&](const int idx, const uint32_t po, const uint32_t pa, const uint32_t pd, const u32x2 pe, const bool palpha0) {
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const int p = pl_plane_of_channel(bpp, cc);
-            const int e0 = pl_sext16((int)(p < 2 ? (e.x >> (16 * p)) : (e.y >> (16 * (p - 2)))));
-            const int orig = (o >> (8 * cc)) & 255, above = (a >> (8 * cc)) & 255, diag = (d >> (8 * cc)) & 255;
-            const uint32_t trf = (alpha0 && (uint32_t)cc == bpp - 1u) ? 1u : 0u;
+            const int e0 = pl_sext16((int)(p < 2 ? (pe.x >> (16 * p)) : (pe.y >> (16 * (p - 2)))));
+            const int orig = (po >> (8 * cc)) & 255, above = (pa >> (8 * cc)) & 255, diag = (pd >> (8 * cc)) & 255;
+            const uint32_t trf = (palpha0 && (uint32_t)cc == bpp - 1u) ? 1u : 0u;
             const int e0tb = e0 * 8 + TB + ((MODE == 0 && orig >= 128) ? PL_LT_N * 8 : 0);
             if (MODE == 0 || MODE == 2) {
                 const int pred = MODE == 2 ? above : 0;
                 const int osym = pl_sext8(orig - pred);
-                R[lane * 4 + cc] = (u32x4){ (uint32_t)(osym * 8 + e0tb), (uint32_t)((osym - orig) * 8),
-                                            (uint32_t)(pl_sext8(-pred) * 8 + TB), trf };
+                R[idx * 4 + cc] = (u32x4){ (uint32_t)(osym * 8 + e0tb), (uint32_t)((osym - orig) * 8),
+                                           (uint32_t)(pl_sext8(-pred) * 8 + TB), trf };
             } else if (MODE == 1) {
-                R[lane * 4 + cc] = (u32x4){ (uint32_t)(orig * 8), (uint32_t)e0tb, trf, 0u };
+                R[idx * 4 + cc] = (u32x4){ (uint32_t)(orig * 8), (uint32_t)e0tb, trf, 0u };
             } else if (MODE == 3) {
-                R[lane * 4 + cc] = (u32x4){ (uint32_t)orig, (uint32_t)e0tb, (uint32_t)(above * 8), chunk_tr ? trf : (uint32_t)(-8 * orig) };
+                R[idx * 4 + cc] = (u32x4){ (uint32_t)orig, (uint32_t)e0tb, (uint32_t)(above * 8), chunk_tr ? trf : (uint32_t)(-8 * orig) };
             } else {
-                R[(lane * 4 + cc) * 2] = (u32x4){ (uint32_t)(diag * 8), (uint32_t)(above * 8), (uint32_t)(diag * 16),
-                                                  ((uint32_t)(abs(above - diag) * 8) << 14) + (uint32_t)(orig * 8 + 2048) };
-                R[(lane * 4 + cc) * 2 + 1] = (u32x4){ (1u << 12) + (uint32_t)((orig - above) * 8 + 2048), (2u << 12) + (uint32_t)((orig - diag) * 8 + 2048),
-                                                      (uint32_t)(orig * 8) | (trf << 31), (uint32_t)e0tb };
+                R[(idx * 4 + cc) * 2] = (u32x4){ (uint32_t)(diag * 8), (uint32_t)(above * 8), (uint32_t)(diag * 16),
+                                                 ((uint32_t)(abs(above - diag) * 8) << 14) + (uint32_t)(orig * 8 + 2048) };
+                R[(idx * 4 + cc) * 2 + 1] = (u32x4){ (1u << 12) + (uint32_t)((orig - above) * 8 + 2048), (2u << 12) + (uint32_t)((orig - diag) * 8 + 2048),
+                                                     (uint32_t)(orig * 8) | (trf << 31), (uint32_t)e0tb };
             }
         }
+        };
+        write_records(lane, o, a, d, e, alpha0);
+        /* the loop overshoots the chunk by up to 4 pixels and fetches 2 more: neutral records (a black pixel, no error) */
+        if (lane < PL_LREC_N - PL_LCHUNK) write_records(PL_LCHUNK + lane, 0u, 0u, 0u, (u32x2){ 0u, 0u }, false);
         wave_lds_sync();
         cyc_vec += __builtin_readcyclecounter() - tv0;
 
@@ -1033,13 +1046,14 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             const unsigned long long tf0 = __builtin_readcyclecounter();
             int cur = n; bool bad = false;
             if (chainlane) {
-                if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(st, R, OUT, c, TB, pos, n, bad);
-                else cur = lead_fast_run<MODE, false>(st, R, OUT, c, TB, pos, n, bad);
+                if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(R, OUT, LUT, c, TB, pos, n, bad);
+                else cur = lead_fast_run<MODE, false>(R, OUT, LUT, c, TB, pos, n, bad);
             }
             cur = __builtin_amdgcn_readfirstlane(cur);    /* lane 0 is channel 0's chain lane: always active */
             const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
             const unsigned long long tf1 = __builtin_readcyclecounter();
             cyc_fast += tf1 - tf0;
+            if (pos == 0 && !anybad) { cyc_clean += tf1 - tf0; px_clean += (uint32_t)n; }   /* diagnostics: undisturbed whole-chunk runs */
             if (__builtin_expect(!anybad, 1)) break;
             /* ---- the first pixel whose reconstruction left 0..255 is among the last records: redo it exactly ---- */
             wave_lds_sync();
@@ -1052,8 +1066,9 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
                 const uint32_t a16 = (uint32_t)((m0 | (m0 >> 16) | (m0 >> 32) | (m0 >> 48)) & 0xffffull);
                 const uint32_t b16 = (uint32_t)((m1 | (m1 >> 16) | (m1 >> 32) | (m1 >> 48)) & 0xffffull);
-                ix = a16 ? cur - 32 + (int)__builtin_ctz(a16) : cur - 16 + (int)__builtin_ctz(b16);
+                ix = a16 ? cur - 32 + (int)__builtin_ctz(a16) : (b16 ? cur - 16 + (int)__builtin_ctz(b16) : n);
             }
+            if (ix >= n) { if (cur >= n) break; pos = cur; continue; }   /* only the neutral pixels behind the chunk were out of range */
             flush(flushed, ix);
             wave_lds_sync();
             /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
@@ -1070,16 +1085,6 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             const unsigned long long tf2 = __builtin_readcyclecounter();
             cyc_exact += tf2 - tf1;
             lead_rescan(k, geo, lane, bin, active, k.work);
-            /* resume behind it */
-            if (chainlane) {
-                const uint32_t le0 = LUT[(diff + 256) & 511];
-                st.e0 = ((uint32_t)(back * 8) & 0xffffu) | ((uint32_t)(pl_sext16((int)le0) * 8) << 16);
-                st.lo8 = 0;
-                st.h1 = ((int)le0 >> 16) * 8;
-                st.h2 = ((int)le1 >> 16) * 8;
-                st.addr = diff * 8 + TB + back * 8;
-                st.mul = 1u;
-            }
             flushed = ix + 1;
             pos = ix + 1;
             cyc_rescan += __builtin_readcyclecounter() - tf2;
@@ -1109,6 +1114,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
     kref.slow = slow;
     kref.rebuilds = k.rebuilds;
     kref.cyc[0] = cyc_vec; kref.cyc[1] = cyc_fast; kref.cyc[2] = cyc_exact; kref.cyc[3] = cyc_rescan;
+    kref.cyc[4] = cyc_clean; kref.cyc[5] = px_clean;
 }
 
 template <int MODE>
@@ -1197,9 +1203,9 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_L_BS ((PL_NFILT + 1) * PL_LT_N * 8)             /* six decision tables: filter none has two */
 #define PL_SM_L_WORK (PL_SM_L_BS + PL_NFILT * 512 * 4)
 #define PL_SM_L_REC (PL_SM_L_WORK + PL_NFILT * 32 * 4)
-#define PL_SM_L_REC_WAVE (PL_LCHUNK * 4 * 16)                 /* per chain; the paeth chain takes two */
+#define PL_SM_L_REC_WAVE (PL_LREC_N * 4 * 16)                  /* per chain; the paeth chain takes two */
 #define PL_SM_L_OUT (PL_SM_L_REC + (PL_NFILT + 1) * PL_SM_L_REC_WAVE)
-#define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2) * 4 * 8)
+#define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2 + 8) * 4 * 8)
 #define PL_SM_LEAD_BYTES (PL_SM_L_OUT + PL_NFILT * PL_SM_L_OUT_WAVE)
 #define PL_SM_TOTAL (4096 + PL_SM_UNION + (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES))
 
@@ -1242,7 +1248,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0, lead_rows = 0, lead_rebuilds = 0;
-    unsigned long long lead_cyc[5] = { 0, 0, 0, 0, 0 };   /* diagnostics: vector | fast | exact | rescan | table build */
+    unsigned long long lead_cyc[7] = { 0, 0, 0, 0, 0, 0, 0 };   /* diagnostics: vector | fast | exact | rescan | table build */
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
     int status = 0;
     for (uint32_t y = 0; y < H && !status; y++) {
@@ -1291,6 +1297,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 lead_rows++;
                 for (int qq = 0; qq < 4; qq++) lead_cyc[qq] += k.cyc[qq];
                 lead_cyc[4] += tb1 - t0;
+                lead_cyc[5] += k.cyc[4]; lead_cyc[6] += k.cyc[5];
             } else
             /* round-1 chains: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
              * waves 1..3 run sub, average, paeth; wave 4 only takes part in the data-parallel passes */
@@ -1402,6 +1409,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     }
     if (lane == 0) {
         for (int qq = 0; qq < 5; qq++) j.result[32 + wave * 5 + qq] = (int32_t)(lead_cyc[qq] >> 10);
+        j.result[57 + wave] = (int32_t)(lead_cyc[6] ? lead_cyc[5] / lead_cyc[6] : 0);   /* cycles per pixel of the undisturbed whole-chunk runs */
     }
     if (lane == 0 && wave == 4) {
         j.result[24] = (int32_t)(chain_cycles >> 10);

@@ -15,7 +15,8 @@ Per pixel step k (pixel i+k), with E[j] = table entry pairs, Q[j] = record quads
 Usage: python tools/gen_lead_asm.py > pngloss_amd/csrc/pl_lead_asm.h
 """
 import os
-BURST = 4
+BURST = int(os.environ.get("PL_LEAD_BURST", "4"))
+PREF = os.environ.get("PL_LEAD_PREF", "shadow")   # where the record prefetch sits: "start" of the step or in its "shadow"
 ABL = int(os.environ.get("PL_LEAD_ABLATE", "0"))   # timing experiments only (tools/lead_ablate.sh): >0 drops pieces, results become wrong
 E = [(200, 201), (202, 203), (204, 205), (206, 207)]
 A = [208, 209]
@@ -48,12 +49,23 @@ def step(mode, k):
     q, qprev, qnext, qpre = Q[k], Q[(k + 3) % 4], Q[(k + 1) % 4], Q[(k + 2) % 4]
     rw = 2 if mode == "pae" else 1
     L = []
-    # the record of pixel i+k+2 first: issued while the wave waits for the previous lookup anyway, and -- being older
-    # than this step's lookup -- guaranteed complete behind the NEXT step's s_waitcnt, which is where it is first used
-    L.append(f"ds_read_b128 {vr(qpre, 4)}, {v(RPTR)} offset:{(k + 2) * 64 * rw}")
+    npre = 2 if mode == "pae" else 1
+    pref = [f"ds_read_b128 {vr(qpre, 4)}, {v(RPTR)} offset:{(k + 2) * 64 * rw}"]
     if mode == "pae":
-        L.append(f"ds_read_b128 {vr(Q2[(k + 2) % 4], 4)}, {v(RPTR)} offset:{(k + 2) * 64 * rw + 16}")
-    L.append("s_waitcnt lgkmcnt(%d)" % (3 if mode == "pae" else 2))
+        pref.append(f"ds_read_b128 {vr(Q2[(k + 2) % 4], 4)}, {v(RPTR)} offset:{(k + 2) * 64 * rw + 16}")
+    pre_add = {"nu": f"v_add_u32_e32 {v(PRE)}, {v(q)}, {v(e2[1])}", "sub": f"v_add_u32_e32 {v(PRE)}, {v(q + 1)}, {v(e2[1])}",
+               "avg": f"v_add_u32_e32 {v(PRE)}, {v(q + 1)}, {v(e2[1])}", "pae": f"v_add_u32_e32 {v(PRE)}, {v(Q2[k] + 3)}, {v(e2[1])}"}[mode]
+    if PREF == "start":
+        # the record of pixel i+k+2 first: issued while the wave waits for the previous lookup anyway, and -- being older
+        # than this step's lookup -- guaranteed complete behind the NEXT step's s_waitcnt, which is where it is first used
+        L += pref
+        L.append("s_waitcnt lgkmcnt(%d)" % (1 + npre))
+    else:
+        # record prefetch in the shadow (behind the lookup, so that it does not queue in front of it); the record of THIS pixel
+        # (fetched two steps ago) is complete once at most lookup, write and prefetch of the previous step are outstanding
+        L.append("s_waitcnt lgkmcnt(%d)" % (2 + npre))
+        L.append(pre_add)
+        L.append("s_waitcnt lgkmcnt(%d)" % (1 + npre))
     if mode == "nu":
         # record: x = 8*osym + 8*e0 + TB, y = 8*lo.  PRE = x + thr(i-2) was added in the previous step's shadow
         L.append(f"v_add_u32_sdwa {v(an)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
@@ -94,21 +106,28 @@ def step(mode, k):
         L.append(f"v_add_u32_e32 {v(an)}, {v(T0)}, {v(OSYM)}")
         L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
     # ---- shadow ----
-    L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
+    if ABL < 3:
+        L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
     L.append(f"v_sub_u32_sdwa {v(DTB)}, {v(ap)}, sext({v(ep[0])}) {SDWA_S1W0}")
     L.append(f"ds_write_b64 {v(OPTR)}, {vr(BACK, 2)} offset:{32 * k}")
+    if PREF != "start":
+        L += pref
     # thr of the next pixel = entry of the previous pixel .y ; pre-add it to the next record's address part
     if mode == "nu":
-        L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext)}, {v(ep[1])}")
+        if PREF == "start":
+            L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext)}, {v(ep[1])}")
     elif mode == "sub":
         L.append(f"v_sub_u32_e32 {v(LO)}, {v(OSYM)}, {v(q)}")
-        L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext + 1)}, {v(ep[1])}")
+        if PREF == "start":
+            L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext + 1)}, {v(ep[1])}")
     elif mode == "avg":
         L.append(f"v_lshl_add_u32 {v(LO)}, {v(OSYM)}, 3, {v(q + 3)}")
-        L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext + 1)}, {v(ep[1])}")
+        if PREF == "start":
+            L.append(f"v_add_u32_e32 {v(PRE)}, {v(qnext + 1)}, {v(ep[1])}")
     else:
         L.append(f"v_sub_u32_e32 {v(LO)}, {v(OSYM)}, {v(Q2[k] + 2)}")
-        L.append(f"v_add_u32_e32 {v(PRE)}, {v(Q2[(k + 1) % 4] + 3)}, {v(ep[1])}")
+        if PREF == "start":
+            L.append(f"v_add_u32_e32 {v(PRE)}, {v(Q2[(k + 1) % 4] + 3)}, {v(ep[1])}")
     return L
 
 

@@ -3,8 +3,9 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/ablate_build
-for n in 1 2; do
-  PL_LEAD_ABLATE=$n python tools/gen_lead_asm.py > tools/ablate_build/pl_lead_asm.h
+for n in 1 2 3 4; do
+  case $n in 1) export PL_LEAD_PREF=shadow;; 2) export PL_LEAD_PREF=start;; 3) export PL_LEAD_PREF=shadow PL_LEAD_BURST=8;; 4) export PL_LEAD_PREF=shadow PL_LEAD_BURST=2;; esac
+  python tools/gen_lead_asm.py > tools/ablate_build/pl_lead_asm.h
   mkdir -p tools/ablate_build/src$n
   cp pngloss_amd/csrc/*.hip pngloss_amd/csrc/*.h tools/ablate_build/src$n/
   cp tools/ablate_build/pl_lead_asm.h tools/ablate_build/src$n/pl_lead_asm.h
