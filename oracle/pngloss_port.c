@@ -414,24 +414,42 @@ static int band_overlaps(const band_geo *g, int id, int out[2])
     return n;
 }
 static inline int band_prio(const band_geo *g, int id) { return id >= g->NP ? 2 * (id - g->NP) + 1 : 2 * id; }
-static inline int band_conflict(const band_geo *g, const band_state *B, int a, int b)
+/* A disagreement about a shared bin only matters once the intruding leader bin could catch up with the band's own leader.
+ * PORT_LEAD_MARGIN = the most bumps one bin can receive between two validations (one chunk of 64 pixels x 4 channels):
+ * while H[intruder] + margin < H[leader] the intruder stays strictly below, whatever the fast path does in between. */
+#define PORT_LEAD_MARGIN 256u
+static inline int band_conflict(const band_geo *g, const band_state *B, const uint32_t *Hs, int a, int b)
 {
     const int la = B[a].L & 255, lb = B[b].L & 255;
-    return (band_has_bin(g, a, lb) && lb != la) || (band_has_bin(g, b, la) && la != lb);
+    if (band_has_bin(g, a, lb) && lb != la && !(Hs[lb] + PORT_LEAD_MARGIN < Hs[la])) return 1;
+    if (band_has_bin(g, b, la) && la != lb && !(Hs[la] + PORT_LEAD_MARGIN < Hs[lb])) return 1;
+    return 0;
 }
 /* after band id was rescanned: decide its usability against its betters, then demote the lesser bands it now conflicts with */
-static void band_settle(const band_geo *g, band_state *B, int id)
+static void band_settle(const band_geo *g, band_state *B, const uint32_t *Hs, int id)
 {
     int ov[2];
     const int n = band_overlaps(g, id, ov);
     int usable = B[id].ok;
     for (int j = 0; j < n && usable; j++)
-        if (band_prio(g, ov[j]) < band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, id, ov[j])) usable = 0;
+        if (band_prio(g, ov[j]) < band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, Hs, id, ov[j])) usable = 0;
     B[id].usable = usable;
     if (!usable) B[id].ok = 0;
     if (usable)
         for (int j = 0; j < n; j++)
-            if (band_prio(g, ov[j]) > band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, id, ov[j])) { B[ov[j]].usable = 0; B[ov[j]].ok = 0; }
+            if (band_prio(g, ov[j]) > band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, Hs, id, ov[j])) { B[ov[j]].usable = 0; B[ov[j]].ok = 0; }
+}
+/* every 64 pixels (the GPU: whenever it has applied the deferred histogram bumps): do all usable bands still keep their
+ * margins?  The lesser band of a pair that does not is demoted. */
+static void band_validate(const band_geo *g, band_state *B, const uint32_t *Hs)
+{
+    for (int id = 0; id < 2 * g->NP; id++) {
+        if (!B[id].usable) continue;
+        int ov[2];
+        const int n = band_overlaps(g, id, ov);
+        for (int j = 0; j < n; j++)
+            if (band_prio(g, ov[j]) < band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, Hs, id, ov[j])) { B[id].usable = 0; B[id].ok = 0; }
+    }
 }
 static void band_rebuild_for_bin(const uint32_t *Hs, const band_geo *g, band_state *B, int bin)
 {
@@ -449,7 +467,7 @@ static void band_rebuild_for_bin(const uint32_t *Hs, const band_geo *g, band_sta
         need[j] = !b->ok || (lbin == bin ? 0 : (hnew > Hs[lbin] || (hnew == Hs[lbin] && onew >= g->O[lbin])));
     }
     for (int j = 0; j < n; j++) if (need[j]) band_scan(Hs, g, ids[j], &B[ids[j]]);
-    for (int j = 0; j < n; j++) if (need[j]) band_settle(g, B, ids[j]);
+    for (int j = 0; j < n; j++) if (need[j]) band_settle(g, B, Hs, ids[j]);
 }
 /* the band a lookup with this filt lands in (-1: not tracked) and, for filter none's two one-value cases, the value it is forced to */
 static inline int band_of_lookup(const band_geo *g, int filt, int npixel, int *forced, int *fv)
@@ -483,12 +501,14 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
     g_lead_f = f;
     for (int id = 0; id < 2 * NP; id++) band_scan(Hs, &g, id, &B[id]);
     /* settle in priority order: positive t, negative t, positive t+1, ... */
-    for (int t = 0; t < NP; t++) { band_settle(&g, B, t); band_settle(&g, B, NP + t); }
+    for (int t = 0; t < NP; t++) { band_settle(&g, B, Hs, t); band_settle(&g, B, Hs, NP + t); }
     LSTAT(7);
     int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
+    int prev_slow = 0;
 
     for (uint32_t x = 0; x < W; x++) {
         int d16[4] = { 0, 0, 0, 0 };
+        if (x && (x & 63) == 0) band_validate(&g, B, Hs);
         const bool transparent = has_alpha && orig[(size_t)x * bpp + bpp - 1] == 0;
         int pred[4], osym[4], filt[4], lo[4], vfast[4], tr[4];
         int why = 0;
@@ -530,6 +550,8 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             vfast[c] = L;
         }
         LSTAT(0);
+        if (why && prev_slow) g_lead_stats[8 + 8 * g_lead_f + 2]++;   /* (slot 2 doubles as: slow pixel right behind a slow pixel) */
+        prev_slow = why != 0;
         if (!why) {
             LSTAT(1);
             for (uint32_t c = 0; c < bpp; c++) {

@@ -473,6 +473,7 @@ __device__ __noinline__ void chain_dispatch(RowCtx &k, int lane, bool wrap)
 #define PL_LT_BADV 0x4000           /* 8*v marker of an unusable entry: reconstructs to a byte far outside 0..255 */
 #define PL_LCHUNK 64                /* pixels per vector phase */
 #define PL_LGROUP 16                /* pixels per speculative group */
+#define PL_LWORK_N 96
 #define PL_LREC_N (PL_LCHUNK + 8)   /* the hand-scheduled loop runs up to 4 pixels past the chunk and fetches 2 ahead */
 #define PL_E0_LEAD_MAX 88           /* rows with larger incoming |error| take the round-1 chain */
 
@@ -483,7 +484,8 @@ struct LeadCtx {
     lds_uint2 *tbl;           /* this chain's {H, rank<<9}[PL_TBL_N] */
     lds_uint2 *T;             /* this chain's decision table [PL_LT_N] */
     lds_u32 *bs;              /* this chain's band states [512]: L+256 | ok<<9 | usable<<10 */
-    lds_u32 *work;            /* 32 words of scratch for the rescan */
+    lds_u32 *work;            /* PL_LWORK_N words: [0..7] rescanned ids, [8..39] bands to rewrite, [40] their count, [41] number of
+                                 watched pairs (255: too many, validate everything), [48..79] the pairs (lesser band, better band) */
     lds_uint4 *crec;          /* chain records of the chunk: [PL_LCHUNK][4][RW] */
     lds_uint2 *out;           /* results of the chunk: [(2 + PL_LCHUNK)][4] {8*byte (checked), 8*diff + TB} */
     lds_u32 *lut;             /* Sierra split table [diff+256] -> rem | thr<<16 */
@@ -541,13 +543,22 @@ __device__ __forceinline__ bool band_has_bin(const LeadGeo &g, int id, int bin)
 }
 __device__ __forceinline__ int band_prio(const LeadGeo &g, int id) { return id >= g.NP ? 2 * (id - g.NP) + 1 : 2 * id; }
 /* band states in LDS: L + 256 | ok << 9 | usable << 10   (ok: L is the unique (H, rank) maximum and the scan is fresh) */
-__device__ __forceinline__ bool band_conflict(const LeadGeo &g, uint32_t sa, uint32_t sb, int a, int b)
+/* Two bands disagree about a shared bin when the leader bin of one lies in the other and is not its leader bin.  That only
+ * matters once the intruder could catch up: PL_LEAD_MARGIN is the most bumps one bin can receive between two validations
+ * (the deferred bumps of one 64-pixel chunk x 4 channels), and while H[intruder] + margin < H[leader] the intruder stays
+ * strictly below whatever the fast path does in between (oracle: band_conflict / band_validate). */
+#define PL_LEAD_MARGIN 256u
+__device__ __forceinline__ bool band_conflict(const LeadGeo &g, lds_uint2 *H, uint32_t sa, uint32_t sb, int a, int b)
 {
     const int la = ((int)(sa & 511u) - 256) & 255, lb = ((int)(sb & 511u) - 256) & 255;
-    return (band_has_bin(g, a, lb) && lb != la) || (band_has_bin(g, b, la) && la != lb);
+    if (la == lb) return false;
+    const bool ia = band_has_bin(g, a, lb), ib = band_has_bin(g, b, la);
+    if (!ia && !ib) return false;
+    const uint32_t ha = H[la].x, hb = H[lb].x;
+    return (ia && !(hb + PL_LEAD_MARGIN < ha)) || (ib && !(ha + PL_LEAD_MARGIN < hb));
 }
 /* usable(id) given the CURRENT usable bits of its (at most two) neighbours of the other sign */
-__device__ __forceinline__ bool band_usable_now(const LeadGeo &g, lds_u32 *bs, int id, uint32_t st)
+__device__ __forceinline__ bool band_usable_now(const LeadGeo &g, lds_u32 *bs, lds_uint2 *H, int id, uint32_t st)
 {
     bool usable = (st >> 9) & 1u;
     const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
@@ -556,7 +567,7 @@ __device__ __forceinline__ bool band_usable_now(const LeadGeo &g, lds_u32 *bs, i
         const int o = band_of_bin(g, ends[e], id < g.NP);
         if (o >= 0 && band_prio(g, o) < band_prio(g, id)) {
             const uint32_t so = bs[o];
-            if ((so & 1024u) && band_conflict(g, st, so, id, o)) usable = false;
+            if ((so & 1024u) && band_conflict(g, H, st, so, id, o)) usable = false;
         }
     }
     return usable;
@@ -619,6 +630,41 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
     return (uint32_t)(L + 256) | (uniq ? 512u : 0u);
 }
 
+/* The pairs of usable bands that disagree about a shared bin and only coexist because of their margin are WATCHED: they are
+ * what lead_validate has to look at after every application of deferred bumps.  Collected after every change of band states. */
+__device__ __forceinline__ void lead_collect_pairs(const LeadCtx &k, const LeadGeo &g, int lane)
+{
+    const int nb = 2 * g.NP;
+    if (lane == 0) k.work[41] = 0u;
+    wave_lds_sync();
+    for (int base = 0; base < nb; base += 64) {
+        const int id = base + lane;
+        if (id < nb) {
+            const uint32_t st = k.bs[id];
+            if (st & 1024u) {
+                const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
+                int prev = -1;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int o = band_of_bin(g, ends[e], id < g.NP);
+                    if (o >= 0 && o != prev && band_prio(g, o) < band_prio(g, id)) {
+                        prev = o;
+                        const uint32_t so = k.bs[o];
+                        const int la = ((int)(st & 511u) - 256) & 255, lb = ((int)(so & 511u) - 256) & 255;
+                        if ((so & 1024u) && la != lb && (band_has_bin(g, id, lb) || band_has_bin(g, o, la))) {
+                            const uint32_t slot = __hip_atomic_fetch_add(&k.work[41], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (slot < 16u) { k.work[48 + 2 * slot] = (uint32_t)id; k.work[49 + 2 * slot] = (uint32_t)o; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    if (lane == 0 && k.work[41] > 16u) k.work[41] = 255u;
+    wave_lds_sync();
+}
+
 /* whole-table rebuild from the chain's histogram (row start / new strength) */
 __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo &g, int lane)
 {
@@ -634,7 +680,7 @@ __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo
         bool changed = false;
         for (int id = lane; id < nb; id += 64) {
             const uint32_t st = k.bs[id];
-            const bool u = band_usable_now(g, k.bs, id, st);
+            const bool u = band_usable_now(g, k.bs, k.tbl, id, st);
             if (u != (bool)((st >> 10) & 1u)) changed = true;
             k.bs[id] = (st & 1023u) | (u ? 1024u : 0u);
         }
@@ -652,6 +698,7 @@ __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo
         k.T[idx] = lead_entry_at(g, k.bs, k.lut, filt, tab);
     }
     wave_lds_sync();
+    lead_collect_pairs(k, g, lane);
 }
 
 /* After a slow pixel: row c of the wave (16 lanes) looks after the bin its channel just bumped.  Bands (one per sign)
@@ -664,27 +711,44 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
     lds_uint2 *const H = k.tbl;
     const int nc = (g.q + 15) >> 4;
     /* work[0..7] = ids of the bands that were rescanned (-1: none), slot 2c + sign */
+    /* both tests first (their LDS reads overlap); most slow pixels end here */
+    int idt[2]; bool needt[2]; uint32_t levt[2];
+    {
+        uint32_t stt[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            idt[pass] = rowactive ? band_of_bin(g, bin, pass == 1) : -1;
+            stt[pass] = idt[pass] >= 0 ? k.bs[idt[pass]] : 512u;
+        }
+        const u32x2 eb = H[bin];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const uint32_t st = stt[pass];
+            const int lbin = ((int)(st & 511u) - 256) & 255;
+            const u32x2 el = H[lbin];
+            levt[pass] = (st >> 16) & 7u;
+            bool need = false;
+            if (idt[pass] >= 0) {
+                if (!(st & 512u)) {
+                    /* a band that is not ok (tie at the top, or demoted by a conflict) is rescanned when touched -- with an
+                     * exponential back-off while rescans keep finding it unusable: bits 11..15 count the touches to skip */
+                    const uint32_t cool = (st >> 11) & 31u;
+                    need = cool == 0;
+                    if (cool && jl == 0) k.bs[idt[pass]] = st - (1u << 11);
+                } else need = lbin == bin ? false : (eb.x > el.x || (eb.x == el.x && eb.y >= el.y));
+            }
+            needt[pass] = need;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(needt[0] || needt[1]) == 0) return;
     if (lane < 8) work[lane] = 0xffffffffu;
     wave_lds_sync();
     bool any = false;
-#pragma unroll 1
+#pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const int id0 = rowactive ? band_of_bin(g, bin, pass == 1) : -1;
-        bool need = false;
-        uint32_t level = 0;
-        if (id0 >= 0) {
-            const uint32_t st = k.bs[id0];
-            const int lbin = ((int)(st & 511u) - 256) & 255;
-            const u32x2 eb = H[bin], el = H[lbin];
-            level = (st >> 16) & 7u;
-            if (!(st & 512u)) {
-                /* a band that is not ok (tie at the top, or demoted by a conflict) is rescanned when touched -- with an
-                 * exponential back-off while rescans keep finding it unusable: bits 11..15 count the touches to skip */
-                const uint32_t cool = (st >> 11) & 31u;
-                need = cool == 0;
-                if (cool && jl == 0) k.bs[id0] = st - (1u << 11);
-            } else need = lbin == bin ? false : (eb.x > el.x || (eb.x == el.x && eb.y >= el.y));
-        }
+        const int id0 = idt[pass];
+        const bool need = needt[pass];
+        const uint32_t level = levt[pass];
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
         any = true;
         const int id = need ? id0 : 0;
@@ -734,7 +798,7 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
             for (int j = 0; j < 8; j++) if (w[j] == id) w[j] = -1;
             const uint32_t sraw = k.bs[id];
             uint32_t st = sraw & 1023u;
-            const bool usable = band_usable_now(g, k.bs, id, st);
+            const bool usable = band_usable_now(g, k.bs, k.tbl, id, st);
             const uint32_t level = min(((sraw >> 16) & 7u) + 1u, 5u);
             st = usable ? (st | 1024u) : ((st & 511u) | (level << 16) | (((1u << level) - 1u) << 11));
             k.bs[id] = st;
@@ -746,17 +810,65 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
                     const int o = band_of_bin(g, ends[e], id < g.NP);
                     if (o >= 0 && band_prio(g, o) > band_prio(g, id)) {
                         const uint32_t so = k.bs[o];
-                        if ((so & 1024u) && band_conflict(g, st, so, id, o)) { k.bs[o] = so & 511u; work[8 + nw++] = (uint32_t)o; }
+                        if ((so & 1024u) && band_conflict(g, H, st, so, id, o)) { k.bs[o] = so & 511u; work[8 + nw++] = (uint32_t)o; }
                     }
                 }
             }
         }
-        work[31] = (uint32_t)nw;
+        work[40] = (uint32_t)nw;
     }
     wave_lds_sync();
-    const int nw = (int)work[31];
+    const int nw = (int)work[40];
     for (int m = 0; m < nw; m++) lead_write_band_entries(k, g, lane, (int)work[8 + m]);
     wave_lds_sync();
+    lead_collect_pairs(k, g, lane);
+}
+
+/* Whenever the deferred histogram bumps have been applied: do all usable bands still keep their margins?  The lesser band
+ * of a pair that does not is demoted and its table entries rewritten (oracle: band_validate). */
+__device__ __forceinline__ void lead_validate(const LeadCtx &k, const LeadGeo &g, int lane)
+{
+    const uint32_t np = k.work[41];
+    if (np == 0u) return;                                  /* nothing is watched: the common case */
+    if (np <= 16u) {
+        bool demote = false; int id = 0;
+        if ((uint32_t)lane < np) {
+            id = (int)k.work[48 + 2 * lane];
+            const int o = (int)k.work[49 + 2 * lane];
+            const uint32_t st = k.bs[id], so = k.bs[o];
+            demote = (st & 1024u) && (so & 1024u) && band_conflict(g, k.tbl, st, so, id, o);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(demote);
+        if (m == 0) return;
+        if (demote) k.bs[id] &= 511u;
+        wave_lds_sync();
+        while (m) {
+            const int j = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            lead_write_band_entries(k, g, lane, (int)k.work[48 + 2 * j]);
+        }
+        wave_lds_sync();
+        return;
+    }
+    const int nb = 2 * g.NP;
+    for (int base = 0; base < nb; base += 64) {
+        const int id = base + lane;
+        bool demote = false;
+        if (id < nb) {
+            const uint32_t st = k.bs[id];
+            if (st & 1024u) demote = !band_usable_now(g, k.bs, k.tbl, id, st);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(demote);
+        if (m == 0) continue;
+        if (demote) k.bs[id] &= 511u;
+        wave_lds_sync();
+        while (m) {
+            const int j = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            lead_write_band_entries(k, g, lane, base + j);
+        }
+        wave_lds_sync();
+    }
 }
 
 /* per-lane state of the speculative fast path (only lanes 0,16,32,48 -- one per channel -- run it) */
@@ -1071,26 +1183,57 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             if (ix >= n) { if (cur >= n) break; pos = cur; continue; }   /* only the neutral pixels behind the chunk were out of range */
             flush(flushed, ix);
             wave_lds_sync();
+            lead_validate(k, geo, lane);
             /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
-            const uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 1) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
-            const uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 0) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
-            const int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
-            int back, diff, bin; uint32_t Hw, Rw; (void)Hw; (void)Rw;
-            lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
-                                   (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
-                                   (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
-            slow++;
-            if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8), (uint32_t)(diff * 8 + TB) };
-            wave_lds_sync();
-            const unsigned long long tf2 = __builtin_readcyclecounter();
-            cyc_exact += tf2 - tf1;
-            lead_rescan(k, geo, lane, bin, active, k.work);
-            flushed = ix + 1;
-            pos = ix + 1;
-            cyc_rescan += __builtin_readcyclecounter() - tf2;
+            uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 1) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
+            uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 0) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
+            int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
+            const unsigned long long tf2a = __builtin_readcyclecounter();
+            cyc_exact += tf2a - tf1;
+            /* slow pixels come in clusters (more than half of them directly follow another one): after each exact pixel, PEEK
+             * at the next one -- would its table entry reconstruct a byte inside 0..255? -- and stay in exact mode while not.
+             * The peek is only a predictor: the fast run validates everything it does. */
+            for (;;) {
+                const unsigned long long te0 = __builtin_readcyclecounter();
+                int back, diff, bin; uint32_t Hw, Rw; (void)Hw; (void)Rw;
+                lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
+                slow++;
+                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8), (uint32_t)(diff * 8 + TB) };
+                const uint32_t le0 = LUT[(diff + 256) & 511];
+                wave_lds_sync();
+                const unsigned long long te1 = __builtin_readcyclecounter();
+                cyc_exact += te1 - te0;
+                lead_rescan(k, geo, lane, bin, active, k.work);
+                ix++;
+                bool again = false;
+                if (ix < n) {
+                    const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)o, ix), pa = (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
+                                   pd = (uint32_t)__builtin_amdgcn_readlane((int)d, ix);
+                    const uint32_t pex = (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix), pey = (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix);
+                    const int p = pl_plane_of_channel(bpp, c);
+                    const int e0 = pl_sext16((int)(p < 2 ? (pex >> (16 * p)) : (pey >> (16 * (p - 2)))));
+                    const int orig = (po >> (8 * c)) & 255, above = (pa >> (8 * c)) & 255, diag = (pd >> (8 * c)) & 255;
+                    const int pred = pl_predict<MODE>(above, diag, back);
+                    const int osym = pl_sext8(orig - pred);
+                    const int filt = osym + e0 + pl_sext16((int)le0) + ((int)le1 >> 16);
+                    const int fcl = med3_i32(filt, -256, 255);
+                    const u32x2 ent = k.T[fcl + 256 + ((MODE == 0 && orig >= 128) ? PL_LT_N : 0)];
+                    const int back8 = pl_sext16((int)ent.x) - (osym - orig) * 8;
+                    again = __builtin_amdgcn_ballot_w64(active && (fcl != filt || (uint32_t)back8 > 2047u)) != 0;
+                }
+                cyc_rescan += __builtin_readcyclecounter() - te1;
+                if (!again) break;
+                left = back; le2 = le1; le1 = le0;
+            }
+            flushed = ix;
+            pos = ix;
         }
         wave_lds_sync();
         flush(flushed, n);
+        wave_lds_sync();
+        lead_validate(k, geo, lane);
         wave_lds_sync();
         const unsigned long long tv1 = __builtin_readcyclecounter();
         /* ---- vector post-phase: candidate row (byte | diff16 << 8 per channel), lane = pixel ---- */
@@ -1202,7 +1345,7 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_LEGACY_BYTES (PL_CHUNK * 4 * (2 + 4) * 16)
 #define PL_SM_L_BS ((PL_NFILT + 1) * PL_LT_N * 8)             /* six decision tables: filter none has two */
 #define PL_SM_L_WORK (PL_SM_L_BS + PL_NFILT * 512 * 4)
-#define PL_SM_L_REC (PL_SM_L_WORK + PL_NFILT * 32 * 4)
+#define PL_SM_L_REC (PL_SM_L_WORK + PL_NFILT * PL_LWORK_N * 4)
 #define PL_SM_L_REC_WAVE (PL_LREC_N * 4 * 16)                  /* per chain; the paeth chain takes two */
 #define PL_SM_L_OUT (PL_SM_L_REC + (PL_NFILT + 1) * PL_SM_L_REC_WAVE)
 #define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2 + 8) * 4 * 8)
@@ -1275,7 +1418,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 k.tbl = (lds_uint2 *)&tbl[lead_f][0];
                 k.T = (lds_uint2 *)(ltab + (lead_f ? lead_f + 1 : 0) * PL_LT_N);   /* none: tables 0 (P pixels) and 1 (N pixels) */
                 k.bs = (lds_u32 *)(lbs + lead_f * 512);
-                k.work = (lds_u32 *)(smem + PL_SM_UNION + PL_SM_L_WORK) + lead_f * 32;
+                k.work = (lds_u32 *)(smem + PL_SM_UNION + PL_SM_L_WORK) + lead_f * PL_LWORK_N;
                 k.crec = (lds_uint4 *)(lrec + lead_f * PL_SM_L_REC_WAVE);   /* none, sub, up, average, paeth (two slots) */
                 k.out = (lds_uint2 *)(lout + lead_f * (PL_SM_L_OUT_WAVE / 8));
                 k.lut = (lds_u32 *)&split_lut[0];
