@@ -17,7 +17,7 @@
 
 #define PL_NFILT 5
 #define PL_NSYM 256
-#define PL_ENGINE_THREADS (PL_NFILT * 64)
+#define PL_ENGINE_THREADS 512   /* 8 waves: five run the candidate chains, all eight the row passes (two waves per SIMD keep 256 VGPRs each) */
 
 /* class flag bits produced by the classify kernel */
 #define PL_FLAG_GRAY 1u

@@ -1272,56 +1272,69 @@ __device__ __noinline__ void chain_lead_dispatch(LeadCtx &k, int lane)
  * libpng's heuristic filter (optimize_state.c:492-562) and entropy cost (optimize_state.c:326-342).
  * Returns the row cost of optimize_state_row (optimize_state.c:360) or UINT64_MAX if rejected (:319-324).
  * --------------------------------------------------------------------------------------------------------- */
-__device__ uint64_t post_pass(const PlJob &j, uint32_t y, uint32_t bpp, int f, const uint2 *T, bool adaptive, int lane)
+/* All five candidates at once, parallel over x with every thread of the workgroup: the neighbourhood of a pixel (original
+ * and optimised rows) is loaded once for the five candidates; per-wave partial sums go to the LDS accumulators
+ * acc[f] = { derr (u64 as two u32 adds: low, high), cost, hs[5] } (8 words per candidate, zeroed by the caller). */
+__device__ void post_pass_all(const PlJob &j, uint32_t y, uint32_t bpp, const uint2 (*tbl)[PL_TBL_N], bool adaptive, int tid, uint32_t *acc)
 {
     const uint32_t W = j.width;
     const uint32_t *row = j.img + (size_t)y * W;
     const uint32_t *nab = y ? row - W : nullptr;
-    const uint4 *cd = j.cand + (size_t)f * W;
-    uint64_t derr = 0;
-    uint32_t cost = 0;
-    uint32_t hs[PL_NFILT] = { 0, 0, 0, 0, 0 };
-    for (uint32_t x = lane; x < W; x += 64) {
-        const uint4 cw = cd[x];
-        const uint4 cl = x ? cd[x - 1] : make_uint4(0, 0, 0, 0);
+    uint64_t derr[PL_NFILT] = { 0, 0, 0, 0, 0 };
+    uint32_t cost[PL_NFILT] = { 0, 0, 0, 0, 0 };
+    uint32_t hs[PL_NFILT][PL_NFILT] = { { 0 } };
+    for (uint32_t x = tid; x < W; x += PL_ENGINE_THREADS) {
         const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
         const uint32_t na = nab ? nab[x] : 0u, nd = (nab && x) ? nab[x - 1] : 0u;
         const uint32_t oa = y ? j.old_above[x] : 0u, od = (y && x) ? j.old_above[x - 1] : 0u;
-        const uint32_t cws[4] = { cw.x, cw.y, cw.z, cw.w }, cls[4] = { cl.x, cl.y, cl.z, cl.w };
-        for (uint32_t c = 0; c < bpp; c++) {
-            const int sh = 8 * c;
-            const int back = cws[c] & 255, nl = x ? (int)(cls[c] & 255) : 0;
-            const int ov = (o >> sh) & 255, olv = (ol >> sh) & 255;
-            const int nav = (na >> sh) & 255, ndv = (nd >> sh) & 255, oav = (oa >> sh) & 255, odv = (od >> sh) & 255;
-            const int da = (oav - ov) - (nav - back);
-            const int dd = (odv - ov) - (ndv - back);
-            const int dl = (olv - ov) - (nl - back);
-            const uint32_t w = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
-            derr += (uint64_t)(w * (uint32_t)(da * da + dd * dd + dl * dl));
-            cost += 33u + (uint32_t)__clz((int)T[(back - pl_predict_rt(f, nav, ndv, nl)) & 255].x);
-            if (adaptive) {
-                const int preds[PL_NFILT] = { 0, nl, nav, (nav + nl) >> 1, pl_paeth(nav, ndv, nl) };
 #pragma unroll
-                for (int g = 0; g < PL_NFILT; g++) {
-                    const int b = (back - preds[g]) & 255;
-                    hs[g] += (uint32_t)(b < 128 ? b : 256 - b);
+        for (int f = 0; f < PL_NFILT; f++) {
+            const uint4 cw = j.cand[(size_t)f * W + x];
+            const uint4 cl = x ? j.cand[(size_t)f * W + x - 1] : make_uint4(0, 0, 0, 0);
+            const uint32_t cws[4] = { cw.x, cw.y, cw.z, cw.w }, cls[4] = { cl.x, cl.y, cl.z, cl.w };
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if ((uint32_t)c < bpp) {
+                    const int sh = 8 * c;
+                    const int back = cws[c] & 255, nl = x ? (int)(cls[c] & 255) : 0;
+                    const int ov = (o >> sh) & 255, olv = (ol >> sh) & 255;
+                    const int nav = (na >> sh) & 255, ndv = (nd >> sh) & 255, oav = (oa >> sh) & 255, odv = (od >> sh) & 255;
+                    const int da = (oav - ov) - (nav - back);
+                    const int dd = (odv - ov) - (ndv - back);
+                    const int dl = (olv - ov) - (nl - back);
+                    const uint32_t w = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
+                    derr[f] += (uint64_t)(w * (uint32_t)(da * da + dd * dd + dl * dl));
+                    const int pred = f == 0 ? 0 : (f == 1 ? nl : (f == 2 ? nav : (f == 3 ? (nav + nl) >> 1 : pl_paeth(nav, ndv, nl))));
+                    cost[f] += 33u + (uint32_t)__clz((int)tbl[f][(back - pred) & 255].x);
+                    if (adaptive) {
+                        const int preds[PL_NFILT] = { 0, nl, nav, (nav + nl) >> 1, pl_paeth(nav, ndv, nl) };
+#pragma unroll
+                        for (int g = 0; g < PL_NFILT; g++) {
+                            const int bb = (back - preds[g]) & 255;
+                            hs[f][g] += (uint32_t)(bb < 128 ? bb : 256 - bb);
+                        }
+                    }
                 }
             }
         }
     }
-    derr = wave_sum_u64(derr);
-    cost = wave_sum_u32(cost);
-    if (adaptive) {
-        int best = 0;
-        uint32_t bs = wave_sum_u32(hs[0]);
+    const int lane = tid & 63;
 #pragma unroll
-        for (int g = 1; g < PL_NFILT; g++) {
-            const uint32_t v = wave_sum_u32(hs[g]);
-            if (v < bs) { bs = v; best = g; }
+    for (int f = 0; f < PL_NFILT; f++) {
+        const uint64_t d = wave_sum_u64(derr[f]);
+        const uint32_t cs = wave_sum_u32(cost[f]);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&acc[8 * f], (unsigned long long)d);
+            atomicAdd(&acc[8 * f + 2], cs);
         }
-        if (best != f) return ~0ull;
+        if (adaptive) {
+#pragma unroll
+            for (int g = 0; g < PL_NFILT; g++) {
+                const uint32_t v = wave_sum_u32(hs[f][g]);
+                if (lane == 0) atomicAdd(&acc[8 * f + 3 + g], v);
+            }
+        }
     }
-    return derr / 128u + cost;
 }
 
 /* next-row Sierra terms of pixel sx of the winner, error plane via channel ch (optimize_state.c:446-465) */
@@ -1340,7 +1353,7 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_HC (PL_SM_TBL + PL_NFILT * PL_TBL_N * 8)
 #define PL_SM_LUT (PL_SM_HC + PL_NSYM * 4)
 #define PL_SM_COSTS (PL_SM_LUT + 512 * 4)
-#define PL_SM_FLAGS (PL_SM_COSTS + 64)
+#define PL_SM_FLAGS (PL_SM_COSTS + 64 + PL_NFILT * 8 * 4)
 #define PL_SM_UNION (PL_SM_FLAGS + 64)
 #define PL_SM_LEGACY_BYTES (PL_CHUNK * 4 * (2 + 4) * 16)
 #define PL_SM_L_BS ((PL_NFILT + 1) * PL_LT_N * 8)             /* six decision tables: filter none has two */
@@ -1362,6 +1375,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     uint32_t *const Hc = (uint32_t *)(smem + PL_SM_HC);                               /* committed symbol_frequency */
     uint32_t *const split_lut = (uint32_t *)(smem + PL_SM_LUT);                       /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255 */
     unsigned long long *const costs = (unsigned long long *)(smem + PL_SM_COSTS);
+    uint32_t *const pacc = (uint32_t *)(smem + PL_SM_COSTS + 64);                     /* post pass accumulators: 8 words per candidate */
     uint32_t &big_err = *(uint32_t *)(smem + PL_SM_FLAGS);                            /* some |incoming error| of the coming row exceeds 8000 (see WRAP) */
     uint32_t &big_lead = *(uint32_t *)(smem + PL_SM_FLAGS + 4);                       /* ... exceeds PL_E0_LEAD_MAX: the row takes the round-1 chain */
     uint32_t &uniq = *(uint32_t *)(smem + PL_SM_FLAGS + 8);
@@ -1391,7 +1405,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0, lead_rows = 0, lead_rebuilds = 0;
-    unsigned long long lead_cyc[7] = { 0, 0, 0, 0, 0, 0, 0 };   /* diagnostics: vector | fast | exact | rescan | table build */
+    unsigned long long lead_cyc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long cyc_post = 0, cyc_commit = 0;      /* diagnostics */   /* diagnostics: vector | fast | exact | rescan | table build */
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
     int status = 0;
     for (uint32_t y = 0; y < H && !status; y++) {
@@ -1401,7 +1416,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         const bool wrap = big_err != 0 || prm.force_careful;
         for (;;) {
             /* every candidate starts from the committed histogram (optimize_state_copy, pngloss_image.c:240) */
-            for (int b = lane; b < PL_NSYM; b += 64) tbl[wave][b].x = Hc[b];
+            for (int i = tid; i < PL_NFILT * PL_NSYM; i += PL_ENGINE_THREADS) tbl[i >> 8][i & 255].x = Hc[i & 255];
+            for (int i = tid; i < PL_NFILT * 8; i += PL_ENGINE_THREADS) pacc[i] = 0u;
             __syncthreads();
             /* chain phase.  Band-leader chains (round 2): five waves, one per candidate filter -- their fast path has
              * no DPP, and plain VALU/LDS waves sharing a SIMD do not slow each other (profiles/r01_ubench_simd_sharing.txt).
@@ -1410,6 +1426,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             const int lead_f = wave == 0 ? 2 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 0)));   /* up | sub | average | paeth | none */
             const bool paired = s + 1 <= 48;
             if (lead) {
+              if (wave < PL_NFILT) {
                 LeadCtx k;
                 k.row = j.img + (size_t)y * W;
                 k.nabove = y ? k.row - W : nullptr;
@@ -1441,12 +1458,13 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 for (int qq = 0; qq < 4; qq++) lead_cyc[qq] += k.cyc[qq];
                 lead_cyc[4] += tb1 - t0;
                 lead_cyc[5] += k.cyc[4]; lead_cyc[6] += k.cyc[5];
+              }
             } else
             /* round-1 chains: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
              * waves 1..3 run sub, average, paeth; wave 4 only takes part in the data-parallel passes */
             /* wide bands (s > 47) would need > 6 candidates per lane in the paired wave: there the five chains run as
              * five waves instead (wave 4 = 'up'), accepting that two of them share a SIMD */
-            if (wave < 4 || !paired) {
+            if (wave < PL_NFILT && (wave < 4 || !paired)) {
                 RowCtx k;
                 k.row = j.img + (size_t)y * W;
                 k.nabove = y ? k.row - W : nullptr;
@@ -1471,10 +1489,22 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 if (PL_SEGPROF) for (int q = 0; q < 4; q++) segs[q] += k.seg[q];
             }
             __syncthreads();   /* candidate rows (global, same CU) and histograms (LDS) complete and visible */
-            /* post pass: one wave per candidate */
-            const int pf = lead ? lead_f : (wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2))));
-            const uint64_t cst = post_pass(j, y, bpp, pf, tbl[pf], adaptive, lane);
-            if (lane == 0) costs[pf] = prm.engine_mode >= 16 ? (pf == prm.engine_mode - 16 ? 0ull : ~0ull) : cst;   /* debugging aid: force one candidate */
+            const unsigned long long tpp0 = __builtin_readcyclecounter();
+            /* post pass: all threads, all candidates (the accumulators were zeroed before the chain phase) */
+            post_pass_all(j, y, bpp, tbl, adaptive, tid, pacc);
+            cyc_post += __builtin_readcyclecounter() - tpp0;
+            __syncthreads();
+            if (tid < PL_NFILT) {
+                const uint32_t *a8 = pacc + 8 * tid;
+                uint64_t cst = (((uint64_t)a8[1] << 32) | a8[0]) / 128u + a8[2];
+                if (adaptive) {
+                    int bestg = 0;
+#pragma unroll
+                    for (int g = 1; g < PL_NFILT; g++) if (a8[3 + g] < a8[3 + bestg]) bestg = g;
+                    if (bestg != tid) cst = ~0ull;           /* libpng's heuristic would not have picked this filter (optimize_state.c:319-324) */
+                }
+                costs[tid] = prm.engine_mode >= 16 ? (tid == prm.engine_mode - 16 ? 0ull : ~0ull) : cst;   /* debugging aid: force one candidate */
+            }
             __syncthreads();
             uint64_t best = ~0ull;
 #pragma unroll
@@ -1491,6 +1521,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         if (status) break;
 
         /* ---- commit (pngloss_image.c:277-308), parallel over x ---- */
+        const unsigned long long tcm0 = __builtin_readcyclecounter();
         if (tid == 0) { big_err = 0; big_lead = 0; }
         __syncthreads();
         bool big = false, bigl = false;
@@ -1531,6 +1562,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         for (int b = tid; b < PL_NSYM; b += PL_ENGINE_THREADS) Hc[b] = tbl[winner][b].x;
         if (tid == 0 && j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);   /* PNG_FILTER_* flags */
         if (tid == 0) j.row_ids[y] = (uint8_t)winner;
+        cyc_commit += __builtin_readcyclecounter() - tcm0;
         __syncthreads();
     }
 
@@ -1550,10 +1582,11 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         j.result[12 + wave] = (int32_t)slow_px;
         if (PL_SEGPROF) for (int q = 0; q < 4; q++) j.result[16 + wave * 4 + q] = (int32_t)(segs[q] >> 10);
     }
-    if (lane == 0) {
+    if (lane == 0 && wave < PL_NFILT) {
         for (int qq = 0; qq < 5; qq++) j.result[32 + wave * 5 + qq] = (int32_t)(lead_cyc[qq] >> 10);
         j.result[57 + wave] = (int32_t)(lead_cyc[6] ? lead_cyc[5] / lead_cyc[6] : 0);   /* cycles per pixel of the undisturbed whole-chunk runs */
     }
+    if (lane == 0 && wave == 0) { j.result[62] = (int32_t)(cyc_post >> 10); j.result[63] = (int32_t)(cyc_commit >> 10); }
     if (lane == 0 && wave == 4) {
         j.result[24] = (int32_t)(chain_cycles >> 10);
         j.result[25] = (int32_t)slow_px;

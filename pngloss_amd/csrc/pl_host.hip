@@ -210,6 +210,8 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
                              r[32 + 5 * w], r[33 + 5 * w], r[34 + 5 * w], r[35 + 5 * w], r[36 + 5 * w]);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
             std::fprintf(stderr, "pngloss_hip:   cycles per pixel of undisturbed whole-chunk runs (up sub average paeth none): %d %d %d %d %d\n", r[57], r[58], r[59], r[60], r[61]);
+        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+            std::fprintf(stderr, "pngloss_hip:   wave 0 kcycles in the post pass %d, in the commit pass %d\n", r[62], r[63]);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[16])
             for (int w = 0; w < 4; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,
