@@ -8,6 +8,8 @@ Outputs (data only -- inputs and expected outputs, no reference source in any fo
                                  (inputs are regenerated from pngloss_amd.synth_rgba, so only outputs are stored)
   tests/golden/suite_small.npz   rose.png / david.png / tux.png of the reference's suite, decoded to RGBA8 (the same
                                  bytes rwpng_read_image24 yields), plus the expected outputs
+  tests/golden/suite_inputs.npz  ALL eleven suite images decoded to RGBA8 (inputs only; their expected outputs are the
+                                 reference-measured digests in digests.json) -- BASELINE.json configs[2] as one batch
   tests/golden/digests.json      FNV-1a-64 digests (SURVEY.md Appendix B basis) of inputs/outputs/filters for every
                                  BASELINE.json configuration, re-measured here against the real reference for all
                                  sizes up to 1920x1080, and carried over from SURVEY.md Appendix B (measured by the
@@ -66,11 +68,13 @@ def main():
 
     from PIL import Image
     suite = {}
+    suite_inputs = {}
     digests = {"basis": "0x%016x" % P.SURVEY_FNV_BASIS, "synthetic": [], "suite": []}
     for name in sorted(os.listdir("/root/reference/suite")):
         if not name.endswith(".png"):
             continue
         img = np.array(Image.open(os.path.join("/root/reference/suite", name)).convert("RGBA"))
+        suite_inputs[name[:-4]] = img
         out, f = run_ref(img, 19, 2)
         digests["suite"].append(dict(image=name[:-4], width=img.shape[1], height=img.shape[0], strength=19, bleed=2,
                                      **{"in": "%016x" % P.fnv1a64(img, P.SURVEY_FNV_BASIS)},
@@ -81,6 +85,7 @@ def main():
             suite[name[:-4] + "/out"] = out
             suite[name[:-4] + "/filters"] = f
     np.savez_compressed(os.path.join(HERE, "suite_small.npz"), **suite)
+    np.savez_compressed(os.path.join(HERE, "suite_inputs.npz"), **suite_inputs)
 
     measured = [(64, 48, m, 19, 2, 0) for m in range(6)] + [(512, 512, 0, 19, 2, 0), (512, 512, 1, 19, 2, 0),
                 (1920, 1080, 0, 19, 2, 0), (1920, 1080, 0, 19, 2, 1), (1920, 1080, 0, 19, 2, 255)]

@@ -4,6 +4,9 @@
   (c) the reference digests of the full-size BASELINE.json configurations, and size-independent properties.
 Bar: bit-exact pixels and filter IDs (integer/byte work, no tolerance)."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -223,14 +226,93 @@ def test_reference_digest_headline_4096(torch_cuda):
     assert int(np.abs(out.astype(np.int16) - img.astype(np.int16)).max()) <= 2 * 19 + 8
 
 
-def test_suite_class_digests_via_synthetic_stand_ins():
-    """BASELINE.json configs[2] (the 11 suite PNGs) cannot travel as files; their three small members are golden
-    fixtures above, and every byte-per-pixel class is covered at suite-like sizes against the oracle here."""
-    for (w, h, m) in [(512, 512, 4), (755, 503, 2), (800, 600, 5), (512, 480, 3)]:
-        img = P.synth_rgba(w, h, m, 1)
-        o1, f1 = U.run_port(img, 19, 2)
-        o2, f2 = P.optimize_with_rows(img, 19, 2)
-        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m)
+def test_suite_batch_all_eleven_images_match_reference_digests(torch_cuda):
+    """BASELINE.json configs[2]: the reference's eleven suite images (decoded RGBA8 inputs in tests/golden/suite_inputs.npz)
+    as ONE image-parallel batch through the device-resident API; every output and filter list must match the digests the
+    real reference produced (tests/golden/digests.json, /root/reference/suite/*.png at s=19 b=2)."""
+    torch = torch_cuda
+    inputs = np.load(os.path.join(U.GOLDEN, "suite_inputs.npz"))
+    digests = {e["image"]: e for e in U.load_digests()["suite"]}
+    names = sorted(inputs.files)
+    assert len(names) == 11 and set(names) == set(digests)
+    imgs = [inputs[n] for n in names]
+    for n, a in zip(names, imgs):
+        assert "%016x" % P.fnv1a64(a, P.SURVEY_FNV_BASIS) == digests[n]["in"], n
+    dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+    filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") for a in imgs]
+    ctx = P.HipContext()
+    res = ctx.run([(d.data_ptr(), f.data_ptr(), a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)], 19, 2,
+                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want_bpp = dict(barbara=1, david=1, dice=4, girl=3, lena=3, parrots=3, redbrush=4, rose=3, ssr=1, tenko=3, tux=4)   # SURVEY.md Appendix B
+    for n, d, f, r in zip(names, dev, filt, res):
+        assert r["status"] == 0 and r["bpp"] == want_bpp[n], (n, r)
+        assert "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS) == digests[n]["out"], n
+        assert "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS) == digests[n]["filters"], n
+    ctx.close()
+
+
+def test_strength_bleed_sweep_8192_matches_reference_digests(torch_cuda):
+    """BASELINE.json configs[4]: strength {0,20,40,85} x bleed {1,2,8} on the 8192x8192 frame, the twelve points run
+    concurrently (one workgroup = one CU each); outputs and filter lists against the reference-measured digests of
+    SURVEY.md Appendix B (tests/golden/digests.json)."""
+    torch = torch_cuda
+    dig = U.load_digests()["synthetic"]
+    base = P.synth_rgba(8192, 8192, 0, 0)
+    points = [(s, b) for s in (0, 20, 40, 85) for b in (1, 2, 8)]
+    ctxs = [P.HipContext() for _ in points]
+    streams = [torch.cuda.Stream() for _ in points]
+    dev = [torch.from_numpy(base).cuda() for _ in points]
+    filt = [torch.zeros(8192, dtype=torch.uint8, device="cuda") for _ in points]
+    torch.cuda.synchronize()
+    for c, st, d, f, (s, b) in zip(ctxs, streams, dev, filt, points):
+        c.enqueue([(d.data_ptr(), f.data_ptr(), 8192, 8192)], s, b, stream=st.cuda_stream)
+    for c in ctxs:
+        c.finish()
+    torch.cuda.synchronize()
+    for c, d, f, (s, b) in zip(ctxs, dev, filt, points):
+        e = [e for e in dig if e["width"] == 8192 and e["strength"] == s and (e["bleed"] == b or s == 0)][0]
+        assert "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS) == e["out"], (s, b)
+        assert "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS) == e["filters"], (s, b)
+        c.close()
+
+
+def test_round1_chains_still_match_the_oracle():
+    """The round-1 chain formulation stays in the kernel for rows the band-leader chains do not take (q > 128, large incoming
+    errors); PNGLOSS_HIP_ENGINE=legacy runs every row through it.  Checked in a fresh process (the hook is read per call)."""
+    code = ("import os, sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import pngloss_amd as P\n"
+            "from tests import util as U\n"
+            "for (w, h, m, s, b) in [(96, 40, 0, 19, 2), (130, 33, 5, 40, 1), (64, 48, 3, 85, 8), (200, 20, 1, 7, 3)]:\n"
+            "    img = P.synth_rgba(w, h, m, 2)\n"
+            "    o1, f1 = U.run_port(img, s, b)\n"
+            "    o2, f2 = P.optimize_with_rows(img, s, b)\n"
+            "    assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m, s, b)\n"
+            "print('legacy ok')\n") % U.ROOT
+    env = dict(os.environ, PNGLOSS_HIP_ENGINE="legacy")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "legacy ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_band_leader_chains_on_hostile_inputs():
+    """Inputs chosen against the band-leader chains: noise (every band in use, ties everywhere), values around 128 (filter
+    none's positive and negative bands compete for the same bins), saturated and fully transparent regions (static and
+    dynamic clamps, forced symbols), widths around the 64-pixel chunk, large strengths (few, wide bands)."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for (w, h) in [(63, 12), (64, 12), (65, 12), (257, 9), (300, 40)]:
+        a = rng.integers(118, 140, (h, w, 4), dtype=np.uint8); a[..., 3] = 255
+        cases.append((a, 19, 2))
+        b = rng.integers(0, 256, (h, w, 4), dtype=np.uint8); b[..., 3] = np.where(rng.random((h, w)) < 0.4, 0, b[..., 3])
+        cases.append((b, 19, 2))
+        c = np.full((h, w, 4), 255, np.uint8); c[:, ::7] = 0; c[h // 2:, :, :3] = rng.integers(230, 256, (h - h // 2, w, 3), dtype=np.uint8)
+        cases.append((c, 30, 1))
+    cases += [(P.synth_rgba(200, 30, m, 5), s, b) for m in range(6) for (s, b) in [(63, 2), (127, 1), (5, 8)]]
+    for i, (img, s, b) in enumerate(cases):
+        o1, f1 = U.run_port(img, s, b)
+        o2, f2 = P.optimize_with_rows(img, s, b)
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (i, img.shape, s, b)
 
 
 def test_careful_int16_wrap_variant_of_the_chain():

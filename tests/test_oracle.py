@@ -15,7 +15,7 @@ from tests import util as U
 
 
 @pytest.mark.parametrize("case", U.SYNTH_CASES, ids=U.case_key)
-@pytest.mark.parametrize("variant", [0, 1], ids=["plain", "gpu-shaped"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["plain", "gpu-shaped", "band-leader"])
 def test_port_matches_golden_synthetic(case, variant):
     w, h, m, s, b, fr, filt = case
     g = U.load_npz("synth_cases.npz")
@@ -53,7 +53,7 @@ def test_port_matches_reference_digest_1080p_frame():
 
 
 @pytest.mark.skipif(U.ref() is None, reason="oracle/_ref not built (no /root/reference on this box)")
-@pytest.mark.parametrize("variant", [0, 1], ids=["plain", "gpu-shaped"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["plain", "gpu-shaped", "band-leader"])
 def test_port_matches_real_reference_on_seeded_inputs(variant):
     for img, s, b, filt in U.seeded_cases(seed=11, n=36):
         o1, f1 = U.run_ref(img, s, b, filt)
