@@ -129,6 +129,19 @@ typedef struct {
 int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
                                     unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results);
 
+/* ---- Every GPU of the node.  The reference's command line walks its files one at a time (/root/reference/src/pngloss.c:
+ * 173-208); a node with several GPUs deals them out instead: one context per device, images split by size (longest first
+ * to the least loaded device), one host thread per context, no collective -- images are independent.
+ * devices: NULL/"" = $PNGLOSS_DEVICES if set, else every visible device; otherwise a comma separated list of device ordinals,
+ * which may repeat ("0,0" = two contexts sharing device 0: the split logic without a second GPU). */
+typedef struct pngloss_hip_multi pngloss_hip_multi;
+pngloss_hip_multi *pngloss_hip_multi_create(const char *devices);
+void pngloss_hip_multi_destroy(pngloss_hip_multi *multi);
+int pngloss_hip_multi_count(const pngloss_hip_multi *multi);
+/* owner[i] = index of the context image i goes to (deterministic LPT split; exported so that callers can plan and tests can
+ * check it against pngloss_amd/shard.py) */
+void pngloss_hip_multi_split(const pngloss_hip_host_image *images, size_t n, int parts, int *owner);
+
 /* As above, and additionally returns, per image, the FILTERED SCANLINES a PNG encoder deflates -- the first piece of
  * the PNG write side done on the device (replaces libpng's png_write_row filtering inside rwpng_write_image24,
  * /root/reference/src/rwpng.c:477-501,558-609): the colour type is re-detected from the optimised pixels, gray images
@@ -173,6 +186,13 @@ typedef struct {
 #define PNGLOSS_HIP_Z_STREAM_ONLY 1u
 
 size_t pngloss_hip_zlib_bound(uint32_t width, uint32_t height);
+
+/* pngloss_hip_optimize_batch_host / _emit / _zlib over every context of `multi`: scanlines and streams may be NULL
+ * (independently); results[], scanlines[], streams[] are indexed like images[].  Returns the worst status; a batch in which
+ * single images failed (results[i].status != 0) returns PNGLOSS_INTERNAL_ABORT with every other image done. */
+int pngloss_hip_multi_optimize_batch_host(pngloss_hip_multi *multi, const pngloss_hip_host_image *images, size_t n,
+                                          unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
+                                          pngloss_hip_scanlines *scanlines, pngloss_hip_zstream *streams);
 
 int pngloss_hip_optimize_batch_host_zlib(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
                                          unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,

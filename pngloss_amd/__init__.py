@@ -10,6 +10,8 @@ There is no CPU fallback in this package: if the HIP library is missing or no GP
 from .lib import (  # noqa: F401
     PNG_FILTER_FLAGS,
     HipContext,
+    HipMulti,
+    multi_split,
     build,
     hip_lib,
     optimize_with_rows,
@@ -21,6 +23,6 @@ from .lib import (  # noqa: F401
 from .synth import SURVEY_FNV_BASIS, fnv1a64, synth_rgba  # noqa: F401
 
 __all__ = [
-    "PNG_FILTER_FLAGS", "HipContext", "build", "hip_lib", "synth_lib", "optimize_with_rows", "optimize_with_stride",
+    "PNG_FILTER_FLAGS", "HipContext", "HipMulti", "multi_split", "build", "hip_lib", "synth_lib", "optimize_with_rows", "optimize_with_stride",
     "optimize_for_average_filter", "optimize_image", "synth_rgba", "fnv1a64", "SURVEY_FNV_BASIS",
 ]

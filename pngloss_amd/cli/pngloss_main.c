@@ -383,7 +383,7 @@ static void decode_ahead_wait(struct decode_ahead *d)
 }
 
 /* stages 2 and 3 of a window whose files are decoded already */
-static pngloss_error run_window(struct job *jobs, size_t n, const struct options *o, pngloss_hip_ctx **ctx, double decode_seconds)
+static pngloss_error run_window(struct job *jobs, size_t n, const struct options *o, pngloss_hip_multi **ctx, double decode_seconds)
 {
     const bool timing = getenv("PNGLOSS_TIMING") != NULL;
     const double t1 = now_s(), t0 = t1 - decode_seconds;
@@ -417,16 +417,18 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
         m = keep;
     }
     if (m) {
-        if (!*ctx) *ctx = pngloss_hip_create(-1);
+        /* every GPU of the node ($PNGLOSS_DEVICES restricts or repeats them): the files of the window are dealt out by size */
+        if (!*ctx) *ctx = pngloss_hip_multi_create(NULL);
         int rc = !*ctx ? PNGLOSS_HIP_ERROR
-               : o->gpu_deflate ? pngloss_hip_optimize_batch_host_zlib(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res, zs)
-                                : pngloss_hip_optimize_batch_host_emit(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res, lines);
+               : pngloss_hip_multi_optimize_batch_host(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res,
+                                                       o->gpu_deflate ? NULL : lines, o->gpu_deflate ? zs : NULL);
         for (size_t k = 0; k < m; k++) {
             jobs[who[k]].gpu = res[k];
             jobs[who[k]].color_type = o->gpu_deflate ? zs[k].color_type : lines[k].color_type;
             jobs[who[k]].zsize = zs[k].size;
-            if (rc != PNGLOSS_SUCCESS) {
-                /* unlike the reference (pngloss.c:266 ignores the return value) a failed optimisation is an error:
+            if (rc != PNGLOSS_SUCCESS && !(rc == PNGLOSS_INTERNAL_ABORT && res[k].status == 0)) {
+                /* (a batch in which single images failed reports PNGLOSS_INTERNAL_ABORT and leaves the others done.)
+                 * Unlike the reference (pngloss.c:266 ignores the return value) a failed optimisation is an error:
                  * there is no CPU path to fall back to, and writing an unoptimised file silently would be wrong */
                 say(&jobs[who[k]], "  error: GPU optimisation failed (%d)\n", rc);
                 jobs[who[k]].status = (pngloss_error)rc;
@@ -488,7 +490,7 @@ int main(int argc, char **argv)
         }
     }
 
-    pngloss_hip_ctx *ctx = NULL;
+    pngloss_hip_multi *ctx = NULL;
     pngloss_error latest = SUCCESS;
     unsigned errors = 0, skipped = 0;
     /* windows of up to WINDOW_FILES files: decoded (threads), optimised as ONE GPU batch, encoded (threads).  The next
@@ -520,7 +522,7 @@ int main(int argc, char **argv)
         }
         start += n;
     }
-    if (ctx) pngloss_hip_destroy(ctx);
+    if (ctx) pngloss_hip_multi_destroy(ctx);
     if (o.verbose) {
         const unsigned files = (unsigned)total;
         if (errors) fprintf(stderr, "There were errors compressing %d file%s out of a total of %d file%s.\n", errors, errors == 1 ? "" : "s", files, files == 1 ? "" : "s");

@@ -28,6 +28,7 @@
  */
 #include "pl_device.h"
 
+#include <atomic>
 #include <type_traits>
 
 #ifndef PL_SEGPROF
@@ -1614,11 +1615,15 @@ int pl_engine_occupancy(void)
 hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream)
 {
     if (!n) return hipSuccess;
-    static bool attr_set = false;   /* per process; the attribute belongs to the function */
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void *)pl_engine, hipFuncAttributeMaxDynamicSharedMemorySize, PL_SM_TOTAL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    {   /* the attribute belongs to the function ON THE CURRENT DEVICE: remembered per device (a node has up to 8) */
+        static std::atomic<unsigned> done{ 0 };
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (dev < 0 || dev >= 32 || !(done.load(std::memory_order_acquire) & (1u << dev))) {
+            const hipError_t e = hipFuncSetAttribute((const void *)pl_engine, hipFuncAttributeMaxDynamicSharedMemorySize, PL_SM_TOTAL);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(pl_engine, dim3((unsigned)n), dim3(PL_ENGINE_THREADS), PL_SM_TOTAL, stream, d_jobs, prm);
     return hipGetLastError();

@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -39,6 +41,14 @@ struct pngloss_hip_ctx {
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; /* total start, engine start, engine stop, total stop */
     double engine_ms = -1.0, total_ms = -1.0, deflate_ms = -1.0;
     bool pending = false;
+    /* host-pointer batches (pngloss_hip_optimize_batch_host*): a persistent device arena and a persistent pinned staging
+     * buffer of the same layout, both regrown on demand -- no hipMalloc/hipFree and no pageable copies per call */
+    char *d_arena = nullptr;
+    size_t arena_bytes = 0;
+    char *h_pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    double upload_ms = -1.0, download_ms = -1.0;
 };
 
 namespace {
@@ -341,6 +351,9 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_arena) (void)hipFree(ctx->d_arena);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
@@ -383,28 +396,97 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         rows_off[i] = total; total = align_up(total + (size_t)pitch * (want ? images[i].height : 0), 256);
         emits[i].pitch = pitch;
     }
-    char *arena = nullptr;
-    if (total) PL_CHECK(hipMalloc(reinterpret_cast<void **>(&arena), total));
+    /* persistent arena + pinned staging of the same layout; images are staged by a few host threads and go up as ONE
+     * asynchronous copy (pageable per-image copies were 0.33 s of a 1.6 s window of 256 720p files in round 1) */
+    if (total > ctx->arena_bytes) {
+        if (ctx->d_arena) PL_CHECK(hipFree(ctx->d_arena));
+        ctx->d_arena = nullptr; ctx->arena_bytes = 0;
+        const size_t want = align_up(total + total / 8, 1 << 20);
+        PL_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_arena), want));
+        ctx->arena_bytes = want;
+    }
+    if (total > ctx->pinned_bytes) {
+        if (ctx->h_pinned) PL_CHECK(hipHostFree(ctx->h_pinned));
+        ctx->h_pinned = nullptr; ctx->pinned_bytes = 0;
+        const size_t want = align_up(total + total / 8, 1 << 20);
+        PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    if (!ctx->copy_stream) PL_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    char *const arena = ctx->d_arena;
     int rc = PNGLOSS_SUCCESS;
     std::vector<pngloss_hip_image_desc> descs(n);
-    for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
+    const auto tu0 = std::chrono::steady_clock::now();
+    {
+        const unsigned nthreads = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t]() {
+                for (size_t i = t; i < n; i += nthreads) {
+                    const size_t px = (size_t)images[i].width * images[i].height;
+                    if (px) std::memcpy(ctx->h_pinned + img_off[i], images[i].rgba, px * 4);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    for (size_t i = 0; i < n; i++) {
         const size_t px = (size_t)images[i].width * images[i].height;
         descs[i] = pngloss_hip_image_desc{ px ? arena + img_off[i] : nullptr,
                                            (px && images[i].row_filters) ? arena + flt_off[i] : nullptr, images[i].width, images[i].height };
         emits[i].d_ids = emits[i].pitch ? arena + ids_off[i] : nullptr;
         emits[i].d_rows = emits[i].pitch ? arena + rows_off[i] : nullptr;
-        if (px && hipMemcpy(arena + img_off[i], images[i].rgba, px * 4, hipMemcpyHostToDevice) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+        /* asynchronous DMA from pinned memory, one per image (the areas between images are filled by the kernels) */
+        if (px && rc == PNGLOSS_SUCCESS &&
+            hipMemcpyAsync(arena + img_off[i], ctx->h_pinned + img_off[i], px * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     }
+    if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
+    std::vector<pngloss_hip_result> own_results;
+    if (!results) { own_results.resize(n ? n : 1); results = own_results.data(); }
     if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, nullptr, emits.data());
     if (rc == PNGLOSS_SUCCESS) rc = finish(ctx, results, n);
+    /* a row without an acceptable filter (device status 65, pngloss_image.c:268-271) fails THAT image only: the others of
+     * the batch are downloaded and the call reports PNGLOSS_INTERNAL_ABORT with the per-image status in results[] */
+    const bool some_aborted = rc == PNGLOSS_INTERNAL_ABORT;
+    if (some_aborted) rc = PNGLOSS_SUCCESS;
+    const auto td0 = std::chrono::steady_clock::now();
+    if (rc == PNGLOSS_SUCCESS) {
+        /* pixels + filter flags of every image come back as one copy into the pinned mirror, then fan out on host threads */
+        bool any_pixels = false;
+        for (size_t i = 0; i < n; i++) {
+            const bool stream_only = zs && zs[i].data && (zs[i].flags & PNGLOSS_HIP_Z_STREAM_ONLY);
+            if (!stream_only && (size_t)images[i].width * images[i].height && results[i].status == 0) any_pixels = true;
+        }
+        if (any_pixels) {
+            for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
+                const size_t px = (size_t)images[i].width * images[i].height;
+                const bool stream_only = zs && zs[i].data && (zs[i].flags & PNGLOSS_HIP_Z_STREAM_ONLY);
+                if (!px || stream_only || results[i].status != 0) continue;
+                /* the filter flags sit right behind the image in the arena: one copy takes both */
+                const size_t bytes = images[i].row_filters ? flt_off[i] + images[i].height - img_off[i] : px * 4;
+                if (hipMemcpyAsync(ctx->h_pinned + img_off[i], arena + img_off[i], bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            }
+            if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            if (rc == PNGLOSS_SUCCESS) {
+                const unsigned nthreads = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n));
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < nthreads; t++)
+                    pool.emplace_back([&, t]() {
+                        for (size_t i = t; i < n; i += nthreads) {
+                            const size_t px = (size_t)images[i].width * images[i].height;
+                            const bool stream_only = zs && zs[i].data && (zs[i].flags & PNGLOSS_HIP_Z_STREAM_ONLY);
+                            if (!px || stream_only || results[i].status != 0) continue;
+                            std::memcpy(images[i].rgba, ctx->h_pinned + img_off[i], px * 4);
+                            if (images[i].row_filters) std::memcpy(images[i].row_filters, ctx->h_pinned + flt_off[i], images[i].height);
+                        }
+                    });
+                for (auto &th : pool) th.join();
+            }
+        }
+    }
     for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
         const size_t px = (size_t)images[i].width * images[i].height;
-        if (!px) continue;
-        const bool stream_only = zs && zs[i].data && (zs[i].flags & PNGLOSS_HIP_Z_STREAM_ONLY);
-        if (stream_only) continue;
-        if (hipMemcpy(images[i].rgba, arena + img_off[i], px * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
-        if (images[i].row_filters &&
-            hipMemcpy(images[i].row_filters, arena + flt_off[i], images[i].height, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+        if (!px || results[i].status != 0) continue;
         if (emits[i].pitch && lines) {
             uint32_t fl = 0;
             if (hipMemcpy(&fl, ctx->h_jobs[i].out_flags, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
@@ -416,6 +498,7 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
                             hipMemcpyDeviceToHost) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
         }
     }
+    ctx->download_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
     if (zs && rc == PNGLOSS_SUCCESS) {
         /* the colour type decides the scanline length, so it is fetched before the deflate stage is laid out */
         const auto t0 = std::chrono::steady_clock::now();
@@ -423,7 +506,7 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         std::vector<size_t> who;
         for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
             zs[i].size = 0; zs[i].color_type = 6; zs[i].blocks[0] = zs[i].blocks[1] = zs[i].blocks[2] = 0;
-            if (!emits[i].pitch) continue;
+            if (!emits[i].pitch || results[i].status != 0) continue;
             uint32_t fl = 0;
             if (hipMemcpy(&fl, ctx->h_jobs[i].out_flags, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
             const bool g = fl & PL_FLAG_GRAY, o = fl & PL_FLAG_OPAQUE;
@@ -451,8 +534,8 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         }
         ctx->deflate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    if (arena) (void)hipFree(arena);
     if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
+    if (rc == PNGLOSS_SUCCESS && some_aborted) rc = PNGLOSS_INTERNAL_ABORT;
     return rc;
 }
 
@@ -460,6 +543,116 @@ int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host
                                     unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results)
 {
     return batch_host(ctx, images, n, quantization_strength, bleed_divider, results, nullptr);
+}
+
+/* ---- all the GPUs of the node (replaces the one-file-at-a-time loop of /root/reference/src/pngloss.c:173-208 for a whole
+ * node): one context per device, images dealt out by size (longest-processing-time first), one host thread per context,
+ * results back in input order.  No collective: images are independent. ---------------------------------------------- */
+struct pngloss_hip_multi {
+    std::vector<pngloss_hip_ctx *> ctx;
+};
+
+void pngloss_hip_multi_split(const pngloss_hip_host_image *images, size_t n, int parts, int *owner)
+{
+    /* LPT greedy, deterministic: items by descending pixel count (ties: lower index first), each to the least loaded part
+     * (ties: lower part) -- the same rule as pngloss_amd/shard.py:lpt_partition */
+    if (parts < 1) parts = 1;
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        return (uint64_t)images[a].width * images[a].height > (uint64_t)images[b].width * images[b].height;
+    });
+    std::vector<uint64_t> load((size_t)parts, 0);
+    for (size_t k = 0; k < n; k++) {
+        const size_t i = order[k];
+        int best = 0;
+        for (int p2 = 1; p2 < parts; p2++) if (load[(size_t)p2] < load[(size_t)best]) best = p2;
+        owner[i] = best;
+        load[(size_t)best] += (uint64_t)images[i].width * images[i].height;
+    }
+}
+
+pngloss_hip_multi *pngloss_hip_multi_create(const char *devices)
+{
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        std::fprintf(stderr, "pngloss_hip: no HIP device available\n");
+        return nullptr;
+    }
+    if (!devices || !*devices) devices = std::getenv("PNGLOSS_DEVICES");
+    std::vector<int> want;
+    if (devices && *devices) {
+        const char *p2 = devices;
+        while (*p2) {
+            char *end = nullptr;
+            const long d = std::strtol(p2, &end, 10);
+            if (end == p2 || d < 0 || d >= visible) {
+                std::fprintf(stderr, "pngloss_hip: bad device list \"%s\" (%d device(s) visible)\n", devices, visible);
+                return nullptr;
+            }
+            want.push_back((int)d);
+            p2 = end;
+            while (*p2 == ',' || *p2 == ' ') p2++;
+        }
+    } else {
+        for (int d = 0; d < visible; d++) want.push_back(d);
+    }
+    if (want.empty()) return nullptr;
+    pngloss_hip_multi *m = new (std::nothrow) pngloss_hip_multi;
+    if (!m) return nullptr;
+    for (int d : want) {
+        pngloss_hip_ctx *c = pngloss_hip_create(d);
+        if (!c) { pngloss_hip_multi_destroy(m); return nullptr; }
+        m->ctx.push_back(c);
+    }
+    return m;
+}
+
+void pngloss_hip_multi_destroy(pngloss_hip_multi *m)
+{
+    if (!m) return;
+    for (pngloss_hip_ctx *c : m->ctx) pngloss_hip_destroy(c);
+    delete m;
+}
+
+int pngloss_hip_multi_count(const pngloss_hip_multi *m) { return m ? (int)m->ctx.size() : 0; }
+
+int pngloss_hip_multi_optimize_batch_host(pngloss_hip_multi *m, const pngloss_hip_host_image *images, size_t n,
+                                          unsigned quantization_strength, long bleed_divider, pngloss_hip_result *results,
+                                          pngloss_hip_scanlines *scanlines, pngloss_hip_zstream *streams)
+{
+    if (!m || m->ctx.empty() || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
+    const int parts = (int)m->ctx.size();
+    std::vector<int> owner(n ? n : 1, 0);
+    pngloss_hip_multi_split(images, n, parts, owner.data());
+    std::vector<int> rcs((size_t)parts, PNGLOSS_SUCCESS);
+    std::vector<std::thread> pool;
+    for (int p2 = 0; p2 < parts; p2++)
+        pool.emplace_back([&, p2]() {
+            std::vector<size_t> mine;
+            for (size_t i = 0; i < n; i++) if (owner[i] == p2) mine.push_back(i);
+            if (mine.empty()) return;
+            std::vector<pngloss_hip_host_image> im(mine.size());
+            std::vector<pngloss_hip_result> rs(mine.size());
+            std::vector<pngloss_hip_scanlines> ln(scanlines ? mine.size() : 0);
+            std::vector<pngloss_hip_zstream> zz(streams ? mine.size() : 0);
+            for (size_t k = 0; k < mine.size(); k++) {
+                im[k] = images[mine[k]];
+                if (scanlines) ln[k] = scanlines[mine[k]];
+                if (streams) zz[k] = streams[mine[k]];
+            }
+            rcs[(size_t)p2] = batch_host(m->ctx[(size_t)p2], im.data(), im.size(), quantization_strength, bleed_divider, rs.data(),
+                                         scanlines ? ln.data() : nullptr, streams ? zz.data() : nullptr);
+            for (size_t k = 0; k < mine.size(); k++) {
+                if (results) results[mine[k]] = rs[k];
+                if (scanlines) scanlines[mine[k]] = ln[k];
+                if (streams) streams[mine[k]] = zz[k];
+            }
+        });
+    for (auto &th : pool) th.join();
+    int worst = PNGLOSS_SUCCESS;
+    for (int rc : rcs) if (rc != PNGLOSS_SUCCESS && (worst == PNGLOSS_SUCCESS || worst == PNGLOSS_INTERNAL_ABORT)) worst = rc;
+    return worst;
 }
 
 int pngloss_hip_optimize_batch_host_emit(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,

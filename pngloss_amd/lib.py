@@ -92,6 +92,8 @@ ABI_SYMBOLS = (
     "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit",
     "pngloss_hip_optimize_batch_host_zlib", "pngloss_hip_zlib_bound", "pngloss_hip_last_deflate_ms", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
     "pngloss_hip_last_histogram", "pngloss_hip_version",
+    "pngloss_hip_multi_create", "pngloss_hip_multi_destroy", "pngloss_hip_multi_count", "pngloss_hip_multi_split",
+    "pngloss_hip_multi_optimize_batch_host",
 )
 
 
@@ -132,6 +134,16 @@ def hip_lib():
             lib.pngloss_hip_optimize_batch_host.restype = C.c_int
             lib.pngloss_hip_optimize_batch_host_emit.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result), C.POINTER(Scanlines)]
             lib.pngloss_hip_optimize_batch_host_emit.restype = C.c_int
+            lib.pngloss_hip_multi_create.argtypes = [C.c_char_p]
+            lib.pngloss_hip_multi_create.restype = C.c_void_p
+            lib.pngloss_hip_multi_destroy.argtypes = [C.c_void_p]
+            lib.pngloss_hip_multi_destroy.restype = None
+            lib.pngloss_hip_multi_count.argtypes = [C.c_void_p]
+            lib.pngloss_hip_multi_count.restype = C.c_int
+            lib.pngloss_hip_multi_split.argtypes = [C.POINTER(HostImage), C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+            lib.pngloss_hip_multi_split.restype = None
+            lib.pngloss_hip_multi_optimize_batch_host.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result), C.POINTER(Scanlines), C.POINTER(ZStream)]
+            lib.pngloss_hip_multi_optimize_batch_host.restype = C.c_int
             lib.pngloss_hip_optimize_batch_host_zlib.argtypes = [C.c_void_p, C.POINTER(HostImage), C.c_size_t, C.c_uint, C.c_long, C.POINTER(Result), C.POINTER(ZStream)]
             lib.pngloss_hip_optimize_batch_host_zlib.restype = C.c_int
             lib.pngloss_hip_zlib_bound.argtypes = [C.c_uint32, C.c_uint32]
@@ -308,3 +320,51 @@ class HipContext:
         h = np.zeros(256, np.uint32)
         _check(self._lib.pngloss_hip_last_histogram(self._ctx, index, h.ctypes.data_as(C.c_void_p)), "histogram")
         return h
+
+
+def multi_split(shapes, parts):
+    """pngloss_hip_multi_split (the C host's LPT split) for a list of (width, height); returns owner indices.  No GPU needed."""
+    lib = hip_lib()
+    n = len(shapes)
+    imgs = (HostImage * max(n, 1))()
+    for i, (w, h) in enumerate(shapes):
+        imgs[i] = HostImage(None, None, w, h)
+    owner = (C.c_int * max(n, 1))()
+    lib.pngloss_hip_multi_split(imgs, n, parts, owner)
+    return list(owner[:n])
+
+
+class HipMulti:
+    """pngloss_hip_multi wrapper: host-memory batches over every GPU of the node (or the devices named, e.g. "0,0")."""
+
+    def __init__(self, devices=None):
+        self._lib = hip_lib()
+        self._m = self._lib.pngloss_hip_multi_create(devices.encode() if devices else None)
+        if not self._m:
+            raise RuntimeError("pngloss_hip_multi_create failed: no usable HIP device (there is no CPU fallback)")
+
+    @property
+    def count(self):
+        return self._lib.pngloss_hip_multi_count(self._m)
+
+    def close(self):
+        if self._m:
+            self._lib.pngloss_hip_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_host(self, arrays, strength=19, bleed=2, want_filters=True):
+        outs = [np.ascontiguousarray(a).copy() for a in arrays]
+        filts = [np.zeros(a.shape[0], np.uint8) if want_filters else None for a in outs]
+        n = len(outs)
+        imgs = (HostImage * max(n, 1))()
+        for i, (a, f) in enumerate(zip(outs, filts)):
+            imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
+        res = (Result * max(n, 1))()
+        _check(self._lib.pngloss_hip_multi_optimize_batch_host(self._m, imgs, n, strength, bleed, res, None, None), "multi_optimize_batch_host")
+        return outs, filts, [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols) for r in res[:n]]

@@ -315,6 +315,27 @@ def test_band_leader_chains_on_hostile_inputs():
         assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (i, img.shape, s, b)
 
 
+def test_multi_device_host_batch_two_contexts_on_one_device():
+    """The node-level C entry point (one context + host thread per device, LPT split, results in input order) with the device
+    list "0,0": two contexts sharing the one GPU of this box exercise the split, the threads and the scatter."""
+    specs = [(200, 150, 0), (64, 48, 2), (300, 20, 5), (1, 1, 1), (130, 90, 3), (96, 64, 4), (257, 33, 1)]
+    imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+    multi = P.HipMulti("0,0")
+    assert multi.count == 2
+    outs, filts, res = multi.run_host(imgs, 19, 2)
+    multi.close()
+    own = P.multi_split([(w, h) for (w, h, m) in specs], 2)
+    assert set(own) == {0, 1}
+    for a, o, f, r, sp in zip(imgs, outs, filts, res, specs):
+        o1, f1 = U.run_port(a, 19, 2)
+        assert r["status"] == 0 and np.array_equal(o, o1) and np.array_equal(f, f1), sp
+    # the same through one context, and with the environment variable instead of the argument
+    ctx = P.HipContext()
+    outs1, filts1, _ = ctx.run_host(imgs, 19, 2)
+    ctx.close()
+    assert all(np.array_equal(x, y) for x, y in zip(outs, outs1)) and all(np.array_equal(x, y) for x, y in zip(filts, filts1))
+
+
 def test_careful_int16_wrap_variant_of_the_chain():
     """Rows whose incoming Sierra error exceeds 8000 switch the chain to a variant with explicit int16 sign
     extensions (DESIGN.md 4.6).  Natural images never get there, so a test hook forces that variant for every row;

@@ -113,3 +113,23 @@ def test_lpt_partition_is_balanced_and_complete():
     assert S.contiguous_partition(256, 8)[3] == list(range(96, 128))
     assert S.contiguous_partition(5, 2) == [[0, 1, 2], [3, 4]]
     assert S.lpt_partition([5, 5, 5, 5], 2) == [[0, 2], [1, 3]]
+
+
+def test_c_host_split_equals_the_python_split():
+    """pngloss_hip_multi_split (the C host's deal of a batch over the GPUs of a node, replaces the sequential file loop of
+    /root/reference/src/pngloss.c:173-208) is the same deterministic LPT split as pngloss_amd.shard.lpt_partition."""
+    import pngloss_amd as P
+    from pngloss_amd import shard as S
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        n = int(rng.integers(0, 40))
+        shapes = [(int(rng.integers(1, 2000)), int(rng.integers(1, 2000))) for _ in range(n)]
+        if trial % 3 == 0 and n:
+            shapes = [shapes[0]] * n                    # equal sizes: ties broken by index and by part
+        for parts in (1, 2, 3, 8):
+            own = P.multi_split(shapes, parts)
+            want = [None] * n
+            for r, items in enumerate(S.lpt_partition([w * h for w, h in shapes], parts)):
+                for i in items:
+                    want[i] = r
+            assert own == want, (trial, parts)
