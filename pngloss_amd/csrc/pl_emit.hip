@@ -65,8 +65,12 @@ __global__ __launch_bounds__(kThreads) void pl_emit_rows(const PlJob *jobs)
     const uint32_t *row = j.img + (size_t)y * W;
     const uint32_t *up = y ? row - W : nullptr;
     const bool adaptive = y == 0 || j.emit_adaptive_all;
+    /* libpng (png_write_start_row / png_set_filter) drops the filters that have no neighbour to predict from: sub, average and
+     * paeth in 1-pixel-wide images, up, average and paeth in 1-pixel-high ones; a row asked to use one is written as "none" */
+    const uint32_t allowed = (W == 1 ? 0x05u : 0x1fu) & (j.height == 1 ? 0x03u : 0x1fu);
 
     int f = j.row_ids[y];
+    if (!((allowed >> f) & 1u)) f = 0;
     if (adaptive) {
         /* libpng's png_write_find_filter with all five filters: least sum of |signed residual|, first minimum wins */
         if (threadIdx.x < PL_NFILT) sums[threadIdx.x] = 0;
@@ -92,9 +96,9 @@ __global__ __launch_bounds__(kThreads) void pl_emit_rows(const PlJob *jobs)
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int best = 0;
+            int best = 0;                                   /* "none" is always allowed */
             for (int g = 1; g < PL_NFILT; g++)
-                if (sums[g] < sums[best]) best = g;
+                if (((allowed >> g) & 1u) && sums[g] < sums[best]) best = g;
             chosen = best;
         }
         __syncthreads();

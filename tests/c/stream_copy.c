@@ -47,9 +47,13 @@ int main(int argc, char **argv)
     for (uint32_t y = 0; y < H; y++) {
         const unsigned char *row = raw + y * rb, *up = y ? row - rb : NULL;
         int f;
+        /* libpng (png_write_start_row / png_set_filter) drops the filters that have no neighbour to predict from: sub, average
+         * and paeth in 1-pixel-wide images, up, average and paeth in 1-pixel-high ones; a row asked to use one gets "none" */
+        const int allowed = (W == 1 ? 0x05 : 0x1f) & (H == 1 ? 0x03 : 0x1f);      /* bit g = filter g may be used */
         if (policy < 0 || y == 0) {          /* libpng's heuristic: least sum of |signed residual|, first minimum wins */
             unsigned long best = ~0ul; f = 0;
             for (int g = 0; g < 5; g++) {
+                if (!((allowed >> g) & 1)) continue;
                 unsigned long sum = 0;
                 for (size_t i = 0; i < rb; i++) {
                     int v = (row[i] - predict(g, i >= (size_t)ch ? row[i - ch] : 0, up ? up[i] : 0, (up && i >= (size_t)ch) ? up[i - ch] : 0)) & 255;
@@ -58,6 +62,7 @@ int main(int argc, char **argv)
                 if (sum < best) { best = sum; f = g; }
             }
         } else f = policy == 5 ? (int)(y % 5) : policy;
+        if (!((allowed >> f) & 1)) f = 0;
         ids[y] = (unsigned char)f;
         if (flags) flags[y] = flag[policy == 5 ? y % 5 : policy];
         for (size_t i = 0; i < rb; i++)
