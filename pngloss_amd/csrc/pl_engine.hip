@@ -915,16 +915,34 @@ __device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uin
     vmax = med3_i32(vmax, lo, hi);
     if (tr) { vmin = -predraw; vmax = -predraw; lo = -predraw; }
     const int span = vmax - vmin, josym = osym - vmin;
-    uint32_t hm = 0;
-    for (int t = 0; t < nc; t++) hm = max(hm, T[(vmin + min(jl + 16 * t, span)) & 255].x);
-    uint32_t Hwin = rowmax_u32(hm);
-    uint32_t km = 0;
-    for (int t = 0; t < nc; t++) {
-        const int j2 = min(jl + 16 * t, span);
-        const u32x2 e = T[(vmin + j2) & 255];
-        km = max(km, e.x == Hwin ? e.y + ((j2 == josym) ? 256u : 0u) + (uint32_t)(256 - j2) : 0u);
+    uint32_t Hwin, K;
+    if (nc <= 4) {
+        /* up to four candidates per lane (q <= 64): every gather is issued before the first wait */
+        u32x2 e[4]; int jj[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            jj[t] = min(jl + 16 * min(t, nc - 1), span);
+            e[t] = T[(vmin + jj[t]) & 255];
+        }
+        uint32_t hm = max(max(e[0].x, e[1].x), max(e[2].x, e[3].x));
+        Hwin = rowmax_u32(hm);
+        uint32_t km = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            km = max(km, e[t].x == Hwin ? e[t].y + ((jj[t] == josym) ? 256u : 0u) + (uint32_t)(256 - jj[t]) : 0u);
+        K = rowmax_u32(km);
+    } else {
+        uint32_t hm = 0;
+        for (int t = 0; t < nc; t++) hm = max(hm, T[(vmin + min(jl + 16 * t, span)) & 255].x);
+        Hwin = rowmax_u32(hm);
+        uint32_t km = 0;
+        for (int t = 0; t < nc; t++) {
+            const int j2 = min(jl + 16 * t, span);
+            const u32x2 e = T[(vmin + j2) & 255];
+            km = max(km, e.x == Hwin ? e.y + ((j2 == josym) ? 256u : 0u) + (uint32_t)(256 - j2) : 0u);
+        }
+        K = rowmax_u32(km);
     }
-    uint32_t K = rowmax_u32(km);
     int jwin = (int)((0u - K) & 255u);
     int vwin = vmin + jwin;
     uint32_t Rwin = (K - 1u) >> 9;
