@@ -1371,7 +1371,8 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_TBL 0
 #define PL_SM_HC (PL_SM_TBL + PL_NFILT * PL_TBL_N * 8)
 #define PL_SM_LUT (PL_SM_HC + PL_NSYM * 4)
-#define PL_SM_COSTS (PL_SM_LUT + 512 * 4)
+#define PL_SM_LUT2 (PL_SM_LUT + 512 * 4)            /* [diff+256] -> twos | fours << 8 | five << 16 | threes << 24 (int8 each) */
+#define PL_SM_COSTS (PL_SM_LUT2 + 512 * 4)
 #define PL_SM_FLAGS (PL_SM_COSTS + 64 + PL_NFILT * 8 * 4)
 #define PL_SM_UNION (PL_SM_FLAGS + 64)
 #define PL_SM_LEGACY_BYTES (PL_CHUNK * 4 * (2 + 4) * 16)
@@ -1393,6 +1394,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     uint2 (*const tbl)[PL_TBL_N] = (uint2 (*)[PL_TBL_N])(smem + PL_SM_TBL);   /* {running symbol_frequency, rank(original_frequency)<<9} per candidate (+64 dummy slots) */
     uint32_t *const Hc = (uint32_t *)(smem + PL_SM_HC);                               /* committed symbol_frequency */
     uint32_t *const split_lut = (uint32_t *)(smem + PL_SM_LUT);                       /* [diff+256] -> rem | thr<<16 of the Sierra split, |diff| <= 255 */
+    uint32_t *const split_lut2 = (uint32_t *)(smem + PL_SM_LUT2);                     /* the next-rows terms of the split, for the commit pass */
     unsigned long long *const costs = (unsigned long long *)(smem + PL_SM_COSTS);
     uint32_t *const pacc = (uint32_t *)(smem + PL_SM_COSTS + 64);                     /* post pass accumulators: 8 words per candidate */
     uint32_t &big_err = *(uint32_t *)(smem + PL_SM_FLAGS);                            /* some |incoming error| of the coming row exceeds 8000 (see WRAP) */
@@ -1419,6 +1421,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     for (int i = tid; i < 512; i += PL_ENGINE_THREADS) {
         const PlSplit sp = pl_sierra_split(i - 256, prm.rbleed, r29);
         split_lut[i] = ((uint32_t)(int)sp.rem & 0xffffu) | ((uint32_t)(int)sp.h << 16);
+        split_lut2[i] = ((uint32_t)(int)sp.t & 255u) | (((uint32_t)(int)sp.f & 255u) << 8) | (((uint32_t)(int)sp.v & 255u) << 16) | ((uint32_t)(int)sp.h << 24);
     }
     if (tid == 0) { big_err = 0; big_lead = 0; }
     __syncthreads();
@@ -1544,37 +1547,55 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         if (tid == 0) { big_err = 0; big_lead = 0; }
         __syncthreads();
         bool big = false, bigl = false;
-        const uint4 *cd = j.cand + (size_t)winner * W;
-        uint32_t *rowp = j.img + (size_t)y * W;
+        const uint4 *__restrict__ cd = j.cand + (size_t)winner * W;
+        uint32_t *__restrict__ rowp = j.img + (size_t)y * W;
+        uint32_t *__restrict__ oldab = j.old_above;
+        uint2 *__restrict__ perr0 = j.err0, *__restrict__ perr1 = j.err1;
         const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
+        /* (the pointers do not alias: telling the compiler lets it keep the loads of several iterations in flight) */
+#pragma unroll 4
         for (uint32_t x = tid; x < W; x += PL_ENGINE_THREADS) {
             const uint4 cw = cd[x];
             const uint32_t np = ((cw.x & 255u) | ((cw.y & 255u) << 8) | ((cw.z & 255u) << 16) | ((cw.w & 255u) << 24)) & keep;
-            j.old_above[x] = rowp[x];
+            oldab[x] = rowp[x];
             rowp[x] = np;
-            const uint2 e1 = j.err1[x];
+            const uint2 e1 = perr1[x];
+            /* the five source pixels of the next-rows terms, loaded once for the four planes */
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            const uint4 cm2 = x >= 2 ? cd[x - 2] : z4, cm1 = x >= 1 ? cd[x - 1] : z4;
+            const uint4 cp1 = x + 1 < W ? cd[x + 1] : z4, cp2 = x + 2 < W ? cd[x + 2] : z4;
             uint32_t n0[4], n1[4];
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const int ch = pl_channel_of_plane(bpp, p);
                 const uint32_t e1p = p < 2 ? (e1.x >> (16 * p)) : (e1.y >> (16 * (p - 2)));
-                float c1 = 0.f, c2 = 0.f;
+                int c1 = 0, c2 = 0;
                 if (ch >= 0) {
-                    const PlSplit m2 = split_at(cd, (long)x - 2, W, ch, prm.rbleed, r29);
-                    const PlSplit m1 = split_at(cd, (long)x - 1, W, ch, prm.rbleed, r29);
-                    const PlSplit z0 = split_at(cd, (long)x, W, ch, prm.rbleed, r29);
-                    const PlSplit p1 = split_at(cd, (long)x + 1, W, ch, prm.rbleed, r29);
-                    const PlSplit p2 = split_at(cd, (long)x + 2, W, ch, prm.rbleed, r29);
-                    c1 = p2.t + p1.f + z0.v + m1.f + m2.t;
-                    c2 = p1.t + z0.h + m1.t;
+                    /* next-rows Sierra terms of the five source pixels x-2..x+2 (optimize_state.c:446-465): from the 512-entry
+                     * LDS table of the split for |diff| <= 255, else by the float arithmetic of pl_sierra_split */
+                    auto terms = [&](const uint4 v) -> uint32_t {
+                        const uint32_t w = ch == 0 ? v.x : (ch == 1 ? v.y : (ch == 2 ? v.z : v.w));
+                        const int diff = pl_sext16((int)(w >> 8));
+                        if (diff >= -256 && diff <= 255) return split_lut2[diff + 256];
+                        const PlSplit sp = pl_sierra_split(diff, prm.rbleed, r29);
+                        return ((uint32_t)(int)sp.t & 255u) | (((uint32_t)(int)sp.f & 255u) << 8) | (((uint32_t)(int)sp.v & 255u) << 16) | ((uint32_t)(int)sp.h << 24);
+                    };
+                    /* (a pixel outside the row has no record: all-zero words give diff 0, whose terms are 0) */
+                    const uint32_t m2 = terms(cm2), m1 = terms(cm1), z0 = terms(cw), p1 = terms(cp1), p2 = terms(cp2);
+                    const auto T_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 0, 8); };
+                    const auto F_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 8, 8); };
+                    const auto V_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 16, 8); };
+                    const auto H_ = [](uint32_t e) { return (int)e >> 24; };
+                    c1 = T_(p2) + F_(p1) + V_(z0) + F_(m1) + T_(m2);
+                    c2 = T_(p1) + H_(z0) + T_(m1);
                 }
-                n0[p] = (uint32_t)((int)e1p + (int)c1) & 0xffffu;   /* int16 wrap-on-store */
+                n0[p] = (uint32_t)((int)e1p + c1) & 0xffffu;   /* int16 wrap-on-store */
                 big |= abs(pl_sext16((int)n0[p])) > 8000;
                 bigl |= abs(pl_sext16((int)n0[p])) > PL_E0_LEAD_MAX;
-                n1[p] = (uint32_t)((int)c2) & 0xffffu;
+                n1[p] = (uint32_t)c2 & 0xffffu;
             }
-            j.err0[x] = make_uint2(n0[0] | (n0[1] << 16), n0[2] | (n0[3] << 16));
-            j.err1[x] = make_uint2(n1[0] | (n1[1] << 16), n1[2] | (n1[3] << 16));
+            perr0[x] = make_uint2(n0[0] | (n0[1] << 16), n0[2] | (n0[3] << 16));
+            perr1[x] = make_uint2(n1[0] | (n1[1] << 16), n1[2] | (n1[3] << 16));
         }
         if (big) big_err = 1;
         if (bigl) big_lead = 1;
