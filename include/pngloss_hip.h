@@ -54,8 +54,9 @@ typedef struct {
  *   row_filters   caller-allocated height bytes or NULL.  Non-NULL: receives libpng filter FLAG values
  *                 0x08,0x10,0x20,0x40,0x80 (PNG_FILTER_NONE..PAETH, pngloss_image.c:290-306) and only row 0 is
  *                 forced to libpng's heuristic filter.  NULL: every row is (pngloss_image.c:210), no IDs returned.
- *   verbose       prints "compression complete" / "used N unique symbols" to stderr like pngloss_image.c:309-325
- *                 (the 10 Hz spinner of :214-237 is host-side cosmetics and is not reproduced)
+ *   verbose       prints the progress display of pngloss_image.c:214-237 (spinner + percentage of finished rows at 10 Hz, fed
+ *                 by a host-mapped word the engine writes per row), then "compression complete" / "used N unique symbols"
+ *                 to stderr like :309-325
  *   quantization_strength 0..255, bleed_divider 1..32767 (pngloss.c:123-131)
  * Returns PNGLOSS_SUCCESS or an error above.  Output bytes and filter IDs are bit-identical to the reference. */
 int optimize_with_rows(unsigned char **rows, uint32_t width, uint32_t height, unsigned char *row_filters,

@@ -53,11 +53,16 @@ int  port_adaptive_filter(const unsigned char *above /*nullable*/, const unsigne
 void port_sierra_split(int diff16, long bleed, int parts[5]);
 unsigned port_symbol_cost(uint32_t freq);
 
-/* 0 (default): straightforward chain.  1: the speculative-channels + rank-key formulation of the HIP row engine
- * (same results, proven by tests/test_oracle.py); process-global, test use only. */
+/* 0 (default): straightforward chain.  1: the speculative-channels + rank-key formulation of the round-1 HIP chains.
+ * 2: the band-leader formulation of the round-2 chains (decision by tracked band leaders, overlapping bands settled by
+ * priority and margin, exact evaluation + rescan otherwise).  Same results, proven by tests/test_oracle.py; process-global,
+ * test use only. */
 void port_set_chain_variant(int variant);
 /* debugging aid: f >= 0 makes candidate filter f the winner of every row (-1: normal) */
 void port_set_force_filter(int f);
+/* statistics of variant 2: [0..7] all chains, [8+8f..] chain f: pixels, fast, -, slow:unusable band, slow:leader clamped away,
+ * slow:forced symbol, band scans, rows */
+void port_lead_stats(unsigned long long out[48], int reset);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,7 @@ struct PlJob {
     uint8_t *emit_rows;   /* [height][emit_pitch] or null: filtered scanline bytes in the output colour type             */
     uint32_t emit_pitch;  /* bytes between emitted rows (multiple of 16, >= width*4)                                     */
     uint32_t emit_adaptive_all; /* 1: every row takes libpng's heuristic filter (row_filters == NULL mode), 0: only row 0 */
+    uint32_t *progress;   /* null, or a host-visible word that receives the number of finished rows (the -v progress display) */
     int32_t *result;      /* [16] status, bpp, unique symbols, retried rows, repaired pixels (wave 0), -,-,-,
                              [8..11] chain kilo-cycles per chain wave, [12..15] repaired pixels per chain wave          */
 };

@@ -1602,6 +1602,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         for (int b = tid; b < PL_NSYM; b += PL_ENGINE_THREADS) Hc[b] = tbl[winner][b].x;
         if (tid == 0 && j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);   /* PNG_FILTER_* flags */
         if (tid == 0) j.row_ids[y] = (uint8_t)winner;
+        if (tid == 0 && j.progress) __hip_atomic_store(j.progress, y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         cyc_commit += __builtin_readcyclecounter() - tcm0;
         __syncthreads();
     }

@@ -49,6 +49,9 @@ struct pngloss_hip_ctx {
     size_t pinned_bytes = 0;
     hipStream_t copy_stream = nullptr;
     double upload_ms = -1.0, download_ms = -1.0;
+    /* -v progress display of the single-image seam: a host-mapped word the engine writes the finished row count to */
+    uint32_t *h_progress = nullptr;
+    bool want_progress = false;
 };
 
 namespace {
@@ -152,6 +155,11 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
             j.emit_rows = static_cast<uint8_t *>(emits[i].d_rows);
             j.emit_pitch = emits[i].pitch;
             j.emit_adaptive_all = images[i].d_row_filters ? 0u : 1u;
+        }
+        j.progress = nullptr;
+        if (ctx->want_progress && i == 0 && ctx->h_progress) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, ctx->h_progress, 0) == hipSuccess) j.progress = static_cast<uint32_t *>(dp);
         }
         ctx->h_jobs.push_back(j);
     }
@@ -281,8 +289,25 @@ int run_host_image(unsigned char **rows, uint32_t width, uint32_t height, uint32
     do {
         if (hipMemcpy(d_img, staging.data(), npx * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
         pngloss_hip_image_desc desc{ d_img, d_filt, width, height };
+        if (verbose && !ctx->h_progress &&
+            hipHostMalloc(reinterpret_cast<void **>(&ctx->h_progress), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+            ctx->h_progress = nullptr;                     /* no display then; not an error */
+        if (ctx->h_progress) *ctx->h_progress = 0;
+        ctx->want_progress = verbose && ctx->h_progress;
         rc = enqueue(ctx, &desc, 1, forced_bpp ? &forced_bpp : nullptr, strength, bleed, nullptr);
+        ctx->want_progress = false;
         if (rc) break;
+        if (verbose && ctx->h_progress) {
+            /* the progress display of pngloss_image.c:214-237: spinner at 10 Hz and the share of finished rows, on stderr */
+            static const char spinner[] = "|/-\\";
+            unsigned spin = 0;
+            while (hipEventQuery(ctx->ev[3]) == hipErrorNotReady) {
+                const uint32_t rows_done = *reinterpret_cast<volatile uint32_t *>(ctx->h_progress);
+                std::fprintf(stderr, "\x1B[\x01G%c %.1f%% complete", spinner[spin++ & 3], 100.0 * rows_done / (double)height);
+                std::fflush(stderr);
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+        }
         rc = finish(ctx, &res, 1);
         if (rc) break;
         if (hipMemcpy(staging.data(), d_img, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = PNGLOSS_HIP_ERROR; break; }
@@ -354,6 +379,7 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->h_progress) (void)hipHostFree(ctx->h_progress);
     delete ctx;
 }
 

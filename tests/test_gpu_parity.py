@@ -336,6 +336,22 @@ def test_multi_device_host_batch_two_contexts_on_one_device():
     assert all(np.array_equal(x, y) for x, y in zip(outs, outs1)) and all(np.array_equal(x, y) for x, y in zip(filts, filts1))
 
 
+def test_verbose_prints_progress_and_summary():
+    """-v surface of the seam (pngloss_image.c:214-237, 309-325): a spinner with the percentage of finished rows while the
+    engine runs, then "compression complete" and "used N unique symbols"; the pixels are the same as without it."""
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import pngloss_amd as P\n"
+            "img = P.synth_rgba(1920, 400, 0, 0)\n"
+            "o1, f1 = P.optimize_with_rows(img, 19, 2)\n"
+            "o2, f2 = P.optimize_with_rows(img, 19, 2, verbose=True)\n"
+            "assert np.array_equal(o1, o2) and np.array_equal(f1, f2)\n"
+            "print('verbose ok')\n") % U.ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "verbose ok" in r.stdout, r.stderr[-1500:]
+    assert "% complete" in r.stderr and "compression complete" in r.stderr and "unique symbols" in r.stderr, r.stderr[-800:]
+
+
 def test_careful_int16_wrap_variant_of_the_chain():
     """Rows whose incoming Sierra error exceeds 8000 switch the chain to a variant with explicit int16 sign
     extensions (DESIGN.md 4.6).  Natural images never get there, so a test hook forces that variant for every row;
