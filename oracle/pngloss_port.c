@@ -32,6 +32,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* self-check of variant 2 (test aid): n > 0 verifies before every pixel that each usable band's recorded leader is the unique
+ * maximum of its bins, and reports up to n violations on stderr */
+static int g_lead_selfcheck = 0;
+void port_lead_selfcheck(int n) { g_lead_selfcheck = n; }
+int port_lead_selfcheck_left(void) { return g_lead_selfcheck; }
 enum { F_NONE = 0, F_SUB, F_UP, F_AVG, F_PAETH, F_COUNT };
 
 static const unsigned char png_filter_flag[F_COUNT] = { 0x08, 0x10, 0x20, 0x40, 0x80 };
@@ -339,11 +344,12 @@ static void run_chain_spec(const engine *e, uint32_t y, int f, unsigned s, long 
  *     and NO per-pixel gather, reduction or channel repair is needed -- one table lookup per channel;
  *   - anything else takes the exact sequential evaluation and then rescans the bands its bumps touched.
  * Bands of opposite sign OVERLAP in histogram bins (bin b is v = b in a positive band and v = b - 256 in a negative
- * one), so "changes no usable band's state" needs a rule: two usable bands must never disagree about a shared bin,
- *   conflict(A, B) = the leader bin of one lies in the other and is not the other's leader bin,
- * and of two conflicting bands the one with the lower priority number 2t + (negative ? 1 : 0) stays usable.  A band
- * demoted by a conflict also loses `ok`: its recorded state may go stale while the winner's leader keeps being bumped
- * on the fast path, and only a rescan brings it back.
+ * one), so "changes no usable band's state" has one exception: the leader bin u of band B may lie in a band A of the other
+ * sign whose leader is another bin.  Bumping u through B's fast path then raises a NON-leader of A, which is harmless
+ * exactly as long as u stays strictly below A's leader in (H, O_f).  Every such (u, leader of A) is a WATCHED RELATION; the
+ * moment a bump would make u catch up, A is rescanned (here: immediately, the counts being current; on the GPU, where the
+ * bumps of a chunk are applied later, the first pixel at which a relation breaks is found when they are applied and that
+ * pixel is redone exactly, which rescans A through the ordinary slow path -- same results, both being exact).
  * Geometry.  Filters with a data dependent clamp (sub, up, average, paeth): bands t < 256/q, the clamp is checked per
  * pixel.  Filter none: the prediction is 0, so the re-centred prediction is 0 (orig <= 127, "P pixels", v = byte) or 256
  * (orig >= 128, "N pixels", v = byte - 256) and the clamp is static: positive bands are cut to [.., 255], negative ones to
@@ -402,72 +408,35 @@ static void band_scan(const uint32_t *Hs, const band_geo *g, int id, band_state 
     b->L = L; b->ok = uniq; b->usable = 0;
     LSTAT(6);
 }
-/* the (at most 2) bands of the other sign that share a bin with band id: those of its first and of its last bin */
-static int band_overlaps(const band_geo *g, int id, int out[2])
-{
-    int n = 0;
-    const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
-    for (int k = 0; k < 2; k++) {
-        const int o = band_of_bin(g, ends[k], id < g->NP);
-        if (o >= 0 && (n == 0 || out[0] != o)) out[n++] = o;
-    }
-    return n;
-}
-static inline int band_prio(const band_geo *g, int id) { return id >= g->NP ? 2 * (id - g->NP) + 1 : 2 * id; }
-/* A disagreement about a shared bin only matters once the intruding leader bin could catch up with the band's own leader.
- * PORT_LEAD_MARGIN = the most bumps one bin can receive between two validations (one chunk of 64 pixels x 4 channels):
- * while H[intruder] + margin < H[leader] the intruder stays strictly below, whatever the fast path does in between. */
-#define PORT_LEAD_MARGIN 256u
-static inline int band_conflict(const band_geo *g, const band_state *B, const uint32_t *Hs, int a, int b)
-{
-    const int la = B[a].L & 255, lb = B[b].L & 255;
-    if (band_has_bin(g, a, lb) && lb != la && !(Hs[lb] + PORT_LEAD_MARGIN < Hs[la])) return 1;
-    if (band_has_bin(g, b, la) && la != lb && !(Hs[la] + PORT_LEAD_MARGIN < Hs[lb])) return 1;
-    return 0;
-}
-/* after band id was rescanned: decide its usability against its betters, then demote the lesser bands it now conflicts with */
-static void band_settle(const band_geo *g, band_state *B, const uint32_t *Hs, int id)
-{
-    int ov[2];
-    const int n = band_overlaps(g, id, ov);
-    int usable = B[id].ok;
-    for (int j = 0; j < n && usable; j++)
-        if (band_prio(g, ov[j]) < band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, Hs, id, ov[j])) usable = 0;
-    B[id].usable = usable;
-    if (!usable) B[id].ok = 0;
-    if (usable)
-        for (int j = 0; j < n; j++)
-            if (band_prio(g, ov[j]) > band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, Hs, id, ov[j])) { B[ov[j]].usable = 0; B[ov[j]].ok = 0; }
-}
-/* every 64 pixels (the GPU: whenever it has applied the deferred histogram bumps): do all usable bands still keep their
- * margins?  The lesser band of a pair that does not is demoted. */
-static void band_validate(const band_geo *g, band_state *B, const uint32_t *Hs)
-{
-    for (int id = 0; id < 2 * g->NP; id++) {
-        if (!B[id].usable) continue;
-        int ov[2];
-        const int n = band_overlaps(g, id, ov);
-        for (int j = 0; j < n; j++)
-            if (band_prio(g, ov[j]) < band_prio(g, id) && B[ov[j]].usable && band_conflict(g, B, Hs, id, ov[j])) { B[id].usable = 0; B[id].ok = 0; }
-    }
-}
 static void band_rebuild_for_bin(const uint32_t *Hs, const band_geo *g, band_state *B, int bin)
 {
-    int ids[2], n = 0;
-    const int p = band_of_bin(g, bin, 0), m = band_of_bin(g, bin, 1);
-    if (p >= 0) ids[n++] = p;
-    if (m >= 0) ids[n++] = m;
-    if (n == 2 && band_prio(g, ids[1]) < band_prio(g, ids[0])) { int t = ids[0]; ids[0] = ids[1]; ids[1] = t; }
-    int need[2] = { 0, 0 };
-    const uint32_t hnew = Hs[bin], onew = g->O[bin];
-    for (int j = 0; j < n; j++) {
+    for (int neg = 0; neg < 2; neg++) {
+        const int id = band_of_bin(g, bin, neg);
+        if (id < 0) continue;
         /* cheap test: a fresh band whose leader is not this bin and still beats it strictly keeps its state */
-        const band_state *b = &B[ids[j]];
+        const band_state *b = &B[id];
         const int lbin = b->L & 255;
-        need[j] = !b->ok || (lbin == bin ? 0 : (hnew > Hs[lbin] || (hnew == Hs[lbin] && onew >= g->O[lbin])));
+        const uint32_t hnew = Hs[bin], onew = g->O[bin];
+        const int need = !b->ok || (lbin == bin ? 0 : (hnew > Hs[lbin] || (hnew == Hs[lbin] && onew >= g->O[lbin])));
+        if (need) { band_scan(Hs, g, id, &B[id]); B[id].usable = B[id].ok; }
     }
-    for (int j = 0; j < n; j++) if (need[j]) band_scan(Hs, g, ids[j], &B[ids[j]]);
-    for (int j = 0; j < n; j++) if (need[j]) band_settle(g, B, Hs, ids[j]);
+}
+/* Would one of the bumps of a fast pixel (bins u[0..n-1], in channel order) make a bin catch up with the leader of the band of
+ * the other sign that holds it -- a watched relation break?  Then the pixel is not fast: a later channel may have looked at
+ * that band.  Counts the pixel's own earlier bumps. */
+static inline int band_watch_breaks(const uint32_t *Hs, const band_geo *g, const band_state *B, const int *u, int n)
+{
+    for (int c = 0; c < n; c++)
+        for (int neg = 0; neg < 2; neg++) {
+            const int a = band_of_bin(g, u[c], neg);
+            if (a < 0 || !B[a].usable) continue;
+            const int l = B[a].L & 255;
+            if (l == u[c]) continue;
+            uint32_t hu = Hs[u[c]] + 1, hl = Hs[l];
+            for (int k = 0; k < c; k++) { hu += u[k] == u[c]; hl += u[k] == l; }
+            if (!(hu < hl || (hu == hl && g->O[u[c]] < g->O[l]))) return 1;
+        }
+    return 0;
 }
 /* the band a lookup with this filt lands in (-1: not tracked) and, for filter none's two one-value cases, the value it is forced to */
 static inline int band_of_lookup(const band_geo *g, int filt, int npixel, int *forced, int *fv)
@@ -500,15 +469,13 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
     memcpy(Hs, e->hist, sizeof(e->hist));
     g_lead_f = f;
     for (int id = 0; id < 2 * NP; id++) band_scan(Hs, &g, id, &B[id]);
-    /* settle in priority order: positive t, negative t, positive t+1, ... */
-    for (int t = 0; t < NP; t++) { band_settle(&g, B, Hs, t); band_settle(&g, B, Hs, NP + t); }
+    for (int id = 0; id < 2 * NP; id++) B[id].usable = B[id].ok;
     LSTAT(7);
     int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
     int prev_slow = 0;
 
     for (uint32_t x = 0; x < W; x++) {
         int d16[4] = { 0, 0, 0, 0 };
-        if (x && (x & 63) == 0) band_validate(&g, B, Hs);
         const bool transparent = has_alpha && orig[(size_t)x * bpp + bpp - 1] == 0;
         int pred[4], osym[4], filt[4], lo[4], vfast[4], tr[4];
         int why = 0;
@@ -549,6 +516,19 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             if (L < lo[c] || L > lo[c] + 255) { why = why ? why : 4; continue; }
             vfast[c] = L;
         }
+        if (!why) {
+            int ub[4];
+            for (uint32_t c = 0; c < bpp; c++) ub[c] = vfast[c] & 255;
+            if (band_watch_breaks(Hs, &g, B, ub, (int)bpp)) why = 6;      /* a watched relation would break inside this pixel */
+        }
+        if (g_lead_selfcheck > 0) {
+            for (int id = 0; id < 2 * NP; id++) {
+                if (!B[id].usable) continue;
+                band_state tmp; const unsigned long long k1 = g_lead_stats[6], k2 = g_lead_stats[8 + 8 * g_lead_f + 6];
+                band_scan(Hs, &g, id, &tmp); g_lead_stats[6] = k1; g_lead_stats[8 + 8 * g_lead_f + 6] = k2;
+                if (tmp.L != B[id].L || !tmp.ok) { g_lead_selfcheck--; fprintf(stderr, "stale usable band: y=%u f=%d x=%u id=%d stored L=%d true L=%d uniq=%d (q=%d NP=%d)\n", y, f, x, id, B[id].L, tmp.L, tmp.ok, q, NP); break; }
+            }
+        }
         LSTAT(0);
         if (why && prev_slow) g_lead_stats[8 + 8 * g_lead_f + 2]++;   /* (slot 2 doubles as: slow pixel right behind a slow pixel) */
         prev_slow = why != 0;
@@ -561,7 +541,7 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
                 Hs[vfast[c] & 255]++;
             }
         } else {
-            LSTAT(why);
+            LSTAT(why == 6 ? 3 : why);
             /* exact sequential evaluation (the reference's own order), then rescan what the bumps touched */
             for (uint32_t c = 0; c < bpp; c++) {
                 const int pl = plane_of(bpp, c);
