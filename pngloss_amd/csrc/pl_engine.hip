@@ -474,7 +474,7 @@ __device__ __noinline__ void chain_dispatch(RowCtx &k, int lane, bool wrap)
 #define PL_LT_BADV 0x4000           /* 8*v marker of an unusable entry: reconstructs to a byte far outside 0..255 */
 #define PL_LCHUNK 64                /* pixels per vector phase */
 #define PL_LGROUP 16                /* pixels per speculative group */
-#define PL_LWORK_N 96
+#define PL_LWORK_N 128
 #define PL_LREC_N (PL_LCHUNK + 8)   /* the hand-scheduled loop runs up to 4 pixels past the chunk and fetches 2 ahead */
 #define PL_E0_LEAD_MAX 88           /* rows with larger incoming |error| take the round-1 chain */
 
@@ -485,8 +485,8 @@ struct LeadCtx {
     lds_uint2 *tbl;           /* this chain's {H, rank<<9}[PL_TBL_N] */
     lds_uint2 *T;             /* this chain's decision table [PL_LT_N] */
     lds_u32 *bs;              /* this chain's band states [512]: L+256 | ok<<9 | usable<<10 */
-    lds_u32 *work;            /* PL_LWORK_N words: [0..7] rescanned ids, [8..39] bands to rewrite, [40] their count, [41] number of
-                                 watched pairs (255: too many, validate everything), [48..79] the pairs (lesser band, better band) */
+    lds_u32 *work;            /* PL_LWORK_N words: [0..7] ids of rescanned bands, [41] number of watched relations, [48..111] the
+                                 relations (leader bin u | bin l of the other band's leader << 8) */
     lds_uint4 *crec;          /* chain records of the chunk: [PL_LCHUNK][4][RW] */
     lds_uint2 *out;           /* results of the chunk: [(2 + PL_LCHUNK)][4] {8*byte (checked), 8*diff + TB} */
     lds_u32 *lut;             /* Sierra split table [diff+256] -> rem | thr<<16 */
@@ -542,37 +542,8 @@ __device__ __forceinline__ bool band_has_bin(const LeadGeo &g, int id, int bin)
     const int v = id < g.NP ? bin : (bin ? bin - 256 : (g.none ? -256 : 0));
     return v >= band_lo(g, id) && v <= band_hi(g, id);
 }
-__device__ __forceinline__ int band_prio(const LeadGeo &g, int id) { return id >= g.NP ? 2 * (id - g.NP) + 1 : 2 * id; }
-/* band states in LDS: L + 256 | ok << 9 | usable << 10   (ok: L is the unique (H, rank) maximum and the scan is fresh) */
-/* Two bands disagree about a shared bin when the leader bin of one lies in the other and is not its leader bin.  That only
- * matters once the intruder could catch up: PL_LEAD_MARGIN is the most bumps one bin can receive between two validations
- * (the deferred bumps of one 64-pixel chunk x 4 channels), and while H[intruder] + margin < H[leader] the intruder stays
- * strictly below whatever the fast path does in between (oracle: band_conflict / band_validate). */
-#define PL_LEAD_MARGIN 256u
-__device__ __forceinline__ bool band_conflict(const LeadGeo &g, lds_uint2 *H, uint32_t sa, uint32_t sb, int a, int b)
-{
-    const int la = ((int)(sa & 511u) - 256) & 255, lb = ((int)(sb & 511u) - 256) & 255;
-    if (la == lb) return false;
-    const bool ia = band_has_bin(g, a, lb), ib = band_has_bin(g, b, la);
-    if (!ia && !ib) return false;
-    const uint32_t ha = H[la].x, hb = H[lb].x;
-    return (ia && !(hb + PL_LEAD_MARGIN < ha)) || (ib && !(ha + PL_LEAD_MARGIN < hb));
-}
-/* usable(id) given the CURRENT usable bits of its (at most two) neighbours of the other sign */
-__device__ __forceinline__ bool band_usable_now(const LeadGeo &g, lds_u32 *bs, lds_uint2 *H, int id, uint32_t st)
-{
-    bool usable = (st >> 9) & 1u;
-    const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int o = band_of_bin(g, ends[e], id < g.NP);
-        if (o >= 0 && band_prio(g, o) < band_prio(g, id)) {
-            const uint32_t so = bs[o];
-            if ((so & 1024u) && band_conflict(g, H, st, so, id, o)) usable = false;
-        }
-    }
-    return usable;
-}
+/* band states in LDS: L + 256 | ok << 9 | usable << 10 | touches-to-skip << 11 | back-off level << 16   (ok: L is the unique
+ * (H, rank) maximum and the scan is fresh; usable = ok, unless the band's watched relation found no room in the list) */
 
 /* one decision-table entry.  tab 0: the table (filter none: of the P pixels), tab 1: filter none's N pixels */
 __device__ __forceinline__ u32x2 lead_entry_at(const LeadGeo &g, lds_u32 *bs, lds_u32 *LUT, int filt, int tab)
@@ -631,38 +602,44 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
     return (uint32_t)(L + 256) | (uniq ? 512u : 0u);
 }
 
-/* The pairs of usable bands that disagree about a shared bin and only coexist because of their margin are WATCHED: they are
- * what lead_validate has to look at after every application of deferred bumps.  Collected after every change of band states. */
-__device__ __forceinline__ void lead_collect_pairs(const LeadCtx &k, const LeadGeo &g, int lane)
+/* WATCHED RELATIONS (oracle: band_watch_breaks).  Bands of opposite sign overlap in histogram bins: the leader bin u of a usable
+ * band may lie in the band A of the other sign, whose leader l is another bin.  Bumping u on the fast path then raises a
+ * non-leader of A -- harmless exactly as long as u stays strictly below l in (H, rank).  The list work[48..] = (u | l << 8) of
+ * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
+ * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
+#define PL_LREL_MAX 64
+__device__ __forceinline__ void lead_collect_relations(const LeadCtx &k, const LeadGeo &g, int lane)
 {
     const int nb = 2 * g.NP;
     if (lane == 0) k.work[41] = 0u;
     wave_lds_sync();
     for (int base = 0; base < nb; base += 64) {
         const int id = base + lane;
+        bool dropped = false;
         if (id < nb) {
             const uint32_t st = k.bs[id];
             if (st & 1024u) {
-                const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
-                int prev = -1;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int o = band_of_bin(g, ends[e], id < g.NP);
-                    if (o >= 0 && o != prev && band_prio(g, o) < band_prio(g, id)) {
-                        prev = o;
-                        const uint32_t so = k.bs[o];
-                        const int la = ((int)(st & 511u) - 256) & 255, lb = ((int)(so & 511u) - 256) & 255;
-                        if ((so & 1024u) && la != lb && (band_has_bin(g, id, lb) || band_has_bin(g, o, la))) {
-                            const uint32_t slot = __hip_atomic_fetch_add(&k.work[41], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (slot < 16u) { k.work[48 + 2 * slot] = (uint32_t)id; k.work[49 + 2 * slot] = (uint32_t)o; }
-                        }
+                const int u = ((int)(st & 511u) - 256) & 255;
+                const int a = band_of_bin(g, u, id < g.NP);
+                if (a >= 0) {
+                    const uint32_t sa = k.bs[a];
+                    const int l = ((int)(sa & 511u) - 256) & 255;
+                    if ((sa & 1024u) && l != u) {
+                        const uint32_t slot = __hip_atomic_fetch_add(&k.work[41], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (slot < PL_LREL_MAX) k.work[48 + slot] = (uint32_t)u | ((uint32_t)l << 8);
+                        else { k.bs[id] = st & ~1024u; dropped = true; }
                     }
                 }
             }
         }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(dropped);
+        if (m) {
+            wave_lds_sync();
+            while (m) { const int j = (int)__builtin_ctzll(m); m &= m - 1; lead_write_band_entries(k, g, lane, base + j); }
+        }
     }
     wave_lds_sync();
-    if (lane == 0 && k.work[41] > 16u) k.work[41] = 255u;
+    if (lane == 0 && k.work[41] > PL_LREL_MAX) k.work[41] = PL_LREL_MAX;
     wave_lds_sync();
 }
 
@@ -672,25 +649,7 @@ __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo
     const int nb = 2 * g.NP;
     for (int id = lane; id < nb; id += 64) {
         const uint32_t st = lead_scan_serial(g, k.tbl, id);
-        k.bs[id] = st | ((st & 512u) << 1);               /* first guess: usable = ok */
-    }
-    wave_lds_sync();
-    /* usable bits: the unique solution of  usable(A) = ok(A) and no usable band of higher priority conflicts with A.
-     * The priority order has short dependency chains, so a few parallel rounds reach the fixpoint. */
-    for (int round = 0; round < 64; round++) {
-        bool changed = false;
-        for (int id = lane; id < nb; id += 64) {
-            const uint32_t st = k.bs[id];
-            const bool u = band_usable_now(g, k.bs, k.tbl, id, st);
-            if (u != (bool)((st >> 10) & 1u)) changed = true;
-            k.bs[id] = (st & 1023u) | (u ? 1024u : 0u);
-        }
-        wave_lds_sync();
-        if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
-    }
-    for (int id = lane; id < nb; id += 64) {
-        const uint32_t st = k.bs[id];
-        if (!(st & 1024u)) k.bs[id] = st & 511u;          /* demoted by a conflict: stale from now on */
+        k.bs[id] = st | ((st & 512u) << 1);               /* usable = ok */
     }
     wave_lds_sync();
     const int ntab = g.none ? 2 : 1;
@@ -699,7 +658,7 @@ __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo
         k.T[idx] = lead_entry_at(g, k.bs, k.lut, filt, tab);
     }
     wave_lds_sync();
-    lead_collect_pairs(k, g, lane);
+    lead_collect_relations(k, g, lane);
 }
 
 /* After a slow pixel: row c of the wave (16 lanes) looks after the bin its channel just bumped.  Bands (one per sign)
@@ -776,100 +735,23 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
         }
         dup = rowmax_u32(dup);
         if (need && jl == 0) {
-            k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 512u) | (level << 16);      /* usable decided below */
+            /* usable = ok; a band that stays unusable backs off: the next 2^level - 1 touches do not rescan it */
+            const uint32_t lv = dup ? min(level + 1u, 5u) : 0u;
+            k.bs[id] = (uint32_t)(v0 + jL + 256) | (dup ? 0u : 1536u) | (lv << 16) | (((1u << lv) - 1u) << 11);
             work[2 * c + pass] = (uint32_t)id;
         }
         k.rebuilds += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(need && jl == 0));
     }
     if (!any) return;
     wave_lds_sync();
-    /* settle, one lane, in priority order; work[8..] collects the bands whose entries must be rewritten, work[31] = count */
-    if (lane == 0) {
-        int w[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) w[j] = (int)work[j];
-        int nw = 0;
+    /* the table entries of the rescanned bands, then the watched relations (leaders may have moved) */
 #pragma unroll 1
-        for (int it = 0; it < 8; it++) {
-            int id = -1, bp = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { const int pj = w[j] >= 0 ? band_prio(g, w[j]) : 0x7fffffff; if (pj < bp) { bp = pj; id = w[j]; } }
-            if (id < 0) break;
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (w[j] == id) w[j] = -1;
-            const uint32_t sraw = k.bs[id];
-            uint32_t st = sraw & 1023u;
-            const bool usable = band_usable_now(g, k.bs, k.tbl, id, st);
-            const uint32_t level = min(((sraw >> 16) & 7u) + 1u, 5u);
-            st = usable ? (st | 1024u) : ((st & 511u) | (level << 16) | (((1u << level) - 1u) << 11));
-            k.bs[id] = st;
-            work[8 + nw++] = (uint32_t)id;
-            if (usable) {
-                const int ends[2] = { band_lo(g, id) & 255, band_hi(g, id) & 255 };
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int o = band_of_bin(g, ends[e], id < g.NP);
-                    if (o >= 0 && band_prio(g, o) > band_prio(g, id)) {
-                        const uint32_t so = k.bs[o];
-                        if ((so & 1024u) && band_conflict(g, H, st, so, id, o)) { k.bs[o] = so & 511u; work[8 + nw++] = (uint32_t)o; }
-                    }
-                }
-            }
-        }
-        work[40] = (uint32_t)nw;
+    for (int j = 0; j < 8; j++) {
+        const int id = (int)work[j];
+        if (id >= 0) lead_write_band_entries(k, g, lane, id);
     }
     wave_lds_sync();
-    const int nw = (int)work[40];
-    for (int m = 0; m < nw; m++) lead_write_band_entries(k, g, lane, (int)work[8 + m]);
-    wave_lds_sync();
-    lead_collect_pairs(k, g, lane);
-}
-
-/* Whenever the deferred histogram bumps have been applied: do all usable bands still keep their margins?  The lesser band
- * of a pair that does not is demoted and its table entries rewritten (oracle: band_validate). */
-__device__ __forceinline__ void lead_validate(const LeadCtx &k, const LeadGeo &g, int lane)
-{
-    const uint32_t np = k.work[41];
-    if (np == 0u) return;                                  /* nothing is watched: the common case */
-    if (np <= 16u) {
-        bool demote = false; int id = 0;
-        if ((uint32_t)lane < np) {
-            id = (int)k.work[48 + 2 * lane];
-            const int o = (int)k.work[49 + 2 * lane];
-            const uint32_t st = k.bs[id], so = k.bs[o];
-            demote = (st & 1024u) && (so & 1024u) && band_conflict(g, k.tbl, st, so, id, o);
-        }
-        unsigned long long m = __builtin_amdgcn_ballot_w64(demote);
-        if (m == 0) return;
-        if (demote) k.bs[id] &= 511u;
-        wave_lds_sync();
-        while (m) {
-            const int j = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            lead_write_band_entries(k, g, lane, (int)k.work[48 + 2 * j]);
-        }
-        wave_lds_sync();
-        return;
-    }
-    const int nb = 2 * g.NP;
-    for (int base = 0; base < nb; base += 64) {
-        const int id = base + lane;
-        bool demote = false;
-        if (id < nb) {
-            const uint32_t st = k.bs[id];
-            if (st & 1024u) demote = !band_usable_now(g, k.bs, k.tbl, id, st);
-        }
-        unsigned long long m = __builtin_amdgcn_ballot_w64(demote);
-        if (m == 0) continue;
-        if (demote) k.bs[id] &= 511u;
-        wave_lds_sync();
-        while (m) {
-            const int j = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            lead_write_band_entries(k, g, lane, base + j);
-        }
-        wave_lds_sync();
-    }
+    lead_collect_relations(k, g, lane);
 }
 
 /* per-lane state of the speculative fast path (only lanes 0,16,32,48 -- one per channel -- run it) */
@@ -1157,52 +1039,102 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 
         /* ---- serial part ---- */
         int pos = 0, flushed = 0;
-        /* histogram bumps of the pixels [from, to) of the chunk, lane = pixel */
-        auto flush = [&](int from, int to) {
-            if (lane >= from && lane < to) {
+        /* The deferred histogram bumps of the pixels [from, to) of the chunk, lane = pixel -- after checking them against the
+         * watched relations: the first pixel whose bumps would let a relation's bin u catch up with its l (counting, in pixel
+         * order, u's bumps up to and including that pixel against l's before it) must not be applied: it and everything behind
+         * it is void, and it is redone exactly (which rescans the band through the ordinary slow path).  Returns that pixel's
+         * index, or `to`; the bumps in front of it are applied. */
+        auto flush_verify = [&](int from, int to) -> int {
+            const bool mine = lane >= from && lane < to;
+            int sym[4] = { -1, -1, -1, -1 };
+            if (mine) {
                 u32x2 rr[4], rl[4];
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++) { rr[cc] = OUT[(lane + 2) * 4 + cc]; rl[cc] = OUT[(lane + 1) * 4 + cc]; }
 #pragma unroll
-                for (int cc = 0; cc < 4; cc++) {
+                for (int cc = 0; cc < 4; cc++)
                     if ((uint32_t)cc < bpp) {
                         const int back = (int)rr[cc].x >> 3, left = (int)rl[cc].x >> 3;
-                        const int sym = (back - pl_predict<MODE>((a >> (8 * cc)) & 255, (d >> (8 * cc)) & 255, left)) & 255;
-                        __hip_atomic_fetch_add((lds_u32 *)&k.tbl[sym], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        sym[cc] = (back - pl_predict<MODE>((a >> (8 * cc)) & 255, (d >> (8 * cc)) & 255, left)) & 255;
                     }
+            }
+            int kv = to;
+            const int nrel = __builtin_amdgcn_readfirstlane((int)k.work[41]);
+            if (nrel && to > from) {
+                /* quick reject, lane = relation: even if every bump of the range went to u it would stay below l */
+                bool close = false;
+                uint32_t rel = 0;
+                if (lane < nrel) {
+                    rel = k.work[48 + lane];
+                    const u32x2 eu = k.tbl[rel & 255u], el = k.tbl[(rel >> 8) & 255u];
+                    close = !(eu.x + 4u * (uint32_t)(to - from) < el.x);
+                }
+                unsigned long long m = __builtin_amdgcn_ballot_w64(close);
+                while (m) {
+                    const int r = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
+                    m &= m - 1;
+                    const uint32_t rr2 = (uint32_t)__builtin_amdgcn_readlane((int)rel, r);
+                    const int u = (int)(rr2 & 255u), l = (int)((rr2 >> 8) & 255u);
+                    const u32x2 eu = k.tbl[u], el = k.tbl[l];
+                    uint32_t cu = 0, cl = 0;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) {
+                        const unsigned long long mu = __builtin_amdgcn_ballot_w64(sym[cc] == u), ml = __builtin_amdgcn_ballot_w64(sym[cc] == l);
+                        cu += __builtin_amdgcn_mbcnt_hi((uint32_t)(mu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mu, 0u)) + (sym[cc] == u ? 1u : 0u);
+                        cl += __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u));
+                    }
+                    const uint32_t hu = eu.x + cu, hl = el.x + cl;
+                    const bool viol = mine && (hu > hl || (hu == hl && eu.y >= el.y));
+                    const unsigned long long mv = __builtin_amdgcn_ballot_w64(viol);
+                    if (mv) kv = min(kv, (int)__builtin_ctzll(mv));
                 }
             }
+            if (mine && lane < kv) {
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++)
+                    if ((uint32_t)cc < bpp) __hip_atomic_fetch_add((lds_u32 *)&k.tbl[sym[cc]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            return kv;
         };
-        while (pos < n) {
+        for (;;) {
             const unsigned long long tf0 = __builtin_readcyclecounter();
-            int cur = n; bool bad = false;
-            if (chainlane) {
-                if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(R, OUT, LUT, c, TB, pos, n, bad);
-                else cur = lead_fast_run<MODE, false>(R, OUT, LUT, c, TB, pos, n, bad);
+            int limit = n, ixb = n;                            /* records up to `limit` are good; ixb: first bad pixel, if any */
+            if (pos < n) {
+                int cur = n; bool bad = false;
+                if (chainlane) {
+                    if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(R, OUT, LUT, c, TB, pos, n, bad);
+                    else cur = lead_fast_run<MODE, false>(R, OUT, LUT, c, TB, pos, n, bad);
+                }
+                cur = __builtin_amdgcn_readfirstlane(cur);    /* lane 0 is channel 0's chain lane: always active */
+                const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
+                const unsigned long long tf1 = __builtin_readcyclecounter();
+                cyc_fast += tf1 - tf0;
+                if (pos == 0 && !anybad) { cyc_clean += tf1 - tf0; px_clean += (uint32_t)n; }   /* diagnostics: undisturbed whole-chunk runs */
+                wave_lds_sync();
+                if (__builtin_expect(anybad, 0)) {
+                    /* the first pixel whose reconstruction left 0..255 is among the last records (a record trails its lookup by
+                     * one pixel, so the window behind a 16-pixel burst is 17 wide: look at 32) */
+                    const int w0 = cur - 32 + jl, w1 = cur - 16 + jl;
+                    const bool f0 = active && w0 >= pos && (OUT[(max(w0, 0) + 2) * 4 + c].x > 2047u);
+                    const bool f1 = active && w1 >= pos && (OUT[(max(w1, 0) + 2) * 4 + c].x > 2047u);
+                    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
+                    const uint32_t a16 = (uint32_t)((m0 | (m0 >> 16) | (m0 >> 32) | (m0 >> 48)) & 0xffffull);
+                    const uint32_t b16 = (uint32_t)((m1 | (m1 >> 16) | (m1 >> 32) | (m1 >> 48)) & 0xffffull);
+                    ixb = a16 ? cur - 32 + (int)__builtin_ctz(a16) : (b16 ? cur - 16 + (int)__builtin_ctz(b16) : n);
+                    /* (only the neutral pixels behind the chunk out of range: ixb = n, everything up to min(cur, n) is good) */
+                    limit = min(ixb, min(cur, n));
+                }
+                pos = limit;
             }
-            cur = __builtin_amdgcn_readfirstlane(cur);    /* lane 0 is channel 0's chain lane: always active */
-            const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
-            const unsigned long long tf1 = __builtin_readcyclecounter();
-            cyc_fast += tf1 - tf0;
-            if (pos == 0 && !anybad) { cyc_clean += tf1 - tf0; px_clean += (uint32_t)n; }   /* diagnostics: undisturbed whole-chunk runs */
-            if (__builtin_expect(!anybad, 1)) break;
-            /* ---- the first pixel whose reconstruction left 0..255 is among the last records: redo it exactly ---- */
+            const unsigned long long tf1b = __builtin_readcyclecounter();
+            /* apply the bumps of what is good so far -- unless a watched relation breaks inside it */
+            const int kv = flush_verify(flushed, limit);
             wave_lds_sync();
-            /* (a record trails its lookup by one pixel, so the window behind a 16-pixel burst is 17 wide: look at 32) */
             int ix;
-            {
-                const int w0 = cur - 32 + jl, w1 = cur - 16 + jl;
-                const bool f0 = active && w0 >= pos && (OUT[(max(w0, 0) + 2) * 4 + c].x > 2047u);
-                const bool f1 = active && w1 >= pos && (OUT[(max(w1, 0) + 2) * 4 + c].x > 2047u);
-                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
-                const uint32_t a16 = (uint32_t)((m0 | (m0 >> 16) | (m0 >> 32) | (m0 >> 48)) & 0xffffull);
-                const uint32_t b16 = (uint32_t)((m1 | (m1 >> 16) | (m1 >> 32) | (m1 >> 48)) & 0xffffull);
-                ix = a16 ? cur - 32 + (int)__builtin_ctz(a16) : (b16 ? cur - 16 + (int)__builtin_ctz(b16) : n);
-            }
-            if (ix >= n) { if (cur >= n) break; pos = cur; continue; }   /* only the neutral pixels behind the chunk were out of range */
-            flush(flushed, ix);
-            wave_lds_sync();
-            lead_validate(k, geo, lane);
+            if (kv < limit) ix = kv;
+            else if (ixb < n && ixb == limit) ix = ixb;
+            else { flushed = limit; if (limit >= n) break; continue; }
+            const unsigned long long tf1 = tf1b;
             /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
             uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 1) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
             uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 0) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
@@ -1249,10 +1181,6 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             flushed = ix;
             pos = ix;
         }
-        wave_lds_sync();
-        flush(flushed, n);
-        wave_lds_sync();
-        lead_validate(k, geo, lane);
         wave_lds_sync();
         const unsigned long long tv1 = __builtin_readcyclecounter();
         /* ---- vector post-phase: candidate row (byte | diff16 << 8 per channel), lane = pixel ---- */
