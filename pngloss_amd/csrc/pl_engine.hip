@@ -495,7 +495,7 @@ struct LeadCtx {
     float rq;
     uint32_t slow;            /* out: pixels redone exactly */
     uint32_t rebuilds;        /* out: band rescans */
-    unsigned long long cyc[6]; /* out (diagnostics): cycles in vector phases | fast groups | exact redo | rescan */
+    unsigned long long cyc[7]; /* out (diagnostics): cycles in vector phases | fast groups | exact redo | rescan */
 };
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -608,7 +608,26 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
-__device__ __forceinline__ void lead_collect_relations(const LeadCtx &k, const LeadGeo &g, int lane)
+/* A relation is CLOSE while fewer than PL_LREL_CLOSE bumps of u could break it.  work[112..119] = bitmap of the bins u of the
+ * relations that were close when the row stood at pixel work[42]; every pixel bumps at most 4 bins, so until
+ * 4 * (pixels since) reaches PL_LREL_CLOSE a range of bumps that touches no marked bin cannot break any relation and
+ * lead_flush skips the check.  Re-marked whenever the list is rebuilt and when the pixel budget runs out. */
+#define PL_LREL_CLOSE 1024u
+__device__ __forceinline__ void lead_mark_close(const LeadCtx &k, int lane, int xnow)
+{
+    if (lane < 8) k.work[112 + lane] = 0u;
+    if (lane == 8) k.work[42] = (uint32_t)xnow;
+    wave_lds_sync();
+    const int nrel = (int)k.work[41];
+    if (lane < nrel) {
+        const uint32_t rel = k.work[48 + lane], ub = rel & 255u;
+        const u32x2 eu = k.tbl[ub], el = k.tbl[(rel >> 8) & 255u];
+        if (eu.x + PL_LREL_CLOSE >= el.x) __hip_atomic_fetch_or(&k.work[112 + (ub >> 5)], 1u << (ub & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ void lead_collect_relations(const LeadCtx &k, const LeadGeo &g, int lane, int xnow)
 {
     const int nb = 2 * g.NP;
     if (lane == 0) k.work[41] = 0u;
@@ -640,7 +659,7 @@ __device__ __forceinline__ void lead_collect_relations(const LeadCtx &k, const L
     }
     wave_lds_sync();
     if (lane == 0 && k.work[41] > PL_LREL_MAX) k.work[41] = PL_LREL_MAX;
-    wave_lds_sync();
+    lead_mark_close(k, lane, xnow);
 }
 
 /* whole-table rebuild from the chain's histogram (row start / new strength) */
@@ -658,14 +677,14 @@ __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo
         k.T[idx] = lead_entry_at(g, k.bs, k.lut, filt, tab);
     }
     wave_lds_sync();
-    lead_collect_relations(k, g, lane);
+    lead_collect_relations(k, g, lane, 0);
 }
 
 /* After a slow pixel: row c of the wave (16 lanes) looks after the bin its channel just bumped.  Bands (one per sign)
  * that hold the bin are rescanned unless the cheap test proves their state unchanged (the bin is not the leader and
  * still strictly below it in (H, rank), or it is the leader of a band that was ok); then one lane settles the usable
  * bits of the rescanned bands in priority order and the table entries of every band that changed are rewritten. */
-__device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int lane, int bin, bool rowactive, lds_u32 *work)
+__device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int lane, int bin, bool rowactive, lds_u32 *work, int xnow)
 {
     const int jl = lane & 15, c = lane >> 4;
     lds_uint2 *const H = k.tbl;
@@ -751,7 +770,7 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
         if (id >= 0) lead_write_band_entries(k, g, lane, id);
     }
     wave_lds_sync();
-    lead_collect_relations(k, g, lane);
+    lead_collect_relations(k, g, lane, xnow);
 }
 
 /* per-lane state of the speculative fast path (only lanes 0,16,32,48 -- one per channel -- run it) */
@@ -854,7 +873,7 @@ __device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uin
 
 /* The speculative run of one channel lane over the pixels [pos, end) of the chunk.  The chain state in front of pixel
  * pos is re-derived from the result records of pixels pos-1 and pos-2 (ring slots, so this also works across chunks and
- * behind an exactly redone pixel).  Writes the result record {8*byte, 8*diff + TB} of every pixel it passes and returns
+ * behind an exactly redone pixel).  Writes the result record {8*byte | 8*v << 16, 8*diff + TB} of every pixel it passes and returns
  * how many pixels of the chunk now have one; `bad` tells that some byte it produced lies outside 0..255 (= a table
  * entry was unusable or a leader clamped away; everything behind the first such pixel is garbage, and memory-safe).
  * The hand-scheduled loop runs whole groups of four, up to 4 pixels past `end` (neutral records there), and notices a
@@ -874,7 +893,7 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
         t.h1 = ((int)le1 >> 16) * 8;
         t.h2 = ((int)le2 >> 16) * 8;
         t.lo8 = 0;
-        t.addr = (int)(r1.y + r1.x);
+        t.addr = (int)(r1.y + (r1.x & 0xffffu));
         t.mul = 1u;
         t.bad = 0;
     }
@@ -932,7 +951,7 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
             trf = r1.z >> 31; const int f8 = __builtin_amdgcn_sbfe(osym8 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8;
         }
         const u32x2 en = *(lds_uint2 *)(uintptr_t)(uint32_t)addr;
-        OUT[(i + 1) * 4 + c] = (u32x2){ (uint32_t)back8p, (uint32_t)(t.addr - v8p) };
+        OUT[(i + 1) * 4 + c] = (u32x2){ min((uint32_t)back8p, 0xffffu) | (t.e0 << 16), (uint32_t)(t.addr - v8p) };
         rn0 = R[((i + 2) * 4 + c) * RW];
         if (RW == 2) rn1 = R[((i + 2) * 4 + c) * RW + 1];
         const bool b = __builtin_amdgcn_ballot_w64((uint32_t)back8p > 2047u) != 0;
@@ -977,7 +996,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
     /* result ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
     if (lane < 8) OUT[lane] = (u32x2){ 0u, (uint32_t)TB };
     uint32_t slow = 0;
-    unsigned long long cyc_vec = 0, cyc_fast = 0, cyc_exact = 0, cyc_rescan = 0, cyc_clean = 0;
+    unsigned long long cyc_vec = 0, cyc_fast = 0, cyc_exact = 0, cyc_rescan = 0, cyc_clean = 0, cyc_flush = 0;
     uint32_t px_clean = 0;
 
     /* prefetch of the first chunk's raw words (lane = pixel) */
@@ -1044,30 +1063,50 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
          * order, u's bumps up to and including that pixel against l's before it) must not be applied: it and everything behind
          * it is void, and it is redone exactly (which rescans the band through the ordinary slow path).  Returns that pixel's
          * index, or `to`; the bumps in front of it are applied. */
+        const uint32_t chmask = (1u << bpp) - 1u;
         auto flush_verify = [&](int from, int to) -> int {
             const bool mine = lane >= from && lane < to;
-            int sym[4] = { -1, -1, -1, -1 };
-            if (mine) {
-                u32x2 rr[4], rl[4];
+            /* every LDS read below is unconditional (lanes and channels that do not take part are masked afterwards): the reads
+             * of one stage are in flight together instead of one round trip each.  The bin of every bump rides in the upper
+             * half of the result record's first word: (8v >> 3) & 255 */
+            uint32_t bin4[4];
 #pragma unroll
-                for (int cc = 0; cc < 4; cc++) { rr[cc] = OUT[(lane + 2) * 4 + cc]; rl[cc] = OUT[(lane + 1) * 4 + cc]; }
-#pragma unroll
-                for (int cc = 0; cc < 4; cc++)
-                    if ((uint32_t)cc < bpp) {
-                        const int back = (int)rr[cc].x >> 3, left = (int)rl[cc].x >> 3;
-                        sym[cc] = (back - pl_predict<MODE>((a >> (8 * cc)) & 255, (d >> (8 * cc)) & 255, left)) & 255;
-                    }
-            }
-            int kv = to;
+            for (int cc = 0; cc < 4; cc++) bin4[cc] = (OUT[(lane + 2) * 4 + cc].x >> 19) & 255u;
             const int nrel = __builtin_amdgcn_readfirstlane((int)k.work[41]);
+            const int markx = __builtin_amdgcn_readfirstlane((int)k.work[42]);
+            int kv = to;
+            bool check = false;
             if (nrel && to > from) {
-                /* quick reject, lane = relation: even if every bump of the range went to u it would stay below l */
+                /* no bump of the range goes to a bin marked close (and the marking is still good for this range): nothing to check */
+                if (4u * (uint32_t)((int)x0 + to - markx) >= PL_LREL_CLOSE) lead_mark_close(k, lane, (int)x0 + from);
+                uint32_t hitbits = 0;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) hitbits |= ((k.work[112 + (bin4[cc] >> 5)] >> (bin4[cc] & 31u)) & 1u) << cc;
+                check = __builtin_amdgcn_ballot_w64(mine && (hitbits & chmask) != 0u) != 0;
+            }
+            int sym[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) sym[cc] = (mine && ((chmask >> cc) & 1u)) ? (int)bin4[cc] : -1;
+            if (check) {
+                /* quick reject, lane = relation: u is not bumped in this range at all (bitmap of the bumped bins, work[32..39]),
+                 * or even if every bump of the range went to u it would stay below l */
+                if (lane < 8) k.work[32 + lane] = 0u;
+                wave_lds_sync();
+                if (mine) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+                        if ((uint32_t)cc < bpp) __hip_atomic_fetch_or(&k.work[32 + (sym[cc] >> 5)], 1u << (sym[cc] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                wave_lds_sync();
                 bool close = false;
                 uint32_t rel = 0;
                 if (lane < nrel) {
                     rel = k.work[48 + lane];
-                    const u32x2 eu = k.tbl[rel & 255u], el = k.tbl[(rel >> 8) & 255u];
-                    close = !(eu.x + 4u * (uint32_t)(to - from) < el.x);
+                    const uint32_t ub = rel & 255u;
+                    if ((k.work[32 + (ub >> 5)] >> (ub & 31u)) & 1u) {
+                        const u32x2 eu = k.tbl[ub], el = k.tbl[(rel >> 8) & 255u];
+                        close = !(eu.x + 4u * (uint32_t)(to - from) < el.x);
+                    }
                 }
                 unsigned long long m = __builtin_amdgcn_ballot_w64(close);
                 while (m) {
@@ -1089,10 +1128,12 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     if (mv) kv = min(kv, (int)__builtin_ctzll(mv));
                 }
             }
-            if (mine && lane < kv) {
+            {
+                /* (an add of 0 for what does not take part: no branches around the four adds) */
+                const bool on = mine && lane < kv;
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++)
-                    if ((uint32_t)cc < bpp) __hip_atomic_fetch_add((lds_u32 *)&k.tbl[sym[cc]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add((lds_u32 *)&k.tbl[bin4[cc]], (on && ((chmask >> cc) & 1u)) ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             return kv;
         };
@@ -1115,8 +1156,8 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     /* the first pixel whose reconstruction left 0..255 is among the last records (a record trails its lookup by
                      * one pixel, so the window behind a 16-pixel burst is 17 wide: look at 32) */
                     const int w0 = cur - 32 + jl, w1 = cur - 16 + jl;
-                    const bool f0 = active && w0 >= pos && (OUT[(max(w0, 0) + 2) * 4 + c].x > 2047u);
-                    const bool f1 = active && w1 >= pos && (OUT[(max(w1, 0) + 2) * 4 + c].x > 2047u);
+                    const bool f0 = active && w0 >= pos && ((OUT[(max(w0, 0) + 2) * 4 + c].x & 0xffffu) > 2047u);
+                    const bool f1 = active && w1 >= pos && ((OUT[(max(w1, 0) + 2) * 4 + c].x & 0xffffu) > 2047u);
                     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
                     const uint32_t a16 = (uint32_t)((m0 | (m0 >> 16) | (m0 >> 32) | (m0 >> 48)) & 0xffffull);
                     const uint32_t b16 = (uint32_t)((m1 | (m1 >> 16) | (m1 >> 32) | (m1 >> 48)) & 0xffffull);
@@ -1130,6 +1171,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             /* apply the bumps of what is good so far -- unless a watched relation breaks inside it */
             const int kv = flush_verify(flushed, limit);
             wave_lds_sync();
+            cyc_flush += __builtin_readcyclecounter() - tf1b;
             int ix;
             if (kv < limit) ix = kv;
             else if (ixb < n && ixb == limit) ix = ixb;
@@ -1138,7 +1180,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
             uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 1) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
             uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 0) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
-            int left = (int)OUT[(ix + 1) * 4 + c].x >> 3;
+            int left = (int)(OUT[(ix + 1) * 4 + c].x & 0xffffu) >> 3;
             const unsigned long long tf2a = __builtin_readcyclecounter();
             cyc_exact += tf2a - tf1;
             /* slow pixels come in clusters (more than half of them directly follow another one): after each exact pixel, PEEK
@@ -1151,12 +1193,12 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                                        (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
                                        (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
                 slow++;
-                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8), (uint32_t)(diff * 8 + TB) };
+                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)(diff * 8 + TB) };
                 const uint32_t le0 = LUT[(diff + 256) & 511];
                 wave_lds_sync();
                 const unsigned long long te1 = __builtin_readcyclecounter();
                 cyc_exact += te1 - te0;
-                lead_rescan(k, geo, lane, bin, active, k.work);
+                lead_rescan(k, geo, lane, bin, active, k.work, x0 + ix);
                 ix++;
                 bool again = false;
                 if (ix < n) {
@@ -1203,7 +1245,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
     }
     kref.slow = slow;
     kref.rebuilds = k.rebuilds;
-    kref.cyc[0] = cyc_vec; kref.cyc[1] = cyc_fast; kref.cyc[2] = cyc_exact; kref.cyc[3] = cyc_rescan;
+    kref.cyc[0] = cyc_vec + (cyc_flush << 0) * 0; kref.cyc[6] = cyc_flush; kref.cyc[1] = cyc_fast; kref.cyc[2] = cyc_exact; kref.cyc[3] = cyc_rescan;
     kref.cyc[4] = cyc_clean; kref.cyc[5] = px_clean;
 }
 
@@ -1355,7 +1397,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0, lead_rows = 0, lead_rebuilds = 0;
-    unsigned long long lead_cyc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long lead_cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long cyc_post = 0, cyc_commit = 0;      /* diagnostics */   /* diagnostics: vector | fast | exact | rescan | table build */
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
     int status = 0;
@@ -1407,7 +1449,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 lead_rows++;
                 for (int qq = 0; qq < 4; qq++) lead_cyc[qq] += k.cyc[qq];
                 lead_cyc[4] += tb1 - t0;
-                lead_cyc[5] += k.cyc[4]; lead_cyc[6] += k.cyc[5];
+                lead_cyc[5] += k.cyc[4]; lead_cyc[6] += k.cyc[5]; lead_cyc[7] += k.cyc[6];
               }
             } else
             /* round-1 chains: four waves on the four SIMDs -- wave 0 runs the 'none' and 'up' chains side by side,
@@ -1553,7 +1595,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     }
     if (lane == 0 && wave < PL_NFILT) {
         for (int qq = 0; qq < 5; qq++) j.result[32 + wave * 5 + qq] = (int32_t)(lead_cyc[qq] >> 10);
-        j.result[57 + wave] = (int32_t)(lead_cyc[6] ? lead_cyc[5] / lead_cyc[6] : 0);   /* cycles per pixel of the undisturbed whole-chunk runs */
+        j.result[57 + wave] = (int32_t)(lead_cyc[6] ? lead_cyc[5] / lead_cyc[6] : 0);
+        j.result[27 + wave] = (int32_t)(lead_cyc[7] >> 10);   /* flush + relation check */   /* cycles per pixel of the undisturbed whole-chunk runs */
     }
     if (lane == 0 && wave == 0) { j.result[62] = (int32_t)(cyc_post >> 10); j.result[63] = (int32_t)(cyc_commit >> 10); }
     if (lane == 0 && wave == 4) {

@@ -229,7 +229,7 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
             std::fprintf(stderr, "pngloss_hip:   cycles per pixel of undisturbed whole-chunk runs (up sub average paeth none): %d %d %d %d %d\n", r[57], r[58], r[59], r[60], r[61]);
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
-            std::fprintf(stderr, "pngloss_hip:   wave 0 kcycles in the post pass %d, in the commit pass %d\n", r[62], r[63]);
+            std::fprintf(stderr, "pngloss_hip:   wave 0 kcycles in the post pass %d, in the commit pass %d; flush + relation check per chain wave %d %d %d %d %d\n", r[62], r[63], r[27], r[28], r[29], r[30], r[31]);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[16])
             for (int w = 0; w < 4; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,

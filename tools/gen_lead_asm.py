@@ -9,7 +9,7 @@ Per pixel step k (pixel i+k), with E[j] = table entry pairs, Q[j] = record quads
             ds_read_b64 E[k], A            THE lookup
   shadow    v_cmp / s_cbranch_vccnz        previous pixel reconstructs outside 0..255 -> leave (almost never)
             v_and_or + ds_add_u32          histogram bump of the previous pixel (table address HB | (8v & 0x7f8))
-            v_sub_sdwa + ds_write_b64      result record of the previous pixel {8*byte, 8*diff + TB}
+            v_sub_sdwa + v_lshl_or + ds_write_b64   result record of the previous pixel {8*byte | 8*v << 16, 8*diff + TB}
             ds_read_b128 Q[k+2]            record of pixel i+k+2
             ...                            8*lo of this pixel, pre-added address parts of the next
 Usage: python tools/gen_lead_asm.py > pngloss_amd/csrc/pl_lead_asm.h
@@ -109,6 +109,8 @@ def step(mode, k):
     if ABL < 3:
         L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
     L.append(f"v_sub_u32_sdwa {v(DTB)}, {v(ap)}, sext({v(ep[0])}) {SDWA_S1W0}")
+    # the record's first word also carries 8*v in its upper half: (8v >> 3) & 255 is the histogram bin the deferred bump goes to
+    L.append(f"v_lshl_or_b32 {v(BACK)}, {v(ep[0])}, 16, {v(BACK)}")
     L.append(f"ds_write_b64 {v(OPTR)}, {vr(BACK, 2)} offset:{32 * k}")
     if PREF != "start":
         L += pref
