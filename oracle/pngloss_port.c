@@ -358,7 +358,7 @@ static void run_chain_spec(const engine *e, uint32_t y, int f, unsigned s, long 
  * port_lead_stats() reports how often each case occurs (the GPU engine's speed is the fast fraction).
  */
 typedef struct { int L; int ok; int usable; } band_state;   /* ok: L is the unique (H,O) maximum AND the scan is fresh */
-static unsigned long long g_lead_stats[8 * 6];   /* [0..7] all chains, [8+8f..] chain f: pixels, fast, slow:untracked, slow:unusable, slow:clamp, slow:forced, scans, rows */
+static unsigned long long g_lead_stats[8 * 6];   /* [0..7] all chains, [8+8f..] chain f: pixels, fast, light (among the fast), slow:untracked/unusable/watched relation, slow:clamp, slow:forced, scans, rows */
 #define LSTAT(i) do { g_lead_stats[i]++; g_lead_stats[8 + 8 * g_lead_f + (i)]++; } while (0)
 static int g_lead_f;
 void port_lead_stats(unsigned long long out[48], int reset)
@@ -472,13 +472,12 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
     for (int id = 0; id < 2 * NP; id++) B[id].usable = B[id].ok;
     LSTAT(7);
     int rem[4] = { 0, 0, 0, 0 }, thr_prev[4] = { 0, 0, 0, 0 }, thr_cur[4] = { 0, 0, 0, 0 };
-    int prev_slow = 0;
 
     for (uint32_t x = 0; x < W; x++) {
         int d16[4] = { 0, 0, 0, 0 };
         const bool transparent = has_alpha && orig[(size_t)x * bpp + bpp - 1] == 0;
         int pred[4], osym[4], filt[4], lo[4], vfast[4], tr[4];
-        int why = 0;
+        int why = 0, light = 0;
         /* fast attempt: every channel looks only at the band states as they were before the pixel */
         for (uint32_t c = 0; c < bpp; c++) {
             const size_t o = (size_t)x * bpp + c;
@@ -505,16 +504,28 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             } else {
                 id = band_of_lookup(&g, filt[c], ov >= 128, &forced, &fv);
             }
-            if (id < 0) { why = why ? why : 2; continue; }
-            if (!B[id].usable) { why = why ? why : 3; continue; }
-            const int L = B[id].L;
-            if (forced) {
+            const int usable = id >= 0 && B[id].usable;
+            const int L = usable ? B[id].L : 0;
+            if (usable && forced) {
                 if (L != fv) { why = why ? why : 5; continue; }
                 if (!tr[c]) vfast[c] = fv;
                 continue;
             }
-            if (L < lo[c] || L > lo[c] + 255) { why = why ? why : 4; continue; }
-            vfast[c] = L;
+            if (usable && L >= lo[c] && L <= lo[c] + 255) { vfast[c] = L; continue; }
+            /* no usable leader inside the clamp.  If what the clamp leaves of the band is a single value, that value is the
+             * answer whatever the histogram says ("light" pixel: the bump goes to a bin that need not lead any band, and
+             * band_watch_breaks below holds it to the same rule as every other bump) */
+            if (!tr[c] && !g.none) {
+                const int fl = filt[c];
+                int vmin, vmax;
+                if (fl < 0) { vmax = -((-fl) - ((-fl) % q)); vmin = vmax - (int)s; }
+                else        { vmin = fl - (fl % q);          vmax = vmin + (int)s; }
+                vmin = med3(vmin, lo[c], lo[c] + 255);
+                vmax = med3(vmax, lo[c], lo[c] + 255);
+                if (vmin == vmax) { vfast[c] = vmin; light = 1; continue; }
+            }
+            why = why ? why : (id < 0 ? 2 : !usable ? 3 : 4);
+            continue;
         }
         if (!why) {
             int ub[4];
@@ -530,10 +541,9 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             }
         }
         LSTAT(0);
-        if (why && prev_slow) g_lead_stats[8 + 8 * g_lead_f + 2]++;   /* (slot 2 doubles as: slow pixel right behind a slow pixel) */
-        prev_slow = why != 0;
         if (!why) {
             LSTAT(1);
+            if (light) g_lead_stats[8 + 8 * g_lead_f + 2]++, g_lead_stats[2]++;   /* slot 2: light pixels (counted among the fast ones) */
             for (uint32_t c = 0; c < bpp; c++) {
                 const int pl = plane_of(bpp, c);
                 cd->bytes[(size_t)x * bpp + c] = (unsigned char)(vfast[c] - lo[c]);
@@ -541,7 +551,7 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
                 Hs[vfast[c] & 255]++;
             }
         } else {
-            LSTAT(why == 6 ? 3 : why);
+            LSTAT((why == 6 || why == 2) ? 3 : why);
             /* exact sequential evaluation (the reference's own order), then rescan what the bumps touched */
             for (uint32_t c = 0; c < bpp; c++) {
                 const int pl = plane_of(bpp, c);

@@ -60,8 +60,8 @@ unsigned port_symbol_cost(uint32_t freq);
 void port_set_chain_variant(int variant);
 /* debugging aid: f >= 0 makes candidate filter f the winner of every row (-1: normal) */
 void port_set_force_filter(int f);
-/* statistics of variant 2: [0..7] all chains, [8+8f..] chain f: pixels, fast, -, slow:unusable band, slow:leader clamped away,
- * slow:forced symbol, band scans, rows */
+/* statistics of variant 2: [0..7] all chains, [8+8f..] chain f: pixels, fast, light (fast pixels with a channel whose clamped band is
+ * a single value), slow:unusable band or watched relation, slow:leader clamped away, slow:forced symbol, band scans, rows */
 void port_lead_stats(unsigned long long out[48], int reset);
 
 #ifdef __cplusplus

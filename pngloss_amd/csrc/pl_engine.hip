@@ -495,6 +495,7 @@ struct LeadCtx {
     float rq;
     uint32_t slow;            /* out: pixels redone exactly */
     uint32_t rebuilds;        /* out: band rescans */
+    uint32_t light;           /* out: light pixels (single-valued clamp, no histogram read) */
     unsigned long long cyc[7]; /* out (diagnostics): cycles in vector phases | fast groups | exact redo | rescan */
 };
 
@@ -889,11 +890,14 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
         const u32x2 r1 = OUT[(pos + 1) * 4 + c], r2 = OUT[pos * 4 + c];
         const uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)r1.y - TB, 0, 12) >> 3) + 256) & 511];
         const uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)r2.y - TB, 0, 12) >> 3) + 256) & 511];
-        t.e0 = (r1.x & 0xffffu) | ((uint32_t)(pl_sext16((int)le1) * 8) << 16);
+        /* the first step writes the record of pixel pos-1 once more: give it back exactly what it holds (that pixel's bump
+         * may still be deferred, and its bin rides in the record's upper half) */
+        const int v8p0 = pl_sext16((int)(r1.x >> 16));
+        t.e0 = (r1.x >> 16) | ((uint32_t)(pl_sext16((int)le1) * 8) << 16);
         t.h1 = ((int)le1 >> 16) * 8;
         t.h2 = ((int)le2 >> 16) * 8;
-        t.lo8 = 0;
-        t.addr = (int)(r1.y + (r1.x & 0xffffu));
+        t.lo8 = v8p0 - (int)(r1.x & 0xffffu);
+        t.addr = (int)r1.y + v8p0;
         t.mul = 1u;
         t.bad = 0;
     }
@@ -995,7 +999,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 
     /* result ring slots 0,1 = the two pixels before the chunk: byte 0, diff 0 */
     if (lane < 8) OUT[lane] = (u32x2){ 0u, (uint32_t)TB };
-    uint32_t slow = 0;
+    uint32_t slow = 0, light = 0;
     unsigned long long cyc_vec = 0, cyc_fast = 0, cyc_exact = 0, cyc_rescan = 0, cyc_clean = 0, cyc_flush = 0;
     uint32_t px_clean = 0;
 
@@ -1058,6 +1062,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 
         /* ---- serial part ---- */
         int pos = 0, flushed = 0;
+        unsigned long long fmask = 0;   /* light pixels of the chunk whose bumps are still deferred */
         /* The deferred histogram bumps of the pixels [from, to) of the chunk, lane = pixel -- after checking them against the
          * watched relations: the first pixel whose bumps would let a relation's bin u catch up with its l (counting, in pixel
          * order, u's bumps up to and including that pixel against l's before it) must not be applied: it and everything behind
@@ -1128,6 +1133,26 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     if (mv) kv = min(kv, (int)__builtin_ctzll(mv));
                 }
             }
+            if (__builtin_amdgcn_ballot_w64(mine && ((fmask >> lane) & 1ull) != 0ull) != 0) {
+                /* light pixels in the range: a bin they bump must stay strictly below the leader of every usable band that
+                 * holds it (unless it is that leader: then the watched relations above cover it) -- decided on the safe side,
+                 * as if every bump of the range went to it */
+                bool viol = false;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+#pragma unroll
+                    for (int sg = 0; sg < 2; sg++) {
+                        const int b = (int)bin4[cc];
+                        const int id = band_of_bin(geo, b, sg == 1);
+                        const uint32_t st = k.bs[max(id, 0)];
+                        const int L = ((int)(st & 511u) - 256) & 255;
+                        const uint32_t hb = k.tbl[b].x, hl = k.tbl[L].x;
+                        viol |= ((chmask >> cc) & 1u) && id >= 0 && (st & 1024u) && L != b && !(hb + 4u * (uint32_t)(to - from) < hl);
+                    }
+                }
+                const unsigned long long mv = __builtin_amdgcn_ballot_w64(mine && ((fmask >> lane) & 1ull) != 0ull && viol);
+                if (mv) kv = min(kv, (int)__builtin_ctzll(mv));
+            }
             {
                 /* (an add of 0 for what does not take part: no branches around the four adds) */
                 const bool on = mine && lane < kv;
@@ -1167,60 +1192,109 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 }
                 pos = limit;
             }
+            /* ---- slow section.  Entered at the first bad pixel of the run WITHOUT flushing, or behind a flush at the pixel
+             * whose bumps would break a watched relation.  Every pixel is classified from the table as it stands (lane row =
+             * channel):
+             *   0  every channel's entry reconstructs a byte inside 0..255: hand back to the fast run
+             *   1  LIGHT: the channels that fail have a band the clamp [lo, lo+255] cuts down to a single value -- the answer
+             *      whatever the histogram says (saturated pixels, 70% of the slow ones).  Result record written here, bump
+             *      deferred like a fast pixel's; its bins need not lead any band, so lead_flush holds them to the rule the
+             *      watched relations enforce for leaders (fmask marks the pixel)
+             *   2  anything else: the pending bumps are flushed and the pixel is evaluated exactly
+             * (oracle: run_chain_lead's light / slow cases) */
+            int ix; bool force_exact = false;
             const unsigned long long tf1b = __builtin_readcyclecounter();
-            /* apply the bumps of what is good so far -- unless a watched relation breaks inside it */
-            const int kv = flush_verify(flushed, limit);
-            wave_lds_sync();
-            cyc_flush += __builtin_readcyclecounter() - tf1b;
-            int ix;
-            if (kv < limit) ix = kv;
-            else if (ixb < n && ixb == limit) ix = ixb;
-            else { flushed = limit; if (limit >= n) break; continue; }
-            const unsigned long long tf1 = tf1b;
-            /* chain state in front of pixel ix, from the results of ix-1 and ix-2 */
-            uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 1) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
-            uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)OUT[(ix + 0) * 4 + c].y - TB, 0, 12) >> 3) + 256) & 511];
-            int left = (int)(OUT[(ix + 1) * 4 + c].x & 0xffffu) >> 3;
-            const unsigned long long tf2a = __builtin_readcyclecounter();
-            cyc_exact += tf2a - tf1;
-            /* slow pixels come in clusters (more than half of them directly follow another one): after each exact pixel, PEEK
-             * at the next one -- would its table entry reconstruct a byte inside 0..255? -- and stay in exact mode while not.
-             * The peek is only a predictor: the fast run validates everything it does. */
+            if (ixb < n && ixb == limit) ix = ixb;
+            else {
+                const int kv = flush_verify(flushed, limit);
+                wave_lds_sync();
+                cyc_flush += __builtin_readcyclecounter() - tf1b;
+                flushed = kv;
+                if (kv >= limit) { if (limit >= n) break; continue; }
+                ix = kv; force_exact = true;
+                fmask &= ~(~0ull << kv);
+            }
+            const unsigned long long tf1 = __builtin_readcyclecounter();
+            uint32_t le1, le2; int left;
+            auto derive = [&](const int at) {
+                /* chain state in front of pixel `at`, from the results of at-1 and at-2 */
+                const u32x2 r1 = OUT[(at + 1) * 4 + c], r2 = OUT[(at + 0) * 4 + c];
+                le1 = LUT[((__builtin_amdgcn_sbfe((int)r1.y - TB, 0, 12) >> 3) + 256) & 511];
+                le2 = LUT[((__builtin_amdgcn_sbfe((int)r2.y - TB, 0, 12) >> 3) + 256) & 511];
+                left = (int)(r1.x & 0xffffu) >> 3;
+            };
+            derive(ix);
+            cyc_exact += __builtin_readcyclecounter() - tf1;
+            bool first = true;
             for (;;) {
                 const unsigned long long te0 = __builtin_readcyclecounter();
-                int back, diff, bin; uint32_t Hw, Rw; (void)Hw; (void)Rw;
-                lead_exact_pixel<MODE>(k, lane, (uint32_t)__builtin_amdgcn_readlane((int)o, ix), (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
-                                       (uint32_t)__builtin_amdgcn_readlane((int)d, ix), (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix),
-                                       (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix), left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
-                slow++;
-                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)(diff * 8 + TB) };
-                const uint32_t le0 = LUT[(diff + 256) & 511];
-                wave_lds_sync();
-                const unsigned long long te1 = __builtin_readcyclecounter();
-                cyc_exact += te1 - te0;
-                lead_rescan(k, geo, lane, bin, active, k.work, x0 + ix);
-                ix++;
-                bool again = false;
-                if (ix < n) {
-                    const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)o, ix), pa = (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
-                                   pd = (uint32_t)__builtin_amdgcn_readlane((int)d, ix);
-                    const uint32_t pex = (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix), pey = (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix);
+                const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)o, ix), pa = (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
+                               pd = (uint32_t)__builtin_amdgcn_readlane((int)d, ix);
+                const uint32_t pex = (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix), pey = (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix);
+                int cls = 2, back = 0, diff = 0, bin = 0;
+                if (!force_exact) {
                     const int p = pl_plane_of_channel(bpp, c);
                     const int e0 = pl_sext16((int)(p < 2 ? (pex >> (16 * p)) : (pey >> (16 * (p - 2)))));
                     const int orig = (po >> (8 * c)) & 255, above = (pa >> (8 * c)) & 255, diag = (pd >> (8 * c)) & 255;
-                    const int pred = pl_predict<MODE>(above, diag, back);
-                    const int osym = pl_sext8(orig - pred);
-                    const int filt = osym + e0 + pl_sext16((int)le0) + ((int)le1 >> 16);
+                    const int pred = pl_predict<MODE>(above, diag, left);
+                    const int osym = pl_sext8(orig - pred), lo = osym - orig;
+                    const int filt = osym + e0 + pl_sext16((int)le1) + ((int)le2 >> 16);
                     const int fcl = med3_i32(filt, -256, 255);
                     const u32x2 ent = k.T[fcl + 256 + ((MODE == 0 && orig >= 128) ? PL_LT_N : 0)];
-                    const int back8 = pl_sext16((int)ent.x) - (osym - orig) * 8;
-                    again = __builtin_amdgcn_ballot_w64(active && (fcl != filt || (uint32_t)back8 > 2047u)) != 0;
+                    const int v8 = pl_sext16((int)ent.x);
+                    const bool okc = fcl == filt && (uint32_t)(v8 - lo * 8) <= 2047u;
+                    const int q = k.s + 1, tq = (int)((float)filt * k.rq);
+                    const int vmin = tq * q - ((filt >> 31) & k.s), hi = lo + 255;
+                    const int cmin = med3_i32(vmin, lo, hi), cmax = med3_i32(vmin + k.s, lo, hi);
+                    const bool single = MODE != 0 && !(TR && chunk_tr) && cmin == cmax;
+                    const int v = okc ? (v8 >> 3) : cmin;
+                    back = v - lo; diff = filt - v; bin = v & 255;
+                    const bool anyheavy = __builtin_amdgcn_ballot_w64(active && !okc && !single) != 0;
+                    const bool anylight = __builtin_amdgcn_ballot_w64(active && !okc) != 0;
+                    cls = anyheavy ? 2 : (anylight ? 1 : 0);
+                    if (first && cls == 0) cls = 2;              /* (cannot happen: the run stopped here; never hand back without progress) */
                 }
-                cyc_rescan += __builtin_readcyclecounter() - te1;
-                if (!again) break;
+                first = false;
+                if (cls == 0) { cyc_rescan += __builtin_readcyclecounter() - te0; break; }
+                if (cls == 2) {
+                    if (flushed < ix) {
+                        const unsigned long long tfa = __builtin_readcyclecounter();
+                        wave_lds_sync();
+                        const int kv = flush_verify(flushed, ix);
+                        wave_lds_sync();
+                        cyc_flush += __builtin_readcyclecounter() - tfa;
+                        flushed = kv;
+                        if (kv < ix) {                          /* a relation breaks in front of this pixel: that one first */
+                            ix = kv; force_exact = true;
+                            fmask &= ~(~0ull << kv);
+                            derive(ix);
+                            continue;
+                        }
+                    }
+                    uint32_t Hw, Rw; (void)Hw; (void)Rw;
+                    lead_exact_pixel<MODE>(k, lane, po, pa, pd, pex, pey, left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
+                    slow++;
+                    force_exact = false;
+                } else {
+                    fmask |= 1ull << ix;
+                    light++;
+                }
+                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)(diff * 8 + TB) };
+                const uint32_t le0 = LUT[(diff + 256) & 511];
+                const unsigned long long te1 = __builtin_readcyclecounter();
+                cyc_exact += te1 - te0;
+                if (cls == 2) {
+                    wave_lds_sync();
+                    lead_rescan(k, geo, lane, bin, active, k.work, x0 + ix);
+                    flushed = ix + 1;
+                    cyc_rescan += __builtin_readcyclecounter() - te1;
+                }
                 left = back; le2 = le1; le1 = le0;
+                ix++;
+                if (ix >= n) break;
             }
-            flushed = ix;
+            wave_lds_sync();
+            if (ix < 64) fmask &= ~(~0ull << ix);
             pos = ix;
         }
         wave_lds_sync();
@@ -1244,6 +1318,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
         cyc_vec += __builtin_readcyclecounter() - tv1;
     }
     kref.slow = slow;
+    kref.light = light;
     kref.rebuilds = k.rebuilds;
     kref.cyc[0] = cyc_vec + (cyc_flush << 0) * 0; kref.cyc[6] = cyc_flush; kref.cyc[1] = cyc_fast; kref.cyc[2] = cyc_exact; kref.cyc[3] = cyc_rescan;
     kref.cyc[4] = cyc_clean; kref.cyc[5] = px_clean;
@@ -1396,7 +1471,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     if (tid == 0) { big_err = 0; big_lead = 0; }
     __syncthreads();
 
-    uint32_t retried = 0, slow_px = 0, lead_rows = 0, lead_rebuilds = 0;
+    uint32_t retried = 0, slow_px = 0, light_px = 0, lead_rows = 0, lead_rebuilds = 0;
     unsigned long long lead_cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long cyc_post = 0, cyc_commit = 0;      /* diagnostics */   /* diagnostics: vector | fast | exact | rescan | table build */
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
@@ -1432,7 +1507,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 k.out = (lds_uint2 *)(lout + lead_f * (PL_SM_L_OUT_WAVE / 8));
                 k.lut = (lds_u32 *)&split_lut[0];
                 k.W = W; k.bpp = bpp; k.s = s; k.rq = recip_up(s + 1);
-                k.slow = 0; k.rebuilds = 0;
+                k.slow = 0; k.rebuilds = 0; k.light = 0;
                 const unsigned long long t0 = __builtin_readcyclecounter();
                 lead_build_table(k, lead_geo(s, lead_f == 0, k.rq), lane);
                 const unsigned long long tb1 = __builtin_readcyclecounter();
@@ -1445,6 +1520,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 }
                 chain_cycles += __builtin_readcyclecounter() - t0;
                 slow_px += k.slow;
+                light_px += k.light;
                 lead_rebuilds += k.rebuilds;
                 lead_rows++;
                 for (int qq = 0; qq < 4; qq++) lead_cyc[qq] += k.cyc[qq];
@@ -1596,7 +1672,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     if (lane == 0 && wave < PL_NFILT) {
         for (int qq = 0; qq < 5; qq++) j.result[32 + wave * 5 + qq] = (int32_t)(lead_cyc[qq] >> 10);
         j.result[57 + wave] = (int32_t)(lead_cyc[6] ? lead_cyc[5] / lead_cyc[6] : 0);
-        j.result[27 + wave] = (int32_t)(lead_cyc[7] >> 10);   /* flush + relation check */   /* cycles per pixel of the undisturbed whole-chunk runs */
+        j.result[27 + wave] = (int32_t)(lead_cyc[7] >> 10);   /* flush + relation check */
+        if (!PL_SEGPROF) j.result[16 + wave] = (int32_t)light_px;   /* light pixels */
     }
     if (lane == 0 && wave == 0) { j.result[62] = (int32_t)(cyc_post >> 10); j.result[63] = (int32_t)(cyc_commit >> 10); }
     if (lane == 0 && wave == 4) {
