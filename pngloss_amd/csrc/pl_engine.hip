@@ -609,6 +609,12 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
+#ifndef PL_LEAD_BURST0_CLEAN
+#define PL_LEAD_BURST0_CLEAN 4
+#endif
+#ifndef PL_LEAD_BURST0_RESTART
+#define PL_LEAD_BURST0_RESTART 2
+#endif
 /* A relation is CLOSE while fewer than PL_LREL_CLOSE bumps of u could break it.  work[112..119] = bitmap of the bins u of the
  * relations that were close when the row stood at pixel work[42]; every pixel bumps at most 4 bins, so until
  * 4 * (pixels since) reaches PL_LREL_CLOSE a range of bumps that touches no marked bin cannot break any relation and
@@ -882,7 +888,7 @@ __device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uin
  * at a time. */
 template <int MODE, bool TRX>
 __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u32 *LUT, const int c, const int TB,
-                                             const int pos, const int end, bool &bad)
+                                             const int pos, const int end, const int burst0, bool &bad)
 {
     constexpr int RW = MODE == 4 ? 2 : 1;
     LeadState t;
@@ -910,10 +916,10 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
         int iters = iters0;
         const uint32_t rptr = (uint32_t)(uintptr_t)&R[(pos * 4 + c) * RW], optr = (uint32_t)(uintptr_t)&OUT[(pos + 1) * 4 + c];
         uint32_t acc;
-        if (MODE == 0 || MODE == 2) acc = lead_asm_noneup(t, rptr, optr, iters, ra0, rb0);
-        else if (MODE == 1) acc = lead_asm_sub(t, rptr, optr, iters, ra0, rb0);
-        else if (MODE == 3) acc = lead_asm_avg(t, rptr, optr, iters, ra0, rb0);
-        else acc = lead_asm_paeth(t, rptr, optr, iters, ra0, rb0, ra1, rb1);
+        if (MODE == 0 || MODE == 2) acc = lead_asm_noneup(t, rptr, optr, iters, burst0, ra0, rb0);
+        else if (MODE == 1) acc = lead_asm_sub(t, rptr, optr, iters, burst0, ra0, rb0);
+        else if (MODE == 3) acc = lead_asm_avg(t, rptr, optr, iters, burst0, ra0, rb0);
+        else acc = lead_asm_paeth(t, rptr, optr, iters, burst0, ra0, rb0, ra1, rb1);
         bad = __builtin_amdgcn_ballot_w64(acc > 2047u) != 0;
         return min(end, pos + 4 * (iters0 - iters) - 1);
     }
@@ -1167,9 +1173,10 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             int limit = n, ixb = n;                            /* records up to `limit` are good; ixb: first bad pixel, if any */
             if (pos < n) {
                 int cur = n; bool bad = false;
+                const int burst0 = pos == 0 ? PL_LEAD_BURST0_CLEAN : PL_LEAD_BURST0_RESTART;   /* first burst of the run, in groups of 4 pixels */
                 if (chainlane) {
-                    if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(R, OUT, LUT, c, TB, pos, n, bad);
-                    else cur = lead_fast_run<MODE, false>(R, OUT, LUT, c, TB, pos, n, bad);
+                    if (TR && chunk_tr) cur = lead_fast_run<MODE, true>(R, OUT, LUT, c, TB, pos, n, burst0, bad);
+                    else cur = lead_fast_run<MODE, false>(R, OUT, LUT, c, TB, pos, n, burst0, bad);
                 }
                 cur = __builtin_amdgcn_readfirstlane(cur);    /* lane 0 is channel 0's chain lane: always active */
                 const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
@@ -1224,15 +1231,16 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 left = (int)(r1.x & 0xffffu) >> 3;
             };
             derive(ix);
-            cyc_exact += __builtin_readcyclecounter() - tf1;
             bool first = true;
+            const uint32_t actbits = active ? ~0u : 0u;
+            unsigned long long cyc_inner = 0;                    /* flush + rescan time inside the section (accounted separately) */
             for (;;) {
-                const unsigned long long te0 = __builtin_readcyclecounter();
                 const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)o, ix), pa = (uint32_t)__builtin_amdgcn_readlane((int)a, ix),
                                pd = (uint32_t)__builtin_amdgcn_readlane((int)d, ix);
                 const uint32_t pex = (uint32_t)__builtin_amdgcn_readlane((int)e.x, ix), pey = (uint32_t)__builtin_amdgcn_readlane((int)e.y, ix);
-                int cls = 2, back = 0, diff = 0, bin = 0;
-                if (!force_exact) {
+                int back, diff, bin;
+                bool anyheavy, anylight;
+                {
                     const int p = pl_plane_of_channel(bpp, c);
                     const int e0 = pl_sext16((int)(p < 2 ? (pex >> (16 * p)) : (pey >> (16 * (p - 2)))));
                     const int orig = (po >> (8 * c)) & 255, above = (pa >> (8 * c)) & 255, diag = (pd >> (8 * c)) & 255;
@@ -1242,27 +1250,33 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     const int fcl = med3_i32(filt, -256, 255);
                     const u32x2 ent = k.T[fcl + 256 + ((MODE == 0 && orig >= 128) ? PL_LT_N : 0)];
                     const int v8 = pl_sext16((int)ent.x);
-                    const bool okc = fcl == filt && (uint32_t)(v8 - lo * 8) <= 2047u;
+                    /* per-lane integers instead of lane masks (no VALU -> SALU -> VALU round trips in front of the one decision):
+                     * notok != 0: no usable leader inside the clamp;  several != 0: the clamp leaves more than one value */
+                    const uint32_t notok = ((uint32_t)(fcl ^ filt) | ((uint32_t)(v8 - lo * 8) >> 11)) & actbits;
                     const int q = k.s + 1, tq = (int)((float)filt * k.rq);
                     const int vmin = tq * q - ((filt >> 31) & k.s), hi = lo + 255;
                     const int cmin = med3_i32(vmin, lo, hi), cmax = med3_i32(vmin + k.s, lo, hi);
-                    const bool single = MODE != 0 && !(TR && chunk_tr) && cmin == cmax;
-                    const int v = okc ? (v8 >> 3) : cmin;
+                    const uint32_t several = (MODE != 0 && !(TR && chunk_tr)) ? (uint32_t)(cmin ^ cmax) : 1u;
+                    const int v = notok ? cmin : (v8 >> 3);
                     back = v - lo; diff = filt - v; bin = v & 255;
-                    const bool anyheavy = __builtin_amdgcn_ballot_w64(active && !okc && !single) != 0;
-                    const bool anylight = __builtin_amdgcn_ballot_w64(active && !okc) != 0;
-                    cls = anyheavy ? 2 : (anylight ? 1 : 0);
-                    if (first && cls == 0) cls = 2;              /* (cannot happen: the run stopped here; never hand back without progress) */
+                    const uint32_t heavyv = notok ? several : 0u;
+                    anylight = __builtin_amdgcn_ballot_w64(notok != 0u) != 0;
+                    /* (first && !anylight cannot happen -- the run stopped here -- but never hand back without progress) */
+                    anyheavy = __builtin_amdgcn_ballot_w64(heavyv != 0u) != 0 || force_exact || (first && !anylight);
                 }
                 first = false;
-                if (cls == 0) { cyc_rescan += __builtin_readcyclecounter() - te0; break; }
-                if (cls == 2) {
+                if (!anyheavy) {
+                    if (!anylight) break;                        /* class 0: back to the fast run */
+                    fmask |= 1ull << ix;
+                    light++;
+                } else {
                     if (flushed < ix) {
                         const unsigned long long tfa = __builtin_readcyclecounter();
                         wave_lds_sync();
                         const int kv = flush_verify(flushed, ix);
                         wave_lds_sync();
-                        cyc_flush += __builtin_readcyclecounter() - tfa;
+                        const unsigned long long tfb = __builtin_readcyclecounter();
+                        cyc_flush += tfb - tfa; cyc_inner += tfb - tfa;
                         flushed = kv;
                         if (kv < ix) {                          /* a relation breaks in front of this pixel: that one first */
                             ix = kv; force_exact = true;
@@ -1275,24 +1289,22 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     lead_exact_pixel<MODE>(k, lane, po, pa, pd, pex, pey, left, pl_sext16((int)le1), (int)le2 >> 16, back, diff, bin, Hw, Rw);
                     slow++;
                     force_exact = false;
-                } else {
-                    fmask |= 1ull << ix;
-                    light++;
                 }
                 if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)(diff * 8 + TB) };
                 const uint32_t le0 = LUT[(diff + 256) & 511];
-                const unsigned long long te1 = __builtin_readcyclecounter();
-                cyc_exact += te1 - te0;
-                if (cls == 2) {
+                if (anyheavy) {
+                    const unsigned long long te1 = __builtin_readcyclecounter();
                     wave_lds_sync();
                     lead_rescan(k, geo, lane, bin, active, k.work, x0 + ix);
                     flushed = ix + 1;
-                    cyc_rescan += __builtin_readcyclecounter() - te1;
+                    const unsigned long long te2 = __builtin_readcyclecounter();
+                    cyc_rescan += te2 - te1; cyc_inner += te2 - te1;
                 }
                 left = back; le2 = le1; le1 = le0;
                 ix++;
                 if (ix >= n) break;
             }
+            cyc_exact += __builtin_readcyclecounter() - tf1 - cyc_inner;
             wave_lds_sync();
             if (ix < 64) fmask &= ~(~0ull << ix);
             pos = ix;

@@ -140,8 +140,12 @@ def gen(mode):
     # between the bursts: a scalar branch on a VALU-written condition costs ~190 cycles on gfx950 even when the v_cmp is 40
     # instructions old (profiles/r02_lead_ablation.txt), so it is paid once per 16 pixels, not per pixel or per iteration
     body.append("2:")
-    body.append("s_min_u32 %[inner], %[cnt], " + str(BURST))
+    # (the first burst of a run may be shorter -- slow pixels cluster, and everything a burst does behind a bad byte is wasted --
+    # and the burst length doubles from there up to BURST)
+    body.append("s_min_u32 %[inner], %[cnt], %[burst]")
     body.append("s_sub_u32 %[cnt], %[cnt], %[inner]")
+    body.append("s_lshl_b32 %[burst], %[burst], 1")
+    body.append("s_min_u32 %[burst], %[burst], " + str(BURST))
     body.append("1:")
     for k in range(4):
         body += step(mode, k)
@@ -165,7 +169,7 @@ def emit(mode, name):
     rw = 2 if mode == "pae" else 1
     out = []
     out.append(f"/* {name}: see tools/gen_lead_asm.py */")
-    args = "LeadState &st, const uint32_t rptr, const uint32_t optr, int &iters, u32x4 &qa, u32x4 &qb"
+    args = "LeadState &st, const uint32_t rptr, const uint32_t optr, int &iters, int burst, u32x4 &qa, u32x4 &qb"
     if rw == 2:
         args += ", u32x4 &qx, u32x4 &qy"
     out.append(f"__device__ __forceinline__ uint32_t {name}({args})")
@@ -209,7 +213,7 @@ def emit(mode, name):
     out.append("    asm volatile(")
     for ln in lines:
         out.append(f'        "{ln}\\n"')
-    outs = ['[bad] "=&v"(bad)', '[cnt] "+s"(cnt)', '[inner] "=&s"(inner)', '[e0] "+v"(e0)', '[h1] "+v"(h1)', '[h2] "+v"(h2)', '[addr] "+v"(addr)', '[lo8] "+v"(lo8)']
+    outs = ['[bad] "=&v"(bad)', '[cnt] "+s"(cnt)', '[inner] "=&s"(inner)', '[burst] "+s"(burst)', '[e0] "+v"(e0)', '[h1] "+v"(h1)', '[h2] "+v"(h2)', '[addr] "+v"(addr)', '[lo8] "+v"(lo8)']
     for j in range(4):
         outs += [f'[qa{j}] "+v"(qa{j})', f'[qb{j}] "+v"(qb{j})']
         if rw == 2:
