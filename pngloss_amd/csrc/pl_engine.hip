@@ -1086,15 +1086,16 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             const int nrel = __builtin_amdgcn_readfirstlane((int)k.work[41]);
             const int markx = __builtin_amdgcn_readfirstlane((int)k.work[42]);
             int kv = to;
-            bool check = false;
-            if (nrel && to > from) {
-                /* no bump of the range goes to a bin marked close (and the marking is still good for this range): nothing to check */
-                if (4u * (uint32_t)((int)x0 + to - markx) >= PL_LREL_CLOSE) lead_mark_close(k, lane, (int)x0 + from);
-                uint32_t hitbits = 0;
+            /* no bump of the range goes to a bin marked close (and the marking is still good for this range) and no light pixel
+             * is in it: nothing to check -- one decision for the common case */
+            if (nrel && to > from && 4u * (uint32_t)((int)x0 + to - markx) >= PL_LREL_CLOSE) lead_mark_close(k, lane, (int)x0 + from);
+            uint32_t hitbits = 0;
 #pragma unroll
-                for (int cc = 0; cc < 4; cc++) hitbits |= ((k.work[112 + (bin4[cc] >> 5)] >> (bin4[cc] & 31u)) & 1u) << cc;
-                check = __builtin_amdgcn_ballot_w64(mine && (hitbits & chmask) != 0u) != 0;
-            }
+            for (int cc = 0; cc < 4; cc++) hitbits |= ((k.work[112 + (bin4[cc] >> 5)] >> (bin4[cc] & 31u)) & 1u) << cc;
+            const uint32_t lightlane = (uint32_t)(fmask >> lane) & 1u;
+            const bool special = __builtin_amdgcn_ballot_w64(mine && ((hitbits & chmask) | lightlane) != 0u) != 0;
+            bool check = false;
+            if (special) check = nrel && __builtin_amdgcn_ballot_w64(mine && (hitbits & chmask) != 0u) != 0;
             int sym[4];
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) sym[cc] = (mine && ((chmask >> cc) & 1u)) ? (int)bin4[cc] : -1;
@@ -1139,7 +1140,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     if (mv) kv = min(kv, (int)__builtin_ctzll(mv));
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(mine && ((fmask >> lane) & 1ull) != 0ull) != 0) {
+            if (special && __builtin_amdgcn_ballot_w64(mine && lightlane != 0u) != 0) {
                 /* light pixels in the range: a bin they bump must stay strictly below the leader of every usable band that
                  * holds it (unless it is that leader: then the watched relations above cover it) -- decided on the safe side,
                  * as if every bump of the range went to it */
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                         viol |= ((chmask >> cc) & 1u) && id >= 0 && (st & 1024u) && L != b && !(hb + 4u * (uint32_t)(to - from) < hl);
                     }
                 }
-                const unsigned long long mv = __builtin_amdgcn_ballot_w64(mine && ((fmask >> lane) & 1ull) != 0ull && viol);
+                const unsigned long long mv = __builtin_amdgcn_ballot_w64(mine && lightlane != 0u && viol);
                 if (mv) kv = min(kv, (int)__builtin_ctzll(mv));
             }
             {
