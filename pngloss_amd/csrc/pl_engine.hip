@@ -609,6 +609,12 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
+/* per-phase cycle counters of the chains (PNGLOSS_HIP_DEBUG prints them).  Every reading drains the LDS queue, eight per chunk:
+ * off in the product build (make HIPFLAGS+=-DPL_LEAD_PROF=1 for a profiling build) */
+#ifndef PL_LEAD_PROF
+#define PL_LEAD_PROF 0
+#endif
+#define LTIME() (PL_LEAD_PROF ? __builtin_readcyclecounter() : 0ull)
 #ifndef PL_LEAD_BURST0_CLEAN
 #define PL_LEAD_BURST0_CLEAN 4
 #endif
@@ -1031,7 +1037,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 ne = err0[xl];
             }
         }
-        const unsigned long long tv0 = __builtin_readcyclecounter();
+        const unsigned long long tv0 = LTIME();
         /* ---- vector pre-phase: lane = pixel ---- */
         const bool alpha0 = TR && lane < n && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
         const bool chunk_tr = TR && __builtin_amdgcn_ballot_w64(alpha0) != 0;
@@ -1064,7 +1070,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
         /* the loop overshoots the chunk by up to 4 pixels and fetches 2 more: neutral records (a black pixel, no error) */
         if (lane < PL_LREC_N - PL_LCHUNK) write_records(PL_LCHUNK + lane, 0u, 0u, 0u, (u32x2){ 0u, 0u }, false);
         wave_lds_sync();
-        cyc_vec += __builtin_readcyclecounter() - tv0;
+        cyc_vec += LTIME() - tv0;
 
         /* ---- serial part ---- */
         int pos = 0, flushed = 0;
@@ -1170,7 +1176,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             return kv;
         };
         for (;;) {
-            const unsigned long long tf0 = __builtin_readcyclecounter();
+            const unsigned long long tf0 = LTIME();
             int limit = n, ixb = n;                            /* records up to `limit` are good; ixb: first bad pixel, if any */
             if (pos < n) {
                 int cur = n; bool bad = false;
@@ -1181,7 +1187,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 }
                 cur = __builtin_amdgcn_readfirstlane(cur);    /* lane 0 is channel 0's chain lane: always active */
                 const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
-                const unsigned long long tf1 = __builtin_readcyclecounter();
+                const unsigned long long tf1 = LTIME();
                 cyc_fast += tf1 - tf0;
                 if (pos == 0 && !anybad) { cyc_clean += tf1 - tf0; px_clean += (uint32_t)n; }   /* diagnostics: undisturbed whole-chunk runs */
                 wave_lds_sync();
@@ -1211,18 +1217,18 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
              *   2  anything else: the pending bumps are flushed and the pixel is evaluated exactly
              * (oracle: run_chain_lead's light / slow cases) */
             int ix; bool force_exact = false;
-            const unsigned long long tf1b = __builtin_readcyclecounter();
+            const unsigned long long tf1b = LTIME();
             if (ixb < n && ixb == limit) ix = ixb;
             else {
                 const int kv = flush_verify(flushed, limit);
                 wave_lds_sync();
-                cyc_flush += __builtin_readcyclecounter() - tf1b;
+                cyc_flush += LTIME() - tf1b;
                 flushed = kv;
                 if (kv >= limit) { if (limit >= n) break; continue; }
                 ix = kv; force_exact = true;
                 fmask &= ~(~0ull << kv);
             }
-            const unsigned long long tf1 = __builtin_readcyclecounter();
+            const unsigned long long tf1 = LTIME();
             uint32_t le1, le2; int left;
             auto derive = [&](const int at) {
                 /* chain state in front of pixel `at`, from the results of at-1 and at-2 */
@@ -1272,11 +1278,11 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     light++;
                 } else {
                     if (flushed < ix) {
-                        const unsigned long long tfa = __builtin_readcyclecounter();
+                        const unsigned long long tfa = LTIME();
                         wave_lds_sync();
                         const int kv = flush_verify(flushed, ix);
                         wave_lds_sync();
-                        const unsigned long long tfb = __builtin_readcyclecounter();
+                        const unsigned long long tfb = LTIME();
                         cyc_flush += tfb - tfa; cyc_inner += tfb - tfa;
                         flushed = kv;
                         if (kv < ix) {                          /* a relation breaks in front of this pixel: that one first */
@@ -1294,24 +1300,24 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)(diff * 8 + TB) };
                 const uint32_t le0 = LUT[(diff + 256) & 511];
                 if (anyheavy) {
-                    const unsigned long long te1 = __builtin_readcyclecounter();
+                    const unsigned long long te1 = LTIME();
                     wave_lds_sync();
                     lead_rescan(k, geo, lane, bin, active, k.work, x0 + ix);
                     flushed = ix + 1;
-                    const unsigned long long te2 = __builtin_readcyclecounter();
+                    const unsigned long long te2 = LTIME();
                     cyc_rescan += te2 - te1; cyc_inner += te2 - te1;
                 }
                 left = back; le2 = le1; le1 = le0;
                 ix++;
                 if (ix >= n) break;
             }
-            cyc_exact += __builtin_readcyclecounter() - tf1 - cyc_inner;
+            cyc_exact += LTIME() - tf1 - cyc_inner;
             wave_lds_sync();
             if (ix < 64) fmask &= ~(~0ull << ix);
             pos = ix;
         }
         wave_lds_sync();
-        const unsigned long long tv1 = __builtin_readcyclecounter();
+        const unsigned long long tv1 = LTIME();
         /* ---- vector post-phase: candidate row (byte | diff16 << 8 per channel), lane = pixel ---- */
         if (lane < n) {
             uint32_t w[4] = { 0u, 0u, 0u, 0u };
@@ -1328,7 +1334,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
         wave_lds_sync();
         if (lane < 8) OUT[lane] = keep;
         wave_lds_sync();
-        cyc_vec += __builtin_readcyclecounter() - tv1;
+        cyc_vec += LTIME() - tv1;
     }
     kref.slow = slow;
     kref.light = light;
