@@ -1464,6 +1464,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     uint32_t &big_err = *(uint32_t *)(smem + PL_SM_FLAGS);                            /* some |incoming error| of the coming row exceeds 8000 (see WRAP) */
     uint32_t &big_lead = *(uint32_t *)(smem + PL_SM_FLAGS + 4);                       /* ... exceeds PL_E0_LEAD_MAX: the row takes the round-1 chain */
     uint32_t &uniq = *(uint32_t *)(smem + PL_SM_FLAGS + 8);
+    uint32_t &simd_map = *(uint32_t *)(smem + PL_SM_FLAGS + 12);                      /* diagnostics */
     uint4 *const rec = (uint4 *)(smem + PL_SM_UNION);                                 /* round-1 chain: chunk records (wave 0 two filters, waves 1..4 one) */
     /* band-leader chain (same region): decision tables, band states, chain records, result rings */
     uint2 *const ltab = (uint2 *)(smem + PL_SM_UNION);
@@ -1487,7 +1488,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         split_lut[i] = ((uint32_t)(int)sp.rem & 0xffffu) | ((uint32_t)(int)sp.h << 16);
         split_lut2[i] = ((uint32_t)(int)sp.t & 255u) | (((uint32_t)(int)sp.f & 255u) << 8) | (((uint32_t)(int)sp.v & 255u) << 16) | ((uint32_t)(int)sp.h << 24);
     }
-    if (tid == 0) { big_err = 0; big_lead = 0; }
+    if (tid == 0) { big_err = 0; big_lead = 0; simd_map = 0; }
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0, light_px = 0, lead_rows = 0, lead_rebuilds = 0;
@@ -1695,6 +1696,13 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         if (!PL_SEGPROF) j.result[16 + wave] = (int32_t)light_px;   /* light pixels */
     }
     if (lane == 0 && wave == 0) { j.result[62] = (int32_t)(cyc_post >> 10); j.result[63] = (int32_t)(cyc_commit >> 10); }
+    {   /* diagnostics: which SIMD each wave of the workgroup sits on (HW_ID bits 5:4), two bits per wave */
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (lane == 0) atomicOr(&simd_map, ((hwid >> 4) & 3u) << (2 * wave));
+    }
+    __syncthreads();
+    if (tid == 0) j.result[7] = (int32_t)simd_map;
     if (lane == 0 && wave == 4) {
         j.result[24] = (int32_t)(chain_cycles >> 10);
         j.result[25] = (int32_t)slow_px;

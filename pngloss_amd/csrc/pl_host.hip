@@ -230,6 +230,9 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
             std::fprintf(stderr, "pngloss_hip:   cycles per pixel of undisturbed whole-chunk runs (up sub average paeth none): %d %d %d %d %d\n", r[57], r[58], r[59], r[60], r[61]);
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
             std::fprintf(stderr, "pngloss_hip:   wave 0 kcycles in the post pass %d, in the commit pass %d; flush + relation check per chain wave %d %d %d %d %d\n", r[62], r[63], r[27], r[28], r[29], r[30], r[31]);
+        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+            std::fprintf(stderr, "pngloss_hip:   SIMD of waves 0..7: %d %d %d %d %d %d %d %d\n", r[7] & 3, (r[7] >> 2) & 3, (r[7] >> 4) & 3, (r[7] >> 6) & 3,
+                         (r[7] >> 8) & 3, (r[7] >> 10) & 3, (r[7] >> 12) & 3, (r[7] >> 14) & 3);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
             std::fprintf(stderr, "pngloss_hip:   light pixels per chain wave %d %d %d %d %d\n", r[16], r[17], r[18], r[19], r[20]);
         if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[16])   /* (engine built with PL_SEGPROF) */
