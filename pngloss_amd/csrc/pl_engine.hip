@@ -609,6 +609,9 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
+#ifndef PL_PREFETCH_FIX
+#define PL_PREFETCH_FIX 1
+#endif
 /* per-phase cycle counters of the chains (PNGLOSS_HIP_DEBUG prints them).  Every reading drains the LDS queue, eight per chunk:
  * off in the product build (make HIPFLAGS+=-DPL_LEAD_PROF=1 for a profiling build) */
 #ifndef PL_LEAD_PROF
@@ -1025,6 +1028,12 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             ne = err0[xl];
         }
     }
+#if PL_PREFETCH_FIX
+    /* (the first chunk's words are complete before the loop: otherwise the compiler, which sees them used inside the serial
+     * loop, flushes vmcnt in front of that loop in EVERY chunk -- right behind the prefetch loads it is supposed to overlap) */
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) */
+#endif
+    u32x4 pend = (u32x4){ 0u, 0u, 0u, 0u }; uint32_t pend_x = 0; int pend_n = 0;
     for (uint32_t x0 = 0; x0 < W; x0 += PL_LCHUNK) {
         const int n = (int)min((uint32_t)PL_LCHUNK, W - x0);
         const uint32_t o = no, a = na, d = nd; const u32x2 e = ne;
@@ -1037,6 +1046,10 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                 ne = err0[xl];
             }
         }
+        /* the previous chunk's candidate words go out BEHIND the prefetch loads: a store issued at the end of the chunk would sit
+         * in front of them in the vmcnt queue, and the wait for the prefetched words at the next chunk's start would wait for
+         * the store's acknowledgement too */
+        if (pend_n && lane < pend_n) ((__attribute__((address_space(1))) u32x4 *)k.cand)[pend_x + lane] = pend;
         const unsigned long long tv0 = LTIME();
         /* ---- vector pre-phase: lane = pixel ---- */
         const bool alpha0 = TR && lane < n && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
@@ -1319,14 +1332,19 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
         wave_lds_sync();
         const unsigned long long tv1 = LTIME();
         /* ---- vector post-phase: candidate row (byte | diff16 << 8 per channel), lane = pixel ---- */
-        if (lane < n) {
+        {
             uint32_t w[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
             for (uint32_t cc = 0; cc < 4; cc++) {
                 const u32x2 r = OUT[(lane + 2) * 4 + cc];
                 if (cc < bpp) w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(__builtin_amdgcn_sbfe((int)r.y - TB, 0, 12) >> 3) << 8);
             }
-            ((__attribute__((address_space(1))) u32x4 *)k.cand)[x0 + lane] = (u32x4){ w[0], w[1], w[2], w[3] };
+            pend = (u32x4){ w[0], w[1], w[2], w[3] };   /* stored at the top of the next chunk (or behind the loop) */
+            pend_x = x0; pend_n = n;
+#if !PL_PREFETCH_FIX
+            if (lane < pend_n) ((__attribute__((address_space(1))) u32x4 *)k.cand)[pend_x + lane] = pend;
+            pend_n = 0;
+#endif
         }
         /* the chunk's last two results become slots 0,1 of the next chunk */
         u32x2 keep = (u32x2){ 0u, 0u };
@@ -1336,6 +1354,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
         wave_lds_sync();
         cyc_vec += LTIME() - tv1;
     }
+    if (pend_n && lane < pend_n) ((__attribute__((address_space(1))) u32x4 *)k.cand)[pend_x + lane] = pend;
     kref.slow = slow;
     kref.light = light;
     kref.rebuilds = k.rebuilds;
