@@ -628,7 +628,9 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * relations that were close when the row stood at pixel work[42]; every pixel bumps at most 4 bins, so until
  * 4 * (pixels since) reaches PL_LREL_CLOSE a range of bumps that touches no marked bin cannot break any relation and
  * lead_flush skips the check.  Re-marked whenever the list is rebuilt and when the pixel budget runs out. */
+#ifndef PL_LREL_CLOSE
 #define PL_LREL_CLOSE 1024u
+#endif
 __device__ __forceinline__ void lead_mark_close(const LeadCtx &k, int lane, int xnow)
 {
     if (lane < 8) k.work[112 + lane] = 0u;
@@ -1610,7 +1612,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                     for (int g = 1; g < PL_NFILT; g++) if (a8[3 + g] < a8[3 + bestg]) bestg = g;
                     if (bestg != tid) cst = ~0ull;           /* libpng's heuristic would not have picked this filter (optimize_state.c:319-324) */
                 }
-                costs[tid] = prm.engine_mode >= 16 ? (tid == prm.engine_mode - 16 ? 0ull : ~0ull) : cst;   /* debugging aid: force one candidate */
+                costs[tid] = (prm.engine_mode >> 8) ? (tid == (prm.engine_mode >> 8) - 1 ? 0ull : ~0ull) : cst;   /* debugging aid: force one candidate */
             }
             __syncthreads();
             uint64_t best = ~0ull;

@@ -176,7 +176,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     {
         const char *em = std::getenv("PNGLOSS_HIP_ENGINE");                     /* test hook: "legacy" = round-1 chains only */
         prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : 0;
-        if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) prm.engine_mode |= 16 + std::atoi(ff);   /* debugging aid */
+        if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) prm.engine_mode |= (std::atoi(ff) + 1) << 8;   /* debugging aid */
     }
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
