@@ -1,5 +1,6 @@
 """Randomised parity campaign on the GPU box: HIP path (C ABI) vs the CPU oracle over random shapes, contents, strengths
-and bleed dividers, both row_filters modes, plus the device batch API with mixed images.  usage: gpu_fuzz.py [seconds] [seed]"""
+and bleed dividers, both row_filters modes, plus the device batch API with mixed images.
+usage: gpu_fuzz.py [seconds] [seed] [big]     (big: shapes up to 1500 x 120, so that histogram counts and error rows grow)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,11 +9,14 @@ from tests import util as U
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 
 
 def make(rng):
     w = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 129, 257, int(rng.integers(1, 400))]))
     h = int(rng.integers(1, 30))
+    if BIG:
+        w = int(rng.integers(200, 1500)); h = int(rng.integers(20, 120))
     kind = int(rng.integers(0, 9))
     if kind == 0:
         img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
