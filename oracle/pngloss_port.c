@@ -350,6 +350,10 @@ static void run_chain_spec(const engine *e, uint32_t y, int f, unsigned s, long 
  * moment a bump would make u catch up, A is rescanned (here: immediately, the counts being current; on the GPU, where the
  * bumps of a chunk are applied later, the first pixel at which a relation breaks is found when they are applied and that
  * pixel is redone exactly, which rescans A through the ordinary slow path -- same results, both being exact).
+ * LIGHT pixels.  If the leader is clamped away and what the clamp leaves of the band is a SINGLE value, that value is the answer
+ * whatever the histogram says (saturated pixels).  Its bin need not lead any band; the rule that keeps every usable band's
+ * state true is the same one, stated for any bump: the bumped bin stays strictly below the leader of every usable band that
+ * holds it, unless it is that leader (band_watch_breaks checks exactly this for all bins a pixel bumps).
  * Geometry.  Filters with a data dependent clamp (sub, up, average, paeth): bands t < 256/q, the clamp is checked per
  * pixel.  Filter none: the prediction is 0, so the re-centred prediction is 0 (orig <= 127, "P pixels", v = byte) or 256
  * (orig >= 128, "N pixels", v = byte - 256) and the clamp is static: positive bands are cut to [.., 255], negative ones to

@@ -54,8 +54,9 @@ void port_sierra_split(int diff16, long bleed, int parts[5]);
 unsigned port_symbol_cost(uint32_t freq);
 
 /* 0 (default): straightforward chain.  1: the speculative-channels + rank-key formulation of the round-1 HIP chains.
- * 2: the band-leader formulation of the round-2 chains (decision by tracked band leaders, overlapping bands settled by
- * priority and margin, exact evaluation + rescan otherwise).  Same results, proven by tests/test_oracle.py; process-global,
+ * 2: the band-leader formulation of the round-2 chains (decision by tracked band leaders; every deferred bump must leave the
+ * bumped bin strictly below the leader of every usable band that holds it -- band_watch_breaks; a clamped band that leaves a
+ * single value is settled without the histogram ("light" pixels); exact evaluation + rescan otherwise).  Same results, proven by tests/test_oracle.py; process-global,
  * test use only. */
 void port_set_chain_variant(int variant);
 /* debugging aid: f >= 0 makes candidate filter f the winner of every row (-1: normal) */

@@ -315,6 +315,29 @@ def test_band_leader_chains_on_hostile_inputs():
         assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (i, img.shape, s, b)
 
 
+def test_light_pixels_and_deferred_bumps_on_saturated_frames():
+    """Saturated and nearly saturated regions: the clamp [lo, lo+255] cuts bands down to one value ("light" pixels, settled without
+    reading the histogram, bumps deferred and checked at the next flush) or to a few (exact redo behind a flush), next to ordinary
+    fast pixels.  Frames large enough for big histogram counts, so that the watched relations and their close-bin map matter;
+    the oracle's band-leader variant must agree with its plain chain on the same frames (same decisions, proven on the CPU)."""
+    rng = np.random.default_rng(23)
+    frames = []
+    for (w, h) in [(640, 96), (1000, 64)]:
+        ramp = np.linspace(-40, 300, w)[None, :, None] + rng.normal(0, 9, (h, w, 4))           # black .. white with both ends clipped
+        a = np.clip(ramp, 0, 255).astype(np.uint8); a[..., 3] = 255
+        b = np.where(rng.random((h, w, 1)) < 0.35, 255, rng.integers(200, 256, (h, w, 4))).astype(np.uint8)   # white with texture
+        c = np.where(rng.random((h, w, 1)) < 0.35, 0, rng.integers(0, 40, (h, w, 4))).astype(np.uint8)        # black with texture
+        c[..., 3] = np.where(rng.random((h, w)) < 0.1, 0, 255)
+        frames += [np.ascontiguousarray(a), np.ascontiguousarray(b), np.ascontiguousarray(c)]
+    for i, img in enumerate(frames):
+        for (s, b) in [(19, 2), (7, 1), (40, 4)]:
+            o0, f0 = U.run_port(img, s, b, variant=0)
+            o1, f1 = U.run_port(img, s, b, variant=2)
+            assert np.array_equal(o0, o1) and np.array_equal(f0, f1), ("oracle variants disagree", i, s, b)
+            o2, f2 = P.optimize_with_rows(img, s, b)
+            assert np.array_equal(o0, o2) and np.array_equal(f0, f2), (i, img.shape, s, b)
+
+
 def test_multi_device_host_batch_two_contexts_on_one_device():
     """The node-level C entry point (one context + host thread per device, LPT split, results in input order) with the device
     list "0,0": two contexts sharing the one GPU of this box exercise the split, the threads and the scatter."""
