@@ -16,7 +16,7 @@ Usage: python tools/gen_lead_asm.py > pngloss_amd/csrc/pl_lead_asm.h
 """
 import os
 BURST = int(os.environ.get("PL_LEAD_BURST", "4"))
-PREF = os.environ.get("PL_LEAD_PREF", "shadow")   # where the record prefetch sits: "start" of the step or in its "shadow"
+PREF = os.environ.get("PL_LEAD_PREF", "single")   # where the record prefetch sits: "start" of the step or in its "shadow"
 ABL = int(os.environ.get("PL_LEAD_ABLATE", "0"))   # timing experiments only (tools/lead_ablate.sh): >0 drops pieces, results become wrong
 E = [(200, 201), (202, 203), (204, 205), (206, 207)]
 A = [208, 209]
@@ -63,9 +63,15 @@ def step(mode, k):
     else:
         # record prefetch in the shadow (behind the lookup, so that it does not queue in front of it); the record of THIS pixel
         # (fetched two steps ago) is complete once at most lookup, write and prefetch of the previous step are outstanding
-        L.append("s_waitcnt lgkmcnt(%d)" % (2 + npre))
-        L.append(pre_add)
-        L.append("s_waitcnt lgkmcnt(%d)" % (1 + npre))
+        if PREF == "single":
+            # one wait: LDS operations complete in order, so the previous lookup's arrival implies this pixel's record (fetched
+            # a step earlier than that lookup was issued)
+            L.append("s_waitcnt lgkmcnt(%d)" % (1 + npre))
+            L.append(pre_add)
+        else:
+            L.append("s_waitcnt lgkmcnt(%d)" % (2 + npre))
+            L.append(pre_add)
+            L.append("s_waitcnt lgkmcnt(%d)" % (1 + npre))
     if mode == "nu":
         # record: x = 8*osym + 8*e0 + TB, y = 8*lo.  PRE = x + thr(i-2) was added in the previous step's shadow
         L.append(f"v_add_u32_sdwa {v(an)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
