@@ -488,7 +488,7 @@ struct LeadCtx {
     lds_u32 *work;            /* PL_LWORK_N words: [0..7] ids of rescanned bands, [41] number of watched relations, [48..111] the
                                  relations (leader bin u | bin l of the other band's leader << 8) */
     lds_uint4 *crec;          /* chain records of the chunk: [PL_LCHUNK][4][RW] */
-    lds_uint2 *out;           /* results of the chunk: [(2 + PL_LCHUNK)][4] {8*byte (checked), 8*diff + TB} */
+    lds_uint2 *out;           /* results of the chunk: [(2 + PL_LCHUNK)][4] {8*byte (checked) | 8*v << 16, table address} (lead_rec_diff) */
     lds_u32 *lut;             /* Sierra split table [diff+256] -> rem | thr<<16 */
     uint32_t W, bpp;
     int s;
@@ -791,6 +791,13 @@ __device__ __forceinline__ void lead_rescan(LeadCtx &k, const LeadGeo &g, int la
     lead_collect_relations(k, g, lane, xnow);
 }
 
+/* Result record of a pixel and channel: { 8*byte | 8*v << 16, table address of its lookup = 8*filt + TB (+ 4 KB for filter none's
+ * N table) }.  The Sierra difference filt - v: 12 bits of the address difference, which also drops the 4 KB. */
+__device__ __forceinline__ int lead_rec_diff(const u32x2 r, const int TB)
+{
+    return __builtin_amdgcn_sbfe((int)r.y - pl_sext16((int)(r.x >> 16)) - TB, 0, 12) >> 3;
+}
+
 /* per-lane state of the speculative fast path (only lanes 0,16,32,48 -- one per channel -- run it) */
 struct LeadState {
     uint32_t e0;     /* previous pixel's entry word 0: 8*v (low 16, signed) | 8*rem << 16 */
@@ -891,7 +898,7 @@ __device__ __forceinline__ void lead_exact_pixel(const LeadCtx &k, int lane, uin
 
 /* The speculative run of one channel lane over the pixels [pos, end) of the chunk.  The chain state in front of pixel
  * pos is re-derived from the result records of pixels pos-1 and pos-2 (ring slots, so this also works across chunks and
- * behind an exactly redone pixel).  Writes the result record {8*byte | 8*v << 16, 8*diff + TB} of every pixel it passes and returns
+ * behind an exactly redone pixel).  Writes the result record {8*byte | 8*v << 16, table address} of every pixel it passes and returns
  * how many pixels of the chunk now have one; `bad` tells that some byte it produced lies outside 0..255 (= a table
  * entry was unusable or a leader clamped away; everything behind the first such pixel is garbage, and memory-safe).
  * The hand-scheduled loop runs whole groups of four, up to 4 pixels past `end` (neutral records there), and notices a
@@ -905,8 +912,8 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
     LeadState t;
     {
         const u32x2 r1 = OUT[(pos + 1) * 4 + c], r2 = OUT[pos * 4 + c];
-        const uint32_t le1 = LUT[((__builtin_amdgcn_sbfe((int)r1.y - TB, 0, 12) >> 3) + 256) & 511];
-        const uint32_t le2 = LUT[((__builtin_amdgcn_sbfe((int)r2.y - TB, 0, 12) >> 3) + 256) & 511];
+        const uint32_t le1 = LUT[(lead_rec_diff(r1, TB) + 256) & 511];
+        const uint32_t le2 = LUT[(lead_rec_diff(r2, TB) + 256) & 511];
         /* the first step writes the record of pixel pos-1 once more: give it back exactly what it holds (that pixel's bump
          * may still be deferred, and its bin rides in the record's upper half) */
         const int v8p0 = pl_sext16((int)(r1.x >> 16));
@@ -914,7 +921,7 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
         t.h1 = ((int)le1 >> 16) * 8;
         t.h2 = ((int)le2 >> 16) * 8;
         t.lo8 = v8p0 - (int)(r1.x & 0xffffu);
-        t.addr = (int)r1.y + v8p0;
+        t.addr = (int)r1.y;
         t.mul = 1u;
         t.bad = 0;
     }
@@ -972,7 +979,7 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
             trf = r1.z >> 31; const int f8 = __builtin_amdgcn_sbfe(osym8 - orig8, 0, 11); addr = trf ? f8 + TB : addr; lo8 = trf ? f8 : lo8;
         }
         const u32x2 en = *(lds_uint2 *)(uintptr_t)(uint32_t)addr;
-        OUT[(i + 1) * 4 + c] = (u32x2){ min((uint32_t)back8p, 0xffffu) | (t.e0 << 16), (uint32_t)(t.addr - v8p) };
+        OUT[(i + 1) * 4 + c] = (u32x2){ min((uint32_t)back8p, 0xffffu) | (t.e0 << 16), (uint32_t)t.addr };
         rn0 = R[((i + 2) * 4 + c) * RW];
         if (RW == 2) rn1 = R[((i + 2) * 4 + c) * RW + 1];
         const bool b = __builtin_amdgcn_ballot_w64((uint32_t)back8p > 2047u) != 0;
@@ -1248,8 +1255,8 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             auto derive = [&](const int at) {
                 /* chain state in front of pixel `at`, from the results of at-1 and at-2 */
                 const u32x2 r1 = OUT[(at + 1) * 4 + c], r2 = OUT[(at + 0) * 4 + c];
-                le1 = LUT[((__builtin_amdgcn_sbfe((int)r1.y - TB, 0, 12) >> 3) + 256) & 511];
-                le2 = LUT[((__builtin_amdgcn_sbfe((int)r2.y - TB, 0, 12) >> 3) + 256) & 511];
+                le1 = LUT[(lead_rec_diff(r1, TB) + 256) & 511];
+                le2 = LUT[(lead_rec_diff(r2, TB) + 256) & 511];
                 left = (int)(r1.x & 0xffffu) >> 3;
             };
             derive(ix);
@@ -1312,7 +1319,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     slow++;
                     force_exact = false;
                 }
-                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)(diff * 8 + TB) };
+                if (chainlane) OUT[(ix + 2) * 4 + c] = (u32x2){ (uint32_t)(back * 8) | ((uint32_t)(bin * 8) << 16), (uint32_t)((diff + bin) * 8 + TB) };
                 const uint32_t le0 = LUT[(diff + 256) & 511];
                 if (anyheavy) {
                     const unsigned long long te1 = LTIME();
@@ -1339,7 +1346,7 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
 #pragma unroll
             for (uint32_t cc = 0; cc < 4; cc++) {
                 const u32x2 r = OUT[(lane + 2) * 4 + cc];
-                if (cc < bpp) w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)(__builtin_amdgcn_sbfe((int)r.y - TB, 0, 12) >> 3) << 8);
+                if (cc < bpp) w[cc] = ((r.x >> 3) & 255u) | ((uint32_t)lead_rec_diff(r, TB) << 8);
             }
             pend = (u32x4){ w[0], w[1], w[2], w[3] };   /* stored at the top of the next chunk (or behind the loop) */
             pend_x = x0; pend_n = n;

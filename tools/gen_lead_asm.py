@@ -19,10 +19,10 @@ BURST = int(os.environ.get("PL_LEAD_BURST", "4"))
 PREF = os.environ.get("PL_LEAD_PREF", "single")   # where the record prefetch sits: "start" of the step or in its "shadow"
 ABL = int(os.environ.get("PL_LEAD_ABLATE", "0"))   # timing experiments only (tools/lead_ablate.sh): >0 drops pieces, results become wrong
 E = [(200, 201), (202, 203), (204, 205), (206, 207)]
-A = [208, 209]
+A = [209, 213]            # looked-up addresses; the register below each one takes 8*byte of that pixel: {8*byte | 8*v << 16, address} is the
+                          # result record as it is written (8*diff = address - 8*v - TB is left to the readers)
 LO = 210
 PRE = 211
-BACK, DTB = 212, 213
 T0, BADACC, OSYM, T1, T2, T3 = 214, 215, 216, 217, 218, 219
 Q = [220, 224, 228, 232]       # quads (paeth: second quads at 240..)
 Q2 = [240, 244, 248, 252]
@@ -46,6 +46,7 @@ def step(mode, k):
     e2 = E[(k + 2) % 4]          # entry of the pixel before it (its .y = thr for this pixel)
     en = E[k]
     an, ap = A[k % 2], A[(k + 1) % 2]
+    BACK = ap - 1
     q, qprev, qnext, qpre = Q[k], Q[(k + 3) % 4], Q[(k + 1) % 4], Q[(k + 2) % 4]
     rw = 2 if mode == "pae" else 1
     L = []
@@ -114,7 +115,6 @@ def step(mode, k):
     # ---- shadow ----
     if ABL < 3:
         L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
-    L.append(f"v_sub_u32_sdwa {v(DTB)}, {v(ap)}, sext({v(ep[0])}) {SDWA_S1W0}")
     # the record's first word also carries 8*v in its upper half: (8v >> 3) & 255 is the histogram bin the deferred bump goes to
     L.append(f"v_lshl_or_b32 {v(BACK)}, {v(ep[0])}, 16, {v(BACK)}")
     L.append(f"ds_write_b64 {v(OPTR)}, {vr(BACK, 2)} offset:{32 * k}")
