@@ -17,6 +17,10 @@ Usage: python tools/gen_lead_asm.py > pngloss_amd/csrc/pl_lead_asm.h
 import os
 BURST = int(os.environ.get("PL_LEAD_BURST", "4"))
 PREF = os.environ.get("PL_LEAD_PREF", "single")   # where the record prefetch sits: "start" of the step or in its "shadow"
+ILV = int(os.environ.get("PL_LEAD_ILV", "0"))   # 1 (tried, 3 % slower: it delays the lookup): independent instructions between the dependent ones of the critical chain
+XW = int(os.environ.get("PL_LEAD_XW", "0"))     # timing experiments that keep the results exact: repeat the record write / the record prefetch / add VALU moves
+XR = int(os.environ.get("PL_LEAD_XR", "0"))
+XV = int(os.environ.get("PL_LEAD_XV", "0"))
 ABL = int(os.environ.get("PL_LEAD_ABLATE", "0"))   # timing experiments only (tools/lead_ablate.sh): >0 drops pieces, results become wrong
 E = [(200, 201), (202, 203), (204, 205), (206, 207)]
 A = [209, 213]            # looked-up addresses; the register below each one takes 8*byte of that pixel: {8*byte | 8*v << 16, address} is the
@@ -67,7 +71,7 @@ def step(mode, k):
         if PREF == "single":
             # one wait: LDS operations complete in order, so the previous lookup's arrival implies this pixel's record (fetched
             # a step earlier than that lookup was issued)
-            L.append("s_waitcnt lgkmcnt(%d)" % (1 + npre))
+            L.append("s_waitcnt lgkmcnt(%d)" % (1 + XW + npre * (1 + XR)))
             L.append(pre_add)
         else:
             L.append("s_waitcnt lgkmcnt(%d)" % (2 + npre))
@@ -78,6 +82,42 @@ def step(mode, k):
         L.append(f"v_add_u32_sdwa {v(an)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
         L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
         L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(qprev + 1)} {SDWA_W0}")
+    elif ILV and mode in ("sub", "avg", "pae"):
+        # A VALU instruction that needs the result of the one in front of it issues ~4 cycles later than an independent one
+        # (profiles/r02_lead_ablation.txt section 8): the record word, the validity OR and the rem + PRE part of the address fill
+        # those slots instead of waiting in the shadow.
+        orr = [f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}"] if ABL < 3 else []
+        pack = f"v_lshl_or_b32 {v(BACK)}, {v(ep[0])}, 16, {v(BACK)}"
+        L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(LO)} {SDWA_W0}")
+        L.append(f"v_add_u32_sdwa {v(T3)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
+        if mode == "sub":
+            L.append(f"v_sub_u32_e32 {v(T0)}, {v(q)}, {v(BACK)}")
+            L += orr
+            L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 11")
+            L.append(pack)
+            L.append(f"v_add_u32_e32 {v(an)}, {v(T3)}, {v(OSYM)}")
+        elif mode == "avg":
+            L.append(f"v_add_u32_e32 {v(T0)}, {v(BACK)}, {v(q + 2)}")
+            L += orr
+            L.append(f"v_bfe_u32 {v(T0)}, {v(T0)}, 4, 8")
+            L.append(pack)
+            L.append(f"v_sub_u32_e32 {v(T0)}, {v(q)}, {v(T0)}")
+            L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 8")
+            L.append(f"v_lshl_add_u32 {v(an)}, {v(OSYM)}, 3, {v(T3)}")
+        else:
+            q2 = Q2[k]
+            L.append(f"v_sad_u32 {v(T0)}, {v(BACK)}, {v(q)}, 0")
+            L.append(f"v_add_u32_e32 {v(T1)}, {v(BACK)}, {v(q + 1)}")
+            L.append(f"v_sub_u32_e32 {v(T2)}, {v(q + 3)}, {v(BACK)}")
+            L.append(f"v_sad_u32 {v(T1)}, {v(T1)}, {v(q + 2)}, 0")
+            L.append(f"v_lshl_or_b32 {v(T0)}, {v(T0)}, 14, {v(q2)}")
+            L += orr
+            L.append(f"v_lshl_or_b32 {v(T1)}, {v(T1)}, 14, {v(q2 + 1)}")
+            L.append(pack)
+            L.append(f"v_min3_u32 {v(T0)}, {v(T2)}, {v(T0)}, {v(T1)}")
+            L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 11")
+            L.append(f"v_add_u32_e32 {v(an)}, {v(T3)}, {v(OSYM)}")
+        L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
     elif mode == "sub":
         # record: x = 8*orig, y = 8*e0 + TB
         L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(LO)} {SDWA_W0}")
@@ -113,13 +153,20 @@ def step(mode, k):
         L.append(f"v_add_u32_e32 {v(an)}, {v(T0)}, {v(OSYM)}")
         L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
     # ---- shadow ----
-    if ABL < 3:
-        L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
-    # the record's first word also carries 8*v in its upper half: (8v >> 3) & 255 is the histogram bin the deferred bump goes to
-    L.append(f"v_lshl_or_b32 {v(BACK)}, {v(ep[0])}, 16, {v(BACK)}")
+    if not (ILV and mode in ("sub", "avg", "pae")):
+        if ABL < 3:
+            L.append(f"v_or_b32_e32 {v(BADACC)}, {v(BADACC)}, {v(BACK)}")
+        # the record's first word also carries 8*v in its upper half: (8v >> 3) & 255 is the histogram bin the deferred bump goes to
+        L.append(f"v_lshl_or_b32 {v(BACK)}, {v(ep[0])}, 16, {v(BACK)}")
     L.append(f"ds_write_b64 {v(OPTR)}, {vr(BACK, 2)} offset:{32 * k}")
+    for _ in range(XW):
+        L.append(f"ds_write_b64 {v(OPTR)}, {vr(BACK, 2)} offset:{32 * k}")
+    for _ in range(XV):
+        L.append(f"v_mov_b32_e32 {v(T3)}, {v(BADACC)}")
     if PREF != "start":
         L += pref
+        for _ in range(XR):
+            L += pref
     # thr of the next pixel = entry of the previous pixel .y ; pre-add it to the next record's address part
     if mode == "nu":
         if PREF == "start":
