@@ -149,6 +149,26 @@ def isa_facts():
     return facts
 
 
+def bandwidth_kernels():
+    """The HBM-class passes around the row engine, from the committed rocprofv3 kernel trace of this very command
+    (profiles/r02_v3_kernel_trace_stats.txt): average duration and bytes moved per launch on the 4096x4096 frame."""
+    out = {}
+    alg = {"pl_classify": 4 * W * H, "pl_hist": 4 * W * H}   # both read the 4 B/px image once
+    try:
+        for ln in open(os.path.join(ROOT, "profiles", "r02_v3_kernel_trace_stats.txt")):
+            for name, nbytes in alg.items():
+                if name + "(" in ln and name not in out:
+                    f = ln.split()
+                    avg_us = float(f[-2])
+                    out[name] = {"avg_us": avg_us, "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / avg_us / 1e3, 1),
+                                 "frac_of_8TBps": round(nbytes / avg_us / 1e3 / 8000.0, 4)}
+    except (OSError, ValueError, IndexError):
+        pass
+    if out:
+        out["source"] = "profiles/r02_v3_kernel_trace_stats.txt (static; pl_hist is bound by its 20 LDS atomics per pixel, DESIGN.md section 11)"
+    return out
+
+
 def run_batch(P, S, torch, ctx_factory, rank, world, local_rank, barrier):
     """BASELINE.json configs[3]: 256 x 1920x1080 frames over `world` ranks, one device-resident batch per rank."""
     mine = S.contiguous_partition(BATCH_FRAMES, world)[rank]
@@ -313,6 +333,7 @@ def main():
                          "note": "dominant kernel is bound by the serial per-pixel dependency chain (DESIGN.md), "
                                  "not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB per launch; traffic = "
                                  "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
+            "bandwidth_kernels": bandwidth_kernels(),
         }
         line["transfers"] = {"h2d_ms": round(h2d_ms, 3), "d2h_ms": round(d2h_ms, 3), "bytes_each_way": W * H * 4,
                              "note": "pinned 64 MiB frame over PCIe, outside the timed region; with both legs one step "

@@ -122,12 +122,14 @@ __global__ __launch_bounds__(kThreads) void pl_hist(const PlJob *jobs)
     /* natural images put most residuals into a handful of bins, so the 64 lanes of a wave keep hitting the same LDS
      * word; kRep lane-interleaved replicas cut that serialisation kRep-fold (replica = lane & (kRep-1)) */
     constexpr int kRep = 8;
-    __shared__ uint32_t h[kRep][PL_NFILT * PL_NSYM];
+    /* replicas of one bin sit in CONSECUTIVE words = different banks (a [replica][bin] layout would put all of them into one
+     * bank: 1280 words apart) */
+    __shared__ uint32_t h[PL_NFILT * PL_NSYM][kRep];
     const PlJob j = jobs[blockIdx.y];
     const uint32_t bpp = pl_job_bpp(j);
     for (uint32_t i = threadIdx.x; i < kRep * PL_NFILT * PL_NSYM; i += kThreads) (&h[0][0])[i] = 0;
     __syncthreads();
-    uint32_t *const mine = h[threadIdx.x & (kRep - 1)];
+    uint32_t *const mine = &h[0][threadIdx.x & (kRep - 1)];
     const uint32_t W = j.width;
     const size_t n = (size_t)W * j.height;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
@@ -140,18 +142,18 @@ __global__ __launch_bounds__(kThreads) void pl_hist(const PlJob *jobs)
         for (uint32_t c = 0; c < bpp; c++) {
             const int hv = (here >> (8 * c)) & 255, lv = (left >> (8 * c)) & 255;
             const int av = (above >> (8 * c)) & 255, dv = (diag >> (8 * c)) & 255;
-            atomicAdd(&mine[0 * PL_NSYM + (hv & 255)], 1u);
-            atomicAdd(&mine[1 * PL_NSYM + ((hv - lv) & 255)], 1u);
-            atomicAdd(&mine[2 * PL_NSYM + ((hv - av) & 255)], 1u);
-            atomicAdd(&mine[3 * PL_NSYM + ((hv - ((av + lv) >> 1)) & 255)], 1u);
-            atomicAdd(&mine[4 * PL_NSYM + ((hv - pl_paeth(av, dv, lv)) & 255)], 1u);
+            atomicAdd(&mine[(0 * PL_NSYM + (hv & 255)) * kRep], 1u);
+            atomicAdd(&mine[(1 * PL_NSYM + ((hv - lv) & 255)) * kRep], 1u);
+            atomicAdd(&mine[(2 * PL_NSYM + ((hv - av) & 255)) * kRep], 1u);
+            atomicAdd(&mine[(3 * PL_NSYM + ((hv - ((av + lv) >> 1)) & 255)) * kRep], 1u);
+            atomicAdd(&mine[(4 * PL_NSYM + ((hv - pl_paeth(av, dv, lv)) & 255)) * kRep], 1u);
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < PL_NFILT * PL_NSYM; i += kThreads) {
         uint32_t v = 0;
 #pragma unroll
-        for (int r = 0; r < kRep; r++) v += h[r][i];
+        for (int r = 0; r < kRep; r++) v += h[i][r];
         if (v) atomicAdd(&j.orig_hist[i], v);
     }
 }
