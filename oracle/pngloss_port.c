@@ -510,11 +510,16 @@ static void run_chain_lead(const engine *e, uint32_t y, int f, unsigned s, long 
             }
             const int usable = id >= 0 && B[id].usable;
             const int L = usable ? B[id].L : 0;
-            if (usable && forced) {
-                if (L != fv) { why = why ? why : 5; continue; }
+            if (usable && forced && L == fv) {
                 if (!tr[c]) vfast[c] = fv;
                 continue;
             }
+            if (tr[c] && !g.none) {
+                /* a forced symbol does not depend on the histogram either: light, under the same rule (vfast is set above) */
+                light = 1;
+                continue;
+            }
+            if (usable && forced) { why = why ? why : 5; continue; }
             if (usable && L >= lo[c] && L <= lo[c] + 255) { vfast[c] = L; continue; }
             /* no usable leader inside the clamp.  If what the clamp leaves of the band is a single value, that value is the
              * answer whatever the histogram says ("light" pixel: the bump goes to a bin that need not lead any band, and

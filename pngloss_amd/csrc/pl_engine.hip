@@ -988,6 +988,8 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
         t.h1 = (int)en.y; t.e0 = en.x;
         return b;
     };
+    /* (validity tested per pixel here: chunks with transparent pixels are dense in forced symbols that do not lead their band, and
+     * what a burst does behind one is wasted -- bursts of 8 were 13 % slower on the checkerboard frame) */
     for (int i = pos; i <= end; i++) {                        /* the step of pixel `end` (a neutral record) writes the record of end-1 */
         if (__builtin_expect(step(i, ra0, ra1, rc0, rc1), 0)) { bad = true; return i; }
         ra0 = rb0; ra1 = rb1; rb0 = rc0; rb1 = rc1;
@@ -1277,17 +1279,22 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
                     const int osym = pl_sext8(orig - pred), lo = osym - orig;
                     const int filt = osym + e0 + pl_sext16((int)le1) + ((int)le2 >> 16);
                     const int fcl = med3_i32(filt, -256, 255);
-                    const u32x2 ent = k.T[fcl + 256 + ((MODE == 0 && orig >= 128) ? PL_LT_N : 0)];
+                    /* the alpha channel of a fully transparent pixel takes the forced symbol -pred (optimize_state.c:158-164): fine
+                     * iff the band that holds it is usable and led by exactly this value (what the fast run tests, too) */
+                    const bool trlane = TR && chunk_tr && (uint32_t)c == bpp - 1u && ((po >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    const int fsym = pl_sext8(-pred);
+                    const u32x2 ent = k.T[(trlane ? fsym : fcl) + 256 + ((MODE == 0 && !trlane && orig >= 128) ? PL_LT_N : 0)];
                     const int v8 = pl_sext16((int)ent.x);
                     /* per-lane integers instead of lane masks (no VALU -> SALU -> VALU round trips in front of the one decision):
                      * notok != 0: no usable leader inside the clamp;  several != 0: the clamp leaves more than one value */
-                    const uint32_t notok = ((uint32_t)(fcl ^ filt) | ((uint32_t)(v8 - lo * 8) >> 11)) & actbits;
+                    const uint32_t notok = (trlane ? (uint32_t)(v8 ^ (fsym * 8)) : ((uint32_t)(fcl ^ filt) | ((uint32_t)(v8 - lo * 8) >> 11))) & actbits;
                     const int q = k.s + 1, tq = (int)((float)filt * k.rq);
                     const int vmin = tq * q - ((filt >> 31) & k.s), hi = lo + 255;
                     const int cmin = med3_i32(vmin, lo, hi), cmax = med3_i32(vmin + k.s, lo, hi);
-                    const uint32_t several = (MODE != 0 && !(TR && chunk_tr)) ? (uint32_t)(cmin ^ cmax) : 1u;
-                    const int v = notok ? cmin : (v8 >> 3);
-                    back = v - lo; diff = filt - v; bin = v & 255;
+                    /* (a forced symbol is as independent of the histogram as a single value the clamp leaves) */
+                    const uint32_t several = MODE != 0 ? (trlane ? 0u : (uint32_t)(cmin ^ cmax)) : 1u;
+                    const int v = trlane ? fsym : (notok ? cmin : (v8 >> 3));
+                    back = trlane ? 0 : v - lo; diff = trlane ? 0 : filt - v; bin = v & 255;
                     const uint32_t heavyv = notok ? several : 0u;
                     anylight = __builtin_amdgcn_ballot_w64(notok != 0u) != 0;
                     /* (first && !anylight cannot happen -- the run stopped here -- but never hand back without progress) */
