@@ -127,7 +127,9 @@ struct PlEngineParams {
     float rq;       /* nextafterf(1/(strength+1), +inf) */
     float rbleed;   /* nextafterf(1/bleed, +inf)        */
     float r29;      /* 2*nextafterf(1/9, +inf)          */
-    int engine_mode;   /* test hook: 0 = band-leader chains where their preconditions hold (default), 1 = round-1 chains only */
+    int engine_mode;   /* low 4 bits, test hook: 0 = band-leader chains where their preconditions hold, round-1 chains where those are
+                          measurably slow (default), 1 = round-1 chains only, 2 = band-leader chains wherever possible;
+                          bits 8..: debugging aid, 1 + the candidate that wins every row */
     int force_careful; /* test hook: always run the chain variant with explicit int16 wrap handling (normally only
                           rows whose incoming |error| exceeds 8000 use it) */
 };

@@ -609,6 +609,12 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
+#ifndef PL_ADAPT_SLOW
+#define PL_ADAPT_SLOW 600u      /* band-leader rows slower than this many cycles per pixel make the kernel try the round-1 chains */
+#endif
+#ifndef PL_ADAPT_REPROBE
+#define PL_ADAPT_REPROBE 32u
+#endif
 #ifndef PL_PREFETCH_FIX
 #define PL_PREFETCH_FIX 1
 #endif
@@ -1500,6 +1506,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     uint32_t &big_lead = *(uint32_t *)(smem + PL_SM_FLAGS + 4);                       /* ... exceeds PL_E0_LEAD_MAX: the row takes the round-1 chain */
     uint32_t &uniq = *(uint32_t *)(smem + PL_SM_FLAGS + 8);
     uint32_t &simd_map = *(uint32_t *)(smem + PL_SM_FLAGS + 12);                      /* diagnostics */
+    uint32_t &rowcyc = *(uint32_t *)(smem + PL_SM_FLAGS + 16);                        /* cycles of the slowest chain wave of this row attempt */
     uint4 *const rec = (uint4 *)(smem + PL_SM_UNION);                                 /* round-1 chain: chunk records (wave 0 two filters, waves 1..4 one) */
     /* band-leader chain (same region): decision tables, band states, chain records, result rings */
     uint2 *const ltab = (uint2 *)(smem + PL_SM_UNION);
@@ -1527,6 +1534,13 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     __syncthreads();
 
     uint32_t retried = 0, slow_px = 0, light_px = 0, lead_rows = 0, lead_rebuilds = 0;
+    /* Which chains a row takes where both could: the band-leader chains unless the rows they just did were slow (dense slow pixels:
+     * noise with ties everywhere, transparency patterns) AND the round-1 chains, tried on one row, were faster.  Both are exact, so
+     * the choice -- made from cycle counts -- never shows in the results.  est_*: cycles per pixel of the slowest chain wave of
+     * the last row each kind ran (0 = not known); the loser is tried again every PL_ADAPT_REPROBE rows. */
+    uint32_t est_lead = 0, est_legacy = 0, adapt_since = 0, adapt_legacy_rows = 0;
+    bool use_legacy = false, adapt_prev_lead = true, adapt_was_legacy = false;
+    uint32_t adapt_backoff = 2u, adapt_last_lead = ~0u;
     unsigned long long lead_cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long cyc_post = 0, cyc_commit = 0;      /* diagnostics */   /* diagnostics: vector | fast | exact | rescan | table build */
     unsigned long long chain_cycles = 0, segs[4] = { 0, 0, 0, 0 };
@@ -1540,11 +1554,13 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             /* every candidate starts from the committed histogram (optimize_state_copy, pngloss_image.c:240) */
             for (int i = tid; i < PL_NFILT * PL_NSYM; i += PL_ENGINE_THREADS) tbl[i >> 8][i & 255].x = Hc[i & 255];
             for (int i = tid; i < PL_NFILT * 8; i += PL_ENGINE_THREADS) pacc[i] = 0u;
+            if (tid == 0) rowcyc = 0u;
             __syncthreads();
             /* chain phase.  Band-leader chains (round 2): five waves, one per candidate filter -- their fast path has
              * no DPP, and plain VALU/LDS waves sharing a SIMD do not slow each other (profiles/r01_ubench_simd_sharing.txt).
              * Rows that do not meet its preconditions take the round-1 chains below. */
-            const bool lead = (prm.engine_mode & 15) != 1 && s + 1 <= 128 && !wrap && big_lead == 0;
+            const bool lead_ok = (prm.engine_mode & 15) != 1 && s + 1 <= 128 && !wrap && big_lead == 0;
+            const bool lead = lead_ok && !(use_legacy && (prm.engine_mode & 15) == 0);
             const int lead_f = wave == 0 ? 2 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 0)));   /* up | sub | average | paeth | none */
             const bool paired = s + 1 <= 48;
             if (lead) {
@@ -1573,7 +1589,9 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 case 3: chain_lead_dispatch<3>(k, lane); break;
                 default: chain_lead_dispatch<4>(k, lane); break;
                 }
-                chain_cycles += __builtin_readcyclecounter() - t0;
+                const unsigned long long dtc = __builtin_readcyclecounter() - t0;
+                chain_cycles += dtc;
+                if (lane == 0) atomicMax(&rowcyc, (uint32_t)min(dtc, 0xffffffffull));
                 slow_px += k.slow;
                 light_px += k.light;
                 lead_rebuilds += k.rebuilds;
@@ -1607,11 +1625,33 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 case 3: chain_dispatch<4>(k, lane, wrap); break;
                 default: chain_dispatch<2>(k, lane, wrap); break;
                 }
-                chain_cycles += __builtin_readcyclecounter() - t0;
+                const unsigned long long dtc = __builtin_readcyclecounter() - t0;
+                chain_cycles += dtc;
+                if (lane == 0) atomicMax(&rowcyc, (uint32_t)min(dtc, 0xffffffffull));
                 slow_px += k.slow;
                 if (PL_SEGPROF) for (int q = 0; q < 4; q++) segs[q] += k.seg[q];
             }
             __syncthreads();   /* candidate rows (global, same CU) and histograms (LDS) complete and visible */
+            if (lead_ok && (prm.engine_mode & 15) == 0) {
+                const uint32_t pp = rowcyc / W + 1u;
+                /* (band-leader rows: the faster of the last two, so that a single slow row -- they exist, 7x the average -- is not a reason to switch) */
+                if (lead) { est_lead = adapt_prev_lead ? min(pp, adapt_last_lead) : pp; adapt_last_lead = pp; }
+                else { est_legacy = (!adapt_prev_lead && est_legacy) ? (est_legacy + pp) >> 1 : pp; adapt_legacy_rows++; }
+                adapt_prev_lead = lead;
+                if (est_lead <= PL_ADAPT_SLOW) { use_legacy = false; adapt_since = 0; adapt_backoff = 2u; }
+                else if (est_legacy == 0) use_legacy = true;                       /* first try of the round-1 chains */
+                else {
+                    /* The loser runs a row now and then.  While the round-1 chains win, the band-leader chains are tried again after
+                     * 2, 4, 8 .. PL_ADAPT_REPROBE rows (a single slow row must not cost 32 rows of the slower engine; a slow region
+                     * is probed rarely); the round-1 chains are retried every PL_ADAPT_REPROBE rows when close behind, else rarely. */
+                    const bool legacy_better = 21u * est_legacy < 20u * est_lead;
+                    if (lead && legacy_better && adapt_was_legacy) adapt_backoff = min(2u * adapt_backoff, PL_ADAPT_REPROBE);   /* a probe lost */
+                    const uint32_t every = legacy_better ? adapt_backoff : (10u * est_legacy < 13u * est_lead ? PL_ADAPT_REPROBE : 256u);
+                    if (++adapt_since >= every) { use_legacy = !legacy_better; adapt_since = 0; }
+                    else use_legacy = legacy_better;
+                }
+                adapt_was_legacy = !lead;
+            }
             const unsigned long long tpp0 = __builtin_readcyclecounter();
             /* post pass: all threads, all candidates (the accumulators were zeroed before the chain phase) */
             post_pass_all(j, y, bpp, tbl, adaptive, tid, pacc);
@@ -1738,6 +1778,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     }
     __syncthreads();
     if (tid == 0) j.result[7] = (int32_t)simd_map;
+    if (tid == 0) { j.result[22] = (int32_t)est_lead; j.result[23] = (int32_t)est_legacy; }
+    if (tid == 0) j.result[21] = (int32_t)adapt_legacy_rows;   /* rows that took the round-1 chains by the adaptive choice */
     if (lane == 0 && wave == 4) {
         j.result[24] = (int32_t)(chain_cycles >> 10);
         j.result[25] = (int32_t)slow_px;

@@ -175,7 +175,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     prm.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;   /* test hook, see pl_device.h */
     {
         const char *em = std::getenv("PNGLOSS_HIP_ENGINE");                     /* test hook: "legacy" = round-1 chains only */
-        prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : 0;
+        prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : ((em && std::strcmp(em, "lead") == 0) ? 2 : 0);   /* "lead": never fall back adaptively */
         if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) prm.engine_mode |= (std::atoi(ff) + 1) << 8;   /* debugging aid */
     }
 
@@ -234,7 +234,7 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
             std::fprintf(stderr, "pngloss_hip:   SIMD of waves 0..7: %d %d %d %d %d %d %d %d\n", r[7] & 3, (r[7] >> 2) & 3, (r[7] >> 4) & 3, (r[7] >> 6) & 3,
                          (r[7] >> 8) & 3, (r[7] >> 10) & 3, (r[7] >> 12) & 3, (r[7] >> 14) & 3);
         if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
-            std::fprintf(stderr, "pngloss_hip:   light pixels per chain wave %d %d %d %d %d\n", r[16], r[17], r[18], r[19], r[20]);
+            std::fprintf(stderr, "pngloss_hip:   light pixels per chain wave %d %d %d %d %d; rows on the round-1 chains by the adaptive choice %d (last cycles per pixel: band-leader %d, round-1 %d)\n", r[16], r[17], r[18], r[19], r[20], r[21], r[22], r[23]);
         if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[16])   /* (engine built with PL_SEGPROF) */
             for (int w = 0; w < 4; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,

@@ -295,7 +295,19 @@ def test_round1_chains_still_match_the_oracle():
     assert r.returncode == 0 and "legacy ok" in r.stdout, r.stderr[-1500:]
 
 
-def test_band_leader_chains_on_hostile_inputs():
+@pytest.fixture(params=["adaptive", "lead"])
+def engine_choice(request, monkeypatch):
+    """The shipped kernel picks, row by row, between the band-leader chains and the round-1 chains where the former are measurably
+    slow (dense slow pixels); "lead" pins the band-leader chains so that hostile inputs keep exercising THEM (the library reads the
+    variable on every call)."""
+    if request.param == "lead":
+        monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "lead")
+    else:
+        monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
+    return request.param
+
+
+def test_band_leader_chains_on_hostile_inputs(engine_choice):
     """Inputs chosen against the band-leader chains: noise (every band in use, ties everywhere), values around 128 (filter
     none's positive and negative bands compete for the same bins), saturated and fully transparent regions (static and
     dynamic clamps, forced symbols), widths around the 64-pixel chunk, large strengths (few, wide bands)."""
@@ -315,7 +327,7 @@ def test_band_leader_chains_on_hostile_inputs():
         assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (i, img.shape, s, b)
 
 
-def test_light_pixels_and_deferred_bumps_on_saturated_frames():
+def test_light_pixels_and_deferred_bumps_on_saturated_frames(engine_choice):
     """Saturated and nearly saturated regions: the clamp [lo, lo+255] cuts bands down to one value ("light" pixels, settled without
     reading the histogram, bumps deferred and checked at the next flush) or to a few (exact redo behind a flush), next to ordinary
     fast pixels.  Frames large enough for big histogram counts, so that the watched relations and their close-bin map matter;

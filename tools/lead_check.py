@@ -1,6 +1,7 @@
 """Developer tool (GPU box): band-leader row engine vs the CPU oracle on a set of synthetic cases; prints the first
 mismatching row/pixel.  usage: python tools/lead_check.py [quick|full]"""
 import os, sys, time
+os.environ.setdefault("PNGLOSS_HIP_ENGINE", "lead")   # this tool is about the band-leader chains: no adaptive fallback to the round-1 chains
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pngloss_amd import lib, synth
