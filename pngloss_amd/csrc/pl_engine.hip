@@ -609,6 +609,7 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
+#define PL_PAETH_BIAS (1u << 27)
 #ifndef PL_ADAPT_SLOW
 #define PL_ADAPT_SLOW 600u      /* band-leader rows slower than this many cycles per pixel make the kernel try the round-1 chains */
 #endif
@@ -974,9 +975,8 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
             /* Paeth without compares: key = distance << 14 | priority << 12 | (8*(orig - candidate) + 2048); the minimum
              * key is the predictor the reference picks (left, then above, then upper-left on ties, optimize_state.c:600-613)
              * and its low 11 bits are 8*osym already */
-            const uint32_t pa = sad_u32((uint32_t)back8p, r0.x);
-            const uint32_t pg = sad_u32((uint32_t)back8p + r0.y, r0.z);
-            const uint32_t kA = (pa << 14) | r1.x, kD = (pg << 14) | r1.y, kL = r0.w - (uint32_t)back8p;
+            const uint32_t b14 = ((uint32_t)back8p << 14) + PL_PAETH_BIAS;
+            const uint32_t kA = sad_u32(b14, r0.x) + r1.x, kD = sad_u32(b14, r0.y) + r1.y, kL = r0.w - (uint32_t)back8p;
             const uint32_t m3 = min(min(kL, kA), kD);
             const int orig8 = (int)(r1.z & 0x7fffffffu);
             const int osym8 = __builtin_amdgcn_sbfe((int)m3, 0, 11);
@@ -1009,7 +1009,7 @@ __device__ __forceinline__ int lead_fast_run(lds_uint4 *R, lds_uint2 *OUT, lds_u
  *   none/up : { 8*osym + 8*e0 + TB, 8*lo, forced address (TB + 8*sext8(-pred)), tr }
  *   sub     : { 8*orig, 8*e0 + TB, tr, - }
  *   average : { orig, 8*e0 + TB, 8*above, -8*orig (tr in chunks that hold a transparent pixel) }
- *   paeth   : { 8*diag, 8*above, 16*diag, (8*|above-diag| << 14) + 8*orig + 2048 }
+ *   paeth   : { (8*diag << 14) + BIAS, (8*(2*diag-above) << 14) + BIAS, -, (8*|above-diag| << 14) + 8*orig + 2048 }
  *             { (1<<12) + 8*(orig-above) + 2048, (2<<12) + 8*(orig-diag) + 2048, 8*orig | tr<<31, 8*e0 + TB }
  * --------------------------------------------------------------------------------------------------------- */
 template <int MODE, bool TR>
@@ -1089,7 +1089,9 @@ __device__ __forceinline__ void chain_lead(LeadCtx &kref, const int lane)
             } else if (MODE == 3) {
                 R[idx * 4 + cc] = (u32x4){ (uint32_t)orig, (uint32_t)e0tb, (uint32_t)(above * 8), chunk_tr ? trf : (uint32_t)(-8 * orig) };
             } else {
-                R[(idx * 4 + cc) * 2] = (u32x4){ (uint32_t)(diag * 8), (uint32_t)(above * 8), (uint32_t)(diag * 16),
+                /* distances in key position already: |8*left - 8*diag| << 14 = |(8*left << 14) + BIAS - x|, the same for
+                 * |8*left + 8*above - 16*diag| with y (BIAS keeps both operands of the unsigned v_sad_u32 positive) */
+                R[(idx * 4 + cc) * 2] = (u32x4){ ((uint32_t)(diag * 8) << 14) + PL_PAETH_BIAS, ((uint32_t)((2 * diag - above) * 8) << 14) + PL_PAETH_BIAS, 0u,
                                                  ((uint32_t)(abs(above - diag) * 8) << 14) + (uint32_t)(orig * 8 + 2048) };
                 R[(idx * 4 + cc) * 2 + 1] = (u32x4){ (1u << 12) + (uint32_t)((orig - above) * 8 + 2048), (2u << 12) + (uint32_t)((orig - diag) * 8 + 2048),
                                                      (uint32_t)(orig * 8) | (trf << 31), (uint32_t)e0tb };

@@ -137,16 +137,14 @@ def step(mode, k):
         L.append(f"v_lshl_add_u32 {v(an)}, {v(OSYM)}, 3, {v(T0)}")
         L.append(f"ds_read_b64 {vr(en[0], 2)}, {v(an)}")
     else:
-        # records: q  = { 8*diag, 8*above, 16*diag, (8*|above-diag| << 14) + 8*orig + 2048 }
+        # records: q  = { (8*diag << 14) + BIAS, (8*(2*diag-above) << 14) + BIAS, -, (8*|above-diag| << 14) + 8*orig + 2048 }
         #          q2 = { (1<<12) + 8*(orig-above) + 2048, (2<<12) + 8*(orig-diag) + 2048, 8*orig, 8*e0 + TB }
         q2 = Q2[k]
         L.append(f"v_sub_u32_sdwa {v(BACK)}, sext({v(ep[0])}), {v(LO)} {SDWA_W0}")
-        L.append(f"v_sad_u32 {v(T0)}, {v(BACK)}, {v(q)}, 0")
-        L.append(f"v_add_u32_e32 {v(T1)}, {v(BACK)}, {v(q + 1)}")
-        L.append(f"v_sad_u32 {v(T1)}, {v(T1)}, {v(q + 2)}, 0")
-        L.append(f"v_lshl_or_b32 {v(T0)}, {v(T0)}, 14, {v(q2)}")
-        L.append(f"v_lshl_or_b32 {v(T1)}, {v(T1)}, 14, {v(q2 + 1)}")
-        L.append(f"v_sub_u32_e32 {v(T2)}, {v(q + 3)}, {v(BACK)}")
+        L.append(f"v_lshl_add_u32 {v(T3)}, {v(BACK)}, 14, %[bias]")      # (8*left << 14) + BIAS
+        L.append(f"v_sub_u32_e32 {v(T2)}, {v(q + 3)}, {v(BACK)}")         # key of 'left'
+        L.append(f"v_sad_u32 {v(T0)}, {v(T3)}, {v(q)}, {v(q2)}")          # key of 'above':      |left - diag| << 14 | ...
+        L.append(f"v_sad_u32 {v(T1)}, {v(T3)}, {v(q + 1)}, {v(q2 + 1)}")  # key of 'upper left': |left + above - 2 diag| << 14 | ...
         L.append(f"v_min3_u32 {v(T0)}, {v(T2)}, {v(T0)}, {v(T1)}")
         L.append(f"v_bfe_i32 {v(OSYM)}, {v(T0)}, 0, 11")
         L.append(f"v_add_u32_sdwa {v(T0)}, sext({v(ep[0])}), {v(PRE)} {SDWA_W1}")
@@ -271,7 +269,7 @@ def emit(mode, name):
         outs += [f'[qa{j}] "+v"(qa{j})', f'[qb{j}] "+v"(qb{j})']
         if rw == 2:
             outs += [f'[qc{j}] "+v"(qc{j})', f'[qd{j}] "+v"(qd{j})']
-    ins = ['[rptr] "v"(rptr)', '[optr] "v"(optr)', '[c2047] "s"(2047u)']
+    ins = ['[rptr] "v"(rptr)', '[optr] "v"(optr)', '[c2047] "s"(2047u)', '[bias] "s"(1u << 27)']
     hi = 256 if rw == 2 else 240
     clob = ", ".join([f'"v{n}"' for n in range(200, hi)] + ['"vcc"', '"scc"', '"memory"'])
     out.append("        : " + ", ".join(outs))
