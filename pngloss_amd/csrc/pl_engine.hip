@@ -595,10 +595,18 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
     const int v0 = band_lo(g, id), v1 = band_hi(g, id);
     u32x2 e = H[v0 & 255];
     int L = v0; uint32_t bh = e.x, br = e.y; bool uniq = true;
-    for (int v = v0 + 1; v <= v1; v++) {
-        e = H[v & 255];
-        if (e.x > bh || (e.x == bh && e.y > br)) { L = v; bh = e.x; br = e.y; uniq = true; }
-        else if (e.x == bh && e.y == br) uniq = false;
+    /* four bins per round trip (the loads do not depend on the comparisons) */
+    for (int v = v0 + 1; v <= v1; v += 4) {
+        u32x2 e4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) e4[i] = H[min(v + i, v1) & 255];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (v + i <= v1) {
+                if (e4[i].x > bh || (e4[i].x == bh && e4[i].y > br)) { L = v + i; bh = e4[i].x; br = e4[i].y; uniq = true; }
+                else if (e4[i].x == bh && e4[i].y == br) uniq = false;
+            }
+        }
     }
     return (uint32_t)(L + 256) | (uniq ? 512u : 0u);
 }
@@ -697,9 +705,13 @@ __device__ __forceinline__ void lead_build_table(const LeadCtx &k, const LeadGeo
     }
     wave_lds_sync();
     const int ntab = g.none ? 2 : 1;
-    for (int idx = lane; idx < ntab * PL_LT_N; idx += 64) {
-        const int tab = idx >> 9, filt = (idx & 511) - 256;
-        k.T[idx] = lead_entry_at(g, k.bs, k.lut, filt, tab);
+    /* (four entries per lane and pass: their band-state and split-table reads are in flight together) */
+    for (int idx = lane; idx < ntab * PL_LT_N; idx += 256) {
+        u32x2 ent[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ent[u] = lead_entry_at(g, k.bs, k.lut, ((idx + 64 * u) & 511) - 256, (idx + 64 * u) >> 9);
+#pragma unroll
+        for (int u = 0; u < 4; u++) k.T[idx + 64 * u] = ent[u];
     }
     wave_lds_sync();
     lead_collect_relations(k, g, lane, 0);
