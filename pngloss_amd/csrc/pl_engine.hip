@@ -617,6 +617,9 @@ __device__ __forceinline__ uint32_t lead_scan_serial(const LeadGeo &g, lds_uint2
  * all such pairs (work[41] = count) is rebuilt after every change of band states; lead_flush checks it against the bumps it is
  * about to apply.  A band whose relation finds no room in the list is made unusable (safe; only with very many tiny bands). */
 #define PL_LREL_MAX 64
+#ifndef PL_POST_EARLY
+#define PL_POST_EARLY 2u        /* how many of the first chains to finish do their own candidate's post pass (0: none) */
+#endif
 #define PL_PAETH_BIAS (1u << 27)
 #ifndef PL_ADAPT_SLOW
 #define PL_ADAPT_SLOW 600u      /* band-leader rows slower than this many cycles per pixel make the kernel try the round-1 chains */
@@ -1413,7 +1416,10 @@ __device__ __noinline__ void chain_lead_dispatch(LeadCtx &k, int lane)
 /* All five candidates at once, parallel over x with every thread of the workgroup: the neighbourhood of a pixel (original
  * and optimised rows) is loaded once for the five candidates; per-wave partial sums go to the LDS accumulators
  * acc[f] = { derr (u64 as two u32 adds: low, high), cost, hs[5] } (8 words per candidate, zeroed by the caller). */
-__device__ void post_pass_all(const PlJob &j, uint32_t y, uint32_t bpp, const uint2 (*tbl)[PL_TBL_N], bool adaptive, int tid, uint32_t *acc)
+/* (first, stride): the pixels this thread takes -- (tid, workgroup size) for the joint pass, (lane, 64) when one wave does a
+ * candidate of its own while the other chains still run; fmask: the candidates to do */
+__device__ void post_pass_all(const PlJob &j, uint32_t y, uint32_t bpp, const uint2 (*tbl)[PL_TBL_N], bool adaptive, int tid, uint32_t *acc,
+                              uint32_t first, uint32_t stride, uint32_t fmask)
 {
     const uint32_t W = j.width;
     const uint32_t *row = j.img + (size_t)y * W;
@@ -1421,12 +1427,13 @@ __device__ void post_pass_all(const PlJob &j, uint32_t y, uint32_t bpp, const ui
     uint64_t derr[PL_NFILT] = { 0, 0, 0, 0, 0 };
     uint32_t cost[PL_NFILT] = { 0, 0, 0, 0, 0 };
     uint32_t hs[PL_NFILT][PL_NFILT] = { { 0 } };
-    for (uint32_t x = tid; x < W; x += PL_ENGINE_THREADS) {
+    for (uint32_t x = first; x < W; x += stride) {
         const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
         const uint32_t na = nab ? nab[x] : 0u, nd = (nab && x) ? nab[x - 1] : 0u;
         const uint32_t oa = y ? j.old_above[x] : 0u, od = (y && x) ? j.old_above[x - 1] : 0u;
 #pragma unroll
         for (int f = 0; f < PL_NFILT; f++) {
+            if (!((fmask >> f) & 1u)) continue;
             const uint4 cw = j.cand[(size_t)f * W + x];
             const uint4 cl = x ? j.cand[(size_t)f * W + x - 1] : make_uint4(0, 0, 0, 0);
             const uint32_t cws[4] = { cw.x, cw.y, cw.z, cw.w }, cls[4] = { cl.x, cl.y, cl.z, cl.w };
@@ -1459,6 +1466,7 @@ __device__ void post_pass_all(const PlJob &j, uint32_t y, uint32_t bpp, const ui
     const int lane = tid & 63;
 #pragma unroll
     for (int f = 0; f < PL_NFILT; f++) {
+        if (!((fmask >> f) & 1u)) continue;
         const uint64_t d = wave_sum_u64(derr[f]);
         const uint32_t cs = wave_sum_u32(cost[f]);
         if (lane == 0) {
@@ -1520,6 +1528,8 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     uint32_t &big_lead = *(uint32_t *)(smem + PL_SM_FLAGS + 4);                       /* ... exceeds PL_E0_LEAD_MAX: the row takes the round-1 chain */
     uint32_t &uniq = *(uint32_t *)(smem + PL_SM_FLAGS + 8);
     uint32_t &simd_map = *(uint32_t *)(smem + PL_SM_FLAGS + 12);                      /* diagnostics */
+    uint32_t &chains_done = *(uint32_t *)(smem + PL_SM_FLAGS + 20);                   /* chain waves that finished this row attempt */
+    uint32_t &post_done = *(uint32_t *)(smem + PL_SM_FLAGS + 24);                     /* candidates whose post pass their own wave already did */
     uint32_t &rowcyc = *(uint32_t *)(smem + PL_SM_FLAGS + 16);                        /* cycles of the slowest chain wave of this row attempt */
     uint4 *const rec = (uint4 *)(smem + PL_SM_UNION);                                 /* round-1 chain: chunk records (wave 0 two filters, waves 1..4 one) */
     /* band-leader chain (same region): decision tables, band states, chain records, result rings */
@@ -1568,7 +1578,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             /* every candidate starts from the committed histogram (optimize_state_copy, pngloss_image.c:240) */
             for (int i = tid; i < PL_NFILT * PL_NSYM; i += PL_ENGINE_THREADS) tbl[i >> 8][i & 255].x = Hc[i & 255];
             for (int i = tid; i < PL_NFILT * 8; i += PL_ENGINE_THREADS) pacc[i] = 0u;
-            if (tid == 0) rowcyc = 0u;
+            if (tid == 0) { rowcyc = 0u; chains_done = 0u; post_done = 0u; }
             __syncthreads();
             /* chain phase.  Band-leader chains (round 2): five waves, one per candidate filter -- their fast path has
              * no DPP, and plain VALU/LDS waves sharing a SIMD do not slow each other (profiles/r01_ubench_simd_sharing.txt).
@@ -1606,6 +1616,19 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 const unsigned long long dtc = __builtin_readcyclecounter() - t0;
                 chain_cycles += dtc;
                 if (lane == 0) atomicMax(&rowcyc, (uint32_t)min(dtc, 0xffffffffull));
+#if PL_POST_EARLY
+                {   /* the first chains to finish (usually up and none, well ahead of sub / average / paeth) do the post pass of their
+                     * own candidate while the others still run: that much less for the joint pass behind the barrier */
+                    uint32_t order = 0;
+                    if (lane == 0) order = atomicAdd(&chains_done, 1u);
+                    order = (uint32_t)__builtin_amdgcn_readfirstlane((int)order);
+                    if (order < PL_POST_EARLY) {
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      /* this wave's candidate row is complete and visible to itself */
+                        post_pass_all(j, y, bpp, tbl, adaptive, tid, pacc, (uint32_t)lane, 64u, 1u << lead_f);
+                        if (lane == 0) atomicOr(&post_done, 1u << lead_f);
+                    }
+                }
+#endif
                 slow_px += k.slow;
                 light_px += k.light;
                 lead_rebuilds += k.rebuilds;
@@ -1668,7 +1691,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             }
             const unsigned long long tpp0 = __builtin_readcyclecounter();
             /* post pass: all threads, all candidates (the accumulators were zeroed before the chain phase) */
-            post_pass_all(j, y, bpp, tbl, adaptive, tid, pacc);
+            post_pass_all(j, y, bpp, tbl, adaptive, tid, pacc, (uint32_t)tid, PL_ENGINE_THREADS, 31u & ~post_done);
             cyc_post += __builtin_readcyclecounter() - tpp0;
             __syncthreads();
             if (tid < PL_NFILT) {
