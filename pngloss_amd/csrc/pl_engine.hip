@@ -8,20 +8,23 @@
  *     adaptive_filter_for_rows  /root/reference/src/optimize_state.c:492-562
  *     color_delta.c             /root/reference/src/color_delta.c:4-66
  *
- * Mapping (one workgroup = one image, blockIdx.x = image of the batch; 5 wavefronts of 64):
+ * One workgroup = one image (blockIdx.x = image of the batch), 8 wavefronts, persistent over all rows.  The five candidate
+ * filters of a row are independent (pngloss_image.c:213,240): waves 0..4 run their serial chains concurrently (up, sub,
+ * average, paeth, none); all eight waves run the passes that are parallel over x (post pass, commit).
  *
- *   wave f (0..4)      = candidate PNG filter f (none, sub, up, average, paeth) -- the five candidates of a row are
- *                        independent (pngloss_image.c:213,240), so they run concurrently on the CU's SIMDs.
- *   lanes 16c..16c+15  = channel c of the current pixel (a DPP "row"); the 16 lanes hold the <= s+1 candidate
- *                        symbols of that channel's band (optimize_state.c:186-214), ceil((s+1)/16) per lane.
- *
- * Per pixel the wave does: predict -> re-centre -> band -> clamp (uniform per 16-lane row), gathers
- * {running frequency, rank of original frequency} for its candidates from the wave's private LDS table, arg-maxes
- * the reference's 4-level key with two 4-step DPP row reductions, then repairs the only coupling between the four
- * channels of a pixel -- the histogram increments of the earlier channels (optimize_state.c:221,253) -- exactly, by
- * re-evaluating just the <= 3 bins those channels incremented.  The Sierra terms that feed the same row
- * (x+1, x+2) stay in registers; the eight terms for the next two rows, the derivative error metric, libpng's
- * heuristic and the entropy cost are deferred to passes that are parallel over x (64 pixels per instruction).
+ * Two formulations of the chain live here, both exact:
+ *   band-leader chains (round 2, chain_lead; section "BAND-LEADER CHAINS" below): per pixel and channel ONE
+ *     dependent LDS lookup in a decision table built from the leaders of the quantisation bands, hand-scheduled loops
+ *     (pl_lead_asm.h) on four lanes, histogram bumps deferred and applied 64 pixels at a time under a rule that keeps the table
+ *     true (watched relations), exceptions settled without the histogram where it cannot matter (light pixels) and by the
+ *     round-1 evaluation otherwise;
+ *   round-1 chains (chain_row): lanes 16c..16c+15 = channel c of the current pixel (a DPP row) hold the <= s+1 candidate symbols
+ *     of that channel's band (optimize_state.c:186-214); per pixel: predict -> re-centre -> band -> clamp, gather of {running
+ *     frequency, rank of original frequency}, two DPP arg-max reductions of the reference's 4-level key, exact repair of the
+ *     coupling between the channels of a pixel (optimize_state.c:221,253).  They take the rows the band-leader chains cannot
+ *     (q > 128, exploding errors) and the rows where those are measurably slower (adaptive choice per row, from cycle counts).
+ * The Sierra terms that feed the same row (x+1, x+2) ride in the table entries / registers; the eight terms for the next two
+ * rows, the derivative error metric, libpng's heuristic and the entropy cost are deferred to the passes parallel over x.
  *
  * The x-chain and the row-to-row dependence through the winner's histogram are inherently serial (SURVEY.md
  * Appendix C): this kernel is bound by that dependency chain, not by HBM and not by MFMA.
@@ -455,18 +458,20 @@ __device__ __noinline__ void chain_dispatch(RowCtx &k, int lane, bool wrap)
  *
  * Without the clamp, the candidate set of a channel is one member of a FIXED partition of v-space into bands
  * [tq, tq+s] (filt >= 0) / [-tq-s, -tq] (filt < 0) (optimize_state.c:186-193) and the choice inside it is the arg-max
- * of (H[v], O_f[v], v==osym, -v) (:212-244).  Per "near" band (inside |v| <= 127, so that only bin 0 sits in two
- * tracked bands) the chain keeps the band's LEADER L = argmax (H, O_f, -v) and whether that maximum of (H, O_f) is
- * unique, folded into a decision table indexed by filt:  T[filt] = { 8*L | 8*rem(filt-L) << 16, 8*thr(filt-L) }.
+ * of (H[v], O_f[v], v==osym, -v) (:212-244).  Per band the chain keeps the band's LEADER L = argmax (H, O_f, -v) and whether that
+ * maximum of (H, O_f) is unique, folded into a decision table indexed by filt:  T[filt] = { 8*L | 8*rem(filt-L) << 16, 8*thr(filt-L) }.
  * A channel whose band is usable and whose leader is reconstructable (lo <= L <= hi, the clamp of :195-210) chooses
  * exactly L, and bumping a unique leader changes no band's leader: the four channels of a pixel decouple, the
  * histogram is not read at all on this path (its bumps are applied later, 64 pixels per instruction), and one pixel
  * step is ONE dependent LDS lookup plus a handful of adds -- instead of a gather, two DPP reductions and a coupling
  * check.  Everything is kept scaled by 8 (the byte size of a table entry) so that filt IS the table address.
- * A pixel whose table entry is unusable (tie at the top, far band, leader clamped away, forced transparent-alpha
- * symbol that is not its band's leader) shows up as a reconstructed byte outside [0,255]; it is detected per group of
- * PL_LGROUP pixels, and the first such pixel is redone by the exact gather/arg-max/repair step of round 1, after
- * which the bands its bumps touched are rescanned and their table entries rewritten.
+ * Bands of opposite sign overlap in histogram bins; the rule that keeps every usable band's state true under deferred bumps is
+ * the WATCHED RELATIONS rule further down (checked when the bumps are applied, lead_flush / flush_verify).
+ * A pixel whose table entry is unusable (tie at the top, band not tracked, leader clamped away, forced transparent-alpha
+ * symbol that is not its band's leader) shows up as a reconstructed byte outside [0,255]; it is detected per burst of 8-16
+ * pixels, and from the first such pixel on the slow section of chain_lead classifies pixel by pixel: back to the loop, LIGHT
+ * (the answer does not depend on the histogram: a clamp that leaves one value, a forced symbol) or exact (the gather / arg-max /
+ * repair step of round 1, after which the bands its bump touched are rescanned and their table entries rewritten).
  * Preconditions (else the row runs the round-1 chain): q <= 128 and every incoming Sierra error of the row
  * |E0| <= 88, which bounds |filt| <= 252 -- so table addresses need no clamp.
  * ========================================================================================================= */
