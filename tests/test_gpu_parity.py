@@ -24,6 +24,18 @@ def torch_cuda():
     return torch
 
 
+@pytest.fixture(params=["adaptive", "lead"])
+def engine_choice(request, monkeypatch):
+    """The shipped kernel picks, row by row, between the band-leader chains and the round-1 chains where the former are measurably
+    slow (dense slow pixels); "lead" pins the band-leader chains so that hostile inputs keep exercising THEM (the library reads the
+    variable on every call)."""
+    if request.param == "lead":
+        monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "lead")
+    else:
+        monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
+    return request.param
+
+
 def test_extension_is_loaded_and_sees_the_gpu():
     lib = P.hip_lib()
     assert lib.pngloss_hip_device_count() >= 1
@@ -213,8 +225,9 @@ def test_reference_digests_1080p_frames():
         assert "%016x" % P.fnv1a64(f, P.SURVEY_FNV_BASIS) == e["filters"], e
 
 
-def test_reference_digest_headline_4096(torch_cuda):
-    """BASELINE.json configs[1]: 4096x4096 synthetic RGBA8, s=19, b=2 -- digests measured on the real reference."""
+def test_reference_digest_headline_4096(torch_cuda, engine_choice):
+    """BASELINE.json configs[1]: 4096x4096 synthetic RGBA8, s=19, b=2 -- digests measured on the real reference (with the
+    kernel's adaptive choice of chains, and with the band-leader chains pinned)."""
     e = [e for e in U.load_digests()["synthetic"] if e["width"] == 4096][0]
     img = P.synth_rgba(4096, 4096, 0, 0)
     assert "%016x" % P.fnv1a64(img, P.SURVEY_FNV_BASIS) == e["in"]
@@ -293,18 +306,6 @@ def test_round1_chains_still_match_the_oracle():
     env = dict(os.environ, PNGLOSS_HIP_ENGINE="legacy")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "legacy ok" in r.stdout, r.stderr[-1500:]
-
-
-@pytest.fixture(params=["adaptive", "lead"])
-def engine_choice(request, monkeypatch):
-    """The shipped kernel picks, row by row, between the band-leader chains and the round-1 chains where the former are measurably
-    slow (dense slow pixels); "lead" pins the band-leader chains so that hostile inputs keep exercising THEM (the library reads the
-    variable on every call)."""
-    if request.param == "lead":
-        monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "lead")
-    else:
-        monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
-    return request.param
 
 
 def test_band_leader_chains_on_hostile_inputs(engine_choice):
