@@ -1515,6 +1515,7 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_L_OUT (PL_SM_L_REC + (PL_NFILT + 1) * PL_SM_L_REC_WAVE)
 #define PL_SM_L_OUT_WAVE ((PL_LCHUNK + 2 + 8) * 4 * 8)
 #define PL_SM_LEAD_BYTES (PL_SM_L_OUT + PL_NFILT * PL_SM_L_OUT_WAVE)
+#define PL_SM_COMMIT_BYTES (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES)   /* what the commit pass may use of the chains' region */
 #define PL_SM_TOTAL (4096 + PL_SM_UNION + (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES))
 
 __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs, PlEngineParams prm)
@@ -1735,6 +1736,62 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
         uint32_t *__restrict__ oldab = j.old_above;
         uint2 *__restrict__ perr0 = j.err0, *__restrict__ perr1 = j.err1;
         const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
+        /* next-rows Sierra terms of one pixel and channel (optimize_state.c:446-465): t | f << 8 | v << 16 | h << 24 (int8 each) from the
+         * 512-entry LDS table of the split for |diff| <= 255, else by the float arithmetic of pl_sierra_split */
+        auto terms_of = [&](const uint4 v, const int ch) -> uint32_t {
+            const uint32_t w = ch == 0 ? v.x : (ch == 1 ? v.y : (ch == 2 ? v.z : v.w));
+            const int diff = pl_sext16((int)(w >> 8));
+            if (diff >= -256 && diff <= 255) return split_lut2[diff + 256];
+            const PlSplit sp = pl_sierra_split(diff, prm.rbleed, r29);
+            return ((uint32_t)(int)sp.t & 255u) | (((uint32_t)(int)sp.f & 255u) << 8) | (((uint32_t)(int)sp.v & 255u) << 16) | ((uint32_t)(int)sp.h << 24);
+        };
+        const auto T_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 0, 8); };
+        const auto F_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 8, 8); };
+        const auto V_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 16, 8); };
+        const auto H_ = [](uint32_t e) { return (int)e >> 24; };
+        if ((size_t)W * 16u <= (size_t)PL_SM_COMMIT_BYTES) {
+            /* Two passes over the row through LDS (the chains' region is free now): every pixel's terms are looked up ONCE -- four
+             * words, one per error plane -- and its four neighbours read them from there, instead of five pixels x four planes of
+             * lookups per pixel. */
+            uint4 *const tterms = (uint4 *)(smem + PL_SM_UNION);
+#pragma unroll 4
+            for (uint32_t x = tid; x < W; x += PL_ENGINE_THREADS) {
+                const uint4 cw = cd[x];
+                const uint32_t np = ((cw.x & 255u) | ((cw.y & 255u) << 8) | ((cw.z & 255u) << 16) | ((cw.w & 255u) << 24)) & keep;
+                oldab[x] = rowp[x];
+                rowp[x] = np;
+                uint32_t tw[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int ch = pl_channel_of_plane(bpp, p);
+                    tw[p] = ch >= 0 ? terms_of(cw, ch) : 0u;
+                }
+                tterms[x] = make_uint4(tw[0], tw[1], tw[2], tw[3]);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (uint32_t x = tid; x < W; x += PL_ENGINE_THREADS) {
+                const uint2 e1 = perr1[x];
+                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);      /* (outside the row: diff 0, whose terms are 0) */
+                const uint4 m2 = x >= 2 ? tterms[x - 2] : z4, m1 = x >= 1 ? tterms[x - 1] : z4, z0 = tterms[x];
+                const uint4 p1 = x + 1 < W ? tterms[x + 1] : z4, p2 = x + 2 < W ? tterms[x + 2] : z4;
+                const uint32_t am2[4] = { m2.x, m2.y, m2.z, m2.w }, am1[4] = { m1.x, m1.y, m1.z, m1.w }, az0[4] = { z0.x, z0.y, z0.z, z0.w };
+                const uint32_t ap1[4] = { p1.x, p1.y, p1.z, p1.w }, ap2[4] = { p2.x, p2.y, p2.z, p2.w };
+                uint32_t n0[4], n1[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t e1p = p < 2 ? (e1.x >> (16 * p)) : (e1.y >> (16 * (p - 2)));
+                    const int c1 = T_(ap2[p]) + F_(ap1[p]) + V_(az0[p]) + F_(am1[p]) + T_(am2[p]);
+                    const int c2 = T_(ap1[p]) + H_(az0[p]) + T_(am1[p]);
+                    n0[p] = (uint32_t)((int)e1p + c1) & 0xffffu;   /* int16 wrap-on-store */
+                    big |= abs(pl_sext16((int)n0[p])) > 8000;
+                    bigl |= abs(pl_sext16((int)n0[p])) > PL_E0_LEAD_MAX;
+                    n1[p] = (uint32_t)c2 & 0xffffu;
+                }
+                perr0[x] = make_uint2(n0[0] | (n0[1] << 16), n0[2] | (n0[3] << 16));
+                perr1[x] = make_uint2(n1[0] | (n1[1] << 16), n1[2] | (n1[3] << 16));
+            }
+        } else {
         /* (the pointers do not alias: telling the compiler lets it keep the loads of several iterations in flight) */
 #pragma unroll 4
         for (uint32_t x = tid; x < W; x += PL_ENGINE_THREADS) {
@@ -1754,21 +1811,10 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 const uint32_t e1p = p < 2 ? (e1.x >> (16 * p)) : (e1.y >> (16 * (p - 2)));
                 int c1 = 0, c2 = 0;
                 if (ch >= 0) {
-                    /* next-rows Sierra terms of the five source pixels x-2..x+2 (optimize_state.c:446-465): from the 512-entry
-                     * LDS table of the split for |diff| <= 255, else by the float arithmetic of pl_sierra_split */
-                    auto terms = [&](const uint4 v) -> uint32_t {
-                        const uint32_t w = ch == 0 ? v.x : (ch == 1 ? v.y : (ch == 2 ? v.z : v.w));
-                        const int diff = pl_sext16((int)(w >> 8));
-                        if (diff >= -256 && diff <= 255) return split_lut2[diff + 256];
-                        const PlSplit sp = pl_sierra_split(diff, prm.rbleed, r29);
-                        return ((uint32_t)(int)sp.t & 255u) | (((uint32_t)(int)sp.f & 255u) << 8) | (((uint32_t)(int)sp.v & 255u) << 16) | ((uint32_t)(int)sp.h << 24);
-                    };
+                    /* (rows wider than the LDS region: the five source pixels x-2..x+2 looked up per pixel) */
+                    auto terms = [&](const uint4 v) -> uint32_t { return terms_of(v, ch); };
                     /* (a pixel outside the row has no record: all-zero words give diff 0, whose terms are 0) */
                     const uint32_t m2 = terms(cm2), m1 = terms(cm1), z0 = terms(cw), p1 = terms(cp1), p2 = terms(cp2);
-                    const auto T_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 0, 8); };
-                    const auto F_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 8, 8); };
-                    const auto V_ = [](uint32_t e) { return __builtin_amdgcn_sbfe((int)e, 16, 8); };
-                    const auto H_ = [](uint32_t e) { return (int)e >> 24; };
                     c1 = T_(p2) + F_(p1) + V_(z0) + F_(m1) + T_(m2);
                     c2 = T_(p1) + H_(z0) + T_(m1);
                 }
@@ -1779,6 +1825,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
             }
             perr0[x] = make_uint2(n0[0] | (n0[1] << 16), n0[2] | (n0[3] << 16));
             perr1[x] = make_uint2(n1[0] | (n1[1] << 16), n1[2] | (n1[3] << 16));
+        }
         }
         if (big) big_err = 1;
         if (bigl) big_lead = 1;
