@@ -1,0 +1,1001 @@
+/*
+ * pl_seg_core.h -- the SEGMENT-PARALLEL row engine ("latency mode"): one image spread over the whole GPU.
+ *
+ * Replaces, like pl_engine.hip, the reference's optimize_image / optimize_state_row / optimize_state_run
+ * (/root/reference/src/pngloss_image.c:159-333, /root/reference/src/optimize_state.c:114-361), but cuts the x-chain of a row
+ * into segments that run concurrently.  Why that is possible (measured: oracle/frozen_study.c, profiles/r03_frozen_study.txt):
+ *
+ *   The only thing that couples a pixel to ALL earlier pixels of its row is the running symbol histogram
+ *   (optimize_state.c:221,253).  If every decision of a row is taken against the histogram FROZEN at the start of the row,
+ *   the decision differs from the reference's in < 1e-5 of the cases (sub, up, average, paeth: 0.002-0.02 mismatches per row on
+ *   every image tried; none: 0.3-0.9 per row where its P and N bands compete).  Against a frozen histogram the four channels
+ *   decouple, and one channel's chain is a FINITE-STATE MACHINE: its state in front of pixel x is
+ *       (left = reconstructed byte of x-1,  cn = rem(diff[x-1]) + thr(diff[x-2]),  th = thr(diff[x-1]))
+ *   (optimize_state.c:146,172,455,467) -- relative to the data at most 253 states for s = 19, bleed = 2.  So:
+ *
+ *   ENUMERATE  (seg_enum_body)    every segment of 32 pixels is run from EVERY possible entry state at once (lane = state),
+ *                                 giving the segment's state map: entry state -> exit state;
+ *   CHAIN      (seg_chain_body)   the maps are composed from the row's true start state: one table lookup per segment
+ *                                 instead of 32 dependent pixel steps -- this is where the serial chain of W steps shrinks;
+ *   REPLAY     (seg_replay_body)  every segment is run once more from its now known entry state and writes the candidate row;
+ *   VALIDATE   (seg_post_body)    THE GROUND TRUTH: every decision of the candidate row is re-derived from its predecessors'
+ *                                 outputs and checked against the reference's arg-max rule under the exact RUNNING histogram
+ *                                 (block counts + in-segment counting).  A row that passes is, by induction over x, exactly
+ *                                 the reference's row -- whatever tables, maps or states produced it.  The first decision that
+ *                                 fails is evaluated exactly (seg_ctl_body), the histogram is re-frozen behind it and the rest
+ *                                 of the row is speculated again ("epoch"); progress is at least one pixel per attempt, and a
+ *                                 candidate that keeps failing finishes its row serially.  The same kernel computes the
+ *                                 derivative error, libpng's heuristic and the entropy cost (optimize_state.c:265-342,492-562);
+ *   CONTROL    (seg_ctl_body)     winner (strict <, pngloss_image.c:257), strength retry (:266-274), commit (:277-308),
+ *                                 decision tables of the next row.
+ *
+ * One "attempt" = these five kernels; all state lives in device memory, so the host only enqueues attempts (no data-dependent
+ * host control flow, no in-kernel grid barrier: a kernel boundary is the cheapest grid-wide sync on this machine).
+ *
+ * This header is compiled twice: by hipcc into the kernels of pl_seg.hip, and by g++ into tests/c/seg_host.cpp, which runs the
+ * very same bodies as plain loops over (block, thread) -- test infrastructure that lets the CPU suite prove the logic bit-exact
+ * against the oracle without a GPU.  The product has no CPU path: only the kernels are shipped.
+ */
+#ifndef PL_SEG_CORE_H
+#define PL_SEG_CORE_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define PLS_HD __host__ __device__ __forceinline__
+#else
+#define PLS_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PLS_THREADS(tid, nt) for (int tid = (int)threadIdx.x, pls_once_ = 1; pls_once_ && tid < (int)(nt); pls_once_ = 0)
+#define PLS_SYNC() __syncthreads()
+#define PLS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define PLS_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define PLS_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#else
+#define PLS_THREADS(tid, nt) for (int tid = 0; tid < (int)(nt); ++tid)
+#define PLS_SYNC() ((void)0)
+#define PLS_ATOMIC_ADD(p, v) (*(p) += (v))
+#define PLS_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define PLS_ATOMIC_ADD64(p, v) (*(p) += (v))
+#endif
+
+#define SEG_NFILT 5
+#define SEG_L 32                 /* pixels per segment */
+#define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
+#define SEG_NSP 256              /* lanes per channel in the enumeration = most states supported */
+#define SEG_TOFF 320             /* decision tables cover v in [-320, 319] */
+#define SEG_TN 640
+#define SEG_TBL_WORDS (4 * SEG_TN + 64)   /* pre[2], suf[2], cls[256 bytes] */
+#define SEG_INVALID 0xFFFFu
+#define SEG_NOFAIL 0xFFFFFFFFu
+#define SEG_MAX_RESTARTS 12      /* epochs per candidate and row before the rest of the row is done serially */
+#define SEG_MAX_NSEG 512
+#define SEG_THREADS 1024
+#define SEG_CHAIN_THREADS 256
+#define SEG_REPLAY_THREADS 64
+#define SEG_KEYLUT_MAX 8192
+
+/* what a row attempt decided (seg_ctl_body) */
+enum { SEG_K_INIT = 0, SEG_K_RESTART, SEG_K_RETRY, SEG_K_COMMIT, SEG_K_ABORT, SEG_K_FINISHED };
+
+/* ---- per-batch constants (strength, bleed): built on the host by seg_build_params ------------------------------------- */
+struct SegParams {
+    int32_t strength, bleed;
+    int32_t ns;                    /* number of chain states */
+    int32_t dmax, cmax, tmax;      /* |delta| <= dmax, |cn| <= cmax, |th| <= tmax */
+    int32_t keyn;                  /* entries of keylut */
+    int32_t engine_flags;          /* bits 8..: debugging aid, 1 + the candidate that wins every row */
+    uint32_t lut_a[512];           /* [diff+256] -> rem (int16) | thr << 16      of the Sierra split (optimize_state.c:445-467) */
+    uint32_t lut_b[512];           /* [diff+256] -> t | f << 8 | v << 16 | h << 24 (int8 each): the next-rows terms          */
+    uint32_t st_pack[SEG_NSP];     /* state i -> (delta+128) | (cn+128) << 8 | (th+128) << 16 */
+    uint16_t keylut[SEG_KEYLUT_MAX]; /* ((delta+dmax) * (2cmax+1) + cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
+};
+
+/* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
+struct SegCtl {
+    uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts;
+    uint32_t active[SEG_NFILT];      /* the candidate still has unvalidated pixels (or sums) to produce in this attempt */
+    uint32_t start_x[SEG_NFILT];     /* pixels [0, start_x) of the candidate row are validated */
+    uint32_t state[SEG_NFILT][4];    /* chain state in front of start_x: left | (cn+128) << 8 | (th+128) << 16 */
+    uint32_t restarts[SEG_NFILT];    /* epochs of this candidate in this row */
+    uint64_t cost[SEG_NFILT];        /* final row cost of a finished candidate (~0 = rejected) */
+};
+
+struct SegAcc {
+    uint64_t derr[SEG_NFILT];
+    uint32_t cost[SEG_NFILT];
+    uint32_t hs[SEG_NFILT][SEG_NFILT];
+    uint32_t fail[SEG_NFILT];        /* smallest failing decision index x*4+c, or SEG_NOFAIL */
+    uint32_t pad[3];
+};
+
+struct SegJob {
+    uint32_t *img;            /* slots image (pl_device.h) */
+    uint8_t *row_filters;     /* or null */
+    uint8_t *row_ids;
+    uint32_t W, H;
+    uint32_t bpp;             /* resolved by the launcher kernel (seg_resolve) / the host harness */
+    const uint32_t *orig_rank;/* [5][256] */
+    uint32_t *cand;           /* [5][W][4]: byte | (diff16 & 0xffff) << 8 | bin << 24 */
+    uint32_t *err0, *err1;    /* [W][2]: 4 x int16 */
+    uint32_t *old_above;      /* [W] */
+    uint32_t *final_hist;     /* [256] */
+    int32_t *result;          /* [64] */
+    uint32_t *progress;       /* or null */
+    SegCtl *ctl;              /* [2] */
+    uint32_t *base;           /* [2][5][256] bumps of the validated prefix [0, start_x) */
+    uint32_t *H0;             /* [2][256] committed histogram */
+    SegAcc *acc;              /* [2] */
+    uint32_t *tables;         /* [5][SEG_TBL_WORDS] */
+    uint16_t *maps;           /* [5][nseg][4][SEG_NSP] */
+    uint32_t *entry;          /* [5][nseg][4] */
+    uint16_t *segcnt;         /* [5][nseg][256] */
+    uint32_t *grpcnt;         /* [5][ngrp][256] */
+    uint32_t nseg, ngrp;
+};
+
+/* ---- small pure helpers -------------------------------------------------------------------------------------------------- */
+PLS_HD int seg_sext8(int v) { return (int)(int8_t)(uint8_t)(v & 0xff); }
+PLS_HD int seg_sext16(int v) { return (int)(int16_t)(uint16_t)(v & 0xffff); }
+PLS_HD int seg_min(int a, int b) { return a < b ? a : b; }
+PLS_HD int seg_max(int a, int b) { return a > b ? a : b; }
+PLS_HD int seg_abs(int a) { return a < 0 ? -a : a; }
+PLS_HD int seg_paeth(int above, int diag, int left)
+{
+    const int p = above - diag, pd = left - diag;
+    const int pl = seg_abs(p), pa = seg_abs(pd), pg = seg_abs(p + pd);
+    return (pl <= pa && pl <= pg) ? left : (pa <= pg ? above : diag);
+}
+PLS_HD int seg_predict(int f, int above, int diag, int left)
+{
+    switch (f) {
+    case 1: return left;
+    case 2: return above;
+    case 3: return (above + left) >> 1;
+    case 4: return seg_paeth(above, diag, left);
+    default: return 0;
+    }
+}
+/* which error plane a channel uses / which channel feeds a plane (color_delta.c:4-41, optimize_state.c:167-171) */
+PLS_HD int seg_plane_of_channel(uint32_t bpp, int c) { return (bpp == 2 && c == 1) ? 3 : c; }
+PLS_HD int seg_channel_of_plane(uint32_t bpp, int p)
+{
+    if (bpp == 2) return p == 0 ? 0 : (p == 3 ? 1 : -1);
+    return p < (int)bpp ? p : -1;
+}
+PLS_HD int seg_err_plane(const uint32_t *e2, int p) { return seg_sext16((int)(p < 2 ? (e2[0] >> (16 * p)) : (e2[1] >> (16 * (p - 2))))); }
+
+/* Sierra split (optimize_state.c:397-401,445-467): truncating divisions */
+struct SegSplit { int t, h, f, v, rem; };
+PLS_HD SegSplit seg_split_slow(int diff16, int bleed)
+{
+    SegSplit s;
+    int d = diff16 / bleed;
+    s.t = d / 16; d -= 4 * s.t;
+    s.h = d / 8; d -= 2 * s.h;
+    s.f = (d * 2) / 9; d -= 2 * s.f;
+    s.v = d / 2; d -= s.v;
+    s.rem = d;
+    return s;
+}
+PLS_HD void seg_rem_thr(const uint32_t *lut_a, int bleed, int diff, int &rem, int &thr)
+{
+    if (diff >= -256 && diff <= 255) { const uint32_t e = lut_a[diff + 256]; rem = seg_sext16((int)e); thr = (int)e >> 16; }
+    else { const SegSplit s = seg_split_slow(diff, bleed); rem = s.rem; thr = s.h; }
+}
+PLS_HD uint32_t seg_terms(const uint32_t *lut_b, int bleed, int diff)
+{
+    if (diff >= -256 && diff <= 255) return lut_b[diff + 256];
+    const SegSplit s = seg_split_slow(diff, bleed);
+    return ((uint32_t)s.t & 255u) | (((uint32_t)s.f & 255u) << 8) | (((uint32_t)s.v & 255u) << 16) | ((uint32_t)s.h << 24);
+}
+
+/* candidate word: byte | diff16 << 8 | bin << 24 */
+PLS_HD uint32_t seg_cand_pack(int back, int diff, int bin) { return (uint32_t)(back & 255) | (((uint32_t)diff & 0xffffu) << 8) | ((uint32_t)(bin & 255) << 24); }
+PLS_HD int seg_cand_byte(uint32_t w) { return (int)(w & 255u); }
+PLS_HD int seg_cand_diff(uint32_t w) { return seg_sext16((int)(w >> 8)); }
+PLS_HD int seg_cand_bin(uint32_t w) { return (int)(w >> 24); }
+
+/* chain state */
+struct SegState { int left, cn, th; };
+PLS_HD uint32_t seg_state_pack(const SegState &s) { return (uint32_t)(s.left & 255) | ((uint32_t)((s.cn + 32768) & 0xffff) << 8) | ((uint32_t)((s.th + 128) & 255) << 24); }
+PLS_HD SegState seg_state_unpack(uint32_t w) { SegState s; s.left = (int)(w & 255u); s.cn = (int)((w >> 8) & 0xffffu) - 32768; s.th = (int)(w >> 24) - 128; return s; }
+
+/* per pixel and channel data of the chain: orig | above << 8 | diag << 16 | tr << 24, e0 */
+struct SegPix { uint32_t w; int e0; };
+PLS_HD SegPix seg_pix_make(int orig, int above, int diag, int tr, int e0) { SegPix p; p.w = (uint32_t)orig | ((uint32_t)above << 8) | ((uint32_t)diag << 16) | ((uint32_t)tr << 24); p.e0 = e0; return p; }
+
+/* pixel x, channel c of row y from the image / error row (slots layout).  row = original row y, nab = optimised row y-1 or null */
+PLS_HD SegPix seg_pix_load(const uint32_t *row, const uint32_t *nab, const uint32_t *err0, uint32_t bpp, uint32_t x, int c)
+{
+    const uint32_t o = row[x];
+    const uint32_t a = nab ? nab[x] : 0u, d = (nab && x) ? nab[x - 1] : 0u;
+    const int tr = ((bpp & 1u) == 0u && (uint32_t)c == bpp - 1u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u) ? 1 : 0;
+    return seg_pix_make((int)((o >> (8 * c)) & 255u), (int)((a >> (8 * c)) & 255u), (int)((d >> (8 * c)) & 255u), tr,
+                        seg_err_plane(err0 + 2 * (size_t)x, seg_plane_of_channel(bpp, c)));
+}
+
+/* band geometry of one lookup (optimize_state.c:186-210): clamped candidate range [v0, v1] (single value when v0 == v1) */
+struct SegBand { int v0, v1, bandlo, neg; };
+PLS_HD SegBand seg_band(int filt, int lo, int s, int q)
+{
+    SegBand b;
+    b.neg = filt < 0;
+    const int af = b.neg ? -filt : filt;
+    const int t = af / q;
+    b.bandlo = b.neg ? -(t * q) - s : t * q;
+    const int bandhi = b.bandlo + s, hi = lo + 255;
+    b.v0 = seg_max(b.bandlo, lo);
+    b.v1 = seg_min(bandhi, hi);
+    if (b.v0 > b.v1) { const int v = bandhi < lo ? lo : hi; b.v0 = b.v1 = v; }
+    return b;
+}
+
+/* the reference's choice inside [v0, v1] (optimize_state.c:212-244) = lexicographic arg-max of (H[v], O[v], v == osym, -v), by scanning.
+ * H: symbol frequencies (256), extra: added on top (may be null), rank: order/equality preserving rank of original_frequency */
+PLS_HD int seg_argmax_scan(const uint32_t *H, const uint32_t *extra, const uint32_t *rank, int v0, int v1, int osym)
+{
+    int best = v0;
+    uint32_t bh = H[v0 & 255] + (extra ? extra[v0 & 255] : 0u), br = rank[v0 & 255];
+    int bflag = v0 == osym;
+    for (int v = v0 + 1; v <= v1; v++) {
+        const uint32_t h = H[v & 255] + (extra ? extra[v & 255] : 0u), r = rank[v & 255];
+        const int fl = v == osym;
+        const bool better = h != bh ? h > bh : (r != br ? r > br : fl > bflag);
+        if (better) { best = v; bh = h; br = r; bflag = fl; }
+    }
+    return best;
+}
+
+/* One step of one channel's chain against a frozen histogram, decision by scanning (replay, chain walk, exact pixel).
+ * Returns the candidate word; st becomes the state in front of the next pixel. */
+PLS_HD uint32_t seg_step_scan(int f, const SegPix &p, SegState &st, const uint32_t *H, const uint32_t *extra, const uint32_t *rank,
+                              int s, int q, const uint32_t *lut_a, int bleed)
+{
+    const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
+    const int pred = seg_predict(f, above, diag, st.left);
+    int back, diff, bin;
+    if (p.w >> 24) { back = 0; diff = 0; bin = (0 - pred) & 255; }             /* optimize_state.c:158-164 */
+    else {
+        const int osym = seg_sext8(orig - pred), lo = osym - orig;
+        const int filt = osym + seg_sext16(p.e0 + st.cn);
+        const SegBand b = seg_band(filt, lo, s, q);
+        const int v = seg_argmax_scan(H, extra, rank, b.v0, b.v1, osym);
+        back = v - lo; diff = seg_sext16(filt - v); bin = v & 255;
+    }
+    int rem, thr;
+    seg_rem_thr(lut_a, bleed, diff, rem, thr);
+    st.left = back; st.cn = rem + st.th; st.th = thr;
+    return seg_cand_pack(back, diff, bin);
+}
+
+/* ---- decision tables of one candidate filter (enumeration only) --------------------------------------------------------------
+ * pre[sgn][v + SEG_TOFF] = leader of [bandlo(v), v], suf[sgn][v + SEG_TOFF] = leader of [v, bandhi(v)] in the band system of that
+ * sign (sgn 0: filt >= 0, bands [tq, tq+s]; sgn 1: filt < 0, bands [-tq-s, -tq]); leader = arg-max of (H, rank, -v).
+ * entry = (L + 512) | cls[L & 255] << 16, cls = dense class of (H, rank): equal class <=> equal (H, rank), which is what decides
+ * whether the original symbol takes the place of the leader (optimize_state.c:236-243). */
+struct SegTabs { const uint32_t *pre[2], *suf[2]; const uint8_t *cls; };
+PLS_HD SegTabs seg_tabs_at(const uint32_t *words)
+{
+    SegTabs t;
+    t.pre[0] = words; t.pre[1] = words + SEG_TN; t.suf[0] = words + 2 * SEG_TN; t.suf[1] = words + 3 * SEG_TN;
+    t.cls = (const uint8_t *)(words + 4 * SEG_TN);
+    return t;
+}
+/* largest |filt| the tables serve */
+PLS_HD int seg_filt_max(int s, int q) { return ((SEG_TOFF - 1 - s) / q) * q + s < SEG_TOFF - 1 - s ? ((SEG_TOFF - 1 - s) / q) * q + s : SEG_TOFF - 1 - s; }
+
+/* decision by table; ok = false when filt is outside the tables (the lane gives up: SEG_INVALID) */
+PLS_HD int seg_decide_tab(const SegTabs &T, int filt, int lo, int osym, int s, int q, bool &ok)
+{
+    const SegBand b = seg_band(filt, lo, s, q);
+    if (b.v0 == b.v1) { ok = true; return b.v0; }
+    if (b.v0 < -SEG_TOFF || b.v1 >= SEG_TOFF || b.bandlo < -SEG_TOFF || b.bandlo + s >= SEG_TOFF) { ok = false; return b.v0; }
+    ok = true;
+    const uint32_t e = b.v0 > b.bandlo ? T.suf[b.neg][b.v0 + SEG_TOFF] : T.pre[b.neg][b.v1 + SEG_TOFF];
+    const int L = (int)(e & 0xffffu) - 512;
+    const bool tie = osym >= b.v0 && osym <= b.v1 && (uint32_t)T.cls[osym & 255] == ((e >> 16) & 255u);
+    return tie ? osym : L;
+}
+
+PLS_HD bool seg_step_tab(int f, const SegPix &p, SegState &st, const SegTabs &T, int s, int q, const uint32_t *lut_a, int bleed)
+{
+    const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
+    const int pred = seg_predict(f, above, diag, st.left);
+    int back, diff;
+    if (p.w >> 24) { back = 0; diff = 0; }
+    else {
+        const int osym = seg_sext8(orig - pred), lo = osym - orig;
+        const int filt = osym + seg_sext16(p.e0 + st.cn);
+        bool ok;
+        const int v = seg_decide_tab(T, filt, lo, osym, s, q, ok);
+        if (!ok) return false;
+        back = v - lo; diff = seg_sext16(filt - v);
+    }
+    int rem, thr;
+    seg_rem_thr(lut_a, bleed, diff, rem, thr);
+    st.left = back; st.cn = rem + st.th; st.th = thr;
+    return true;
+}
+
+/* state <-> index, relative to the data of the boundary pixel b (the last pixel in front of the segment):
+ * left = orig_b + e0_b + delta (0 for a forced transparent alpha, whose delta is 0 by definition) */
+PLS_HD bool seg_state_decode(const SegParams &P, int i, const SegPix &b, SegState &st)
+{
+    if (i >= P.ns) return false;
+    const uint32_t w = P.st_pack[i];
+    const int delta = (int)(w & 255u) - 128;
+    st.cn = (int)((w >> 8) & 255u) - 128;
+    st.th = (int)((w >> 16) & 255u) - 128;
+    if (b.w >> 24) { if (delta != 0) return false; st.left = 0; return true; }
+    st.left = (int)(b.w & 255u) + b.e0 + delta;
+    return st.left >= 0 && st.left <= 255;
+}
+PLS_HD uint32_t seg_state_encode(const SegParams &P, const SegPix &b, const SegState &st)
+{
+    const int delta = (b.w >> 24) ? 0 : st.left - ((int)(b.w & 255u) + b.e0);
+    if ((b.w >> 24) && st.left != 0) return SEG_INVALID;
+    if (delta < -P.dmax || delta > P.dmax || st.cn < -P.cmax || st.cn > P.cmax || st.th < -P.tmax || st.th > P.tmax) return SEG_INVALID;
+    const int key = ((delta + P.dmax) * (2 * P.cmax + 1) + st.cn + P.cmax) * (2 * P.tmax + 1) + st.th + P.tmax;
+    return key < P.keyn ? (uint32_t)P.keylut[key] : SEG_INVALID;
+}
+
+/* ---- host: the constants of a (strength, bleed) pair.  false: more states than the enumeration has lanes ------------------ */
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline bool seg_build_params(SegParams &P, int strength, int bleed)
+{
+    memset(&P, 0, sizeof P);
+    P.strength = strength; P.bleed = bleed;
+    for (int d = -256; d <= 255; d++) {
+        const SegSplit s = seg_split_slow(d, bleed);
+        P.lut_a[d + 256] = ((uint32_t)s.rem & 0xffffu) | ((uint32_t)s.h << 16);
+        P.lut_b[d + 256] = ((uint32_t)s.t & 255u) | (((uint32_t)s.f & 255u) << 8) | (((uint32_t)s.v & 255u) << 16) | ((uint32_t)s.h << 24);
+    }
+    if (strength > 127) return false;
+    int rmax = 0, tmax = 0;
+    for (int d = -strength; d <= strength; d++) { const SegSplit s = seg_split_slow(d, bleed); if (seg_abs(s.rem) > rmax) rmax = seg_abs(s.rem); if (seg_abs(s.h) > tmax) tmax = seg_abs(s.h); }
+    P.cmax = rmax + tmax; P.tmax = tmax; P.dmax = strength + P.cmax;
+    if (P.dmax > 127 || P.cmax > 127) return false;
+    P.keyn = (2 * P.dmax + 1) * (2 * P.cmax + 1) * (2 * P.tmax + 1);
+    if (P.keyn > SEG_KEYLUT_MAX) return false;
+    for (int k = 0; k < P.keyn; k++) P.keylut[k] = (uint16_t)SEG_INVALID;
+    int ns = 0;
+    /* every (diff of the boundary pixel, carry it received, thr of the pixel before it) gives one state */
+    for (int diff = -strength; diff <= strength; diff++) {
+        const SegSplit sp = seg_split_slow(diff, bleed);
+        for (int carry = -P.cmax; carry <= P.cmax; carry++)
+            for (int thp = -tmax; thp <= tmax; thp++) {
+                const int delta = carry - diff, cn = sp.rem + thp, th = sp.h;
+                if (seg_abs(delta) > P.dmax || seg_abs(cn) > P.cmax) continue;
+                const int key = ((delta + P.dmax) * (2 * P.cmax + 1) + cn + P.cmax) * (2 * P.tmax + 1) + th + P.tmax;
+                if (P.keylut[key] != (uint16_t)SEG_INVALID) continue;
+                if (ns >= SEG_NSP) return false;
+                P.keylut[key] = (uint16_t)ns;
+                P.st_pack[ns] = (uint32_t)(delta + 128) | ((uint32_t)(cn + 128) << 8) | ((uint32_t)(th + 128) << 16);
+                ns++;
+            }
+    }
+    P.ns = ns;
+    return true;
+}
+#endif
+
+/* =========================================================================================================================
+ * Kernel bodies.  smem: the workgroup's shared memory (device: dynamic LDS; host harness: a scratch buffer).
+ * par = attempt & 1: which copy of the control block this attempt reads.
+ * ========================================================================================================================= */
+
+/* shared-memory budgets (bytes) */
+#define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 64)
+#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 2048 + SEG_L * 8 + (size_t)(nseg) * 16 + 64)
+#define SEG_SM_REPLAY (1024 + 1024 + SEG_GRP * (SEG_L + 1) * 4 * 8 + SEG_GRP * 256 * 4 + 64)
+#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4)
+#define SEG_SM_CTL (256 * 4 * 4 + 256 + 64 * 4 + 2 * SEG_TN * 4)
+
+/* ---- ENUMERATE: task (f, seg), SEG_THREADS lanes = 4 channels x SEG_NSP states ----------------------------------------- */
+PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    if (ctl.finished || !ctl.active[f]) return;
+    const uint32_t W = j.W, bpp = j.bpp;
+    const uint32_t x0 = (uint32_t)seg * SEG_L;
+    if (x0 + SEG_L >= W) return;                              /* the last segment has no successor */
+    if (x0 <= ctl.start_x[f]) return;                         /* the epoch's first (partial) segment is walked by the chain kernel */
+    uint32_t *tw = (uint32_t *)smem;
+    SegPix *px = (SegPix *)(smem + SEG_TBL_WORDS * 4);        /* [(SEG_L + 1)][4]: slot 0 = boundary pixel x0-1 */
+    const uint32_t y = ctl.y;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const int s = (int)ctl.s, q = s + 1;
+    PLS_THREADS(tid, SEG_THREADS) {
+        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+        if (tid < (SEG_L + 1) * 4) {
+            const int k = tid >> 2, c = tid & 3;
+            const uint32_t x = x0 - 1 + (uint32_t)k;
+            px[tid] = ((uint32_t)c < bpp && x < W) ? seg_pix_load(row, nab, j.err0, bpp, x, c) : seg_pix_make(0, 0, 0, 0, 0);
+        }
+    }
+    PLS_SYNC();
+    const SegTabs T = seg_tabs_at(tw);
+    PLS_THREADS(tid, SEG_THREADS) {
+        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
+        if ((uint32_t)c < bpp && i < P.ns) {
+            SegState st;
+            uint32_t out = SEG_INVALID;
+            if (seg_state_decode(P, i, px[c], st)) {
+                bool ok = true;
+                for (int k = 1; k <= SEG_L && ok; k++) ok = seg_step_tab(f, px[k * 4 + c], st, T, s, q, P.lut_a, P.bleed);
+                if (ok) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
+            }
+            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
+        }
+    }
+}
+
+/* frozen histogram of candidate f in this attempt: H0 + base[f] */
+PLS_HD void seg_load_frozen(const SegJob &j, int par, int f, uint32_t *Hf, uint32_t *rank, int tid, int nt)
+{
+    for (int b = tid; b < 256; b += nt) {
+        Hf[b] = j.H0[par * 256 + b] + j.base[((size_t)par * SEG_NFILT + f) * 256 + b];
+        rank[b] = j.orig_rank[f * 256 + b];
+    }
+}
+
+/* ---- CHAIN: task (f, c): compose the segment maps from the epoch's start state -----------------------------------------
+ * The exit index of segment sg (relative to its last pixel) IS the entry index of segment sg+1 (relative to the same pixel, its
+ * boundary pixel), so the chain is one shared-memory lookup per segment; entry states are decoded afterwards, in parallel. */
+PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    if (ctl.finished || !ctl.active[f] || (uint32_t)c >= j.bpp) return;
+    const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
+    const uint32_t sx = ctl.start_x[f];
+    if (sx >= W) return;
+    const uint32_t first = sx / SEG_L;
+    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256;
+    SegPix *px = (SegPix *)(smem + 2048);                     /* [SEG_L] pixels of the first segment, this channel */
+    SegPix *bpx = px + SEG_L;                                 /* [nseg] boundary pixel sg*SEG_L - 1 of every segment */
+    uint32_t *idxs = (uint32_t *)(bpx + nseg);                /* [nseg] entry index of every segment, or a packed state | 1 << 31... see below */
+    uint16_t *maps = (uint16_t *)(idxs + 2 * nseg);
+    const uint32_t y = ctl.y;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const int s = (int)ctl.s, q = s + 1;
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        seg_load_frozen(j, par, f, Hf, rank, tid, SEG_CHAIN_THREADS);
+        if (tid < SEG_L) { const uint32_t x = first * SEG_L + (uint32_t)tid; px[tid] = x < W ? seg_pix_load(row, nab, j.err0, bpp, x, c) : seg_pix_make(0, 0, 0, 0, 0); }
+        for (uint32_t sg = first + 1 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c);
+        for (uint32_t sg = first + 1; sg + 1 < nseg; sg++) {
+            const uint16_t *src = j.maps + (((size_t)f * nseg + sg) * 4 + c) * SEG_NSP;
+            for (int i = tid; i < SEG_NSP; i += SEG_CHAIN_THREADS) maps[(size_t)sg * SEG_NSP + i] = src[i];
+        }
+    }
+    PLS_SYNC();
+    /* idxs[2*sg] = entry index of segment sg or SEG_INVALID; idxs[2*sg+1] = packed entry state when the index is invalid */
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        if (tid == 0) {
+            SegState st = seg_state_unpack(ctl.state[f][c]);
+            /* the epoch's first segment, from its start pixel, step by step */
+            const uint32_t fend = (uint32_t)seg_min((int)((first + 1) * SEG_L), (int)W);
+            for (uint32_t x = sx; x < fend; x++) (void)seg_step_scan(f, px[x - first * SEG_L], st, Hf, nullptr, rank, s, q, P.lut_a, P.bleed);
+            uint32_t idx = first + 1 < nseg ? seg_state_encode(P, bpx[first + 1], st) : SEG_INVALID;
+            for (uint32_t sg = first + 1; sg < nseg; sg++) {
+                idxs[2 * sg] = idx;
+                if (idx == SEG_INVALID) idxs[2 * sg + 1] = seg_state_pack(st);
+                if (sg + 1 == nseg) break;
+                uint32_t nidx = idx == SEG_INVALID ? SEG_INVALID : (uint32_t)maps[(size_t)sg * SEG_NSP + idx];
+                if (nidx == SEG_INVALID) {
+                    /* a state or a lookup outside what the enumeration covers: this segment step by step (rare, slow, exact) */
+                    if (idx != SEG_INVALID) (void)seg_state_decode(P, (int)idx, bpx[sg], st);
+                    for (uint32_t x = sg * SEG_L; x < (sg + 1) * SEG_L && x < W; x++) {
+                        const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
+                        (void)seg_step_scan(f, p, st, Hf, nullptr, rank, s, q, P.lut_a, P.bleed);
+                    }
+                    nidx = seg_state_encode(P, bpx[sg + 1], st);
+                }
+                idx = nidx;
+            }
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        for (uint32_t sg = first + 1 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) {
+            uint32_t packed;
+            if (idxs[2 * sg] == SEG_INVALID) packed = idxs[2 * sg + 1];
+            else { SegState st; (void)seg_state_decode(P, (int)idxs[2 * sg], bpx[sg], st); packed = seg_state_pack(st); }
+            j.entry[((size_t)f * nseg + sg) * 4 + c] = packed;
+        }
+    }
+}
+
+/* ---- REPLAY: task (f, grp): lane = (segment of the group, channel) ------------------------------------------------------ */
+PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    if (ctl.finished || !ctl.active[f]) return;
+    const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
+    const uint32_t sx = ctl.start_x[f];
+    if (sx >= W) return;
+    const uint32_t first = sx / SEG_L;
+    const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
+    if (seg0 + SEG_GRP <= first) return;                      /* the whole group is validated already */
+    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256;
+    SegPix *px = (SegPix *)(smem + 2048);                     /* [SEG_GRP][SEG_L][4] */
+    uint32_t *cnt = (uint32_t *)(smem + 2048 + SEG_GRP * (SEG_L + 1) * 4 * 8);   /* [SEG_GRP][256] */
+    const uint32_t y = ctl.y;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const int s = (int)ctl.s, q = s + 1;
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        seg_load_frozen(j, par, f, Hf, rank, tid, SEG_REPLAY_THREADS);
+        for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_THREADS) cnt[i] = 0u;
+        for (int i = tid; i < SEG_GRP * SEG_L * 4; i += SEG_REPLAY_THREADS) {
+            const int c = i & 3;
+            const uint32_t x = seg0 * SEG_L + (uint32_t)(i >> 2);
+            px[i] = ((uint32_t)c < bpp && x < W) ? seg_pix_load(row, nab, j.err0, bpp, x, c) : seg_pix_make(0, 0, 0, 0, 0);
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        const int sl = tid >> 2, c = tid & 3;
+        const uint32_t sg = seg0 + (uint32_t)sl;
+        if (sg < nseg && sg >= first && (uint32_t)c < bpp) {
+            SegState st = sg == first ? seg_state_unpack(ctl.state[f][c]) : seg_state_unpack(j.entry[((size_t)f * nseg + sg) * 4 + c]);
+            const uint32_t xa = sg == first ? sx : sg * SEG_L, xe = seg_min((int)((sg + 1) * SEG_L), (int)W);
+            for (uint32_t x = xa; x < xe; x++) {
+                const uint32_t w = seg_step_scan(f, px[(x - seg0 * SEG_L) * 4 + c], st, Hf, nullptr, rank, s, q, P.lut_a, P.bleed);
+                j.cand[((size_t)f * W + x) * 4 + c] = w;
+                PLS_ATOMIC_ADD(&cnt[sl * 256 + seg_cand_bin(w)], 1u);
+            }
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        for (int b = tid; b < 256; b += SEG_REPLAY_THREADS) {
+            uint32_t tot = 0;
+            for (int sl = 0; sl < SEG_GRP; sl++) {
+                const uint32_t sg = seg0 + (uint32_t)sl;
+                if (sg < nseg && sg >= first) { j.segcnt[((size_t)f * nseg + sg) * 256 + b] = (uint16_t)cnt[sl * 256 + b]; tot += cnt[sl * 256 + b]; }
+            }
+            j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
+        }
+    }
+}
+
+/* ---- VALIDATE + POST: task (f, grp) ----------------------------------------------------------------------------------------
+ * A decision (x, c) of the candidate row is CORRECT iff, with everything re-derived from the outputs of x-1 and x-2 (left byte,
+ * carried error terms) and from the data, the stored byte/diff/bin are consistent and the chosen v is the reference's arg-max
+ * over its clamped band under the histogram H0 + (bumps of all earlier decisions of the row, in chain order).  The bumps in
+ * front of a decision: validated prefix (base) + whole groups + whole segments (counts written by the replay) + the earlier
+ * decisions of its own segment (counted here).  Cheap bound first (counts at the segment's start and end), exact count only when
+ * the bound cannot tell. */
+PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    if (ctl.finished || !ctl.active[f]) return;
+    const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
+    const uint32_t sx = ctl.start_x[f];
+    const uint32_t first = sx / SEG_L, fgrp = first / SEG_GRP;
+    const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
+    uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256, *Hpost = H0 + 512;
+    uint32_t *cum = H0 + 768;                                  /* [(SEG_GRP + 1)][256]: bumps in front of each segment of the group */
+    uint32_t *cw = cum + (SEG_GRP + 1) * 256;                  /* [(SEG_GRP * SEG_L + 2)][4] candidate words, from pixel seg0*SEG_L - 2 */
+    uint32_t *red = cw + (SEG_GRP * SEG_L + 2) * 4;            /* reductions: derr lo/hi, cost, hs[5], fail */
+    const uint32_t y = ctl.y;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const int s = (int)ctl.s, q = s + 1;
+    const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
+    const uint32_t xg0 = seg0 * SEG_L;
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid < 256) {
+            const int b = tid;
+            H0[b] = j.H0[par * 256 + b];
+            rank[b] = j.orig_rank[f * 256 + b];
+            uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b], total = before;
+            if (sx < W)
+                for (uint32_t g = fgrp; g < ngrp; g++) {
+                    const uint32_t v = j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
+                    total += v;
+                    if (g < (uint32_t)grp) before += v;
+                }
+            Hpost[b] = H0[b] + total;
+            uint32_t run = before;
+            for (int sl = 0; sl <= SEG_GRP; sl++) {
+                cum[sl * 256 + b] = run;
+                const uint32_t sg = seg0 + (uint32_t)sl;
+                if (sl < SEG_GRP && sg < nseg && sg >= first && sx < W) run += j.segcnt[((size_t)f * nseg + sg) * 256 + b];
+            }
+        }
+        for (int i = tid; i < (SEG_GRP * SEG_L + 2) * 4; i += SEG_THREADS) {
+            const long x = (long)xg0 - 2 + (i >> 2);
+            cw[i] = (x >= 0 && x < (long)W) ? j.cand[((size_t)f * W + (size_t)x) * 4 + (i & 3)] : 0u;
+        }
+        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : 0u;
+    }
+    PLS_SYNC();
+    /* -- validation: lane = decision -- */
+    PLS_THREADS(tid, SEG_THREADS) {
+        for (int d = tid; d < SEG_GRP * SEG_L * 4; d += SEG_THREADS) {
+            const int c = d & 3, k = d >> 2;                       /* pixel k of the group */
+            const uint32_t x = xg0 + (uint32_t)k;
+            if (x >= W || x < sx || (uint32_t)c >= bpp) continue;
+            const int sl = k / SEG_L;
+            const uint32_t w0 = cw[(k + 2) * 4 + c], w1 = cw[(k + 1) * 4 + c], w2 = cw[k * 4 + c];
+            const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
+            /* state in front of x from the outputs of x-1, x-2 */
+            int rem1, thr1, rem2, thr2;
+            seg_rem_thr(P.lut_a, P.bleed, x >= 1 ? seg_cand_diff(w1) : 0, rem1, thr1);
+            seg_rem_thr(P.lut_a, P.bleed, x >= 2 ? seg_cand_diff(w2) : 0, rem2, thr2);
+            const int left = x >= 1 ? seg_cand_byte(w1) : 0, cn = rem1 + thr2;
+            const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
+            const int pred = seg_predict(f, above, diag, left);
+            const int back = seg_cand_byte(w0), diff = seg_cand_diff(w0), bin = seg_cand_bin(w0);
+            bool good;
+            if (p.w >> 24) good = back == 0 && diff == 0 && bin == ((0 - pred) & 255);
+            else {
+                const int osym = seg_sext8(orig - pred), lo = osym - orig;
+                const int filt = osym + seg_sext16(p.e0 + cn);
+                const SegBand bd = seg_band(filt, lo, s, q);
+                const int v = back + lo;
+                good = v >= bd.v0 && v <= bd.v1 && diff == seg_sext16(filt - v) && bin == (v & 255);
+                if (good && bd.v0 < bd.v1) {
+                    const uint32_t *cs = cum + sl * 256, *ce = cum + (sl + 1) * 256;
+                    /* first pixel of this decision's segment that belongs to the epoch */
+                    const int kseg = seg_max(sl * SEG_L, (int)sx - (int)xg0);
+                    const uint32_t hv_lo = H0[bin] + cs[bin], rv = rank[bin];
+                    const int fv = v == osym;
+                    int exact_hv = -1; uint32_t hv_exact = 0;
+                    for (int u = bd.v0; u <= bd.v1 && good; u++) {
+                        if (u == v) continue;
+                        const int ub = u & 255;
+                        const uint32_t ru = rank[ub];
+                        const int fu = u == osym;
+                        /* u beats v at equal frequency?  (O, flag, lower v) */
+                        const bool u_wins_ties = ru != rv ? ru > rv : (fu != fv ? fu > fv : u < v);
+                        const uint32_t hu_hi = H0[ub] + ce[ub];
+                        if (u_wins_ties ? hu_hi < hv_lo : hu_hi <= hv_lo) continue;      /* proven by the bounds */
+                        /* exact counts: the earlier decisions of this segment */
+                        if (exact_hv < 0) {
+                            uint32_t n = 0;
+                            for (int e = kseg * 4; e < k * 4 + c; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(cw[(e >> 2) * 4 + 8 + (e & 3)]) == bin) n++;
+                            hv_exact = hv_lo + n; exact_hv = 1;
+                        }
+                        uint32_t n = 0;
+                        for (int e = kseg * 4; e < k * 4 + c; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(cw[(e >> 2) * 4 + 8 + (e & 3)]) == ub) n++;
+                        const uint32_t hu = H0[ub] + cs[ub] + n;
+                        if (u_wins_ties ? hu >= hv_exact : hu > hv_exact) good = false;
+                    }
+                }
+            }
+            if (!good) PLS_ATOMIC_MIN(&red[8], x * 4u + (uint32_t)c);
+        }
+    }
+    PLS_SYNC();
+    /* -- post pass of this candidate over the group's pixels (optimize_state.c:265-287, 326-342, 492-562): lane = pixel -- */
+    PLS_THREADS(tid, SEG_THREADS) {
+        for (int k = tid; k < SEG_GRP * SEG_L; k += SEG_THREADS) {
+            const uint32_t x = xg0 + (uint32_t)k;
+            if (x >= W) continue;
+            const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
+            const uint32_t na = nab ? nab[x] : 0u, nd = (nab && x) ? nab[x - 1] : 0u;
+            const uint32_t oa = y ? j.old_above[x] : 0u, od = (y && x) ? j.old_above[x - 1] : 0u;
+            uint64_t derr = 0; uint32_t cost = 0, hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
+            for (uint32_t c = 0; c < bpp; c++) {
+                const int sh = 8 * (int)c;
+                const int back = seg_cand_byte(cw[(k + 2) * 4 + c]), nl = x ? seg_cand_byte(cw[(k + 1) * 4 + c]) : 0;
+                const int ov = (int)((o >> sh) & 255u), olv = (int)((ol >> sh) & 255u);
+                const int nav = (int)((na >> sh) & 255u), ndv = (int)((nd >> sh) & 255u), oav = (int)((oa >> sh) & 255u), odv = (int)((od >> sh) & 255u);
+                const int da = (oav - ov) - (nav - back), dd = (odv - ov) - (ndv - back), dl = (olv - ov) - (nl - back);
+                const uint32_t wgt = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
+                derr += (uint64_t)(wgt * (uint32_t)(da * da + dd * dd + dl * dl));
+                const int preds[SEG_NFILT] = { 0, nl, nav, (nav + nl) >> 1, seg_paeth(nav, ndv, nl) };
+                const uint32_t fr = Hpost[(back - preds[f]) & 255];
+                cost += fr ? 33u + (uint32_t)__builtin_clz(fr) : 0u;
+                if (adaptive)
+                    for (int g = 0; g < SEG_NFILT; g++) { const int bb = (back - preds[g]) & 255; hs[g] += (uint32_t)(bb < 128 ? bb : 256 - bb); }
+            }
+            PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
+            PLS_ATOMIC_ADD(&red[2], cost);
+            if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&red[3 + g], hs[g]);
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid == 0) {
+            SegAcc &A = j.acc[par];
+            PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
+            PLS_ATOMIC_ADD(&A.cost[f], red[2]);
+            for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[3 + g]);
+            if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
+        }
+    }
+}
+
+/* ---- CONTROL -------------------------------------------------------------------------------------------------------------- */
+struct SegDecision {
+    int kind, winner;
+    uint32_t failed;                /* bit f: candidate f failed validation in the attempt just finished */
+    uint64_t cost[SEG_NFILT];
+};
+
+/* what the attempt that just finished (control block `cur`, sums `A`) means.  Every workgroup of the control kernel computes this. */
+PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, const SegCtl &cur, const SegAcc &A)
+{
+    SegDecision D;
+    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0;
+    for (int f = 0; f < SEG_NFILT; f++) D.cost[f] = ~0ull;
+    if (attempt == 0) return D;
+    if (cur.finished) { D.kind = SEG_K_FINISHED; return D; }
+    const bool adaptive = !j.row_filters || cur.y == 0;
+    bool any_failed = false;
+    for (int f = 0; f < SEG_NFILT; f++) {
+        if (!cur.active[f]) { D.cost[f] = cur.cost[f]; continue; }
+        if (A.fail[f] != SEG_NOFAIL) { D.failed |= 1u << f; any_failed = true; continue; }
+        uint64_t cst = A.derr[f] / 128u + A.cost[f];                              /* optimize_state.c:360 */
+        if (adaptive) {
+            int bestg = 0;
+            for (int g = 1; g < SEG_NFILT; g++) if (A.hs[f][g] < A.hs[f][bestg]) bestg = g;
+            if (bestg != f) cst = ~0ull;                                          /* optimize_state.c:319-324 */
+        }
+        if (P.engine_flags >> 8) cst = f == (P.engine_flags >> 8) - 1 ? 0ull : ~0ull;
+        D.cost[f] = cst;
+    }
+    if (any_failed) { D.kind = SEG_K_RESTART; return D; }
+    uint64_t best = ~0ull;
+    for (int f = 0; f < SEG_NFILT; f++) if (D.cost[f] < best) { best = D.cost[f]; D.winner = f; }   /* strict <: pngloss_image.c:257 */
+    if (D.winner >= 0) D.kind = SEG_K_COMMIT;
+    else D.kind = cur.s == 0 ? SEG_K_ABORT : SEG_K_RETRY;                           /* pngloss_image.c:266-274 */
+    return D;
+}
+
+/* decision tables of one candidate from a histogram (all threads of the workgroup; H, rank: 256 words each in shared memory;
+ * out: SEG_TBL_WORDS words in global memory; scratch: 256 words) */
+PLS_HD void seg_build_tables(uint32_t *out, const uint32_t *H, const uint32_t *rank, uint32_t *scratch, int s, int q, int nt)
+{
+    /* cls[b] = number of bins strictly below b in (H, rank): equal class <=> equal key */
+    PLS_THREADS(tid, nt) { for (int b = tid; b < 256; b += nt) scratch[b] = 0u; }
+    PLS_SYNC();
+    PLS_THREADS(tid, nt) {
+        for (int i = tid; i < 256 * 4; i += nt) {
+            const int b = i & 255, part = i >> 8;
+            uint32_t n = 0;
+            for (int k = part * 64; k < part * 64 + 64; k++) n += (H[k] < H[b] || (H[k] == H[b] && rank[k] < rank[b])) ? 1u : 0u;
+            PLS_ATOMIC_ADD(&scratch[b], n);
+        }
+    }
+    PLS_SYNC();
+    /* classes are 0..255 but only equality matters: two bins with the same count of smaller keys have the same key */
+    PLS_THREADS(tid, nt) {
+        for (int w = tid; w < 64; w += nt)
+            out[4 * SEG_TN + w] = (scratch[4 * w] & 255u) | ((scratch[4 * w + 1] & 255u) << 8) | ((scratch[4 * w + 2] & 255u) << 16) | ((scratch[4 * w + 3] & 255u) << 24);
+        /* one lane per band and direction */
+        const int nb = SEG_TOFF / q + 1;                                   /* bands per sign that touch [-320, 319] */
+        for (int i = tid; i < nb * 4; i += nt) {
+            const int t = i >> 2, sgn = (i >> 1) & 1, dir = i & 1;
+            const int blo = sgn ? -(t * q) - s : t * q, bhi = blo + s;
+            uint32_t *dst = out + (dir ? 2 * SEG_TN : 0) + sgn * SEG_TN;
+            int L = 0; uint32_t bh = 0, br = 0; bool have = false;
+            if (!dir) {
+                for (int v = blo; v <= bhi; v++) {                         /* prefix leaders: lowest v among equals */
+                    const uint32_t h = H[v & 255], r = rank[v & 255];
+                    if (!have || h > bh || (h == bh && r > br)) { L = v; bh = h; br = r; have = true; }
+                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((scratch[L & 255] & 255u) << 16);
+                }
+            } else {
+                for (int v = bhi; v >= blo; v--) {                         /* suffix leaders: scanning down, equals replace */
+                    const uint32_t h = H[v & 255], r = rank[v & 255];
+                    if (!have || h > bh || (h == bh && r >= br)) { L = v; bh = h; br = r; have = true; }
+                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((scratch[L & 255] & 255u) << 16);
+                }
+            }
+        }
+    }
+    PLS_SYNC();
+}
+
+/* histogram the coming attempt starts from, for the decisions that begin a row attempt afresh (not SEG_K_RESTART):
+ * INIT: zero; RETRY / ABORT: the committed histogram; COMMIT: committed histogram + every bump of the winner's row */
+PLS_HD void seg_next_hist(const SegJob &j, const SegDecision &D, const SegCtl &cur, int prev, uint32_t *Hn, int nt)
+{
+    const uint32_t W = j.W, ngrp = j.ngrp;
+    PLS_THREADS(tid, nt) {
+        for (int b = tid; b < 256; b += nt) {
+            uint32_t v = 0u;
+            if (D.kind == SEG_K_RETRY || D.kind == SEG_K_ABORT) v = j.H0[prev * 256 + b];
+            else if (D.kind == SEG_K_COMMIT) {
+                const int w = D.winner;
+                const uint32_t wsx = cur.start_x[w], wfg = (wsx / SEG_L) / SEG_GRP;
+                v = j.H0[prev * 256 + b] + j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
+                if (wsx < W) for (uint32_t g = wfg; g < ngrp; g++) v += j.grpcnt[((size_t)w * ngrp + g) * 256 + b];
+            }
+            Hn[b] = v;
+        }
+    }
+    PLS_SYNC();
+}
+
+/* Control kernel of attempt `attempt`: reads what attempt-1 left (control block and sums of parity prev), writes the control block
+ * of parity par.  bx < SEG_NFILT: candidate bx (epoch setup, decision tables); bx == SEG_NFILT: the image-wide fields;
+ * bx > SEG_NFILT: commit of pixels [(bx - SEG_NFILT - 1) * SEG_THREADS, ...) */
+PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int bx, unsigned char *smem)
+{
+    const int par = attempt & 1, prev = par ^ 1;
+    const SegCtl &cur = j.ctl[prev];
+    SegCtl &nxt = j.ctl[par];
+    const SegAcc &A = j.acc[prev];
+    const uint32_t W = j.W, H = j.H, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
+    uint32_t *Hn = (uint32_t *)smem, *rank = Hn + 256, *scratch = Hn + 512, *basen = Hn + 768;   /* 4 x 256 words */
+    const SegDecision D = seg_decide(j, P, attempt, cur, A);
+    const uint32_t y = attempt ? cur.y : 0u;
+    int s_next = attempt ? (int)cur.s : P.strength;
+    if (D.kind == SEG_K_RETRY) s_next = (int)cur.s - 1;
+    if (D.kind == SEG_K_COMMIT) s_next = P.strength;
+
+    if (bx == SEG_NFILT) {
+        /* ---- the image-wide fields ---- */
+        if (D.kind == SEG_K_FINISHED) {
+            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; } }
+            return;
+        }
+        if (D.kind != SEG_K_RESTART) seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int b = tid; b < 256; b += SEG_THREADS) j.H0[par * 256 + b] = D.kind == SEG_K_RESTART ? j.H0[prev * 256 + b] : Hn[b];
+            /* zero the sums the coming attempt accumulates into */
+            if (tid < (int)(sizeof(SegAcc) / 4)) ((uint32_t *)&j.acc[par])[tid] = 0u;
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid < SEG_NFILT) j.acc[par].fail[tid] = SEG_NOFAIL;
+            if (tid == 0) {
+                uint32_t ny = y, fin = 0, st = attempt ? cur.status : 0u, retried = attempt ? cur.retried : 0u, rt = attempt ? cur.restarts_total : 0u;
+                uint32_t ser = attempt ? cur.serial_rows : 0u;
+                if (D.kind == SEG_K_COMMIT) { ny = y + 1; if (ny >= H) fin = 1; }
+                if (D.kind == SEG_K_RETRY) retried += cur.s == (uint32_t)P.strength ? 1u : 0u;
+                if (D.kind == SEG_K_ABORT) { st = 65u; fin = 1; }                         /* pngloss_image.c:268-271 aborts here */
+                if (D.kind == SEG_K_RESTART)
+                    for (int g = 0; g < SEG_NFILT; g++) if ((D.failed >> g) & 1u) { rt++; if (cur.restarts[g] + 1 > SEG_MAX_RESTARTS) ser++; }
+                if (W == 0 || H == 0) fin = 1;
+                nxt.y = ny; nxt.s = (uint32_t)(s_next < 0 ? 0 : s_next); nxt.status = st; nxt.finished = fin; nxt.retried = retried; nxt.restarts_total = rt;
+                nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt;
+                if (j.progress && D.kind == SEG_K_COMMIT) *(volatile uint32_t *)j.progress = ny;
+                if (fin) {
+                    /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
+                    uint32_t nz = 0;
+                    for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
+                    for (int i = 0; i < 64; i++) j.result[i] = 0;
+                    j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
+                    j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[20] = 3;   /* engine id: segment-parallel */
+                }
+            }
+        }
+        return;
+    }
+    if (D.kind == SEG_K_FINISHED) return;
+
+    if (bx > SEG_NFILT) {
+        /* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x ---- */
+        if (D.kind != SEG_K_COMMIT) return;
+        const uint32_t *cd = j.cand + (size_t)D.winner * W * 4;
+        uint32_t *rowp = j.img + (size_t)y * W;
+        const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
+        PLS_THREADS(tid, SEG_THREADS) {
+            const uint32_t x = (uint32_t)(bx - SEG_NFILT - 1) * SEG_THREADS + (uint32_t)tid;
+            if (x < W) {
+                const uint32_t *cwp = cd + (size_t)x * 4;
+                const uint32_t np = ((cwp[0] & 255u) | ((cwp[1] & 255u) << 8) | ((cwp[2] & 255u) << 16) | ((cwp[3] & 255u) << 24)) & keep;
+                j.old_above[x] = rowp[x];
+                rowp[x] = np;
+                /* error rows: err0'[x] = err1[x] + t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2), err1'[x] = t(x+1)+h(x)+t(x-1) (optimize_state.c:446-465) */
+                uint32_t n0[4], n1[4];
+                for (int p = 0; p < 4; p++) {
+                    const int ch = seg_channel_of_plane(bpp, p);
+                    int c1 = 0, c2 = 0;
+                    if (ch >= 0)
+                        for (int dx = -2; dx <= 2; dx++) {
+                            const long sxp = (long)x + dx;
+                            if (sxp < 0 || sxp >= (long)W) continue;
+                            const uint32_t e = seg_terms(P.lut_b, P.bleed, seg_cand_diff(cd[(size_t)sxp * 4 + ch]));
+                            const int T_ = (int)(int8_t)(e & 255u), F_ = (int)(int8_t)((e >> 8) & 255u), V_ = (int)(int8_t)((e >> 16) & 255u), H_ = (int)e >> 24;
+                            const int ad = dx < 0 ? -dx : dx;
+                            c1 += ad == 2 ? T_ : (ad == 1 ? F_ : V_);
+                            if (ad <= 1) c2 += ad == 1 ? T_ : H_;
+                        }
+                    n0[p] = (uint32_t)(seg_err_plane(j.err1 + 2 * (size_t)x, p) + c1) & 0xffffu;     /* int16 wrap-on-store */
+                    n1[p] = (uint32_t)c2 & 0xffffu;
+                }
+                j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
+                j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
+            }
+            if (bx == SEG_NFILT + 1 && tid == 0) {
+                if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << D.winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
+                j.row_ids[y] = (uint8_t)D.winner;
+            }
+        }
+        return;
+    }
+
+    /* ---- candidate f ---- */
+    const int f = bx;
+    const bool failed = (D.failed >> f) & 1u;
+    PLS_THREADS(tid, SEG_THREADS) { for (int b = tid; b < 256; b += SEG_THREADS) rank[b] = j.orig_rank[f * 256 + b]; }
+    if (D.kind != SEG_K_RESTART) {
+        /* a fresh row attempt: start of the row, no validated prefix */
+        seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int b = tid; b < 256; b += SEG_THREADS) { basen[b] = 0u; j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
+            if (tid == 0) {
+                nxt.active[f] = 1; nxt.start_x[f] = 0; nxt.restarts[f] = 0; nxt.cost[f] = ~0ull;
+                for (int c = 0; c < 4; c++) nxt.state[f][c] = seg_state_pack(SegState{ 0, 0, 0 });
+            }
+        }
+        PLS_SYNC();
+        const int sn = s_next < 0 ? 0 : s_next;
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, sn, sn + 1, SEG_THREADS);
+        return;
+    }
+    if (!failed) {
+        /* nothing changes for this candidate: finished (now or earlier), its cost is kept */
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int b = tid; b < 256; b += SEG_THREADS) j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = j.base[((size_t)prev * SEG_NFILT + f) * 256 + b];
+            if (tid == 0) {
+                nxt.active[f] = 0; nxt.start_x[f] = cur.start_x[f]; nxt.restarts[f] = cur.restarts[f];
+                for (int c = 0; c < 4; c++) nxt.state[f][c] = cur.state[f][c];
+                nxt.cost[f] = D.cost[f];
+            }
+        }
+        return;
+    }
+    /* epoch setup: bumps in front of the failing pixel xp, that pixel evaluated exactly, new start behind it */
+    {
+        const uint32_t xp = A.fail[f] >> 2, sx = cur.start_x[f], first = sx / SEG_L, fgrp = first / SEG_GRP;
+        const uint32_t sgp = xp / SEG_L, gp = sgp / SEG_GRP;
+        const bool serial = cur.restarts[f] + 1 > SEG_MAX_RESTARTS;
+        const int s = (int)cur.s, q = s + 1;
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int b = tid; b < 256; b += SEG_THREADS) {
+                uint32_t v = j.base[((size_t)prev * SEG_NFILT + f) * 256 + b];
+                for (uint32_t g = fgrp; g < gp; g++) v += j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
+                for (uint32_t sg = (uint32_t)seg_max((int)(gp * SEG_GRP), (int)first); sg < sgp; sg++) v += j.segcnt[((size_t)f * nseg + sg) * 256 + b];
+                basen[b] = v; Hn[b] = j.H0[prev * 256 + b];
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid == 0) {
+                const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+                uint32_t *cd = j.cand + (size_t)f * W * 4;
+                for (uint32_t x = (uint32_t)seg_max((int)(sgp * SEG_L), (int)sx); x < xp; x++) for (uint32_t c = 0; c < bpp; c++) basen[seg_cand_bin(cd[(size_t)x * 4 + c])]++;
+                const uint32_t xend = serial ? W : xp + 1;
+                SegState st[4];
+                for (uint32_t c = 0; c < bpp; c++) {
+                    int rem1, thr1, rem2, thr2;
+                    seg_rem_thr(P.lut_a, P.bleed, xp >= 1 ? seg_cand_diff(cd[(size_t)(xp - 1) * 4 + c]) : 0, rem1, thr1);
+                    seg_rem_thr(P.lut_a, P.bleed, xp >= 2 ? seg_cand_diff(cd[(size_t)(xp - 2) * 4 + c]) : 0, rem2, thr2);
+                    st[c].left = xp >= 1 ? seg_cand_byte(cd[(size_t)(xp - 1) * 4 + c]) : 0; st[c].cn = rem1 + thr2; st[c].th = thr1;
+                }
+                /* the reference's own order: channel after channel against the running histogram H0 + basen (optimize_state.c:212-254) */
+                for (uint32_t x = xp; x < xend; x++)
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, (int)c);
+                        const uint32_t w = seg_step_scan(f, p, st[c], Hn, basen, rank, s, q, P.lut_a, P.bleed);
+                        cd[(size_t)x * 4 + c] = w;
+                        basen[seg_cand_bin(w)]++;
+                    }
+                for (uint32_t c = 0; c < 4; c++) nxt.state[f][c] = c < bpp ? seg_state_pack(st[c]) : 0u;
+                nxt.start_x[f] = xend;
+                nxt.active[f] = 1; nxt.restarts[f] = cur.restarts[f] + 1; nxt.cost[f] = ~0ull;
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int b = tid; b < 256; b += SEG_THREADS) {
+                j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = basen[b];
+                Hn[b] += basen[b];                                                /* frozen histogram of the new epoch */
+            }
+        }
+        PLS_SYNC();
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, s, q, SEG_THREADS);
+    }
+}
+
+#endif /* PL_SEG_CORE_H */

@@ -1,0 +1,101 @@
+/*
+ * seg_host.cpp -- TEST INFRASTRUCTURE: runs the kernel bodies of the segment-parallel row engine
+ * (pngloss_amd/csrc/pl_seg_core.h, the same source hipcc compiles into pl_seg.hip's kernels) on the CPU, as plain loops
+ * over (workgroup, thread), so that the CPU suite can check the engine's logic bit-exactly against the oracle without a GPU.
+ * Never shipped, never loaded by the product (which has no CPU path).
+ *
+ *   seg_host_optimize(rgba, W, H, row_filters|NULL, strength, bleed, stats[8])  -> 0, or 64 if (strength, bleed) has more
+ *   chain states than the enumeration has lanes (the product then uses the one-workgroup-per-image engine)
+ */
+#include "../../pngloss_amd/csrc/pl_seg_core.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+int paeth_i(int a, int d, int l) { return seg_paeth(a, d, l); }
+
+struct Arena {
+    std::vector<std::vector<unsigned char>> bufs;
+    template <class T> T *take(size_t n) { bufs.emplace_back((n ? n : 1) * sizeof(T) + 64, (unsigned char)0xA5); return (T *)bufs.back().data(); }   /* junk-filled: nothing may rely on zeroed memory */
+};
+
+} // namespace
+
+extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, unsigned char *row_filters, unsigned strength, long bleed, uint32_t *stats)
+{
+    if (!W || !H) return 0;
+    static SegParams P;
+    if (!seg_build_params(P, (int)strength, (int)bleed)) return 64;
+    if (getenv("SEG_HOST_FORCE_FILTER")) P.engine_flags = (atoi(getenv("SEG_HOST_FORCE_FILTER")) + 1) << 8;
+    /* classify + pack into slots (what pl_classify / pl_repack do on the device) */
+    bool gray = true, opaque = true;
+    for (size_t i = 0; i < (size_t)W * H; i++) { const unsigned char *p = rgba + 4 * i; gray &= p[0] == p[1] && p[1] == p[2]; opaque &= p[3] == 255; }
+    const uint32_t bpp = gray ? (opaque ? 1u : 2u) : (opaque ? 3u : 4u);
+    Arena A;
+    uint32_t *img = A.take<uint32_t>((size_t)W * H);
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        const unsigned char *p = rgba + 4 * i;
+        img[i] = bpp == 4 ? ((uint32_t)p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)) : bpp == 3 ? ((uint32_t)p[0] | (p[1] << 8) | (p[2] << 16))
+                 : bpp == 2 ? ((uint32_t)p[1] | (p[3] << 8)) : (uint32_t)p[1];
+    }
+    /* original_frequency + ranks (pl_hist / pl_rank) */
+    std::vector<uint32_t> oh(5 * 256, 0), rank(5 * 256, 0);
+    for (uint32_t y = 0; y < H; y++)
+        for (uint32_t x = 0; x < W; x++)
+            for (uint32_t c = 0; c < bpp; c++) {
+                auto at = [&](long yy, long xx) -> int { return (yy < 0 || xx < 0) ? 0 : (int)((img[(size_t)yy * W + xx] >> (8 * c)) & 255u); };
+                const int hv = at(y, x), lv = at(y, (long)x - 1), av = at((long)y - 1, x), dv = at((long)y - 1, (long)x - 1);
+                oh[0 * 256 + (hv & 255)]++; oh[1 * 256 + ((hv - lv) & 255)]++; oh[2 * 256 + ((hv - av) & 255)]++;
+                oh[3 * 256 + ((hv - ((av + lv) >> 1)) & 255)]++; oh[4 * 256 + ((hv - paeth_i(av, dv, lv)) & 255)]++;
+            }
+    for (int f = 0; f < 5; f++) for (int b = 0; b < 256; b++) { uint32_t r = 0; for (int k = 0; k < 256; k++) r += oh[f * 256 + k] < oh[f * 256 + b]; rank[f * 256 + b] = r; }
+
+    SegJob j{};
+    j.img = img; j.W = W; j.H = H; j.bpp = bpp;
+    j.row_filters = row_filters;
+    j.row_ids = A.take<uint8_t>(H);
+    j.orig_rank = rank.data();
+    j.cand = A.take<uint32_t>((size_t)5 * W * 4);
+    j.err0 = A.take<uint32_t>((size_t)W * 2); j.err1 = A.take<uint32_t>((size_t)W * 2);
+    for (size_t i = 0; i < (size_t)W * 2; i++) j.err0[i] = j.err1[i] = 0;            /* pl_init zeroes these */
+    j.old_above = A.take<uint32_t>(W);
+    j.final_hist = A.take<uint32_t>(256); j.result = A.take<int32_t>(64); j.progress = nullptr;
+    j.nseg = (W + SEG_L - 1) / SEG_L; j.ngrp = (j.nseg + SEG_GRP - 1) / SEG_GRP;
+    if (j.nseg > SEG_MAX_NSEG) return 64;
+    j.ctl = A.take<SegCtl>(2); j.base = A.take<uint32_t>(2 * 5 * 256); j.H0 = A.take<uint32_t>(2 * 256); j.acc = A.take<SegAcc>(2);
+    j.tables = A.take<uint32_t>(5 * SEG_TBL_WORDS);
+    j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
+    j.entry = A.take<uint32_t>((size_t)5 * j.nseg * 4);
+    j.segcnt = A.take<uint16_t>((size_t)5 * j.nseg * 256);
+    j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);
+    std::vector<unsigned char> smem(160 * 1024, 0x5A);
+    const int ncommit = (int)((W + SEG_THREADS - 1) / SEG_THREADS);
+    int attempt = 0;
+    const long max_attempts = (long)H * 64 + 1024;
+    for (;; attempt++) {
+        if (attempt > max_attempts) { fprintf(stderr, "seg_host: no progress\n"); return 65; }
+        for (int bx = 0; bx < SEG_NFILT + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt, bx, smem.data());
+        const int par = attempt & 1;
+        if (j.ctl[par].finished) break;
+        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body(j, P, par, f, (int)sg, smem.data());
+        for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, smem.data());
+        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, smem.data());
+        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_post_body(j, P, par, f, (int)g, smem.data());
+    }
+    const SegCtl &fc = j.ctl[attempt & 1];
+    if (stats) { stats[0] = (uint32_t)attempt; stats[1] = fc.restarts_total; stats[2] = fc.retried; stats[3] = fc.serial_rows; stats[4] = (uint32_t)j.result[2]; stats[5] = bpp; stats[6] = (uint32_t)P.ns; stats[7] = fc.status; }
+    /* unpack (pl_unpack) */
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        unsigned char *p = rgba + 4 * i; const uint32_t w = img[i];
+        switch (bpp) {
+        case 1: p[0] = p[1] = p[2] = (unsigned char)w; p[3] = 255; break;
+        case 2: p[0] = p[1] = p[2] = (unsigned char)w; p[3] = (unsigned char)(w >> 8); break;
+        case 3: p[0] = (unsigned char)w; p[1] = (unsigned char)(w >> 8); p[2] = (unsigned char)(w >> 16); p[3] = 255; break;
+        default: p[0] = (unsigned char)w; p[1] = (unsigned char)(w >> 8); p[2] = (unsigned char)(w >> 16); p[3] = (unsigned char)(w >> 24); break;
+        }
+    }
+    return (int)fc.status;
+}

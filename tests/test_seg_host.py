@@ -1,0 +1,53 @@
+"""The segment-parallel row engine (pngloss_amd/csrc/pl_seg_core.h: enumerate / chain / replay / validate / control) run on the
+CPU by tests/c/seg_host.cpp -- the same kernel bodies hipcc compiles, as loops over (workgroup, thread) -- against the oracle.
+Bit-exact bytes and filter IDs on every byte-per-pixel class, strengths with few and many chain states, bleed dividers,
+rows that need the strength retry, NULL row_filters (every row adaptive), ragged widths around the segment and group sizes."""
+import numpy as np
+import pytest
+
+import pngloss_amd as P
+from tests import util as U
+
+CASES = [(64, 48, m, 19, 2) for m in range(6)] + [
+    (200, 40, 0, 19, 2), (333, 37, 1, 19, 2), (100, 30, 0, 20, 8), (97, 33, 2, 7, 3), (130, 20, 5, 19, 4),
+    (1, 1, 1, 19, 2), (2, 3, 1, 19, 2), (5, 1, 1, 19, 2), (1, 7, 1, 19, 2), (33, 5, 3, 19, 2), (64, 6, 4, 0, 2),
+    (31, 9, 0, 19, 2), (32, 9, 0, 19, 2), (65, 9, 5, 19, 2), (511, 6, 0, 19, 2), (513, 6, 1, 19, 2), (96, 20, 0, 3, 1),
+    (80, 12, 1, 19, 32767),
+]
+
+
+@pytest.mark.parametrize("w,h,mode,s,b", CASES)
+def test_seg_engine_bodies_match_oracle(w, h, mode, s, b):
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    assert rc == 0, "more chain states than lanes? stats %s" % st
+    want, wf = U.run_port(img, s, b)
+    assert np.array_equal(out, want) and np.array_equal(f, wf)
+
+
+def test_seg_engine_all_rows_adaptive():
+    img = P.synth_rgba(150, 24, 0, 3)
+    rc, out, f, st = U.run_seg_host(img, 19, 2, filters=False)
+    want, _ = U.run_port(img, 19, 2, filters=False)
+    assert rc == 0 and np.array_equal(out, want)
+
+
+def test_seg_engine_declines_state_sets_it_has_no_lanes_for():
+    img = P.synth_rgba(40, 8, 0, 0)
+    rc, out, f, st = U.run_seg_host(img, 85, 2)
+    assert rc == 64          # the product takes the one-workgroup-per-image engine for these
+
+
+def test_seg_engine_seeded_random_images():
+    """random images of every class incl. transparency and few-valued ones (ties, saturation), the strengths/bleeds the lanes cover"""
+    ran = 0
+    for img, s, b, want_filters in U.seeded_cases(seed=11, n=36):
+        rc, out, f, st = U.run_seg_host(img, s, b, filters=want_filters)
+        if rc == 64:
+            continue
+        want, wf = U.run_port(img, s, b, filters=want_filters)
+        assert rc == 0 and np.array_equal(out, want), (img.shape, s, b, st)
+        if want_filters:
+            assert np.array_equal(f, wf)
+        ran += 1
+    assert ran >= 12

@@ -216,3 +216,33 @@ def zlib9_filtered(data):
     import zlib
     c = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_FILTERED)
     return c.compress(data) + c.flush()
+
+
+_seg = None
+
+
+def seg_host_lib():
+    """tests/c/seg_host.cpp (the kernel bodies of the segment-parallel row engine, pngloss_amd/csrc/pl_seg_core.h, run as
+    loops on the CPU) built into a shared object (cached per process)."""
+    global _seg
+    if _seg is None:
+        import subprocess
+        import tempfile
+        so = os.path.join(tempfile.mkdtemp(prefix="seg_host_"), "libseg_host.so")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", so, os.path.join(ROOT, "tests", "c", "seg_host.cpp")], check=True)
+        lib = C.CDLL(so)
+        lib.seg_host_optimize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint, C.c_long, C.c_void_p]
+        lib.seg_host_optimize.restype = C.c_int
+        _seg = lib
+    return _seg
+
+
+def run_seg_host(img, s=19, b=2, filters=True):
+    """The segment-parallel engine's kernel bodies on the CPU: returns rc, out, filters, stats
+    (attempts, restarts, retried rows, serial rows, unique symbols, bpp, chain states, status)."""
+    out = np.ascontiguousarray(img).copy()
+    h, w, _ = out.shape
+    f = np.zeros(h, np.uint8)
+    st = np.zeros(8, np.uint32)
+    rc = seg_host_lib().seg_host_optimize(out.ctypes.data, w, h, f.ctypes.data if filters else None, s, b, st.ctypes.data)
+    return rc, out, (f if filters else None), st
