@@ -8,6 +8,7 @@
 #include "../../include/pngloss_hip.h"
 #include "pl_device.h"
 #include "pl_deflate.h"
+#include "pl_seg.h"
 
 #include <chrono>
 #include <cmath>
@@ -52,6 +53,11 @@ struct pngloss_hip_ctx {
     /* -v progress display of the single-image seam: a host-mapped word the engine writes the finished row count to */
     uint32_t *h_progress = nullptr;
     bool want_progress = false;
+    /* segment-parallel engine: two host-mapped words (images finished, attempt being started) the control kernel writes and the
+     * launch loop reads, and what the last batch did */
+    uint32_t *h_seg_words = nullptr;
+    int last_engine = 0;            /* 0 = one workgroup per image (pl_engine), 3 = segment-parallel (pl_seg) */
+    long seg_attempts = 0;
 };
 
 namespace {
@@ -105,6 +111,82 @@ int ensure_ws(pngloss_hip_ctx *ctx, size_t bytes)
 
 struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
 
+/* The segment-parallel engine on the batch in ctx->h_jobs: builds the SegJob table, then enqueues row attempts (five kernels each,
+ * pl_seg.hip) until every image has reported that it is finished.  All control flow of the algorithm is on the device; the host
+ * only keeps the stream fed, at most SEG_LOOKAHEAD attempts ahead of the attempt the device says it is working on.  Records
+ * ev[1]/ev[2] around the engine.  Synchronous up to the end of the engine (the kernels behind it stay asynchronous). */
+int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const SegParams &params, const std::vector<size_t> &seg_offs,
+                   size_t jobs_off, size_t params_off, hipStream_t stream)
+{
+    constexpr long SEG_LOOKAHEAD = 32;
+    if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    void *d_words = nullptr;
+    PL_CHECK(hipHostGetDevicePointer(&d_words, ctx->h_seg_words, 0));
+    volatile uint32_t *words = ctx->h_seg_words;
+    words[0] = 0; words[1] = 0;
+    std::vector<SegJob> sj(n);
+    PlSegBatch b{};
+    uint32_t max_h = 0;
+    for (size_t i = 0; i < n; i++) {
+        const PlJob &pj = ctx->h_jobs[i];
+        const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1);
+        char *base = ctx->d_ws + seg_offs[i];
+        SegJob &s = sj[i];
+        s.img = pj.img; s.row_filters = pj.row_filters; s.row_ids = pj.row_ids; s.W = pj.width; s.H = pj.height; s.bpp = 0;
+        s.orig_rank = pj.orig_rank; s.cand = reinterpret_cast<uint32_t *>(pj.cand);
+        s.err0 = reinterpret_cast<uint32_t *>(pj.err0); s.err1 = reinterpret_cast<uint32_t *>(pj.err1);
+        s.old_above = pj.old_above; s.final_hist = pj.final_hist; s.result = pj.result; s.progress = pj.progress;
+        s.done_counter = static_cast<uint32_t *>(d_words); s.attempt_word = i == 0 ? static_cast<uint32_t *>(d_words) + 1 : nullptr;
+        s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
+        s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
+        s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps);
+        s.entry = reinterpret_cast<uint32_t *>(base + l.entry); s.segcnt = reinterpret_cast<uint16_t *>(base + l.segcnt);
+        s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt);
+        s.firstidx = reinterpret_cast<uint32_t *>(base + l.firstidx); s.rowmm = reinterpret_cast<int32_t *>(base + l.rowmm);
+        s.nseg = pj.width ? l.nseg : 0; s.ngrp = pj.width ? l.ngrp : 0;
+        b.max_nseg = std::max(b.max_nseg, l.nseg); b.max_ngrp = std::max(b.max_ngrp, l.ngrp);
+        b.max_ncommit = std::max(b.max_ncommit, (pj.width + SEG_THREADS - 1) / SEG_THREADS);
+        max_h = std::max(max_h, pj.height);
+    }
+    if (!b.max_ncommit) b.max_ncommit = 1;
+    SegJob *d_sj = reinterpret_cast<SegJob *>(ctx->d_ws + jobs_off);
+    SegParams *d_params = reinterpret_cast<SegParams *>(ctx->d_ws + params_off);
+    PL_CHECK(hipMemcpyAsync(d_sj, sj.data(), sizeof(SegJob) * n, hipMemcpyHostToDevice, stream));
+    PL_CHECK(hipMemcpyAsync(d_params, &params, sizeof(SegParams), hipMemcpyHostToDevice, stream));
+    PL_CHECK(hipStreamSynchronize(stream));          /* sj / params are stack and vector memory */
+    b.d_sj = d_sj; b.d_params = d_params; b.n = n;
+    b.enum_blocks = (params.small_ok ? 3 * b.max_nseg + 2 * ((b.max_nseg + SEG_SMALL_SEGS - 1) / SEG_SMALL_SEGS) : SEG_NFILT * b.max_nseg) + SEG_NFILT;
+    PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
+    PL_CHECK(hipEventRecord(ctx->ev[1], stream));
+    /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */
+    const long max_attempts = (long)max_h * (2 + SEG_MAX_RESTARTS * SEG_NFILT) + 1024;
+    long launched = 0;
+    auto t_last = std::chrono::steady_clock::now();
+    uint32_t seen = 0;
+    while (words[0] < (uint32_t)n) {
+        const uint32_t at = words[1];
+        if (at != seen) { seen = at; t_last = std::chrono::steady_clock::now(); }
+        if (launched - (long)at > SEG_LOOKAHEAD) {
+            if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
+                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress at attempt %u\n", at);
+                return PNGLOSS_HIP_ERROR;
+            }
+            if (hipStreamQuery(stream) != hipErrorNotReady) { /* the queue ran dry without the word moving: re-read */ }
+            std::this_thread::yield();
+            continue;
+        }
+        if (launched > max_attempts) {
+            std::fprintf(stderr, "pngloss_hip: the segment engine needed more than %ld attempts\n", max_attempts);
+            return PNGLOSS_HIP_ERROR;
+        }
+        PL_CHECK(pl_seg_launch_attempt(b, (int)launched, stream));
+        launched++;
+    }
+    PL_CHECK(hipEventRecord(ctx->ev[2], stream));
+    ctx->seg_attempts = launched;
+    return PNGLOSS_SUCCESS;
+}
+
 int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n, const uint32_t *forced_bpp,
             unsigned strength, long bleed, hipStream_t stream, const EmitTarget *emits = nullptr)
 {
@@ -127,6 +209,30 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         if (!images[i].d_rgba && images[i].width && images[i].height) return PNGLOSS_INVALID_ARGUMENT;
         offs.push_back(total);
         total += image_ws(images[i].width ? images[i].width : 1, images[i].height).total;
+    }
+    /* Which row engine: one workgroup per image (pl_engine: batches) or the whole GPU on few images (pl_seg: latency).  The segment
+     * engine needs the chain states of (strength, bleed) to fit its lanes and a row's maps to fit the chain kernel's LDS; it pays
+     * off while the batch leaves it the machine (its work per row is ~250x redundant by design). */
+    SegParams seg_params;
+    bool use_seg = false;
+    uint32_t seg_max_nseg = 1;
+    {
+        const char *em = std::getenv("PNGLOSS_HIP_ENGINE");
+        std::vector<uint32_t> widths(n);
+        for (size_t i = 0; i < n; i++) { widths[i] = images[i].width; seg_max_nseg = std::max(seg_max_nseg, (images[i].width + SEG_L - 1) / SEG_L); }
+        const bool forced = em && std::strcmp(em, "seg") == 0;
+        const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;
+        if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && (forced || n * (size_t)seg_max_nseg <= 2048))
+            use_seg = pl_seg_supported(widths.data(), n, strength, bleed, &seg_params);
+        if (forced && !use_seg && n)
+            std::fprintf(stderr, "pngloss_hip: PNGLOSS_HIP_ENGINE=seg: strength %u / bleed %ld or a width beyond %d are not covered by the segment engine; using the one-workgroup-per-image engine\n", strength, bleed, SEG_MAX_NSEG * SEG_L);
+    }
+    std::vector<size_t> seg_offs;
+    size_t seg_jobs_off = 0, seg_params_off = 0;
+    if (use_seg) {
+        seg_jobs_off = total; total += align_up(sizeof(SegJob) * n, 256);
+        seg_params_off = total; total += align_up(sizeof(SegParams), 256);
+        for (size_t i = 0; i < n; i++) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1).total; }
     }
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
@@ -181,9 +287,16 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
     PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));
+    ctx->last_engine = use_seg ? 3 : 0;
+    if (use_seg) {
+        if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) seg_params.engine_flags = (std::atoi(ff) + 1) << 8;   /* debugging aid */
+        rc = run_seg_engine(ctx, d_jobs, n, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream);
+        if (rc) return rc;
+    } else {
     PL_CHECK(hipEventRecord(ctx->ev[1], stream));
     PL_CHECK(pl_launch_engine(d_jobs, n, prm, stream));
     PL_CHECK(hipEventRecord(ctx->ev[2], stream));
+    }
     PL_CHECK(pl_launch_finish(d_jobs, ctx->h_jobs.data(), n, stream));
     PL_CHECK(pl_launch_emit(d_jobs, ctx->h_jobs.data(), n, stream));
     PL_CHECK(hipEventRecord(ctx->ev[3], stream));
@@ -215,6 +328,14 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         int32_t r[64] = { 0 };
         PL_CHECK(hipMemcpy(r, ctx->h_jobs[i].result, sizeof r, hipMemcpyDeviceToHost));
         if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4] };
+        if (r[20] == 3) {
+            if (std::getenv("PNGLOSS_HIP_DEBUG"))
+                std::fprintf(stderr, "pngloss_hip: image %zu: segment-parallel engine: %d attempts for %u rows, %d epochs (validation restarts), %d rows finished serially, candidate none dropped by its cost bound %d times, engine %.3f ms\n",
+                             i, r[5], ctx->h_jobs[i].height, r[4], r[6], r[7], ctx->engine_ms);
+            if (r[0]) { std::fprintf(stderr, "pngloss_hip: image %zu: no acceptable filter row (device status %d)\n", i, r[0]); worst = PNGLOSS_INTERNAL_ABORT; }
+            if (results && i < n) results[i].repaired_pixels = (uint32_t)r[4];
+            continue;
+        }
         if (std::getenv("PNGLOSS_HIP_DEBUG"))
             std::fprintf(stderr, "pngloss_hip: image %zu: chain kcycles per wave %d %d %d %d, repaired pixels %d %d %d %d, engine %.3f ms\n", i,
                          r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15], ctx->engine_ms);
@@ -385,6 +506,7 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->h_progress) (void)hipHostFree(ctx->h_progress);
+    if (ctx->h_seg_words) (void)hipHostFree(ctx->h_seg_words);
     delete ctx;
 }
 
@@ -715,7 +837,7 @@ int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *his
     return PNGLOSS_SUCCESS;
 }
 
-const char *pngloss_hip_version(void) { return "pngloss_hip 0.1 (gfx950 row engine v5; seam: pngloss_image.h:14-29)"; }
+const char *pngloss_hip_version(void) { return "pngloss_hip 0.3 (gfx950; row engines: segment-parallel v1 + band-leader v2; seam: pngloss_image.h:14-29)"; }
 
 /* ---- the reference's seam ------------------------------------------------------------------------------- */
 

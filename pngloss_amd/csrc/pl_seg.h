@@ -1,0 +1,32 @@
+/*
+ * pl_seg.h -- host-side interface of the segment-parallel row engine (pl_seg.hip / pl_seg_core.h).  Internal.
+ */
+#ifndef PL_SEG_H
+#define PL_SEG_H
+
+#include "pl_device.h"
+#include "pl_seg_core.h"
+
+/* per-image device workspace of the engine, beyond what PlJob already has (offsets into one 256-B aligned carve) */
+struct PlSegLayout { size_t ctl, base, h0, acc, tables, maps, entry, segcnt, grpcnt, firstidx, rowmm, total; uint32_t nseg, ngrp; };
+PlSegLayout pl_seg_layout(uint32_t width);
+
+/* can the engine take this batch?  (chain states of (strength, bleed) fit the lanes, every row fits the chain kernel) */
+bool pl_seg_supported(const uint32_t *widths, size_t n, unsigned strength, long bleed, SegParams *params_out);
+
+struct PlSegBatch {
+    const SegJob *d_sj;       /* device: one per image */
+    const SegParams *d_params;
+    size_t n;
+    uint32_t max_nseg, max_ngrp, max_ncommit;
+    uint32_t enum_blocks;     /* grid of the enumeration kernel: 3 (or 5) x max_nseg + 2 x ceil(max_nseg / SEG_SMALL_SEGS) + 5 first-segment walkers */
+};
+
+/* fills sj[i].bpp from the class the prepare kernels detected */
+hipError_t pl_seg_launch_resolve(const PlJob *d_jobs, SegJob *d_sj, size_t n, hipStream_t stream);
+/* one attempt = control, enumerate, chain, replay, validate+post */
+hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t stream);
+/* control kernel only (the attempt after the last row's: writes the final control block) */
+hipError_t pl_seg_launch_control(const PlSegBatch &b, int attempt, hipStream_t stream);
+
+#endif

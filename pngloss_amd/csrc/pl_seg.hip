@@ -1,0 +1,159 @@
+/*
+ * pl_seg.hip -- kernels and launcher of the SEGMENT-PARALLEL row engine: one image spread over the whole MI355X.
+ *
+ * The algorithm, its proof obligation (the validation pass) and the kernel bodies live in pl_seg_core.h, which is also compiled
+ * for the CPU by tests/c/seg_host.cpp.  Here: the five gfx950 kernels of one row attempt, blockIdx.y = image of the batch,
+ *
+ *   seg_k_ctl     5 candidate workgroups + 1 image-wide + W/1024 commit workgroups
+ *   seg_k_enum    5 x nseg workgroups of 1024 lanes (4 channels x 256 chain states), decision tables + pixel records in LDS
+ *   seg_k_chain   5 x 4 workgroups, a row's state maps in LDS (up to 132 KB of the CU's 160 KB), one lookup per segment
+ *   seg_k_replay  5 x ngrp workgroups of one wave: lane = (segment, channel)
+ *   seg_k_post    5 x ngrp workgroups of 1024 lanes: exact validation of every decision + the row cost sums
+ *
+ * and no grid barrier anywhere: consecutive kernels on one stream are the grid-wide synchronisation (1.5-2 us on this machine
+ * against 4-7 us for a hand-made in-kernel barrier across 8 XCDs, /opt/skills/guides/MI355X_MICROARCH.md), and every piece of
+ * state is in device memory, so the host only enqueues attempts until the images report that they are finished.
+ */
+#include "pl_seg.h"
+
+#include <atomic>
+
+namespace {
+
+__global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sj[i].bpp = pl_job_bpp(jobs[i]);
+}
+
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *sj, const SegParams *P, int attempt)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    if (blockIdx.x > SEG_NFILT && (blockIdx.x - SEG_NFILT - 1) * SEG_THREADS >= j.W) return;
+    seg_ctl_body(j, *P, attempt, (int)blockIdx.x, seg_smem);
+}
+
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_enum(const SegJob *sj, const SegParams *P, int par, unsigned max_nseg)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    /* workgroups [0, nbig * max_nseg): one segment of a filter that looks at the left pixel; behind them: SEG_SMALL_SEGS segments of none / up */
+    const bool small_ok = P->small_ok != 0;
+    const unsigned nbig = small_ok ? 3u : 5u;
+    if (blockIdx.x < nbig * max_nseg) {
+        const unsigned k = blockIdx.x / max_nseg, seg = blockIdx.x % max_nseg;
+        const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
+        if (seg >= j.nseg) return;
+        seg_enum_body(j, *P, par, (int)f, (int)seg, seg_smem);
+    } else if (blockIdx.x < gridDim.x - SEG_NFILT) {
+        const unsigned r = blockIdx.x - nbig * max_nseg, per = (max_nseg + SEG_SMALL_SEGS - 1) / SEG_SMALL_SEGS;
+        const unsigned f = r / per ? 2u : 0u, seg0 = (r % per) * SEG_SMALL_SEGS;
+        if (seg0 >= j.nseg) return;
+        seg_enum_small_body(j, *P, par, (int)f, (int)seg0, seg_smem);
+    } else {
+        /* the last five workgroups walk the epoch's first segment of one candidate each */
+        seg_first_body(j, *P, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
+    }
+}
+
+__global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *sj, const SegParams *P, int par)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    seg_chain_body(j, *P, par, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), seg_smem);
+}
+
+__global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *sj, const SegParams *P, int par, unsigned max_ngrp)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    const unsigned f = blockIdx.x / max_ngrp, grp = blockIdx.x % max_ngrp;
+    if (grp >= j.ngrp) return;
+    seg_replay_body(j, *P, par, (int)f, (int)grp, seg_smem);
+}
+
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_post(const SegJob *sj, const SegParams *P, int par, unsigned max_ngrp)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    const unsigned f = blockIdx.x / max_ngrp, grp = blockIdx.x % max_ngrp;
+    if (grp >= j.ngrp) return;
+    seg_post_body(j, *P, par, (int)f, (int)grp, seg_smem);
+}
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+hipError_t chain_attr()
+{
+    /* the attribute belongs to the function ON THE CURRENT DEVICE: remembered per device (a node has up to 8) */
+    static std::atomic<unsigned> done{ 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= 32 || !(done.load(std::memory_order_acquire) & (1u << dev))) {
+        const hipError_t e = hipFuncSetAttribute((const void *)seg_k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_SM_CHAIN(SEG_MAX_NSEG));
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+
+} // namespace
+
+PlSegLayout pl_seg_layout(uint32_t width)
+{
+    PlSegLayout l{};
+    l.nseg = (width + SEG_L - 1) / SEG_L;
+    l.ngrp = (l.nseg + SEG_GRP - 1) / SEG_GRP;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align256(o + (bytes ? bytes : 4)); return at; };
+    l.ctl = take(2 * sizeof(SegCtl));
+    l.base = take(2 * SEG_NFILT * 256 * 4);
+    l.h0 = take(2 * 256 * 4);
+    l.acc = take(2 * sizeof(SegAcc));
+    l.tables = take((size_t)SEG_NFILT * SEG_TBL_WORDS * 4);
+    l.maps = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 2);
+    l.entry = take((size_t)SEG_NFILT * l.nseg * 4 * 4);
+    l.segcnt = take((size_t)SEG_NFILT * l.nseg * 256 * 2);
+    l.grpcnt = take((size_t)SEG_NFILT * l.ngrp * 256 * 4);
+    l.firstidx = take(SEG_NFILT * 4 * 2 * 4);
+    l.rowmm = take(((size_t)(width + SEG_THREADS - 1) / SEG_THREADS) * 8);
+    l.total = o;
+    return l;
+}
+
+bool pl_seg_supported(const uint32_t *widths, size_t n, unsigned strength, long bleed, SegParams *params_out)
+{
+    if (bleed < 1 || bleed > 32767 || strength > 255) return false;
+    for (size_t i = 0; i < n; i++)
+        if ((widths[i] + SEG_L - 1) / SEG_L > SEG_MAX_NSEG) return false;
+    return seg_build_params(*params_out, (int)strength, (int)bleed);
+}
+
+hipError_t pl_seg_launch_resolve(const PlJob *d_jobs, SegJob *d_sj, size_t n, hipStream_t stream)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(seg_k_resolve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_jobs, d_sj, (unsigned)n);
+    return hipGetLastError();
+}
+
+hipError_t pl_seg_launch_control(const PlSegBatch &b, int attempt, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_NFILT + 1 + b.max_ncommit, (unsigned)b.n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
+    return hipGetLastError();
+}
+
+hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t stream)
+{
+    if (!b.n) return hipSuccess;
+    hipError_t e = chain_attr();
+    if (e != hipSuccess) return e;
+    const int par = attempt & 1;
+    const unsigned n = (unsigned)b.n;
+    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_NFILT + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
+    hipLaunchKernelGGL(seg_k_enum, dim3(b.enum_blocks, n), dim3(SEG_THREADS), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
+    hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
+    hipLaunchKernelGGL(seg_k_post, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_THREADS), SEG_SM_POST, stream, b.d_sj, b.d_params, par, b.max_ngrp);
+    return hipGetLastError();
+}

@@ -54,12 +54,31 @@
 #define PLS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define PLS_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define PLS_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#define PLS_WAVE_LEADER(tid) (((tid) & 63) == 0)
+__device__ __forceinline__ uint32_t pls_wave_sum_u32(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__device__ __forceinline__ uint64_t pls_wave_sum_u64(uint64_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__device__ __forceinline__ int pls_wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ int pls_wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
+#define PLS_ATOMIC_MAX_I(p, v) atomicMax((p), (v))
+#define PLS_ATOMIC_MIN_I(p, v) atomicMin((p), (v))
+#define PLS_HOST_VISIBLE_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define PLS_HOST_VISIBLE_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #else
 #define PLS_THREADS(tid, nt) for (int tid = 0; tid < (int)(nt); ++tid)
 #define PLS_SYNC() ((void)0)
 #define PLS_ATOMIC_ADD(p, v) (*(p) += (v))
 #define PLS_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
 #define PLS_ATOMIC_ADD64(p, v) (*(p) += (v))
+/* the CPU harness runs one "thread" at a time: every thread is its own wave */
+#define PLS_WAVE_LEADER(tid) (true)
+inline uint32_t pls_wave_sum_u32(uint32_t v) { return v; }
+inline uint64_t pls_wave_sum_u64(uint64_t v) { return v; }
+inline int pls_wave_max_i(int v) { return v; }
+inline int pls_wave_min_i(int v) { return v; }
+#define PLS_ATOMIC_MAX_I(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
+#define PLS_ATOMIC_MIN_I(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define PLS_HOST_VISIBLE_ADD(p, v) (*(p) += (v))
+#define PLS_HOST_VISIBLE_STORE(p, v) (*(p) = (v))
 #endif
 
 #define SEG_NFILT 5
@@ -72,11 +91,14 @@
 #define SEG_INVALID 0xFFFFu
 #define SEG_NOFAIL 0xFFFFFFFFu
 #define SEG_MAX_RESTARTS 12      /* epochs per candidate and row before the rest of the row is done serially */
-#define SEG_MAX_NSEG 512
+#define SEG_MAX_NSEG 256              /* the chain kernel keeps a row's maps in shared memory: 256 x 512 B */
 #define SEG_THREADS 1024
 #define SEG_CHAIN_THREADS 256
-#define SEG_REPLAY_THREADS 64
+#define SEG_REPLAY_THREADS 512       /* SEG_GRP * SEG_L: every thread loads one pixel of the group, 64 of them walk */
 #define SEG_KEYLUT_MAX 8192
+#define SEG_NSS 32                /* lanes per channel for none / up */
+#define SEG_SMALL_SEGS 8           /* segments per enumeration workgroup for them */
+#define SEG_KEYS_MAX 2048
 
 /* what a row attempt decided (seg_ctl_body) */
 enum { SEG_K_INIT = 0, SEG_K_RESTART, SEG_K_RETRY, SEG_K_COMMIT, SEG_K_ABORT, SEG_K_FINISHED };
@@ -92,11 +114,15 @@ struct SegParams {
     uint32_t lut_b[512];           /* [diff+256] -> t | f << 8 | v << 16 | h << 24 (int8 each): the next-rows terms          */
     uint32_t st_pack[SEG_NSP];     /* state i -> (delta+128) | (cn+128) << 8 | (th+128) << 16 */
     uint16_t keylut[SEG_KEYLUT_MAX]; /* ((delta+dmax) * (2cmax+1) + cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
+    /* filters whose prediction ignores the left pixel (none, up): the state is (cn, th) alone */
+    int32_t ns_small, small_ok;
+    uint32_t st_small[SEG_NSS];    /* state i -> (cn+128) | (th+128) << 8 */
+    uint16_t keylut_small[SEG_KEYS_MAX];   /* (cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
 };
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
 struct SegCtl {
-    uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts;
+    uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts, dropped_none, pad0;
     uint32_t active[SEG_NFILT];      /* the candidate still has unvalidated pixels (or sums) to produce in this attempt */
     uint32_t start_x[SEG_NFILT];     /* pixels [0, start_x) of the candidate row are validated */
     uint32_t state[SEG_NFILT][4];    /* chain state in front of start_x: left | (cn+128) << 8 | (th+128) << 16 */
@@ -109,7 +135,8 @@ struct SegAcc {
     uint32_t cost[SEG_NFILT];
     uint32_t hs[SEG_NFILT][SEG_NFILT];
     uint32_t fail[SEG_NFILT];        /* smallest failing decision index x*4+c, or SEG_NOFAIL */
-    uint32_t pad[3];
+    uint32_t lb_valid;               /* workgroups that contributed to none_lb (must reach ngrp) */
+    uint64_t none_lb;                /* lower bound of candidate none's row cost (seg_post_body) */
 };
 
 struct SegJob {
@@ -124,7 +151,9 @@ struct SegJob {
     uint32_t *old_above;      /* [W] */
     uint32_t *final_hist;     /* [256] */
     int32_t *result;          /* [64] */
-    uint32_t *progress;       /* or null */
+    uint32_t *progress;       /* or null: host-visible word that receives the number of finished rows (-v display) */
+    uint32_t *done_counter;   /* or null: host-visible word, +1 when this image is finished (the host stops enqueueing attempts) */
+    uint32_t *attempt_word;   /* or null: host-visible word that receives the number of the attempt being started (launch throttle) */
     SegCtl *ctl;              /* [2] */
     uint32_t *base;           /* [2][5][256] bumps of the validated prefix [0, start_x) */
     uint32_t *H0;             /* [2][256] committed histogram */
@@ -134,6 +163,8 @@ struct SegJob {
     uint32_t *entry;          /* [5][nseg][4] */
     uint16_t *segcnt;         /* [5][nseg][256] */
     uint32_t *grpcnt;         /* [5][ngrp][256] */
+    uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
+    int32_t *rowmm;           /* [ncommit][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
     uint32_t nseg, ngrp;
 };
 
@@ -199,6 +230,8 @@ PLS_HD int seg_cand_byte(uint32_t w) { return (int)(w & 255u); }
 PLS_HD int seg_cand_diff(uint32_t w) { return seg_sext16((int)(w >> 8)); }
 PLS_HD int seg_cand_bin(uint32_t w) { return (int)(w >> 24); }
 
+struct alignas(16) SegVec16 { uint32_t a, b, c, d; };
+
 /* chain state */
 struct SegState { int left, cn, th; };
 PLS_HD uint32_t seg_state_pack(const SegState &s) { return (uint32_t)(s.left & 255) | ((uint32_t)((s.cn + 32768) & 0xffff) << 8) | ((uint32_t)((s.th + 128) & 255) << 24); }
@@ -218,14 +251,51 @@ PLS_HD SegPix seg_pix_load(const uint32_t *row, const uint32_t *nab, const uint3
                         seg_err_plane(err0 + 2 * (size_t)x, seg_plane_of_channel(bpp, c)));
 }
 
+/* strength geometry: s, q = s + 1 and (device) the float reciprocal that makes trunc(a / q) == (int)(a * rq) for |a| < 2^17
+ * (exhaustively checked in tests/test_host_logic.py::test_float_reciprocal_division) */
+struct SegGeo { int s, q; float rq; };
+PLS_HD SegGeo seg_geo(int s)
+{
+    SegGeo g; g.s = s; g.q = s + 1;
+    union { float f; uint32_t u; } r; r.f = 1.0f / (float)(s + 1); r.u += 2u; g.rq = r.f;
+    return g;
+}
+PLS_HD int seg_div_q(int a, const SegGeo &g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)((float)a * g.rq);
+#else
+    return a / g.q;
+#endif
+}
+
+/* the four channel records of pixel x (zero records beyond the row / for unused channels): every load of the pixel is issued once */
+PLS_HD void seg_pix_load4(SegPix *dst, const uint32_t *row, const uint32_t *nab, const uint32_t *err0, uint32_t bpp, uint32_t x, uint32_t W)
+{
+    uint32_t o = 0, a = 0, d = 0, e[2] = { 0, 0 };
+    if (x < W) {
+        o = row[x];
+        if (nab) { a = nab[x]; d = x ? nab[x - 1] : 0u; }
+        e[0] = err0[2 * (size_t)x]; e[1] = err0[2 * (size_t)x + 1];
+    }
+    const bool alpha0 = x < W && (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+    for (int c = 0; c < 4; c++) {
+        if ((uint32_t)c < bpp && x < W)
+            dst[c] = seg_pix_make((int)((o >> (8 * c)) & 255u), (int)((a >> (8 * c)) & 255u), (int)((d >> (8 * c)) & 255u), (alpha0 && (uint32_t)c == bpp - 1u) ? 1 : 0,
+                                  seg_err_plane(e, seg_plane_of_channel(bpp, c)));
+        else dst[c] = seg_pix_make(0, 0, 0, 0, 0);
+    }
+}
+
 /* band geometry of one lookup (optimize_state.c:186-210): clamped candidate range [v0, v1] (single value when v0 == v1) */
 struct SegBand { int v0, v1, bandlo, neg; };
-PLS_HD SegBand seg_band(int filt, int lo, int s, int q)
+PLS_HD SegBand seg_band(int filt, int lo, const SegGeo &g)
 {
+    const int s = g.s, q = g.q;
     SegBand b;
     b.neg = filt < 0;
     const int af = b.neg ? -filt : filt;
-    const int t = af / q;
+    const int t = seg_div_q(af, g);
     b.bandlo = b.neg ? -(t * q) - s : t * q;
     const int bandhi = b.bandlo + s, hi = lo + 255;
     b.v0 = seg_max(b.bandlo, lo);
@@ -253,7 +323,7 @@ PLS_HD int seg_argmax_scan(const uint32_t *H, const uint32_t *extra, const uint3
 /* One step of one channel's chain against a frozen histogram, decision by scanning (replay, chain walk, exact pixel).
  * Returns the candidate word; st becomes the state in front of the next pixel. */
 PLS_HD uint32_t seg_step_scan(int f, const SegPix &p, SegState &st, const uint32_t *H, const uint32_t *extra, const uint32_t *rank,
-                              int s, int q, const uint32_t *lut_a, int bleed)
+                              const SegGeo &g, const uint32_t *lut_a, int bleed)
 {
     const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
     const int pred = seg_predict(f, above, diag, st.left);
@@ -262,7 +332,7 @@ PLS_HD uint32_t seg_step_scan(int f, const SegPix &p, SegState &st, const uint32
     else {
         const int osym = seg_sext8(orig - pred), lo = osym - orig;
         const int filt = osym + seg_sext16(p.e0 + st.cn);
-        const SegBand b = seg_band(filt, lo, s, q);
+        const SegBand b = seg_band(filt, lo, g);
         const int v = seg_argmax_scan(H, extra, rank, b.v0, b.v1, osym);
         back = v - lo; diff = seg_sext16(filt - v); bin = v & 255;
     }
@@ -276,49 +346,69 @@ PLS_HD uint32_t seg_step_scan(int f, const SegPix &p, SegState &st, const uint32
  * pre[sgn][v + SEG_TOFF] = leader of [bandlo(v), v], suf[sgn][v + SEG_TOFF] = leader of [v, bandhi(v)] in the band system of that
  * sign (sgn 0: filt >= 0, bands [tq, tq+s]; sgn 1: filt < 0, bands [-tq-s, -tq]); leader = arg-max of (H, rank, -v).
  * entry = (L + 512) | cls[L & 255] << 16, cls = dense class of (H, rank): equal class <=> equal (H, rank), which is what decides
- * whether the original symbol takes the place of the leader (optimize_state.c:236-243). */
-struct SegTabs { const uint32_t *pre[2], *suf[2]; const uint8_t *cls; };
-PLS_HD SegTabs seg_tabs_at(const uint32_t *words)
-{
-    SegTabs t;
-    t.pre[0] = words; t.pre[1] = words + SEG_TN; t.suf[0] = words + 2 * SEG_TN; t.suf[1] = words + 3 * SEG_TN;
-    t.cls = (const uint8_t *)(words + 4 * SEG_TN);
-    return t;
-}
-/* largest |filt| the tables serve */
-PLS_HD int seg_filt_max(int s, int q) { return ((SEG_TOFF - 1 - s) / q) * q + s < SEG_TOFF - 1 - s ? ((SEG_TOFF - 1 - s) / q) * q + s : SEG_TOFF - 1 - s; }
+ * whether the original symbol takes the place of the leader (optimize_state.c:236-243).  Layout: pre[0] pre[1] suf[0] suf[1] cls. */
+/* shared-memory pointers: naming the address space makes every access a ds_* instruction on the device (a generic pointer that
+ * the compiler cannot trace back to LDS becomes a FLAT access: slower, and it ties LDS waits to outstanding global stores) */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) const uint32_t *seg_lds_cu32;
+typedef __attribute__((address_space(3))) const uint8_t *seg_lds_cu8;
+#define SEG_LDS_CU32(p) ((seg_lds_cu32)(p))
+#define SEG_LDS_CU8(p) ((seg_lds_cu8)(p))
+#else
+typedef const uint32_t *seg_lds_cu32;
+typedef const uint8_t *seg_lds_cu8;
+#define SEG_LDS_CU32(p) ((seg_lds_cu32)(p))
+#define SEG_LDS_CU8(p) ((seg_lds_cu8)(p))
+#endif
 
-/* decision by table; ok = false when filt is outside the tables (the lane gives up: SEG_INVALID) */
-PLS_HD int seg_decide_tab(const SegTabs &T, int filt, int lo, int osym, int s, int q, bool &ok)
+template <int F> PLS_HD int seg_predict_t(int above, int diag, int left)
 {
-    const SegBand b = seg_band(filt, lo, s, q);
-    if (b.v0 == b.v1) { ok = true; return b.v0; }
-    if (b.v0 < -SEG_TOFF || b.v1 >= SEG_TOFF || b.bandlo < -SEG_TOFF || b.bandlo + s >= SEG_TOFF) { ok = false; return b.v0; }
-    ok = true;
-    const uint32_t e = b.v0 > b.bandlo ? T.suf[b.neg][b.v0 + SEG_TOFF] : T.pre[b.neg][b.v1 + SEG_TOFF];
-    const int L = (int)(e & 0xffffu) - 512;
-    const bool tie = osym >= b.v0 && osym <= b.v1 && (uint32_t)T.cls[osym & 255] == ((e >> 16) & 255u);
-    return tie ? osym : L;
+    if (F == 1) return left;
+    if (F == 2) return above;
+    if (F == 3) return (above + left) >> 1;
+    if (F == 4) {
+        const int p = above - diag, pd = left - diag;
+        const int pl = seg_abs(p), pa = seg_abs(pd), pg = seg_abs(p + pd);
+        return (pl <= pa && pl <= pg) ? left : (pa <= pg ? above : diag);
+    }
+    return 0;
 }
 
-PLS_HD bool seg_step_tab(int f, const SegPix &p, SegState &st, const SegTabs &T, int s, int q, const uint32_t *lut_a, int bleed)
+/* One step of one channel's chain against the frozen decision tables, without a branch: the hot loop of the enumeration, the replay
+ * and the chain walk.  tw = the candidate's tables (pre[2] | suf[2] | cls) in shared memory, lut = the split table.
+ * bad accumulates "this lane left what the tables cover" (band beyond +-SEG_TOFF, |diff| > 255): its results are void then and the
+ * caller falls back (enumeration: the map entry is SEG_INVALID; replay / walk: seg_step_scan).  Returns the candidate word. */
+template <int F>
+PLS_HD uint32_t seg_step_fast(const SegPix &p, SegState &st, int &bad, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
 {
     const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
-    const int pred = seg_predict(f, above, diag, st.left);
-    int back, diff;
-    if (p.w >> 24) { back = 0; diff = 0; }
-    else {
-        const int osym = seg_sext8(orig - pred), lo = osym - orig;
-        const int filt = osym + seg_sext16(p.e0 + st.cn);
-        bool ok;
-        const int v = seg_decide_tab(T, filt, lo, osym, s, q, ok);
-        if (!ok) return false;
-        back = v - lo; diff = seg_sext16(filt - v);
-    }
-    int rem, thr;
-    seg_rem_thr(lut_a, bleed, diff, rem, thr);
-    st.left = back; st.cn = rem + st.th; st.th = thr;
-    return true;
+    const bool tr = (p.w >> 24) != 0;
+    const int pred = seg_predict_t<F>(above, diag, st.left);
+    const int osym = seg_sext8(orig - pred), lo = osym - orig, hi = lo + 255;
+    const int filt = osym + seg_sext16(p.e0 + st.cn);
+    const int neg = filt < 0 ? 1 : 0;
+    const int af = neg ? -filt : filt;
+    const int t = seg_div_q(af, g);
+    const int bandlo = neg ? -(t * g.q) - g.s : t * g.q, bandhi = bandlo + g.s;
+    const int v0 = seg_max(bandlo, lo), v1 = seg_min(bandhi, hi);
+    const bool degen = v0 > v1;                                /* the whole band lies outside [lo, hi]: the clamp leaves lo or hi */
+    const int vd = bandhi < lo ? lo : hi;
+    const bool usesuf = v0 > bandlo;
+    int key = usesuf ? v0 : v1;
+    bad |= (bandlo < -SEG_TOFF || bandhi >= SEG_TOFF) ? 1 : 0;
+    key = seg_min(seg_max(key, -SEG_TOFF), SEG_TOFF - 1);
+    const uint32_t e = tw[(usesuf ? 2 * SEG_TN : 0) + neg * SEG_TN + key + SEG_TOFF];
+    const uint32_t c_os = (uint32_t)cls[osym & 255];
+    const int L = (int)(e & 0xffffu) - 512;
+    const bool tie = osym >= v0 && osym <= v1 && c_os == ((e >> 16) & 255u);
+    int v = tie ? osym : L;
+    v = degen ? vd : v;
+    int back = v - lo, diff = seg_sext16(filt - v), bin = v & 255;
+    back = tr ? 0 : back; diff = tr ? 0 : diff; bin = tr ? ((0 - pred) & 255) : bin;      /* optimize_state.c:158-164 */
+    bad |= (diff < -256 || diff > 255) ? 1 : 0;
+    const uint32_t le = lut[(diff + 256) & 511];
+    st.left = back; st.cn = seg_sext16((int)le) + st.th; st.th = (int)le >> 16;
+    return seg_cand_pack(back, diff, bin);
 }
 
 /* state <-> index, relative to the data of the boundary pixel b (the last pixel in front of the segment):
@@ -343,8 +433,25 @@ PLS_HD uint32_t seg_state_encode(const SegParams &P, const SegPix &b, const SegS
     return key < P.keyn ? (uint32_t)P.keylut[key] : SEG_INVALID;
 }
 
+/* none / up: the state is (cn, th) */
+PLS_HD bool seg_is_small(const SegParams &P, int f) { return P.small_ok && (f == 0 || f == 2); }
+PLS_HD bool seg_small_decode(const SegParams &P, int i, SegState &st)
+{
+    if (i >= P.ns_small) return false;
+    const uint32_t w = P.st_small[i];
+    st.left = 0; st.cn = (int)(w & 255u) - 128; st.th = (int)((w >> 8) & 255u) - 128;
+    return true;
+}
+PLS_HD uint32_t seg_small_encode(const SegParams &P, const SegState &st)
+{
+    if (st.cn < -P.cmax || st.cn > P.cmax || st.th < -P.tmax || st.th > P.tmax) return SEG_INVALID;
+    return (uint32_t)P.keylut_small[(st.cn + P.cmax) * (2 * P.tmax + 1) + st.th + P.tmax];
+}
+/* either kind, by filter */
+PLS_HD bool seg_any_decode(const SegParams &P, int f, int i, const SegPix &b, SegState &st) { return seg_is_small(P, f) ? seg_small_decode(P, i, st) : seg_state_decode(P, i, b, st); }
+PLS_HD uint32_t seg_any_encode(const SegParams &P, int f, const SegPix &b, const SegState &st) { return seg_is_small(P, f) ? seg_small_encode(P, st) : seg_state_encode(P, b, st); }
+
 /* ---- host: the constants of a (strength, bleed) pair.  false: more states than the enumeration has lanes ------------------ */
-#if !defined(__HIP_DEVICE_COMPILE__)
 inline bool seg_build_params(SegParams &P, int strength, int bleed)
 {
     memset(&P, 0, sizeof P);
@@ -379,9 +486,26 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
             }
     }
     P.ns = ns;
+    {
+        const int kn = (2 * P.cmax + 1) * (2 * P.tmax + 1);
+        int n2 = 0; bool ok = kn <= SEG_KEYS_MAX;
+        for (int k = 0; k < SEG_KEYS_MAX; k++) P.keylut_small[k] = (uint16_t)SEG_INVALID;
+        for (int diff = -strength; diff <= strength && ok; diff++) {
+            const SegSplit sp = seg_split_slow(diff, bleed);
+            for (int thp = -tmax; thp <= tmax; thp++) {
+                const int cn = sp.rem + thp, th = sp.h;
+                const int key = (cn + P.cmax) * (2 * P.tmax + 1) + th + P.tmax;
+                if (P.keylut_small[key] != (uint16_t)SEG_INVALID) continue;
+                if (n2 >= SEG_NSS) { ok = false; break; }
+                P.keylut_small[key] = (uint16_t)n2;
+                P.st_small[n2] = (uint32_t)(cn + 128) | ((uint32_t)(th + 128) << 8);
+                n2++;
+            }
+        }
+        P.ns_small = ok ? n2 : 0; P.small_ok = ok ? 1 : 0;
+    }
     return true;
 }
-#endif
 
 /* =========================================================================================================================
  * Kernel bodies.  smem: the workgroup's shared memory (device: dynamic LDS; host harness: a scratch buffer).
@@ -389,13 +513,32 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
  * ========================================================================================================================= */
 
 /* shared-memory budgets (bytes) */
-#define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 64)
-#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 2048 + SEG_L * 8 + (size_t)(nseg) * 16 + 64)
-#define SEG_SM_REPLAY (1024 + 1024 + SEG_GRP * (SEG_L + 1) * 4 * 8 + SEG_GRP * 256 * 4 + 64)
-#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4)
+#define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64)
+#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + SEG_TBL_WORDS * 4 + SEG_L * 8 + (size_t)(nseg) * 16 + 64)
+#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
+#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + 256 + 64 * 4 + 2 * SEG_TN * 4)
 
-/* ---- ENUMERATE: task (f, seg), SEG_THREADS lanes = 4 channels x SEG_NSP states ----------------------------------------- */
+/* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad */
+template <int F>
+PLS_HD int seg_run_fast(const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
+{
+    int bad = 0;
+    for (int k = 0; k < n; k++) (void)seg_step_fast<F>(px[k * pstride], st, bad, tw, cls, g, lut);
+    return bad;
+}
+PLS_HD int seg_run_fast_f(int f, const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
+{
+    switch (f) {
+    case 1: return seg_run_fast<1>(px, pstride, n, st, tw, cls, g, lut);
+    case 2: return seg_run_fast<2>(px, pstride, n, st, tw, cls, g, lut);
+    case 3: return seg_run_fast<3>(px, pstride, n, st, tw, cls, g, lut);
+    case 4: return seg_run_fast<4>(px, pstride, n, st, tw, cls, g, lut);
+    default: return seg_run_fast<0>(px, pstride, n, st, tw, cls, g, lut);
+    }
+}
+
+/* ---- ENUMERATE, filters that look at the left pixel: task (f, seg), SEG_THREADS lanes = 4 channels x SEG_NSP states -------- */
 PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -406,28 +549,58 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     if (x0 <= ctl.start_x[f]) return;                         /* the epoch's first (partial) segment is walked by the chain kernel */
     uint32_t *tw = (uint32_t *)smem;
     SegPix *px = (SegPix *)(smem + SEG_TBL_WORDS * 4);        /* [(SEG_L + 1)][4]: slot 0 = boundary pixel x0-1 */
+    uint32_t *lut = (uint32_t *)(px + (SEG_L + 1) * 4);       /* the split table */
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const int s = (int)ctl.s, q = s + 1;
+    const SegGeo G = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_THREADS) {
         for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
-        if (tid < (SEG_L + 1) * 4) {
-            const int k = tid >> 2, c = tid & 3;
-            const uint32_t x = x0 - 1 + (uint32_t)k;
-            px[tid] = ((uint32_t)c < bpp && x < W) ? seg_pix_load(row, nab, j.err0, bpp, x, c) : seg_pix_make(0, 0, 0, 0, 0);
-        }
+        if (tid < 512) lut[tid] = P.lut_a[tid];
+        if (tid >= 512 && tid < 512 + SEG_L + 1) seg_pix_load4(px + (tid - 512) * 4, row, nab, j.err0, bpp, x0 - 1 + (uint32_t)(tid - 512), W);
     }
     PLS_SYNC();
-    const SegTabs T = seg_tabs_at(tw);
     PLS_THREADS(tid, SEG_THREADS) {
         const int c = tid / SEG_NSP, i = tid % SEG_NSP;
         if ((uint32_t)c < bpp && i < P.ns) {
             SegState st;
             uint32_t out = SEG_INVALID;
             if (seg_state_decode(P, i, px[c], st)) {
-                bool ok = true;
-                for (int k = 1; k <= SEG_L && ok; k++) ok = seg_step_tab(f, px[k * 4 + c], st, T, s, q, P.lut_a, P.bleed);
-                if (ok) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
+                const int bad = seg_run_fast_f(f, px + 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                if (!bad) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
+            }
+            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
+        }
+    }
+}
+
+/* ---- ENUMERATE, none / up (state = (cn, th), SEG_NSS lanes per channel): task (f, SEG_SMALL_SEGS segments from seg0) -------- */
+PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    if (ctl.finished || !ctl.active[f]) return;
+    const uint32_t W = j.W, bpp = j.bpp;
+    if ((uint32_t)(seg0 + SEG_SMALL_SEGS) * SEG_L <= ctl.start_x[f]) return;
+    uint32_t *tw = (uint32_t *)smem;
+    uint32_t *lut = tw + SEG_TBL_WORDS;
+    SegPix *px = (SegPix *)(lut + 512);                        /* [SEG_SMALL_SEGS][SEG_L][4] */
+    const uint32_t y = ctl.y;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SegGeo G = seg_geo((int)ctl.s);
+    PLS_THREADS(tid, SEG_THREADS) {
+        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+        if (tid < 512) lut[tid] = P.lut_a[tid];
+        if (tid < SEG_SMALL_SEGS * SEG_L) seg_pix_load4(px + tid * 4, row, nab, j.err0, bpp, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        const int sl = tid / (4 * SEG_NSS), c = (tid / SEG_NSS) & 3, i = tid % SEG_NSS;
+        const uint32_t seg = (uint32_t)seg0 + (uint32_t)sl, x0 = seg * SEG_L;
+        if (seg < j.nseg && x0 + SEG_L < W && x0 > ctl.start_x[f] && (uint32_t)c < bpp && i < P.ns_small) {
+            SegState st;
+            uint32_t out = SEG_INVALID;
+            if (seg_small_decode(P, i, st)) {
+                const int bad = seg_run_fast_f(f, px + (sl * SEG_L) * 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                if (!bad) out = seg_small_encode(P, st);
             }
             j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
         }
@@ -443,6 +616,77 @@ PLS_HD void seg_load_frozen(const SegJob &j, int par, int f, uint32_t *Hf, uint3
     }
 }
 
+/* pixels [xa, xe) of one channel from state st: the table steps, and if a lane leaves what the tables cover, once more by scanning.
+ * out: candidate words (stride 4 words per pixel) or null; cnt: bump counters (256) or null. */
+PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t xe, SegState &st, seg_lds_cu32 tw, seg_lds_cu32 lut, const uint32_t *Hf,
+                     const uint32_t *rank, const SegGeo &G, const uint32_t *lut_g, int bleed, uint32_t *out, uint32_t *cnt)
+{
+    const SegState st0 = st;
+    int bad = 0;
+    const seg_lds_cu8 cls = SEG_LDS_CU8(tw + 4 * SEG_TN);
+    for (uint32_t x = xa; x < xe; x++) {
+        uint32_t w;
+        const SegPix &p = px[(size_t)(x - xa) * pstride];
+        switch (f) {
+        case 1: w = seg_step_fast<1>(p, st, bad, tw, cls, G, lut); break;
+        case 2: w = seg_step_fast<2>(p, st, bad, tw, cls, G, lut); break;
+        case 3: w = seg_step_fast<3>(p, st, bad, tw, cls, G, lut); break;
+        case 4: w = seg_step_fast<4>(p, st, bad, tw, cls, G, lut); break;
+        default: w = seg_step_fast<0>(p, st, bad, tw, cls, G, lut); break;
+        }
+        if (out) out[(size_t)(x - xa) * 4] = w;
+        if (cnt) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(w)], 1u);
+    }
+    if (bad) {
+        /* (rare) take the bumps back and do the range again by scanning */
+        if (cnt && out) for (uint32_t x = xa; x < xe; x++) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(out[(size_t)(x - xa) * 4])], 0u - 1u);
+        st = st0;
+        for (uint32_t x = xa; x < xe; x++) {
+            const uint32_t w = seg_step_scan(f, px[(size_t)(x - xa) * pstride], st, Hf, nullptr, rank, G, lut_g, bleed);
+            if (out) out[(size_t)(x - xa) * 4] = w;
+            if (cnt) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(w)], 1u);
+        }
+    }
+}
+
+/* ---- FIRST SEGMENT: task (f): the epoch's first (partial) segment has a known entry state, so it is not enumerated but walked,
+ * lane = channel, next to the enumeration workgroups (same kernel); out: the index the chain starts from ------------------------ */
+PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    if (ctl.finished || !ctl.active[f]) return;
+    const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
+    const uint32_t sx = ctl.start_x[f];
+    if (sx >= W) return;
+    const uint32_t first = sx / SEG_L;
+    if (first + 1 >= nseg) return;                            /* no segment behind it */
+    uint32_t *tw = (uint32_t *)smem;
+    uint32_t *lut = tw + SEG_TBL_WORDS;
+    uint32_t *Hf = lut + 512, *rank = Hf + 256;
+    SegPix *px = (SegPix *)(rank + 256);                      /* [SEG_L][4] */
+    const uint32_t y = ctl.y;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SegGeo G = seg_geo((int)ctl.s);
+    PLS_THREADS(tid, SEG_THREADS) {
+        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+        if (tid < 512) lut[tid] = P.lut_a[tid];
+        if (tid >= 512 && tid < 768) seg_load_frozen(j, par, f, Hf, rank, tid - 512, 256);
+        if (tid >= 768 && tid < 768 + SEG_L) seg_pix_load4(px + (tid - 768) * 4, row, nab, j.err0, bpp, first * SEG_L + (uint32_t)(tid - 768), W);
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid < 4 && (uint32_t)tid < bpp) {
+            const int c = tid;
+            SegState st = seg_state_unpack(ctl.state[f][c]);
+            const uint32_t fend = (first + 1) * SEG_L;         /* < W: there is a segment behind */
+            seg_walk(f, px + (sx - first * SEG_L) * 4 + c, 4, sx, fend, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed, nullptr, nullptr);
+            const uint32_t idx = seg_any_encode(P, f, px[(SEG_L - 1) * 4 + c], st);
+            j.firstidx[(f * 4 + c) * 2] = idx;
+            j.firstidx[(f * 4 + c) * 2 + 1] = seg_state_pack(st);
+        }
+    }
+}
+
 /* ---- CHAIN: task (f, c): compose the segment maps from the epoch's start state -----------------------------------------
  * The exit index of segment sg (relative to its last pixel) IS the entry index of segment sg+1 (relative to the same pixel, its
  * boundary pixel), so the chain is one shared-memory lookup per segment; entry states are decoded afterwards, in parallel. */
@@ -454,45 +698,51 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     const uint32_t sx = ctl.start_x[f];
     if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
-    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256;
-    SegPix *px = (SegPix *)(smem + 2048);                     /* [SEG_L] pixels of the first segment, this channel */
+    if (first + 1 >= nseg) return;
+    const bool small = seg_is_small(P, f);
+    const int nmap = small ? SEG_NSS : SEG_NSP;               /* entries per map */
+    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
+    SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_L] pixels of the first segment, this channel */
     SegPix *bpx = px + SEG_L;                                 /* [nseg] boundary pixel sg*SEG_L - 1 of every segment */
-    uint32_t *idxs = (uint32_t *)(bpx + nseg);                /* [nseg] entry index of every segment, or a packed state | 1 << 31... see below */
-    uint16_t *maps = (uint16_t *)(idxs + 2 * nseg);
+    uint32_t *idxs = (uint32_t *)(bpx + ((nseg + 1) & ~1u));  /* [nseg][2]: entry index of every segment | packed state when it has none */
+    uint16_t *maps = (uint16_t *)(idxs + 2 * ((nseg + 1) & ~1u));
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const int s = (int)ctl.s, q = s + 1;
+    const SegGeo G = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         seg_load_frozen(j, par, f, Hf, rank, tid, SEG_CHAIN_THREADS);
-        if (tid < SEG_L) { const uint32_t x = first * SEG_L + (uint32_t)tid; px[tid] = x < W ? seg_pix_load(row, nab, j.err0, bpp, x, c) : seg_pix_make(0, 0, 0, 0, 0); }
+        for (int i = tid; i < 512; i += SEG_CHAIN_THREADS) lut[i] = P.lut_a[i];
         for (uint32_t sg = first + 1 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c);
-        for (uint32_t sg = first + 1; sg + 1 < nseg; sg++) {
-            const uint16_t *src = j.maps + (((size_t)f * nseg + sg) * 4 + c) * SEG_NSP;
-            for (int i = tid; i < SEG_NSP; i += SEG_CHAIN_THREADS) maps[(size_t)sg * SEG_NSP + i] = src[i];
+        {
+            /* the maps of segments first+1 .. nseg-2, 16 bytes per load (a map is nmap * 2 bytes, contiguous) */
+            const int per = nmap / 8;                                   /* 16-byte pieces per map */
+            const uint32_t nm = nseg > first + 2 ? nseg - first - 2 : 0u;
+            for (uint32_t i = (uint32_t)tid; i < nm * (uint32_t)per; i += SEG_CHAIN_THREADS) {
+                const uint32_t sg = first + 1 + i / (uint32_t)per, piece = i % (uint32_t)per;
+                const SegVec16 *src = (const SegVec16 *)(j.maps + (((size_t)f * nseg + sg) * 4 + c) * SEG_NSP) + piece;
+                ((SegVec16 *)(maps + (size_t)sg * nmap))[piece] = *src;
+            }
         }
     }
     PLS_SYNC();
-    /* idxs[2*sg] = entry index of segment sg or SEG_INVALID; idxs[2*sg+1] = packed entry state when the index is invalid */
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         if (tid == 0) {
-            SegState st = seg_state_unpack(ctl.state[f][c]);
-            /* the epoch's first segment, from its start pixel, step by step */
-            const uint32_t fend = (uint32_t)seg_min((int)((first + 1) * SEG_L), (int)W);
-            for (uint32_t x = sx; x < fend; x++) (void)seg_step_scan(f, px[x - first * SEG_L], st, Hf, nullptr, rank, s, q, P.lut_a, P.bleed);
-            uint32_t idx = first + 1 < nseg ? seg_state_encode(P, bpx[first + 1], st) : SEG_INVALID;
+            /* the epoch's first segment was walked by seg_first_body */
+            uint32_t idx = j.firstidx[(f * 4 + c) * 2];
+            SegState st = seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]);
             for (uint32_t sg = first + 1; sg < nseg; sg++) {
                 idxs[2 * sg] = idx;
                 if (idx == SEG_INVALID) idxs[2 * sg + 1] = seg_state_pack(st);
                 if (sg + 1 == nseg) break;
-                uint32_t nidx = idx == SEG_INVALID ? SEG_INVALID : (uint32_t)maps[(size_t)sg * SEG_NSP + idx];
+                uint32_t nidx = idx == SEG_INVALID ? SEG_INVALID : (uint32_t)maps[(size_t)sg * nmap + idx];
                 if (nidx == SEG_INVALID) {
                     /* a state or a lookup outside what the enumeration covers: this segment step by step (rare, slow, exact) */
-                    if (idx != SEG_INVALID) (void)seg_state_decode(P, (int)idx, bpx[sg], st);
+                    if (idx != SEG_INVALID) (void)seg_any_decode(P, f, (int)idx, bpx[sg], st);
                     for (uint32_t x = sg * SEG_L; x < (sg + 1) * SEG_L && x < W; x++) {
                         const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
-                        (void)seg_step_scan(f, p, st, Hf, nullptr, rank, s, q, P.lut_a, P.bleed);
+                        (void)seg_step_scan(f, p, st, Hf, nullptr, rank, G, lut, P.bleed);
                     }
-                    nidx = seg_state_encode(P, bpx[sg + 1], st);
+                    nidx = seg_any_encode(P, f, bpx[sg + 1], st);
                 }
                 idx = nidx;
             }
@@ -503,7 +753,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
         for (uint32_t sg = first + 1 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) {
             uint32_t packed;
             if (idxs[2 * sg] == SEG_INVALID) packed = idxs[2 * sg + 1];
-            else { SegState st; (void)seg_state_decode(P, (int)idxs[2 * sg], bpx[sg], st); packed = seg_state_pack(st); }
+            else { SegState st{ 0, 0, 0 }; (void)seg_any_decode(P, f, (int)idxs[2 * sg], bpx[sg], st); packed = seg_state_pack(st); }
             j.entry[((size_t)f * nseg + sg) * 4 + c] = packed;
         }
     }
@@ -520,33 +770,28 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     const uint32_t first = sx / SEG_L;
     const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
     if (seg0 + SEG_GRP <= first) return;                      /* the whole group is validated already */
-    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256;
-    SegPix *px = (SegPix *)(smem + 2048);                     /* [SEG_GRP][SEG_L][4] */
-    uint32_t *cnt = (uint32_t *)(smem + 2048 + SEG_GRP * (SEG_L + 1) * 4 * 8);   /* [SEG_GRP][256] */
+    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
+    SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_GRP][SEG_L][4] */
+    uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const int s = (int)ctl.s, q = s + 1;
+    const SegGeo G = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
         seg_load_frozen(j, par, f, Hf, rank, tid, SEG_REPLAY_THREADS);
+        for (int i = tid; i < 512; i += SEG_REPLAY_THREADS) lut[i] = P.lut_a[i];
+        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_REPLAY_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
         for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_THREADS) cnt[i] = 0u;
-        for (int i = tid; i < SEG_GRP * SEG_L * 4; i += SEG_REPLAY_THREADS) {
-            const int c = i & 3;
-            const uint32_t x = seg0 * SEG_L + (uint32_t)(i >> 2);
-            px[i] = ((uint32_t)c < bpp && x < W) ? seg_pix_load(row, nab, j.err0, bpp, x, c) : seg_pix_make(0, 0, 0, 0, 0);
-        }
+        seg_pix_load4(px + tid * 4, row, nab, j.err0, bpp, seg0 * SEG_L + (uint32_t)tid, W);
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
         const int sl = tid >> 2, c = tid & 3;
         const uint32_t sg = seg0 + (uint32_t)sl;
-        if (sg < nseg && sg >= first && (uint32_t)c < bpp) {
+        if (tid < SEG_GRP * 4 && sg < nseg && sg >= first && (uint32_t)c < bpp) {
             SegState st = sg == first ? seg_state_unpack(ctl.state[f][c]) : seg_state_unpack(j.entry[((size_t)f * nseg + sg) * 4 + c]);
-            const uint32_t xa = sg == first ? sx : sg * SEG_L, xe = seg_min((int)((sg + 1) * SEG_L), (int)W);
-            for (uint32_t x = xa; x < xe; x++) {
-                const uint32_t w = seg_step_scan(f, px[(x - seg0 * SEG_L) * 4 + c], st, Hf, nullptr, rank, s, q, P.lut_a, P.bleed);
-                j.cand[((size_t)f * W + x) * 4 + c] = w;
-                PLS_ATOMIC_ADD(&cnt[sl * 256 + seg_cand_bin(w)], 1u);
-            }
+            const uint32_t xa = sg == first ? sx : sg * SEG_L, xe = (uint32_t)seg_min((int)((sg + 1) * SEG_L), (int)W);
+            seg_walk(f, px + (xa - seg0 * SEG_L) * 4 + c, 4, xa, xe, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed,
+                     j.cand + ((size_t)f * W + xa) * 4 + c, cnt + sl * 256);
         }
     }
     PLS_SYNC();
@@ -560,6 +805,31 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
             j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
         }
     }
+}
+
+/* Candidate none (prediction 0): how far from  orig + incoming error  its reconstructed byte can lie.  With C a bound of the carried
+ * terms |cn| and D of the quantisation differences |diff|:  |byte - (orig + e0)| <= s + C  (the chosen v lies in the band of filt, or the
+ * clamp moved it towards 0..255);  D <= s + overshoot(C), overshoot = how far orig + e0 +- C can leave 0..255 (rowmm holds the row's
+ * extremes of orig + e0);  C <= max |rem| + max |thr| over |d| <= D.  Iterated from C = the table bound to a fixed point; -1 = none found
+ * (then no bound is claimed). */
+PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, const uint32_t *lut_a, int s)
+{
+    if (!j.rowmm) return -1;
+    int M = -(1 << 30), m = 1 << 30;
+    const int nc = (int)((j.W + SEG_THREADS - 1) / SEG_THREADS);
+    for (int i = 0; i < nc; i++) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
+    int C = P.cmax;
+    for (int it = 0; it < 4; it++) {
+        const int ov = seg_max(0, seg_max(M + C - 255, C - m));
+        const int D = s + ov;
+        if (D > 255) return -1;
+        int rmax = 0, tmax = 0;
+        for (int d = -D; d <= D; d++) { int rem, thr; seg_rem_thr(lut_a, P.bleed, d, rem, thr); rmax = seg_max(rmax, seg_abs(rem)); tmax = seg_max(tmax, seg_abs(thr)); }
+        const int C2 = seg_max(C, rmax + tmax);
+        if (C2 == C) return s + C;
+        C = C2;
+    }
+    return -1;
 }
 
 /* ---- VALIDATE + POST: task (f, grp) ----------------------------------------------------------------------------------------
@@ -577,20 +847,62 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     const uint32_t sx = ctl.start_x[f];
     const uint32_t first = sx / SEG_L, fgrp = first / SEG_GRP;
     const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
+    constexpr int NPX = SEG_GRP * SEG_L;                       /* pixels of a group */
     uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256, *Hpost = H0 + 512;
     uint32_t *cum = H0 + 768;                                  /* [(SEG_GRP + 1)][256]: bumps in front of each segment of the group */
-    uint32_t *cw = cum + (SEG_GRP + 1) * 256;                  /* [(SEG_GRP * SEG_L + 2)][4] candidate words, from pixel seg0*SEG_L - 2 */
-    uint32_t *red = cw + (SEG_GRP * SEG_L + 2) * 4;            /* reductions: derr lo/hi, cost, hs[5], fail */
+    uint32_t *cw = cum + (SEG_GRP + 1) * 256;                  /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
+    uint32_t *red = cw + (NPX + 2) * 4;                        /* reductions: derr lo/hi, cost, hs[5], fail, lb lo/hi */
+    uint32_t *lut = red + 64;                                  /* [512] split table */
+    uint32_t *ro = lut + 512;                                  /* [NPX + 1] original row, from pixel xg0 - 1 */
+    uint32_t *na = ro + NPX + 2;                               /* [NPX + 1] optimised row above */
+    uint32_t *oa = na + NPX + 2;                               /* [NPX + 1] original row above */
+    uint32_t *e0 = oa + NPX + 2;                               /* [NPX][2] incoming error */
+    uint32_t *rm = e0 + 2 * NPX;                               /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const int s = (int)ctl.s, q = s + 1;
+    const SegGeo G = seg_geo((int)ctl.s);
     const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
     const uint32_t xg0 = seg0 * SEG_L;
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < 256) {
+            H0[tid] = j.H0[par * 256 + tid];
+            rank[tid] = j.orig_rank[f * 256 + tid];
+        }
+        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : 0u;
+        if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
+        for (int i = tid; i < (NPX + 2) * 4; i += SEG_THREADS) {
+            const long x = (long)xg0 - 2 + (i >> 2);
+            cw[i] = (x >= 0 && x < (long)W) ? j.cand[((size_t)f * W + (size_t)x) * 4 + (i & 3)] : 0u;
+        }
+        if (tid <= NPX) {
+            const long x = (long)xg0 - 1 + tid;
+            const bool in = x >= 0 && x < (long)W;
+            ro[tid] = in ? row[x] : 0u;
+            na[tid] = (in && nab) ? nab[x] : 0u;
+            oa[tid] = (in && y) ? j.old_above[x] : 0u;
+        }
+        if (tid >= 512) {
+            const uint32_t x = xg0 + (uint32_t)(tid - 512);
+            e0[2 * (tid - 512)] = x < W ? j.err0[2 * (size_t)x] : 0u;
+            e0[2 * (tid - 512) + 1] = x < W ? j.err0[2 * (size_t)x + 1] : 0u;
+        }
+        /* bump counts per segment of the group, staged (one 8-byte load per thread), prefix below */
+        {
+            const int sl = tid >> 6, q4 = tid & 63;
+            const uint32_t sg = seg0 + (uint32_t)sl;
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (sg < nseg && sg >= first && sx < W) {
+                const uint16_t *sc = j.segcnt + ((size_t)f * nseg + sg) * 256 + 4 * q4;
+                c0 = sc[0]; c1 = sc[1]; c2 = sc[2]; c3 = sc[3];
+            }
+            uint32_t *dst = cum + (sl + 1) * 256 + 4 * q4;
+            dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid < 256) {
             const int b = tid;
-            H0[b] = j.H0[par * 256 + b];
-            rank[b] = j.orig_rank[f * 256 + b];
             uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b], total = before;
             if (sx < W)
                 for (uint32_t g = fgrp; g < ngrp; g++) {
@@ -601,41 +913,39 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             Hpost[b] = H0[b] + total;
             uint32_t run = before;
             for (int sl = 0; sl <= SEG_GRP; sl++) {
+                const uint32_t add = sl < SEG_GRP ? cum[(sl + 1) * 256 + b] : 0u;
                 cum[sl * 256 + b] = run;
-                const uint32_t sg = seg0 + (uint32_t)sl;
-                if (sl < SEG_GRP && sg < nseg && sg >= first && sx < W) run += j.segcnt[((size_t)f * nseg + sg) * 256 + b];
+                run += add;
             }
         }
-        for (int i = tid; i < (SEG_GRP * SEG_L + 2) * 4; i += SEG_THREADS) {
-            const long x = (long)xg0 - 2 + (i >> 2);
-            cw[i] = (x >= 0 && x < (long)W) ? j.cand[((size_t)f * W + (size_t)x) * 4 + (i & 3)] : 0u;
-        }
-        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : 0u;
     }
     PLS_SYNC();
     /* -- validation: lane = decision -- */
     PLS_THREADS(tid, SEG_THREADS) {
-        for (int d = tid; d < SEG_GRP * SEG_L * 4; d += SEG_THREADS) {
+        for (int d = tid; d < NPX * 4; d += SEG_THREADS) {
             const int c = d & 3, k = d >> 2;                       /* pixel k of the group */
             const uint32_t x = xg0 + (uint32_t)k;
             if (x >= W || x < sx || (uint32_t)c >= bpp) continue;
             const int sl = k / SEG_L;
             const uint32_t w0 = cw[(k + 2) * 4 + c], w1 = cw[(k + 1) * 4 + c], w2 = cw[k * 4 + c];
-            const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
+            const uint32_t o = ro[k + 1];
+            const int pl = seg_plane_of_channel(bpp, c);
+            const int pe0 = seg_err_plane(e0 + 2 * k, pl);
+            const bool trp = (bpp & 1u) == 0u && (uint32_t)c == bpp - 1u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
             /* state in front of x from the outputs of x-1, x-2 */
             int rem1, thr1, rem2, thr2;
-            seg_rem_thr(P.lut_a, P.bleed, x >= 1 ? seg_cand_diff(w1) : 0, rem1, thr1);
-            seg_rem_thr(P.lut_a, P.bleed, x >= 2 ? seg_cand_diff(w2) : 0, rem2, thr2);
+            seg_rem_thr(lut, P.bleed, x >= 1 ? seg_cand_diff(w1) : 0, rem1, thr1);
+            seg_rem_thr(lut, P.bleed, x >= 2 ? seg_cand_diff(w2) : 0, rem2, thr2);
             const int left = x >= 1 ? seg_cand_byte(w1) : 0, cn = rem1 + thr2;
-            const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
+            const int orig = (int)((o >> (8 * c)) & 255u), above = (int)((na[k + 1] >> (8 * c)) & 255u), diag = x ? (int)((na[k] >> (8 * c)) & 255u) : 0;
             const int pred = seg_predict(f, above, diag, left);
             const int back = seg_cand_byte(w0), diff = seg_cand_diff(w0), bin = seg_cand_bin(w0);
             bool good;
-            if (p.w >> 24) good = back == 0 && diff == 0 && bin == ((0 - pred) & 255);
+            if (trp) good = back == 0 && diff == 0 && bin == ((0 - pred) & 255);
             else {
                 const int osym = seg_sext8(orig - pred), lo = osym - orig;
-                const int filt = osym + seg_sext16(p.e0 + cn);
-                const SegBand bd = seg_band(filt, lo, s, q);
+                const int filt = osym + seg_sext16(pe0 + cn);
+                const SegBand bd = seg_band(filt, lo, G);
                 const int v = back + lo;
                 good = v >= bd.v0 && v <= bd.v1 && diff == seg_sext16(filt - v) && bin == (v & 255);
                 if (good && bd.v0 < bd.v1) {
@@ -670,21 +980,61 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             if (!good) PLS_ATOMIC_MIN(&red[8], x * 4u + (uint32_t)c);
         }
     }
+    /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
+     *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
+     *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) red[12] = (uint32_t)(f == 0 ? seg_none_reach(j, P, lut, (int)ctl.s) : -1); }
+    PLS_SYNC();
+    const int R = (int)red[12];
+    if (f == 0 && R >= 0) {
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid < 768) {
+                const int centre = tid - 256;
+                const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
+                uint32_t m = 0;
+                for (int b = lo; b <= hi; b++) m = H0[b] > m ? H0[b] : m;
+                rm[tid] = m;
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            uint64_t lb = 0;
+            const uint32_t rowbumps = W * bpp;
+            for (int k = tid; k < NPX; k += SEG_THREADS) {
+                const uint32_t x = xg0 + (uint32_t)k;
+                if (x >= W) continue;
+                const uint32_t o = ro[k + 1];
+                const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                for (uint32_t c = 0; c < bpp; c++) {
+                    uint32_t hmax;
+                    if (alpha0 && c == bpp - 1u) hmax = H0[0];                         /* forced symbol 0 */
+                    else {
+                        const int centre = (int)((o >> (8 * c)) & 255u) + seg_err_plane(e0 + 2 * k, seg_plane_of_channel(bpp, (int)c));
+                        hmax = rm[seg_min(seg_max(centre, -256), 511) + 256];
+                    }
+                    const uint32_t fr = hmax + rowbumps;
+                    lb += 33u + (uint32_t)__builtin_clz(fr ? fr : 1u);
+                }
+            }
+            lb = pls_wave_sum_u64(lb);
+            if (PLS_WAVE_LEADER(tid) && lb) PLS_ATOMIC_ADD64((uint64_t *)&red[10], lb);
+        }
+    }
     PLS_SYNC();
     /* -- post pass of this candidate over the group's pixels (optimize_state.c:265-287, 326-342, 492-562): lane = pixel -- */
     PLS_THREADS(tid, SEG_THREADS) {
-        for (int k = tid; k < SEG_GRP * SEG_L; k += SEG_THREADS) {
+        uint64_t derr = 0; uint32_t cost = 0, hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
+        for (int k = tid; k < NPX; k += SEG_THREADS) {
             const uint32_t x = xg0 + (uint32_t)k;
             if (x >= W) continue;
-            const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
-            const uint32_t na = nab ? nab[x] : 0u, nd = (nab && x) ? nab[x - 1] : 0u;
-            const uint32_t oa = y ? j.old_above[x] : 0u, od = (y && x) ? j.old_above[x - 1] : 0u;
-            uint64_t derr = 0; uint32_t cost = 0, hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
+            const uint32_t o = ro[k + 1], ol = ro[k];
+            const uint32_t nav4 = na[k + 1], ndv4 = x ? na[k] : 0u;
+            const uint32_t oav4 = oa[k + 1], odv4 = x ? oa[k] : 0u;
             for (uint32_t c = 0; c < bpp; c++) {
                 const int sh = 8 * (int)c;
                 const int back = seg_cand_byte(cw[(k + 2) * 4 + c]), nl = x ? seg_cand_byte(cw[(k + 1) * 4 + c]) : 0;
                 const int ov = (int)((o >> sh) & 255u), olv = (int)((ol >> sh) & 255u);
-                const int nav = (int)((na >> sh) & 255u), ndv = (int)((nd >> sh) & 255u), oav = (int)((oa >> sh) & 255u), odv = (int)((od >> sh) & 255u);
+                const int nav = (int)((nav4 >> sh) & 255u), ndv = (int)((ndv4 >> sh) & 255u), oav = (int)((oav4 >> sh) & 255u), odv = (int)((odv4 >> sh) & 255u);
                 const int da = (oav - ov) - (nav - back), dd = (odv - ov) - (ndv - back), dl = (olv - ov) - (nl - back);
                 const uint32_t wgt = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
                 derr += (uint64_t)(wgt * (uint32_t)(da * da + dd * dd + dl * dl));
@@ -694,6 +1044,10 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
                 if (adaptive)
                     for (int g = 0; g < SEG_NFILT; g++) { const int bb = (back - preds[g]) & 255; hs[g] += (uint32_t)(bb < 128 ? bb : 256 - bb); }
             }
+        }
+        derr = pls_wave_sum_u64(derr); cost = pls_wave_sum_u32(cost);
+        if (adaptive) for (int g = 0; g < SEG_NFILT; g++) hs[g] = pls_wave_sum_u32(hs[g]);
+        if (PLS_WAVE_LEADER(tid)) {
             PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
             PLS_ATOMIC_ADD(&red[2], cost);
             if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&red[3 + g], hs[g]);
@@ -707,13 +1061,14 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             PLS_ATOMIC_ADD(&A.cost[f], red[2]);
             for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[3 + g]);
             if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
+            if (f == 0 && R >= 0) { PLS_ATOMIC_ADD64(&A.none_lb, *(uint64_t *)&red[10]); PLS_ATOMIC_ADD(&A.lb_valid, 1u); }
         }
     }
 }
 
 /* ---- CONTROL -------------------------------------------------------------------------------------------------------------- */
 struct SegDecision {
-    int kind, winner;
+    int kind, winner, dropped_none;
     uint32_t failed;                /* bit f: candidate f failed validation in the attempt just finished */
     uint64_t cost[SEG_NFILT];
 };
@@ -722,7 +1077,7 @@ struct SegDecision {
 PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, const SegCtl &cur, const SegAcc &A)
 {
     SegDecision D;
-    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0;
+    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0; D.dropped_none = 0;
     for (int f = 0; f < SEG_NFILT; f++) D.cost[f] = ~0ull;
     if (attempt == 0) return D;
     if (cur.finished) { D.kind = SEG_K_FINISHED; return D; }
@@ -739,6 +1094,18 @@ PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, 
         }
         if (P.engine_flags >> 8) cst = f == (P.engine_flags >> 8) - 1 ? 0ull : ~0ull;
         D.cost[f] = cst;
+    }
+    D.dropped_none = 0;
+    if ((D.failed & 1u) && !(P.engine_flags >> 8) && A.lb_valid == j.ngrp) {
+        /* Candidate none failed validation.  Its row cost is at least none_lb (seg_post_body); it has the lowest index, so it wins ties
+         * (pngloss_image.c:257) and loses only to a strictly cheaper row: if one exists already, none cannot be the winner whatever its
+         * exact row would be -- its epoch is not worth running.  (The winner's row, histogram and errors are all that is committed.) */
+        uint64_t best_other = ~0ull;
+        for (int f = 1; f < SEG_NFILT; f++) if (!((D.failed >> f) & 1u) && D.cost[f] < best_other) best_other = D.cost[f];
+        if (best_other < A.none_lb) {
+            D.failed &= ~1u; D.cost[0] = ~0ull; D.dropped_none = 1;
+            any_failed = D.failed != 0;
+        }
     }
     if (any_failed) { D.kind = SEG_K_RESTART; return D; }
     uint64_t best = ~0ull;
@@ -834,7 +1201,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     if (bx == SEG_NFILT) {
         /* ---- the image-wide fields ---- */
         if (D.kind == SEG_K_FINISHED) {
-            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; } }
+            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; } }
             return;
         }
         if (D.kind != SEG_K_RESTART) seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
@@ -848,7 +1215,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             if (tid < SEG_NFILT) j.acc[par].fail[tid] = SEG_NOFAIL;
             if (tid == 0) {
                 uint32_t ny = y, fin = 0, st = attempt ? cur.status : 0u, retried = attempt ? cur.retried : 0u, rt = attempt ? cur.restarts_total : 0u;
-                uint32_t ser = attempt ? cur.serial_rows : 0u;
+                uint32_t ser = attempt ? cur.serial_rows : 0u, dropped = (attempt ? cur.dropped_none : 0u) + (uint32_t)D.dropped_none;
                 if (D.kind == SEG_K_COMMIT) { ny = y + 1; if (ny >= H) fin = 1; }
                 if (D.kind == SEG_K_RETRY) retried += cur.s == (uint32_t)P.strength ? 1u : 0u;
                 if (D.kind == SEG_K_ABORT) { st = 65u; fin = 1; }                         /* pngloss_image.c:268-271 aborts here */
@@ -856,15 +1223,17 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     for (int g = 0; g < SEG_NFILT; g++) if ((D.failed >> g) & 1u) { rt++; if (cur.restarts[g] + 1 > SEG_MAX_RESTARTS) ser++; }
                 if (W == 0 || H == 0) fin = 1;
                 nxt.y = ny; nxt.s = (uint32_t)(s_next < 0 ? 0 : s_next); nxt.status = st; nxt.finished = fin; nxt.retried = retried; nxt.restarts_total = rt;
-                nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt;
-                if (j.progress && D.kind == SEG_K_COMMIT) *(volatile uint32_t *)j.progress = ny;
+                nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt; nxt.dropped_none = dropped;
+                if (j.progress && D.kind == SEG_K_COMMIT) PLS_HOST_VISIBLE_STORE(j.progress, ny);
+                if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt);
                 if (fin) {
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
                     for (int i = 0; i < 64; i++) j.result[i] = 0;
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
-                    j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[20] = 3;   /* engine id: segment-parallel */
+                    j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
+                    if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
                 }
             }
         }
@@ -874,12 +1243,37 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
 
     if (bx > SEG_NFILT) {
         /* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x ---- */
-        if (D.kind != SEG_K_COMMIT) return;
+        if (D.kind != SEG_K_COMMIT && D.kind != SEG_K_INIT) return;
+        int *mm = (int *)smem;                                            /* max, min of orig + incoming error over this workgroup's pixels of the COMING row */
+        const uint32_t ynext = D.kind == SEG_K_COMMIT ? y + 1 : 0u;
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
+        PLS_SYNC();
+        if (D.kind == SEG_K_INIT) {
+            PLS_THREADS(tid, SEG_THREADS) {
+                const uint32_t x = (uint32_t)(bx - SEG_NFILT - 1) * SEG_THREADS + (uint32_t)tid;
+                int vmax = -(1 << 30), vmin = 1 << 30;
+                if (x < W && H) {
+                    const uint32_t o = j.img[x];
+                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        if (alpha0 && c == bpp - 1u) continue;
+                        const int v = (int)((o >> (8 * c)) & 255u);
+                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                    }
+                }
+                vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+                if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * (bx - SEG_NFILT - 1)] = mm[0]; j.rowmm[2 * (bx - SEG_NFILT - 1) + 1] = mm[1]; } }
+            return;
+        }
         const uint32_t *cd = j.cand + (size_t)D.winner * W * 4;
         uint32_t *rowp = j.img + (size_t)y * W;
         const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
         PLS_THREADS(tid, SEG_THREADS) {
             const uint32_t x = (uint32_t)(bx - SEG_NFILT - 1) * SEG_THREADS + (uint32_t)tid;
+            int vmax = -(1 << 30), vmin = 1 << 30;
             if (x < W) {
                 const uint32_t *cwp = cd + (size_t)x * 4;
                 const uint32_t np = ((cwp[0] & 255u) | ((cwp[1] & 255u) << 8) | ((cwp[2] & 255u) << 16) | ((cwp[3] & 255u) << 24)) & keep;
@@ -905,12 +1299,25 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 }
                 j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
                 j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
+                if (ynext < H) {
+                    const uint32_t o = j.img[(size_t)ynext * W + x];
+                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        if (alpha0 && c == bpp - 1u) continue;
+                        const int v = (int)((o >> (8 * c)) & 255u) + seg_sext16((int)n0[seg_plane_of_channel(bpp, (int)c)]);
+                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                    }
+                }
             }
+            vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+            if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
             if (bx == SEG_NFILT + 1 && tid == 0) {
                 if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << D.winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
                 j.row_ids[y] = (uint8_t)D.winner;
             }
         }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * (bx - SEG_NFILT - 1)] = mm[0]; j.rowmm[2 * (bx - SEG_NFILT - 1) + 1] = mm[1]; } }
         return;
     }
 
@@ -950,7 +1357,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         const uint32_t xp = A.fail[f] >> 2, sx = cur.start_x[f], first = sx / SEG_L, fgrp = first / SEG_GRP;
         const uint32_t sgp = xp / SEG_L, gp = sgp / SEG_GRP;
         const bool serial = cur.restarts[f] + 1 > SEG_MAX_RESTARTS;
-        const int s = (int)cur.s, q = s + 1;
+        const SegGeo G = seg_geo((int)cur.s);
         PLS_THREADS(tid, SEG_THREADS) {
             for (int b = tid; b < 256; b += SEG_THREADS) {
                 uint32_t v = j.base[((size_t)prev * SEG_NFILT + f) * 256 + b];
@@ -977,7 +1384,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 for (uint32_t x = xp; x < xend; x++)
                     for (uint32_t c = 0; c < bpp; c++) {
                         const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, (int)c);
-                        const uint32_t w = seg_step_scan(f, p, st[c], Hn, basen, rank, s, q, P.lut_a, P.bleed);
+                        const uint32_t w = seg_step_scan(f, p, st[c], Hn, basen, rank, G, P.lut_a, P.bleed);
                         cd[(size_t)x * 4 + c] = w;
                         basen[seg_cand_bin(w)]++;
                     }
@@ -994,7 +1401,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             }
         }
         PLS_SYNC();
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, s, q, SEG_THREADS);
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, G.s, G.q, SEG_THREADS);
     }
 }
 

@@ -71,6 +71,8 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.entry = A.take<uint32_t>((size_t)5 * j.nseg * 4);
     j.segcnt = A.take<uint16_t>((size_t)5 * j.nseg * 256);
     j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);
+    j.firstidx = A.take<uint32_t>(5 * 4 * 2);
+    j.rowmm = A.take<int32_t>(2 * ((W + SEG_THREADS - 1) / SEG_THREADS));
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
     const int ncommit = (int)((W + SEG_THREADS - 1) / SEG_THREADS);
     int attempt = 0;
@@ -80,7 +82,11 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         for (int bx = 0; bx < SEG_NFILT + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt, bx, smem.data());
         const int par = attempt & 1;
         if (j.ctl[par].finished) break;
-        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body(j, P, par, f, (int)sg, smem.data());
+        for (int f = 0; f < SEG_NFILT; f++) {
+            if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += SEG_SMALL_SEGS) seg_enum_small_body(j, P, par, f, (int)sg, smem.data());
+            else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body(j, P, par, f, (int)sg, smem.data());
+        }
+        for (int f = 0; f < SEG_NFILT; f++) seg_first_body(j, P, par, f, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_post_body(j, P, par, f, (int)g, smem.data());
