@@ -53,6 +53,7 @@
 #define PLS_SYNC() __syncthreads()
 #define PLS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define PLS_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define PLS_ATOMIC_OR(p, v) atomicOr((p), (v))
 #define PLS_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define PLS_WAVE_LEADER(tid) (((tid) & 63) == 0)
 __device__ __forceinline__ uint32_t pls_wave_sum_u32(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
@@ -68,6 +69,7 @@ __device__ __forceinline__ int pls_wave_min_i(int v) { for (int o = 32; o > 0; o
 #define PLS_SYNC() ((void)0)
 #define PLS_ATOMIC_ADD(p, v) (*(p) += (v))
 #define PLS_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define PLS_ATOMIC_OR(p, v) (*(p) |= (v))
 #define PLS_ATOMIC_ADD64(p, v) (*(p) += (v))
 /* the CPU harness runs one "thread" at a time: every thread is its own wave */
 #define PLS_WAVE_LEADER(tid) (true)
@@ -93,7 +95,7 @@ inline int pls_wave_min_i(int v) { return v; }
 #define SEG_MAX_RESTARTS 12      /* epochs per candidate and row before the rest of the row is done serially */
 #define SEG_MAX_NSEG 256              /* the chain kernel keeps a row's maps in shared memory: 256 x 512 B */
 #define SEG_THREADS 1024
-#define SEG_CHAIN_THREADS 256
+#define SEG_CHAIN_THREADS 1024
 #define SEG_REPLAY_THREADS 512       /* SEG_GRP * SEG_L: every thread loads one pixel of the group, 64 of them walk */
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
@@ -514,9 +516,9 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 
 /* shared-memory budgets (bytes) */
 #define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64)
-#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + SEG_TBL_WORDS * 4 + SEG_L * 8 + (size_t)(nseg) * 16 + 64)
+#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 16 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
-#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 64)
+#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 * 9 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + 256 + 64 * 4 + 2 * SEG_TN * 4)
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad */
@@ -689,7 +691,10 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 
 /* ---- CHAIN: task (f, c): compose the segment maps from the epoch's start state -----------------------------------------
  * The exit index of segment sg (relative to its last pixel) IS the entry index of segment sg+1 (relative to the same pixel, its
- * boundary pixel), so the chain is one shared-memory lookup per segment; entry states are decoded afterwards, in parallel. */
+ * boundary pixel), so composing is a lookup per segment.  Done in blocks of SEG_CBLK segments: every block's composed map for ALL
+ * entry indices in parallel (lane = (block, index)), then the true path across the blocks, then inside every block in parallel:
+ * 16 + nblk + 16 dependent lookups instead of nseg.  Entry states are decoded afterwards, in parallel. */
+#define SEG_CBLK 16
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -701,56 +706,87 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     if (first + 1 >= nseg) return;
     const bool small = seg_is_small(P, f);
     const int nmap = small ? SEG_NSS : SEG_NSP;               /* entries per map */
-    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
-    SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_L] pixels of the first segment, this channel */
-    SegPix *bpx = px + SEG_L;                                 /* [nseg] boundary pixel sg*SEG_L - 1 of every segment */
+    const uint32_t s0 = first + 1, ns = nseg - 1 - s0;        /* maps of segments s0 .. s0+ns-1; entries wanted for s0 .. nseg-1 */
+    const uint32_t nblk = (ns + SEG_CBLK - 1) / SEG_CBLK;
+    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512;
+    SegPix *bpx = (SegPix *)(Hf + 1024);                      /* [nseg] boundary pixel sg*SEG_L - 1 of every segment */
     uint32_t *idxs = (uint32_t *)(bpx + ((nseg + 1) & ~1u));  /* [nseg][2]: entry index of every segment | packed state when it has none */
-    uint16_t *maps = (uint16_t *)(idxs + 2 * ((nseg + 1) & ~1u));
+    uint32_t *idxb = idxs + 2 * ((nseg + 1) & ~1u);           /* [32]: entry index of every block, [31] = the slow path is needed */
+    uint16_t *G = (uint16_t *)(idxb + 32);                    /* [nblk][nmap] composed maps of the blocks */
+    uint16_t *maps = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G = seg_geo((int)ctl.s);
+    const SegGeo G_ = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        seg_load_frozen(j, par, f, Hf, rank, tid, SEG_CHAIN_THREADS);
-        for (int i = tid; i < 512; i += SEG_CHAIN_THREADS) lut[i] = P.lut_a[i];
-        for (uint32_t sg = first + 1 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c);
+        if (tid < 256) seg_load_frozen(j, par, f, Hf, rank, tid, 256);
+        if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
+        for (uint32_t sg = s0 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c);
         {
-            /* the maps of segments first+1 .. nseg-2, 16 bytes per load (a map is nmap * 2 bytes, contiguous) */
-            const int per = nmap / 8;                                   /* 16-byte pieces per map */
-            const uint32_t nm = nseg > first + 2 ? nseg - first - 2 : 0u;
-            for (uint32_t i = (uint32_t)tid; i < nm * (uint32_t)per; i += SEG_CHAIN_THREADS) {
-                const uint32_t sg = first + 1 + i / (uint32_t)per, piece = i % (uint32_t)per;
+            /* the maps, 16 bytes per load (a map is nmap * 2 bytes, contiguous) */
+            const int per = nmap / 8;                                   /* 16-byte pieces per map: 32 or 4 */
+            for (uint32_t i = (uint32_t)tid; i < ns * (uint32_t)per; i += SEG_CHAIN_THREADS) {
+                const uint32_t sg = s0 + i / (uint32_t)per, piece = i % (uint32_t)per;
                 const SegVec16 *src = (const SegVec16 *)(j.maps + (((size_t)f * nseg + sg) * 4 + c) * SEG_NSP) + piece;
-                ((SegVec16 *)(maps + (size_t)sg * nmap))[piece] = *src;
+                ((SegVec16 *)(maps + (size_t)(sg - s0) * nmap))[piece] = *src;
             }
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        for (uint32_t t = (uint32_t)tid; t < nblk * (uint32_t)nmap; t += SEG_CHAIN_THREADS) {
+            const uint32_t b = t / (uint32_t)nmap;
+            uint32_t idx = t % (uint32_t)nmap;
+            for (uint32_t k = b * SEG_CBLK; k < (b + 1) * SEG_CBLK && k < ns; k++) idx = idx == SEG_INVALID ? idx : (uint32_t)maps[(size_t)k * nmap + idx];
+            G[t] = (uint16_t)idx;
         }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         if (tid == 0) {
-            /* the epoch's first segment was walked by seg_first_body */
             uint32_t idx = j.firstidx[(f * 4 + c) * 2];
-            SegState st = seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]);
-            for (uint32_t sg = first + 1; sg < nseg; sg++) {
-                idxs[2 * sg] = idx;
-                if (idx == SEG_INVALID) idxs[2 * sg + 1] = seg_state_pack(st);
-                if (sg + 1 == nseg) break;
-                uint32_t nidx = idx == SEG_INVALID ? SEG_INVALID : (uint32_t)maps[(size_t)sg * nmap + idx];
-                if (nidx == SEG_INVALID) {
-                    /* a state or a lookup outside what the enumeration covers: this segment step by step (rare, slow, exact) */
-                    if (idx != SEG_INVALID) (void)seg_any_decode(P, f, (int)idx, bpx[sg], st);
-                    for (uint32_t x = sg * SEG_L; x < (sg + 1) * SEG_L && x < W; x++) {
-                        const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
-                        (void)seg_step_scan(f, p, st, Hf, nullptr, rank, G, lut, P.bleed);
+            uint32_t slow = 0;
+            for (uint32_t b = 0; b <= nblk; b++) {
+                idxb[b] = idx;
+                if (idx == SEG_INVALID) { slow = 1; break; }
+                if (b < nblk) idx = (uint32_t)G[(size_t)b * nmap + idx];
+            }
+            idxb[31] = slow;
+            if (slow) {
+                /* (rare) some state or lookup on the path lies outside what the enumeration covers: the whole chain step by step */
+                idx = j.firstidx[(f * 4 + c) * 2];
+                SegState st = seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]);
+                for (uint32_t sg = s0; sg < nseg; sg++) {
+                    idxs[2 * sg] = idx;
+                    if (idx == SEG_INVALID) idxs[2 * sg + 1] = seg_state_pack(st);
+                    if (sg + 1 == nseg) break;
+                    uint32_t nidx = idx == SEG_INVALID ? SEG_INVALID : (uint32_t)maps[(size_t)(sg - s0) * nmap + idx];
+                    if (nidx == SEG_INVALID) {
+                        if (idx != SEG_INVALID) (void)seg_any_decode(P, f, (int)idx, bpx[sg], st);
+                        for (uint32_t x = sg * SEG_L; x < (sg + 1) * SEG_L && x < W; x++) {
+                            const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
+                            (void)seg_step_scan(f, p, st, Hf, nullptr, rank, G_, lut, P.bleed);
+                        }
+                        nidx = seg_any_encode(P, f, bpx[sg + 1], st);
                     }
-                    nidx = seg_any_encode(P, f, bpx[sg + 1], st);
+                    idx = nidx;
                 }
-                idx = nidx;
             }
         }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        for (uint32_t sg = first + 1 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) {
+        if (!idxb[31] && (uint32_t)tid <= nblk) {
+            /* inside block tid (the pseudo block nblk holds only the entry of the last segment when ns is a multiple of SEG_CBLK) */
+            uint32_t idx = idxb[tid];
+            for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k <= ns; k++) {
+                idxs[2 * (s0 + k)] = idx;
+                if (k < ns) idx = (uint32_t)maps[(size_t)k * nmap + idx];
+            }
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        for (uint32_t sg = s0 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) {
             uint32_t packed;
             if (idxs[2 * sg] == SEG_INVALID) packed = idxs[2 * sg + 1];
             else { SegState st{ 0, 0, 0 }; (void)seg_any_decode(P, f, (int)idxs[2 * sg], bpx[sg], st); packed = seg_state_pack(st); }
@@ -807,6 +843,82 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     }
 }
 
+/* Validation of one decision d = (pixel k of the group) * 4 + channel.  mode 0: with the block bounds only -- returns 1 good, 0 bad,
+ * 2 cannot tell (its bins are marked in wbits); mode 1: exactly, with the per-segment prefix counts of the watched bins (pc), or by
+ * counting the earlier decisions of the segment for a bin that got no slot. */
+#define SEG_WATCH 8
+struct SegVal {
+    const uint32_t *cw, *ro, *na, *e0, *lut, *H0, *rank, *cum;
+    uint32_t bpp, sx, xg0, W;
+    int f, bleed;
+    SegGeo G;
+    uint32_t *wbits;
+    const uint8_t *slot_of, *pc;
+};
+PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
+{
+    constexpr int NPX = SEG_GRP * SEG_L;
+    const int c = d & 3, k = d >> 2;
+    const uint32_t x = V.xg0 + (uint32_t)k, bpp = V.bpp;
+    if (x >= V.W || x < V.sx || (uint32_t)c >= bpp) return 1;
+    const int sl = k / SEG_L;
+    const uint32_t w0 = V.cw[(k + 2) * 4 + c], w1 = V.cw[(k + 1) * 4 + c], w2 = V.cw[k * 4 + c];
+    const uint32_t o = V.ro[k + 1];
+    const int pe0 = seg_err_plane(V.e0 + 2 * k, seg_plane_of_channel(bpp, c));
+    const bool trp = (bpp & 1u) == 0u && (uint32_t)c == bpp - 1u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+    /* state in front of x from the outputs of x-1, x-2 */
+    int rem1, thr1, rem2, thr2;
+    seg_rem_thr(V.lut, V.bleed, x >= 1 ? seg_cand_diff(w1) : 0, rem1, thr1);
+    seg_rem_thr(V.lut, V.bleed, x >= 2 ? seg_cand_diff(w2) : 0, rem2, thr2);
+    const int left = x >= 1 ? seg_cand_byte(w1) : 0, cn = rem1 + thr2;
+    const int orig = (int)((o >> (8 * c)) & 255u), above = (int)((V.na[k + 1] >> (8 * c)) & 255u), diag = x ? (int)((V.na[k] >> (8 * c)) & 255u) : 0;
+    const int pred = seg_predict(V.f, above, diag, left);
+    const int back = seg_cand_byte(w0), diff = seg_cand_diff(w0), bin = seg_cand_bin(w0);
+    if (trp) return (back == 0 && diff == 0 && bin == ((0 - pred) & 255)) ? 1 : 0;
+    const int osym = seg_sext8(orig - pred), lo = osym - orig;
+    const int filt = osym + seg_sext16(pe0 + cn);
+    const SegBand bd = seg_band(filt, lo, V.G);
+    const int v = back + lo;
+    if (!(v >= bd.v0 && v <= bd.v1 && diff == seg_sext16(filt - v) && bin == (v & 255))) return 0;
+    if (bd.v0 == bd.v1) return 1;
+    const uint32_t *cs = V.cum + sl * 256, *ce = V.cum + (sl + 1) * 256;
+    const int kseg = seg_max(sl * SEG_L, (int)V.sx - (int)V.xg0);   /* first pixel of this decision's segment that belongs to the epoch */
+    const uint32_t hv_lo = V.H0[bin] + cs[bin], rv = V.rank[bin];
+    const int fv = v == osym;
+    bool have_hv = false; uint32_t hv_exact = 0;
+    int result = 1;
+    for (int u = bd.v0; u <= bd.v1; u++) {
+        if (u == v) continue;
+        const int ub = u & 255;
+        const uint32_t ru = V.rank[ub];
+        const int fu = u == osym;
+        const bool u_wins_ties = ru != rv ? ru > rv : (fu != fv ? fu > fv : u < v);      /* u beats v at equal frequency?  (O, flag, lower v) */
+        const uint32_t hu_hi = V.H0[ub] + ce[ub];
+        if (u_wins_ties ? hu_hi < hv_lo : hu_hi <= hv_lo) continue;                      /* proven by the bounds */
+        if (mode == 0) {
+            PLS_ATOMIC_OR(&V.wbits[bin >> 5], 1u << (bin & 31));
+            PLS_ATOMIC_OR(&V.wbits[ub >> 5], 1u << (ub & 31));
+            result = 2;
+            continue;
+        }
+        if (!have_hv) {
+            uint32_t n = 0;
+            const uint32_t sv = V.slot_of[bin];
+            if (sv != 255u) n = V.pc[(size_t)sv * NPX * 4 + d];
+            else for (int e = kseg * 4; e < d; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(V.cw[e + 8]) == bin) n++;
+            hv_exact = hv_lo + n; have_hv = true;
+        }
+        uint32_t n = 0;
+        const uint32_t su = V.slot_of[ub];
+        if (su != 255u) n = V.pc[(size_t)su * NPX * 4 + d];
+        else for (int e = kseg * 4; e < d; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(V.cw[e + 8]) == ub) n++;
+        const uint32_t hu = V.H0[ub] + cs[ub] + n;
+        if (u_wins_ties ? hu >= hv_exact : hu > hv_exact) return 0;
+    }
+    if (result == 2) PLS_ATOMIC_ADD(&V.wbits[8], 1u);
+    return result;
+}
+
 /* Candidate none (prediction 0): how far from  orig + incoming error  its reconstructed byte can lie.  With C a bound of the carried
  * terms |cn| and D of the quantisation differences |diff|:  |byte - (orig + e0)| <= s + C  (the chosen v lies in the band of filt, or the
  * clamp moved it towards 0..255);  D <= s + overshoot(C), overshoot = how far orig + e0 +- C can leave 0..255 (rowmm holds the row's
@@ -858,6 +970,10 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint32_t *oa = na + NPX + 2;                               /* [NPX + 1] original row above */
     uint32_t *e0 = oa + NPX + 2;                               /* [NPX][2] incoming error */
     uint32_t *rm = e0 + 2 * NPX;                               /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
+    uint32_t *wbits = rm + 768;                                /* [8] bitmap of watched bins, [8] pending decisions / slots in use, [9..] bin of each slot */
+    uint8_t *slot_of = (uint8_t *)(wbits + 32);                /* [256] slot of a watched bin or 255 */
+    uint8_t *pend = slot_of + 256;                             /* [NPX * 4] decision waits for pass 3 */
+    uint8_t *pc = pend + NPX * 4;                              /* [SEG_WATCH][NPX * 4] bumps of the slot's bin in front of the decision, within its segment */
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
@@ -920,64 +1036,53 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         }
     }
     PLS_SYNC();
-    /* -- validation: lane = decision -- */
+    /* -- validation: lane = decision.  Pass 1 settles what the block bounds can settle and marks the bins of the others ("watched");
+     *    pass 2 counts, per segment, the bumps of each watched bin in front of every decision; pass 3 settles the rest exactly. -- */
+    SegVal V;
+    V.cw = cw; V.ro = ro; V.na = na; V.e0 = e0; V.lut = lut; V.H0 = H0; V.rank = rank; V.cum = cum; V.bpp = bpp; V.f = f; V.G = G; V.bleed = P.bleed;
+    V.sx = sx; V.xg0 = xg0; V.W = W; V.wbits = wbits; V.slot_of = slot_of; V.pc = pc;
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid < 8) wbits[tid] = 0u;
+        if (tid == 8) wbits[8] = 0u;                                   /* number of pending decisions */
+        if (tid >= 64 && tid < 128) ((uint32_t *)slot_of)[tid - 64] = 0xffffffffu;
+    }
+    PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
         for (int d = tid; d < NPX * 4; d += SEG_THREADS) {
-            const int c = d & 3, k = d >> 2;                       /* pixel k of the group */
-            const uint32_t x = xg0 + (uint32_t)k;
-            if (x >= W || x < sx || (uint32_t)c >= bpp) continue;
-            const int sl = k / SEG_L;
-            const uint32_t w0 = cw[(k + 2) * 4 + c], w1 = cw[(k + 1) * 4 + c], w2 = cw[k * 4 + c];
-            const uint32_t o = ro[k + 1];
-            const int pl = seg_plane_of_channel(bpp, c);
-            const int pe0 = seg_err_plane(e0 + 2 * k, pl);
-            const bool trp = (bpp & 1u) == 0u && (uint32_t)c == bpp - 1u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-            /* state in front of x from the outputs of x-1, x-2 */
-            int rem1, thr1, rem2, thr2;
-            seg_rem_thr(lut, P.bleed, x >= 1 ? seg_cand_diff(w1) : 0, rem1, thr1);
-            seg_rem_thr(lut, P.bleed, x >= 2 ? seg_cand_diff(w2) : 0, rem2, thr2);
-            const int left = x >= 1 ? seg_cand_byte(w1) : 0, cn = rem1 + thr2;
-            const int orig = (int)((o >> (8 * c)) & 255u), above = (int)((na[k + 1] >> (8 * c)) & 255u), diag = x ? (int)((na[k] >> (8 * c)) & 255u) : 0;
-            const int pred = seg_predict(f, above, diag, left);
-            const int back = seg_cand_byte(w0), diff = seg_cand_diff(w0), bin = seg_cand_bin(w0);
-            bool good;
-            if (trp) good = back == 0 && diff == 0 && bin == ((0 - pred) & 255);
-            else {
-                const int osym = seg_sext8(orig - pred), lo = osym - orig;
-                const int filt = osym + seg_sext16(pe0 + cn);
-                const SegBand bd = seg_band(filt, lo, G);
-                const int v = back + lo;
-                good = v >= bd.v0 && v <= bd.v1 && diff == seg_sext16(filt - v) && bin == (v & 255);
-                if (good && bd.v0 < bd.v1) {
-                    const uint32_t *cs = cum + sl * 256, *ce = cum + (sl + 1) * 256;
-                    /* first pixel of this decision's segment that belongs to the epoch */
-                    const int kseg = seg_max(sl * SEG_L, (int)sx - (int)xg0);
-                    const uint32_t hv_lo = H0[bin] + cs[bin], rv = rank[bin];
-                    const int fv = v == osym;
-                    int exact_hv = -1; uint32_t hv_exact = 0;
-                    for (int u = bd.v0; u <= bd.v1 && good; u++) {
-                        if (u == v) continue;
-                        const int ub = u & 255;
-                        const uint32_t ru = rank[ub];
-                        const int fu = u == osym;
-                        /* u beats v at equal frequency?  (O, flag, lower v) */
-                        const bool u_wins_ties = ru != rv ? ru > rv : (fu != fv ? fu > fv : u < v);
-                        const uint32_t hu_hi = H0[ub] + ce[ub];
-                        if (u_wins_ties ? hu_hi < hv_lo : hu_hi <= hv_lo) continue;      /* proven by the bounds */
-                        /* exact counts: the earlier decisions of this segment */
-                        if (exact_hv < 0) {
-                            uint32_t n = 0;
-                            for (int e = kseg * 4; e < k * 4 + c; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(cw[(e >> 2) * 4 + 8 + (e & 3)]) == bin) n++;
-                            hv_exact = hv_lo + n; exact_hv = 1;
-                        }
-                        uint32_t n = 0;
-                        for (int e = kseg * 4; e < k * 4 + c; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(cw[(e >> 2) * 4 + 8 + (e & 3)]) == ub) n++;
-                        const uint32_t hu = H0[ub] + cs[ub] + n;
-                        if (u_wins_ties ? hu >= hv_exact : hu > hv_exact) good = false;
-                    }
+            const int r = seg_validate_one(V, d, 0);
+            pend[d] = (uint8_t)(r == 2);
+            if (r == 0) PLS_ATOMIC_MIN(&red[8], (xg0 + (uint32_t)(d >> 2)) * 4u + (uint32_t)(d & 3));
+        }
+    }
+    PLS_SYNC();
+    if (wbits[8]) {
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid == 0) {
+                int ns = 0;
+                for (int b = 0; b < 256 && ns < SEG_WATCH; b++) if ((wbits[b >> 5] >> (b & 31)) & 1u) { slot_of[b] = (uint8_t)ns; wbits[9 + ns] = (uint32_t)b; ns++; }
+                wbits[8] = (uint32_t)ns;
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            const int sl = tid / SEG_WATCH, slot = tid % SEG_WATCH;
+            if (sl < SEG_GRP && slot < (int)wbits[8]) {
+                const int b = (int)wbits[9 + slot];
+                uint8_t *dst = pc + (size_t)slot * NPX * 4;
+                const int kseg = seg_max(sl * SEG_L, (int)sx - (int)xg0);
+                uint32_t run = 0;
+                for (int e = kseg * 4; e < (sl + 1) * SEG_L * 4; e++) {
+                    dst[e] = (uint8_t)run;
+                    if ((uint32_t)(e & 3) < bpp && seg_cand_bin(cw[e + 8]) == b) run++;
                 }
             }
-            if (!good) PLS_ATOMIC_MIN(&red[8], x * 4u + (uint32_t)c);
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int d = tid; d < NPX * 4; d += SEG_THREADS) {
+                if (!pend[d]) continue;
+                if (seg_validate_one(V, d, 1) == 0) PLS_ATOMIC_MIN(&red[8], (xg0 + (uint32_t)(d >> 2)) * 4u + (uint32_t)(d & 3));
+            }
         }
     }
     /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
@@ -1201,7 +1306,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     if (bx == SEG_NFILT) {
         /* ---- the image-wide fields ---- */
         if (D.kind == SEG_K_FINISHED) {
-            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; } }
+            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
             return;
         }
         if (D.kind != SEG_K_RESTART) seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
