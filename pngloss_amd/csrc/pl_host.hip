@@ -290,6 +290,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     ctx->last_engine = use_seg ? 3 : 0;
     if (use_seg) {
         if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) seg_params.engine_flags = (std::atoi(ff) + 1) << 8;   /* debugging aid */
+        if (std::getenv("PNGLOSS_HIP_SEGPROF")) seg_params.engine_flags |= 1;                                                   /* phase clocks of the validation kernel */
         rc = run_seg_engine(ctx, d_jobs, n, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream);
         if (rc) return rc;
     } else {
@@ -332,6 +333,13 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
             if (std::getenv("PNGLOSS_HIP_DEBUG"))
                 std::fprintf(stderr, "pngloss_hip: image %zu: segment-parallel engine: %d attempts for %u rows, %d epochs (validation restarts), %d rows finished serially, candidate none dropped by its cost bound %d times, engine %.3f ms\n",
                              i, r[5], ctx->h_jobs[i].height, r[4], r[6], r[7], ctx->engine_ms);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF"))
+                std::fprintf(stderr, "pngloss_hip:   validation kernel, slowest workgroup per phase (us): load %.1f  pass1 %.1f  watched bins + pass3 %.1f  none bound %.1f  sums %.1f; pending decisions %d, largest reach %d\n",
+                             r[40] / 100.0, r[41] / 100.0, r[42] / 100.0, r[43] / 100.0, r[44] / 100.0, r[46], r[47]);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[53])
+                std::fprintf(stderr, "pngloss_hip:   ... average per workgroup (us): load %.2f  pass1 %.2f  watched bins + pass3 %.2f  none bound %.2f  sums %.2f  (%u workgroup runs)\n",
+                             (uint32_t)r[48] / 100.0 / (uint32_t)r[53], (uint32_t)r[49] / 100.0 / (uint32_t)r[53], (uint32_t)r[50] / 100.0 / (uint32_t)r[53], (uint32_t)r[51] / 100.0 / (uint32_t)r[53],
+                             (uint32_t)r[52] / 100.0 / (uint32_t)r[53], (uint32_t)r[53]);
             if (r[0]) { std::fprintf(stderr, "pngloss_hip: image %zu: no acceptable filter row (device status %d)\n", i, r[0]); worst = PNGLOSS_INTERNAL_ABORT; }
             if (results && i < n) results[i].repaired_pixels = (uint32_t)r[4];
             continue;

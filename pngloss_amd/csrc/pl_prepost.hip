@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kThreads) void pl_init(const PlJob *jobs)
     if (t == 0) {
         *j.flags = PL_FLAG_GRAY | PL_FLAG_OPAQUE;
         *j.out_flags = PL_FLAG_GRAY | PL_FLAG_OPAQUE;
-        for (int r = 0; r < 32; r++) j.result[r] = 0;
+        for (int r = 0; r < 64; r++) j.result[r] = 0;
     }
     for (uint32_t i = t; i < PL_NFILT * PL_NSYM; i += kThreads) j.orig_hist[i] = 0;
     for (uint32_t i = t; i < j.width; i += kThreads) {

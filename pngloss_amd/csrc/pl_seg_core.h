@@ -55,6 +55,8 @@
 #define PLS_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define PLS_ATOMIC_OR(p, v) atomicOr((p), (v))
 #define PLS_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#define PLS_CLOCK() wall_clock64()
+#define PLS_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define PLS_WAVE_LEADER(tid) (((tid) & 63) == 0)
 __device__ __forceinline__ uint32_t pls_wave_sum_u32(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 __device__ __forceinline__ uint64_t pls_wave_sum_u64(uint64_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
@@ -72,6 +74,8 @@ __device__ __forceinline__ int pls_wave_min_i(int v) { for (int o = 32; o > 0; o
 #define PLS_ATOMIC_OR(p, v) (*(p) |= (v))
 #define PLS_ATOMIC_ADD64(p, v) (*(p) += (v))
 /* the CPU harness runs one "thread" at a time: every thread is its own wave */
+#define PLS_CLOCK() 0ull
+#define PLS_ATOMIC_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 #define PLS_WAVE_LEADER(tid) (true)
 inline uint32_t pls_wave_sum_u32(uint32_t v) { return v; }
 inline uint64_t pls_wave_sum_u64(uint64_t v) { return v; }
@@ -117,6 +121,7 @@ struct SegParams {
     uint32_t st_pack[SEG_NSP];     /* state i -> (delta+128) | (cn+128) << 8 | (th+128) << 16 */
     uint16_t keylut[SEG_KEYLUT_MAX]; /* ((delta+dmax) * (2cmax+1) + cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
     /* filters whose prediction ignores the left pixel (none, up): the state is (cn, th) alone */
+    uint8_t rt_max[256];           /* [D] -> max |rem(d)| + max |thr(d)| over |d| <= D (capped at 255) */
     int32_t ns_small, small_ok;
     uint32_t st_small[SEG_NSS];    /* state i -> (cn+128) | (th+128) << 8 */
     uint16_t keylut_small[SEG_KEYS_MAX];   /* (cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
@@ -124,7 +129,8 @@ struct SegParams {
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
 struct SegCtl {
-    uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts, dropped_none, pad0;
+    uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts, dropped_none;
+    uint32_t none_eager;             /* rows for which candidate none is run straight away (its bound did not rule it out lately) */
     uint32_t active[SEG_NFILT];      /* the candidate still has unvalidated pixels (or sums) to produce in this attempt */
     uint32_t start_x[SEG_NFILT];     /* pixels [0, start_x) of the candidate row are validated */
     uint32_t state[SEG_NFILT][4];    /* chain state in front of start_x: left | (cn+128) << 8 | (th+128) << 16 */
@@ -290,7 +296,7 @@ PLS_HD void seg_pix_load4(SegPix *dst, const uint32_t *row, const uint32_t *nab,
 }
 
 /* band geometry of one lookup (optimize_state.c:186-210): clamped candidate range [v0, v1] (single value when v0 == v1) */
-struct SegBand { int v0, v1, bandlo, neg; };
+struct SegBand { int v0, v1, bandlo, neg, t; };
 PLS_HD SegBand seg_band(int filt, int lo, const SegGeo &g)
 {
     const int s = g.s, q = g.q;
@@ -298,6 +304,7 @@ PLS_HD SegBand seg_band(int filt, int lo, const SegGeo &g)
     b.neg = filt < 0;
     const int af = b.neg ? -filt : filt;
     const int t = seg_div_q(af, g);
+    b.t = t;
     b.bandlo = b.neg ? -(t * q) - s : t * q;
     const int bandhi = b.bandlo + s, hi = lo + 255;
     b.v0 = seg_max(b.bandlo, lo);
@@ -463,6 +470,14 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
         P.lut_a[d + 256] = ((uint32_t)s.rem & 0xffffu) | ((uint32_t)s.h << 16);
         P.lut_b[d + 256] = ((uint32_t)s.t & 255u) | (((uint32_t)s.f & 255u) << 8) | (((uint32_t)s.v & 255u) << 16) | ((uint32_t)s.h << 24);
     }
+    {
+        int rm_ = 0, tm_ = 0;
+        for (int D = 0; D < 256; D++) {
+            const SegSplit a = seg_split_slow(D, bleed), b = seg_split_slow(-D, bleed);
+            rm_ = seg_max(rm_, seg_max(seg_abs(a.rem), seg_abs(b.rem))); tm_ = seg_max(tm_, seg_max(seg_abs(a.h), seg_abs(b.h)));
+            P.rt_max[D] = (uint8_t)seg_min(255, rm_ + tm_);
+        }
+    }
     if (strength > 127) return false;
     int rmax = 0, tmax = 0;
     for (int d = -strength; d <= strength; d++) { const SegSplit s = seg_split_slow(d, bleed); if (seg_abs(s.rem) > rmax) rmax = seg_abs(s.rem); if (seg_abs(s.h) > tmax) tmax = seg_abs(s.h); }
@@ -518,7 +533,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 #define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 16 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
-#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 * 9 + 64)
+#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + 256 + 64 * 4 + 2 * SEG_TN * 4)
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad */
@@ -544,7 +559,7 @@ PLS_HD int seg_run_fast_f(int f, const SegPix *px, int pstride, int n, SegState 
 PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || !ctl.active[f]) return;
+    if (ctl.finished || ctl.active[f] != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     const uint32_t x0 = (uint32_t)seg * SEG_L;
     if (x0 + SEG_L >= W) return;                              /* the last segment has no successor */
@@ -579,7 +594,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
 PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || !ctl.active[f]) return;
+    if (ctl.finished || ctl.active[f] != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     if ((uint32_t)(seg0 + SEG_SMALL_SEGS) * SEG_L <= ctl.start_x[f]) return;
     uint32_t *tw = (uint32_t *)smem;
@@ -656,7 +671,7 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
 PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || !ctl.active[f]) return;
+    if (ctl.finished || ctl.active[f] != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = ctl.start_x[f];
     if (sx >= W) return;
@@ -698,7 +713,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || !ctl.active[f] || (uint32_t)c >= j.bpp) return;
+    if (ctl.finished || ctl.active[f] != 1 || (uint32_t)c >= j.bpp) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = ctl.start_x[f];
     if (sx >= W) return;
@@ -799,7 +814,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
 PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || !ctl.active[f]) return;
+    if (ctl.finished || ctl.active[f] != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = ctl.start_x[f];
     if (sx >= W) return;
@@ -853,16 +868,29 @@ struct SegVal {
     int f, bleed;
     SegGeo G;
     uint32_t *wbits;
-    const uint8_t *slot_of, *pc;
+    const uint8_t *slot_of;
+    const uint32_t *pcw;          /* prefix counts of the watched bins, 4 decisions per word: [slot][SEG_PC_STRIDE] */
+    uint8_t *binb;                /* bin of every decision, [segment of the group][SEG_BINB_STRIDE bytes] */
+    const uint32_t *btop;         /* [2][SEG_NBAND][4]: per band of either sign: largest upper count bound, its bin, second largest */
+    const uint32_t *hiG, *loG;    /* [256] frequency of a bin: upper bound (through the group's end), lower bound (at the group's start) */
 };
+#define SEG_BINB_STRIDE (SEG_L * 4 + 4)
+#define SEG_PC_SEG (SEG_L + 1)                   /* words per segment and slot (one pad word: bank spread) */
+#define SEG_PC_STRIDE (SEG_GRP * SEG_PC_SEG + 8)
+#define SEG_NBAND 20
+PLS_HD uint32_t seg_pc_get(const uint32_t *pcw, uint32_t slot, int d)
+{
+    const uint32_t w = pcw[(size_t)slot * SEG_PC_STRIDE + (d / (SEG_L * 4)) * SEG_PC_SEG + ((d % (SEG_L * 4)) >> 2)];
+    return (w >> (8 * (d & 3))) & 255u;
+}
 PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
 {
-    constexpr int NPX = SEG_GRP * SEG_L;
     const int c = d & 3, k = d >> 2;
     const uint32_t x = V.xg0 + (uint32_t)k, bpp = V.bpp;
-    if (x >= V.W || x < V.sx || (uint32_t)c >= bpp) return 1;
     const int sl = k / SEG_L;
     const uint32_t w0 = V.cw[(k + 2) * 4 + c], w1 = V.cw[(k + 1) * 4 + c], w2 = V.cw[k * 4 + c];
+    if (mode == 0) V.binb[sl * SEG_BINB_STRIDE + (d - sl * SEG_L * 4)] = (uint8_t)seg_cand_bin(w0);
+    if (x >= V.W || x < V.sx || (uint32_t)c >= bpp) return 1;
     const uint32_t o = V.ro[k + 1];
     const int pe0 = seg_err_plane(V.e0 + 2 * k, seg_plane_of_channel(bpp, c));
     const bool trp = (bpp & 1u) == 0u && (uint32_t)c == bpp - 1u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
@@ -881,6 +909,13 @@ PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
     const int v = back + lo;
     if (!(v >= bd.v0 && v <= bd.v1 && diff == seg_sext16(filt - v) && bin == (v & 255))) return 0;
     if (bd.v0 == bd.v1) return 1;
+    if (mode == 0 && bd.t < SEG_NBAND) {
+        /* the clamped range is part of band t: if every OTHER bin of the whole band stays strictly below v's lower bound for the
+         * whole group, nothing in the range can beat v -- one comparison for most decisions */
+        const uint32_t *bt = V.btop + ((size_t)bd.neg * SEG_NBAND + bd.t) * 4;
+        const uint32_t other = bt[1] == (uint32_t)bin ? bt[2] : bt[0];
+        if (other < V.loG[bin]) return 1;
+    }
     const uint32_t *cs = V.cum + sl * 256, *ce = V.cum + (sl + 1) * 256;
     const int kseg = seg_max(sl * SEG_L, (int)V.sx - (int)V.xg0);   /* first pixel of this decision's segment that belongs to the epoch */
     const uint32_t hv_lo = V.H0[bin] + cs[bin], rv = V.rank[bin];
@@ -904,13 +939,13 @@ PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
         if (!have_hv) {
             uint32_t n = 0;
             const uint32_t sv = V.slot_of[bin];
-            if (sv != 255u) n = V.pc[(size_t)sv * NPX * 4 + d];
+            if (sv != 255u) n = seg_pc_get(V.pcw, sv, d);
             else for (int e = kseg * 4; e < d; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(V.cw[e + 8]) == bin) n++;
             hv_exact = hv_lo + n; have_hv = true;
         }
         uint32_t n = 0;
         const uint32_t su = V.slot_of[ub];
-        if (su != 255u) n = V.pc[(size_t)su * NPX * 4 + d];
+        if (su != 255u) n = seg_pc_get(V.pcw, su, d);
         else for (int e = kseg * 4; e < d; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(V.cw[e + 8]) == ub) n++;
         const uint32_t hu = V.H0[ub] + cs[ub] + n;
         if (u_wins_ties ? hu >= hv_exact : hu > hv_exact) return 0;
@@ -924,7 +959,7 @@ PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
  * clamp moved it towards 0..255);  D <= s + overshoot(C), overshoot = how far orig + e0 +- C can leave 0..255 (rowmm holds the row's
  * extremes of orig + e0);  C <= max |rem| + max |thr| over |d| <= D.  Iterated from C = the table bound to a fixed point; -1 = none found
  * (then no bound is claimed). */
-PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, const uint32_t *lut_a, int s)
+PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s)
 {
     if (!j.rowmm) return -1;
     int M = -(1 << 30), m = 1 << 30;
@@ -935,9 +970,7 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, const uint32_t *l
         const int ov = seg_max(0, seg_max(M + C - 255, C - m));
         const int D = s + ov;
         if (D > 255) return -1;
-        int rmax = 0, tmax = 0;
-        for (int d = -D; d <= D; d++) { int rem, thr; seg_rem_thr(lut_a, P.bleed, d, rem, thr); rmax = seg_max(rmax, seg_abs(rem)); tmax = seg_max(tmax, seg_abs(thr)); }
-        const int C2 = seg_max(C, rmax + tmax);
+        const int C2 = seg_max(C, (int)P.rt_max[D]);
         if (C2 == C) return s + C;
         C = C2;
     }
@@ -973,12 +1006,19 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint32_t *wbits = rm + 768;                                /* [8] bitmap of watched bins, [8] pending decisions / slots in use, [9..] bin of each slot */
     uint8_t *slot_of = (uint8_t *)(wbits + 32);                /* [256] slot of a watched bin or 255 */
     uint8_t *pend = slot_of + 256;                             /* [NPX * 4] decision waits for pass 3 */
-    uint8_t *pc = pend + NPX * 4;                              /* [SEG_WATCH][NPX * 4] bumps of the slot's bin in front of the decision, within its segment */
+    uint8_t *binb = pend + NPX * 4;                            /* [SEG_GRP][SEG_BINB_STRIDE] bin of every decision */
+    uint32_t *pcw = (uint32_t *)(binb + SEG_GRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][SEG_PC_STRIDE] prefix counts of the watched bins */
+    uint32_t *btop = pcw + SEG_WATCH * SEG_PC_STRIDE;          /* [2][SEG_NBAND][4] */
+    uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
     const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
     const uint32_t xg0 = seg0 * SEG_L;
+    const bool lazy = ctl.active[f] == 2;                       /* candidate none, not run yet: only its cost bound is wanted */
+    const bool prof = (P.engine_flags & 1) != 0;                /* debugging: phase clocks (100 MHz ticks) into result[40..], max over the workgroups */
+    unsigned long long tk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (prof) tk[0] = PLS_CLOCK();
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < 256) {
             H0[tid] = j.H0[par * 256 + tid];
@@ -1036,15 +1076,34 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         }
     }
     PLS_SYNC();
+    if (prof) tk[1] = PLS_CLOCK();
+    if (!lazy) {
     /* -- validation: lane = decision.  Pass 1 settles what the block bounds can settle and marks the bins of the others ("watched");
      *    pass 2 counts, per segment, the bumps of each watched bin in front of every decision; pass 3 settles the rest exactly. -- */
     SegVal V;
     V.cw = cw; V.ro = ro; V.na = na; V.e0 = e0; V.lut = lut; V.H0 = H0; V.rank = rank; V.cum = cum; V.bpp = bpp; V.f = f; V.G = G; V.bleed = P.bleed;
-    V.sx = sx; V.xg0 = xg0; V.W = W; V.wbits = wbits; V.slot_of = slot_of; V.pc = pc;
+    V.sx = sx; V.xg0 = xg0; V.W = W; V.wbits = wbits; V.slot_of = slot_of; V.pcw = pcw; V.binb = binb; V.btop = btop; V.hiG = hiG; V.loG = loG;
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < 8) wbits[tid] = 0u;
         if (tid == 8) wbits[8] = 0u;                                   /* number of pending decisions */
         if (tid >= 64 && tid < 128) ((uint32_t *)slot_of)[tid - 64] = 0xffffffffu;
+        if (tid >= 256 && tid < 512) { const int b = tid - 256; hiG[b] = H0[b] + cum[SEG_GRP * 256 + b]; loG[b] = H0[b] + cum[b]; }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid < 2 * SEG_NBAND) {
+            const int neg = tid / SEG_NBAND, t = tid % SEG_NBAND;
+            const int blo = neg ? -(t * G.q) - G.s : t * G.q;
+            uint32_t m1 = 0, b1 = 256, m2 = 0;
+            for (int v = blo; v <= blo + G.s; v++) {
+                const uint32_t h = hiG[v & 255];
+                if (b1 == 256u || h > m1) { m2 = b1 == 256u ? 0u : m1; m1 = h; b1 = (uint32_t)(v & 255); }
+                else if (h > m2) m2 = h;
+            }
+            /* ">=" semantics: a second bin as large as the first must count as "other" for the first as well */
+            uint32_t *bt = btop + ((size_t)neg * SEG_NBAND + t) * 4;
+            bt[0] = m1; bt[1] = b1; bt[2] = m2; bt[3] = 0u;
+        }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
@@ -1055,10 +1114,12 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         }
     }
     PLS_SYNC();
+    if (prof) tk[2] = PLS_CLOCK();
     if (wbits[8]) {
         PLS_THREADS(tid, SEG_THREADS) {
             if (tid == 0) {
                 int ns = 0;
+                red[13] = wbits[8];
                 for (int b = 0; b < 256 && ns < SEG_WATCH; b++) if ((wbits[b >> 5] >> (b & 31)) & 1u) { slot_of[b] = (uint8_t)ns; wbits[9 + ns] = (uint32_t)b; ns++; }
                 wbits[8] = (uint32_t)ns;
             }
@@ -1067,13 +1128,20 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         PLS_THREADS(tid, SEG_THREADS) {
             const int sl = tid / SEG_WATCH, slot = tid % SEG_WATCH;
             if (sl < SEG_GRP && slot < (int)wbits[8]) {
-                const int b = (int)wbits[9 + slot];
-                uint8_t *dst = pc + (size_t)slot * NPX * 4;
-                const int kseg = seg_max(sl * SEG_L, (int)sx - (int)xg0);
+                /* bumps of the slot's bin in front of every decision of segment sl, four decisions per word in and out */
+                const uint32_t b = wbits[9 + slot];
+                const uint32_t *src = (const uint32_t *)(binb + sl * SEG_BINB_STRIDE);
+                uint32_t *dst = pcw + (size_t)slot * SEG_PC_STRIDE + sl * SEG_PC_SEG;
+                const int e0seg = seg_max(0, ((int)sx - (int)xg0 - sl * SEG_L) * 4);          /* decisions of the segment in front of the epoch do not count */
                 uint32_t run = 0;
-                for (int e = kseg * 4; e < (sl + 1) * SEG_L * 4; e++) {
-                    dst[e] = (uint8_t)run;
-                    if ((uint32_t)(e & 3) < bpp && seg_cand_bin(cw[e + 8]) == b) run++;
+                for (int iw = 0; iw < SEG_L; iw++) {
+                    const uint32_t w = src[iw];
+                    uint32_t out = 0;
+                    for (int t = 0; t < 4; t++) {
+                        out |= (run & 255u) << (8 * t);
+                        if (iw * 4 + t >= e0seg && (uint32_t)t < bpp && ((w >> (8 * t)) & 255u) == b) run++;
+                    }
+                    dst[iw] = out;
                 }
             }
         }
@@ -1085,10 +1153,12 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             }
         }
     }
+    }
+    if (prof) { tk[3] = PLS_CLOCK(); if (lazy) tk[2] = tk[3]; }
     /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
      *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
      *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) red[12] = (uint32_t)(f == 0 ? seg_none_reach(j, P, lut, (int)ctl.s) : -1); }
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) red[12] = (uint32_t)(f == 0 ? seg_none_reach(j, P, (int)ctl.s) : -1); }
     PLS_SYNC();
     const int R = (int)red[12];
     if (f == 0 && R >= 0) {
@@ -1126,7 +1196,9 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         }
     }
     PLS_SYNC();
+    if (prof) tk[4] = PLS_CLOCK();
     /* -- post pass of this candidate over the group's pixels (optimize_state.c:265-287, 326-342, 492-562): lane = pixel -- */
+    if (!lazy)
     PLS_THREADS(tid, SEG_THREADS) {
         uint64_t derr = 0; uint32_t cost = 0, hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
         for (int k = tid; k < NPX; k += SEG_THREADS) {
@@ -1162,18 +1234,27 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid == 0) {
             SegAcc &A = j.acc[par];
-            PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
-            PLS_ATOMIC_ADD(&A.cost[f], red[2]);
-            for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[3 + g]);
-            if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
+            if (!lazy) {
+                PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
+                PLS_ATOMIC_ADD(&A.cost[f], red[2]);
+                for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[3 + g]);
+                if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
+            }
             if (f == 0 && R >= 0) { PLS_ATOMIC_ADD64(&A.none_lb, *(uint64_t *)&red[10]); PLS_ATOMIC_ADD(&A.lb_valid, 1u); }
+            if (prof) {
+                tk[5] = PLS_CLOCK();
+                for (int q = 0; q < 5; q++) { PLS_ATOMIC_MAX(&j.result[40 + q], (int32_t)(tk[q + 1] - tk[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[48 + q], (uint32_t)(tk[q + 1] - tk[q])); }
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[53], 1u);
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[46], red[13]);                     /* pending decisions (pass 3) */
+                PLS_ATOMIC_MAX(&j.result[47], (int32_t)(f == 0 ? R : 0));
+            }
         }
     }
 }
 
 /* ---- CONTROL -------------------------------------------------------------------------------------------------------------- */
 struct SegDecision {
-    int kind, winner, dropped_none;
+    int kind, winner, dropped_none, start_none, keep_lazy;
     uint32_t failed;                /* bit f: candidate f failed validation in the attempt just finished */
     uint64_t cost[SEG_NFILT];
 };
@@ -1182,14 +1263,16 @@ struct SegDecision {
 PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, const SegCtl &cur, const SegAcc &A)
 {
     SegDecision D;
-    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0; D.dropped_none = 0;
+    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0; D.dropped_none = 0; D.start_none = 0; D.keep_lazy = 0;
     for (int f = 0; f < SEG_NFILT; f++) D.cost[f] = ~0ull;
     if (attempt == 0) return D;
     if (cur.finished) { D.kind = SEG_K_FINISHED; return D; }
     const bool adaptive = !j.row_filters || cur.y == 0;
     bool any_failed = false;
+    bool lazy0 = false;
     for (int f = 0; f < SEG_NFILT; f++) {
         if (!cur.active[f]) { D.cost[f] = cur.cost[f]; continue; }
+        if (cur.active[f] == 2) { lazy0 = true; continue; }                        /* candidate none, not run yet */
         if (A.fail[f] != SEG_NOFAIL) { D.failed |= 1u << f; any_failed = true; continue; }
         uint64_t cst = A.derr[f] / 128u + A.cost[f];                              /* optimize_state.c:360 */
         if (adaptive) {
@@ -1200,17 +1283,22 @@ PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, 
         if (P.engine_flags >> 8) cst = f == (P.engine_flags >> 8) - 1 ? 0ull : ~0ull;
         D.cost[f] = cst;
     }
-    D.dropped_none = 0;
-    if ((D.failed & 1u) && !(P.engine_flags >> 8) && A.lb_valid == j.ngrp) {
-        /* Candidate none failed validation.  Its row cost is at least none_lb (seg_post_body); it has the lowest index, so it wins ties
-         * (pngloss_image.c:257) and loses only to a strictly cheaper row: if one exists already, none cannot be the winner whatever its
-         * exact row would be -- its epoch is not worth running.  (The winner's row, histogram and errors are all that is committed.) */
+    D.dropped_none = 0; D.start_none = 0; D.keep_lazy = 0;
+    if (((D.failed & 1u) || lazy0) && !(P.engine_flags >> 8)) {
+        /* Candidate none failed validation, or has not been run at all (lazy).  Its row cost is at least none_lb (seg_post_body); it has
+         * the lowest index, so it wins ties (pngloss_image.c:257) and loses only to a strictly cheaper row: if one exists already, none
+         * cannot be the winner whatever its exact row would be -- running it (again) is not worth it.  (The winner's row, histogram and
+         * errors are all that is committed.) */
         uint64_t best_other = ~0ull;
         for (int f = 1; f < SEG_NFILT; f++) if (!((D.failed >> f) & 1u) && D.cost[f] < best_other) best_other = D.cost[f];
-        if (best_other < A.none_lb) {
-            D.failed &= ~1u; D.cost[0] = ~0ull; D.dropped_none = 1;
+        if (A.lb_valid == j.ngrp && best_other < A.none_lb) {
+            D.failed &= ~1u; D.cost[0] = ~0ull; D.dropped_none = 1; lazy0 = false;
             any_failed = D.failed != 0;
         }
+    }
+    if (lazy0) {
+        if (any_failed) D.keep_lazy = 1;             /* others still have epochs to run: none can wait for their costs */
+        else { D.start_none = 1; any_failed = true; }/* the bound does not rule none out: run it now */
     }
     if (any_failed) { D.kind = SEG_K_RESTART; return D; }
     uint64_t best = ~0ull;
@@ -1306,7 +1394,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     if (bx == SEG_NFILT) {
         /* ---- the image-wide fields ---- */
         if (D.kind == SEG_K_FINISHED) {
-            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
+            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
             return;
         }
         if (D.kind != SEG_K_RESTART) seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
@@ -1329,13 +1417,17 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 if (W == 0 || H == 0) fin = 1;
                 nxt.y = ny; nxt.s = (uint32_t)(s_next < 0 ? 0 : s_next); nxt.status = st; nxt.finished = fin; nxt.retried = retried; nxt.restarts_total = rt;
                 nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt; nxt.dropped_none = dropped;
+                {
+                    const uint32_t ne = attempt ? cur.none_eager : 0u;
+                    nxt.none_eager = D.start_none ? 16u : ((D.kind == SEG_K_COMMIT || D.kind == SEG_K_RETRY) && ne ? ne - 1u : ne);
+                }
                 if (j.progress && D.kind == SEG_K_COMMIT) PLS_HOST_VISIBLE_STORE(j.progress, ny);
                 if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt);
                 if (fin) {
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 64; i++) j.result[i] = 0;
+                    for (int i = 0; i < 40; i++) j.result[i] = 0;
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
                     j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
                     if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
@@ -1436,13 +1528,27 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         PLS_THREADS(tid, SEG_THREADS) {
             for (int b = tid; b < 256; b += SEG_THREADS) { basen[b] = 0u; j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
             if (tid == 0) {
-                nxt.active[f] = 1; nxt.start_x[f] = 0; nxt.restarts[f] = 0; nxt.cost[f] = ~0ull;
+                /* candidate none starts lazy: its cost bound first, the chain only if that cannot rule it out (seg_decide) */
+                nxt.active[f] = (f == 0 && j.rowmm && !(P.engine_flags >> 8) && !(P.engine_flags & 2) && !(attempt && cur.none_eager)) ? 2u : 1u;
+                nxt.start_x[f] = 0; nxt.restarts[f] = 0; nxt.cost[f] = ~0ull;
                 for (int c = 0; c < 4; c++) nxt.state[f][c] = seg_state_pack(SegState{ 0, 0, 0 });
             }
         }
         PLS_SYNC();
         const int sn = s_next < 0 ? 0 : s_next;
         seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, sn, sn + 1, SEG_THREADS);
+        return;
+    }
+    if (f == 0 && cur.active[0] == 2 && (D.start_none || D.keep_lazy)) {
+        PLS_THREADS(tid, SEG_THREADS) {
+            for (int b = tid; b < 256; b += SEG_THREADS) { Hn[b] = j.H0[prev * 256 + b]; j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
+            if (tid == 0) {
+                nxt.active[0] = D.start_none ? 1u : 2u; nxt.start_x[0] = 0; nxt.restarts[0] = 0; nxt.cost[0] = ~0ull;
+                for (int c = 0; c < 4; c++) nxt.state[0][c] = seg_state_pack(SegState{ 0, 0, 0 });
+            }
+        }
+        PLS_SYNC();
+        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, (int)cur.s, (int)cur.s + 1, SEG_THREADS);
         return;
     }
     if (!failed) {
