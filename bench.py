@@ -12,7 +12,11 @@
   batch    : for every N, additionally BASELINE.json configs[3] -- 256 synthetic 1920x1080 frames split over the N ranks
              with pngloss_amd.shard.contiguous_partition, one device-resident batch per rank; reported under the `batch`
              key (whole-job Mpixels/s, per-rank engine ms, reference digests of frames 0/1/255 checked).  This is the
-             image-batch (strong) scaling north_star asks about; it is not part of `value`.
+             image-batch (strong) scaling north_star asks about; it is not part of `value`.  One GPU runs one image per CU, so
+             configs[3] cannot get faster below 256 frames per GPU: `batch_saturating` (512 frames per rank for N <= 8, i.e.
+             4096 frames in all at N = 8) is the leg whose rate can scale with N.
+  engines  : the library picks the row engine per batch (pngloss_hip_last_engine_info): few large images -> segment-parallel
+             (the whole GPU on one image), batches -> one workgroup per image.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the row engine) against HBM with the
 ALGORITHMIC traffic of SURVEY.md section 8(d): 8 bytes per RGBA8 pixel (read 4 + write 4; the H filter bytes are
@@ -64,11 +68,38 @@ def _warm_worker(i):
     return os.getpid()
 
 
+def usable_cpus():
+    """CPUs this process may really use: the scheduler affinity mask, capped by the cgroup CPU quota (cpu.max) when one is set.
+    os.cpu_count() is the host's, not the container's: one process per host core inside a small quota measures the throttle."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(quota)))
+    return n, quota
+
+
 def cpu_all_cores():
-    """N processes = host cores, one frame each (the reference is single-threaded; its natural scale-out is one process
-    per file)."""
+    """N processes, one frame strip each (the reference is single-threaded; its natural scale-out is one process per file,
+    SURVEY.md 8(d)(ii)), at N = 1, 8, 64 and every usable CPU; per_process_mpx next to each aggregate shows whether the processes
+    really ran in parallel."""
     import multiprocessing as mp
-    n = os.cpu_count() or 1
+    nmax, quota = usable_cpus()
     model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -77,17 +108,22 @@ def cpu_all_cores():
     except OSError:
         pass
     ctxm = mp.get_context("fork")
-    with ctxm.Pool(n) as pool:
-        pool.map(_warm_worker, range(n), chunksize=1)        # process start-up, imports and library loads stay outside the timed map
-        t = time.perf_counter()
-        res = pool.map(_ref_worker, range(n), chunksize=1)
-        wall = time.perf_counter() - t
-    assert all(r[0] == 0 for r in res)
-    px = sum(r[1] for r in res)
-    return {"value": round(px / wall / 1e6, 3), "unit": "Mpixels/s", "cores": n, "cpu_model": model,
+    curve = []
+    for n in sorted({1, min(8, nmax), min(64, nmax), nmax}):
+        with ctxm.Pool(n) as pool:
+            pool.map(_warm_worker, range(n), chunksize=1)        # process start-up, imports and library loads stay outside the timed map
+            t = time.perf_counter()
+            res = pool.map(_ref_worker, range(n), chunksize=1)
+            wall = time.perf_counter() - t
+        assert all(r[0] == 0 for r in res)
+        px = sum(r[1] for r in res)
+        curve.append({"processes": n, "value": round(px / wall / 1e6, 3), "per_process_mpx": round(sum(r[1] / r[2] for r in res) / len(res) / 1e6, 4), "wall_s": round(wall, 2)})
+    best = max(curve, key=lambda c: c["value"])
+    return {"value": best["value"], "unit": "Mpixels/s", "cores": best["processes"], "cpu_model": model,
+            "usable_cpus": nmax, "cgroup_cpu_quota": quota, "host_logical_cpus": os.cpu_count(),
             "kind": "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpngloss_ref.so")) else "port",
-            "sample": f"{n} processes, one {BATCH_W}x{BATCH_H // 4} strip of a configs[3] frame each, s={STRENGTH} b={BLEED}; wall {wall:.1f} s",
-            "per_process_mpx": round(sum(r[1] / r[2] for r in res) / len(res) / 1e6, 4)}
+            "sample": f"one {BATCH_W}x{BATCH_H // 4} strip of a configs[3] frame per process, s={STRENGTH} b={BLEED}",
+            "per_process_mpx": best["per_process_mpx"], "curve": curve}
 
 
 def cpu_baseline(frame0):
@@ -124,7 +160,7 @@ def cpu_baseline(frame0):
         assert np.array_equal(rbuf, pbuf) and np.array_equal(rfilt, pfilt)
     out = {"value": round(value, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
            "sample": f"top {w}x{h} strip of the 4096x4096 frame, s={STRENGTH} b={BLEED}, single thread "
-                     f"(the reference is single-threaded); host has {os.cpu_count()} logical cores",
+                     f"(the reference is single-threaded); host has {os.cpu_count()} logical cores, {usable_cpus()[0]} usable here",
            "port_value": round(port_mpx, 4),
            "note": f"the build container measured {BUILD_CONTAINER_REFERENCE_MPX} Mpixels/s for the reference on the FULL frame "
                    "(BASELINE.md section 2); the >=50x target of BASELINE.json was defined on that number"}
@@ -135,23 +171,26 @@ def cpu_baseline(frame0):
     return out
 
 
-def isa_facts():
-    """Issue slots per pixel step of the hand-scheduled inner loops, from the committed ISA excerpt (profiles/r02_engine_isa.txt,
-    written by tools/engine_isa.py from the code object) -- not a literal."""
-    facts = {}
+def engine_kernels():
+    """Per-kernel share of the row engine from the committed rocprofv3 kernel trace of this very command
+    (profiles/r03_kernel_trace_stats.txt): calls, average duration, share of the engine's time."""
+    out = {}
     try:
-        for ln in open(os.path.join(ROOT, "profiles", "r02_engine_isa.txt")):
-            if ln.startswith("issue_slots_per_pixel_step"):
-                k, v = ln.split(":", 1)
-                facts = json.loads(v)
-    except (OSError, ValueError):
+        for ln in open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")):
+            if "seg_k_" in ln and ln.count(",") >= 5:
+                f = [x.strip('"') for x in ln.strip().split('","')]
+                name = f[0].split("seg_k_")[1].split("(")[0]
+                out["seg_k_" + name] = {"calls": int(f[1]), "avg_us": round(float(f[3]) / 1e3, 2), "percent_of_gpu_time": round(float(f[4]), 2)}
+    except (OSError, ValueError, IndexError):
         pass
-    return facts
+    if out:
+        out["source"] = "profiles/r03_kernel_trace_stats.txt (rocprofv3 --kernel-trace --stats of this command)"
+    return out
 
 
 def bandwidth_kernels():
     """The HBM-class passes around the row engine, from the committed rocprofv3 kernel trace of this very command
-    (profiles/r02_v3_kernel_trace_stats.txt): average duration and bytes moved per launch on the 4096x4096 frame."""
+    (profiles/r03_kernel_trace_stats.txt): average duration and bytes moved per launch on the 4096x4096 frame."""
     out = {}
     alg = {"pl_classify": 4 * W * H, "pl_hist": 4 * W * H}   # both read the 4 B/px image once
     try:
@@ -165,7 +204,7 @@ def bandwidth_kernels():
     except (OSError, ValueError, IndexError):
         pass
     if out:
-        out["source"] = "profiles/r02_v3_kernel_trace_stats.txt (static; pl_hist is bound by its 20 LDS atomics per pixel, DESIGN.md section 11)"
+        out["source"] = "profiles/r03_kernel_trace_stats.txt (static; pl_hist is bound by its 20 LDS atomics per pixel, DESIGN.md section 11)"
     return out
 
 
@@ -195,13 +234,44 @@ def run_batch(P, S, torch, ctx_factory, rank, world, local_rank, barrier):
     return dt, eng, recs
 
 
+SAT_FRAMES_PER_RANK, SAT_DISTINCT = 512, 32
+
+
+def run_batch_saturating(P, S, torch, ctx_factory, rank, world, barrier):
+    """512 frames of 1920x1080 PER RANK (4096 in all at N = 8), in device-resident batches of 256: a workload that keeps N GPUs
+    busy, unlike configs[3] split N ways.  The frames are 32 distinct synthetic ones (indices 0, 1, 255 and 29 more), each
+    uploaded once and cloned on the device; the digests of the copies of frames 0, 1 and 255 are checked."""
+    idx = [0, 1, 255] + list(range(2, 2 + SAT_DISTINCT - 3))
+    base = [torch.from_numpy(P.synth_rgba(BATCH_W, BATCH_H, MODE, i)).cuda() for i in idx]
+    ctx = ctx_factory()
+    total, eng, recs = 0.0, 0.0, []
+    for part in range(SAT_FRAMES_PER_RANK // 256):
+        dev = [base[k % SAT_DISTINCT].clone() for k in range(256)]
+        filt = [torch.zeros(BATCH_H, dtype=torch.uint8, device="cuda") for _ in dev]
+        desc = [(d.data_ptr(), f.data_ptr(), BATCH_W, BATCH_H) for d, f in zip(dev, filt)]
+        barrier()
+        t0 = time.perf_counter()
+        res = ctx.run(desc, STRENGTH, BLEED, stream=torch.cuda.current_stream().cuda_stream)
+        barrier()
+        total += time.perf_counter() - t0
+        eng += ctx.engine_ms
+        ok = all(r["status"] == 0 for r in res)
+        for k in (0, 1, 2):
+            recs.append(dict(frame=idx[k], ok=ok, out="%016x" % P.fnv1a64(dev[k].cpu().numpy(), P.SURVEY_FNV_BASIS),
+                             filters="%016x" % P.fnv1a64(filt[k].cpu().numpy(), P.SURVEY_FNV_BASIS)))
+        del dev, filt
+    info = ctx.engine_info(0)
+    ctx.close()
+    return total, eng, recs, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batch", action="store_true", help="skip the configs[3] batch leg")
+    ap.add_argument("--no-batch", action="store_true", help="skip the configs[3] batch leg and the saturating batch leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -239,9 +309,12 @@ def main():
     ctx = P.HipContext(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
+    engine_info = {}
+
     def step(i):
         res = ctx.run([(work[i].data_ptr(), filt[i].data_ptr(), W, H)], STRENGTH, BLEED, stream=stream)
         assert res[0]["status"] == 0 and res[0]["bpp"] == 4
+        engine_info.update(ctx.engine_info(0))
         return ctx.engine_ms, ctx.total_ms
 
     # PCIe legs, reported separately and never part of `value` (inputs are resident before the timed region)
@@ -282,6 +355,7 @@ def main():
 
     # ---- the image-batch leg (BASELINE.json configs[3]); outside the timed region of `value` ----
     batch = None
+    batch_sat = None
     if not args.no_batch:
         del work, filt
         torch.cuda.empty_cache()
@@ -296,6 +370,16 @@ def main():
             print(f"bench.py: batch record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
             allrecs, engs = brecs, [dict(index=rank, engine_ms=beng, frames=len(brecs))]
         batch = (float(tb.item()), allrecs, engs)
+        sdt, seng, srecs, sinfo = run_batch_saturating(P, S, torch, lambda: P.HipContext(local_rank), rank, world, barrier)
+        ts = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        try:
+            sall = S.gather_records([dict(index=rank, engine_ms=seng, recs=srecs, engine=sinfo)])
+        except Exception as exc:
+            print(f"bench.py: saturating batch record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
+            sall = [dict(index=rank, engine_ms=seng, recs=srecs, engine=sinfo)]
+        batch_sat = (float(ts.item()), sall)
 
     if rank == 0:
         golden = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -320,18 +404,20 @@ def main():
                                    "row_filters requested; device-resident in, device-resident out",
                        "images_per_gpu": 1, "parallelism": f"image-parallel x{world}, no data-path collective"},
             "bit_exact_vs_reference_digest": bool(bit_exact),
-            "roofline": {"bound": "hbm", "kernel": "pl_engine", "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "row engine: " + str(engine_info.get("engine")) + (" (seg_k_ctl, seg_k_enum, seg_k_chain, seg_k_replay, seg_k_post per row attempt)" if engine_info.get("engine") == "segment-parallel" else " (pl_engine)"),
+                         "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "engine_ms_per_launch": round(eng_ms, 3),
+                         "engine": engine_info,
+                         "engine_kernels": engine_kernels(),
                          "chain_bound": {"ns_per_pixel_step": round(eng_ms * 1e6 / px, 1),
-                                         "static_issue_slots_per_pixel_step": isa_facts(),
-                                         "note": "secondary, honest bound (SURVEY 8d): W*H pixel steps in series per image and "
-                                                 "candidate filter.  Band-leader chains: one dependent LDS table lookup (~100 "
-                                                 "cycles under load) plus the issue slots of profiles/r02_engine_isa.txt per step "
-                                                 "on the fast path; pixels whose table entry is unusable are redone exactly "
-                                                 "(DESIGN.md section 4)"},
-                         "note": "dominant kernel is bound by the serial per-pixel dependency chain (DESIGN.md), "
-                                 "not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB per launch; traffic = "
+                                         "us_per_row_attempt": round(eng_ms * 1e3 / max(1, engine_info.get("attempts", 0)), 2) if engine_info.get("engine") == "segment-parallel" else None,
+                                         "note": "secondary, honest bound (SURVEY 8d): the rows of an image are strictly serial (the winner of row y seeds "
+                                                 "row y+1), and so is a row's x-chain in the reference.  The segment-parallel engine cuts the x-chain into "
+                                                 "32-pixel segments (state enumeration + map composition + exact validation, DESIGN.md section 4), so what is "
+                                                 "left in series is H row attempts of five dependent kernels each"},
+                         "note": "bound by the row-to-row dependency chain (DESIGN.md), not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB "
+                                 "per engine run, measured with HIP events around the engine's launches on the launch stream; traffic = "
                                  "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
             "bandwidth_kernels": bandwidth_kernels(),
         }
@@ -366,6 +452,19 @@ def main():
                              "all_status_ok": all(r["status"] == 0 for r in brecs) and len(brecs) == BATCH_FRAMES,
                              "digests_match_reference": bool(checked) and all(r["out"] == want[r["index"]]["out"] and r["filters"] == want[r["index"]]["filters"] for r in checked),
                              "digests_checked_frames": [r["index"] for r in checked]}
+        if batch_sat is not None:
+            st, sall = batch_sat
+            want = {e["frame"]: e for e in golden["synthetic"] if (e["width"], e["height"]) == (BATCH_W, BATCH_H)}
+            chk = [r for e in sall for r in e["recs"]]
+            nfr = SAT_FRAMES_PER_RANK * world
+            line["batch_saturating"] = {"workload": f"{SAT_FRAMES_PER_RANK} synthetic {BATCH_W}x{BATCH_H} RGBA8 frames PER GPU ({nfr} in all), s={STRENGTH} b={BLEED}, "
+                                                    f"device-resident batches of 256; {SAT_DISTINCT} distinct frames cloned on the device",
+                                        "value": round(nfr * BATCH_W * BATCH_H / st / 1e6, 2), "unit": "Mpixels/s", "seconds": round(st, 4), "scaling": "weak",
+                                        "engine_ms_per_rank": [round(e["engine_ms"], 2) for e in sall],
+                                        "engine": sall[0].get("engine", {}).get("engine"),
+                                        "digests_match_reference": bool(chk) and all(r["ok"] and r["out"] == want[r["frame"]]["out"] and r["filters"] == want[r["frame"]]["filters"] for r in chk),
+                                        "note": "configs[3] (256 frames in all) leaves a GPU 256/N images = 256/N busy CUs, so it cannot speed up past N = 1; "
+                                                "this leg gives every GPU two full batches"}
         print(json.dumps(line), flush=True)
     ctx.close()
     if use_dist:

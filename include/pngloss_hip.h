@@ -211,6 +211,16 @@ double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx);
 /* Final 256-bin symbol histogram of image `index` of the last finished batch (host buffer of 256 uint32). */
 int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *hist256);
 
+/* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
+ *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
+ *            (batches).  Chosen per batch by pngloss_hip_optimize_batch_async; PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy pins it (test hook).
+ *   info[1]  row attempts (engine 3) / rows on the band-leader chains (engine 0)
+ *   info[2]  validation restarts (engine 3) / pixels redone exactly (engine 0)
+ *   info[3]  rows finished serially (engine 3) / rows on the round-1 chains by the adaptive choice (engine 0)
+ *   info[4]  rows in which candidate none was ruled out by its cost bound (engine 3)
+ * No reference equivalent. */
+int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8]);
+
 /* Library / device identification string (static storage). */
 const char *pngloss_hip_version(void);
 

@@ -8,6 +8,7 @@
 #include "../../include/pngloss_hip.h"
 #include "pl_device.h"
 #include "pl_deflate.h"
+#define SEG_PLAIN_POINTERS   /* host plumbing only: SegJob is filled here, never dereferenced */
 #include "pl_seg.h"
 
 #include <chrono>
@@ -221,7 +222,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         std::vector<uint32_t> widths(n);
         for (size_t i = 0; i < n; i++) { widths[i] = images[i].width; seg_max_nseg = std::max(seg_max_nseg, (images[i].width + SEG_L - 1) / SEG_L); }
         const bool forced = em && std::strcmp(em, "seg") == 0;
-        const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;
+        const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
         if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && (forced || n * (size_t)seg_max_nseg <= 2048))
             use_seg = pl_seg_supported(widths.data(), n, strength, bleed, &seg_params);
         if (forced && !use_seg && n)
@@ -336,6 +337,8 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
             if (std::getenv("PNGLOSS_HIP_SEGPROF"))
                 std::fprintf(stderr, "pngloss_hip:   validation kernel, slowest workgroup per phase (us): load %.1f  pass1 %.1f  watched bins + pass3 %.1f  none bound %.1f  sums %.1f; pending decisions %d, largest reach %d\n",
                              r[40] / 100.0, r[41] / 100.0, r[42] / 100.0, r[43] / 100.0, r[44] / 100.0, r[46], r[47]);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF"))
+                std::fprintf(stderr, "pngloss_hip:   control kernel, slowest (us): candidate workgroup up to the table build %.1f, table build %.1f, commit workgroup %.1f\n", r[56] / 100.0, r[57] / 100.0, r[58] / 100.0);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[53])
                 std::fprintf(stderr, "pngloss_hip:   ... average per workgroup (us): load %.2f  pass1 %.2f  watched bins + pass3 %.2f  none bound %.2f  sums %.2f  (%u workgroup runs)\n",
                              (uint32_t)r[48] / 100.0 / (uint32_t)r[53], (uint32_t)r[49] / 100.0 / (uint32_t)r[53], (uint32_t)r[50] / 100.0 / (uint32_t)r[53], (uint32_t)r[51] / 100.0 / (uint32_t)r[53],
@@ -842,6 +845,18 @@ int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *his
     if (!ctx || !hist256 || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     PL_CHECK(hipMemcpy(hist256, ctx->h_jobs[index].final_hist, sizeof(uint32_t) * PL_NSYM, hipMemcpyDeviceToHost));
+    return PNGLOSS_SUCCESS;
+}
+
+int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8])
+{
+    if (!ctx || !info || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
+    PL_CHECK(hipSetDevice(ctx->device));
+    int32_t r[64] = { 0 };
+    PL_CHECK(hipMemcpy(r, ctx->h_jobs[index].result, sizeof r, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) info[i] = 0;
+    if (r[20] == 3) { info[0] = 3; info[1] = r[5]; info[2] = r[4]; info[3] = r[6]; info[4] = r[7]; }
+    else { info[0] = 0; info[1] = r[5]; info[2] = r[4]; info[3] = r[21]; }
     return PNGLOSS_SUCCESS;
 }
 

@@ -87,13 +87,26 @@ inline int pls_wave_min_i(int v) { return v; }
 #define PLS_HOST_VISIBLE_STORE(p, v) (*(p) = (v))
 #endif
 
+/* Pointers with their address space named (device): shared memory -> ds_* instructions, device memory -> global_* instead of FLAT
+ * (a FLAT access counts in both wait counters, so every wait for an LDS result would also wait for outstanding global traffic, and
+ * LDS through FLAT is several times slower).  On the host they are plain pointers of the same size. */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SEG_PLAIN_POINTERS)   /* (a translation unit without kernels of this engine sets SEG_PLAIN_POINTERS) */
+#define SEG_AS_LDS __attribute__((address_space(3)))
+#define SEG_AS_GLB __attribute__((address_space(1)))
+#else
+#define SEG_AS_LDS
+#define SEG_AS_GLB
+#endif
+typedef SEG_AS_LDS uint32_t *seg_lds_u32;
+typedef SEG_AS_LDS uint8_t *seg_lds_u8;
+
 #define SEG_NFILT 5
 #define SEG_L 32                 /* pixels per segment */
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
 #define SEG_NSP 256              /* lanes per channel in the enumeration = most states supported */
 #define SEG_TOFF 320             /* decision tables cover v in [-320, 319] */
 #define SEG_TN 640
-#define SEG_TBL_WORDS (4 * SEG_TN + 64)   /* pre[2], suf[2], cls[256 bytes] */
+#define SEG_TBL_WORDS (4 * SEG_TN + 128)  /* pre[2], suf[2], cls[2][256 bytes] */
 #define SEG_INVALID 0xFFFFu
 #define SEG_NOFAIL 0xFFFFFFFFu
 #define SEG_MAX_RESTARTS 12      /* epochs per candidate and row before the rest of the row is done serially */
@@ -148,31 +161,31 @@ struct SegAcc {
 };
 
 struct SegJob {
-    uint32_t *img;            /* slots image (pl_device.h) */
-    uint8_t *row_filters;     /* or null */
-    uint8_t *row_ids;
+    SEG_AS_GLB uint32_t *img;            /* slots image (pl_device.h) */
+    SEG_AS_GLB uint8_t *row_filters;     /* or null */
+    SEG_AS_GLB uint8_t *row_ids;
     uint32_t W, H;
     uint32_t bpp;             /* resolved by the launcher kernel (seg_resolve) / the host harness */
-    const uint32_t *orig_rank;/* [5][256] */
-    uint32_t *cand;           /* [5][W][4]: byte | (diff16 & 0xffff) << 8 | bin << 24 */
-    uint32_t *err0, *err1;    /* [W][2]: 4 x int16 */
-    uint32_t *old_above;      /* [W] */
-    uint32_t *final_hist;     /* [256] */
-    int32_t *result;          /* [64] */
-    uint32_t *progress;       /* or null: host-visible word that receives the number of finished rows (-v display) */
-    uint32_t *done_counter;   /* or null: host-visible word, +1 when this image is finished (the host stops enqueueing attempts) */
-    uint32_t *attempt_word;   /* or null: host-visible word that receives the number of the attempt being started (launch throttle) */
-    SegCtl *ctl;              /* [2] */
-    uint32_t *base;           /* [2][5][256] bumps of the validated prefix [0, start_x) */
-    uint32_t *H0;             /* [2][256] committed histogram */
-    SegAcc *acc;              /* [2] */
-    uint32_t *tables;         /* [5][SEG_TBL_WORDS] */
-    uint16_t *maps;           /* [5][nseg][4][SEG_NSP] */
-    uint32_t *entry;          /* [5][nseg][4] */
-    uint16_t *segcnt;         /* [5][nseg][256] */
-    uint32_t *grpcnt;         /* [5][ngrp][256] */
-    uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
-    int32_t *rowmm;           /* [ncommit][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
+    const SEG_AS_GLB uint32_t *orig_rank;/* [5][256] */
+    SEG_AS_GLB uint32_t *cand;           /* [5][W][4]: byte | (diff16 & 0xffff) << 8 | bin << 24 */
+    SEG_AS_GLB uint32_t *err0, *err1;    /* [W][2]: 4 x int16 */
+    SEG_AS_GLB uint32_t *old_above;      /* [W] */
+    SEG_AS_GLB uint32_t *final_hist;     /* [256] */
+    SEG_AS_GLB int32_t *result;          /* [64] */
+    SEG_AS_GLB uint32_t *progress;       /* or null: host-visible word that receives the number of finished rows (-v display) */
+    SEG_AS_GLB uint32_t *done_counter;   /* or null: host-visible word, +1 when this image is finished (the host stops enqueueing attempts) */
+    SEG_AS_GLB uint32_t *attempt_word;   /* or null: host-visible word that receives the number of the attempt being started (launch throttle) */
+    SEG_AS_GLB SegCtl *ctl;              /* [2] */
+    SEG_AS_GLB uint32_t *base;           /* [2][5][256] bumps of the validated prefix [0, start_x) */
+    SEG_AS_GLB uint32_t *H0;             /* [2][256] committed histogram */
+    SEG_AS_GLB SegAcc *acc;              /* [2] */
+    SEG_AS_GLB uint32_t *tables;         /* [5][SEG_TBL_WORDS] */
+    SEG_AS_GLB uint16_t *maps;           /* [5][nseg][4][SEG_NSP] */
+    SEG_AS_GLB uint32_t *entry;          /* [5][nseg][4] */
+    SEG_AS_GLB uint16_t *segcnt;         /* [5][nseg][256] */
+    SEG_AS_GLB uint32_t *grpcnt;         /* [5][ngrp][256] */
+    SEG_AS_GLB uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
+    SEG_AS_GLB int32_t *rowmm;           /* [ncommit][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
     uint32_t nseg, ngrp;
 };
 
@@ -261,11 +274,12 @@ PLS_HD SegPix seg_pix_load(const uint32_t *row, const uint32_t *nab, const uint3
 
 /* strength geometry: s, q = s + 1 and (device) the float reciprocal that makes trunc(a / q) == (int)(a * rq) for |a| < 2^17
  * (exhaustively checked in tests/test_host_logic.py::test_float_reciprocal_division) */
-struct SegGeo { int s, q; float rq; };
+struct SegGeo { int s, q, fmax; float rq; };
 PLS_HD SegGeo seg_geo(int s)
 {
     SegGeo g; g.s = s; g.q = s + 1;
     union { float f; uint32_t u; } r; r.f = 1.0f / (float)(s + 1); r.u += 2u; g.rq = r.f;
+    g.fmax = ((SEG_TOFF - 1 - s) / (s + 1)) * (s + 1) + s;      /* largest |filt| whose band lies inside the tables */
     return g;
 }
 PLS_HD int seg_div_q(int a, const SegGeo &g)
@@ -387,34 +401,48 @@ template <int F> PLS_HD int seg_predict_t(int above, int diag, int left)
  * and the chain walk.  tw = the candidate's tables (pre[2] | suf[2] | cls) in shared memory, lut = the split table.
  * bad accumulates "this lane left what the tables cover" (band beyond +-SEG_TOFF, |diff| > 255): its results are void then and the
  * caller falls back (enumeration: the map entry is SEG_INVALID; replay / walk: seg_step_scan).  Returns the candidate word. */
-template <int F>
+/* 24-bit multiply (full rate on the device; the 32-bit v_mul_lo_u32 is quarter rate) */
+PLS_HD int seg_mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+template <int F, bool TRX>
 PLS_HD uint32_t seg_step_fast(const SegPix &p, SegState &st, int &bad, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
 {
+    /* TRX: the range holds a fully transparent pixel (optimize_state.c:158-164): only then the forced-alpha selects are compiled in.
+     * bad accumulates max(|filt| - fmax, |diff| - 255 ...) > 0 as a sign test: one max per quantity and step */
     const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
-    const bool tr = (p.w >> 24) != 0;
     const int pred = seg_predict_t<F>(above, diag, st.left);
     const int osym = seg_sext8(orig - pred), lo = osym - orig, hi = lo + 255;
     const int filt = osym + seg_sext16(p.e0 + st.cn);
     const int neg = filt < 0 ? 1 : 0;
     const int af = neg ? -filt : filt;
     const int t = seg_div_q(af, g);
-    const int bandlo = neg ? -(t * g.q) - g.s : t * g.q, bandhi = bandlo + g.s;
+    const int tq = seg_mul24(t, g.q);
+    const int bandlo = neg ? -tq - g.s : tq, bandhi = bandlo + g.s;
     const int v0 = seg_max(bandlo, lo), v1 = seg_min(bandhi, hi);
     const bool degen = v0 > v1;                                /* the whole band lies outside [lo, hi]: the clamp leaves lo or hi */
     const int vd = bandhi < lo ? lo : hi;
     const bool usesuf = v0 > bandlo;
     int key = usesuf ? v0 : v1;
-    bad |= (bandlo < -SEG_TOFF || bandhi >= SEG_TOFF) ? 1 : 0;
     key = seg_min(seg_max(key, -SEG_TOFF), SEG_TOFF - 1);
     const uint32_t e = tw[(usesuf ? 2 * SEG_TN : 0) + neg * SEG_TN + key + SEG_TOFF];
-    const uint32_t c_os = (uint32_t)cls[osym & 255];
+    const uint32_t c_os = (uint32_t)cls[neg * 256 + (osym & 255)];
     const int L = (int)(e & 0xffffu) - 512;
     const bool tie = osym >= v0 && osym <= v1 && c_os == ((e >> 16) & 255u);
     int v = tie ? osym : L;
     v = degen ? vd : v;
     int back = v - lo, diff = seg_sext16(filt - v), bin = v & 255;
-    back = tr ? 0 : back; diff = tr ? 0 : diff; bin = tr ? ((0 - pred) & 255) : bin;      /* optimize_state.c:158-164 */
-    bad |= (diff < -256 || diff > 255) ? 1 : 0;
+    if (TRX) {
+        const bool tr = (p.w >> 24) != 0;
+        back = tr ? 0 : back; diff = tr ? 0 : diff; bin = tr ? ((0 - pred) & 255) : bin;
+    }
+    const int ad = diff < 0 ? -diff : diff;
+    bad = seg_max(bad, seg_max(af - g.fmax, ad - 255));        /* > 0: outside what the tables cover */
     const uint32_t le = lut[(diff + 256) & 511];
     st.left = back; st.cn = seg_sext16((int)le) + st.th; st.th = (int)le >> 16;
     return seg_cand_pack(back, diff, bin);
@@ -534,25 +562,31 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 16 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
-#define SEG_SM_CTL (256 * 4 * 4 + 256 + 64 * 4 + 2 * SEG_TN * 4)
+#define SEG_SM_CTL (256 * 4 * 4 + SEG_TBL_WORDS * 4 + 64)
 
-/* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad */
-template <int F>
+/* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad > 0 when the lane left the tables */
+template <int F, bool TRX>
 PLS_HD int seg_run_fast(const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
 {
     int bad = 0;
-    for (int k = 0; k < n; k++) (void)seg_step_fast<F>(px[k * pstride], st, bad, tw, cls, g, lut);
-    return bad;
+    for (int k = 0; k < n; k++) (void)seg_step_fast<F, TRX>(px[k * pstride], st, bad, tw, cls, g, lut);
+    return bad > 0;
 }
-PLS_HD int seg_run_fast_f(int f, const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
+template <bool TRX>
+PLS_HD int seg_run_fast_t(int f, const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
 {
     switch (f) {
-    case 1: return seg_run_fast<1>(px, pstride, n, st, tw, cls, g, lut);
-    case 2: return seg_run_fast<2>(px, pstride, n, st, tw, cls, g, lut);
-    case 3: return seg_run_fast<3>(px, pstride, n, st, tw, cls, g, lut);
-    case 4: return seg_run_fast<4>(px, pstride, n, st, tw, cls, g, lut);
-    default: return seg_run_fast<0>(px, pstride, n, st, tw, cls, g, lut);
+    case 1: return seg_run_fast<1, TRX>(px, pstride, n, st, tw, cls, g, lut);
+    case 2: return seg_run_fast<2, TRX>(px, pstride, n, st, tw, cls, g, lut);
+    case 3: return seg_run_fast<3, TRX>(px, pstride, n, st, tw, cls, g, lut);
+    case 4: return seg_run_fast<4, TRX>(px, pstride, n, st, tw, cls, g, lut);
+    default: return seg_run_fast<0, TRX>(px, pstride, n, st, tw, cls, g, lut);
     }
+}
+/* trx: some pixel of the range is fully transparent (uniform over the workgroup) */
+PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
+{
+    return trx ? seg_run_fast_t<true>(f, px, pstride, n, st, tw, cls, g, lut) : seg_run_fast_t<false>(f, px, pstride, n, st, tw, cls, g, lut);
 }
 
 /* ---- ENUMERATE, filters that look at the left pixel: task (f, seg), SEG_THREADS lanes = 4 channels x SEG_NSP states -------- */
@@ -570,19 +604,26 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
+    uint32_t *trflag = lut + 512;                             /* some pixel of the segment is fully transparent */
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) *trflag = 0u; }
+    PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
         for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
         if (tid < 512) lut[tid] = P.lut_a[tid];
-        if (tid >= 512 && tid < 512 + SEG_L + 1) seg_pix_load4(px + (tid - 512) * 4, row, nab, j.err0, bpp, x0 - 1 + (uint32_t)(tid - 512), W);
+        if (tid >= 512 && tid < 512 + SEG_L + 1) {
+            seg_pix_load4(px + (tid - 512) * 4, row, nab, j.err0, bpp, x0 - 1 + (uint32_t)(tid - 512), W);
+            if ((bpp & 1u) == 0u && (px[(tid - 512) * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
+        }
     }
     PLS_SYNC();
+    const bool trx = *trflag != 0u;
     PLS_THREADS(tid, SEG_THREADS) {
         const int c = tid / SEG_NSP, i = tid % SEG_NSP;
         if ((uint32_t)c < bpp && i < P.ns) {
             SegState st;
             uint32_t out = SEG_INVALID;
             if (seg_state_decode(P, i, px[c], st)) {
-                const int bad = seg_run_fast_f(f, px + 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
                 if (!bad) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
             }
             j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
@@ -603,12 +644,19 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
+    uint32_t *trflag = (uint32_t *)(px + SEG_SMALL_SEGS * SEG_L * 4);
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) *trflag = 0u; }
+    PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
         for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
         if (tid < 512) lut[tid] = P.lut_a[tid];
-        if (tid < SEG_SMALL_SEGS * SEG_L) seg_pix_load4(px + tid * 4, row, nab, j.err0, bpp, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+        if (tid < SEG_SMALL_SEGS * SEG_L) {
+            seg_pix_load4(px + tid * 4, row, nab, j.err0, bpp, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+            if ((bpp & 1u) == 0u && (px[tid * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
+        }
     }
     PLS_SYNC();
+    const bool trx = *trflag != 0u;
     PLS_THREADS(tid, SEG_THREADS) {
         const int sl = tid / (4 * SEG_NSS), c = (tid / SEG_NSS) & 3, i = tid % SEG_NSS;
         const uint32_t seg = (uint32_t)seg0 + (uint32_t)sl, x0 = seg * SEG_L;
@@ -616,7 +664,7 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
             SegState st;
             uint32_t out = SEG_INVALID;
             if (seg_small_decode(P, i, st)) {
-                const int bad = seg_run_fast_f(f, px + (sl * SEG_L) * 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                const int bad = seg_run_fast_f(f, trx, px + (sl * SEG_L) * 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
                 if (!bad) out = seg_small_encode(P, st);
             }
             j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
@@ -645,16 +693,16 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
         uint32_t w;
         const SegPix &p = px[(size_t)(x - xa) * pstride];
         switch (f) {
-        case 1: w = seg_step_fast<1>(p, st, bad, tw, cls, G, lut); break;
-        case 2: w = seg_step_fast<2>(p, st, bad, tw, cls, G, lut); break;
-        case 3: w = seg_step_fast<3>(p, st, bad, tw, cls, G, lut); break;
-        case 4: w = seg_step_fast<4>(p, st, bad, tw, cls, G, lut); break;
-        default: w = seg_step_fast<0>(p, st, bad, tw, cls, G, lut); break;
+        case 1: w = seg_step_fast<1, true>(p, st, bad, tw, cls, G, lut); break;
+        case 2: w = seg_step_fast<2, true>(p, st, bad, tw, cls, G, lut); break;
+        case 3: w = seg_step_fast<3, true>(p, st, bad, tw, cls, G, lut); break;
+        case 4: w = seg_step_fast<4, true>(p, st, bad, tw, cls, G, lut); break;
+        default: w = seg_step_fast<0, true>(p, st, bad, tw, cls, G, lut); break;
         }
         if (out) out[(size_t)(x - xa) * 4] = w;
         if (cnt) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(w)], 1u);
     }
-    if (bad) {
+    if (bad > 0) {
         /* (rare) take the bumps back and do the range again by scanning */
         if (cnt && out) for (uint32_t x = xa; x < xe; x++) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(out[(size_t)(x - xa) * 4])], 0u - 1u);
         st = st0;
@@ -1309,53 +1357,68 @@ PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, 
 }
 
 /* decision tables of one candidate from a histogram (all threads of the workgroup; H, rank: 256 words each in shared memory;
- * out: SEG_TBL_WORDS words in global memory; scratch: 256 words) */
-PLS_HD void seg_build_tables(uint32_t *out, const uint32_t *H, const uint32_t *rank, uint32_t *scratch, int s, int q, int nt)
+ * out: SEG_TBL_WORDS words in global memory; stage: SEG_TBL_WORDS words of shared memory).  One lane per band, sign and direction
+ * scans its band once (prefix leaders upwards, suffix leaders downwards).
+ * Tie classes are band local: cls[sgn][b] = offset inside its band (of that sign) of the FIRST bin with the same (H, rank) as bin b,
+ * so two bins of one band have equal classes iff their keys are equal -- all the tie test of seg_step_fast needs (the original
+ * symbol and the leader it may replace always lie in the same band). */
+PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u32 rank, seg_lds_u32 scratch, seg_lds_u32 stage, int s, int q, int nt)
 {
-    /* cls[b] = number of bins strictly below b in (H, rank): equal class <=> equal key */
-    PLS_THREADS(tid, nt) { for (int b = tid; b < 256; b += nt) scratch[b] = 0u; }
-    PLS_SYNC();
+    (void)scratch;
+    seg_lds_u8 cls = (seg_lds_u8)(stage + 4 * SEG_TN);        /* [2][256] */
     PLS_THREADS(tid, nt) {
-        for (int i = tid; i < 256 * 4; i += nt) {
-            const int b = i & 255, part = i >> 8;
-            uint32_t n = 0;
-            for (int k = part * 64; k < part * 64 + 64; k++) n += (H[k] < H[b] || (H[k] == H[b] && rank[k] < rank[b])) ? 1u : 0u;
-            PLS_ATOMIC_ADD(&scratch[b], n);
+        for (int i = tid; i < 4 * SEG_TN; i += nt) stage[i] = 0u;
+        for (int i = tid; i < 512; i += nt) {
+            /* class of bin b in the band system of sign sgn: v = the value of the bin in that system */
+            const int sgn = i >> 8, b = i & 255;
+            const int v = sgn ? (b ? b - 256 : 0) : b;                    /* negative system: bins 1..255 are v = b - 256, bin 0 is v = 0 */
+            const int t = (sgn ? -v : v) / q;
+            const int blo = sgn ? -(t * q) - s : t * q;
+            const uint32_t hb = H[b], rb = rank[b];
+            int first = v - blo;
+            for (int u = blo; u < v; u++) if (H[u & 255] == hb && rank[u & 255] == rb) { first = u - blo; break; }
+            cls[i] = (uint8_t)first;
         }
     }
     PLS_SYNC();
-    /* classes are 0..255 but only equality matters: two bins with the same count of smaller keys have the same key */
     PLS_THREADS(tid, nt) {
-        for (int w = tid; w < 64; w += nt)
-            out[4 * SEG_TN + w] = (scratch[4 * w] & 255u) | ((scratch[4 * w + 1] & 255u) << 8) | ((scratch[4 * w + 2] & 255u) << 16) | ((scratch[4 * w + 3] & 255u) << 24);
-        /* one lane per band and direction */
         const int nb = SEG_TOFF / q + 1;                                   /* bands per sign that touch [-320, 319] */
         for (int i = tid; i < nb * 4; i += nt) {
             const int t = i >> 2, sgn = (i >> 1) & 1, dir = i & 1;
             const int blo = sgn ? -(t * q) - s : t * q, bhi = blo + s;
-            uint32_t *dst = out + (dir ? 2 * SEG_TN : 0) + sgn * SEG_TN;
+            seg_lds_u32 dst = stage + (dir ? 2 * SEG_TN : 0) + sgn * SEG_TN;
             int L = 0; uint32_t bh = 0, br = 0; bool have = false;
             if (!dir) {
                 for (int v = blo; v <= bhi; v++) {                         /* prefix leaders: lowest v among equals */
                     const uint32_t h = H[v & 255], r = rank[v & 255];
                     if (!have || h > bh || (h == bh && r > br)) { L = v; bh = h; br = r; have = true; }
-                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((scratch[L & 255] & 255u) << 16);
+                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((uint32_t)(L - blo) << 16);
                 }
             } else {
                 for (int v = bhi; v >= blo; v--) {                         /* suffix leaders: scanning down, equals replace */
                     const uint32_t h = H[v & 255], r = rank[v & 255];
                     if (!have || h > bh || (h == bh && r >= br)) { L = v; bh = h; br = r; have = true; }
-                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((scratch[L & 255] & 255u) << 16);
+                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((uint32_t)(L - blo) << 16);
                 }
             }
         }
     }
     PLS_SYNC();
+    /* the leader's class in an entry must be the class of ITS key: the first equal bin of the band, not the leader's own offset */
+    PLS_THREADS(tid, nt) {
+        for (int i = tid; i < 4 * SEG_TN; i += nt) {
+            const uint32_t e = stage[i];
+            if (e) { const int sgn = (i / SEG_TN) & 1, L = (int)(e & 0xffffu) - 512; stage[i] = (e & 0xffffu) | ((uint32_t)cls[sgn * 256 + (L & 255)] << 16); }
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, nt) { for (int i = tid; i < SEG_TBL_WORDS; i += nt) out[i] = stage[i]; }
+    PLS_SYNC();
 }
 
 /* histogram the coming attempt starts from, for the decisions that begin a row attempt afresh (not SEG_K_RESTART):
  * INIT: zero; RETRY / ABORT: the committed histogram; COMMIT: committed histogram + every bump of the winner's row */
-PLS_HD void seg_next_hist(const SegJob &j, const SegDecision &D, const SegCtl &cur, int prev, uint32_t *Hn, int nt)
+PLS_HD void seg_next_hist(const SegJob &j, const SegDecision &D, const SegCtl &cur, int prev, seg_lds_u32 Hn, int nt)
 {
     const uint32_t W = j.W, ngrp = j.ngrp;
     PLS_THREADS(tid, nt) {
@@ -1384,7 +1447,11 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     SegCtl &nxt = j.ctl[par];
     const SegAcc &A = j.acc[prev];
     const uint32_t W = j.W, H = j.H, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
-    uint32_t *Hn = (uint32_t *)smem, *rank = Hn + 256, *scratch = Hn + 512, *basen = Hn + 768;   /* 4 x 256 words */
+    seg_lds_u32 Hn = (seg_lds_u32)smem, rank = Hn + 256, scratch = Hn + 512, basen = Hn + 768;   /* 4 x 256 words */
+    seg_lds_u32 stage = Hn + 1024;                               /* SEG_TBL_WORDS: a candidate's tables before they go out; the commit workgroups keep the split table here */
+    const bool prof = (P.engine_flags & 1) != 0;
+    unsigned long long tc0 = 0;
+    if (prof) tc0 = PLS_CLOCK();
     const SegDecision D = seg_decide(j, P, attempt, cur, A);
     const uint32_t y = attempt ? cur.y : 0u;
     int s_next = attempt ? (int)cur.s : P.strength;
@@ -1441,7 +1508,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     if (bx > SEG_NFILT) {
         /* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x ---- */
         if (D.kind != SEG_K_COMMIT && D.kind != SEG_K_INIT) return;
-        int *mm = (int *)smem;                                            /* max, min of orig + incoming error over this workgroup's pixels of the COMING row */
+        SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                                            /* max, min of orig + incoming error over this workgroup's pixels of the COMING row */
         const uint32_t ynext = D.kind == SEG_K_COMMIT ? y + 1 : 0u;
         PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
         PLS_SYNC();
@@ -1467,6 +1534,9 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         }
         const uint32_t *cd = j.cand + (size_t)D.winner * W * 4;
         uint32_t *rowp = j.img + (size_t)y * W;
+        seg_lds_u32 lutb = stage;                                           /* [512] next-rows terms of the split */
+        PLS_THREADS(tid, SEG_THREADS) { if (tid < 512) lutb[tid] = P.lut_b[tid]; }
+        PLS_SYNC();
         const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
         PLS_THREADS(tid, SEG_THREADS) {
             const uint32_t x = (uint32_t)(bx - SEG_NFILT - 1) * SEG_THREADS + (uint32_t)tid;
@@ -1485,7 +1555,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                         for (int dx = -2; dx <= 2; dx++) {
                             const long sxp = (long)x + dx;
                             if (sxp < 0 || sxp >= (long)W) continue;
-                            const uint32_t e = seg_terms(P.lut_b, P.bleed, seg_cand_diff(cd[(size_t)sxp * 4 + ch]));
+                            const uint32_t e = seg_terms(lutb, P.bleed, seg_cand_diff(cd[(size_t)sxp * 4 + ch]));
                             const int T_ = (int)(int8_t)(e & 255u), F_ = (int)(int8_t)((e >> 8) & 255u), V_ = (int)(int8_t)((e >> 16) & 255u), H_ = (int)e >> 24;
                             const int ad = dx < 0 ? -dx : dx;
                             c1 += ad == 2 ? T_ : (ad == 1 ? F_ : V_);
@@ -1515,6 +1585,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         }
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * (bx - SEG_NFILT - 1)] = mm[0]; j.rowmm[2 * (bx - SEG_NFILT - 1) + 1] = mm[1]; } }
+        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) PLS_ATOMIC_MAX(&j.result[58], (int32_t)(PLS_CLOCK() - tc0)); } }
         return;
     }
 
@@ -1536,7 +1607,10 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         }
         PLS_SYNC();
         const int sn = s_next < 0 ? 0 : s_next;
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, sn, sn + 1, SEG_THREADS);
+        unsigned long long tc1 = 0;
+        if (prof) tc1 = PLS_CLOCK();
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS);
+        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const unsigned long long t2 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[56], (int32_t)(tc1 - tc0)); PLS_ATOMIC_MAX(&j.result[57], (int32_t)(t2 - tc1)); } } }
         return;
     }
     if (f == 0 && cur.active[0] == 2 && (D.start_none || D.keep_lazy)) {
@@ -1548,7 +1622,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             }
         }
         PLS_SYNC();
-        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, (int)cur.s, (int)cur.s + 1, SEG_THREADS);
+        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, (int)cur.s, (int)cur.s + 1, SEG_THREADS);
         return;
     }
     if (!failed) {
@@ -1612,7 +1686,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             }
         }
         PLS_SYNC();
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, G.s, G.q, SEG_THREADS);
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, G.s, G.q, SEG_THREADS);
     }
 }
 

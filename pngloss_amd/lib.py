@@ -91,7 +91,7 @@ ABI_SYMBOLS = (
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
     "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit",
     "pngloss_hip_optimize_batch_host_zlib", "pngloss_hip_zlib_bound", "pngloss_hip_last_deflate_ms", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
-    "pngloss_hip_last_histogram", "pngloss_hip_version",
+    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_version",
     "pngloss_hip_multi_create", "pngloss_hip_multi_destroy", "pngloss_hip_multi_count", "pngloss_hip_multi_split",
     "pngloss_hip_multi_optimize_batch_host",
 )
@@ -315,6 +315,14 @@ class HipContext:
     @property
     def total_ms(self):
         return self._lib.pngloss_hip_last_total_ms(self._ctx)
+
+    def engine_info(self, index=0):
+        """pngloss_hip_last_engine_info: dict(engine, attempts, restarts, serial_rows, none_dropped) for image `index`."""
+        a = (C.c_int32 * 8)()
+        self._lib.pngloss_hip_last_engine_info.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        self._lib.pngloss_hip_last_engine_info.restype = C.c_int
+        _check(self._lib.pngloss_hip_last_engine_info(self._ctx, index, a), "engine_info")
+        return dict(engine={3: "segment-parallel", 0: "workgroup-per-image"}.get(a[0], a[0]), attempts=a[1], restarts=a[2], serial_rows=a[3], none_dropped=a[4])
 
     def histogram(self, index=0):
         h = np.zeros(256, np.uint32)

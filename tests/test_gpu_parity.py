@@ -24,15 +24,13 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(params=["adaptive", "lead"])
+@pytest.fixture(params=["seg", "wg", "lead"])
 def engine_choice(request, monkeypatch):
-    """The shipped kernel picks, row by row, between the band-leader chains and the round-1 chains where the former are measurably
-    slow (dense slow pixels); "lead" pins the band-leader chains so that hostile inputs keep exercising THEM (the library reads the
-    variable on every call)."""
-    if request.param == "lead":
-        monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "lead")
-    else:
-        monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
+    """The library has two row engines and picks per batch: few large images -> the SEGMENT-PARALLEL engine (one image over the whole
+    GPU, pl_seg.hip), batches -> one workgroup per image (pl_engine.hip), which in turn picks, row by row, between its band-leader
+    chains and its round-1 chains.  The tests that care pin each: "seg" the segment engine, "wg" the workgroup engine with its own
+    adaptive choice, "lead" the workgroup engine with the band-leader chains pinned (the library reads the variable on every call)."""
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", request.param)
     return request.param
 
 
@@ -288,6 +286,65 @@ def test_strength_bleed_sweep_8192_matches_reference_digests(torch_cuda):
         assert "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS) == e["out"], (s, b)
         assert "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS) == e["filters"], (s, b)
         c.close()
+
+
+def test_segment_engine_is_the_default_for_single_images_and_reports_what_it_did(torch_cuda):
+    """No engine pinned: a single image of a strength/bleed the segment engine has lanes for goes through it (engine_info says so),
+    other strengths fall back to the workgroup engine; both exact."""
+    torch = torch_cuda
+    env_before = os.environ.pop("PNGLOSS_HIP_ENGINE", None)
+    try:
+        for (s, b, want) in [(19, 2, "segment-parallel"), (85, 2, "workgroup-per-image")]:
+            img = P.synth_rgba(1000, 70, 0, 4)
+            d = torch.from_numpy(img.copy()).cuda()
+            f = torch.zeros(70, dtype=torch.uint8, device="cuda")
+            ctx = P.HipContext()
+            res = ctx.run([(d.data_ptr(), f.data_ptr(), 1000, 70)], s, b, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            info = ctx.engine_info(0)
+            assert info["engine"] == want, info
+            if want == "segment-parallel":
+                assert info["attempts"] >= 70 and info["serial_rows"] == 0
+            o1, f1 = U.run_port(img, s, b)
+            assert res[0]["status"] == 0 and np.array_equal(d.cpu().numpy(), o1) and np.array_equal(f.cpu().numpy(), f1)
+            ctx.close()
+    finally:
+        if env_before is not None:
+            os.environ["PNGLOSS_HIP_ENGINE"] = env_before
+
+
+def test_segment_engine_batch_of_mixed_images(torch_cuda, monkeypatch):
+    """Several images of different sizes and classes in ONE segment-engine batch (blockIdx.y = image; images finish at different
+    attempts, incl. a 1x1 one that is done at once), rows that need the strength retry, NULL row_filters."""
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    specs = [(300, 40, 0), (1, 1, 1), (64, 48, 4), (700, 25, 5), (33, 77, 3), (129, 10, 2), (512, 16, 1)]
+    imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+    dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+    filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") if i != 3 else None for i, a in enumerate(imgs)]
+    ctx = P.HipContext()
+    res = ctx.run([(d.data_ptr(), f.data_ptr() if f is not None else 0, a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)], 19, 2,
+                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i, (a, d, f, r) in enumerate(zip(imgs, dev, filt, res)):
+        assert ctx.engine_info(i)["engine"] == "segment-parallel"
+        o1, f1 = U.run_port(a, 19, 2, filters=f is not None)
+        assert r["status"] == 0 and np.array_equal(d.cpu().numpy(), o1), (i, specs[i])
+        if f is not None:
+            assert np.array_equal(f.cpu().numpy(), f1), (i, specs[i])
+    ctx.close()
+
+
+def test_segment_engine_strengths_and_bleeds_with_few_and_many_states(monkeypatch):
+    """(strength, bleed) pairs from one chain state (s = 0) to the most the lanes hold; widths around the segment (32), group (512)
+    and commit-workgroup (1024) sizes; every byte-per-pixel class."""
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    for (w, h, m, s, b) in [(31, 9, 0, 19, 2), (32, 9, 1, 19, 2), (33, 9, 2, 19, 2), (511, 7, 3, 19, 2), (513, 7, 4, 19, 2), (1025, 6, 5, 19, 2),
+                            (200, 30, 0, 0, 2), (200, 30, 1, 3, 1), (200, 30, 5, 7, 3), (200, 30, 0, 20, 8), (200, 30, 2, 19, 4), (200, 30, 1, 19, 32767), (200, 30, 0, 30, 3)]:
+        img = P.synth_rgba(w, h, m, 2)
+        o1, f1 = U.run_port(img, s, b)
+        o2, f2 = P.optimize_with_rows(img, s, b)
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m, s, b)
 
 
 def test_round1_chains_still_match_the_oracle():
