@@ -339,6 +339,10 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
                              r[40] / 100.0, r[41] / 100.0, r[42] / 100.0, r[43] / 100.0, r[44] / 100.0, r[46], r[47]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF"))
                 std::fprintf(stderr, "pngloss_hip:   control kernel, slowest (us): candidate workgroup up to the table build %.1f, table build %.1f, commit workgroup %.1f\n", r[56] / 100.0, r[57] / 100.0, r[58] / 100.0);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[32])
+                std::fprintf(stderr, "pngloss_hip:   enumeration workgroups (us), slowest / average: load %.1f / %.2f  first %d steps + dedupe %.1f / %.2f  remaining steps %.1f / %.2f  map %.1f / %.2f; distinct states per channel after the dedupe %.1f; first-segment walker %.1f / %.2f\n",
+                             r[24] / 100.0, (uint32_t)r[28] / 100.0 / (uint32_t)r[32], SEG_K1, r[25] / 100.0, (uint32_t)r[29] / 100.0 / (uint32_t)r[32], r[26] / 100.0, (uint32_t)r[30] / 100.0 / (uint32_t)r[32],
+                             r[27] / 100.0, (uint32_t)r[31] / 100.0 / (uint32_t)r[32], (uint32_t)r[33] / 4.0 / (uint32_t)r[32], r[34] / 100.0, r[36] ? (uint32_t)r[35] / 100.0 / (uint32_t)r[36] : 0.0);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[53])
                 std::fprintf(stderr, "pngloss_hip:   ... average per workgroup (us): load %.2f  pass1 %.2f  watched bins + pass3 %.2f  none bound %.2f  sums %.2f  (%u workgroup runs)\n",
                              (uint32_t)r[48] / 100.0 / (uint32_t)r[53], (uint32_t)r[49] / 100.0 / (uint32_t)r[53], (uint32_t)r[50] / 100.0 / (uint32_t)r[53], (uint32_t)r[51] / 100.0 / (uint32_t)r[53],

@@ -54,6 +54,8 @@
 #define PLS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define PLS_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define PLS_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define PLS_ATOMIC_CAS(p, cmp, v) atomicCAS((p), (cmp), (v))
+#define PLS_ATOMIC_ADD_RET(p, v) atomicAdd((p), (v))
 #define PLS_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define PLS_CLOCK() wall_clock64()
 #define PLS_ATOMIC_MAX(p, v) atomicMax((p), (v))
@@ -72,6 +74,10 @@ __device__ __forceinline__ int pls_wave_min_i(int v) { for (int o = 32; o > 0; o
 #define PLS_ATOMIC_ADD(p, v) (*(p) += (v))
 #define PLS_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
 #define PLS_ATOMIC_OR(p, v) (*(p) |= (v))
+inline uint32_t pls_host_cas(uint32_t *p, uint32_t cmp, uint32_t v) { const uint32_t old = *p; if (old == cmp) *p = v; return old; }
+inline uint32_t pls_host_add_ret(uint32_t *p, uint32_t v) { const uint32_t old = *p; *p += v; return old; }
+#define PLS_ATOMIC_CAS(p, cmp, v) pls_host_cas((p), (cmp), (v))
+#define PLS_ATOMIC_ADD_RET(p, v) pls_host_add_ret((p), (v))
 #define PLS_ATOMIC_ADD64(p, v) (*(p) += (v))
 /* the CPU harness runs one "thread" at a time: every thread is its own wave */
 #define PLS_CLOCK() 0ull
@@ -101,7 +107,9 @@ typedef SEG_AS_LDS uint32_t *seg_lds_u32;
 typedef SEG_AS_LDS uint8_t *seg_lds_u8;
 
 #define SEG_NFILT 5
-#define SEG_L 32                 /* pixels per segment */
+#ifndef SEG_L
+#define SEG_L 32                 /* pixels per segment (16 was measured: enumeration -5 us, chain +5 us, no gain) */
+#endif
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
 #define SEG_NSP 256              /* lanes per channel in the enumeration = most states supported */
 #define SEG_TOFF 320             /* decision tables cover v in [-320, 319] */
@@ -113,10 +121,10 @@ typedef SEG_AS_LDS uint8_t *seg_lds_u8;
 #define SEG_MAX_NSEG 256              /* the chain kernel keeps a row's maps in shared memory: 256 x 512 B */
 #define SEG_THREADS 1024
 #define SEG_CHAIN_THREADS 1024
-#define SEG_REPLAY_THREADS 512       /* SEG_GRP * SEG_L: every thread loads one pixel of the group, 64 of them walk */
+#define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* every thread loads one pixel of the group, 64 of them walk */
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
-#define SEG_SMALL_SEGS 8           /* segments per enumeration workgroup for them */
+#define SEG_SMALL_SEGS 8           /* segments per enumeration workgroup for them: 8 segments x 4 channels x SEG_NSS lanes */
 #define SEG_KEYS_MAX 2048
 
 /* what a row attempt decided (seg_ctl_body) */
@@ -558,7 +566,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
  * ========================================================================================================================= */
 
 /* shared-memory budgets (bytes) */
-#define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64)
+#define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64 + 4 * 512 * 4 + 4 * 512 * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + SEG_THREADS * 2 + SEG_THREADS * 4 + 64)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 16 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
@@ -569,7 +577,12 @@ template <int F, bool TRX>
 PLS_HD int seg_run_fast(const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
 {
     int bad = 0;
-    for (int k = 0; k < n; k++) (void)seg_step_fast<F, TRX>(px[k * pstride], st, bad, tw, cls, g, lut);
+    SegPix p = px[0];
+    for (int k = 0; k < n; k++) {
+        const SegPix pn = px[(k + 1 < n ? k + 1 : k) * pstride];     /* the next record is on its way while this step runs */
+        (void)seg_step_fast<F, TRX>(p, st, bad, tw, cls, g, lut);
+        p = pn;
+    }
     return bad > 0;
 }
 template <bool TRX>
@@ -589,7 +602,13 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
     return trx ? seg_run_fast_t<true>(f, px, pstride, n, st, tw, cls, g, lut) : seg_run_fast_t<false>(f, px, pstride, n, st, tw, cls, g, lut);
 }
 
-/* ---- ENUMERATE, filters that look at the left pixel: task (f, seg), SEG_THREADS lanes = 4 channels x SEG_NSP states -------- */
+/* ---- ENUMERATE, filters that look at the left pixel: task (f, seg), SEG_THREADS lanes = 4 channels x SEG_NSP states --------
+ * Trajectories merge quickly (the carried error terms contract within a few pixels; what stays apart are the ~2s+1 possible left
+ * bytes): after SEG_K1 steps the lanes of a channel hold far fewer DISTINCT states than lanes.  They are deduplicated through a small
+ * hash table in shared memory (exact: full keys are compared), the distinct ones are packed into the first lanes of the channel and only
+ * those run the remaining steps -- whole waves fall idle -- then every lane picks up the result of its representative. */
+#define SEG_K1 4
+#define SEG_HT 512
 PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -597,15 +616,29 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     const uint32_t W = j.W, bpp = j.bpp;
     const uint32_t x0 = (uint32_t)seg * SEG_L;
     if (x0 + SEG_L >= W) return;                              /* the last segment has no successor */
-    if (x0 <= ctl.start_x[f]) return;                         /* the epoch's first (partial) segment is walked by the chain kernel */
+    if (ctl.start_x[f] && x0 <= ctl.start_x[f]) return;       /* an epoch that starts inside the row: its first (partial) segment is walked by
+                                                                 seg_first_body.  A fresh row starts from the known state in front of pixel 0,
+                                                                 which has an index like any other (boundary record = zeros): segment 0 is
+                                                                 enumerated with the rest */
     uint32_t *tw = (uint32_t *)smem;
     SegPix *px = (SegPix *)(smem + SEG_TBL_WORDS * 4);        /* [(SEG_L + 1)][4]: slot 0 = boundary pixel x0-1 */
     uint32_t *lut = (uint32_t *)(px + (SEG_L + 1) * 4);       /* the split table */
+    uint32_t *trflag = lut + 512;                             /* [0] some pixel of the segment is fully transparent, [1..4] distinct states per channel */
+    uint32_t *ht = trflag + 8;                                /* [4][SEG_HT] hash table: packed state or ~0 */
+    uint16_t *dense = (uint16_t *)(ht + 4 * SEG_HT);          /* [4][SEG_HT] slot -> rank among the distinct states */
+    uint32_t *uniq = (uint32_t *)(dense + 4 * SEG_HT);        /* [4][SEG_NSP] the distinct states, packed */
+    uint16_t *res = (uint16_t *)(uniq + 4 * SEG_NSP);         /* [4][SEG_NSP] exit index of each distinct state */
+    uint16_t *lslot = res + 4 * SEG_NSP;                      /* [SEG_THREADS] the hash slot of every lane's state (or 0xffff) */
     const uint32_t y = ctl.y;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
-    uint32_t *trflag = lut + 512;                             /* some pixel of the segment is fully transparent */
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) *trflag = 0u; }
+    const bool prof = (P.engine_flags & 1) != 0;
+    unsigned long long te[5] = { 0, 0, 0, 0, 0 };
+    if (prof) te[0] = PLS_CLOCK();
+    PLS_THREADS(tid, SEG_THREADS) {
+        if (tid < 8) trflag[tid] = 0u;
+        for (int i = tid; i < 4 * SEG_HT; i += SEG_THREADS) ht[i] = 0xffffffffu;
+    }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
         for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
@@ -616,17 +649,86 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
         }
     }
     PLS_SYNC();
-    const bool trx = *trflag != 0u;
+    const bool trx = trflag[0] != 0u;
+    if (prof) te[1] = PLS_CLOCK();
+    /* -- the first SEG_K1 steps from every state; neighbouring lanes mostly end in the same state, so only the first lane of a run of
+     *    equal keys ("head") goes to the hash table with an atomic, the others look their key up afterwards -- */
+    uint32_t *keys = (uint32_t *)(lslot + SEG_THREADS);       /* [SEG_THREADS] state key of every lane after SEG_K1 steps, ~0 = none */
+    PLS_THREADS(tid, SEG_THREADS) {
+        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
+        uint32_t key = 0xffffffffu;
+        if ((uint32_t)c < bpp && i < P.ns) {
+            SegState st;
+            if (seg_state_decode(P, i, px[c], st)) {
+                const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                if (!bad && st.cn >= -128 && st.cn <= 127) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16);
+            }
+        }
+        keys[tid] = key;
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
+        const uint32_t key = keys[tid];
+        if (key != 0xffffffffu && (i == 0 || keys[tid - 1] != key)) {
+            uint32_t h = (key * 0x9E3779B1u) >> 23;                            /* 9 bits */
+            for (int probe = 0; probe < SEG_HT; probe++) {
+                const uint32_t old = PLS_ATOMIC_CAS(&ht[c * SEG_HT + h], 0xffffffffu, key);
+                if (old == 0xffffffffu) {                                     /* the representative of a new state */
+                    const uint32_t d = PLS_ATOMIC_ADD_RET(&trflag[1 + c], 1u);
+                    dense[c * SEG_HT + h] = (uint16_t)d;
+                    uniq[c * SEG_NSP + d] = key;
+                    break;
+                }
+                if (old == key) break;
+                h = (h + 1) & (SEG_HT - 1);
+            }
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        const int c = tid / SEG_NSP;
+        const uint32_t key = keys[tid];
+        uint32_t slot = 0xffffu;
+        if (key != 0xffffffffu) {
+            uint32_t h = (key * 0x9E3779B1u) >> 23;
+            for (int probe = 0; probe < SEG_HT; probe++) {
+                if (ht[c * SEG_HT + h] == key) { slot = h; break; }
+                h = (h + 1) & (SEG_HT - 1);
+            }
+        }
+        lslot[tid] = (uint16_t)slot;
+    }
+    PLS_SYNC();
+    if (prof) te[2] = PLS_CLOCK();
+    /* -- the remaining steps, distinct states only (packed into the first lanes of each channel) -- */
+    PLS_THREADS(tid, SEG_THREADS) {
+        /* distinct state i of channel c runs on thread (i >> 6) * 256 + c * 64 + (i & 63): the first 64 of every channel are waves 0..3 of
+         * the workgroup, one per SIMD (waves 0, 4, 8, 12 would share one) */
+        const int c = (tid >> 6) & 3, i = (tid & 63) + 64 * (tid >> 8);
+        if ((uint32_t)c < bpp && (uint32_t)i < trflag[1 + c]) {
+            const uint32_t key = uniq[c * SEG_NSP + i];
+            SegState st;
+            st.left = (int)(key & 255u); st.cn = seg_sext8((int)(key >> 8)); st.th = seg_sext8((int)(key >> 16));
+            uint32_t out = SEG_INVALID;
+            const int bad = seg_run_fast_f(f, trx, px + (1 + SEG_K1) * 4 + c, 4, SEG_L - SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            if (!bad) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
+            res[c * SEG_NSP + i] = (uint16_t)out;
+        }
+    }
+    PLS_SYNC();
+    if (prof) te[3] = PLS_CLOCK();
     PLS_THREADS(tid, SEG_THREADS) {
         const int c = tid / SEG_NSP, i = tid % SEG_NSP;
         if ((uint32_t)c < bpp && i < P.ns) {
-            SegState st;
-            uint32_t out = SEG_INVALID;
-            if (seg_state_decode(P, i, px[c], st)) {
-                const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
-                if (!bad) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
-            }
-            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
+            const uint32_t slot = lslot[tid];
+            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = slot == 0xffffu ? (uint16_t)SEG_INVALID : res[c * SEG_NSP + dense[c * SEG_HT + slot]];
+        }
+        if (prof && tid == 0) {
+            te[4] = PLS_CLOCK();
+            for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
+            PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
+            PLS_ATOMIC_ADD((uint32_t *)&j.result[33], trflag[1] + trflag[2] + trflag[3] + trflag[4]);
         }
     }
 }
@@ -660,7 +762,7 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
     PLS_THREADS(tid, SEG_THREADS) {
         const int sl = tid / (4 * SEG_NSS), c = (tid / SEG_NSS) & 3, i = tid % SEG_NSS;
         const uint32_t seg = (uint32_t)seg0 + (uint32_t)sl, x0 = seg * SEG_L;
-        if (seg < j.nseg && x0 + SEG_L < W && x0 > ctl.start_x[f] && (uint32_t)c < bpp && i < P.ns_small) {
+        if (seg < j.nseg && x0 + SEG_L < W && (x0 > ctl.start_x[f] || ctl.start_x[f] == 0) && (uint32_t)c < bpp && i < P.ns_small) {
             SegState st;
             uint32_t out = SEG_INVALID;
             if (seg_small_decode(P, i, st)) {
@@ -722,13 +824,14 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
     if (ctl.finished || ctl.active[f] != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = ctl.start_x[f];
-    if (sx >= W) return;
+    if (sx >= W || sx == 0) return;                           /* a fresh row needs no walk: its segment 0 is enumerated */
     const uint32_t first = sx / SEG_L;
     if (first + 1 >= nseg) return;                            /* no segment behind it */
     uint32_t *tw = (uint32_t *)smem;
     uint32_t *lut = tw + SEG_TBL_WORDS;
     uint32_t *Hf = lut + 512, *rank = Hf + 256;
     SegPix *px = (SegPix *)(rank + 256);                      /* [SEG_L][4] */
+    const unsigned long long tf0 = (P.engine_flags & 1) ? PLS_CLOCK() : 0ull;
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
@@ -748,6 +851,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
             const uint32_t idx = seg_any_encode(P, f, px[(SEG_L - 1) * 4 + c], st);
             j.firstidx[(f * 4 + c) * 2] = idx;
             j.firstidx[(f * 4 + c) * 2 + 1] = seg_state_pack(st);
+            if ((P.engine_flags & 1) && tid == 0) { const unsigned long long t1 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[34], (int32_t)(t1 - tf0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[35], (uint32_t)(t1 - tf0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[36], 1u); }
         }
     }
 }
@@ -769,7 +873,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     if (first + 1 >= nseg) return;
     const bool small = seg_is_small(P, f);
     const int nmap = small ? SEG_NSS : SEG_NSP;               /* entries per map */
-    const uint32_t s0 = first + 1, ns = nseg - 1 - s0;        /* maps of segments s0 .. s0+ns-1; entries wanted for s0 .. nseg-1 */
+    const uint32_t s0 = sx ? first + 1 : 0u, ns = nseg - 1 - s0;   /* maps of segments s0 .. s0+ns-1; entries wanted for s0 .. nseg-1 (a fresh row: from 0) */
     const uint32_t nblk = (ns + SEG_CBLK - 1) / SEG_CBLK;
     uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512;
     SegPix *bpx = (SegPix *)(Hf + 1024);                      /* [nseg] boundary pixel sg*SEG_L - 1 of every segment */
@@ -783,7 +887,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         if (tid < 256) seg_load_frozen(j, par, f, Hf, rank, tid, 256);
         if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
-        for (uint32_t sg = s0 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c);
+        for (uint32_t sg = s0 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = sg ? seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c) : seg_pix_make(0, 0, 0, 0, 0);
         {
             /* the maps, 16 bytes per load (a map is nmap * 2 bytes, contiguous) */
             const int per = nmap / 8;                                   /* 16-byte pieces per map: 32 or 4 */
@@ -806,7 +910,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     PLS_SYNC();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         if (tid == 0) {
-            uint32_t idx = j.firstidx[(f * 4 + c) * 2];
+            const SegState start0 = { 0, 0, 0 };
+            const uint32_t idx_first = sx ? j.firstidx[(f * 4 + c) * 2] : seg_any_encode(P, f, bpx[0], start0);
+            uint32_t idx = idx_first;
             uint32_t slow = 0;
             for (uint32_t b = 0; b <= nblk; b++) {
                 idxb[b] = idx;
@@ -816,8 +922,8 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
             idxb[31] = slow;
             if (slow) {
                 /* (rare) some state or lookup on the path lies outside what the enumeration covers: the whole chain step by step */
-                idx = j.firstidx[(f * 4 + c) * 2];
-                SegState st = seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]);
+                idx = idx_first;
+                SegState st = sx ? seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]) : start0;
                 for (uint32_t sg = s0; sg < nseg; sg++) {
                     idxs[2 * sg] = idx;
                     if (idx == SEG_INVALID) idxs[2 * sg + 1] = seg_state_pack(st);
@@ -1085,7 +1191,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             na[tid] = (in && nab) ? nab[x] : 0u;
             oa[tid] = (in && y) ? j.old_above[x] : 0u;
         }
-        if (tid >= 512) {
+        if (tid >= 512 && tid - 512 < NPX) {
             const uint32_t x = xg0 + (uint32_t)(tid - 512);
             e0[2 * (tid - 512)] = x < W ? j.err0[2 * (size_t)x] : 0u;
             e0[2 * (tid - 512) + 1] = x < W ? j.err0[2 * (size_t)x + 1] : 0u;
@@ -1494,7 +1600,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 40; i++) j.result[i] = 0;
+                    for (int i = 0; i < 24; i++) j.result[i] = 0;
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
                     j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
                     if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
