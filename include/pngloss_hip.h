@@ -211,6 +211,29 @@ double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx);
 /* Final 256-bin symbol histogram of image `index` of the last finished batch (host buffer of 256 uint32). */
 int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *hist256);
 
+/* ---- PNG read side behind the inflate.  Replaces what libpng does for rwpng_read_image24_libpng
+ * (/root/reference/src/rwpng.c:179-400) between "inflated IDAT bytes" and "RGBA8 rows": the inverse scanline filters (a recurrence over
+ * x and y, run as a row wavefront on the device) and the transformations that reader registers -- palette / low bit depths / tRNS
+ * expanded, 16-bit samples stripped to their high byte, gray to RGB, alpha 255 filled in (rwpng.c:239-258).  The caller parses the
+ * chunks and inflates IDAT (zlib; pngloss_amd/cli/png_stream_reader.c does, on host threads) and passes
+ *   scanlines     height * (1 + rowbytes) inflated bytes of a NON-INTERLACED image, filter type byte first in every row
+ *   color_type, bit_depth   as in IHDR;  palette / palette_entries   the PLTE payload (RGB triples);  trns / trns_bytes   the tRNS payload
+ *   rgba          out: width * height * 4 bytes, exactly what rwpng_read_image24 returns in rgba_data
+ * Returns PNGLOSS_SUCCESS, PNGLOSS_INVALID_ARGUMENT (not a PNG format) or 25 (LIBPNG_FATAL_ERROR, rwpng.h:33: a filter type beyond 4).
+ * Interlaced files are not taken (Adam7 passes have their own geometry): the tool reads those with libpng. */
+typedef struct {
+    const unsigned char *scanlines;
+    uint32_t width, height;
+    uint8_t color_type, bit_depth;
+    const unsigned char *palette;
+    uint32_t palette_entries;
+    const unsigned char *trns;
+    uint32_t trns_bytes;
+    unsigned char *rgba;
+} pngloss_hip_png_source;
+
+int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n);
+
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
  *            (batches).  Chosen per batch by pngloss_hip_optimize_batch_async; PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy pins it (test hook).

@@ -8,6 +8,7 @@
 #include "../../include/pngloss_hip.h"
 #include "pl_device.h"
 #include "pl_deflate.h"
+#include "pl_pngread.h"
 #define SEG_PLAIN_POINTERS   /* host plumbing only: SegJob is filled here, never dereferenced */
 #include "pl_seg.h"
 
@@ -849,6 +850,49 @@ int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *his
     if (!ctx || !hist256 || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     PL_CHECK(hipMemcpy(hist256, ctx->h_jobs[index].final_hist, sizeof(uint32_t) * PL_NSYM, hipMemcpyDeviceToHost));
+    return PNGLOSS_SUCCESS;
+}
+
+int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n)
+{
+    if (!ctx || (!src && n)) return PNGLOSS_INVALID_ARGUMENT;
+    if (!n) return PNGLOSS_SUCCESS;
+    PL_CHECK(hipSetDevice(ctx->device));
+    std::vector<PrJob> jobs(n);
+    std::vector<size_t> raw_off(n), out_off(n), last_off(n);
+    size_t total = align_up(sizeof(PrJob) * n, 256) + align_up(sizeof(int32_t) * n, 256);
+    const size_t jobs_bytes = align_up(sizeof(PrJob) * n, 256);
+    for (size_t i = 0; i < n; i++) {
+        if (!src[i].scanlines || !src[i].rgba) return PNGLOSS_INVALID_ARGUMENT;
+        if (!pr_format(jobs[i].F, src[i].width, src[i].height, src[i].color_type, src[i].bit_depth, src[i].palette, src[i].palette_entries, src[i].trns, src[i].trns_bytes)) {
+            std::fprintf(stderr, "pngloss_hip: image %zu: colour type %d with bit depth %d (or an empty image / a palette image without PLTE) is not a PNG format\n", i, src[i].color_type, src[i].bit_depth);
+            return PNGLOSS_INVALID_ARGUMENT;
+        }
+        raw_off[i] = total; total += align_up(((size_t)jobs[i].F.rowbytes + 1) * src[i].height, 256);
+        out_off[i] = total; total += align_up((size_t)src[i].width * src[i].height * 4, 256);
+        last_off[i] = total; total += align_up(jobs[i].F.rowbytes, 256);
+    }
+    int rc = ensure_ws(ctx, total);
+    if (rc) return rc;
+    char *b = ctx->d_ws;
+    int32_t *d_status = reinterpret_cast<int32_t *>(b + jobs_bytes);
+    PL_CHECK(hipMemsetAsync(d_status, 0, sizeof(int32_t) * n, nullptr));
+    for (size_t i = 0; i < n; i++) {
+        jobs[i].raw = reinterpret_cast<const uint8_t *>(b + raw_off[i]);
+        jobs[i].rgba = reinterpret_cast<uint32_t *>(b + out_off[i]);
+        jobs[i].lastrow = reinterpret_cast<uint8_t *>(b + last_off[i]);
+        jobs[i].status = d_status + i;
+        PL_CHECK(hipMemcpyAsync(b + raw_off[i], src[i].scanlines, ((size_t)jobs[i].F.rowbytes + 1) * src[i].height, hipMemcpyHostToDevice, nullptr));
+    }
+    PL_CHECK(hipMemcpyAsync(b, jobs.data(), sizeof(PrJob) * n, hipMemcpyHostToDevice, nullptr));
+    PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, nullptr));
+    std::vector<int32_t> st(n);
+    for (size_t i = 0; i < n; i++)
+        PL_CHECK(hipMemcpyAsync(src[i].rgba, b + out_off[i], (size_t)src[i].width * src[i].height * 4, hipMemcpyDeviceToHost, nullptr));
+    PL_CHECK(hipMemcpyAsync(st.data(), d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, nullptr));
+    PL_CHECK(hipStreamSynchronize(nullptr));
+    for (size_t i = 0; i < n; i++)
+        if (st[i]) { std::fprintf(stderr, "pngloss_hip: image %zu: a scanline has a filter type beyond 4 (corrupt stream)\n", i); return 25; }
     return PNGLOSS_SUCCESS;
 }
 

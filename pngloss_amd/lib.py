@@ -47,6 +47,38 @@ class ZStream(C.Structure):
                 ("blocks", C.c_uint32 * 3), ("flags", C.c_uint32)]
 
 
+class PngSource(C.Structure):
+    _fields_ = [("scanlines", C.c_char_p), ("width", C.c_uint32), ("height", C.c_uint32), ("color_type", C.c_uint8), ("bit_depth", C.c_uint8),
+                ("palette", C.c_char_p), ("palette_entries", C.c_uint32), ("trns", C.c_char_p), ("trns_bytes", C.c_uint32), ("rgba", C.c_void_p)]
+
+
+def parse_png(data):
+    """Chunk walk + inflate of a PNG file (what pngloss_amd/cli/png_stream_reader.c does in C with zlib): dict(width, height, depth, ctype,
+    interlace, plte, trns, scanlines).  Host work by design: the inflate is a serial bit stream."""
+    import struct
+    import zlib
+    data = bytes(data)
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG file")
+    o, out, idat = 8, dict(plte=None, trns=None), []
+    while o + 8 <= len(data):
+        n, tag = struct.unpack(">I4s", data[o:o + 8])
+        body = data[o + 8:o + 8 + n]
+        o += 12 + n
+        if tag == b"IHDR":
+            out["width"], out["height"], out["depth"], out["ctype"], _, _, out["interlace"] = struct.unpack(">IIBBBBB", body)
+        elif tag == b"PLTE":
+            out["plte"] = body
+        elif tag == b"tRNS":
+            out["trns"] = body
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+    out["scanlines"] = zlib.decompress(b"".join(idat))
+    return out
+
+
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("bytes_per_pixel", C.c_uint32), ("unique_symbols", C.c_uint32),
                 ("retried_rows", C.c_uint32), ("repaired_pixels", C.c_uint32)]
@@ -91,7 +123,7 @@ ABI_SYMBOLS = (
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
     "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit",
     "pngloss_hip_optimize_batch_host_zlib", "pngloss_hip_zlib_bound", "pngloss_hip_last_deflate_ms", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
-    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_version",
+    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_png_decode_batch_host", "pngloss_hip_version",
     "pngloss_hip_multi_create", "pngloss_hip_multi_destroy", "pngloss_hip_multi_count", "pngloss_hip_multi_split",
     "pngloss_hip_multi_optimize_batch_host",
 )
@@ -315,6 +347,22 @@ class HipContext:
     @property
     def total_ms(self):
         return self._lib.pngloss_hip_last_total_ms(self._ctx)
+
+    def png_decode(self, files):
+        """pngloss_hip_png_decode_batch_host on a list of PNG file contents (bytes): chunk parsing and inflate on the host (parse_png), the
+        inverse filters and the expansion to RGBA8 on the device.  Returns a list of (H, W, 4) uint8 arrays."""
+        parsed = [parse_png(f) for f in files]
+        outs = [np.zeros((p["height"], p["width"], 4), np.uint8) for p in parsed]
+        src = (PngSource * max(1, len(parsed)))()
+        for i, (p, o) in enumerate(zip(parsed, outs)):
+            if p["interlace"]:
+                raise ValueError("interlaced PNG files are read with libpng, not on the device")
+            src[i] = PngSource(p["scanlines"], p["width"], p["height"], p["ctype"], p["depth"], p["plte"], len(p["plte"]) // 3 if p["plte"] else 0,
+                               p["trns"], len(p["trns"]) if p["trns"] else 0, o.ctypes.data)
+        self._lib.pngloss_hip_png_decode_batch_host.argtypes = [C.c_void_p, C.POINTER(PngSource), C.c_size_t]
+        self._lib.pngloss_hip_png_decode_batch_host.restype = C.c_int
+        _check(self._lib.pngloss_hip_png_decode_batch_host(self._ctx, src, len(parsed)), "png_decode")
+        return outs
 
     def engine_info(self, index=0):
         """pngloss_hip_last_engine_info: dict(engine, attempts, restarts, serial_rows, none_dropped) for image `index`."""

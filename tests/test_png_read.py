@@ -1,0 +1,64 @@
+"""PNG READ side: inflated IDAT bytes -> RGBA8.  Expected outputs come from the REAL reference reader
+(rwpng_read_image24, /root/reference/src/rwpng.c:422, through oracle/_ref/librwpng_ref.so in the build container,
+tests/golden/make_png_read_golden.py): every colour type x bit depth PNG allows, with and without tRNS, random filter types per row,
+plus the reference's eleven suite files.
+  not gpu: the pixel arithmetic shared with the kernel (pl_pngread_core.h) on the CPU
+  gpu:     the device reader through the C ABI (pngloss_hip_png_decode_batch_host), one batch of all 78 files"""
+import numpy as np
+import pytest
+
+import pngloss_amd as P
+from pngloss_amd import lib as L
+from tests import util as U
+
+
+def test_pixel_arithmetic_matches_the_reference_reader():
+    lib = U.pngread_host_lib()
+    n = 0
+    for name, png, want in U.png_read_fixtures():
+        p = L.parse_png(png)
+        assert not p["interlace"]
+        out = np.zeros((p["height"], p["width"], 4), np.uint8)
+        rc = lib.pngread_host_decode(p["scanlines"], p["width"], p["height"], p["ctype"], p["depth"], p["plte"], len(p["plte"]) // 3 if p["plte"] else 0,
+                                     p["trns"], len(p["trns"]) if p["trns"] else 0, out.ctypes.data)
+        assert rc == 0 and np.array_equal(out, want), name
+        n += 1
+    assert n == 78
+
+
+def test_fixture_set_covers_every_png_format():
+    names = [n for n, _, _ in U.png_read_fixtures()]
+    for ctype, depths in [(0, [1, 2, 4, 8, 16]), (2, [8, 16]), (3, [1, 2, 4, 8]), (4, [8, 16]), (6, [8, 16])]:
+        for d in depths:
+            assert any(n.startswith("t%d_d%d_plain" % (ctype, d)) for n in names)
+            if ctype in (0, 2, 3):
+                assert any(n.startswith("t%d_d%d_trns" % (ctype, d)) for n in names)
+
+
+@pytest.mark.gpu
+def test_device_reader_matches_the_reference_reader():
+    fx = U.png_read_fixtures()
+    ctx = P.HipContext()
+    outs = ctx.png_decode([png for _, png, _ in fx])
+    for (name, _, want), out in zip(fx, outs):
+        assert np.array_equal(out, want), (name, np.argwhere((out != want).any(axis=2))[:3].tolist())
+    # one at a time too (band / block bookkeeping must not depend on the batch)
+    for name, png, want in fx[::9]:
+        assert np.array_equal(ctx.png_decode([png])[0], want), name
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_reader_rejects_what_is_not_png():
+    ctx = P.HipContext()
+    good = [f for f in U.png_read_fixtures() if f[0].startswith("t6_d8_plain_37x19")][0][1]
+    p = L.parse_png(good)
+    bad_rows = bytearray(p["scanlines"]); bad_rows[0] = 7                       # filter type 7
+    out = np.zeros((p["height"], p["width"], 4), np.uint8)
+    src = (L.PngSource * 1)(L.PngSource(bytes(bad_rows), p["width"], p["height"], p["ctype"], p["depth"], None, 0, None, 0, out.ctypes.data))
+    lib = P.hip_lib()
+    lib.pngloss_hip_png_decode_batch_host.restype = __import__("ctypes").c_int
+    assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 25
+    src[0] = L.PngSource(p["scanlines"], p["width"], p["height"], 2, 4, None, 0, None, 0, out.ctypes.data)   # RGB with 4 bits: no such format
+    assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 4
+    ctx.close()

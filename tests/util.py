@@ -246,3 +246,30 @@ def run_seg_host(img, s=19, b=2, filters=True):
     st = np.zeros(8, np.uint32)
     rc = seg_host_lib().seg_host_optimize(out.ctypes.data, w, h, f.ctypes.data if filters else None, s, b, st.ctypes.data)
     return rc, out, (f if filters else None), st
+
+
+_prh = None
+
+
+def pngread_host_lib():
+    """tests/c/pngread_host.cpp (the pixel arithmetic of the device PNG reader, pl_pngread_core.h, on the CPU) as a shared object."""
+    global _prh
+    if _prh is None:
+        import subprocess
+        import tempfile
+        so = os.path.join(tempfile.mkdtemp(prefix="pngread_host_"), "libpngread_host.so")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", so, os.path.join(ROOT, "tests", "c", "pngread_host.cpp")], check=True)
+        lib = C.CDLL(so)
+        lib.pngread_host_decode.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_void_p]
+        lib.pngread_host_decode.restype = C.c_int
+        _prh = lib
+    return _prh
+
+
+def png_read_fixtures():
+    """(name, png bytes, expected RGBA8 of the REAL reference reader): tests/golden/png_read_cases.npz + the suite files."""
+    g = load_npz("png_read_cases.npz")
+    out = [(k[:-4], g[k].tobytes(), g[k[:-4] + "/rgba"]) for k in g.files if k.endswith("/png")]
+    s, inp = load_npz("suite_png.npz"), load_npz("suite_inputs.npz")
+    out += [("suite_" + k, s[k].tobytes(), inp[k]) for k in s.files]
+    return out
