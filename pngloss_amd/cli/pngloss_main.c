@@ -17,6 +17,7 @@
  */
 #include <getopt.h>
 #include <pthread.h>
+#include "png_stream_reader.h"
 #include <stdarg.h>
 #include <stdbool.h>
 #include <stdio.h>
@@ -40,6 +41,7 @@ struct options {
     unsigned num_files;
     bool from_stdin, to_stdout, force, skip_if_larger, strip, help, version, missing, verbose;
     bool gpu_deflate;          /* --gpu-deflate: IDAT data compressed on the device instead of by zlib level 9 */
+    bool gpu_read;             /* --gpu-read: inverse filters + expansion to RGBA8 on the device (inflate stays zlib on the decode threads) */
 };
 
 static const char usage_text[] =
@@ -58,6 +60,8 @@ static const char usage_text[] =
     "  --strip           remove optional metadata (default on Mac)\n"
     "  --gpu-deflate     compress the image data on the GPU too (not zlib's bytes, same pixels,\n"
     "                    files several percent smaller than with zlib level 9, much faster)\n"
+    "  --gpu-read        undo the PNG scanline filters and expand to RGBA on the GPU (plain,\n"
+    "                    non-interlaced files; the others are read with libpng as usual)\n"
     "\n"
     "Lossily compresses PNGs by using more compressible colors that are close enough to the\n"
     "original values; the filter+quantise pass runs on the GPU (all files of a call as one batch).\n"
@@ -66,7 +70,7 @@ static const char usage_text[] =
 
 /* ------------------------------------------------------------------------------------------- options */
 
-enum { OPT_EXT = 256, OPT_NO_FORCE, OPT_SKIP_LARGER, OPT_STRIP, OPT_GPU_DEFLATE };
+enum { OPT_EXT = 256, OPT_NO_FORCE, OPT_SKIP_LARGER, OPT_STRIP, OPT_GPU_DEFLATE, OPT_GPU_READ };
 
 static bool parse_number(const char *text, unsigned long *out)
 {
@@ -87,6 +91,7 @@ static pngloss_error parse_options(int argc, char **argv, struct options *o)
         { "skip-if-larger", no_argument, NULL, OPT_SKIP_LARGER }, { "strip", no_argument, NULL, OPT_STRIP },
         { "version", no_argument, NULL, 'V' },        { "help", no_argument, NULL, 'h' },
         { "gpu-deflate", no_argument, NULL, OPT_GPU_DEFLATE },
+        { "gpu-read", no_argument, NULL, OPT_GPU_READ },
         { NULL, 0, NULL, 0 },
     };
     for (int c; (c = getopt_long(argc, argv, "vqfo:Vhs:b:", table, NULL)) != -1;) {
@@ -99,6 +104,7 @@ static pngloss_error parse_options(int argc, char **argv, struct options *o)
         case OPT_SKIP_LARGER: o->skip_if_larger = true; break;
         case OPT_STRIP: o->strip = true; break;
         case OPT_GPU_DEFLATE: o->gpu_deflate = true; break;
+        case OPT_GPU_READ: o->gpu_read = true; break;
         case 'h': o->help = true; break;
         case 'V': o->version = true; break;
         case 'o':
@@ -151,6 +157,7 @@ struct job {
     char *log;                /* buffered stderr text */
     size_t log_len;
     pngloss_hip_result gpu;
+    png_stream_source src;    /* --gpu-read: inflated scanlines waiting for the device (src.scanlines != NULL) */
 };
 
 static void say(struct job *j, const char *fmt, ...)
@@ -201,24 +208,10 @@ static bool exists(const char *path)
     return f != NULL;
 }
 
-/* stage 1: open + decode + private output copy (pngloss.c:433-484 of the reference) */
-static void decode_job(struct job *j, const struct options *o)
+/* the private output copy of a decoded image (pngloss.c:471-484 of the reference) */
+static void finish_decode(struct job *j, const struct options *o)
 {
     if (j->status != SUCCESS) return;
-    if (o->verbose) say(j, "%s:\n", j->in_name);
-    FILE *f = o->from_stdin ? stdin : fopen(j->in_name, "rb");
-    if (!f) {
-        say(j, "  error: cannot open %s for reading\n", j->in_name);
-        j->status = READ_ERROR;
-        return;
-    }
-    pngloss_error rc = rwpng_read_image24(f, &j->in, o->strip, o->verbose);
-    if (!o->from_stdin) fclose(f);
-    if (rc != SUCCESS) {
-        say(j, "  error: cannot decode image %s\n", o->from_stdin ? "from stdin" : leaf(j->in_name));
-        j->status = rc;
-        return;
-    }
     if (o->verbose) {
         say(j, "  read %luKB file\n", (unsigned long)((j->in.file_size + 500UL) / 1000UL));
         if (j->in.input_color == RWPNG_SRGB) say(j, "  passing sRGB tag from the input\n");
@@ -240,6 +233,55 @@ static void decode_job(struct job *j, const struct options *o)
         j->out.row_pointers[y] = j->out.rgba_data + y * W * 4;
         memcpy(j->out.row_pointers[y], j->in.row_pointers[y], W * 4);
     }
+}
+
+/* --gpu-read, host half: chunk walk + inflate (png_stream_reader.c); the image header fields the libpng path would have set
+ * (rwpng.c:260-277: sRGB tag, else gAMA inside (0, 1], else the default) and the RGBA buffer the device will fill */
+static bool decode_job_stream(struct job *j)
+{
+    if (!png_stream_read(j->in_name, &j->src)) return false;
+    png24_image *im = &j->in;
+    im->width = j->src.width; im->height = j->src.height; im->file_size = j->src.file_size;
+    double gamma = 0.45455;
+    if (j->src.has_srgb) im->input_color = im->output_color = RWPNG_SRGB;
+    else {
+        if (j->src.has_gama) gamma = j->src.gamma;
+        if (gamma > 0 && gamma <= 1.0) im->input_color = im->output_color = RWPNG_GAMA_ONLY;
+        else {
+            say(j, "pngloss readpng:  ignored out-of-range gamma %f\n", gamma);
+            im->input_color = im->output_color = RWPNG_NONE;
+            gamma = 0.45455;
+        }
+    }
+    im->gamma = gamma;
+    const size_t W = im->width, H = im->height;
+    im->rgba_data = malloc(W * H * 4);
+    im->row_pointers = malloc(H * sizeof(unsigned char *));
+    if (!im->rgba_data || !im->row_pointers) { free(j->src.scanlines); j->src.scanlines = NULL; j->status = OUT_OF_MEMORY_ERROR; return true; }
+    for (size_t y = 0; y < H; y++) im->row_pointers[y] = im->rgba_data + y * W * 4;
+    return true;
+}
+
+/* stage 1: open + decode + private output copy (pngloss.c:433-484 of the reference) */
+static void decode_job(struct job *j, const struct options *o)
+{
+    if (j->status != SUCCESS) return;
+    if (o->verbose) say(j, "%s:\n", j->in_name);
+    if (o->gpu_read && !o->from_stdin && decode_job_stream(j)) return;       /* pixels follow from the device (decode_window_on_device) */
+    FILE *f = o->from_stdin ? stdin : fopen(j->in_name, "rb");
+    if (!f) {
+        say(j, "  error: cannot open %s for reading\n", j->in_name);
+        j->status = READ_ERROR;
+        return;
+    }
+    pngloss_error rc = rwpng_read_image24(f, &j->in, o->strip, o->verbose);
+    if (!o->from_stdin) fclose(f);
+    if (rc != SUCCESS) {
+        say(j, "  error: cannot decode image %s\n", o->from_stdin ? "from stdin" : leaf(j->in_name));
+        j->status = rc;
+        return;
+    }
+    finish_decode(j, o);
 }
 
 /* stage 3: encode to "<out>.tmp", rename over the destination (pngloss.c:379-431 of the reference) */
@@ -360,11 +402,45 @@ static size_t window_files(void)
 /* stage 1 of a window, possibly running in the background while the previous window is on the GPU */
 struct decode_ahead { struct job *jobs; size_t n; const struct options *o; pthread_t thread; bool running; double seconds; };
 
+/* --gpu-read, device half: every file of the window whose scanlines were inflated, as ONE batch (its own context: the optimiser's
+ * contexts may be busy with the previous window) */
+static pngloss_hip_ctx *g_read_ctx = NULL;
+static void decode_window_on_device(struct job *jobs, size_t n, const struct options *o)
+{
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) if (jobs[i].src.scanlines && jobs[i].status == SUCCESS) m++;
+    if (m) {
+        pngloss_hip_png_source *src = calloc(m, sizeof *src);
+        size_t *who = calloc(m, sizeof *who);
+        int rc = src && who ? PNGLOSS_SUCCESS : PNGLOSS_OUT_OF_MEMORY_ERROR;
+        if (rc == PNGLOSS_SUCCESS && !g_read_ctx) { g_read_ctx = pngloss_hip_create(-1); if (!g_read_ctx) rc = PNGLOSS_HIP_ERROR; }
+        size_t k = 0;
+        for (size_t i = 0; i < n && rc == PNGLOSS_SUCCESS; i++) {
+            struct job *j = &jobs[i];
+            if (!j->src.scanlines || j->status != SUCCESS) continue;
+            src[k] = (pngloss_hip_png_source){ j->src.scanlines, j->src.width, j->src.height, j->src.color_type, j->src.bit_depth,
+                                               j->src.palette_entries ? j->src.palette : NULL, j->src.palette_entries,
+                                               j->src.has_trns ? j->src.trns : NULL, j->src.trns_bytes, j->in.rgba_data };
+            who[k++] = i;
+        }
+        if (rc == PNGLOSS_SUCCESS) rc = pngloss_hip_png_decode_batch_host(g_read_ctx, src, m);
+        for (size_t q = 0; q < k; q++)
+            if (rc != PNGLOSS_SUCCESS) { say(&jobs[who[q]], "  error: cannot decode image %s on the GPU (%d)\n", leaf(jobs[who[q]].in_name), rc); jobs[who[q]].status = (pngloss_error)rc; }
+        free(src); free(who);
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (!jobs[i].src.scanlines) continue;
+        free(jobs[i].src.scanlines); jobs[i].src.scanlines = NULL;
+        finish_decode(&jobs[i], o);
+    }
+}
+
 static void *decode_ahead_main(void *arg)
 {
     struct decode_ahead *d = arg;
     const double t0 = now_s();
     for_each_job(d->jobs, d->n, d->o, decode_job);
+    if (d->o->gpu_read) decode_window_on_device(d->jobs, d->n, d->o);
     d->seconds = now_s() - t0;
     return NULL;
 }

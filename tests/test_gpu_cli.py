@@ -198,3 +198,32 @@ def test_batch_cli_windows_are_pipelined_without_changing_the_outputs(tmp_path):
     for r in runs.values():
         pos = [r.stderr.index(f"{n}.png:") for n in names[:4]] + [r.stderr.index("missing.png")] + [r.stderr.index(f"{n}.png:") for n in names[4:]]
         assert pos == sorted(pos)
+
+
+@needs_our_cli
+def test_batch_cli_gpu_read_writes_the_same_files(tmp_path):
+    """--gpu-read: chunk walk + inflate on the decode threads, inverse filters + expansion to RGBA8 on the device.  Files of
+    every colour type / bit depth / tRNS (fixtures written by tests/golden/make_png_read_golden.py), three suite files and one file with
+    a text chunk (which must fall back to libpng): the outputs must be byte for byte what the tool writes without the option -- and
+    therefore what the reference tool writes."""
+    from PIL import Image, PngImagePlugin
+    import pngloss_amd as P
+    fx = U.png_read_fixtures()
+    pick = [f for f in fx if f[0].startswith("suite_rose") or f[0].startswith("suite_tux") or f[0].startswith("suite_david") or "37x19" in f[0] or "130x70" in f[0]][:40]
+    a_dir, b_dir = tmp_path / "libpng", tmp_path / "gpu"
+    a_dir.mkdir(); b_dir.mkdir()
+    names = []
+    for name, png, _ in pick:
+        for d in (a_dir, b_dir):
+            (d / f"{name}.png").write_bytes(png)
+        names.append(name)
+    inter = P.synth_rgba(70, 33, 5, 1)
+    meta = PngImagePlugin.PngInfo(); meta.add_text("Comment", "made for the fallback test")
+    for d in (a_dir, b_dir):
+        Image.fromarray(inter, "RGBA").save(str(d / "withtext.png"), pnginfo=meta)
+    names.append("withtext")
+    ra = subprocess.run([OUR_CLI, "-s", "19", "-b", "2"] + [str(a_dir / f"{n}.png") for n in names], capture_output=True, text=True, timeout=600)
+    rb = subprocess.run([OUR_CLI, "--gpu-read", "-s", "19", "-b", "2"] + [str(b_dir / f"{n}.png") for n in names], capture_output=True, text=True, timeout=600)
+    assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr[-600:], rb.stderr[-600:])
+    for n in names:
+        assert (a_dir / f"{n}-loss.png").read_bytes() == (b_dir / f"{n}-loss.png").read_bytes(), n
