@@ -93,8 +93,8 @@ typedef struct {
     uint32_t bytes_per_pixel;   /* 1 gray, 2 gray+alpha, 3 rgb, 4 rgba -- what pngloss_image.c:64-96 detects       */
     uint32_t unique_symbols;    /* non-zero bins of the final histogram (pngloss_image.c:311-325)                  */
     uint32_t retried_rows;      /* rows that needed the strength-decrement retry (pngloss_image.c:266-274)         */
-    uint32_t repaired_pixels;   /* diagnostics: pixels of the 'none' candidate whose channel speculation had to be
-                                   repaired exactly; no reference equivalent                        */
+    uint32_t repaired_pixels;   /* diagnostics, no reference equivalent: segment engine: validation restarts (epochs); workgroup engine:
+                                   pixels its first chain wave redid exactly                          */
 } pngloss_hip_result;
 
 /* Number of HIP devices visible, or a negative PNGLOSS_HIP_ERROR-style code if the runtime is unusable. */

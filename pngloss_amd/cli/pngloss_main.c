@@ -41,6 +41,7 @@ struct options {
     unsigned num_files;
     bool from_stdin, to_stdout, force, skip_if_larger, strip, help, version, missing, verbose;
     bool gpu_deflate;          /* --gpu-deflate: IDAT data compressed on the device instead of by zlib level 9 */
+    size_t total_files;        /* files of this call (how many GPUs are worth a context) */
     bool gpu_read;             /* --gpu-read: inverse filters + expansion to RGBA8 on the device (inflate stays zlib on the decode threads) */
 };
 
@@ -494,7 +495,17 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
     }
     if (m) {
         /* every GPU of the node ($PNGLOSS_DEVICES restricts or repeats them): the files of the window are dealt out by size */
-        if (!*ctx) *ctx = pngloss_hip_multi_create(NULL);
+        if (!*ctx) {
+            /* a context (device initialisation, events, arenas) only on as many GPUs as the call has files for */
+            const char *envd = getenv("PNGLOSS_DEVICES");
+            const int ndev = pngloss_hip_device_count();
+            if ((envd && *envd) || ndev <= 1 || (size_t)ndev <= o->total_files) *ctx = pngloss_hip_multi_create(NULL);
+            else {
+                char list[256]; size_t at = 0;
+                for (size_t d = 0; d < o->total_files && at + 8 < sizeof list; d++) at += (size_t)snprintf(list + at, sizeof list - at, d ? ",%zu" : "%zu", d);
+                *ctx = pngloss_hip_multi_create(list);
+            }
+        }
         int rc = !*ctx ? PNGLOSS_HIP_ERROR
                : pngloss_hip_multi_optimize_batch_host(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res,
                                                        o->gpu_deflate ? NULL : lines, o->gpu_deflate ? zs : NULL);
@@ -550,6 +561,7 @@ int main(int argc, char **argv)
     }
 
     const size_t total = o.num_files;
+    o.total_files = total;
     struct job *jobs = calloc(total ? total : 1, sizeof *jobs);
     if (!jobs) return OUT_OF_MEMORY_ERROR;
     for (size_t i = 0; i < total; i++) {

@@ -45,8 +45,13 @@ struct PlJob {
     uint32_t emit_pitch;  /* bytes between emitted rows (multiple of 16, >= width*4)                                     */
     uint32_t emit_adaptive_all; /* 1: every row takes libpng's heuristic filter (row_filters == NULL mode), 0: only row 0 */
     uint32_t *progress;   /* null, or a host-visible word that receives the number of finished rows (the -v progress display) */
-    int32_t *result;      /* [16] status, bpp, unique symbols, retried rows, repaired pixels (wave 0), -,-,-,
-                             [8..11] chain kilo-cycles per chain wave, [12..15] repaired pixels per chain wave          */
+    int32_t *result;      /* [64]: [0] status, [1] bpp, [2] unique symbols, [3] retried rows; [20] engine (0 workgroup per image, 3 segment-parallel).
+                             Workgroup engine: [4] pixels redone exactly (chain wave 0 = 'up' on band-leader rows), [5] row attempts on the band-leader
+                             chains, [6] band rescans, [7] SIMD map, [8..15] chain kilo-cycles / repaired pixels per chain wave, [16..20] light pixels
+                             per chain wave (or PL_SEGPROF stamps [16..31]), [21] rows on the round-1 chains by the adaptive choice, [22..23] last
+                             cycles per pixel, [24..31] wave 4 + flush diagnostics, [32..63] phase kilo-cycles per chain (pl_engine.hip epilogue).
+                             Segment engine: [4] epochs, [5] row attempts, [6] rows finished serially, [7] rows in which 'none' was ruled out,
+                             [24..58] phase clocks when PNGLOSS_HIP_SEGPROF is set (pl_seg_core.h)                                                  */
 };
 
 __device__ __forceinline__ uint32_t pl_bpp_from_flags(uint32_t fl)

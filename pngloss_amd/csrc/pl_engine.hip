@@ -32,6 +32,7 @@
 #include "pl_device.h"
 
 #include <atomic>
+#include <cstdio>
 #include <type_traits>
 
 #ifndef PL_SEGPROF
@@ -1902,7 +1903,12 @@ hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, h
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (dev < 0 || dev >= 32 || !(done.load(std::memory_order_acquire) & (1u << dev))) {
             const hipError_t e = hipFuncSetAttribute((const void *)pl_engine, hipFuncAttributeMaxDynamicSharedMemorySize, PL_SM_TOTAL);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess) {
+                /* 104 KB of dynamic LDS per workgroup: a gfx950-class CU (160 KB) has it, the 64 KB parts do not */
+                fprintf(stderr, "pngloss_hip: the row engine needs %d bytes of LDS per workgroup (gfx950-class CU with 160 KB); device %d refused: %s\n",
+                        (int)PL_SM_TOTAL, dev, hipGetErrorString(e));
+                return e;
+            }
             if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
         }
     }

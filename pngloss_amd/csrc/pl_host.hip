@@ -57,6 +57,8 @@ struct pngloss_hip_ctx {
     bool want_progress = false;
     /* segment-parallel engine: two host-mapped words (images finished, attempt being started) the control kernel writes and the
      * launch loop reads, and what the last batch did */
+    bool split_last = false;         /* the last host window ran in two halves: images behind n_last are the peer's */
+    pngloss_hip_ctx *peer = nullptr; /* second context on the same device: the other half of a host window (batch_host) */
     uint32_t *h_seg_words = nullptr;
     int last_engine = 0;            /* 0 = one workgroup per image (pl_engine), 3 = segment-parallel (pl_seg) */
     long seg_attempts = 0;
@@ -523,6 +525,7 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->h_progress) (void)hipHostFree(ctx->h_progress);
     if (ctx->h_seg_words) (void)hipHostFree(ctx->h_seg_words);
+    if (ctx->peer) { pngloss_hip_destroy(ctx->peer); ctx->peer = nullptr; }
     delete ctx;
 }
 
@@ -543,9 +546,9 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
     return finish(ctx, results, n);
 }
 
-static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n, unsigned quantization_strength,
+static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n, unsigned quantization_strength,
                       long bleed_divider, pngloss_hip_result *results, pngloss_hip_scanlines *lines,
-                      pngloss_hip_zstream *zs = nullptr)
+                      pngloss_hip_zstream *zs)
 {
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
@@ -565,8 +568,10 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         rows_off[i] = total; total = align_up(total + (size_t)pitch * (want ? images[i].height : 0), 256);
         emits[i].pitch = pitch;
     }
-    /* persistent arena + pinned staging of the same layout; images are staged by a few host threads and go up as ONE
-     * asynchronous copy (pageable per-image copies were 0.33 s of a 1.6 s window of 256 720p files in round 1) */
+    /* persistent arena + pinned staging of the same layout; images are staged by a few host threads and go up as asynchronous
+     * copies from pinned memory, one per image (pageable per-image copies were 0.33 s of a 1.6 s window of 256 720p files in round 1).
+     * Copies and kernels of a context run on its own non-blocking stream, so that two contexts (the two halves of a window,
+     * batch_host) overlap: one half's transfers with the other half's kernels. */
     if (total > ctx->arena_bytes) {
         if (ctx->d_arena) PL_CHECK(hipFree(ctx->d_arena));
         ctx->d_arena = nullptr; ctx->arena_bytes = 0;
@@ -587,7 +592,7 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
     std::vector<pngloss_hip_image_desc> descs(n);
     const auto tu0 = std::chrono::steady_clock::now();
     {
-        const unsigned nthreads = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n));
+        const unsigned nthreads = (unsigned)std::min<size_t>(12, std::max<size_t>(1, n));
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < nthreads; t++)
             pool.emplace_back([&, t]() {
@@ -606,13 +611,13 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
         emits[i].d_rows = emits[i].pitch ? arena + rows_off[i] : nullptr;
         /* asynchronous DMA from pinned memory, one per image (the areas between images are filled by the kernels) */
         if (px && rc == PNGLOSS_SUCCESS &&
-            hipMemcpyAsync(arena + img_off[i], ctx->h_pinned + img_off[i], px * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            hipMemcpyAsync(arena + img_off[i], ctx->h_pinned + img_off[i], px * 4, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     }
-    if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(ctx->copy_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
     std::vector<pngloss_hip_result> own_results;
     if (!results) { own_results.resize(n ? n : 1); results = own_results.data(); }
-    if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, nullptr, emits.data());
+    if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, ctx->copy_stream, emits.data());
     if (rc == PNGLOSS_SUCCESS) rc = finish(ctx, results, n);
     /* a row without an acceptable filter (device status 65, pngloss_image.c:268-271) fails THAT image only: the others of
      * the batch are downloaded and the call reports PNGLOSS_INTERNAL_ABORT with the per-image status in results[] */
@@ -633,11 +638,11 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
                 if (!px || stream_only || results[i].status != 0) continue;
                 /* the filter flags sit right behind the image in the arena: one copy takes both */
                 const size_t bytes = images[i].row_filters ? flt_off[i] + images[i].height - img_off[i] : px * 4;
-                if (hipMemcpyAsync(ctx->h_pinned + img_off[i], arena + img_off[i], bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+                if (hipMemcpyAsync(ctx->h_pinned + img_off[i], arena + img_off[i], bytes, hipMemcpyDeviceToHost, ctx->copy_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
             }
-            if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(nullptr) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+            if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(ctx->copy_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
             if (rc == PNGLOSS_SUCCESS) {
-                const unsigned nthreads = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n));
+                const unsigned nthreads = (unsigned)std::min<size_t>(12, std::max<size_t>(1, n));
                 std::vector<std::thread> pool;
                 for (unsigned t = 0; t < nthreads; t++)
                     pool.emplace_back([&, t]() {
@@ -706,6 +711,45 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
     if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
     if (rc == PNGLOSS_SUCCESS && some_aborted) rc = PNGLOSS_INTERNAL_ABORT;
     return rc;
+}
+
+
+/* A window of host images: in two halves on two contexts of the same device, a host thread each, when it is large enough -- the
+ * second half is staged and uploaded while the first one computes, the first one is downloaded while the second one computes
+ * (profiles/r02_host_seam.txt: staging + PCIe were 0.26 s next to a 0.28 s engine for 256 x 720p, one after the other).  The deflate
+ * stage (zs) keeps its single pass: it sorts the whole window's scanlines as one stream. */
+static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n, unsigned quantization_strength,
+                      long bleed_divider, pngloss_hip_result *results, pngloss_hip_scanlines *lines,
+                      pngloss_hip_zstream *zs = nullptr)
+{
+    if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
+    const char *no = std::getenv("PNGLOSS_HIP_NO_SPLIT");
+    ctx->split_last = false;
+    if (n < 16 || zs || (no && *no == '1')) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
+    if (!ctx->peer) {
+        ctx->peer = pngloss_hip_create(ctx->device);
+        if (!ctx->peer) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
+    }
+    /* cut where half of the pixels are */
+    size_t total = 0, run = 0, cut = n / 2;
+    for (size_t i = 0; i < n; i++) total += (size_t)images[i].width * images[i].height;
+    for (size_t i = 0; i < n; i++) { run += (size_t)images[i].width * images[i].height; if (2 * run >= total) { cut = i + 1; break; } }
+    if (cut == 0 || cut >= n) cut = n / 2;
+    std::vector<pngloss_hip_result> own;
+    if (!results) { own.resize(n); results = own.data(); }
+    int rc2 = PNGLOSS_SUCCESS;
+    std::thread second([&]() {
+        rc2 = batch_host_one(ctx->peer, images + cut, n - cut, quantization_strength, bleed_divider, results + cut, lines ? lines + cut : nullptr, nullptr);
+    });
+    const int rc1 = batch_host_one(ctx, images, cut, quantization_strength, bleed_divider, results, lines ? lines + 0 : nullptr, nullptr);
+    second.join();
+    ctx->split_last = true;
+    ctx->engine_ms = std::max(ctx->engine_ms, ctx->peer->engine_ms);
+    ctx->total_ms = std::max(ctx->total_ms, ctx->peer->total_ms);
+    ctx->upload_ms += ctx->peer->upload_ms; ctx->download_ms += ctx->peer->download_ms;
+    if (rc1 != PNGLOSS_SUCCESS && rc1 != PNGLOSS_INTERNAL_ABORT) return rc1;
+    if (rc2 != PNGLOSS_SUCCESS && rc2 != PNGLOSS_INTERNAL_ABORT) return rc2;
+    return (rc1 == PNGLOSS_INTERNAL_ABORT || rc2 == PNGLOSS_INTERNAL_ABORT) ? PNGLOSS_INTERNAL_ABORT : PNGLOSS_SUCCESS;
 }
 
 int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
@@ -847,6 +891,7 @@ double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx-
 
 int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *hist256)
 {
+    if (ctx && ctx->split_last && ctx->peer && index >= ctx->n_last) return pngloss_hip_last_histogram(ctx->peer, index - ctx->n_last, hist256);
     if (!ctx || !hist256 || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     PL_CHECK(hipMemcpy(hist256, ctx->h_jobs[index].final_hist, sizeof(uint32_t) * PL_NSYM, hipMemcpyDeviceToHost));
@@ -898,6 +943,7 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
 
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8])
 {
+    if (ctx && ctx->split_last && ctx->peer && index >= ctx->n_last) return pngloss_hip_last_engine_info(ctx->peer, index - ctx->n_last, info);
     if (!ctx || !info || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     int32_t r[64] = { 0 };

@@ -193,8 +193,14 @@ def hip_lib():
         return _hip
 
 
-def _check(rc, what):
-    if rc != PNGLOSS_SUCCESS:
+PNGLOSS_INTERNAL_ABORT = 65
+
+
+def _check(rc, what, partial_ok=False):
+    """partial_ok: the batch entry points return PNGLOSS_INTERNAL_ABORT (65) when SINGLE images hit the row the reference abort()s on
+    (pngloss_image.c:268-271) -- every other image of the batch is done and results[i].status tells which failed, so the wrappers
+    hand the per-image statuses back instead of throwing the whole batch away."""
+    if rc != PNGLOSS_SUCCESS and not (partial_ok and rc == PNGLOSS_INTERNAL_ABORT):
         raise RuntimeError(f"{what} failed with pngloss_error {rc}")
 
 
@@ -282,7 +288,7 @@ class HipContext:
     def finish(self):
         n = getattr(self, "_n", 0)
         res = (Result * max(n, 1))()
-        _check(self._lib.pngloss_hip_finish(self._ctx, res, n), "finish")
+        _check(self._lib.pngloss_hip_finish(self._ctx, res, n), "finish", partial_ok=True)
         return [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols, retried_rows=r.retried_rows, repaired_pixels=r.repaired_pixels) for r in res[:n]]
 
     def run(self, images, strength=19, bleed=2, stream=0):
@@ -298,7 +304,7 @@ class HipContext:
         for i, (a, f) in enumerate(zip(outs, filts)):
             imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
         res = (Result * max(n, 1))()
-        _check(self._lib.pngloss_hip_optimize_batch_host(self._ctx, imgs, n, strength, bleed, res), "optimize_batch_host")
+        _check(self._lib.pngloss_hip_optimize_batch_host(self._ctx, imgs, n, strength, bleed, res), "optimize_batch_host", partial_ok=True)
         return outs, filts, [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols) for r in res[:n]]
 
     def run_host_emit(self, arrays, strength=19, bleed=2, want_filters=True):
@@ -314,7 +320,7 @@ class HipContext:
             imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
             lines[i] = Scanlines(ids[i].ctypes.data, rows[i].ctypes.data, a.shape[1] * 4, -1)
         res = (Result * max(n, 1))()
-        _check(self._lib.pngloss_hip_optimize_batch_host_emit(self._ctx, imgs, n, strength, bleed, res, lines), "optimize_batch_host_emit")
+        _check(self._lib.pngloss_hip_optimize_batch_host_emit(self._ctx, imgs, n, strength, bleed, res, lines), "optimize_batch_host_emit", partial_ok=True)
         chans = {0: 1, 4: 2, 2: 3, 6: 4}
         emitted = [(lines[i].color_type, ids[i], rows[i][:, : outs[i].shape[1] * chans.get(lines[i].color_type, 4)].copy()) for i in range(n)]
         return outs, filts, emitted
@@ -332,7 +338,7 @@ class HipContext:
             imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
             zs[i] = ZStream(bufs[i].ctypes.data, bufs[i].size, 0, -1, (C.c_uint32 * 3)(0, 0, 0), 1 if stream_only else 0)
         res = (Result * max(n, 1))()
-        _check(self._lib.pngloss_hip_optimize_batch_host_zlib(self._ctx, imgs, n, strength, bleed, res, zs), "optimize_batch_host_zlib")
+        _check(self._lib.pngloss_hip_optimize_batch_host_zlib(self._ctx, imgs, n, strength, bleed, res, zs), "optimize_batch_host_zlib", partial_ok=True)
         streams = [(zs[i].color_type, bufs[i][: zs[i].size].tobytes(), tuple(zs[i].blocks)) for i in range(n)]
         return outs, filts, streams
 
@@ -422,5 +428,5 @@ class HipMulti:
         for i, (a, f) in enumerate(zip(outs, filts)):
             imgs[i] = HostImage(a.ctypes.data, f.ctypes.data if f is not None else None, a.shape[1], a.shape[0])
         res = (Result * max(n, 1))()
-        _check(self._lib.pngloss_hip_multi_optimize_batch_host(self._m, imgs, n, strength, bleed, res, None, None), "multi_optimize_batch_host")
+        _check(self._lib.pngloss_hip_multi_optimize_batch_host(self._m, imgs, n, strength, bleed, res, None, None), "multi_optimize_batch_host", partial_ok=True)
         return outs, filts, [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols) for r in res[:n]]

@@ -429,6 +429,37 @@ def test_multi_device_host_batch_two_contexts_on_one_device():
     assert all(np.array_equal(x, y) for x, y in zip(outs, outs1)) and all(np.array_equal(x, y) for x, y in zip(filts, filts1))
 
 
+def test_every_visible_device_takes_part_when_there_are_several(tmp_path):
+    """The REAL multi-device branch (the "0,0" test above shares one GPU): with two or more visible devices, HipMulti(None) opens one
+    context per device and every one must come back with its share, bit-exact; and a 2-rank bench.py under torch.distributed.run (RCCL)
+    must print a line whose frames_per_gpu and digests are right.  Skipped, with the reason, on a one-GPU box -- so that the first
+    multi-GPU box the driver gets runs a test, not a debugging session."""
+    ndev = P.hip_lib().pngloss_hip_device_count()
+    if ndev < 2:
+        pytest.skip("only %d HIP device visible: the multi-device branch needs two (the split logic itself is covered with devices '0,0')" % ndev)
+    specs = [(200 + 7 * i, 60 + 3 * i, i % 6) for i in range(4 * ndev)]
+    imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+    multi = P.HipMulti(None)
+    assert multi.count == ndev
+    outs, filts, res = multi.run_host(imgs, 19, 2)
+    multi.close()
+    assert set(P.multi_split([(w, h) for (w, h, m) in specs], ndev)) == set(range(ndev))
+    for a, o, f, r, sp in zip(imgs, outs, filts, res, specs):
+        o1, f1 = U.run_port(a, 19, 2)
+        assert r["status"] == 0 and np.array_equal(o, o1) and np.array_equal(f, f1), sp
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PNGLOSS_HIP_ENGINE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+                        os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["bit_exact_vs_reference_digest"] is True
+    assert line["batch"]["frames_per_gpu"] == [128, 128] and line["batch"]["digests_match_reference"] is True
+    assert line["batch_saturating"]["digests_match_reference"] is True
+
+
 def test_verbose_prints_progress_and_summary():
     """-v surface of the seam (pngloss_image.c:214-237, 309-325): a spinner with the percentage of finished rows while the
     engine runs, then "compression complete" and "used N unique symbols"; the pixels are the same as without it."""

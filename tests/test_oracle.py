@@ -170,3 +170,20 @@ def test_adaptive_filter_against_bruteforce():
             want = sums.index(min(sums))
             got = U.port().port_adaptive_filter(above.ctypes.data if above is not None else None, row.ctypes.data, w, bpp)
             assert got == want
+
+
+def test_restatement_is_clean_under_asan_and_ubsan(tmp_path):
+    """the checker every GPU test trusts (oracle/pngloss_port.c, all three chain variants) built with
+    -fsanitize=address,undefined must run without a report, agree between its variants, and print the digests of the ordinary build."""
+    import os
+    import subprocess
+    src = [os.path.join(U.ROOT, "tests", "c", "port_sanitize_main.c"), os.path.join(U.ROOT, "pngloss_amd", "csrc", "pngloss_synth.c")]
+    outs = []
+    for tag, flags in (("plain", ["-O1"]), ("san", ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"])):
+        exe = str(tmp_path / ("port_" + tag))
+        subprocess.run(["gcc", "-std=gnu11", "-Wno-unknown-pragmas", "-Wno-unused-function"] + flags + ["-o", exe] + src, check=True, capture_output=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") == 15
