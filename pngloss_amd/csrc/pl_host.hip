@@ -133,7 +133,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) {
         const PlJob &pj = ctx->h_jobs[i];
-        const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1);
+        const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1, (uint32_t)params.nsp);
         char *base = ctx->d_ws + seg_offs[i];
         SegJob &s = sj[i];
         s.img = pj.img; s.row_filters = pj.row_filters; s.row_ids = pj.row_ids; s.W = pj.width; s.H = pj.height; s.bpp = 0;
@@ -144,6 +144,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
         s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
         s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
         s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps);
+        s.rout = reinterpret_cast<uint16_t *>(base + l.rout); s.rst = reinterpret_cast<uint32_t *>(base + l.rst); s.dcnt = reinterpret_cast<uint32_t *>(base + l.dcnt);
         s.entry = reinterpret_cast<uint32_t *>(base + l.entry); s.segcnt = reinterpret_cast<uint16_t *>(base + l.segcnt);
         s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt);
         s.firstidx = reinterpret_cast<uint32_t *>(base + l.firstidx); s.rowmm = reinterpret_cast<int32_t *>(base + l.rowmm);
@@ -236,7 +237,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     if (use_seg) {
         seg_jobs_off = total; total += align_up(sizeof(SegJob) * n, 256);
         seg_params_off = total; total += align_up(sizeof(SegParams), 256);
-        for (size_t i = 0; i < n; i++) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1).total; }
+        for (size_t i = 0; i < n; i++) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1, (uint32_t)seg_params.nsp).total; }
     }
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
@@ -346,6 +347,10 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
                 std::fprintf(stderr, "pngloss_hip:   enumeration workgroups (us), slowest / average: load %.1f / %.2f  first %d steps + dedupe %.1f / %.2f  remaining steps %.1f / %.2f  map %.1f / %.2f; distinct states per channel after the dedupe %.1f; first-segment walker %.1f / %.2f\n",
                              r[24] / 100.0, (uint32_t)r[28] / 100.0 / (uint32_t)r[32], SEG_K1, r[25] / 100.0, (uint32_t)r[29] / 100.0 / (uint32_t)r[32], r[26] / 100.0, (uint32_t)r[30] / 100.0 / (uint32_t)r[32],
                              r[27] / 100.0, (uint32_t)r[31] / 100.0 / (uint32_t)r[32], (uint32_t)r[33] / 4.0 / (uint32_t)r[32], r[34] / 100.0, r[36] ? (uint32_t)r[35] / 100.0 / (uint32_t)r[36] : 0.0);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[16])
+                std::fprintf(stderr, "pngloss_hip:   chain workgroups (us), slowest / average: gather %.1f / %.2f  compose %.1f / %.2f  walk %.1f / %.2f  tail %.1f / %.2f; %u runs, %u through the serial walk, %u at the wide stride\n",
+                             r[8] / 100.0, (uint32_t)r[12] / 100.0 / (uint32_t)r[16], r[9] / 100.0, (uint32_t)r[13] / 100.0 / (uint32_t)r[16], r[10] / 100.0, (uint32_t)r[14] / 100.0 / (uint32_t)r[16],
+                             r[11] / 100.0, (uint32_t)r[15] / 100.0 / (uint32_t)r[16], (uint32_t)r[16], (uint32_t)r[17], (uint32_t)r[18]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[53])
                 std::fprintf(stderr, "pngloss_hip:   ... average per workgroup (us): load %.2f  pass1 %.2f  watched bins + pass3 %.2f  none bound %.2f  sums %.2f  (%u workgroup runs)\n",
                              (uint32_t)r[48] / 100.0 / (uint32_t)r[53], (uint32_t)r[49] / 100.0 / (uint32_t)r[53], (uint32_t)r[50] / 100.0 / (uint32_t)r[53], (uint32_t)r[51] / 100.0 / (uint32_t)r[53],

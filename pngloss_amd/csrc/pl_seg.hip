@@ -100,7 +100,7 @@ hipError_t chain_attr()
 
 } // namespace
 
-PlSegLayout pl_seg_layout(uint32_t width)
+PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp)
 {
     PlSegLayout l{};
     l.nseg = (width + SEG_L - 1) / SEG_L;
@@ -112,7 +112,10 @@ PlSegLayout pl_seg_layout(uint32_t width)
     l.h0 = take(2 * 256 * 4);
     l.acc = take(2 * sizeof(SegAcc));
     l.tables = take((size_t)SEG_NFILT * SEG_TBL_WORDS * 4);
-    l.maps = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 2);
+    l.maps = take((size_t)SEG_NFILT * l.nseg * 4 * nsp * 2);
+    l.rout = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 2);
+    l.rst = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 4);
+    l.dcnt = take((size_t)SEG_NFILT * l.nseg * 4 * 4);
     l.entry = take((size_t)SEG_NFILT * l.nseg * 4 * 4);
     l.segcnt = take((size_t)SEG_NFILT * l.nseg * 256 * 2);
     l.grpcnt = take((size_t)SEG_NFILT * l.ngrp * 256 * 4);

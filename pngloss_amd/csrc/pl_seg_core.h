@@ -65,6 +65,7 @@ __device__ __forceinline__ uint64_t pls_wave_sum_u64(uint64_t v) { for (int o = 
 __device__ __forceinline__ int pls_wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; } return v; }
 __device__ __forceinline__ int pls_wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
 #define PLS_ATOMIC_MAX_I(p, v) atomicMax((p), (v))
+#define PLS_ATOMIC_MAX_U(p, v) atomicMax((p), (v))
 #define PLS_ATOMIC_MIN_I(p, v) atomicMin((p), (v))
 #define PLS_HOST_VISIBLE_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define PLS_HOST_VISIBLE_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
@@ -88,6 +89,7 @@ inline uint64_t pls_wave_sum_u64(uint64_t v) { return v; }
 inline int pls_wave_max_i(int v) { return v; }
 inline int pls_wave_min_i(int v) { return v; }
 #define PLS_ATOMIC_MAX_I(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
+#define PLS_ATOMIC_MAX_U(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 #define PLS_ATOMIC_MIN_I(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
 #define PLS_HOST_VISIBLE_ADD(p, v) (*(p) += (v))
 #define PLS_HOST_VISIBLE_STORE(p, v) (*(p) = (v))
@@ -105,13 +107,20 @@ inline int pls_wave_min_i(int v) { return v; }
 #endif
 typedef SEG_AS_LDS uint32_t *seg_lds_u32;
 typedef SEG_AS_LDS uint8_t *seg_lds_u8;
+typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 
+#if defined(__HIPCC__)
+#define PLS_UNROLL _Pragma("unroll")
+#else
+#define PLS_UNROLL
+#endif
 #define SEG_NFILT 5
 #ifndef SEG_L
 #define SEG_L 32                 /* pixels per segment (16 was measured: enumeration -5 us, chain +5 us, no gain) */
 #endif
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
-#define SEG_NSP 256              /* lanes per channel in the enumeration = most states supported */
+#define SEG_NSP 256              /* lanes per channel in the enumeration; also the most DISTINCT states a segment may have after the dedupe */
+#define SEG_NS_MAX 1024          /* most chain states of a (strength, bleed) pair the engine takes (enumerated in chunks of SEG_NSP) */
 #define SEG_TOFF 320             /* decision tables cover v in [-320, 319] */
 #define SEG_TN 640
 #define SEG_TBL_WORDS (4 * SEG_TN + 128)  /* pre[2], suf[2], cls[2][256 bytes] */
@@ -139,7 +148,8 @@ struct SegParams {
     int32_t engine_flags;          /* bits 8..: debugging aid, 1 + the candidate that wins every row */
     uint32_t lut_a[512];           /* [diff+256] -> rem (int16) | thr << 16      of the Sierra split (optimize_state.c:445-467) */
     uint32_t lut_b[512];           /* [diff+256] -> t | f << 8 | v << 16 | h << 24 (int8 each): the next-rows terms          */
-    uint32_t st_pack[SEG_NSP];     /* state i -> (delta+128) | (cn+128) << 8 | (th+128) << 16 */
+    uint32_t st_pack[SEG_NS_MAX];  /* state i -> (delta+128) | (cn+128) << 8 | (th+128) << 16 */
+    int32_t nsp;                   /* ns rounded up to a multiple of 64: stride of a segment's entry map */
     uint16_t keylut[SEG_KEYLUT_MAX]; /* ((delta+dmax) * (2cmax+1) + cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
     /* filters whose prediction ignores the left pixel (none, up): the state is (cn, th) alone */
     uint8_t rt_max[256];           /* [D] -> max |rem(d)| + max |thr(d)| over |d| <= D (capped at 255) */
@@ -188,7 +198,10 @@ struct SegJob {
     SEG_AS_GLB uint32_t *H0;             /* [2][256] committed histogram */
     SEG_AS_GLB SegAcc *acc;              /* [2] */
     SEG_AS_GLB uint32_t *tables;         /* [5][SEG_TBL_WORDS] */
-    SEG_AS_GLB uint16_t *maps;           /* [5][nseg][4][SEG_NSP] */
+    SEG_AS_GLB uint16_t *maps;           /* [5][nseg][4][nsp]: entry index of a segment -> dense id of its state after the dedupe (0xffff: none) */
+    SEG_AS_GLB uint16_t *rout;           /* [5][nseg][4][SEG_NSP]: dense id -> exit index of the segment (0xffff: left what the tables cover) */
+    SEG_AS_GLB uint32_t *rst;            /* [5][nseg][4][SEG_NSP]: dense id -> exit state of the segment, packed (0xffffffff: none) */
+    SEG_AS_GLB uint32_t *dcnt;           /* [5][nseg][4]: distinct states of the segment */
     SEG_AS_GLB uint32_t *entry;          /* [5][nseg][4] */
     SEG_AS_GLB uint16_t *segcnt;         /* [5][nseg][256] */
     SEG_AS_GLB uint32_t *grpcnt;         /* [5][ngrp][256] */
@@ -532,13 +545,13 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
                 if (seg_abs(delta) > P.dmax || seg_abs(cn) > P.cmax) continue;
                 const int key = ((delta + P.dmax) * (2 * P.cmax + 1) + cn + P.cmax) * (2 * P.tmax + 1) + th + P.tmax;
                 if (P.keylut[key] != (uint16_t)SEG_INVALID) continue;
-                if (ns >= SEG_NSP) return false;
+                if (ns >= SEG_NS_MAX) return false;
                 P.keylut[key] = (uint16_t)ns;
                 P.st_pack[ns] = (uint32_t)(delta + 128) | ((uint32_t)(cn + 128) << 8) | ((uint32_t)(th + 128) << 16);
                 ns++;
             }
     }
-    P.ns = ns;
+    P.ns = ns; P.nsp = (ns + 63) / 64 * 64;
     {
         const int kn = (2 * P.cmax + 1) * (2 * P.tmax + 1);
         int n2 = 0; bool ok = kn <= SEG_KEYS_MAX;
@@ -567,7 +580,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 
 /* shared-memory budgets (bytes) */
 #define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64 + 4 * 512 * 4 + 4 * 512 * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + SEG_THREADS * 2 + SEG_THREADS * 4 + 64)
-#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 16 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
+#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + SEG_TBL_WORDS * 4 + 64)
@@ -651,81 +664,81 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     PLS_SYNC();
     const bool trx = trflag[0] != 0u;
     if (prof) te[1] = PLS_CLOCK();
-    /* -- the first SEG_K1 steps from every state; neighbouring lanes mostly end in the same state, so only the first lane of a run of
-     *    equal keys ("head") goes to the hash table with an atomic, the others look their key up afterwards -- */
+    /* -- the first SEG_K1 steps from every state, SEG_NSP states per channel at a time; neighbouring lanes mostly end in the same state,
+     *    so only the first lane of a run of equal keys ("head") goes to the hash table with an atomic, the others look their key up
+     *    afterwards.  Every entry index gets the DENSE id of its state: that is the segment's entry map -- */
     uint32_t *keys = (uint32_t *)(lslot + SEG_THREADS);       /* [SEG_THREADS] state key of every lane after SEG_K1 steps, ~0 = none */
-    PLS_THREADS(tid, SEG_THREADS) {
-        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
-        uint32_t key = 0xffffffffu;
-        if ((uint32_t)c < bpp && i < P.ns) {
-            SegState st;
-            if (seg_state_decode(P, i, px[c], st)) {
-                const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
-                if (!bad && st.cn >= -128 && st.cn <= 127) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16);
-            }
-        }
-        keys[tid] = key;
-    }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) {
-        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
-        const uint32_t key = keys[tid];
-        if (key != 0xffffffffu && (i == 0 || keys[tid - 1] != key)) {
-            uint32_t h = (key * 0x9E3779B1u) >> 23;                            /* 9 bits */
-            for (int probe = 0; probe < SEG_HT; probe++) {
-                const uint32_t old = PLS_ATOMIC_CAS(&ht[c * SEG_HT + h], 0xffffffffu, key);
-                if (old == 0xffffffffu) {                                     /* the representative of a new state */
-                    const uint32_t d = PLS_ATOMIC_ADD_RET(&trflag[1 + c], 1u);
-                    dense[c * SEG_HT + h] = (uint16_t)d;
-                    uniq[c * SEG_NSP + d] = key;
-                    break;
+    SEG_AS_GLB uint16_t *dmap = j.maps + (((size_t)f * j.nseg + seg) * 4) * (size_t)P.nsp;
+    for (int i0 = 0; i0 < P.ns; i0 += SEG_NSP) {
+        PLS_THREADS(tid, SEG_THREADS) {
+            const int c = tid / SEG_NSP, i = i0 + tid % SEG_NSP;
+            uint32_t key = 0xffffffffu;
+            if ((uint32_t)c < bpp && i < P.ns) {
+                SegState st;
+                if (seg_state_decode(P, i, px[c], st)) {
+                    const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                    if (!bad && st.cn >= -128 && st.cn <= 127) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16);
                 }
-                if (old == key) break;
-                h = (h + 1) & (SEG_HT - 1);
+            }
+            keys[tid] = key;
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            const int c = tid / SEG_NSP, i = tid % SEG_NSP;
+            const uint32_t key = keys[tid];
+            if (key != 0xffffffffu && (i == 0 || keys[tid - 1] != key)) {
+                uint32_t h = (key * 0x9E3779B1u) >> 23;                            /* 9 bits */
+                for (int probe = 0; probe < SEG_HT; probe++) {
+                    const uint32_t old = PLS_ATOMIC_CAS(&ht[c * SEG_HT + h], 0xffffffffu, key);
+                    if (old == 0xffffffffu) {                                     /* the representative of a new state */
+                        const uint32_t d = PLS_ATOMIC_ADD_RET(&trflag[1 + c], 1u);
+                        dense[c * SEG_HT + h] = (uint16_t)(d < SEG_NSP ? d : 0xffffu);          /* more distinct states than lanes: the surplus has no id */
+                        if (d < SEG_NSP) uniq[c * SEG_NSP + d] = key;
+                        break;
+                    }
+                    if (old == key) break;
+                    h = (h + 1) & (SEG_HT - 1);
+                }
             }
         }
-    }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) {
-        const int c = tid / SEG_NSP;
-        const uint32_t key = keys[tid];
-        uint32_t slot = 0xffffu;
-        if (key != 0xffffffffu) {
-            uint32_t h = (key * 0x9E3779B1u) >> 23;
-            for (int probe = 0; probe < SEG_HT; probe++) {
-                if (ht[c * SEG_HT + h] == key) { slot = h; break; }
-                h = (h + 1) & (SEG_HT - 1);
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            const int c = tid / SEG_NSP, i = i0 + tid % SEG_NSP;
+            const uint32_t key = keys[tid];
+            uint32_t d = 0xffffu;
+            if (key != 0xffffffffu) {
+                uint32_t h = (key * 0x9E3779B1u) >> 23;
+                for (int probe = 0; probe < SEG_HT; probe++) {
+                    const uint32_t at = ht[c * SEG_HT + h];
+                    if (at == key) { d = dense[c * SEG_HT + h]; break; }
+                    if (at == 0xffffffffu) break;                                 /* (the table was full when its head came) */
+                    h = (h + 1) & (SEG_HT - 1);
+                }
             }
+            if ((uint32_t)c < bpp && i < P.ns) dmap[(size_t)c * P.nsp + i] = (uint16_t)d;
         }
-        lslot[tid] = (uint16_t)slot;
+        PLS_SYNC();
     }
-    PLS_SYNC();
     if (prof) te[2] = PLS_CLOCK();
-    /* -- the remaining steps, distinct states only (packed into the first lanes of each channel) -- */
+    /* -- the remaining steps, distinct states only (packed into the first lanes of each channel): dense id -> exit index -- */
     PLS_THREADS(tid, SEG_THREADS) {
         /* distinct state i of channel c runs on thread (i >> 6) * 256 + c * 64 + (i & 63): the first 64 of every channel are waves 0..3 of
          * the workgroup, one per SIMD (waves 0, 4, 8, 12 would share one) */
         const int c = (tid >> 6) & 3, i = (tid & 63) + 64 * (tid >> 8);
-        if ((uint32_t)c < bpp && (uint32_t)i < trflag[1 + c]) {
+        const uint32_t D = trflag[1 + c] < SEG_NSP ? trflag[1 + c] : SEG_NSP;
+        if ((uint32_t)c < bpp && (uint32_t)i < D) {
             const uint32_t key = uniq[c * SEG_NSP + i];
             SegState st;
             st.left = (int)(key & 255u); st.cn = seg_sext8((int)(key >> 8)); st.th = seg_sext8((int)(key >> 16));
             uint32_t out = SEG_INVALID;
             const int bad = seg_run_fast_f(f, trx, px + (1 + SEG_K1) * 4 + c, 4, SEG_L - SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
             if (!bad) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
-            res[c * SEG_NSP + i] = (uint16_t)out;
+            j.rout[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
+            j.rst[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
         }
-    }
-    PLS_SYNC();
-    if (prof) te[3] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_THREADS) {
-        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
-        if ((uint32_t)c < bpp && i < P.ns) {
-            const uint32_t slot = lslot[tid];
-            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = slot == 0xffffu ? (uint16_t)SEG_INVALID : res[c * SEG_NSP + dense[c * SEG_HT + slot]];
-        }
+        if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
         if (prof && tid == 0) {
-            te[4] = PLS_CLOCK();
+            te[3] = PLS_CLOCK(); te[4] = te[3];
             for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
             PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
             PLS_ATOMIC_ADD((uint32_t *)&j.result[33], trflag[1] + trflag[2] + trflag[3] + trflag[4]);
@@ -769,7 +782,11 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
                 const int bad = seg_run_fast_f(f, trx, px + (sl * SEG_L) * 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
                 if (!bad) out = seg_small_encode(P, st);
             }
-            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
+            /* no dedupe for the handful of (cn, th) states: the dense id of an entry index is the index itself */
+            j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * (size_t)P.nsp + i] = (uint16_t)i;
+            j.rout[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
+            j.rst[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = out == SEG_INVALID ? 0xFFFFFFFFu : seg_state_pack(st);
+            if (i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = (uint32_t)P.ns_small;
         }
     }
 }
@@ -856,12 +873,19 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
     }
 }
 
-/* ---- CHAIN: task (f, c): compose the segment maps from the epoch's start state -----------------------------------------
- * The exit index of segment sg (relative to its last pixel) IS the entry index of segment sg+1 (relative to the same pixel, its
- * boundary pixel), so composing is a lookup per segment.  Done in blocks of SEG_CBLK segments: every block's composed map for ALL
- * entry indices in parallel (lane = (block, index)), then the true path across the blocks, then inside every block in parallel:
- * 16 + nblk + 16 dependent lookups instead of nseg.  Entry states are decoded afterwards, in parallel. */
+/* ---- CHAIN: task (f, c): compose the segments from the epoch's start state ----------------------------------------------
+ * The enumeration left, per segment: entry index -> dense id of the state after the dedupe (maps), dense id -> exit index (rout) and
+ * exit state (rst).  The exit index of segment k IS the entry index of segment k+1 (same reference pixel), so the chain only needs the
+ * DENSE transition tables  T_k[d] = maps_{k+1}[rout_k[d]]  (dense id in segment k -> dense id in segment k+1): a few dozen entries per
+ * segment whatever the number of chain states, gathered here in parallel.  Composed in blocks of SEG_CBLK segments (every block's
+ * composed table for all ids in parallel, then every block walks from the row's start id across the composed tables to its own head
+ * and through its segments): 16 + nblk + 16 dependent lookups instead of nseg.  The entry state of segment k+1 is the exit state
+ * rst_k[d_k]: nothing to decode. */
 #define SEG_CBLK 16
+#define SEG_CR_SH 6
+#define SEG_CR_MAX (1 << SEG_CR_SH)                             /* the usual table stride; the exit states are staged in shared memory at this stride */
+#define SEG_NOSTATE 0xFFFFFFFFu
+#define SEG_CQ 8                                                /* gather items in flight per thread */
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -871,95 +895,171 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
     if (first + 1 >= nseg) return;
-    const bool small = seg_is_small(P, f);
-    const int nmap = small ? SEG_NSS : SEG_NSP;               /* entries per map */
-    const uint32_t s0 = sx ? first + 1 : 0u, ns = nseg - 1 - s0;   /* maps of segments s0 .. s0+ns-1; entries wanted for s0 .. nseg-1 (a fresh row: from 0) */
+    const uint32_t s0 = sx ? first + 1 : 0u, ns = nseg - 1 - s0;   /* enumerated segments s0 .. s0+ns-1; entries wanted for s0 .. nseg-1 (a fresh row: from 0) */
     const uint32_t nblk = (ns + SEG_CBLK - 1) / SEG_CBLK;
-    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512;
-    SegPix *bpx = (SegPix *)(Hf + 1024);                      /* [nseg] boundary pixel sg*SEG_L - 1 of every segment */
-    uint32_t *idxs = (uint32_t *)(bpx + ((nseg + 1) & ~1u));  /* [nseg][2]: entry index of every segment | packed state when it has none */
-    uint32_t *idxb = idxs + 2 * ((nseg + 1) & ~1u);           /* [32]: entry index of every block, [31] = the slow path is needed */
-    uint16_t *G = (uint16_t *)(idxb + 32);                    /* [nblk][nmap] composed maps of the blocks */
-    uint16_t *maps = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;
+    /* table stride: SEG_CR_MAX entries per segment cover nearly every row (measured: 17 distinct states per segment on average);
+     * a row with a segment beyond that is gathered again at the widest stride */
+    uint32_t sh = SEG_CR_SH;
+    uint32_t stride = 1u << sh;
+    bool useR = true;
+    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512;   /* (slow path only) */
+    seg_lds_u32 idxb = (seg_lds_u32)(Hf + 1024);               /* [32]: [27] most distinct states of a segment (only when [30]), [28] dense id the chain starts with, [29] its entry index, [30] some segment has more distinct states than the stride, [31] slow path needed */
+    seg_lds_u32 dn = idxb + 32;                                /* [ns] dense id inside every enumerated segment */
+    seg_lds_u16 G = (seg_lds_u16)(dn + ((nseg + 1) & ~1u));    /* [nblk][stride] composed tables of the blocks */
+    seg_lds_u16 T = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;   /* [ns][stride]: T[k] takes a dense id of segment s0+k to one of segment s0+k+1 */
+    seg_lds_u32 R = (seg_lds_u32)(T + (size_t)((ns + 1) & ~1u) * stride);    /* [ns][stride] (useR): exit state of segment s0+k under that id */
     const uint32_t y = ctl.y;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G_ = seg_geo((int)ctl.s);
+    const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SEG_AS_GLB uint16_t *maps = j.maps + ((size_t)f * nseg * 4 + c) * (size_t)P.nsp;     /* + sg * 4 * nsp */
+    const SEG_AS_GLB uint16_t *rout = j.rout + ((size_t)f * nseg * 4 + c) * SEG_NSP;           /* + sg * 4 * SEG_NSP */
+    const SEG_AS_GLB uint32_t *rst = j.rst + ((size_t)f * nseg * 4 + c) * SEG_NSP;
+    const SEG_AS_GLB uint32_t *dcnt = j.dcnt + (size_t)f * nseg * 4 + c;                       /* + sg * 4 */
+    SEG_AS_GLB uint32_t *entry = j.entry + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
+    const size_t mstep = 4 * (size_t)P.nsp, rstep = 4 * SEG_NSP;
+    const int nstates = P.ns;
+    const SegState start0 = { 0, 0, 0 };
+    const bool prof = (P.engine_flags & 1) != 0;
+    unsigned long long tc[5] = { 0, 0, 0, 0, 0 };
+    if (prof) tc[0] = PLS_CLOCK();
+    /* -- gather: T[k][d] = maps_{k+1}[rout_k[d]] and R[k][d] = the exit state itself (= entry state of segment k+1); per item three
+     *    loads in flight, then one dependent load; SEG_CQ items per thread at a time -- */
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid < 32) idxb[tid] = 0u; }
+    PLS_SYNC();
+    for (int pass = 0; pass < 2; pass++) {
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (pass == 0 && tid == SEG_CHAIN_THREADS - 1) {
+                SegPix b0 = seg_pix_make(0, 0, 0, 0, 0);
+                const uint32_t idx_first = sx ? j.firstidx[(f * 4 + c) * 2] : seg_any_encode(P, f, b0, start0);
+                idxb[29] = idx_first;
+                idxb[28] = (ns && idx_first != SEG_INVALID && (int)idx_first < nstates) ? (uint32_t)maps[(size_t)s0 * mstep + idx_first] : SEG_INVALID;
+                entry[(size_t)s0 * 4] = sx ? j.firstidx[(f * 4 + c) * 2 + 1] : seg_state_pack(start0);
+            }
+            const uint32_t total = ns << sh;
+            for (uint32_t base = 0; base < total; base += SEG_CQ * SEG_CHAIN_THREADS) {
+                uint32_t dcv[SEG_CQ], r[SEG_CQ], ps[SEG_CQ], v[SEG_CQ];
+                PLS_UNROLL
+                for (int q = 0; q < SEG_CQ; q++) {
+                    const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
+                    dcv[q] = 0; r[q] = SEG_INVALID; ps[q] = SEG_NOSTATE;
+                    if (t < total) {
+                        const uint32_t k = t >> sh, d = t & (stride - 1), sg = s0 + k;
+                        dcv[q] = dcnt[(size_t)sg * 4];
+                        r[q] = rout[(size_t)sg * rstep + d];
+                        if (useR) ps[q] = rst[(size_t)sg * rstep + d];
+                    }
+                }
+                PLS_UNROLL
+                for (int q = 0; q < SEG_CQ; q++) {
+                    const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
+                    const uint32_t k = t >> sh, d = t & (stride - 1), sg = s0 + k;
+                    const bool valid = t < total && d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
+                    v[q] = SEG_INVALID;
+                    if (valid && k + 1 < ns) v[q] = maps[(size_t)(sg + 1) * mstep + r[q]];
+                    if (!valid) ps[q] = SEG_NOSTATE;
+                }
+                PLS_UNROLL
+                for (int q = 0; q < SEG_CQ; q++) {
+                    const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
+                    if (t < total) {
+                        T[t] = (uint16_t)v[q];
+                        if (useR) R[t] = ps[q];
+                        if ((t & (stride - 1)) == 0 && (dcv[q] > stride || (P.engine_flags & 4))) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], dcv[q]); }
+                    }
+                }
+            }
+        }
+        PLS_SYNC();
+        if (pass == 1 || !idxb[30]) break;
+        sh = SEG_CR_SH + 1;                                     /* (flag 4: test hook) */
+        while ((1u << sh) < idxb[27] && sh < 8) sh++;
+        stride = 1u << sh; useR = false;
+    }
+    if (prof) tc[1] = PLS_CLOCK();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        if (tid < 256) seg_load_frozen(j, par, f, Hf, rank, tid, 256);
-        if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
-        for (uint32_t sg = s0 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) bpx[sg] = sg ? seg_pix_load(row, nab, j.err0, bpp, sg * SEG_L - 1, c) : seg_pix_make(0, 0, 0, 0, 0);
-        {
-            /* the maps, 16 bytes per load (a map is nmap * 2 bytes, contiguous) */
-            const int per = nmap / 8;                                   /* 16-byte pieces per map: 32 or 4 */
-            for (uint32_t i = (uint32_t)tid; i < ns * (uint32_t)per; i += SEG_CHAIN_THREADS) {
-                const uint32_t sg = s0 + i / (uint32_t)per, piece = i % (uint32_t)per;
-                const SegVec16 *src = (const SegVec16 *)(j.maps + (((size_t)f * nseg + sg) * 4 + c) * SEG_NSP) + piece;
-                ((SegVec16 *)(maps + (size_t)(sg - s0) * nmap))[piece] = *src;
+        /* block b composes T[b*CBLK .. (b+1)*CBLK - 1]: the id in its first segment -> the id in the next block's first segment */
+        for (uint32_t t = (uint32_t)tid; t + stride < (nblk << sh); t += SEG_CHAIN_THREADS) {
+            const uint32_t b = t >> sh;
+            uint32_t d = t & (stride - 1);
+            for (uint32_t k = b * SEG_CBLK; k < (b + 1) * SEG_CBLK; k++) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
+            G[t] = (uint16_t)d;
+        }
+    }
+    PLS_SYNC();
+    if (prof) tc[2] = PLS_CLOCK();
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        if ((uint32_t)tid < nblk) {
+            /* thread b: the true id at the head of block b (across the composed tables), then through the block */
+            uint32_t d = idxb[28];
+            for (uint32_t b = 0; b < (uint32_t)tid; b++) d = d == SEG_INVALID ? d : (uint32_t)G[((size_t)b << sh) + d];
+            for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k < ns; k++) {
+                dn[k] = d;
+                if (k + 1 < ns) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
             }
         }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        for (uint32_t t = (uint32_t)tid; t < nblk * (uint32_t)nmap; t += SEG_CHAIN_THREADS) {
-            const uint32_t b = t / (uint32_t)nmap;
-            uint32_t idx = t % (uint32_t)nmap;
-            for (uint32_t k = b * SEG_CBLK; k < (b + 1) * SEG_CBLK && k < ns; k++) idx = idx == SEG_INVALID ? idx : (uint32_t)maps[(size_t)k * nmap + idx];
-            G[t] = (uint16_t)idx;
+        /* entry state of segment s0+k+1 = exit state of segment s0+k under its id */
+        for (uint32_t k = (uint32_t)tid; k < ns; k += SEG_CHAIN_THREADS) {
+            const uint32_t d = dn[k];
+            uint32_t ps = SEG_NOSTATE;
+            if (d != SEG_INVALID && d < stride) {
+                if (useR) ps = R[((size_t)k << sh) + d];
+                else if (d < dcnt[(size_t)(s0 + k) * 4] && rout[(size_t)(s0 + k) * rstep + d] != SEG_INVALID) ps = rst[(size_t)(s0 + k) * rstep + d];
+            }
+            if (ps == SEG_NOSTATE) idxb[31] = 1u; else entry[(size_t)(s0 + k + 1) * 4] = ps;
         }
+        if (tid == 0 && (P.engine_flags & 2)) idxb[31] = 1u;     /* (test hook: the serial walk) */
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        if (tid == 0) {
-            const SegState start0 = { 0, 0, 0 };
-            const uint32_t idx_first = sx ? j.firstidx[(f * 4 + c) * 2] : seg_any_encode(P, f, bpx[0], start0);
-            uint32_t idx = idx_first;
-            uint32_t slow = 0;
-            for (uint32_t b = 0; b <= nblk; b++) {
-                idxb[b] = idx;
-                if (idx == SEG_INVALID) { slow = 1; break; }
-                if (b < nblk) idx = (uint32_t)G[(size_t)b * nmap + idx];
-            }
-            idxb[31] = slow;
-            if (slow) {
-                /* (rare) some state or lookup on the path lies outside what the enumeration covers: the whole chain step by step */
-                idx = idx_first;
+    if (prof) tc[3] = PLS_CLOCK();
+    if (idxb[31]) {
+        /* (rare) some state on the path lies outside what the enumeration covers: segment after segment, through its tables where
+         * that works, step by step where it does not */
+        const SegGeo G_ = seg_geo((int)ctl.s);
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (tid < 256) seg_load_frozen(j, par, f, Hf, rank, tid, 256);
+            if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (tid == 0) {
+                uint32_t idx = idxb[29];
                 SegState st = sx ? seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]) : start0;
                 for (uint32_t sg = s0; sg < nseg; sg++) {
-                    idxs[2 * sg] = idx;
-                    if (idx == SEG_INVALID) idxs[2 * sg + 1] = seg_state_pack(st);
+                    entry[(size_t)sg * 4] = seg_state_pack(st);
                     if (sg + 1 == nseg) break;
-                    uint32_t nidx = idx == SEG_INVALID ? SEG_INVALID : (uint32_t)maps[(size_t)(sg - s0) * nmap + idx];
-                    if (nidx == SEG_INVALID) {
-                        if (idx != SEG_INVALID) (void)seg_any_decode(P, f, (int)idx, bpx[sg], st);
+                    bool have = false;
+                    uint32_t nidx = SEG_INVALID;
+                    if (idx != SEG_INVALID && (int)idx < nstates) {
+                        const uint32_t dd = maps[(size_t)sg * mstep + idx];
+                        if (dd != SEG_INVALID && dd < dcnt[(size_t)sg * 4]) {
+                            const uint32_t ps = rst[(size_t)sg * rstep + dd];
+                            if (ps != SEG_NOSTATE) { st = seg_state_unpack(ps); nidx = rout[(size_t)sg * rstep + dd]; have = true; }
+                        }
+                    }
+                    if (!have) {
                         for (uint32_t x = sg * SEG_L; x < (sg + 1) * SEG_L && x < W; x++) {
                             const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
                             (void)seg_step_scan(f, p, st, Hf, nullptr, rank, G_, lut, P.bleed);
                         }
-                        nidx = seg_any_encode(P, f, bpx[sg + 1], st);
+                        const SegPix bp = seg_pix_load(row, nab, j.err0, bpp, (sg + 1) * SEG_L - 1, c);
+                        nidx = seg_any_encode(P, f, bp, st);
                     }
                     idx = nidx;
                 }
             }
         }
     }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        if (!idxb[31] && (uint32_t)tid <= nblk) {
-            /* inside block tid (the pseudo block nblk holds only the entry of the last segment when ns is a multiple of SEG_CBLK) */
-            uint32_t idx = idxb[tid];
-            for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k <= ns; k++) {
-                idxs[2 * (s0 + k)] = idx;
-                if (k < ns) idx = (uint32_t)maps[(size_t)k * nmap + idx];
+    if (prof) {
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (tid == 0) {
+                tc[4] = PLS_CLOCK();
+                for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[8 + q], (int32_t)(tc[q + 1] - tc[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[12 + q], (uint32_t)(tc[q + 1] - tc[q])); }
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[16], 1u);
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[17], idxb[31]);
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[18], useR ? 0u : 1u);
             }
-        }
-    }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        for (uint32_t sg = s0 + (uint32_t)tid; sg < nseg; sg += SEG_CHAIN_THREADS) {
-            uint32_t packed;
-            if (idxs[2 * sg] == SEG_INVALID) packed = idxs[2 * sg + 1];
-            else { SegState st{ 0, 0, 0 }; (void)seg_any_decode(P, f, (int)idxs[2 * sg], bpx[sg], st); packed = seg_state_pack(st); }
-            j.entry[((size_t)f * nseg + sg) * 4 + c] = packed;
         }
     }
 }
@@ -1600,7 +1700,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 24; i++) j.result[i] = 0;
+                    for (int i = 0; i < 24; i++) if (i < 8 || i > 18 || !(P.engine_flags & 1)) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
                     j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
                     if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);

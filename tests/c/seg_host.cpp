@@ -30,6 +30,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     static SegParams P;
     if (!seg_build_params(P, (int)strength, (int)bleed)) return 64;
     if (getenv("SEG_HOST_FORCE_FILTER")) P.engine_flags = (atoi(getenv("SEG_HOST_FORCE_FILTER")) + 1) << 8;
+    if (getenv("SEG_HOST_FLAGS")) P.engine_flags |= atoi(getenv("SEG_HOST_FLAGS")) & 0xfe;   /* test hooks of the chain kernel (2: slow path, 4: wide stride) */
     /* classify + pack into slots (what pl_classify / pl_repack do on the device) */
     bool gray = true, opaque = true;
     for (size_t i = 0; i < (size_t)W * H; i++) { const unsigned char *p = rgba + 4 * i; gray &= p[0] == p[1] && p[1] == p[2]; opaque &= p[3] == 255; }
@@ -67,7 +68,10 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     if (j.nseg > SEG_MAX_NSEG) return 64;
     j.ctl = A.take<SegCtl>(2); j.base = A.take<uint32_t>(2 * 5 * 256); j.H0 = A.take<uint32_t>(2 * 256); j.acc = A.take<SegAcc>(2);
     j.tables = A.take<uint32_t>(5 * SEG_TBL_WORDS);
-    j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
+    j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * P.nsp);
+    j.rout = A.take<uint16_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
+    j.rst = A.take<uint32_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
+    j.dcnt = A.take<uint32_t>((size_t)5 * j.nseg * 4);
     j.entry = A.take<uint32_t>((size_t)5 * j.nseg * 4);
     j.segcnt = A.take<uint16_t>((size_t)5 * j.nseg * 256);
     j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);

@@ -340,7 +340,10 @@ def test_segment_engine_strengths_and_bleeds_with_few_and_many_states(monkeypatc
     and commit-workgroup (1024) sizes; every byte-per-pixel class."""
     monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
     for (w, h, m, s, b) in [(31, 9, 0, 19, 2), (32, 9, 1, 19, 2), (33, 9, 2, 19, 2), (511, 7, 3, 19, 2), (513, 7, 4, 19, 2), (1025, 6, 5, 19, 2),
-                            (200, 30, 0, 0, 2), (200, 30, 1, 3, 1), (200, 30, 5, 7, 3), (200, 30, 0, 20, 8), (200, 30, 2, 19, 4), (200, 30, 1, 19, 32767), (200, 30, 0, 30, 3)]:
+                            (200, 30, 0, 0, 2), (200, 30, 1, 3, 1), (200, 30, 5, 7, 3), (200, 30, 0, 20, 8), (200, 30, 2, 19, 4), (200, 30, 1, 19, 32767), (200, 30, 0, 30, 3),
+                            # state sets enumerated in several chunks of lanes (259 .. 955 states), rows whose segments have more distinct
+                            # states than the chain kernel's usual table stride
+                            (1100, 12, 0, 20, 2), (1100, 12, 1, 20, 1), (700, 16, 2, 40, 2), (1100, 12, 0, 85, 8), (520, 16, 4, 26, 2), (300, 16, 3, 40, 2)]:
         img = P.synth_rgba(w, h, m, 2)
         o1, f1 = U.run_port(img, s, b)
         o2, f2 = P.optimize_with_rows(img, s, b)

@@ -13,6 +13,8 @@ CASES = [(64, 48, m, 19, 2) for m in range(6)] + [
     (1, 1, 1, 19, 2), (2, 3, 1, 19, 2), (5, 1, 1, 19, 2), (1, 7, 1, 19, 2), (33, 5, 3, 19, 2), (64, 6, 4, 0, 2),
     (31, 9, 0, 19, 2), (32, 9, 0, 19, 2), (65, 9, 5, 19, 2), (511, 6, 0, 19, 2), (513, 6, 1, 19, 2), (96, 20, 0, 3, 1),
     (80, 12, 1, 19, 32767),
+    # state sets enumerated in several chunks of lanes (259 .. 955 states)
+    (260, 24, 0, 20, 2), (200, 24, 1, 20, 1), (200, 20, 2, 40, 2), (200, 20, 0, 85, 8), (150, 20, 4, 26, 2), (150, 16, 3, 40, 2),
 ]
 
 
@@ -35,6 +37,18 @@ def test_seg_engine_speculation_is_right_almost_always():
     assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
     attempts, restarts, serial = int(st[0]), int(st[1]), int(st[3])
     assert attempts <= 128 + 16 and restarts <= 12 and serial == 0, (attempts, restarts, serial)
+
+
+@pytest.mark.parametrize("flags", [2, 4, 6])
+@pytest.mark.parametrize("w,h,mode,s,b", [(333, 37, 3, 19, 2), (520, 24, 0, 19, 2), (300, 24, 1, 20, 1), (200, 20, 4, 26, 2)])
+def test_seg_engine_chain_fallback_paths(monkeypatch, flags, w, h, mode, s, b):
+    """the chain kernel's rare paths, forced through its test hooks: 2 = the serial walk for states outside the enumeration,
+    4 = the row-wide table stride for rows with more distinct states per segment than the fast stride"""
+    monkeypatch.setenv("SEG_HOST_FLAGS", str(flags))
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
 
 
 def test_seg_engine_all_rows_adaptive():
