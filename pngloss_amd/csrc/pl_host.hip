@@ -144,7 +144,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
         s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
         s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
         s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps);
-        s.rout = reinterpret_cast<uint16_t *>(base + l.rout); s.rst = reinterpret_cast<uint32_t *>(base + l.rst); s.dcnt = reinterpret_cast<uint32_t *>(base + l.dcnt);
+        s.rout = reinterpret_cast<uint16_t *>(base + l.rout); s.rst = reinterpret_cast<uint32_t *>(base + l.rst); s.rck = reinterpret_cast<uint32_t *>(base + l.rck); s.dnout = reinterpret_cast<uint16_t *>(base + l.dnout); s.dcnt = reinterpret_cast<uint32_t *>(base + l.dcnt);
         s.entry = reinterpret_cast<uint32_t *>(base + l.entry); s.segcnt = reinterpret_cast<uint16_t *>(base + l.segcnt);
         s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt);
         s.firstidx = reinterpret_cast<uint32_t *>(base + l.firstidx); s.rowmm = reinterpret_cast<int32_t *>(base + l.rowmm);

@@ -115,6 +115,8 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp)
     l.maps = take((size_t)SEG_NFILT * l.nseg * 4 * nsp * 2);
     l.rout = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 2);
     l.rst = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 4);
+    l.rck = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * (SEG_PARTS - 1) * 4);
+    l.dnout = take((size_t)SEG_NFILT * l.nseg * 4 * 2);
     l.dcnt = take((size_t)SEG_NFILT * l.nseg * 4 * 4);
     l.entry = take((size_t)SEG_NFILT * l.nseg * 4 * 4);
     l.segcnt = take((size_t)SEG_NFILT * l.nseg * 256 * 2);

@@ -115,10 +115,15 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define PLS_UNROLL
 #endif
 #define SEG_NFILT 5
+#ifndef SEG_DEBUG_COUNT
+#define SEG_DEBUG_COUNT(slot, v)   /* (the CPU harness counts a few things the tests pin) */
+#endif
 #ifndef SEG_L
 #define SEG_L 32                 /* pixels per segment (16 was measured: enumeration -5 us, chain +5 us, no gain) */
 #endif
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
+#define SEG_PARTS 4               /* the replay cuts a segment into this many parts: the enumeration leaves the state at every cut (checkpoints) */
+#define SEG_PL (SEG_L / SEG_PARTS)
 #define SEG_NSP 256              /* lanes per channel in the enumeration; also the most DISTINCT states a segment may have after the dedupe */
 #define SEG_NS_MAX 1024          /* most chain states of a (strength, bleed) pair the engine takes (enumerated in chunks of SEG_NSP) */
 #define SEG_TOFF 320             /* decision tables cover v in [-320, 319] */
@@ -130,7 +135,7 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_MAX_NSEG 256              /* the chain kernel keeps a row's maps in shared memory: 256 x 512 B */
 #define SEG_THREADS 1024
 #define SEG_CHAIN_THREADS 1024
-#define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* every thread loads one pixel of the group, 64 of them walk */
+#define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* every thread loads one pixel of the group, SEG_GRP * SEG_PARTS * 4 of them walk */
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
 #define SEG_SMALL_SEGS 8           /* segments per enumeration workgroup for them: 8 segments x 4 channels x SEG_NSS lanes */
@@ -201,6 +206,8 @@ struct SegJob {
     SEG_AS_GLB uint16_t *maps;           /* [5][nseg][4][nsp]: entry index of a segment -> dense id of its state after the dedupe (0xffff: none) */
     SEG_AS_GLB uint16_t *rout;           /* [5][nseg][4][SEG_NSP]: dense id -> exit index of the segment (0xffff: left what the tables cover) */
     SEG_AS_GLB uint32_t *rst;            /* [5][nseg][4][SEG_NSP]: dense id -> exit state of the segment, packed (0xffffffff: none) */
+    SEG_AS_GLB uint32_t *rck;            /* [5][nseg][4][SEG_NSP][SEG_PARTS-1]: dense id -> state in front of part 1, 2, .. of the segment (0xffffffff: none) */
+    SEG_AS_GLB uint16_t *dnout;          /* [5][nseg][4]: the dense id the row's true path has in every segment (chain kernel; 0xffff: unknown) */
     SEG_AS_GLB uint32_t *dcnt;           /* [5][nseg][4]: distinct states of the segment */
     SEG_AS_GLB uint32_t *entry;          /* [5][nseg][4] */
     SEG_AS_GLB uint16_t *segcnt;         /* [5][nseg][256] */
@@ -581,7 +588,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 /* shared-memory budgets (bytes) */
 #define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64 + 4 * 512 * 4 + 4 * 512 * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + SEG_THREADS * 2 + SEG_THREADS * 4 + 64)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
-#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + 64)
+#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + SEG_TBL_WORDS * 4 + 64)
 
@@ -628,7 +635,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     if (ctl.finished || ctl.active[f] != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     const uint32_t x0 = (uint32_t)seg * SEG_L;
-    if (x0 + SEG_L >= W) return;                              /* the last segment has no successor */
+    if (x0 >= W) return;                                      /* (the last segment has no successor, but the replay wants its checkpoints) */
     if (ctl.start_x[f] && x0 <= ctl.start_x[f]) return;       /* an epoch that starts inside the row: its first (partial) segment is walked by
                                                                  seg_first_body.  A fresh row starts from the known state in front of pixel 0,
                                                                  which has an index like any other (boundary record = zeros): segment 0 is
@@ -731,10 +738,16 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
             SegState st;
             st.left = (int)(key & 255u); st.cn = seg_sext8((int)(key >> 8)); st.th = seg_sext8((int)(key >> 16));
             uint32_t out = SEG_INVALID;
-            const int bad = seg_run_fast_f(f, trx, px + (1 + SEG_K1) * 4 + c, 4, SEG_L - SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            /* to the end of part 0, then part by part: the state at every cut is a checkpoint the replay starts a lane from */
+            const size_t slot = (((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i;
+            int bad = seg_run_fast_f(f, trx, px + (1 + SEG_K1) * 4 + c, 4, SEG_PL - SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            for (int part = 1; part < SEG_PARTS; part++) {
+                j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                bad |= seg_run_fast_f(f, trx, px + (1 + part * SEG_PL) * 4 + c, 4, SEG_PL, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            }
             if (!bad) out = seg_state_encode(P, px[SEG_L * 4 + c], st);
-            j.rout[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = (uint16_t)out;
-            j.rst[(((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+            j.rout[slot] = (uint16_t)out;
+            j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
         }
         if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
         if (prof && tid == 0) {
@@ -775,12 +788,19 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
     PLS_THREADS(tid, SEG_THREADS) {
         const int sl = tid / (4 * SEG_NSS), c = (tid / SEG_NSS) & 3, i = tid % SEG_NSS;
         const uint32_t seg = (uint32_t)seg0 + (uint32_t)sl, x0 = seg * SEG_L;
-        if (seg < j.nseg && x0 + SEG_L < W && (x0 > ctl.start_x[f] || ctl.start_x[f] == 0) && (uint32_t)c < bpp && i < P.ns_small) {
+        if (seg < j.nseg && x0 < W && (x0 > ctl.start_x[f] || ctl.start_x[f] == 0) && (uint32_t)c < bpp && i < P.ns_small) {
             SegState st;
             uint32_t out = SEG_INVALID;
+            const size_t slot = (((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i;
             if (seg_small_decode(P, i, st)) {
-                const int bad = seg_run_fast_f(f, trx, px + (sl * SEG_L) * 4 + c, 4, SEG_L, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                int bad = 0;
+                for (int part = 0; part < SEG_PARTS; part++) {
+                    if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                    bad |= seg_run_fast_f(f, trx, px + (sl * SEG_L + part * SEG_PL) * 4 + c, 4, SEG_PL, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                }
                 if (!bad) out = seg_small_encode(P, st);
+            } else {
+                for (int part = 1; part < SEG_PARTS; part++) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = 0xFFFFFFFFu;
             }
             /* no dedupe for the handful of (cn, th) states: the dense id of an entry index is the index itself */
             j.maps[(((size_t)f * j.nseg + seg) * 4 + c) * (size_t)P.nsp + i] = (uint16_t)i;
@@ -894,9 +914,12 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     const uint32_t sx = ctl.start_x[f];
     if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
+    SEG_AS_GLB uint16_t *dnout = j.dnout + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
+    if (sx || nseg == 1) { PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) dnout[(size_t)first * 4] = (uint16_t)SEG_INVALID; } }   /* a walked first segment has no checkpoints */
     if (first + 1 >= nseg) return;
-    const uint32_t s0 = sx ? first + 1 : 0u, ns = nseg - 1 - s0;   /* enumerated segments s0 .. s0+ns-1; entries wanted for s0 .. nseg-1 (a fresh row: from 0) */
-    const uint32_t nblk = (ns + SEG_CBLK - 1) / SEG_CBLK;
+    /* enumerated segments s0 .. nseg-1 (ne of them; a fresh row: from 0); ns = ne - 1 transitions, and as many entry states (of s0+1 .. nseg-1) */
+    const uint32_t s0 = sx ? first + 1 : 0u, ne = nseg - s0, ns = ne - 1;
+    const uint32_t nblk = (ne + SEG_CBLK - 1) / SEG_CBLK;
     /* table stride: SEG_CR_MAX entries per segment cover nearly every row (measured: 17 distinct states per segment on average);
      * a row with a segment beyond that is gathered again at the widest stride */
     uint32_t sh = SEG_CR_SH;
@@ -904,7 +927,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     bool useR = true;
     uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512;   /* (slow path only) */
     seg_lds_u32 idxb = (seg_lds_u32)(Hf + 1024);               /* [32]: [27] most distinct states of a segment (only when [30]), [28] dense id the chain starts with, [29] its entry index, [30] some segment has more distinct states than the stride, [31] slow path needed */
-    seg_lds_u32 dn = idxb + 32;                                /* [ns] dense id inside every enumerated segment */
+    seg_lds_u32 dn = idxb + 32;                                /* [ne] dense id inside every enumerated segment */
     seg_lds_u16 G = (seg_lds_u16)(dn + ((nseg + 1) & ~1u));    /* [nblk][stride] composed tables of the blocks */
     seg_lds_u16 T = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;   /* [ns][stride]: T[k] takes a dense id of segment s0+k to one of segment s0+k+1 */
     seg_lds_u32 R = (seg_lds_u32)(T + (size_t)((ns + 1) & ~1u) * stride);    /* [ns][stride] (useR): exit state of segment s0+k under that id */
@@ -931,7 +954,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                 SegPix b0 = seg_pix_make(0, 0, 0, 0, 0);
                 const uint32_t idx_first = sx ? j.firstidx[(f * 4 + c) * 2] : seg_any_encode(P, f, b0, start0);
                 idxb[29] = idx_first;
-                idxb[28] = (ns && idx_first != SEG_INVALID && (int)idx_first < nstates) ? (uint32_t)maps[(size_t)s0 * mstep + idx_first] : SEG_INVALID;
+                idxb[28] = (idx_first != SEG_INVALID && (int)idx_first < nstates) ? (uint32_t)maps[(size_t)s0 * mstep + idx_first] : SEG_INVALID;
                 entry[(size_t)s0 * 4] = sx ? j.firstidx[(f * 4 + c) * 2 + 1] : seg_state_pack(start0);
             }
             const uint32_t total = ns << sh;
@@ -954,7 +977,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                     const uint32_t k = t >> sh, d = t & (stride - 1), sg = s0 + k;
                     const bool valid = t < total && d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
                     v[q] = SEG_INVALID;
-                    if (valid && k + 1 < ns) v[q] = maps[(size_t)(sg + 1) * mstep + r[q]];
+                    if (valid) v[q] = maps[(size_t)(sg + 1) * mstep + r[q]];
                     if (!valid) ps[q] = SEG_NOSTATE;
                 }
                 PLS_UNROLL
@@ -991,17 +1014,19 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
             /* thread b: the true id at the head of block b (across the composed tables), then through the block */
             uint32_t d = idxb[28];
             for (uint32_t b = 0; b < (uint32_t)tid; b++) d = d == SEG_INVALID ? d : (uint32_t)G[((size_t)b << sh) + d];
-            for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k < ns; k++) {
+            for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k < ne; k++) {
                 dn[k] = d;
-                if (k + 1 < ns) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
+                if (k < ns) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
             }
         }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         /* entry state of segment s0+k+1 = exit state of segment s0+k under its id */
-        for (uint32_t k = (uint32_t)tid; k < ns; k += SEG_CHAIN_THREADS) {
+        for (uint32_t k = (uint32_t)tid; k < ne; k += SEG_CHAIN_THREADS) {
             const uint32_t d = dn[k];
+            dnout[(size_t)(s0 + k) * 4] = (uint16_t)(d < stride ? d : SEG_INVALID);
+            if (k >= ns) continue;
             uint32_t ps = SEG_NOSTATE;
             if (d != SEG_INVALID && d < stride) {
                 if (useR) ps = R[((size_t)k << sh) + d];
@@ -1028,6 +1053,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                 SegState st = sx ? seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]) : start0;
                 for (uint32_t sg = s0; sg < nseg; sg++) {
                     entry[(size_t)sg * 4] = seg_state_pack(st);
+                    dnout[(size_t)sg * 4] = (uint16_t)SEG_INVALID;       /* (whole segments from their entry states) */
                     if (sg + 1 == nseg) break;
                     bool have = false;
                     uint32_t nidx = SEG_INVALID;
@@ -1064,7 +1090,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     }
 }
 
-/* ---- REPLAY: task (f, grp): lane = (segment of the group, channel) ------------------------------------------------------ */
+/* ---- REPLAY: task (f, grp): lane = (segment of the group, part of the segment, channel) -----------------------------------
+ * A lane starts from a state it knows: part 0 from the segment's entry state, part p from the checkpoint the enumeration left for
+ * the segment's dense id.  A part without a checkpoint is walked by the lane in front of it. */
 PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -1078,10 +1106,39 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
     SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_GRP][SEG_L][4] */
     uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
+    uint32_t *lane = cnt + SEG_GRP * 256;                     /* [SEG_GRP * SEG_PARTS * 4][2]: start state, first | end pixel << 16 (or ~0: idle) */
     const uint32_t y = ctl.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        /* the walkers' start states first: two dependent loads (dense id, then its checkpoints), in flight while the tables come in */
+        uint32_t st0 = 0, range = 0xFFFFFFFFu;
+        if (tid < SEG_GRP * SEG_PARTS * 4) {
+            const int sl = tid / (SEG_PARTS * 4), part = (tid >> 2) % SEG_PARTS, c = tid & 3;
+            const uint32_t sg = seg0 + (uint32_t)sl;
+            if (sg < nseg && sg >= first && (uint32_t)c < bpp) {
+                const size_t sc = ((size_t)f * nseg + sg) * 4 + c;
+                const uint32_t d = j.dnout[sc];
+                uint32_t ck[SEG_PARTS - 1];
+                for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = 0xFFFFFFFFu;
+                if (d != SEG_INVALID && d < SEG_NSP)
+                    for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = j.rck[(sc * SEG_NSP + d) * (SEG_PARTS - 1) + q];
+                const uint32_t x0 = sg * SEG_L, xend = (uint32_t)seg_min((int)(x0 + SEG_L), (int)W);
+                /* this lane's part has a start state: part 0 always (entry state, or the epoch's start inside the row's first segment) */
+                bool mine = part == 0;
+                uint32_t xa = sg == first ? sx : x0;
+                if (part == 0) st0 = sg == first ? ctl.state[f][c] : j.entry[sc];
+                else if (ck[part - 1] != 0xFFFFFFFFu && x0 + (uint32_t)part * SEG_PL < xend && x0 + (uint32_t)part * SEG_PL > xa) { mine = true; st0 = ck[part - 1]; xa = x0 + (uint32_t)part * SEG_PL; }
+                if (mine) {
+                    uint32_t xe = xend;                        /* up to the next part that starts on its own */
+                    for (int q = SEG_PARTS - 1; q > part; q--)
+                        if (ck[q - 1] != 0xFFFFFFFFu && x0 + (uint32_t)q * SEG_PL < xend && x0 + (uint32_t)q * SEG_PL > xa) xe = x0 + (uint32_t)q * SEG_PL;
+                    range = (xa - seg0 * SEG_L) | ((xe - seg0 * SEG_L) << 16);
+                    SEG_DEBUG_COUNT(part ? 1 : 0, xe - xa);
+                }
+            }
+            lane[2 * tid] = st0; lane[2 * tid + 1] = range;
+        }
         seg_load_frozen(j, par, f, Hf, rank, tid, SEG_REPLAY_THREADS);
         for (int i = tid; i < 512; i += SEG_REPLAY_THREADS) lut[i] = P.lut_a[i];
         for (int i = tid; i < SEG_TBL_WORDS; i += SEG_REPLAY_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
@@ -1090,12 +1147,12 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-        const int sl = tid >> 2, c = tid & 3;
-        const uint32_t sg = seg0 + (uint32_t)sl;
-        if (tid < SEG_GRP * 4 && sg < nseg && sg >= first && (uint32_t)c < bpp) {
-            SegState st = sg == first ? seg_state_unpack(ctl.state[f][c]) : seg_state_unpack(j.entry[((size_t)f * nseg + sg) * 4 + c]);
-            const uint32_t xa = sg == first ? sx : sg * SEG_L, xe = (uint32_t)seg_min((int)((sg + 1) * SEG_L), (int)W);
-            seg_walk(f, px + (xa - seg0 * SEG_L) * 4 + c, 4, xa, xe, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed,
+        if (tid < SEG_GRP * SEG_PARTS * 4 && lane[2 * tid + 1] != 0xFFFFFFFFu) {
+            const int sl = tid / (SEG_PARTS * 4), c = tid & 3;
+            SegState st = seg_state_unpack(lane[2 * tid]);
+            const uint32_t ra = lane[2 * tid + 1] & 0xffffu, re = lane[2 * tid + 1] >> 16;       /* pixels of the group */
+            const uint32_t xa = seg0 * SEG_L + ra, xe = seg0 * SEG_L + re;
+            seg_walk(f, px + ra * 4 + c, 4, xa, xe, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed,
                      j.cand + ((size_t)f * W + xa) * 4 + c, cnt + sl * 256);
         }
     }

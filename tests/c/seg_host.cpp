@@ -7,6 +7,8 @@
  *   seg_host_optimize(rgba, W, H, row_filters|NULL, strength, bleed, stats[8])  -> 0, or 64 if (strength, bleed) has more
  *   chain states than the enumeration has lanes (the product then uses the one-workgroup-per-image engine)
  */
+static unsigned long long seg_dbg[4][2];   /* [slot]: events, sum */
+#define SEG_DEBUG_COUNT(slot, v) (seg_dbg[slot][0]++, seg_dbg[slot][1] += (v))
 #include "../../pngloss_amd/csrc/pl_seg_core.h"
 
 #include <cstdio>
@@ -71,6 +73,8 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * P.nsp);
     j.rout = A.take<uint16_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
     j.rst = A.take<uint32_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
+    j.rck = A.take<uint32_t>((size_t)5 * j.nseg * 4 * SEG_NSP * (SEG_PARTS - 1));
+    j.dnout = A.take<uint16_t>((size_t)5 * j.nseg * 4);
     j.dcnt = A.take<uint32_t>((size_t)5 * j.nseg * 4);
     j.entry = A.take<uint32_t>((size_t)5 * j.nseg * 4);
     j.segcnt = A.take<uint16_t>((size_t)5 * j.nseg * 256);
@@ -96,6 +100,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_post_body(j, P, par, f, (int)g, smem.data());
     }
     const SegCtl &fc = j.ctl[attempt & 1];
+    if (getenv("SEG_HOST_VERBOSE")) fprintf(stderr, "seg_host: replay lanes from an entry state %llu (%.1f px each), from a checkpoint %llu (%.1f px each)\n", seg_dbg[0][0], seg_dbg[0][0] ? (double)seg_dbg[0][1] / seg_dbg[0][0] : 0.0, seg_dbg[1][0], seg_dbg[1][0] ? (double)seg_dbg[1][1] / seg_dbg[1][0] : 0.0);
     if (stats) { stats[0] = (uint32_t)attempt; stats[1] = fc.restarts_total; stats[2] = fc.retried; stats[3] = fc.serial_rows; stats[4] = (uint32_t)j.result[2]; stats[5] = bpp; stats[6] = (uint32_t)P.ns; stats[7] = fc.status; }
     /* unpack (pl_unpack) */
     for (size_t i = 0; i < (size_t)W * H; i++) {
