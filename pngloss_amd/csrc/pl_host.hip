@@ -343,6 +343,12 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
                              r[40] / 100.0, r[41] / 100.0, r[42] / 100.0, r[43] / 100.0, r[44] / 100.0, r[46], r[47]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF"))
                 std::fprintf(stderr, "pngloss_hip:   control kernel, slowest (us): candidate workgroup up to the table build %.1f, table build %.1f, commit workgroup %.1f\n", r[56] / 100.0, r[57] / 100.0, r[58] / 100.0);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61] && r[63])
+                std::fprintf(stderr, "pngloss_hip:   ... average (us): candidate workgroup up to the table build %.2f, table build %.2f, commit workgroup %.2f\n",
+                             (uint32_t)r[59] / 100.0 / (uint32_t)r[61], (uint32_t)r[60] / 100.0 / (uint32_t)r[61], (uint32_t)r[62] / 100.0 / (uint32_t)r[63]);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
+                std::fprintf(stderr, "pngloss_hip:   ... table build, average (us): keys %.2f, classes %.2f, entries + write %.2f\n",
+                             (uint32_t)r[37] / 100.0 / (uint32_t)r[61], (uint32_t)r[38] / 100.0 / (uint32_t)r[61], (uint32_t)r[39] / 100.0 / (uint32_t)r[61]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[32])
                 std::fprintf(stderr, "pngloss_hip:   enumeration workgroups (us), slowest / average: load %.1f / %.2f  first %d steps + dedupe %.1f / %.2f  remaining steps %.1f / %.2f  map %.1f / %.2f; distinct states per channel after the dedupe %.1f; first-segment walker %.1f / %.2f\n",
                              r[24] / 100.0, (uint32_t)r[28] / 100.0 / (uint32_t)r[32], SEG_K1, r[25] / 100.0, (uint32_t)r[29] / 100.0 / (uint32_t)r[32], r[26] / 100.0, (uint32_t)r[30] / 100.0 / (uint32_t)r[32],

@@ -183,6 +183,9 @@ struct SegAcc {
     uint64_t none_lb;                /* lower bound of candidate none's row cost (seg_post_body) */
 };
 
+static_assert(sizeof(SegCtl) / 4 <= 128 && sizeof(SegAcc) / 4 <= 128, "the control kernel copies both with 128 lanes each");
+static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 <= 4 * SEG_TN, "they live in the table staging area, below the classes");
+
 struct SegJob {
     SEG_AS_GLB uint32_t *img;            /* slots image (pl_device.h) */
     SEG_AS_GLB uint8_t *row_filters;     /* or null */
@@ -267,6 +270,13 @@ PLS_HD void seg_rem_thr(const uint32_t *lut_a, int bleed, int diff, int &rem, in
     else { const SegSplit s = seg_split_slow(diff, bleed); rem = s.rem; thr = s.h; }
 }
 PLS_HD uint32_t seg_terms(const uint32_t *lut_b, int bleed, int diff)
+{
+    if (diff >= -256 && diff <= 255) return lut_b[diff + 256];
+    const SegSplit s = seg_split_slow(diff, bleed);
+    return ((uint32_t)s.t & 255u) | (((uint32_t)s.f & 255u) << 8) | (((uint32_t)s.v & 255u) << 16) | ((uint32_t)s.h << 24);
+}
+
+PLS_HD uint32_t seg_terms_lds(seg_lds_u32 lut_b, int bleed, int diff)
 {
     if (diff >= -256 && diff <= 255) return lut_b[diff + 256];
     const SegSplit s = seg_split_slow(diff, bleed);
@@ -590,7 +600,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
-#define SEG_SM_CTL (256 * 4 * 4 + SEG_TBL_WORDS * 4 + 64)
+#define SEG_SM_CTL (256 * 4 * 4 + (512 + (SEG_THREADS + 4) * 4 + SEG_THREADS * 4) * 4 + 64)   /* (commit: 8 + 512 + tile + ext words; candidates: 1024 + SEG_TBL_WORDS) */   /* (the commit workgroups' tile is the larger use; a candidate's tables need SEG_TBL_WORDS) */
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad > 0 when the lane left the tables */
 template <int F, bool TRX>
@@ -1625,79 +1635,207 @@ PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, 
  * Tie classes are band local: cls[sgn][b] = offset inside its band (of that sign) of the FIRST bin with the same (H, rank) as bin b,
  * so two bins of one band have equal classes iff their keys are equal -- all the tie test of seg_step_fast needs (the original
  * symbol and the leader it may replace always lie in the same band). */
-PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u32 rank, seg_lds_u32 scratch, seg_lds_u32 stage, int s, int q, int nt)
+PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u32 rank, seg_lds_u32 scratch, seg_lds_u32 stage, int s, int q, int nt, int32_t *profslots = nullptr)
 {
-    (void)scratch;
+    unsigned long long tb[4] = { 0, 0, 0, 0 };
+    if (profslots) tb[0] = PLS_CLOCK();
     seg_lds_u8 cls = (seg_lds_u8)(stage + 4 * SEG_TN);        /* [2][256] */
+    /* [256] (H << 32 | rank) of a bin: one 64-bit read and one compare per bin (scratch: 512 words) */
+    SEG_AS_LDS uint64_t *K = (SEG_AS_LDS uint64_t *)scratch;
+    PLS_THREADS(tid, nt) { for (int b = tid; b < 256; b += nt) K[b] = ((uint64_t)H[b] << 32) | rank[b]; }
+    PLS_SYNC();
+    if (profslots) tb[1] = PLS_CLOCK();
     PLS_THREADS(tid, nt) {
-        for (int i = tid; i < 4 * SEG_TN; i += nt) stage[i] = 0u;
         for (int i = tid; i < 512; i += nt) {
             /* class of bin b in the band system of sign sgn: v = the value of the bin in that system */
             const int sgn = i >> 8, b = i & 255;
             const int v = sgn ? (b ? b - 256 : 0) : b;                    /* negative system: bins 1..255 are v = b - 256, bin 0 is v = 0 */
             const int t = (sgn ? -v : v) / q;
             const int blo = sgn ? -(t * q) - s : t * q;
-            const uint32_t hb = H[b], rb = rank[b];
+            const uint64_t kb = K[b];
             int first = v - blo;
-            for (int u = blo; u < v; u++) if (H[u & 255] == hb && rank[u & 255] == rb) { first = u - blo; break; }
+            /* four reads in flight per turn (indices past the range are clamped onto its end: they change nothing) */
+            for (int u = v - 1; u >= blo; u -= 4) {
+                const int u1 = seg_max(u - 1, blo), u2 = seg_max(u - 2, blo), u3 = seg_max(u - 3, blo);
+                const uint64_t k0 = K[u & 255], k1 = K[u1 & 255], k2 = K[u2 & 255], k3 = K[u3 & 255];
+                if (k0 == kb) first = u - blo;
+                if (k1 == kb) first = u1 - blo;
+                if (k2 == kb) first = u2 - blo;
+                if (k3 == kb) first = u3 - blo;
+            }
             cls[i] = (uint8_t)first;
         }
     }
     PLS_SYNC();
-    PLS_THREADS(tid, nt) {
-        const int nb = SEG_TOFF / q + 1;                                   /* bands per sign that touch [-320, 319] */
-        for (int i = tid; i < nb * 4; i += nt) {
-            const int t = i >> 2, sgn = (i >> 1) & 1, dir = i & 1;
-            const int blo = sgn ? -(t * q) - s : t * q, bhi = blo + s;
-            seg_lds_u32 dst = stage + (dir ? 2 * SEG_TN : 0) + sgn * SEG_TN;
-            int L = 0; uint32_t bh = 0, br = 0; bool have = false;
-            if (!dir) {
-                for (int v = blo; v <= bhi; v++) {                         /* prefix leaders: lowest v among equals */
-                    const uint32_t h = H[v & 255], r = rank[v & 255];
-                    if (!have || h > bh || (h == bh && r > br)) { L = v; bh = h; br = r; have = true; }
-                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((uint32_t)(L - blo) << 16);
-                }
-            } else {
-                for (int v = bhi; v >= blo; v--) {                         /* suffix leaders: scanning down, equals replace */
-                    const uint32_t h = H[v & 255], r = rank[v & 255];
-                    if (!have || h > bh || (h == bh && r >= br)) { L = v; bh = h; br = r; have = true; }
-                    if (v >= -SEG_TOFF && v < SEG_TOFF) dst[v + SEG_TOFF] = (uint32_t)(L + 512) | ((uint32_t)(L - blo) << 16);
-                }
-            }
-        }
-    }
-    PLS_SYNC();
-    /* the leader's class in an entry must be the class of ITS key: the first equal bin of the band, not the leader's own offset */
+    if (profslots) tb[2] = PLS_CLOCK();
+    /* one entry per thread and turn: the leader of [bandlo, v] (prefix) or [v, bandhi] (suffix) = largest (H, rank), lowest v among equals */
     PLS_THREADS(tid, nt) {
         for (int i = tid; i < 4 * SEG_TN; i += nt) {
-            const uint32_t e = stage[i];
-            if (e) { const int sgn = (i / SEG_TN) & 1, L = (int)(e & 0xffffu) - 512; stage[i] = (e & 0xffffu) | ((uint32_t)cls[sgn * 256 + (L & 255)] << 16); }
+            const int dir = i / (2 * SEG_TN), sgn = (i / SEG_TN) & 1, v = i % SEG_TN - SEG_TOFF;
+            uint32_t e = 0u;
+            if (sgn ? v <= 0 : v >= 0) {
+                const int t = (sgn ? -v : v) / q;
+                const int blo = sgn ? -(t * q) - s : t * q, bhi = blo + s;
+                const int ua = dir ? v : blo, ue = dir ? bhi : v;
+                int L = ua; uint64_t bk = K[ua & 255];
+                for (int u = ua + 1; u <= ue; u += 4) {
+                    const int u1 = seg_min(u + 1, ue), u2 = seg_min(u + 2, ue), u3 = seg_min(u + 3, ue);
+                    const uint64_t k0 = K[u & 255], k1 = K[u1 & 255], k2 = K[u2 & 255], k3 = K[u3 & 255];
+                    if (k0 > bk) { L = u; bk = k0; }
+                    if (k1 > bk) { L = u1; bk = k1; }
+                    if (k2 > bk) { L = u2; bk = k2; }
+                    if (k3 > bk) { L = u3; bk = k3; }
+                }
+                e = (uint32_t)(L + 512) | ((uint32_t)cls[sgn * 256 + (L & 255)] << 16);     /* the class of the leader's key: the first equal bin of its band */
+            }
+            out[i] = e;
         }
+        for (int i = tid; i < SEG_TBL_WORDS - 4 * SEG_TN; i += nt) out[4 * SEG_TN + i] = stage[4 * SEG_TN + i];
     }
     PLS_SYNC();
-    PLS_THREADS(tid, nt) { for (int i = tid; i < SEG_TBL_WORDS; i += nt) out[i] = stage[i]; }
-    PLS_SYNC();
+    if (profslots) { PLS_THREADS(tid, nt) { if (tid == 0) { tb[3] = PLS_CLOCK(); for (int q = 0; q < 3; q++) PLS_ATOMIC_ADD((uint32_t *)&profslots[q], (uint32_t)(tb[q + 1] - tb[q])); } } }
 }
 
 /* histogram the coming attempt starts from, for the decisions that begin a row attempt afresh (not SEG_K_RESTART):
  * INIT: zero; RETRY / ABORT: the committed histogram; COMMIT: committed histogram + every bump of the winner's row */
-PLS_HD void seg_next_hist(const SegJob &j, const SegDecision &D, const SegCtl &cur, int prev, seg_lds_u32 Hn, int nt)
+PLS_HD void seg_next_hist(const SegDecision &D, seg_lds_u32 spec, seg_lds_u32 Hn, int nt)
 {
-    const uint32_t W = j.W, ngrp = j.ngrp;
+    PLS_SYNC();
     PLS_THREADS(tid, nt) {
         for (int b = tid; b < 256; b += nt) {
             uint32_t v = 0u;
-            if (D.kind == SEG_K_RETRY || D.kind == SEG_K_ABORT) v = j.H0[prev * 256 + b];
-            else if (D.kind == SEG_K_COMMIT) {
-                const int w = D.winner;
-                const uint32_t wsx = cur.start_x[w], wfg = (wsx / SEG_L) / SEG_GRP;
-                v = j.H0[prev * 256 + b] + j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
-                if (wsx < W) for (uint32_t g = wfg; g < ngrp; g++) v += j.grpcnt[((size_t)w * ngrp + g) * 256 + b];
-            }
+            if (D.kind == SEG_K_RETRY || D.kind == SEG_K_ABORT) v = spec[SEG_NFILT * 256 + b];
+            else if (D.kind == SEG_K_COMMIT) v = spec[SEG_NFILT * 256 + b] + spec[D.winner * 256 + b];
             Hn[b] = v;
         }
     }
     PLS_SYNC();
+}
+
+/* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x: workgroup cw takes pixels [cw * SEG_THREADS, ...) ----
+ * Which candidate won is known only after the control block and the sums of the finished attempt have arrived; the candidate words
+ * of ALL five are requested before that (they do not depend on the decision), so the winner's are there when it is known. */
+PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int cw, unsigned char *smem)
+{
+    const int prev = (attempt & 1) ^ 1;
+    const SegCtl &cur = j.ctl[prev];
+    const SegAcc &A = j.acc[prev];
+    const uint32_t W = j.W, H = j.H, bpp = j.bpp;
+    SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                /* [0] max, [1] min of orig + incoming error over this workgroup's pixels of the COMING row; [2] decision kind, [3] winner */
+    seg_lds_u32 lutb = (seg_lds_u32)smem + 8;                  /* [512] next-rows terms of the split */
+    seg_lds_u32 cwt = lutb + 512;                              /* [(SEG_THREADS + 4)][4] the winner's candidate words of this workgroup's pixels, two more on either side; then their terms */
+    seg_lds_u32 ext = cwt + (SEG_THREADS + 4) * 4;             /* [SEG_THREADS][4]: err1 (2 words), the row's new pixel */
+    const uint32_t xw0 = (uint32_t)cw * SEG_THREADS;
+    const bool prof = (P.engine_flags & 1) != 0;
+    unsigned long long tc0 = 0;
+    if (prof) tc0 = PLS_CLOCK();
+    if (attempt == 0) {
+        /* the first row: extremes of the original values (no incoming error yet) */
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            const uint32_t x = xw0 + (uint32_t)tid;
+            int vmax = -(1 << 30), vmin = 1 << 30;
+            if (x < W && H) {
+                const uint32_t o = j.img[x];
+                const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                for (uint32_t c = 0; c < bpp; c++) {
+                    if (alpha0 && c == bpp - 1u) continue;
+                    const int v = (int)((o >> (8 * c)) & 255u);
+                    vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                }
+            }
+            vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+            if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
+        return;
+    }
+    const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
+    PLS_THREADS(tid, SEG_THREADS) {
+        const uint32_t x = xw0 + (uint32_t)tid;
+        /* requests that do not wait for the decision */
+        uint32_t w5[SEG_NFILT][4], h5[SEG_NFILT][4], e1a = 0, e1b = 0;
+        const long xh = tid < 2 ? (long)xw0 - 2 + tid : (long)xw0 + SEG_THREADS + (tid - 2);     /* (threads 0..3) the halo pixel */
+        for (int f = 0; f < SEG_NFILT; f++)
+            for (int q = 0; q < 4; q++) {
+                w5[f][q] = x < W ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
+                h5[f][q] = (tid < 4 && xh >= 0 && xh < (long)W) ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
+            }
+        if (x < W) { e1a = j.err1[2 * (size_t)x]; e1b = j.err1[2 * (size_t)x + 1]; }
+        const uint32_t lb = tid < 512 ? P.lut_b[tid] : 0u;
+        const SegDecision D = seg_decide(j, P, attempt, cur, A);     /* (its loads follow the ones above without a wait in between) */
+        if (tid < 512) lutb[tid] = lb;
+        if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; mm[2] = D.kind; mm[3] = D.winner; }
+        if (D.kind == SEG_K_COMMIT) {
+            uint32_t w4[4] = { 0, 0, 0, 0 }, h4[4] = { 0, 0, 0, 0 };
+            for (int f = 0; f < SEG_NFILT; f++) if (f == D.winner) for (int q = 0; q < 4; q++) { w4[q] = w5[f][q]; h4[q] = h5[f][q]; }
+            for (int q = 0; q < 4; q++) cwt[(tid + 2) * 4 + q] = w4[q];
+            if (tid < 4) for (int q = 0; q < 4; q++) cwt[(tid < 2 ? tid : SEG_THREADS + tid) * 4 + q] = h4[q];
+            ext[tid * 4 + 0] = e1a; ext[tid * 4 + 1] = e1b;
+            ext[tid * 4 + 2] = ((w4[0] & 255u) | ((w4[1] & 255u) << 8) | ((w4[2] & 255u) << 16) | ((w4[3] & 255u) << 24)) & keep;
+        }
+    }
+    PLS_SYNC();
+    if (mm[2] != SEG_K_COMMIT) return;
+    const int winner = mm[3];
+    const uint32_t y = cur.y, ynext = y + 1;
+    uint32_t *rowp = j.img + (size_t)y * W;
+    PLS_THREADS(tid, SEG_THREADS) {
+        /* candidate words -> the next-rows terms of their differences, once per pixel and channel */
+        for (int q = 0; q < 4; q++) cwt[(tid + 2) * 4 + q] = seg_terms_lds(lutb, P.bleed, seg_cand_diff(cwt[(tid + 2) * 4 + q]));
+        if (tid < 4) { const int hs = tid < 2 ? tid : SEG_THREADS + tid; for (int q = 0; q < 4; q++) cwt[hs * 4 + q] = seg_terms_lds(lutb, P.bleed, seg_cand_diff(cwt[hs * 4 + q])); }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        const uint32_t x = xw0 + (uint32_t)tid;
+        int vmax = -(1 << 30), vmin = 1 << 30;
+        if (x < W) {
+            const uint32_t onext = ynext < H ? j.img[(size_t)ynext * W + x] : 0u;
+            const uint32_t oldrow = rowp[x];
+            const uint32_t e1[2] = { ext[tid * 4 + 0], ext[tid * 4 + 1] };
+            /* error rows: err0'[x] = err1[x] + t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2), err1'[x] = t(x+1)+h(x)+t(x-1) (optimize_state.c:446-465) */
+            uint32_t n0[4], n1[4];
+            for (int p = 0; p < 4; p++) {
+                const int ch = seg_channel_of_plane(bpp, p);
+                int c1 = 0, c2 = 0;
+                if (ch >= 0)
+                    for (int dx = -2; dx <= 2; dx++) {
+                        const long sxp = (long)x + dx;
+                        if (sxp < 0 || sxp >= (long)W) continue;
+                        const uint32_t e = cwt[(tid + 2 + dx) * 4 + ch];
+                        const int T_ = (int)(int8_t)(e & 255u), F_ = (int)(int8_t)((e >> 8) & 255u), V_ = (int)(int8_t)((e >> 16) & 255u), H_ = (int)e >> 24;
+                        const int ad = dx < 0 ? -dx : dx;
+                        c1 += ad == 2 ? T_ : (ad == 1 ? F_ : V_);
+                        if (ad <= 1) c2 += ad == 1 ? T_ : H_;
+                    }
+                n0[p] = (uint32_t)(seg_err_plane(e1, p) + c1) & 0xffffu;     /* int16 wrap-on-store */
+                n1[p] = (uint32_t)c2 & 0xffffu;
+            }
+            j.old_above[x] = oldrow;
+            rowp[x] = ext[tid * 4 + 2];
+            j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
+            j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
+            if (ynext < H) {
+                const bool alpha0 = (bpp & 1u) == 0u && ((onext >> (8u * (bpp - 1u))) & 255u) == 0u;
+                for (uint32_t c = 0; c < bpp; c++) {
+                    if (alpha0 && c == bpp - 1u) continue;
+                    const int v = (int)((onext >> (8 * c)) & 255u) + seg_sext16((int)n0[seg_plane_of_channel(bpp, (int)c)]);
+                    vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                }
+            }
+        }
+        vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+        if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
+        if (cw == 0 && tid == 0) {
+            if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
+            j.row_ids[y] = (uint8_t)winner;
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
+    if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const uint32_t dt = (uint32_t)(PLS_CLOCK() - tc0); PLS_ATOMIC_MAX(&j.result[58], (int32_t)dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[62], dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[63], 1u); } } }
 }
 
 /* Control kernel of attempt `attempt`: reads what attempt-1 left (control block and sums of parity prev), writes the control block
@@ -1705,16 +1843,46 @@ PLS_HD void seg_next_hist(const SegJob &j, const SegDecision &D, const SegCtl &c
  * bx > SEG_NFILT: commit of pixels [(bx - SEG_NFILT - 1) * SEG_THREADS, ...) */
 PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int bx, unsigned char *smem)
 {
+    if (bx > SEG_NFILT) { seg_ctl_commit(j, P, attempt, bx - SEG_NFILT - 1, smem); return; }
     const int par = attempt & 1, prev = par ^ 1;
-    const SegCtl &cur = j.ctl[prev];
+    const SegCtl &curg = j.ctl[prev];
     SegCtl &nxt = j.ctl[par];
-    const SegAcc &A = j.acc[prev];
+    const SegAcc &Ag = j.acc[prev];
     const uint32_t W = j.W, H = j.H, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
     seg_lds_u32 Hn = (seg_lds_u32)smem, rank = Hn + 256, scratch = Hn + 512, basen = Hn + 768;   /* 4 x 256 words */
     seg_lds_u32 stage = Hn + 1024;                               /* SEG_TBL_WORDS: a candidate's tables before they go out; the commit workgroups keep the split table here */
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long tc0 = 0;
     if (prof) tc0 = PLS_CLOCK();
+    /* What the coming attempt's histogram may need is requested before the decision is known (it depends on which candidate won):
+     * per candidate w, base[w] + every group's bumps of w's row, and the committed histogram; groups in front of w's epoch are masked
+     * out afterwards.  spec[w][b] in the table staging area, which is free until the tables are built. */
+    seg_lds_u32 spec = stage;                                  /* [SEG_NFILT + 1][256] */
+    /* the finished attempt's control block and sums, copied into shared memory by the same burst of loads: everything below reads the copies */
+    seg_lds_u32 ctlc = stage + (SEG_NFILT + 1) * 256, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2;
+    if (attempt) {
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = ((const uint32_t *)&curg)[tid];
+            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = ((const uint32_t *)&Ag)[tid - 128];
+            for (int i = tid; i < (SEG_NFILT + 1) * 256; i += SEG_THREADS) {
+                const int w = i >> 8, b = i & 255;
+                uint32_t v;
+                if (w == SEG_NFILT) v = j.H0[prev * 256 + b];
+                else {
+                    uint32_t g0[SEG_MAX_NSEG / SEG_GRP];
+                    const uint32_t bs = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
+                    for (uint32_t g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) g0[g] = g < ngrp ? j.grpcnt[((size_t)w * ngrp + g) * 256 + b] : 0u;
+                    const uint32_t wsx = curg.start_x[w], wfg = (wsx / SEG_L) / SEG_GRP;
+                    v = bs;
+                    for (uint32_t g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) v += (g >= wfg && g < ngrp && wsx < W) ? g0[g] : 0u;
+                }
+                spec[i] = v;
+            }
+        }
+    }
+    PLS_SYNC();
+    const SegCtl &cur = *(const SegCtl *)(uint32_t *)ctlc;
+    const SegAcc &A = *(const SegAcc *)(uint32_t *)accc;
     const SegDecision D = seg_decide(j, P, attempt, cur, A);
     const uint32_t y = attempt ? cur.y : 0u;
     int s_next = attempt ? (int)cur.s : P.strength;
@@ -1727,7 +1895,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
             return;
         }
-        if (D.kind != SEG_K_RESTART) seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
+        if (D.kind != SEG_K_RESTART) seg_next_hist(D, spec, Hn, SEG_THREADS);
         PLS_THREADS(tid, SEG_THREADS) {
             for (int b = tid; b < 256; b += SEG_THREADS) j.H0[par * 256 + b] = D.kind == SEG_K_RESTART ? j.H0[prev * 256 + b] : Hn[b];
             /* zero the sums the coming attempt accumulates into */
@@ -1768,97 +1936,13 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     }
     if (D.kind == SEG_K_FINISHED) return;
 
-    if (bx > SEG_NFILT) {
-        /* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x ---- */
-        if (D.kind != SEG_K_COMMIT && D.kind != SEG_K_INIT) return;
-        SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                                            /* max, min of orig + incoming error over this workgroup's pixels of the COMING row */
-        const uint32_t ynext = D.kind == SEG_K_COMMIT ? y + 1 : 0u;
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
-        PLS_SYNC();
-        if (D.kind == SEG_K_INIT) {
-            PLS_THREADS(tid, SEG_THREADS) {
-                const uint32_t x = (uint32_t)(bx - SEG_NFILT - 1) * SEG_THREADS + (uint32_t)tid;
-                int vmax = -(1 << 30), vmin = 1 << 30;
-                if (x < W && H) {
-                    const uint32_t o = j.img[x];
-                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                    for (uint32_t c = 0; c < bpp; c++) {
-                        if (alpha0 && c == bpp - 1u) continue;
-                        const int v = (int)((o >> (8 * c)) & 255u);
-                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
-                    }
-                }
-                vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-                if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
-            }
-            PLS_SYNC();
-            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * (bx - SEG_NFILT - 1)] = mm[0]; j.rowmm[2 * (bx - SEG_NFILT - 1) + 1] = mm[1]; } }
-            return;
-        }
-        const uint32_t *cd = j.cand + (size_t)D.winner * W * 4;
-        uint32_t *rowp = j.img + (size_t)y * W;
-        seg_lds_u32 lutb = stage;                                           /* [512] next-rows terms of the split */
-        PLS_THREADS(tid, SEG_THREADS) { if (tid < 512) lutb[tid] = P.lut_b[tid]; }
-        PLS_SYNC();
-        const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
-        PLS_THREADS(tid, SEG_THREADS) {
-            const uint32_t x = (uint32_t)(bx - SEG_NFILT - 1) * SEG_THREADS + (uint32_t)tid;
-            int vmax = -(1 << 30), vmin = 1 << 30;
-            if (x < W) {
-                const uint32_t *cwp = cd + (size_t)x * 4;
-                const uint32_t np = ((cwp[0] & 255u) | ((cwp[1] & 255u) << 8) | ((cwp[2] & 255u) << 16) | ((cwp[3] & 255u) << 24)) & keep;
-                j.old_above[x] = rowp[x];
-                rowp[x] = np;
-                /* error rows: err0'[x] = err1[x] + t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2), err1'[x] = t(x+1)+h(x)+t(x-1) (optimize_state.c:446-465) */
-                uint32_t n0[4], n1[4];
-                for (int p = 0; p < 4; p++) {
-                    const int ch = seg_channel_of_plane(bpp, p);
-                    int c1 = 0, c2 = 0;
-                    if (ch >= 0)
-                        for (int dx = -2; dx <= 2; dx++) {
-                            const long sxp = (long)x + dx;
-                            if (sxp < 0 || sxp >= (long)W) continue;
-                            const uint32_t e = seg_terms(lutb, P.bleed, seg_cand_diff(cd[(size_t)sxp * 4 + ch]));
-                            const int T_ = (int)(int8_t)(e & 255u), F_ = (int)(int8_t)((e >> 8) & 255u), V_ = (int)(int8_t)((e >> 16) & 255u), H_ = (int)e >> 24;
-                            const int ad = dx < 0 ? -dx : dx;
-                            c1 += ad == 2 ? T_ : (ad == 1 ? F_ : V_);
-                            if (ad <= 1) c2 += ad == 1 ? T_ : H_;
-                        }
-                    n0[p] = (uint32_t)(seg_err_plane(j.err1 + 2 * (size_t)x, p) + c1) & 0xffffu;     /* int16 wrap-on-store */
-                    n1[p] = (uint32_t)c2 & 0xffffu;
-                }
-                j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
-                j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
-                if (ynext < H) {
-                    const uint32_t o = j.img[(size_t)ynext * W + x];
-                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                    for (uint32_t c = 0; c < bpp; c++) {
-                        if (alpha0 && c == bpp - 1u) continue;
-                        const int v = (int)((o >> (8 * c)) & 255u) + seg_sext16((int)n0[seg_plane_of_channel(bpp, (int)c)]);
-                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
-                    }
-                }
-            }
-            vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-            if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
-            if (bx == SEG_NFILT + 1 && tid == 0) {
-                if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << D.winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
-                j.row_ids[y] = (uint8_t)D.winner;
-            }
-        }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * (bx - SEG_NFILT - 1)] = mm[0]; j.rowmm[2 * (bx - SEG_NFILT - 1) + 1] = mm[1]; } }
-        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) PLS_ATOMIC_MAX(&j.result[58], (int32_t)(PLS_CLOCK() - tc0)); } }
-        return;
-    }
-
     /* ---- candidate f ---- */
     const int f = bx;
     const bool failed = (D.failed >> f) & 1u;
     PLS_THREADS(tid, SEG_THREADS) { for (int b = tid; b < 256; b += SEG_THREADS) rank[b] = j.orig_rank[f * 256 + b]; }
     if (D.kind != SEG_K_RESTART) {
         /* a fresh row attempt: start of the row, no validated prefix */
-        seg_next_hist(j, D, cur, prev, Hn, SEG_THREADS);
+        seg_next_hist(D, spec, Hn, SEG_THREADS);
         PLS_THREADS(tid, SEG_THREADS) {
             for (int b = tid; b < 256; b += SEG_THREADS) { basen[b] = 0u; j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
             if (tid == 0) {
@@ -1872,8 +1956,8 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         const int sn = s_next < 0 ? 0 : s_next;
         unsigned long long tc1 = 0;
         if (prof) tc1 = PLS_CLOCK();
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS);
-        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const unsigned long long t2 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[56], (int32_t)(tc1 - tc0)); PLS_ATOMIC_MAX(&j.result[57], (int32_t)(t2 - tc1)); } } }
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS, prof ? &j.result[37] : nullptr);
+        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const unsigned long long t2 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[56], (int32_t)(tc1 - tc0)); PLS_ATOMIC_MAX(&j.result[57], (int32_t)(t2 - tc1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[59], (uint32_t)(tc1 - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[60], (uint32_t)(t2 - tc1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[61], 1u); } } }
         return;
     }
     if (f == 0 && cur.active[0] == 2 && (D.start_none || D.keep_lazy)) {
