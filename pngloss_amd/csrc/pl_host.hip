@@ -150,7 +150,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
         s.firstidx = reinterpret_cast<uint32_t *>(base + l.firstidx); s.rowmm = reinterpret_cast<int32_t *>(base + l.rowmm);
         s.nseg = pj.width ? l.nseg : 0; s.ngrp = pj.width ? l.ngrp : 0;
         b.max_nseg = std::max(b.max_nseg, l.nseg); b.max_ngrp = std::max(b.max_ngrp, l.ngrp);
-        b.max_ncommit = std::max(b.max_ncommit, (pj.width + SEG_THREADS - 1) / SEG_THREADS);
+        b.max_ncommit = std::max(b.max_ncommit, (pj.width + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
         max_h = std::max(max_h, pj.height);
     }
     if (!b.max_ncommit) b.max_ncommit = 1;
@@ -346,6 +346,9 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61] && r[63])
                 std::fprintf(stderr, "pngloss_hip:   ... average (us): candidate workgroup up to the table build %.2f, table build %.2f, commit workgroup %.2f\n",
                              (uint32_t)r[59] / 100.0 / (uint32_t)r[61], (uint32_t)r[60] / 100.0 / (uint32_t)r[61], (uint32_t)r[62] / 100.0 / (uint32_t)r[63]);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
+                std::fprintf(stderr, "pngloss_hip:   ... candidate workgroup, average (us): requests + copy %.2f, decision %.2f, new histogram + fields %.2f\n",
+                             (uint32_t)r[19] / 100.0 / (uint32_t)r[61], (uint32_t)r[21] / 100.0 / (uint32_t)r[61], (uint32_t)r[22] / 100.0 / (uint32_t)r[61]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
                 std::fprintf(stderr, "pngloss_hip:   ... table build, average (us): keys %.2f, classes %.2f, entries + write %.2f\n",
                              (uint32_t)r[37] / 100.0 / (uint32_t)r[61], (uint32_t)r[38] / 100.0 / (uint32_t)r[61], (uint32_t)r[39] / 100.0 / (uint32_t)r[61]);

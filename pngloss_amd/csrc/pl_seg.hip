@@ -30,7 +30,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *sj, const
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    if (blockIdx.x > SEG_NFILT && (blockIdx.x - SEG_NFILT - 1) * SEG_THREADS >= j.W) return;
+    if (blockIdx.x > SEG_CTL_IMG && (blockIdx.x - SEG_CTL_IMG - 1) * SEG_COMMIT_W >= j.W) return;
     seg_ctl_body(j, *P, attempt, (int)blockIdx.x, seg_smem);
 }
 
@@ -122,7 +122,7 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp)
     l.segcnt = take((size_t)SEG_NFILT * l.nseg * 256 * 2);
     l.grpcnt = take((size_t)SEG_NFILT * l.ngrp * 256 * 4);
     l.firstidx = take(SEG_NFILT * 4 * 2 * 4);
-    l.rowmm = take(((size_t)(width + SEG_THREADS - 1) / SEG_THREADS) * 8);
+    l.rowmm = take(((size_t)(width + SEG_COMMIT_W - 1) / SEG_COMMIT_W) * 8);
     l.total = o;
     return l;
 }
@@ -144,7 +144,7 @@ hipError_t pl_seg_launch_resolve(const PlJob *d_jobs, SegJob *d_sj, size_t n, hi
 
 hipError_t pl_seg_launch_control(const PlSegBatch &b, int attempt, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_NFILT + 1 + b.max_ncommit, (unsigned)b.n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
+    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, (unsigned)b.n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
     return hipGetLastError();
 }
 
@@ -155,7 +155,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     if (e != hipSuccess) return e;
     const int par = attempt & 1;
     const unsigned n = (unsigned)b.n;
-    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_NFILT + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
+    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
     hipLaunchKernelGGL(seg_k_enum, dim3(b.enum_blocks, n), dim3(SEG_THREADS), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
     hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);

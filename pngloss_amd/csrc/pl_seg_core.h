@@ -40,6 +40,7 @@
 #define PL_SEG_CORE_H
 
 #include <stdint.h>
+#include <stddef.h>
 #include <string.h>
 
 #if defined(__HIPCC__)
@@ -122,6 +123,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_L 32                 /* pixels per segment (16 was measured: enumeration -5 us, chain +5 us, no gain) */
 #endif
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
+#define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
+#define SEG_COMMIT_W 256           /* control kernel: pixels per commit workgroup */
+#define SEG_CTL_IMG (SEG_NFILT * SEG_TPARTS)      /* blockIdx.x of the image-wide workgroup; the commit workgroups follow */
 #define SEG_PARTS 4               /* the replay cuts a segment into this many parts: the enumeration leaves the state at every cut (checkpoints) */
 #define SEG_PL (SEG_L / SEG_PARTS)
 #define SEG_NSP 256              /* lanes per channel in the enumeration; also the most DISTINCT states a segment may have after the dedupe */
@@ -184,7 +188,7 @@ struct SegAcc {
 };
 
 static_assert(sizeof(SegCtl) / 4 <= 128 && sizeof(SegAcc) / 4 <= 128, "the control kernel copies both with 128 lanes each");
-static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 <= 4 * SEG_TN, "they live in the table staging area, below the classes");
+static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 40 <= 4 * SEG_TN, "they live in the table staging area, below the classes (and the decision behind them)");
 
 struct SegJob {
     SEG_AS_GLB uint32_t *img;            /* slots image (pl_device.h) */
@@ -216,7 +220,7 @@ struct SegJob {
     SEG_AS_GLB uint16_t *segcnt;         /* [5][nseg][256] */
     SEG_AS_GLB uint32_t *grpcnt;         /* [5][ngrp][256] */
     SEG_AS_GLB uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
-    SEG_AS_GLB int32_t *rowmm;           /* [ncommit][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
+    SEG_AS_GLB int32_t *rowmm;           /* [ceil(W / SEG_COMMIT_W)][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
     uint32_t nseg, ngrp;
 };
 
@@ -600,7 +604,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
-#define SEG_SM_CTL (256 * 4 * 4 + (512 + (SEG_THREADS + 4) * 4 + SEG_THREADS * 4) * 4 + 64)   /* (commit: 8 + 512 + tile + ext words; candidates: 1024 + SEG_TBL_WORDS) */   /* (the commit workgroups' tile is the larger use; a candidate's tables need SEG_TBL_WORDS) */
+#define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 2 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad > 0 when the lane left the tables */
 template <int F, bool TRX>
@@ -1284,7 +1288,7 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s)
 {
     if (!j.rowmm) return -1;
     int M = -(1 << 30), m = 1 << 30;
-    const int nc = (int)((j.W + SEG_THREADS - 1) / SEG_THREADS);
+    const int nc = (int)((j.W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
     for (int i = 0; i < nc; i++) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
     int C = P.cmax;
     for (int it = 0; it < 4; it++) {
@@ -1580,31 +1584,44 @@ struct SegDecision {
     uint64_t cost[SEG_NFILT];
 };
 
-/* what the attempt that just finished (control block `cur`, sums `A`) means.  Every workgroup of the control kernel computes this. */
-PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, const SegCtl &cur, const SegAcc &A)
+/* what the attempt that just finished (control block `cur`, sums `A`) means -- in two steps, so that five lanes can look at a
+ * candidate each before one lane draws the conclusion.  Step 1, candidate f: its row cost, or why it has none yet. */
+static_assert(offsetof(SegDecision, cost) == 24, "seg_ctl_body reads cost[f] out of the shared copy by word index");
+struct SegCandDec { uint64_t cost; uint32_t state; uint32_t pad_; };      /* state 0: cost is final (or ~0: no acceptable row), 1: lazy (none, not run yet), 2: failed validation */
+template <class CT, class AT>
+PLS_HD SegCandDec seg_decide_cand(const SegJob &j, const SegParams &P, CT &cur, AT &A, int f)
+{
+    SegCandDec r; r.cost = ~0ull; r.state = 0; r.pad_ = 0;
+    if (!cur.active[f]) { r.cost = cur.cost[f]; return r; }
+    if (cur.active[f] == 2) { r.state = 1; return r; }                             /* candidate none, not run yet */
+    if (A.fail[f] != SEG_NOFAIL) { r.state = 2; return r; }
+    const bool adaptive = !j.row_filters || cur.y == 0;
+    uint64_t cst = A.derr[f] / 128u + A.cost[f];                                  /* optimize_state.c:360 */
+    if (adaptive) {
+        int bestg = 0;
+        for (int g = 1; g < SEG_NFILT; g++) if (A.hs[f][g] < A.hs[f][bestg]) bestg = g;
+        if (bestg != f) cst = ~0ull;                                              /* optimize_state.c:319-324 */
+    }
+    if (P.engine_flags >> 8) cst = f == (P.engine_flags >> 8) - 1 ? 0ull : ~0ull;
+    r.cost = cst;
+    return r;
+}
+/* Step 2: the conclusion.  Every workgroup of the control kernel comes to the same one. */
+template <class CT, class AT, class DT>
+PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int attempt, CT &cur, AT &A, DT *cd)
 {
     SegDecision D;
     D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0; D.dropped_none = 0; D.start_none = 0; D.keep_lazy = 0;
     for (int f = 0; f < SEG_NFILT; f++) D.cost[f] = ~0ull;
     if (attempt == 0) return D;
     if (cur.finished) { D.kind = SEG_K_FINISHED; return D; }
-    const bool adaptive = !j.row_filters || cur.y == 0;
     bool any_failed = false;
     bool lazy0 = false;
     for (int f = 0; f < SEG_NFILT; f++) {
-        if (!cur.active[f]) { D.cost[f] = cur.cost[f]; continue; }
-        if (cur.active[f] == 2) { lazy0 = true; continue; }                        /* candidate none, not run yet */
-        if (A.fail[f] != SEG_NOFAIL) { D.failed |= 1u << f; any_failed = true; continue; }
-        uint64_t cst = A.derr[f] / 128u + A.cost[f];                              /* optimize_state.c:360 */
-        if (adaptive) {
-            int bestg = 0;
-            for (int g = 1; g < SEG_NFILT; g++) if (A.hs[f][g] < A.hs[f][bestg]) bestg = g;
-            if (bestg != f) cst = ~0ull;                                          /* optimize_state.c:319-324 */
-        }
-        if (P.engine_flags >> 8) cst = f == (P.engine_flags >> 8) - 1 ? 0ull : ~0ull;
-        D.cost[f] = cst;
+        if (cd[f].state == 1) { lazy0 = true; continue; }
+        if (cd[f].state == 2) { D.failed |= 1u << f; any_failed = true; continue; }
+        D.cost[f] = cd[f].cost;
     }
-    D.dropped_none = 0; D.start_none = 0; D.keep_lazy = 0;
     if (((D.failed & 1u) || lazy0) && !(P.engine_flags >> 8)) {
         /* Candidate none failed validation, or has not been run at all (lazy).  Its row cost is at least none_lb (seg_post_body); it has
          * the lowest index, so it wins ties (pngloss_image.c:257) and loses only to a strictly cheaper row: if one exists already, none
@@ -1628,6 +1645,37 @@ PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, 
     else D.kind = cur.s == 0 ? SEG_K_ABORT : SEG_K_RETRY;                           /* pngloss_image.c:266-274 */
     return D;
 }
+/* the whole workgroup: lanes 0..4 step 1, lane 0 step 2; the result in shared memory (dshare: 16 words, cdw: 20 words in front of it) */
+/* the control block, the sums and the decision in shared memory, with the address space in the type (ds_* instead of FLAT accesses) */
+typedef SEG_AS_LDS const SegCtl seg_lds_ctl_t;
+typedef SEG_AS_LDS const SegAcc seg_lds_acc_t;
+/* the whole workgroup: lanes 0..4 step 1, lane 0 step 2; the result in shared memory (dshare: 16 words, cdw: 20 words behind it) */
+PLS_HD SegDecision seg_decide_wg(const SegJob &j, const SegParams &P, int attempt, seg_lds_ctl_t &cur, seg_lds_acc_t &A, seg_lds_u32 cdw, seg_lds_u32 dshare, int nt)
+{
+    PLS_THREADS(tid, nt) {
+        if (tid < SEG_NFILT && attempt) {
+            const SegCandDec r = seg_decide_cand(j, P, cur, A, tid);
+            cdw[4 * tid] = (uint32_t)r.cost; cdw[4 * tid + 1] = (uint32_t)(r.cost >> 32); cdw[4 * tid + 2] = r.state; cdw[4 * tid + 3] = 0u;
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, nt) {
+        if (tid == 0) {
+            SegCandDec cd[SEG_NFILT];
+            for (int f = 0; f < SEG_NFILT; f++) { cd[f].cost = (uint64_t)cdw[4 * f] | ((uint64_t)cdw[4 * f + 1] << 32); cd[f].state = cdw[4 * f + 2]; cd[f].pad_ = 0; }
+            const SegDecision D = seg_decide_combine(j, P, attempt, cur, A, cd);
+            uint32_t w[sizeof(SegDecision) / 4];
+            memcpy(w, &D, sizeof D);
+            for (int i = 0; i < (int)(sizeof(SegDecision) / 4); i++) dshare[i] = w[i];
+        }
+    }
+    PLS_SYNC();
+    uint32_t w[sizeof(SegDecision) / 4];
+    for (int i = 0; i < (int)(sizeof(SegDecision) / 4); i++) w[i] = dshare[i];
+    SegDecision D;
+    memcpy(&D, w, sizeof D);
+    return D;
+}
 
 /* decision tables of one candidate from a histogram (all threads of the workgroup; H, rank: 256 words each in shared memory;
  * out: SEG_TBL_WORDS words in global memory; stage: SEG_TBL_WORDS words of shared memory).  One lane per band, sign and direction
@@ -1635,7 +1683,7 @@ PLS_HD SegDecision seg_decide(const SegJob &j, const SegParams &P, int attempt, 
  * Tie classes are band local: cls[sgn][b] = offset inside its band (of that sign) of the FIRST bin with the same (H, rank) as bin b,
  * so two bins of one band have equal classes iff their keys are equal -- all the tie test of seg_step_fast needs (the original
  * symbol and the leader it may replace always lie in the same band). */
-PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u32 rank, seg_lds_u32 scratch, seg_lds_u32 stage, int s, int q, int nt, int32_t *profslots = nullptr)
+PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u32 rank, seg_lds_u32 scratch, seg_lds_u32 stage, int s, int q, int nt, int part, int nparts, int32_t *profslots = nullptr)
 {
     unsigned long long tb[4] = { 0, 0, 0, 0 };
     if (profslots) tb[0] = PLS_CLOCK();
@@ -1670,7 +1718,8 @@ PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u3
     if (profslots) tb[2] = PLS_CLOCK();
     /* one entry per thread and turn: the leader of [bandlo, v] (prefix) or [v, bandhi] (suffix) = largest (H, rank), lowest v among equals */
     PLS_THREADS(tid, nt) {
-        for (int i = tid; i < 4 * SEG_TN; i += nt) {
+        /* (the workgroups that share a candidate's tables take every nparts-th block of nt entries) */
+        for (int i = part * nt + tid; i < 4 * SEG_TN; i += nt * nparts) {
             const int dir = i / (2 * SEG_TN), sgn = (i / SEG_TN) & 1, v = i % SEG_TN - SEG_TOFF;
             uint32_t e = 0u;
             if (sgn ? v <= 0 : v >= 0) {
@@ -1690,7 +1739,7 @@ PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u3
             }
             out[i] = e;
         }
-        for (int i = tid; i < SEG_TBL_WORDS - 4 * SEG_TN; i += nt) out[4 * SEG_TN + i] = stage[4 * SEG_TN + i];
+        if (part == 0) for (int i = tid; i < SEG_TBL_WORDS - 4 * SEG_TN; i += nt) out[4 * SEG_TN + i] = stage[4 * SEG_TN + i];
     }
     PLS_SYNC();
     if (profslots) { PLS_THREADS(tid, nt) { if (tid == 0) { tb[3] = PLS_CLOCK(); for (int q = 0; q < 3; q++) PLS_ATOMIC_ADD((uint32_t *)&profslots[q], (uint32_t)(tb[q + 1] - tb[q])); } } }
@@ -1712,20 +1761,22 @@ PLS_HD void seg_next_hist(const SegDecision &D, seg_lds_u32 spec, seg_lds_u32 Hn
     PLS_SYNC();
 }
 
-/* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x: workgroup cw takes pixels [cw * SEG_THREADS, ...) ----
+/* ---- commit of the winner's row (pngloss_image.c:277-308), parallel over x: workgroup cw takes pixels [cw * SEG_COMMIT_W, ...) ----
  * Which candidate won is known only after the control block and the sums of the finished attempt have arrived; the candidate words
- * of ALL five are requested before that (they do not depend on the decision), so the winner's are there when it is known. */
+ * of ALL five are requested in the same burst (they do not depend on the decision), so the winner's are there when it is known.
+ * SEG_COMMIT_W lanes work (one wave per SIMD); the other waves of the launch shape only keep the barriers company. */
 PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int cw, unsigned char *smem)
 {
     const int prev = (attempt & 1) ^ 1;
-    const SegCtl &cur = j.ctl[prev];
-    const SegAcc &A = j.acc[prev];
+    const SegCtl &curg = j.ctl[prev];
+    const SegAcc &Ag = j.acc[prev];
     const uint32_t W = j.W, H = j.H, bpp = j.bpp;
-    SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                /* [0] max, [1] min of orig + incoming error over this workgroup's pixels of the COMING row; [2] decision kind, [3] winner */
+    SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                /* [0] max, [1] min of orig + incoming error over this workgroup's pixels of the COMING row */
     seg_lds_u32 lutb = (seg_lds_u32)smem + 8;                  /* [512] next-rows terms of the split */
-    seg_lds_u32 cwt = lutb + 512;                              /* [(SEG_THREADS + 4)][4] the winner's candidate words of this workgroup's pixels, two more on either side; then their terms */
-    seg_lds_u32 ext = cwt + (SEG_THREADS + 4) * 4;             /* [SEG_THREADS][4]: err1 (2 words), the row's new pixel */
-    const uint32_t xw0 = (uint32_t)cw * SEG_THREADS;
+    seg_lds_u32 ctlc = lutb + 512, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2, dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
+    seg_lds_u32 cw5 = dshare + 40;                             /* [SEG_NFILT][(SEG_COMMIT_W + 4)][4] every candidate's words of this workgroup's pixels, two more on either side; the winner's become their terms */
+    seg_lds_u32 ext = cw5 + SEG_NFILT * (SEG_COMMIT_W + 4) * 4;/* [SEG_COMMIT_W][2]: err1 */
+    const uint32_t xw0 = (uint32_t)cw * SEG_COMMIT_W;
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long tc0 = 0;
     if (prof) tc0 = PLS_CLOCK();
@@ -1734,103 +1785,108 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
         PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) {
-            const uint32_t x = xw0 + (uint32_t)tid;
-            int vmax = -(1 << 30), vmin = 1 << 30;
-            if (x < W && H) {
-                const uint32_t o = j.img[x];
-                const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                for (uint32_t c = 0; c < bpp; c++) {
-                    if (alpha0 && c == bpp - 1u) continue;
-                    const int v = (int)((o >> (8 * c)) & 255u);
-                    vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+            if (tid < SEG_COMMIT_W) {
+                const uint32_t x = xw0 + (uint32_t)tid;
+                int vmax = -(1 << 30), vmin = 1 << 30;
+                if (x < W && H) {
+                    const uint32_t o = j.img[x];
+                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        if (alpha0 && c == bpp - 1u) continue;
+                        const int v = (int)((o >> (8 * c)) & 255u);
+                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                    }
                 }
+                vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+                if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
             }
-            vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-            if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
         }
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
         return;
     }
-    const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
     PLS_THREADS(tid, SEG_THREADS) {
-        const uint32_t x = xw0 + (uint32_t)tid;
-        /* requests that do not wait for the decision */
-        uint32_t w5[SEG_NFILT][4], h5[SEG_NFILT][4], e1a = 0, e1b = 0;
-        const long xh = tid < 2 ? (long)xw0 - 2 + tid : (long)xw0 + SEG_THREADS + (tid - 2);     /* (threads 0..3) the halo pixel */
-        for (int f = 0; f < SEG_NFILT; f++)
-            for (int q = 0; q < 4; q++) {
-                w5[f][q] = x < W ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
-                h5[f][q] = (tid < 4 && xh >= 0 && xh < (long)W) ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
-            }
-        if (x < W) { e1a = j.err1[2 * (size_t)x]; e1b = j.err1[2 * (size_t)x + 1]; }
-        const uint32_t lb = tid < 512 ? P.lut_b[tid] : 0u;
-        const SegDecision D = seg_decide(j, P, attempt, cur, A);     /* (its loads follow the ones above without a wait in between) */
-        if (tid < 512) lutb[tid] = lb;
-        if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; mm[2] = D.kind; mm[3] = D.winner; }
-        if (D.kind == SEG_K_COMMIT) {
-            uint32_t w4[4] = { 0, 0, 0, 0 }, h4[4] = { 0, 0, 0, 0 };
-            for (int f = 0; f < SEG_NFILT; f++) if (f == D.winner) for (int q = 0; q < 4; q++) { w4[q] = w5[f][q]; h4[q] = h5[f][q]; }
-            for (int q = 0; q < 4; q++) cwt[(tid + 2) * 4 + q] = w4[q];
-            if (tid < 4) for (int q = 0; q < 4; q++) cwt[(tid < 2 ? tid : SEG_THREADS + tid) * 4 + q] = h4[q];
-            ext[tid * 4 + 0] = e1a; ext[tid * 4 + 1] = e1b;
-            ext[tid * 4 + 2] = ((w4[0] & 255u) | ((w4[1] & 255u) << 8) | ((w4[2] & 255u) << 16) | ((w4[3] & 255u) << 24)) & keep;
+        if (tid < SEG_COMMIT_W) {
+            const uint32_t x = xw0 + (uint32_t)tid;
+            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = ((const uint32_t *)&curg)[tid];
+            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = ((const uint32_t *)&Ag)[tid - 128];
+            lutb[tid] = P.lut_b[tid]; lutb[tid + SEG_COMMIT_W] = P.lut_b[tid + SEG_COMMIT_W];
+            const long xh = tid < 2 ? (long)xw0 - 2 + tid : (long)xw0 + SEG_COMMIT_W + (tid - 2);     /* (threads 0..3) the halo pixel */
+            for (int f = 0; f < SEG_NFILT; f++)
+                for (int q = 0; q < 4; q++) {
+                    cw5[(f * (SEG_COMMIT_W + 4) + tid + 2) * 4 + q] = x < W ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
+                    if (tid < 4) cw5[(f * (SEG_COMMIT_W + 4) + (tid < 2 ? tid : SEG_COMMIT_W + tid)) * 4 + q] = (xh >= 0 && xh < (long)W) ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
+                }
+            ext[tid * 2 + 0] = x < W ? j.err1[2 * (size_t)x] : 0u; ext[tid * 2 + 1] = x < W ? j.err1[2 * (size_t)x + 1] : 0u;
+            if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; }
         }
     }
     PLS_SYNC();
-    if (mm[2] != SEG_K_COMMIT) return;
-    const int winner = mm[3];
+    seg_lds_ctl_t &cur = *(seg_lds_ctl_t *)ctlc;
+    seg_lds_acc_t &A = *(seg_lds_acc_t *)accc;
+    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
+    if (D.kind != SEG_K_COMMIT) return;
+    const int winner = D.winner;
+    seg_lds_u32 cwt = cw5 + winner * (SEG_COMMIT_W + 4) * 4;
+    const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
     const uint32_t y = cur.y, ynext = y + 1;
     uint32_t *rowp = j.img + (size_t)y * W;
+    seg_lds_u32 npx = cw5 + ((winner + 1) % SEG_NFILT) * (SEG_COMMIT_W + 4) * 4;     /* (a loser's tile) the row's new pixel */
     PLS_THREADS(tid, SEG_THREADS) {
-        /* candidate words -> the next-rows terms of their differences, once per pixel and channel */
-        for (int q = 0; q < 4; q++) cwt[(tid + 2) * 4 + q] = seg_terms_lds(lutb, P.bleed, seg_cand_diff(cwt[(tid + 2) * 4 + q]));
-        if (tid < 4) { const int hs = tid < 2 ? tid : SEG_THREADS + tid; for (int q = 0; q < 4; q++) cwt[hs * 4 + q] = seg_terms_lds(lutb, P.bleed, seg_cand_diff(cwt[hs * 4 + q])); }
+        if (tid < SEG_COMMIT_W) {
+            /* the row's new pixel, then candidate words -> the next-rows terms of their differences, once per pixel and channel */
+            seg_lds_u32 mine = cwt + (tid + 2) * 4;
+            npx[tid] = ((mine[0] & 255u) | ((mine[1] & 255u) << 8) | ((mine[2] & 255u) << 16) | ((mine[3] & 255u) << 24)) & keep;
+            for (int q = 0; q < 4; q++) mine[q] = seg_terms_lds(lutb, P.bleed, seg_cand_diff(mine[q]));
+            if (tid < 4) { seg_lds_u32 halo = cwt + (tid < 2 ? tid : SEG_COMMIT_W + tid) * 4; for (int q = 0; q < 4; q++) halo[q] = seg_terms_lds(lutb, P.bleed, seg_cand_diff(halo[q])); }
+        }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
-        const uint32_t x = xw0 + (uint32_t)tid;
-        int vmax = -(1 << 30), vmin = 1 << 30;
-        if (x < W) {
-            const uint32_t onext = ynext < H ? j.img[(size_t)ynext * W + x] : 0u;
-            const uint32_t oldrow = rowp[x];
-            const uint32_t e1[2] = { ext[tid * 4 + 0], ext[tid * 4 + 1] };
-            /* error rows: err0'[x] = err1[x] + t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2), err1'[x] = t(x+1)+h(x)+t(x-1) (optimize_state.c:446-465) */
-            uint32_t n0[4], n1[4];
-            for (int p = 0; p < 4; p++) {
-                const int ch = seg_channel_of_plane(bpp, p);
-                int c1 = 0, c2 = 0;
-                if (ch >= 0)
-                    for (int dx = -2; dx <= 2; dx++) {
-                        const long sxp = (long)x + dx;
-                        if (sxp < 0 || sxp >= (long)W) continue;
-                        const uint32_t e = cwt[(tid + 2 + dx) * 4 + ch];
-                        const int T_ = (int)(int8_t)(e & 255u), F_ = (int)(int8_t)((e >> 8) & 255u), V_ = (int)(int8_t)((e >> 16) & 255u), H_ = (int)e >> 24;
-                        const int ad = dx < 0 ? -dx : dx;
-                        c1 += ad == 2 ? T_ : (ad == 1 ? F_ : V_);
-                        if (ad <= 1) c2 += ad == 1 ? T_ : H_;
+        if (tid < SEG_COMMIT_W) {
+            const uint32_t x = xw0 + (uint32_t)tid;
+            int vmax = -(1 << 30), vmin = 1 << 30;
+            if (x < W) {
+                const uint32_t onext = ynext < H ? j.img[(size_t)ynext * W + x] : 0u;
+                const uint32_t oldrow = rowp[x];
+                const uint32_t e1[2] = { ext[tid * 2 + 0], ext[tid * 2 + 1] };
+                /* error rows: err0'[x] = err1[x] + t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2), err1'[x] = t(x+1)+h(x)+t(x-1) (optimize_state.c:446-465) */
+                uint32_t n0[4], n1[4];
+                for (int p = 0; p < 4; p++) {
+                    const int ch = seg_channel_of_plane(bpp, p);
+                    int c1 = 0, c2 = 0;
+                    if (ch >= 0)
+                        for (int dx = -2; dx <= 2; dx++) {
+                            const long sxp = (long)x + dx;
+                            if (sxp < 0 || sxp >= (long)W) continue;
+                            const uint32_t e = cwt[(tid + 2 + dx) * 4 + ch];
+                            const int T_ = (int)(int8_t)(e & 255u), F_ = (int)(int8_t)((e >> 8) & 255u), V_ = (int)(int8_t)((e >> 16) & 255u), H_ = (int)e >> 24;
+                            const int ad = dx < 0 ? -dx : dx;
+                            c1 += ad == 2 ? T_ : (ad == 1 ? F_ : V_);
+                            if (ad <= 1) c2 += ad == 1 ? T_ : H_;
+                        }
+                    n0[p] = (uint32_t)(seg_err_plane(e1, p) + c1) & 0xffffu;     /* int16 wrap-on-store */
+                    n1[p] = (uint32_t)c2 & 0xffffu;
+                }
+                j.old_above[x] = oldrow;
+                rowp[x] = npx[tid];
+                j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
+                j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
+                if (ynext < H) {
+                    const bool alpha0 = (bpp & 1u) == 0u && ((onext >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        if (alpha0 && c == bpp - 1u) continue;
+                        const int v = (int)((onext >> (8 * c)) & 255u) + seg_sext16((int)n0[seg_plane_of_channel(bpp, (int)c)]);
+                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
                     }
-                n0[p] = (uint32_t)(seg_err_plane(e1, p) + c1) & 0xffffu;     /* int16 wrap-on-store */
-                n1[p] = (uint32_t)c2 & 0xffffu;
-            }
-            j.old_above[x] = oldrow;
-            rowp[x] = ext[tid * 4 + 2];
-            j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
-            j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
-            if (ynext < H) {
-                const bool alpha0 = (bpp & 1u) == 0u && ((onext >> (8u * (bpp - 1u))) & 255u) == 0u;
-                for (uint32_t c = 0; c < bpp; c++) {
-                    if (alpha0 && c == bpp - 1u) continue;
-                    const int v = (int)((onext >> (8 * c)) & 255u) + seg_sext16((int)n0[seg_plane_of_channel(bpp, (int)c)]);
-                    vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
                 }
             }
-        }
-        vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-        if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
-        if (cw == 0 && tid == 0) {
-            if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
-            j.row_ids[y] = (uint8_t)winner;
+            vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+            if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
+            if (cw == 0 && tid == 0) {
+                if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
+                j.row_ids[y] = (uint8_t)winner;
+            }
         }
     }
     PLS_SYNC();
@@ -1843,7 +1899,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
  * bx > SEG_NFILT: commit of pixels [(bx - SEG_NFILT - 1) * SEG_THREADS, ...) */
 PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int bx, unsigned char *smem)
 {
-    if (bx > SEG_NFILT) { seg_ctl_commit(j, P, attempt, bx - SEG_NFILT - 1, smem); return; }
+    if (bx > SEG_CTL_IMG) { seg_ctl_commit(j, P, attempt, bx - SEG_CTL_IMG - 1, smem); return; }
     const int par = attempt & 1, prev = par ^ 1;
     const SegCtl &curg = j.ctl[prev];
     SegCtl &nxt = j.ctl[par];
@@ -1864,6 +1920,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         PLS_THREADS(tid, SEG_THREADS) {
             if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = ((const uint32_t *)&curg)[tid];
             if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = ((const uint32_t *)&Ag)[tid - 128];
+            if (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) rank[tid - 256] = j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)];
             for (int i = tid; i < (SEG_NFILT + 1) * 256; i += SEG_THREADS) {
                 const int w = i >> 8, b = i & 255;
                 uint32_t v;
@@ -1871,9 +1928,11 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 else {
                     uint32_t g0[SEG_MAX_NSEG / SEG_GRP];
                     const uint32_t bs = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
+                    PLS_UNROLL
                     for (uint32_t g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) g0[g] = g < ngrp ? j.grpcnt[((size_t)w * ngrp + g) * 256 + b] : 0u;
                     const uint32_t wsx = curg.start_x[w], wfg = (wsx / SEG_L) / SEG_GRP;
                     v = bs;
+                    PLS_UNROLL
                     for (uint32_t g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) v += (g >= wfg && g < ngrp && wsx < W) ? g0[g] : 0u;
                 }
                 spec[i] = v;
@@ -1881,15 +1940,20 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
         }
     }
     PLS_SYNC();
-    const SegCtl &cur = *(const SegCtl *)(uint32_t *)ctlc;
-    const SegAcc &A = *(const SegAcc *)(uint32_t *)accc;
-    const SegDecision D = seg_decide(j, P, attempt, cur, A);
+    unsigned long long tq1 = 0, tq2 = 0;
+    if (prof) tq1 = PLS_CLOCK();
+    seg_lds_ctl_t &cur = *(seg_lds_ctl_t *)ctlc;
+    seg_lds_acc_t &A = *(seg_lds_acc_t *)accc;
+    /* one lane decides, the workgroup reads the result (16 waves working it out side by side only take each other's issue slots) */
+    seg_lds_u32 dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
+    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
+    if (prof) tq2 = PLS_CLOCK();
     const uint32_t y = attempt ? cur.y : 0u;
     int s_next = attempt ? (int)cur.s : P.strength;
     if (D.kind == SEG_K_RETRY) s_next = (int)cur.s - 1;
     if (D.kind == SEG_K_COMMIT) s_next = P.strength;
 
-    if (bx == SEG_NFILT) {
+    if (bx == SEG_CTL_IMG) {
         /* ---- the image-wide fields ---- */
         if (D.kind == SEG_K_FINISHED) {
             PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
@@ -1925,7 +1989,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 24; i++) if (i < 8 || i > 18 || !(P.engine_flags & 1)) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
+                    for (int i = 0; i < 24; i++) if (i < 8 || i > 22 || i == 20 || !(P.engine_flags & 1)) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
                     j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
                     if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
@@ -1936,42 +2000,46 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     }
     if (D.kind == SEG_K_FINISHED) return;
 
-    /* ---- candidate f ---- */
-    const int f = bx;
+    /* ---- candidate f: SEG_TPARTS workgroups; all of them follow the decision and the new histogram, workgroup 0 writes the control
+     *      fields, each builds its share of the decision tables ---- */
+    const int f = bx / SEG_TPARTS, tpart = bx % SEG_TPARTS;
     const bool failed = (D.failed >> f) & 1u;
-    PLS_THREADS(tid, SEG_THREADS) { for (int b = tid; b < 256; b += SEG_THREADS) rank[b] = j.orig_rank[f * 256 + b]; }
+    if (!attempt) { PLS_THREADS(tid, SEG_THREADS) { for (int b = tid; b < 256; b += SEG_THREADS) rank[b] = j.orig_rank[f * 256 + b]; } }   /* (otherwise it came with the first burst) */
     if (D.kind != SEG_K_RESTART) {
         /* a fresh row attempt: start of the row, no validated prefix */
         seg_next_hist(D, spec, Hn, SEG_THREADS);
-        PLS_THREADS(tid, SEG_THREADS) {
-            for (int b = tid; b < 256; b += SEG_THREADS) { basen[b] = 0u; j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
-            if (tid == 0) {
-                /* candidate none starts lazy: its cost bound first, the chain only if that cannot rule it out (seg_decide) */
-                nxt.active[f] = (f == 0 && j.rowmm && !(P.engine_flags >> 8) && !(P.engine_flags & 2) && !(attempt && cur.none_eager)) ? 2u : 1u;
-                nxt.start_x[f] = 0; nxt.restarts[f] = 0; nxt.cost[f] = ~0ull;
-                for (int c = 0; c < 4; c++) nxt.state[f][c] = seg_state_pack(SegState{ 0, 0, 0 });
-            }
-        }
-        PLS_SYNC();
+        /* (global stores wait until nothing is left to synchronise: a barrier behind a store waits for the store to arrive) */
         const int sn = s_next < 0 ? 0 : s_next;
         unsigned long long tc1 = 0;
         if (prof) tc1 = PLS_CLOCK();
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS, prof ? &j.result[37] : nullptr);
-        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const unsigned long long t2 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[56], (int32_t)(tc1 - tc0)); PLS_ATOMIC_MAX(&j.result[57], (int32_t)(t2 - tc1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[59], (uint32_t)(tc1 - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[60], (uint32_t)(t2 - tc1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[61], 1u); } } }
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS, tpart, SEG_TPARTS, prof ? &j.result[37] : nullptr);
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tpart == 0) {
+                for (int b = tid; b < 256; b += SEG_THREADS) j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u;
+                if (tid == 0) {
+                    /* candidate none starts lazy: its cost bound first, the chain only if that cannot rule it out (seg_decide_combine) */
+                    nxt.active[f] = (f == 0 && j.rowmm && !(P.engine_flags >> 8) && !(P.engine_flags & 2) && !(attempt && cur.none_eager)) ? 2u : 1u;
+                    nxt.start_x[f] = 0; nxt.restarts[f] = 0; nxt.cost[f] = ~0ull;
+                    for (int c = 0; c < 4; c++) nxt.state[f][c] = seg_state_pack(SegState{ 0, 0, 0 });
+                }
+            }
+        }
+        if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const unsigned long long t2 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[56], (int32_t)(tc1 - tc0)); PLS_ATOMIC_MAX(&j.result[57], (int32_t)(t2 - tc1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[59], (uint32_t)(tc1 - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[60], (uint32_t)(t2 - tc1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[61], 1u); PLS_ATOMIC_ADD((uint32_t *)&j.result[19], (uint32_t)(tq1 - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[21], (uint32_t)(tq2 - tq1)); PLS_ATOMIC_ADD((uint32_t *)&j.result[22], (uint32_t)(tc1 - tq2)); } } }
         return;
     }
     if (f == 0 && cur.active[0] == 2 && (D.start_none || D.keep_lazy)) {
         PLS_THREADS(tid, SEG_THREADS) {
-            for (int b = tid; b < 256; b += SEG_THREADS) { Hn[b] = j.H0[prev * 256 + b]; j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
-            if (tid == 0) {
+            for (int b = tid; b < 256; b += SEG_THREADS) { Hn[b] = j.H0[prev * 256 + b]; if (tpart == 0) j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
+            if (tid == 0 && tpart == 0) {
                 nxt.active[0] = D.start_none ? 1u : 2u; nxt.start_x[0] = 0; nxt.restarts[0] = 0; nxt.cost[0] = ~0ull;
                 for (int c = 0; c < 4; c++) nxt.state[0][c] = seg_state_pack(SegState{ 0, 0, 0 });
             }
         }
         PLS_SYNC();
-        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, (int)cur.s, (int)cur.s + 1, SEG_THREADS);
+        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, (int)cur.s, (int)cur.s + 1, SEG_THREADS, tpart, SEG_TPARTS);
         return;
     }
+    if (tpart) return;                                        /* (an epoch inside the row is set up by one workgroup) */
     if (!failed) {
         /* nothing changes for this candidate: finished (now or earlier), its cost is kept */
         PLS_THREADS(tid, SEG_THREADS) {
@@ -1979,7 +2047,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             if (tid == 0) {
                 nxt.active[f] = 0; nxt.start_x[f] = cur.start_x[f]; nxt.restarts[f] = cur.restarts[f];
                 for (int c = 0; c < 4; c++) nxt.state[f][c] = cur.state[f][c];
-                nxt.cost[f] = D.cost[f];
+                nxt.cost[f] = (uint64_t)dshare[6 + 2 * f] | ((uint64_t)dshare[7 + 2 * f] << 32);     /* D.cost[f], from shared memory: indexing the copy in registers with f would send it to the stack */
             }
         }
         return;
@@ -2005,7 +2073,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 uint32_t *cd = j.cand + (size_t)f * W * 4;
                 for (uint32_t x = (uint32_t)seg_max((int)(sgp * SEG_L), (int)sx); x < xp; x++) for (uint32_t c = 0; c < bpp; c++) basen[seg_cand_bin(cd[(size_t)x * 4 + c])]++;
                 const uint32_t xend = serial ? W : xp + 1;
-                SegState st[4];
+                SegState *st = (SegState *)(uint32_t *)scratch;       /* [4], in shared memory: indexed by the channel, in registers it would go to the stack */
                 for (uint32_t c = 0; c < bpp; c++) {
                     int rem1, thr1, rem2, thr2;
                     seg_rem_thr(P.lut_a, P.bleed, xp >= 1 ? seg_cand_diff(cd[(size_t)(xp - 1) * 4 + c]) : 0, rem1, thr1);
@@ -2033,7 +2101,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
             }
         }
         PLS_SYNC();
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, G.s, G.q, SEG_THREADS);
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, G.s, G.q, SEG_THREADS, 0, 1);
     }
 }
 

@@ -80,14 +80,14 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.segcnt = A.take<uint16_t>((size_t)5 * j.nseg * 256);
     j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);
     j.firstidx = A.take<uint32_t>(5 * 4 * 2);
-    j.rowmm = A.take<int32_t>(2 * ((W + SEG_THREADS - 1) / SEG_THREADS));
+    j.rowmm = A.take<int32_t>(2 * ((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W));
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
-    const int ncommit = (int)((W + SEG_THREADS - 1) / SEG_THREADS);
+    const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
     int attempt = 0;
     const long max_attempts = (long)H * 64 + 1024;
     for (;; attempt++) {
         if (attempt > max_attempts) { fprintf(stderr, "seg_host: no progress\n"); return 65; }
-        for (int bx = 0; bx < SEG_NFILT + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt, bx, smem.data());
+        for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt, bx, smem.data());
         const int par = attempt & 1;
         if (j.ctl[par].finished) break;
         for (int f = 0; f < SEG_NFILT; f++) {

@@ -20,6 +20,39 @@ __global__ void k_produce(uint32_t *buf, unsigned n, unsigned stride, unsigned s
     if (i < n) buf[(size_t)i * stride] = ((i + (salt ? 257u : 1u)) % n) * stride;
 }
 __global__ void k_empty() {}
+// barriers: nb rounds of (one LDS write, barrier, one LDS read of a neighbour's word) in a workgroup of blockDim.x threads
+__global__ __launch_bounds__(1024) void k_barriers(unsigned nb, unsigned long long *res, uint32_t *sink)
+{
+    __shared__ uint32_t lds[1024];
+    uint32_t v = threadIdx.x;
+    __syncthreads();
+    unsigned long long t0 = wall_clock64();
+    for (unsigned k = 0; k < nb; k++) {
+        lds[threadIdx.x] = v + k;
+        __syncthreads();
+        v = lds[(threadIdx.x + 67) % blockDim.x];
+        __syncthreads();
+    }
+    unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) { res[0] = t1 - t0; sink[0] = v; }
+}
+// the same with a pending global store in front of every barrier
+__global__ __launch_bounds__(1024) void k_barriers_st(unsigned nb, unsigned long long *res, uint32_t *sink, uint32_t *glob)
+{
+    __shared__ uint32_t lds[1024];
+    uint32_t v = threadIdx.x;
+    __syncthreads();
+    unsigned long long t0 = wall_clock64();
+    for (unsigned k = 0; k < nb; k++) {
+        lds[threadIdx.x] = v + k;
+        glob[(size_t)k * 1024 + threadIdx.x] = v;
+        __syncthreads();
+        v = lds[(threadIdx.x + 67) % blockDim.x];
+        __syncthreads();
+    }
+    unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) { res[0] = t1 - t0; sink[0] = v; }
+}
 // producer whose working workgroups are those with blockIdx.x % 8 == xcd (workgroups go to the XCDs round robin): fills 32 KB per 256 KB block
 __global__ __launch_bounds__(1024) void k_produce_xcd(uint32_t *buf, unsigned xcd, unsigned salt)
 {
@@ -151,6 +184,17 @@ int main()
             printf("  8-word burst by workgroup 0 of lines produced by workgroups with id %% 8 == %u: %.0f ns\n", xcd, sw / 36 * tick_ns);
         }
         printf("1024-thread workgroup, 1 / 4 / 8 coalesced words per thread from fresh lines to LDS + barrier: %.0f / %.0f / %.0f ns\n", sb[0] / 56 * tick_ns, sb[1] / 56 * tick_ns, sb[2] / 56 * tick_ns);
+    }
+    for (unsigned nt = 64; nt <= 1024; nt *= 4) {
+        double a = 0, b2 = 0;
+        for (int r = 0; r < 30; r++) {
+            unsigned long long h[6];
+            hipLaunchKernelGGL(k_barriers, dim3(1), dim3(nt), 0, 0, 32u, res, out);
+            CK(hipMemcpy(h, res, sizeof h, hipMemcpyDeviceToHost)); if (r >= 2) a += (double)h[0];
+            hipLaunchKernelGGL(k_barriers_st, dim3(1), dim3(nt), 0, 0, 32u, res, out, fresh);
+            CK(hipMemcpy(h, res, sizeof h, hipMemcpyDeviceToHost)); if (r >= 2) b2 += (double)h[0];
+        }
+        printf("workgroup of %4u threads: LDS write, barrier, LDS read, barrier: %.0f ns per round; with a global store in front of the barrier: %.0f ns\n", nt, a / 28 / 32 * tick_ns, b2 / 28 / 32 * tick_ns);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms;
