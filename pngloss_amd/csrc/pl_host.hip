@@ -350,6 +350,9 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
                 std::fprintf(stderr, "pngloss_hip:   ... candidate workgroup, average (us): requests + copy %.2f, decision %.2f, new histogram + fields %.2f\n",
                              (uint32_t)r[19] / 100.0 / (uint32_t)r[61], (uint32_t)r[21] / 100.0 / (uint32_t)r[61], (uint32_t)r[22] / 100.0 / (uint32_t)r[61]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
+                std::fprintf(stderr, "pngloss_hip:   ... commit workgroup, average (us): requests + copy %.2f, decision %.2f, terms %.2f, rows + extremes %.2f\n",
+                             (uint32_t)r[23] / 100.0 / (uint32_t)r[63], (uint32_t)r[45] / 100.0 / (uint32_t)r[63], (uint32_t)r[54] / 100.0 / (uint32_t)r[63], (uint32_t)r[55] / 100.0 / (uint32_t)r[63]);
+            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
                 std::fprintf(stderr, "pngloss_hip:   ... table build, average (us): keys %.2f, classes %.2f, entries + write %.2f\n",
                              (uint32_t)r[37] / 100.0 / (uint32_t)r[61], (uint32_t)r[38] / 100.0 / (uint32_t)r[61], (uint32_t)r[39] / 100.0 / (uint32_t)r[61]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[32])

@@ -1808,24 +1808,45 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < SEG_COMMIT_W) {
             const uint32_t x = xw0 + (uint32_t)tid;
-            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = ((const uint32_t *)&curg)[tid];
-            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = ((const uint32_t *)&Ag)[tid - 128];
-            lutb[tid] = P.lut_b[tid]; lutb[tid + SEG_COMMIT_W] = P.lut_b[tid + SEG_COMMIT_W];
+            const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
+            const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
+            const uint32_t lb0 = P.lut_b[tid], lb1 = P.lut_b[tid + SEG_COMMIT_W];
             const long xh = tid < 2 ? (long)xw0 - 2 + tid : (long)xw0 + SEG_COMMIT_W + (tid - 2);     /* (threads 0..3) the halo pixel */
-            for (int f = 0; f < SEG_NFILT; f++)
+            /* every request first, then the stores: a loop that loads and stores turn by turn waits for each load on its own */
+            uint32_t w5[SEG_NFILT][4], h5[SEG_NFILT][4];
+            const bool inrow = x < W, halo = tid < 4 && xh >= 0 && xh < (long)W;
+            PLS_UNROLL
+            for (int f = 0; f < SEG_NFILT; f++) {
+                PLS_UNROLL
                 for (int q = 0; q < 4; q++) {
-                    cw5[(f * (SEG_COMMIT_W + 4) + tid + 2) * 4 + q] = x < W ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
-                    if (tid < 4) cw5[(f * (SEG_COMMIT_W + 4) + (tid < 2 ? tid : SEG_COMMIT_W + tid)) * 4 + q] = (xh >= 0 && xh < (long)W) ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
+                    w5[f][q] = inrow ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
+                    h5[f][q] = halo ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
                 }
-            ext[tid * 2 + 0] = x < W ? j.err1[2 * (size_t)x] : 0u; ext[tid * 2 + 1] = x < W ? j.err1[2 * (size_t)x + 1] : 0u;
+            }
+            const uint32_t e1a = inrow ? j.err1[2 * (size_t)x] : 0u, e1b = inrow ? j.err1[2 * (size_t)x + 1] : 0u;
+            PLS_UNROLL
+            for (int f = 0; f < SEG_NFILT; f++) {
+                PLS_UNROLL
+                for (int q = 0; q < 4; q++) {
+                    cw5[(f * (SEG_COMMIT_W + 4) + tid + 2) * 4 + q] = w5[f][q];
+                    if (tid < 4) cw5[(f * (SEG_COMMIT_W + 4) + (tid < 2 ? tid : SEG_COMMIT_W + tid)) * 4 + q] = h5[f][q];
+                }
+            }
+            ext[tid * 2 + 0] = e1a; ext[tid * 2 + 1] = e1b;
+            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
+            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
+            lutb[tid] = lb0; lutb[tid + SEG_COMMIT_W] = lb1;
             if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; }
         }
     }
     PLS_SYNC();
+    unsigned long long tk[4] = { 0, 0, 0, 0 };
+    if (prof) tk[0] = PLS_CLOCK();
     seg_lds_ctl_t &cur = *(seg_lds_ctl_t *)ctlc;
     seg_lds_acc_t &A = *(seg_lds_acc_t *)accc;
     const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
     if (D.kind != SEG_K_COMMIT) return;
+    if (prof) tk[1] = PLS_CLOCK();
     const int winner = D.winner;
     seg_lds_u32 cwt = cw5 + winner * (SEG_COMMIT_W + 4) * 4;
     const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
@@ -1842,6 +1863,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
         }
     }
     PLS_SYNC();
+    if (prof) tk[2] = PLS_CLOCK();
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < SEG_COMMIT_W) {
             const uint32_t x = xw0 + (uint32_t)tid;
@@ -1891,7 +1913,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
-    if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const uint32_t dt = (uint32_t)(PLS_CLOCK() - tc0); PLS_ATOMIC_MAX(&j.result[58], (int32_t)dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[62], dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[63], 1u); } } }
+    if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const uint32_t dt = (uint32_t)(PLS_CLOCK() - tc0); PLS_ATOMIC_MAX(&j.result[58], (int32_t)dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[62], dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[63], 1u); PLS_ATOMIC_ADD((uint32_t *)&j.result[23], (uint32_t)(tk[0] - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[45], (uint32_t)(tk[1] - tk[0])); PLS_ATOMIC_ADD((uint32_t *)&j.result[54], (uint32_t)(tk[2] - tk[1])); PLS_ATOMIC_ADD((uint32_t *)&j.result[55], (uint32_t)(PLS_CLOCK() - tk[2])); } } }
 }
 
 /* Control kernel of attempt `attempt`: reads what attempt-1 left (control block and sums of parity prev), writes the control block
@@ -1989,7 +2011,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 24; i++) if (i < 8 || i > 22 || i == 20 || !(P.engine_flags & 1)) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
+                    for (int i = 0; i < 24; i++) if (i < 8 || i == 20 || !(P.engine_flags & 1)) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
                     j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
                     if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
