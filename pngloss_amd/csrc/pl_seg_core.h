@@ -334,6 +334,31 @@ PLS_HD int seg_div_q(int a, const SegGeo &g)
 }
 
 /* the four channel records of pixel x (zero records beyond the row / for unused channels): every load of the pixel is issued once */
+/* the same in two steps -- the loads (registers), then the split into per-channel records -- so that a block can put all its
+ * requests in front of all its stores */
+struct SegPixRaw { uint32_t o, a, d, e0, e1; };
+PLS_HD SegPixRaw seg_pix_raw_zero() { SegPixRaw r; r.o = r.a = r.d = r.e0 = r.e1 = 0u; return r; }
+PLS_HD SegPixRaw seg_pix_fetch(const uint32_t *row, const uint32_t *nab, const uint32_t *err0, uint32_t x, uint32_t W)
+{
+    SegPixRaw r = seg_pix_raw_zero();
+    if (x < W) {
+        r.o = row[x];
+        if (nab) { r.a = nab[x]; r.d = x ? nab[x - 1] : 0u; }
+        r.e0 = err0[2 * (size_t)x]; r.e1 = err0[2 * (size_t)x + 1];
+    }
+    return r;
+}
+PLS_HD void seg_pix_split4(SegPix *dst, const SegPixRaw &r, uint32_t bpp, uint32_t x, uint32_t W)
+{
+    const uint32_t e[2] = { r.e0, r.e1 };
+    const bool alpha0 = x < W && (bpp & 1u) == 0u && ((r.o >> (8u * (bpp - 1u))) & 255u) == 0u;
+    for (int c = 0; c < 4; c++) {
+        if ((uint32_t)c < bpp && x < W)
+            dst[c] = seg_pix_make((int)((r.o >> (8 * c)) & 255u), (int)((r.a >> (8 * c)) & 255u), (int)((r.d >> (8 * c)) & 255u), (alpha0 && (uint32_t)c == bpp - 1u) ? 1 : 0,
+                                  seg_err_plane(e, seg_plane_of_channel(bpp, c)));
+        else dst[c] = seg_pix_make(0, 0, 0, 0, 0);
+    }
+}
 PLS_HD void seg_pix_load4(SegPix *dst, const uint32_t *row, const uint32_t *nab, const uint32_t *err0, uint32_t bpp, uint32_t x, uint32_t W)
 {
     uint32_t o = 0, a = 0, d = 0, e[2] = { 0, 0 };
@@ -675,10 +700,19 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
-        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
-        if (tid < 512) lut[tid] = P.lut_a[tid];
+        /* requests first, stores behind them (one round trip) */
+        constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
+        uint32_t vt[NTW], vl = 0;
+        SegPixRaw vp = seg_pix_raw_zero();
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (tid < 512) vl = P.lut_a[tid];
+        if (tid >= 512 && tid < 512 + SEG_L + 1) vp = seg_pix_fetch(row, nab, j.err0, x0 - 1 + (uint32_t)(tid - 512), W);
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        if (tid < 512) lut[tid] = vl;
         if (tid >= 512 && tid < 512 + SEG_L + 1) {
-            seg_pix_load4(px + (tid - 512) * 4, row, nab, j.err0, bpp, x0 - 1 + (uint32_t)(tid - 512), W);
+            seg_pix_split4(px + (tid - 512) * 4, vp, bpp, x0 - 1 + (uint32_t)(tid - 512), W);
             if ((bpp & 1u) == 0u && (px[(tid - 512) * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
         }
     }
@@ -790,10 +824,18 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
     PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) *trflag = 0u; }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
-        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
-        if (tid < 512) lut[tid] = P.lut_a[tid];
+        constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
+        uint32_t vt[NTW], vl = 0;
+        SegPixRaw vp = seg_pix_raw_zero();
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (tid < 512) vl = P.lut_a[tid];
+        if (tid < SEG_SMALL_SEGS * SEG_L) vp = seg_pix_fetch(row, nab, j.err0, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        if (tid < 512) lut[tid] = vl;
         if (tid < SEG_SMALL_SEGS * SEG_L) {
-            seg_pix_load4(px + tid * 4, row, nab, j.err0, bpp, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+            seg_pix_split4(px + tid * 4, vp, bpp, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
             if ((bpp & 1u) == 0u && (px[tid * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
         }
     }
@@ -887,10 +929,19 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_THREADS) {
-        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
-        if (tid < 512) lut[tid] = P.lut_a[tid];
-        if (tid >= 512 && tid < 768) seg_load_frozen(j, par, f, Hf, rank, tid - 512, 256);
-        if (tid >= 768 && tid < 768 + SEG_L) seg_pix_load4(px + (tid - 768) * 4, row, nab, j.err0, bpp, first * SEG_L + (uint32_t)(tid - 768), W);
+        constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
+        uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
+        SegPixRaw vp = seg_pix_raw_zero();
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (tid < 512) vl = P.lut_a[tid];
+        if (tid >= 512 && tid < 768) { const int b = tid - 512; vh = j.H0[par * 256 + b]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + b]; vr = j.orig_rank[f * 256 + b]; }
+        if (tid >= 768 && tid < 768 + SEG_L) vp = seg_pix_fetch(row, nab, j.err0, first * SEG_L + (uint32_t)(tid - 768), W);
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        if (tid < 512) lut[tid] = vl;
+        if (tid >= 512 && tid < 768) { Hf[tid - 512] = vh + vb; rank[tid - 512] = vr; }
+        if (tid >= 768 && tid < 768 + SEG_L) seg_pix_split4(px + (tid - 768) * 4, vp, bpp, first * SEG_L + (uint32_t)(tid - 768), W);
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
@@ -1125,39 +1176,60 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)ctl.s);
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-        /* the walkers' start states first: two dependent loads (dense id, then its checkpoints), in flight while the tables come in */
-        uint32_t st0 = 0, range = 0xFFFFFFFFu;
-        if (tid < SEG_GRP * SEG_PARTS * 4) {
-            const int sl = tid / (SEG_PARTS * 4), part = (tid >> 2) % SEG_PARTS, c = tid & 3;
-            const uint32_t sg = seg0 + (uint32_t)sl;
-            if (sg < nseg && sg >= first && (uint32_t)c < bpp) {
-                const size_t sc = ((size_t)f * nseg + sg) * 4 + c;
-                const uint32_t d = j.dnout[sc];
-                uint32_t ck[SEG_PARTS - 1];
-                for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = 0xFFFFFFFFu;
-                if (d != SEG_INVALID && d < SEG_NSP)
-                    for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = j.rck[(sc * SEG_NSP + d) * (SEG_PARTS - 1) + q];
-                const uint32_t x0 = sg * SEG_L, xend = (uint32_t)seg_min((int)(x0 + SEG_L), (int)W);
-                /* this lane's part has a start state: part 0 always (entry state, or the epoch's start inside the row's first segment) */
-                bool mine = part == 0;
-                uint32_t xa = sg == first ? sx : x0;
-                if (part == 0) st0 = sg == first ? ctl.state[f][c] : j.entry[sc];
-                else if (ck[part - 1] != 0xFFFFFFFFu && x0 + (uint32_t)part * SEG_PL < xend && x0 + (uint32_t)part * SEG_PL > xa) { mine = true; st0 = ck[part - 1]; xa = x0 + (uint32_t)part * SEG_PL; }
-                if (mine) {
-                    uint32_t xe = xend;                        /* up to the next part that starts on its own */
-                    for (int q = SEG_PARTS - 1; q > part; q--)
-                        if (ck[q - 1] != 0xFFFFFFFFu && x0 + (uint32_t)q * SEG_PL < xend && x0 + (uint32_t)q * SEG_PL > xa) xe = x0 + (uint32_t)q * SEG_PL;
-                    range = (xa - seg0 * SEG_L) | ((xe - seg0 * SEG_L) << 16);
-                    SEG_DEBUG_COUNT(part ? 1 : 0, xe - xa);
-                }
+        /* Order of the requests: the walkers' dense ids, then everything the block stages (tables, frozen histogram, pixels), then the
+         * checkpoints and entry states (which wait for the dense ids only); the stores to shared memory behind all of them. */
+        const bool walker = tid < SEG_GRP * SEG_PARTS * 4;
+        const int sl = tid / (SEG_PARTS * 4), part = (tid >> 2) % SEG_PARTS, c = tid & 3;
+        const uint32_t sg = seg0 + (uint32_t)sl;
+        const bool live = walker && sg < nseg && sg >= first && (uint32_t)c < bpp;
+        const size_t sc = ((size_t)f * nseg + (live ? sg : 0u)) * 4 + c;
+        const uint32_t d = live ? (uint32_t)j.dnout[sc] : SEG_INVALID;
+        constexpr int NTW = (SEG_TBL_WORDS + SEG_REPLAY_THREADS - 1) / SEG_REPLAY_THREADS;
+        uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (tid < 512) vl = P.lut_a[tid];
+        if (tid < 256) { vh = j.H0[par * 256 + tid]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + tid]; vr = j.orig_rank[f * 256 + tid]; }
+        const SegPixRaw vp = seg_pix_fetch(row, nab, j.err0, seg0 * SEG_L + (uint32_t)tid, W);
+        uint32_t ck[SEG_PARTS - 1], ent = 0;
+        PLS_UNROLL
+        for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = 0xFFFFFFFFu;
+        if (live) {
+            if (d != SEG_INVALID && d < SEG_NSP) {
+                PLS_UNROLL
+                for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = j.rck[(sc * SEG_NSP + d) * (SEG_PARTS - 1) + q];
             }
-            lane[2 * tid] = st0; lane[2 * tid + 1] = range;
+            if (part == 0) ent = sg == first ? ctl.state[f][c] : j.entry[sc];
         }
-        seg_load_frozen(j, par, f, Hf, rank, tid, SEG_REPLAY_THREADS);
-        for (int i = tid; i < 512; i += SEG_REPLAY_THREADS) lut[i] = P.lut_a[i];
-        for (int i = tid; i < SEG_TBL_WORDS; i += SEG_REPLAY_THREADS) tw[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+        uint32_t st0 = 0, range = 0xFFFFFFFFu;
+        if (live) {
+            const uint32_t x0 = sg * SEG_L, xend = (uint32_t)seg_min((int)(x0 + SEG_L), (int)W);
+            /* this lane's part has a start state: part 0 always (entry state, or the epoch's start inside the row's first segment) */
+            bool mine = part == 0;
+            uint32_t xa = sg == first ? sx : x0;
+            if (part == 0) st0 = ent;
+            else {
+                uint32_t ckp = 0xFFFFFFFFu;
+                PLS_UNROLL
+                for (int q = 0; q < SEG_PARTS - 1; q++) if (q == part - 1) ckp = ck[q];
+                if (ckp != 0xFFFFFFFFu && x0 + (uint32_t)part * SEG_PL < xend && x0 + (uint32_t)part * SEG_PL > xa) { mine = true; st0 = ckp; xa = x0 + (uint32_t)part * SEG_PL; }
+            }
+            if (mine) {
+                uint32_t xe = xend;                        /* up to the next part that starts on its own */
+                PLS_UNROLL
+                for (int q = SEG_PARTS - 1; q >= 1; q--)
+                    if (q > part && ck[q - 1] != 0xFFFFFFFFu && x0 + (uint32_t)q * SEG_PL < xend && x0 + (uint32_t)q * SEG_PL > xa) xe = x0 + (uint32_t)q * SEG_PL;
+                range = (xa - seg0 * SEG_L) | ((xe - seg0 * SEG_L) << 16);
+                SEG_DEBUG_COUNT(part ? 1 : 0, xe - xa);
+            }
+        }
+        if (walker) { lane[2 * tid] = st0; lane[2 * tid + 1] = range; }
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        if (tid < 512) lut[tid] = vl;
+        if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
         for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_THREADS) cnt[i] = 0u;
-        seg_pix_load4(px + tid * 4, row, nab, j.err0, bpp, seg0 * SEG_L + (uint32_t)tid, W);
+        seg_pix_split4(px + tid * 4, vp, bpp, seg0 * SEG_L + (uint32_t)tid, W);
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
@@ -1345,37 +1417,47 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     unsigned long long tk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (prof) tk[0] = PLS_CLOCK();
     PLS_THREADS(tid, SEG_THREADS) {
-        if (tid < 256) {
-            H0[tid] = j.H0[par * 256 + tid];
-            rank[tid] = j.orig_rank[f * 256 + tid];
-        }
-        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : 0u;
-        if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
-        for (int i = tid; i < (NPX + 2) * 4; i += SEG_THREADS) {
+        /* every request first, the stores to shared memory behind them: one round trip instead of one per statement (the compiler
+         * cannot move a load in front of an earlier store through a generic pointer) */
+        constexpr int NCW = ((NPX + 2) * 4 + SEG_THREADS - 1) / SEG_THREADS;
+        uint32_t vh0 = 0, vrank = 0, vlut = 0, vcw[NCW], vro = 0, vna = 0, voa = 0, ve0a = 0, ve0b = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (tid < 256) { vh0 = j.H0[par * 256 + tid]; vrank = j.orig_rank[f * 256 + tid]; }
+        if (tid >= 256 && tid < 768) vlut = P.lut_a[tid - 256];
+        PLS_UNROLL
+        for (int q = 0; q < NCW; q++) {
+            const int i = tid + q * SEG_THREADS;
             const long x = (long)xg0 - 2 + (i >> 2);
-            cw[i] = (x >= 0 && x < (long)W) ? j.cand[((size_t)f * W + (size_t)x) * 4 + (i & 3)] : 0u;
+            vcw[q] = (i < (NPX + 2) * 4 && x >= 0 && x < (long)W) ? j.cand[((size_t)f * W + (size_t)x) * 4 + (i & 3)] : 0u;
         }
         if (tid <= NPX) {
             const long x = (long)xg0 - 1 + tid;
             const bool in = x >= 0 && x < (long)W;
-            ro[tid] = in ? row[x] : 0u;
-            na[tid] = (in && nab) ? nab[x] : 0u;
-            oa[tid] = (in && y) ? j.old_above[x] : 0u;
+            vro = in ? row[x] : 0u;
+            vna = (in && nab) ? nab[x] : 0u;
+            voa = (in && y) ? j.old_above[x] : 0u;
         }
         if (tid >= 512 && tid - 512 < NPX) {
             const uint32_t x = xg0 + (uint32_t)(tid - 512);
-            e0[2 * (tid - 512)] = x < W ? j.err0[2 * (size_t)x] : 0u;
-            e0[2 * (tid - 512) + 1] = x < W ? j.err0[2 * (size_t)x + 1] : 0u;
+            ve0a = x < W ? j.err0[2 * (size_t)x] : 0u;
+            ve0b = x < W ? j.err0[2 * (size_t)x + 1] : 0u;
         }
         /* bump counts per segment of the group, staged (one 8-byte load per thread), prefix below */
+        const int sl = tid >> 6, q4 = tid & 63;
         {
-            const int sl = tid >> 6, q4 = tid & 63;
             const uint32_t sg = seg0 + (uint32_t)sl;
-            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             if (sg < nseg && sg >= first && sx < W) {
                 const uint16_t *sc = j.segcnt + ((size_t)f * nseg + sg) * 256 + 4 * q4;
                 c0 = sc[0]; c1 = sc[1]; c2 = sc[2]; c3 = sc[3];
             }
+        }
+        if (tid < 256) { H0[tid] = vh0; rank[tid] = vrank; }
+        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : 0u;
+        if (tid >= 256 && tid < 768) lut[tid - 256] = vlut;
+        PLS_UNROLL
+        for (int q = 0; q < NCW; q++) { const int i = tid + q * SEG_THREADS; if (i < (NPX + 2) * 4) cw[i] = vcw[q]; }
+        if (tid <= NPX) { ro[tid] = vro; na[tid] = vna; oa[tid] = voa; }
+        if (tid >= 512 && tid - 512 < NPX) { e0[2 * (tid - 512)] = ve0a; e0[2 * (tid - 512) + 1] = ve0b; }
+        {
             uint32_t *dst = cum + (sl + 1) * 256 + 4 * q4;
             dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
         }
@@ -1940,24 +2022,44 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     seg_lds_u32 ctlc = stage + (SEG_NFILT + 1) * 256, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2;
     if (attempt) {
         PLS_THREADS(tid, SEG_THREADS) {
-            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = ((const uint32_t *)&curg)[tid];
-            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = ((const uint32_t *)&Ag)[tid - 128];
-            if (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) rank[tid - 256] = j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)];
-            for (int i = tid; i < (SEG_NFILT + 1) * 256; i += SEG_THREADS) {
-                const int w = i >> 8, b = i & 255;
-                uint32_t v;
-                if (w == SEG_NFILT) v = j.H0[prev * 256 + b];
-                else {
-                    uint32_t g0[SEG_MAX_NSEG / SEG_GRP];
-                    const uint32_t bs = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
-                    PLS_UNROLL
-                    for (uint32_t g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) g0[g] = g < ngrp ? j.grpcnt[((size_t)w * ngrp + g) * 256 + b] : 0u;
-                    const uint32_t wsx = curg.start_x[w], wfg = (wsx / SEG_L) / SEG_GRP;
-                    v = bs;
-                    PLS_UNROLL
-                    for (uint32_t g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) v += (g >= wfg && g < ngrp && wsx < W) ? g0[g] : 0u;
+            /* every request of the burst first, the stores behind them */
+            const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
+            const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
+            const uint32_t rword = (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) ? j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)] : 0u;
+            constexpr int NSP = ((SEG_NFILT + 1) * 256 + SEG_THREADS - 1) / SEG_THREADS;
+            constexpr int NG = SEG_MAX_NSEG / SEG_GRP;
+            uint32_t bs[NSP], g0[NSP][NG], wsx[NSP];
+            PLS_UNROLL
+            for (int q = 0; q < NSP; q++) {
+                const int i = tid + q * SEG_THREADS, w = i >> 8, b = i & 255;
+                bs[q] = 0; wsx[q] = 0;
+                PLS_UNROLL
+                for (int g = 0; g < NG; g++) g0[q][g] = 0u;
+                if (i < (SEG_NFILT + 1) * 256) {
+                    if (w == SEG_NFILT) bs[q] = j.H0[prev * 256 + b];
+                    else {
+                        bs[q] = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
+                        wsx[q] = curg.start_x[w];
+                        PLS_UNROLL
+                        for (int g = 0; g < NG; g++) if ((uint32_t)g < ngrp) g0[q][g] = j.grpcnt[((size_t)w * ngrp + g) * 256 + b];
+                    }
                 }
-                spec[i] = v;
+            }
+            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
+            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
+            if (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) rank[tid - 256] = rword;
+            PLS_UNROLL
+            for (int q = 0; q < NSP; q++) {
+                const int i = tid + q * SEG_THREADS, w = i >> 8;
+                if (i < (SEG_NFILT + 1) * 256) {
+                    uint32_t v = bs[q];
+                    if (w != SEG_NFILT) {
+                        const uint32_t wfg = (wsx[q] / SEG_L) / SEG_GRP;
+                        PLS_UNROLL
+                        for (int g = 0; g < NG; g++) v += ((uint32_t)g >= wfg && (uint32_t)g < ngrp && wsx[q] < W) ? g0[q][g] : 0u;
+                    }
+                    spec[i] = v;
+                }
             }
         }
     }
