@@ -26,7 +26,7 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
     if (i < n) sj[i].bpp = pl_job_bpp(jobs[i]);
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *sj, const SegParams *P, int attempt)
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int attempt)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *sj, const
     seg_ctl_body(j, *P, attempt, (int)blockIdx.x, seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_enum(const SegJob *sj, const SegParams *P, int par, unsigned max_nseg)
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_enum(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_nseg)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
@@ -57,14 +57,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_k_enum(const SegJob *sj, cons
     }
 }
 
-__global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *sj, const SegParams *P, int par)
+__global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     seg_chain_body(j, *P, par, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *sj, const SegParams *P, int par, unsigned max_ngrp)
+__global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob 
     seg_replay_body(j, *P, par, (int)f, (int)grp, seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_post(const SegJob *sj, const SegParams *P, int par, unsigned max_ngrp)
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_post(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];

@@ -1041,8 +1041,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                     const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
                     const uint32_t k = t >> sh, d = t & (stride - 1), sg = s0 + k;
                     const bool valid = t < total && d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                    v[q] = SEG_INVALID;
-                    if (valid) v[q] = maps[(size_t)(sg + 1) * mstep + r[q]];
+                    /* (no branch around the load: the eight of them leave together; an index that is not valid reads entry 0 of a row that exists) */
+                    const uint32_t mv = maps[(size_t)(valid ? sg + 1 : s0) * mstep + (valid ? r[q] : 0u)];
+                    v[q] = valid ? mv : (uint32_t)SEG_INVALID;
                     if (!valid) ps[q] = SEG_NOSTATE;
                 }
                 PLS_UNROLL
