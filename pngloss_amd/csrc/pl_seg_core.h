@@ -163,6 +163,7 @@ struct SegParams {
     /* filters whose prediction ignores the left pixel (none, up): the state is (cn, th) alone */
     uint8_t rt_max[256];           /* [D] -> max |rem(d)| + max |thr(d)| over |d| <= D (capped at 255) */
     int32_t ns_small, small_ok;
+    uint32_t idx0_big, idx0_small; /* entry index of the state a fresh row starts with (nothing carried, boundary record all zero) */
     uint32_t st_small[SEG_NSS];    /* state i -> (cn+128) | (th+128) << 8 */
     uint16_t keylut_small[SEG_KEYS_MAX];   /* (cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
 };
@@ -177,6 +178,16 @@ struct SegCtl {
     uint32_t restarts[SEG_NFILT];    /* epochs of this candidate in this row */
     uint64_t cost[SEG_NFILT];        /* final row cost of a finished candidate (~0 = rejected) */
 };
+
+/* the fields of the control block a workgroup branches on, in one burst of loads (read one by one where they are needed, each
+ * `if` waits for its own round trip to device memory) */
+struct SegCtlView { uint32_t finished, y, s, active, start_x; };
+PLS_HD SegCtlView seg_ctl_view(const SegCtl &c, int f)
+{
+    SegCtlView v;
+    v.finished = c.finished; v.y = c.y; v.s = c.s; v.active = c.active[f]; v.start_x = c.start_x[f];
+    return v;
+}
 
 struct SegAcc {
     uint64_t derr[SEG_NFILT];
@@ -616,6 +627,12 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
         }
         P.ns_small = ok ? n2 : 0; P.small_ok = ok ? 1 : 0;
     }
+    {
+        const SegState z = { 0, 0, 0 };
+        const SegPix b0 = seg_pix_make(0, 0, 0, 0, 0);
+        P.idx0_big = seg_state_encode(P, b0, z);
+        P.idx0_small = P.small_ok ? seg_small_encode(P, z) : (uint32_t)SEG_INVALID;
+    }
     return true;
 }
 
@@ -671,11 +688,12 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
 PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || ctl.active[f] != 1) return;
+    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     const uint32_t x0 = (uint32_t)seg * SEG_L;
     if (x0 >= W) return;                                      /* (the last segment has no successor, but the replay wants its checkpoints) */
-    if (ctl.start_x[f] && x0 <= ctl.start_x[f]) return;       /* an epoch that starts inside the row: its first (partial) segment is walked by
+    if (cv.start_x && x0 <= cv.start_x) return;       /* an epoch that starts inside the row: its first (partial) segment is walked by
                                                                  seg_first_body.  A fresh row starts from the known state in front of pixel 0,
                                                                  which has an index like any other (boundary record = zeros): segment 0 is
                                                                  enumerated with the rest */
@@ -688,9 +706,9 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint32_t *uniq = (uint32_t *)(dense + 4 * SEG_HT);        /* [4][SEG_NSP] the distinct states, packed */
     uint16_t *res = (uint16_t *)(uniq + 4 * SEG_NSP);         /* [4][SEG_NSP] exit index of each distinct state */
     uint16_t *lslot = res + 4 * SEG_NSP;                      /* [SEG_THREADS] the hash slot of every lane's state (or 0xffff) */
-    const uint32_t y = ctl.y;
+    const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G = seg_geo((int)ctl.s);
+    const SegGeo G = seg_geo((int)cv.s);
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long te[5] = { 0, 0, 0, 0, 0 };
     if (prof) te[0] = PLS_CLOCK();
@@ -811,15 +829,16 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
 PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || ctl.active[f] != 1) return;
+    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
-    if ((uint32_t)(seg0 + SEG_SMALL_SEGS) * SEG_L <= ctl.start_x[f]) return;
+    if ((uint32_t)(seg0 + SEG_SMALL_SEGS) * SEG_L <= cv.start_x) return;
     uint32_t *tw = (uint32_t *)smem;
     uint32_t *lut = tw + SEG_TBL_WORDS;
     SegPix *px = (SegPix *)(lut + 512);                        /* [SEG_SMALL_SEGS][SEG_L][4] */
-    const uint32_t y = ctl.y;
+    const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G = seg_geo((int)ctl.s);
+    const SegGeo G = seg_geo((int)cv.s);
     uint32_t *trflag = (uint32_t *)(px + SEG_SMALL_SEGS * SEG_L * 4);
     PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) *trflag = 0u; }
     PLS_SYNC();
@@ -844,7 +863,7 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
     PLS_THREADS(tid, SEG_THREADS) {
         const int sl = tid / (4 * SEG_NSS), c = (tid / SEG_NSS) & 3, i = tid % SEG_NSS;
         const uint32_t seg = (uint32_t)seg0 + (uint32_t)sl, x0 = seg * SEG_L;
-        if (seg < j.nseg && x0 < W && (x0 > ctl.start_x[f] || ctl.start_x[f] == 0) && (uint32_t)c < bpp && i < P.ns_small) {
+        if (seg < j.nseg && x0 < W && (x0 > cv.start_x || cv.start_x == 0) && (uint32_t)c < bpp && i < P.ns_small) {
             SegState st;
             uint32_t out = SEG_INVALID;
             const size_t slot = (((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i;
@@ -914,9 +933,10 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
 PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || ctl.active[f] != 1) return;
+    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
-    const uint32_t sx = ctl.start_x[f];
+    const uint32_t sx = cv.start_x;
     if (sx >= W || sx == 0) return;                           /* a fresh row needs no walk: its segment 0 is enumerated */
     const uint32_t first = sx / SEG_L;
     if (first + 1 >= nseg) return;                            /* no segment behind it */
@@ -925,9 +945,9 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
     uint32_t *Hf = lut + 512, *rank = Hf + 256;
     SegPix *px = (SegPix *)(rank + 256);                      /* [SEG_L][4] */
     const unsigned long long tf0 = (P.engine_flags & 1) ? PLS_CLOCK() : 0ull;
-    const uint32_t y = ctl.y;
+    const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G = seg_geo((int)ctl.s);
+    const SegGeo G = seg_geo((int)cv.s);
     PLS_THREADS(tid, SEG_THREADS) {
         constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
         uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
@@ -974,9 +994,10 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || ctl.active[f] != 1 || (uint32_t)c >= j.bpp) return;
+    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
-    const uint32_t sx = ctl.start_x[f];
+    const uint32_t sx = cv.start_x;
     if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
     SEG_AS_GLB uint16_t *dnout = j.dnout + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
@@ -996,7 +1017,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     seg_lds_u16 G = (seg_lds_u16)(dn + ((nseg + 1) & ~1u));    /* [nblk][stride] composed tables of the blocks */
     seg_lds_u16 T = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;   /* [ns][stride]: T[k] takes a dense id of segment s0+k to one of segment s0+k+1 */
     seg_lds_u32 R = (seg_lds_u32)(T + (size_t)((ns + 1) & ~1u) * stride);    /* [ns][stride] (useR): exit state of segment s0+k under that id */
-    const uint32_t y = ctl.y;
+    const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SEG_AS_GLB uint16_t *maps = j.maps + ((size_t)f * nseg * 4 + c) * (size_t)P.nsp;     /* + sg * 4 * nsp */
     const SEG_AS_GLB uint16_t *rout = j.rout + ((size_t)f * nseg * 4 + c) * SEG_NSP;           /* + sg * 4 * SEG_NSP */
@@ -1015,13 +1036,11 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     PLS_SYNC();
     for (int pass = 0; pass < 2; pass++) {
         PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            if (pass == 0 && tid == SEG_CHAIN_THREADS - 1) {
-                SegPix b0 = seg_pix_make(0, 0, 0, 0, 0);
-                const uint32_t idx_first = sx ? j.firstidx[(f * 4 + c) * 2] : seg_any_encode(P, f, b0, start0);
-                idxb[29] = idx_first;
-                idxb[28] = (idx_first != SEG_INVALID && (int)idx_first < nstates) ? (uint32_t)maps[(size_t)s0 * mstep + idx_first] : SEG_INVALID;
-                entry[(size_t)s0 * 4] = sx ? j.firstidx[(f * 4 + c) * 2 + 1] : seg_state_pack(start0);
-            }
+            /* (one lane) the state the chain starts from: its loads ride along with the gather's, one level each */
+            const bool starter = pass == 0 && tid == SEG_CHAIN_THREADS - 1;
+            uint32_t fi0 = 0, fi1 = 0, dfirst = SEG_INVALID;
+            if (starter) { fi0 = j.firstidx[(f * 4 + c) * 2]; fi1 = j.firstidx[(f * 4 + c) * 2 + 1]; }
+            const uint32_t idx_first = sx ? fi0 : (seg_is_small(P, f) ? P.idx0_small : P.idx0_big);
             const uint32_t total = ns << sh;
             for (uint32_t base = 0; base < total; base += SEG_CQ * SEG_CHAIN_THREADS) {
                 uint32_t dcv[SEG_CQ], r[SEG_CQ], ps[SEG_CQ], v[SEG_CQ];
@@ -1036,6 +1055,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                         if (useR) ps[q] = rst[(size_t)sg * rstep + d];
                     }
                 }
+                if (starter && base == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(size_t)s0 * mstep + idx_first];
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
                     const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
@@ -1055,6 +1075,12 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                         if ((t & (stride - 1)) == 0 && (dcv[q] > stride || (P.engine_flags & 4))) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], dcv[q]); }
                     }
                 }
+            }
+            if (starter) {
+                if (total == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(size_t)s0 * mstep + idx_first];
+                idxb[29] = idx_first;
+                idxb[28] = dfirst;
+                entry[(size_t)s0 * 4] = sx ? fi1 : seg_state_pack(start0);
             }
         }
         PLS_SYNC();
@@ -1107,7 +1133,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     if (idxb[31]) {
         /* (rare) some state on the path lies outside what the enumeration covers: segment after segment, through its tables where
          * that works, step by step where it does not */
-        const SegGeo G_ = seg_geo((int)ctl.s);
+        const SegGeo G_ = seg_geo((int)cv.s);
         PLS_THREADS(tid, SEG_CHAIN_THREADS) {
             if (tid < 256) seg_load_frozen(j, par, f, Hf, rank, tid, 256);
             if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
@@ -1162,9 +1188,10 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
 PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || ctl.active[f] != 1) return;
+    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
-    const uint32_t sx = ctl.start_x[f];
+    const uint32_t sx = cv.start_x;
     if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
     const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
@@ -1173,9 +1200,9 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_GRP][SEG_L][4] */
     uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
     uint32_t *lane = cnt + SEG_GRP * 256;                     /* [SEG_GRP * SEG_PARTS * 4][2]: start state, first | end pixel << 16 (or ~0: idle) */
-    const uint32_t y = ctl.y;
+    const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G = seg_geo((int)ctl.s);
+    const SegGeo G = seg_geo((int)cv.s);
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
         /* Order of the requests: the walkers' dense ids, then everything the block stages (tables, frozen histogram, pixels), then the
          * checkpoints and entry states (which wait for the dense ids only); the stores to shared memory behind all of them. */
@@ -1357,12 +1384,9 @@ PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
  * clamp moved it towards 0..255);  D <= s + overshoot(C), overshoot = how far orig + e0 +- C can leave 0..255 (rowmm holds the row's
  * extremes of orig + e0);  C <= max |rem| + max |thr| over |d| <= D.  Iterated from C = the table bound to a fixed point; -1 = none found
  * (then no bound is claimed). */
-PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s)
+PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int m)
 {
     if (!j.rowmm) return -1;
-    int M = -(1 << 30), m = 1 << 30;
-    const int nc = (int)((j.W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
-    for (int i = 0; i < nc; i++) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
     int C = P.cmax;
     for (int it = 0; it < 4; it++) {
         const int ov = seg_max(0, seg_max(M + C - 255, C - m));
@@ -1385,9 +1409,10 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s)
 PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    if (ctl.finished || !ctl.active[f]) return;
+    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    if (cv.finished || !cv.active) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
-    const uint32_t sx = ctl.start_x[f];
+    const uint32_t sx = cv.start_x;
     const uint32_t first = sx / SEG_L, fgrp = first / SEG_GRP;
     const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
     constexpr int NPX = SEG_GRP * SEG_L;                       /* pixels of a group */
@@ -1408,12 +1433,12 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint32_t *pcw = (uint32_t *)(binb + SEG_GRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][SEG_PC_STRIDE] prefix counts of the watched bins */
     uint32_t *btop = pcw + SEG_WATCH * SEG_PC_STRIDE;          /* [2][SEG_NBAND][4] */
     uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
-    const uint32_t y = ctl.y;
+    const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
-    const SegGeo G = seg_geo((int)ctl.s);
+    const SegGeo G = seg_geo((int)cv.s);
     const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
     const uint32_t xg0 = seg0 * SEG_L;
-    const bool lazy = ctl.active[f] == 2;                       /* candidate none, not run yet: only its cost bound is wanted */
+    const bool lazy = cv.active == 2;                       /* candidate none, not run yet: only its cost bound is wanted */
     const bool prof = (P.engine_flags & 1) != 0;                /* debugging: phase clocks (100 MHz ticks) into result[40..], max over the workgroups */
     unsigned long long tk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (prof) tk[0] = PLS_CLOCK();
@@ -1467,13 +1492,18 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < 256) {
             const int b = tid;
-            uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b], total = before;
-            if (sx < W)
-                for (uint32_t g = fgrp; g < ngrp; g++) {
-                    const uint32_t v = j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
-                    total += v;
-                    if (g < (uint32_t)grp) before += v;
-                }
+            /* (all groups requested at once, the ones that do not count masked out: a loop with the load inside waits for every one) */
+            uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b], total;
+            uint32_t gv[SEG_MAX_NSEG / SEG_GRP];
+            PLS_UNROLL
+            for (int g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) gv[g] = ((uint32_t)g < ngrp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;
+            total = before;
+            PLS_UNROLL
+            for (int g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) {
+                const bool in = sx < W && (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
+                total += in ? gv[g] : 0u;
+                before += (in && g < grp) ? gv[g] : 0u;
+            }
             Hpost[b] = H0[b] + total;
             uint32_t run = before;
             for (int sl = 0; sl <= SEG_GRP; sl++) {
@@ -1566,7 +1596,20 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
      *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
      *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) red[12] = (uint32_t)(f == 0 ? seg_none_reach(j, P, (int)ctl.s) : -1); }
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { red[14] = 0x80000000u ^ (uint32_t)(-(1 << 30)); red[15] = 0x80000000u ^ (uint32_t)(1 << 30); } }   /* (biased: unsigned max / min) */
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) {
+        /* the row's extremes of orig + incoming error: one pair per commit workgroup, read side by side */
+        const int nc = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
+        if (f == 0 && j.rowmm && tid < 64) {
+            int M = -(1 << 30), m = 1 << 30;
+            for (int i = tid; i < nc; i += 64) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
+            M = pls_wave_max_i(M); m = pls_wave_min_i(m);
+            PLS_ATOMIC_MAX_U(&red[14], 0x80000000u ^ (uint32_t)M); PLS_ATOMIC_MIN(&red[15], 0x80000000u ^ (uint32_t)m);
+        }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) red[12] = (uint32_t)(f == 0 ? seg_none_reach(j, P, (int)cv.s, (int)(red[14] ^ 0x80000000u), (int)(red[15] ^ 0x80000000u)) : -1); }
     PLS_SYNC();
     const int R = (int)red[12];
     if (f == 0 && R >= 0) {
