@@ -176,11 +176,12 @@ def engine_kernels():
     (profiles/r03_kernel_trace_stats.txt): calls, average duration, share of the engine's time."""
     out = {}
     try:
-        for ln in open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")):
-            if "seg_k_" in ln and ln.count(",") >= 5:
-                f = [x.strip('"') for x in ln.strip().split('","')]
-                name = f[0].split("seg_k_")[1].split("(")[0]
-                out["seg_k_" + name] = {"calls": int(f[1]), "avg_us": round(float(f[3]) / 1e3, 2), "percent_of_gpu_time": round(float(f[4]), 2)}
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")) as fh:
+            for f in csv.reader(ln for ln in fh if not ln.startswith("#")):
+                if len(f) >= 5 and "seg_k_" in f[0] and "resolve" not in f[0]:
+                    name = f[0].split("seg_k_")[1].split("(")[0]
+                    out["seg_k_" + name] = {"calls": int(f[1]), "avg_us": round(float(f[3]) / 1e3, 2), "percent_of_gpu_time": round(float(f[4]), 2)}
     except (OSError, ValueError, IndexError):
         pass
     if out:
@@ -194,13 +195,14 @@ def bandwidth_kernels():
     out = {}
     alg = {"pl_classify": 4 * W * H, "pl_hist": 4 * W * H}   # both read the 4 B/px image once
     try:
-        for ln in open(os.path.join(ROOT, "profiles", "r02_v3_kernel_trace_stats.txt")):
-            for name, nbytes in alg.items():
-                if name + "(" in ln and name not in out:
-                    f = ln.split()
-                    avg_us = float(f[-2])
-                    out[name] = {"avg_us": avg_us, "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / avg_us / 1e3, 1),
-                                 "frac_of_8TBps": round(nbytes / avg_us / 1e3 / 8000.0, 4)}
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")) as fh:
+            for f in csv.reader(ln for ln in fh if not ln.startswith("#")):
+                for name, nbytes in alg.items():
+                    if len(f) >= 5 and name + "(" in f[0] and name not in out:
+                        avg_us = round(float(f[3]) / 1e3, 2)
+                        out[name] = {"avg_us": avg_us, "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / avg_us / 1e3, 1),
+                                     "frac_of_8TBps": round(nbytes / avg_us / 1e3 / 8000.0, 4)}
     except (OSError, ValueError, IndexError):
         pass
     if out:
