@@ -227,7 +227,21 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         for (size_t i = 0; i < n; i++) { widths[i] = images[i].width; seg_max_nseg = std::max(seg_max_nseg, (images[i].width + SEG_L - 1) / SEG_L); }
         const bool forced = em && std::strcmp(em, "seg") == 0;
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
-        if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && (forced || n * (size_t)seg_max_nseg <= 2048))
+        /* Cost model (measured): the segment engine spends ~65 us per row attempt whatever the width, as long as
+         * its workgroups (about 3 per segment and image) fit the machine's ~512 resident ones; the workgroup engine ~0.16 us per pixel
+         * of its largest image, all images side by side.  Narrow images (< ~450 pixels) are faster on the latter. */
+        bool worth = forced;
+        if (!worth && n * (size_t)seg_max_nseg <= 2048) {
+            double wg_us = 0, seg_rows = 0, seg_wgs = 0;
+            for (size_t i = 0; i < n; i++) {
+                wg_us = std::max(wg_us, 0.16 * (double)images[i].width * (double)images[i].height);
+                seg_rows = std::max(seg_rows, (double)images[i].height);
+                seg_wgs += 3.0 * ((images[i].width + SEG_L - 1) / SEG_L) + 40.0;
+            }
+            const double seg_us = seg_rows * 65.0 * std::max(1.0, seg_wgs / 512.0);
+            worth = seg_us < wg_us;
+        }
+        if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && worth)
             use_seg = pl_seg_supported(widths.data(), n, strength, bleed, &seg_params);
         if (forced && !use_seg && n)
             std::fprintf(stderr, "pngloss_hip: PNGLOSS_HIP_ENGINE=seg: strength %u / bleed %ld or a width beyond %d are not covered by the segment engine; using the one-workgroup-per-image engine\n", strength, bleed, SEG_MAX_NSEG * SEG_L);

@@ -289,17 +289,18 @@ def test_strength_bleed_sweep_8192_matches_reference_digests(torch_cuda):
 
 
 def test_segment_engine_is_the_default_for_single_images_and_reports_what_it_did(torch_cuda):
-    """No engine pinned: a single image of a strength/bleed the segment engine has lanes for goes through it (engine_info says so),
-    other strengths fall back to the workgroup engine; both exact."""
+    """No engine pinned: a single wide image of a strength/bleed the segment engine has lanes for goes through it (engine_info says
+    so), other strengths and narrow images go to the workgroup engine; all exact."""
     torch = torch_cuda
     env_before = os.environ.pop("PNGLOSS_HIP_ENGINE", None)
     try:
-        for (s, b, want) in [(19, 2, "segment-parallel"), (85, 2, "workgroup-per-image")]:
-            img = P.synth_rgba(1000, 70, 0, 4)
+        # (a narrow image is faster on the workgroup engine: the segment engine's row attempt costs the same whatever the width)
+        for (w, s, b, want) in [(1000, 19, 2, "segment-parallel"), (1000, 85, 2, "workgroup-per-image"), (200, 19, 2, "workgroup-per-image")]:
+            img = P.synth_rgba(w, 70, 0, 4)
             d = torch.from_numpy(img.copy()).cuda()
             f = torch.zeros(70, dtype=torch.uint8, device="cuda")
             ctx = P.HipContext()
-            res = ctx.run([(d.data_ptr(), f.data_ptr(), 1000, 70)], s, b, stream=torch.cuda.current_stream().cuda_stream)
+            res = ctx.run([(d.data_ptr(), f.data_ptr(), w, 70)], s, b, stream=torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             info = ctx.engine_info(0)
             assert info["engine"] == want, info
