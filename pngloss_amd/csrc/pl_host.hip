@@ -227,18 +227,19 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         for (size_t i = 0; i < n; i++) { widths[i] = images[i].width; seg_max_nseg = std::max(seg_max_nseg, (images[i].width + SEG_L - 1) / SEG_L); }
         const bool forced = em && std::strcmp(em, "seg") == 0;
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
-        /* Cost model (measured): the segment engine spends ~65 us per row attempt whatever the width, as long as
-         * its workgroups (about 3 per segment and image) fit the machine's ~512 resident ones; the workgroup engine ~0.16 us per pixel
-         * of its largest image, all images side by side.  Narrow images (< ~450 pixels) are faster on the latter. */
+        /* Cost model (measured on 1 .. 64 frames of 512x512 and 1920x1080, tests/tools/gpu_seg_batch.py): a row
+         * attempt of the segment engine takes ~51 us plus ~0.032 us per workgroup of its widest kernel (about 3 per segment and 40
+         * more per image), whatever the width; the workgroup engine ~0.18 us per pixel of its largest image, all images side by
+         * side.  So: wide images and small batches to the former, narrow images (< ~400 pixels) and large batches to the latter. */
         bool worth = forced;
-        if (!worth && n * (size_t)seg_max_nseg <= 2048) {
+        if (!worth && n * (size_t)seg_max_nseg <= 4096) {
             double wg_us = 0, seg_rows = 0, seg_wgs = 0;
             for (size_t i = 0; i < n; i++) {
-                wg_us = std::max(wg_us, 0.16 * (double)images[i].width * (double)images[i].height);
+                wg_us = std::max(wg_us, 0.18 * (double)images[i].width * (double)images[i].height);
                 seg_rows = std::max(seg_rows, (double)images[i].height);
                 seg_wgs += 3.0 * ((images[i].width + SEG_L - 1) / SEG_L) + 40.0;
             }
-            const double seg_us = seg_rows * 65.0 * std::max(1.0, seg_wgs / 512.0);
+            const double seg_us = seg_rows * (51.0 + 0.032 * seg_wgs);
             worth = seg_us < wg_us;
         }
         if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && worth)
