@@ -186,6 +186,7 @@ PLS_HD SegCtlView seg_ctl_view(const SegCtl &c, int f)
 {
     SegCtlView v;
     v.finished = c.finished; v.y = c.y; v.s = c.s; v.active = c.active[f]; v.start_x = c.start_x[f];
+    /* (forcing all five to arrive here -- an empty asm that names them -- was measured 1 % slower than letting the compiler place the waits) */
     return v;
 }
 
