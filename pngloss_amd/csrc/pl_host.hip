@@ -584,7 +584,8 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
 {
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
-    /* one device arena for the whole batch: [image | filter flags | emitted ids | emitted rows] per image, 256-B aligned */
+    /* one device arena for the whole batch, 256-B aligned: first [image | filter flags] of every image -- the part that has a pinned
+     * mirror on the host --, behind them [emitted ids | emitted rows] of every image (those come back straight into the caller's memory) */
     std::vector<size_t> img_off(n), flt_off(n), ids_off(n), rows_off(n);
     std::vector<EmitTarget> emits(n);
     size_t total = 0;
@@ -593,6 +594,10 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
         if (px && !images[i].rgba) return PNGLOSS_INVALID_ARGUMENT;
         img_off[i] = total; total = align_up(total + px * 4, 256);
         flt_off[i] = total; total = align_up(total + (images[i].row_filters ? images[i].height : 0), 256);
+    }
+    const size_t mirrored = total;
+    for (size_t i = 0; i < n; i++) {
+        const size_t px = (size_t)images[i].width * images[i].height;
         const bool want = ((lines && lines[i].scanlines && lines[i].filter_types) || (zs && zs[i].data)) && px;
         const uint32_t pitch = want ? (uint32_t)align_up((size_t)images[i].width * 4, 16) : 0;
         if (want && lines && lines[i].pitch < (size_t)images[i].width * 4) return PNGLOSS_INVALID_ARGUMENT;
@@ -611,10 +616,10 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
         PL_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_arena), want));
         ctx->arena_bytes = want;
     }
-    if (total > ctx->pinned_bytes) {
+    if (mirrored > ctx->pinned_bytes) {
         if (ctx->h_pinned) PL_CHECK(hipHostFree(ctx->h_pinned));
         ctx->h_pinned = nullptr; ctx->pinned_bytes = 0;
-        const size_t want = align_up(total + total / 8, 1 << 20);
+        const size_t want = align_up(mirrored + mirrored / 8, 1 << 20);
         PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), want, hipHostMallocDefault));
         ctx->pinned_bytes = want;
     }
