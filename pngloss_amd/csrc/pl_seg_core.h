@@ -481,6 +481,7 @@ template <int F> PLS_HD int seg_predict_t(int above, int diag, int left)
  * bad accumulates "this lane left what the tables cover" (band beyond +-SEG_TOFF, |diff| > 255): its results are void then and the
  * caller falls back (enumeration: the map entry is SEG_INVALID; replay / walk: seg_step_scan).  Returns the candidate word. */
 /* 24-bit multiply (full rate on the device; the 32-bit v_mul_lo_u32 is quarter rate) */
+PLS_HD uint32_t seg_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 PLS_HD int seg_mul24(int a, int b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1027,8 +1028,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     SEG_AS_GLB uint32_t *entry = j.entry + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
     const size_t mstep = 4 * (size_t)P.nsp, rstep = 4 * SEG_NSP;
     const int nstates = P.ns;
+    const uint32_t eflags = (uint32_t)P.engine_flags, mstep32_ = (uint32_t)mstep;
     const SegState start0 = { 0, 0, 0 };
-    const bool prof = (P.engine_flags & 1) != 0;
+    const bool prof = (eflags & 1) != 0;
     unsigned long long tc[5] = { 0, 0, 0, 0, 0 };
     if (prof) tc[0] = PLS_CLOCK();
     /* -- gather: T[k][d] = maps_{k+1}[rout_k[d]] and R[k][d] = the exit state itself (= entry state of segment k+1); per item three
@@ -1043,42 +1045,44 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
             if (starter) { fi0 = j.firstidx[(f * 4 + c) * 2]; fi1 = j.firstidx[(f * 4 + c) * 2 + 1]; }
             const uint32_t idx_first = sx ? fi0 : (seg_is_small(P, f) ? P.idx0_small : P.idx0_big);
             const uint32_t total = ns << sh;
-            for (uint32_t base = 0; base < total; base += SEG_CQ * SEG_CHAIN_THREADS) {
+            /* item (k, d): k = segment (relative), d = dense id; this thread's items share d and step through k by kstep.  32-bit offsets
+             * from uniform bases (the whole gather is bound by the instructions 1024 threads issue on one CU, not by memory) */
+            const uint32_t d = (uint32_t)tid & (stride - 1), k0 = (uint32_t)tid >> sh, kstep = (uint32_t)SEG_CHAIN_THREADS >> sh;
+            const uint32_t mstep32 = (uint32_t)mstep, rstep32 = (uint32_t)rstep;
+            uint32_t widest = 0;
+            for (uint32_t kb = 0; kb < ns; kb += SEG_CQ * kstep) {
+                /* no branch per item: an item beyond the last segment is clamped onto it and does that segment's work once more (same
+                 * values to the same places) -- 70 scalar branches and their mask arithmetic were half of this block's instructions */
                 uint32_t dcv[SEG_CQ], r[SEG_CQ], ps[SEG_CQ], v[SEG_CQ];
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
-                    const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
-                    dcv[q] = 0; r[q] = SEG_INVALID; ps[q] = SEG_NOSTATE;
-                    if (t < total) {
-                        const uint32_t k = t >> sh, d = t & (stride - 1), sg = s0 + k;
-                        dcv[q] = dcnt[(size_t)sg * 4];
-                        r[q] = rout[(size_t)sg * rstep + d];
-                        if (useR) ps[q] = rst[(size_t)sg * rstep + d];
-                    }
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u), sg = s0 + k;
+                    const uint32_t o = sg * rstep32 + d;
+                    dcv[q] = dcnt[sg * 4u];
+                    r[q] = rout[o];
+                    ps[q] = useR ? rst[o] : SEG_NOSTATE;
                 }
-                if (starter && base == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(size_t)s0 * mstep + idx_first];
+                if (starter && kb == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[s0 * mstep32 + idx_first];
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
-                    const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
-                    const uint32_t k = t >> sh, d = t & (stride - 1), sg = s0 + k;
-                    const bool valid = t < total && d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                    /* (no branch around the load: the eight of them leave together; an index that is not valid reads entry 0 of a row that exists) */
-                    const uint32_t mv = maps[(size_t)(valid ? sg + 1 : s0) * mstep + (valid ? r[q] : 0u)];
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u), sg = s0 + k;
+                    const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
+                    const uint32_t mv = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
                     v[q] = valid ? mv : (uint32_t)SEG_INVALID;
-                    if (!valid) ps[q] = SEG_NOSTATE;
+                    ps[q] = valid ? ps[q] : SEG_NOSTATE;
+                    widest = dcv[q] > widest ? dcv[q] : widest;
                 }
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
-                    const uint32_t t = base + (uint32_t)tid + (uint32_t)q * SEG_CHAIN_THREADS;
-                    if (t < total) {
-                        T[t] = (uint16_t)v[q];
-                        if (useR) R[t] = ps[q];
-                        if ((t & (stride - 1)) == 0 && (dcv[q] > stride || (P.engine_flags & 4))) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], dcv[q]); }
-                    }
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u);
+                    const uint32_t t = (k << sh) + d;
+                    T[t] = (uint16_t)v[q];
+                    if (useR) R[t] = ps[q];
                 }
             }
+            if (widest > stride || ((eflags & 4) && total)) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], widest); }
             if (starter) {
-                if (total == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(size_t)s0 * mstep + idx_first];
+                if (total == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[s0 * mstep32_ + idx_first];
                 idxb[29] = idx_first;
                 idxb[28] = dfirst;
                 entry[(size_t)s0 * 4] = sx ? fi1 : seg_state_pack(start0);
