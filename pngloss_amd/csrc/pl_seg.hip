@@ -77,9 +77,10 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_k_post(const SegJob *__restri
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    const unsigned f = blockIdx.x / max_ngrp, grp = blockIdx.x % max_ngrp;
-    if (grp >= j.ngrp) return;
-    seg_post_body(j, *P, par, (int)f, (int)grp, seg_smem);
+    /* validation groups are half replay groups: max_ngrp * (SEG_GRP / SEG_VGRP) workgroups per candidate */
+    const unsigned per = max_ngrp * (SEG_GRP / SEG_VGRP), f = blockIdx.x / per, vg = blockIdx.x % per;
+    if (vg * SEG_VGRP >= j.nseg) return;
+    seg_post_body(j, *P, par, (int)f, (int)vg, seg_smem);
 }
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -159,6 +160,6 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     hipLaunchKernelGGL(seg_k_enum, dim3(b.enum_blocks, n), dim3(SEG_THREADS), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
     hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
-    hipLaunchKernelGGL(seg_k_post, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_THREADS), SEG_SM_POST, stream, b.d_sj, b.d_params, par, b.max_ngrp);
+    hipLaunchKernelGGL(seg_k_post, dim3(SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP), n), dim3(SEG_THREADS), SEG_SM_POST, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();
 }

@@ -123,6 +123,7 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_L 32                 /* pixels per segment (16 was measured: enumeration -5 us, chain +5 us, no gain) */
 #endif
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
+#define SEG_VGRP 8                /* segments per VALIDATION workgroup (half a replay group: one decision per thread, twice the CUs) */
 #define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
 #define SEG_COMMIT_W 256           /* control kernel: pixels per commit workgroup */
 #define SEG_CTL_IMG (SEG_NFILT * SEG_TPARTS)      /* blockIdx.x of the image-wide workgroup; the commit workgroups follow */
@@ -1306,7 +1307,7 @@ struct SegVal {
 };
 #define SEG_BINB_STRIDE (SEG_L * 4 + 4)
 #define SEG_PC_SEG (SEG_L + 1)                   /* words per segment and slot (one pad word: bank spread) */
-#define SEG_PC_STRIDE (SEG_GRP * SEG_PC_SEG + 8)
+#define SEG_PC_STRIDE (SEG_VGRP * SEG_PC_SEG + 8)
 #define SEG_NBAND 20
 PLS_HD uint32_t seg_pc_get(const uint32_t *pcw, uint32_t slot, int d)
 {
@@ -1411,7 +1412,7 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int
  * front of a decision: validated prefix (base) + whole groups + whole segments (counts written by the replay) + the earlier
  * decisions of its own segment (counted here).  Cheap bound first (counts at the segment's start and end), exact count only when
  * the bound cannot tell. */
-PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
+PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, int vg, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
     const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
@@ -1419,11 +1420,12 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
     const uint32_t sx = cv.start_x;
     const uint32_t first = sx / SEG_L, fgrp = first / SEG_GRP;
-    const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
-    constexpr int NPX = SEG_GRP * SEG_L;                       /* pixels of a group */
+    const uint32_t seg0 = (uint32_t)vg * SEG_VGRP;             /* vg: validation group = SEG_VGRP segments (half a replay group) */
+    const uint32_t grp = seg0 / SEG_GRP, segp = grp * SEG_GRP;  /* the replay group it lies in, and that group's first segment */
+    constexpr int NPX = SEG_VGRP * SEG_L;                       /* pixels of a group */
     uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256, *Hpost = H0 + 512;
-    uint32_t *cum = H0 + 768;                                  /* [(SEG_GRP + 1)][256]: bumps in front of each segment of the group */
-    uint32_t *cw = cum + (SEG_GRP + 1) * 256;                  /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
+    uint32_t *cum = H0 + 768;                                  /* [(2 * SEG_VGRP + 1)][256]: bumps in front of each segment of the group */
+    uint32_t *cw = cum + (2 * SEG_VGRP + 1) * 256;             /* (rows SEG_VGRP+1 ..: the bumps of the replay group's segments in front of this half) */                  /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
     uint32_t *red = cw + (NPX + 2) * 4;                        /* reductions: derr lo/hi, cost, hs[5], fail, lb lo/hi */
     uint32_t *lut = red + 64;                                  /* [512] split table */
     uint32_t *ro = lut + 512;                                  /* [NPX + 1] original row, from pixel xg0 - 1 */
@@ -1434,8 +1436,8 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint32_t *wbits = rm + 768;                                /* [8] bitmap of watched bins, [8] pending decisions / slots in use, [9..] bin of each slot */
     uint8_t *slot_of = (uint8_t *)(wbits + 32);                /* [256] slot of a watched bin or 255 */
     uint8_t *pend = slot_of + 256;                             /* [NPX * 4] decision waits for pass 3 */
-    uint8_t *binb = pend + NPX * 4;                            /* [SEG_GRP][SEG_BINB_STRIDE] bin of every decision */
-    uint32_t *pcw = (uint32_t *)(binb + SEG_GRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][SEG_PC_STRIDE] prefix counts of the watched bins */
+    uint8_t *binb = pend + NPX * 4;                            /* [SEG_VGRP][SEG_BINB_STRIDE] bin of every decision */
+    uint32_t *pcw = (uint32_t *)(binb + SEG_VGRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][SEG_PC_STRIDE] prefix counts of the watched bins */
     uint32_t *btop = pcw + SEG_WATCH * SEG_PC_STRIDE;          /* [2][SEG_NBAND][4] */
     uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
     const uint32_t y = cv.y;
@@ -1475,8 +1477,10 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         /* bump counts per segment of the group, staged (one 8-byte load per thread), prefix below */
         const int sl = tid >> 6, q4 = tid & 63;
         {
-            const uint32_t sg = seg0 + (uint32_t)sl;
-            if (sg < nseg && sg >= first && sx < W) {
+            /* lanes of rows 0 .. SEG_VGRP-1: this group's segments; rows SEG_VGRP ..: the segments of the same REPLAY group in front of it
+             * (the replay's group counts are per SEG_GRP segments: what lies between that group's start and ours is added from these) */
+            const uint32_t sg = sl < SEG_VGRP ? seg0 + (uint32_t)sl : segp + (uint32_t)(sl - SEG_VGRP);
+            if (sg < nseg && sg >= first && sx < W && (sl < SEG_VGRP || sg < seg0)) {
                 const uint16_t *sc = j.segcnt + ((size_t)f * nseg + sg) * 256 + 4 * q4;
                 c0 = sc[0]; c1 = sc[1]; c2 = sc[2]; c3 = sc[3];
             }
@@ -1507,12 +1511,13 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             for (int g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) {
                 const bool in = sx < W && (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
                 total += in ? gv[g] : 0u;
-                before += (in && g < grp) ? gv[g] : 0u;
+                before += (in && (uint32_t)g < grp) ? gv[g] : 0u;
             }
             Hpost[b] = H0[b] + total;
+            for (int r = SEG_VGRP + 1; r <= 2 * SEG_VGRP; r++) before += cum[r * 256 + b];
             uint32_t run = before;
-            for (int sl = 0; sl <= SEG_GRP; sl++) {
-                const uint32_t add = sl < SEG_GRP ? cum[(sl + 1) * 256 + b] : 0u;
+            for (int sl = 0; sl <= SEG_VGRP; sl++) {
+                const uint32_t add = sl < SEG_VGRP ? cum[(sl + 1) * 256 + b] : 0u;
                 cum[sl * 256 + b] = run;
                 run += add;
             }
@@ -1530,7 +1535,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         if (tid < 8) wbits[tid] = 0u;
         if (tid == 8) wbits[8] = 0u;                                   /* number of pending decisions */
         if (tid >= 64 && tid < 128) ((uint32_t *)slot_of)[tid - 64] = 0xffffffffu;
-        if (tid >= 256 && tid < 512) { const int b = tid - 256; hiG[b] = H0[b] + cum[SEG_GRP * 256 + b]; loG[b] = H0[b] + cum[b]; }
+        if (tid >= 256 && tid < 512) { const int b = tid - 256; hiG[b] = H0[b] + cum[SEG_VGRP * 256 + b]; loG[b] = H0[b] + cum[b]; }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
@@ -1570,7 +1575,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) {
             const int sl = tid / SEG_WATCH, slot = tid % SEG_WATCH;
-            if (sl < SEG_GRP && slot < (int)wbits[8]) {
+            if (sl < SEG_VGRP && slot < (int)wbits[8]) {
                 /* bumps of the slot's bin in front of every decision of segment sl, four decisions per word in and out */
                 const uint32_t b = wbits[9 + slot];
                 const uint32_t *src = (const uint32_t *)(binb + sl * SEG_BINB_STRIDE);
@@ -1760,7 +1765,7 @@ PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int a
          * errors are all that is committed.) */
         uint64_t best_other = ~0ull;
         for (int f = 1; f < SEG_NFILT; f++) if (!((D.failed >> f) & 1u) && D.cost[f] < best_other) best_other = D.cost[f];
-        if (A.lb_valid == j.ngrp && best_other < A.none_lb) {
+        if (A.lb_valid == (j.nseg + SEG_VGRP - 1) / SEG_VGRP && best_other < A.none_lb) {
             D.failed &= ~1u; D.cost[0] = ~0ull; D.dropped_none = 1; lazy0 = false;
             any_failed = D.failed != 0;
         }

@@ -97,7 +97,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         for (int f = 0; f < SEG_NFILT; f++) seg_first_body(j, P, par, f, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, smem.data());
-        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_post_body(j, P, par, f, (int)g, smem.data());
+        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, par, f, (int)vg, smem.data());
     }
     const SegCtl &fc = j.ctl[attempt & 1];
     if (getenv("SEG_HOST_VERBOSE")) fprintf(stderr, "seg_host: replay lanes from an entry state %llu (%.1f px each), from a checkpoint %llu (%.1f px each)\n", seg_dbg[0][0], seg_dbg[0][0] ? (double)seg_dbg[0][1] / seg_dbg[0][0] : 0.0, seg_dbg[1][0], seg_dbg[1][0] ? (double)seg_dbg[1][1] / seg_dbg[1][0] : 0.0);
