@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <mutex>
 #include <new>
@@ -57,8 +58,9 @@ struct pngloss_hip_ctx {
     bool want_progress = false;
     /* segment-parallel engine: two host-mapped words (images finished, attempt being started) the control kernel writes and the
      * launch loop reads, and what the last batch did */
-    bool split_last = false;         /* the last host window ran in two halves: images behind n_last are the peer's */
-    pngloss_hip_ctx *peer = nullptr; /* second context on the same device: the other half of a host window (batch_host) */
+    bool split_last = false;         /* the last host window ran in chunks: images behind n_last are the peers' */
+    std::vector<pngloss_hip_ctx *> peers;   /* further contexts on the same device: the other chunks of a host window (batch_host) */
+    std::vector<size_t> chunk_first; /* first image of every chunk of the last split window (chunk 0 is this context's) */
     uint32_t *h_seg_words = nullptr;
     int last_engine = 0;            /* 0 = one workgroup per image (pl_engine), 3 = segment-parallel (pl_seg) */
     long seg_attempts = 0;
@@ -557,7 +559,8 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->h_progress) (void)hipHostFree(ctx->h_progress);
     if (ctx->h_seg_words) (void)hipHostFree(ctx->h_seg_words);
-    if (ctx->peer) { pngloss_hip_destroy(ctx->peer); ctx->peer = nullptr; }
+    for (pngloss_hip_ctx *p : ctx->peers) if (p) pngloss_hip_destroy(p);
+    ctx->peers.clear();
     delete ctx;
 }
 
@@ -578,10 +581,16 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
     return finish(ctx, results, n);
 }
 
+/* chunks of one host window take turns at the two phases that are bound by the host's memory (staging in, fanning out), so that
+ * chunk k+1 stages while chunk k computes instead of every chunk being in the same phase at the same time */
+struct HostTurns { std::atomic<int> stage_turn{ 0 }; std::mutex out_mu; };
+
 static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n, unsigned quantization_strength,
                       long bleed_divider, pngloss_hip_result *results, pngloss_hip_scanlines *lines,
-                      pngloss_hip_zstream *zs)
+                      pngloss_hip_zstream *zs, HostTurns *turns = nullptr, int my_turn = 0)
 {
+    /* whatever happens below, the next chunk must get its turn */
+    struct TurnGuard { HostTurns *t; int mine; bool passed = false; void pass() { if (t && !passed) { while (t->stage_turn.load(std::memory_order_acquire) != mine) std::this_thread::yield(); t->stage_turn.store(mine + 1, std::memory_order_release); passed = true; } } ~TurnGuard() { pass(); } } turn{ turns, my_turn };
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     /* one device arena for the whole batch, 256-B aligned: first [image | filter flags] of every image -- the part that has a pinned
@@ -627,6 +636,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
     char *const arena = ctx->d_arena;
     int rc = PNGLOSS_SUCCESS;
     std::vector<pngloss_hip_image_desc> descs(n);
+    if (turns) while (turns->stage_turn.load(std::memory_order_acquire) != my_turn) std::this_thread::yield();
     const auto tu0 = std::chrono::steady_clock::now();
     {
         const unsigned nthreads = (unsigned)std::min<size_t>(12, std::max<size_t>(1, n));
@@ -640,6 +650,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
             });
         for (auto &th : pool) th.join();
     }
+    turn.pass();                                              /* the next chunk may stage while this one uploads and computes */
     for (size_t i = 0; i < n; i++) {
         const size_t px = (size_t)images[i].width * images[i].height;
         descs[i] = pngloss_hip_image_desc{ px ? arena + img_off[i] : nullptr,
@@ -679,6 +690,8 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
             }
             if (rc == PNGLOSS_SUCCESS && hipStreamSynchronize(ctx->copy_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
             if (rc == PNGLOSS_SUCCESS) {
+                std::unique_lock<std::mutex> out_lock;
+                if (turns) out_lock = std::unique_lock<std::mutex>(turns->out_mu);
                 const unsigned nthreads = (unsigned)std::min<size_t>(12, std::max<size_t>(1, n));
                 std::vector<std::thread> pool;
                 for (unsigned t = 0; t < nthreads; t++)
@@ -710,6 +723,9 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
         }
     }
     ctx->download_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
+    if (std::getenv("PNGLOSS_HIP_DEBUG_SEAM"))
+        std::fprintf(stderr, "pngloss_hip: host window chunk %d: %zu images, wait+stage+upload %.1f ms, engine %.1f ms (enqueue..finish %.1f ms), download+fan-out %.1f ms\n", my_turn, n, ctx->upload_ms, ctx->engine_ms,
+                     std::chrono::duration<double, std::milli>(td0 - tu0).count() - ctx->upload_ms, ctx->download_ms);
     if (zs && rc == PNGLOSS_SUCCESS) {
         /* the colour type decides the scanline length, so it is fetched before the deflate stage is laid out */
         const auto t0 = std::chrono::steady_clock::now();
@@ -762,31 +778,60 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
     const char *no = std::getenv("PNGLOSS_HIP_NO_SPLIT");
     ctx->split_last = false;
-    if (n < 16 || zs || (no && *no == '1')) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
-    if (!ctx->peer) {
-        ctx->peer = pngloss_hip_create(ctx->device);
-        if (!ctx->peer) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
+    /* Chunks, each on its own context and stream, staggered by the staging turns: chunk k+1 is staged and uploaded while chunk k
+     * computes, chunk k is downloaded while chunk k+1 computes.  Measured on 256 x 1280x720 (profiles/r03_host_seam.txt): one chunk
+     * 0.237 s, two 0.221 s, four 0.218 s (the engine alone: 0.176 s) -- two it is; PNGLOSS_HIP_SPLIT=k for experiments. */
+    size_t K = n >= 16 ? 2 : 1;
+    if (const char *ks = std::getenv("PNGLOSS_HIP_SPLIT")) { const long v = std::atol(ks); if (v >= 1 && v <= 8) K = (size_t)v; }
+    if (K > n) K = n ? n : 1;
+    if (K <= 1 || zs || (no && *no == '1')) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
+    while (ctx->peers.size() < K - 1) {
+        pngloss_hip_ctx *p = pngloss_hip_create(ctx->device);
+        if (!p) break;
+        ctx->peers.push_back(p);
     }
-    /* cut where half of the pixels are */
-    size_t total = 0, run = 0, cut = n / 2;
+    K = std::min(K, ctx->peers.size() + 1);
+    if (K <= 1) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
+    /* cut where the pixels are: equal shares */
+    size_t total = 0;
     for (size_t i = 0; i < n; i++) total += (size_t)images[i].width * images[i].height;
-    for (size_t i = 0; i < n; i++) { run += (size_t)images[i].width * images[i].height; if (2 * run >= total) { cut = i + 1; break; } }
-    if (cut == 0 || cut >= n) cut = n / 2;
+    std::vector<size_t> first(K + 1, n);
+    first[0] = 0;
+    {
+        size_t run = 0, c = 1;
+        for (size_t i = 0; i < n && c < K; i++) {
+            run += (size_t)images[i].width * images[i].height;
+            if (run * K >= total * c && i + 1 < n) first[c++] = i + 1;
+        }
+        for (; c < K; c++) first[c] = n;
+    }
     std::vector<pngloss_hip_result> own;
     if (!results) { own.resize(n); results = own.data(); }
-    int rc2 = PNGLOSS_SUCCESS;
-    std::thread second([&]() {
-        rc2 = batch_host_one(ctx->peer, images + cut, n - cut, quantization_strength, bleed_divider, results + cut, lines ? lines + cut : nullptr, nullptr);
-    });
-    const int rc1 = batch_host_one(ctx, images, cut, quantization_strength, bleed_divider, results, lines ? lines + 0 : nullptr, nullptr);
-    second.join();
+    HostTurns turns;
+    std::vector<int> rcs(K, PNGLOSS_SUCCESS);
+    auto run_chunk = [&](size_t c) {
+        pngloss_hip_ctx *cc = c == 0 ? ctx : ctx->peers[c - 1];
+        rcs[c] = batch_host_one(cc, images + first[c], first[c + 1] - first[c], quantization_strength, bleed_divider, results + first[c],
+                                lines ? lines + first[c] : nullptr, nullptr, &turns, (int)c);
+    };
+    std::vector<std::thread> others;
+    for (size_t c = 1; c < K; c++) others.emplace_back(run_chunk, c);
+    run_chunk(0);
+    for (auto &t : others) t.join();
     ctx->split_last = true;
-    ctx->engine_ms = std::max(ctx->engine_ms, ctx->peer->engine_ms);
-    ctx->total_ms = std::max(ctx->total_ms, ctx->peer->total_ms);
-    ctx->upload_ms += ctx->peer->upload_ms; ctx->download_ms += ctx->peer->download_ms;
-    if (rc1 != PNGLOSS_SUCCESS && rc1 != PNGLOSS_INTERNAL_ABORT) return rc1;
-    if (rc2 != PNGLOSS_SUCCESS && rc2 != PNGLOSS_INTERNAL_ABORT) return rc2;
-    return (rc1 == PNGLOSS_INTERNAL_ABORT || rc2 == PNGLOSS_INTERNAL_ABORT) ? PNGLOSS_INTERNAL_ABORT : PNGLOSS_SUCCESS;
+    ctx->chunk_first.assign(first.begin(), first.begin() + (long)K);
+    for (size_t c = 1; c < K; c++) {
+        pngloss_hip_ctx *p = ctx->peers[c - 1];
+        ctx->engine_ms = std::max(ctx->engine_ms, p->engine_ms);
+        ctx->total_ms = std::max(ctx->total_ms, p->total_ms);
+        ctx->upload_ms += p->upload_ms; ctx->download_ms += p->download_ms;
+    }
+    bool aborted = false;
+    for (size_t c = 0; c < K; c++) {
+        if (rcs[c] == PNGLOSS_INTERNAL_ABORT) aborted = true;
+        else if (rcs[c] != PNGLOSS_SUCCESS) return rcs[c];
+    }
+    return aborted ? PNGLOSS_INTERNAL_ABORT : PNGLOSS_SUCCESS;
 }
 
 int pngloss_hip_optimize_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images, size_t n,
@@ -926,9 +971,18 @@ double pngloss_hip_last_deflate_ms(const pngloss_hip_ctx *ctx) { return ctx ? ct
 double pngloss_hip_last_engine_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->engine_ms : -1.0; }
 double pngloss_hip_last_total_ms(const pngloss_hip_ctx *ctx) { return ctx ? ctx->total_ms : -1.0; }
 
+/* the context that ran image `index` of the last (possibly split) host window, and the image's index there */
+static pngloss_hip_ctx *chunk_of(pngloss_hip_ctx *ctx, size_t &index)
+{
+    if (!ctx || !ctx->split_last || index < ctx->n_last) return ctx;
+    for (size_t c = ctx->chunk_first.size(); c-- > 1;)
+        if (index >= ctx->chunk_first[c] && c - 1 < ctx->peers.size() && ctx->peers[c - 1]) { index -= ctx->chunk_first[c]; return ctx->peers[c - 1]; }
+    return ctx;
+}
+
 int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *hist256)
 {
-    if (ctx && ctx->split_last && ctx->peer && index >= ctx->n_last) return pngloss_hip_last_histogram(ctx->peer, index - ctx->n_last, hist256);
+    ctx = chunk_of(ctx, index);
     if (!ctx || !hist256 || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     PL_CHECK(hipMemcpy(hist256, ctx->h_jobs[index].final_hist, sizeof(uint32_t) * PL_NSYM, hipMemcpyDeviceToHost));
@@ -980,7 +1034,7 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
 
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8])
 {
-    if (ctx && ctx->split_last && ctx->peer && index >= ctx->n_last) return pngloss_hip_last_engine_info(ctx->peer, index - ctx->n_last, info);
+    ctx = chunk_of(ctx, index);
     if (!ctx || !info || index >= ctx->n_last || ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     PL_CHECK(hipSetDevice(ctx->device));
     int32_t r[64] = { 0 };

@@ -295,9 +295,12 @@ class HipContext:
         self.enqueue(images, strength, bleed, stream)
         return self.finish()
 
-    def run_host(self, arrays, strength=19, bleed=2, want_filters=True):
-        """pngloss_hip_optimize_batch_host on a list of (H, W, 4) uint8 arrays.  Returns (outs, filters, results)."""
-        outs = [np.ascontiguousarray(a).copy() for a in arrays]
+    def run_host(self, arrays, strength=19, bleed=2, want_filters=True, inplace=False):
+        """pngloss_hip_optimize_batch_host on a list of (H, W, 4) uint8 arrays.  Returns (outs, filters, results).
+        inplace: the arrays (C-contiguous uint8) are optimised where they are, like the C call does; otherwise copies are."""
+        outs = list(arrays) if inplace else [np.ascontiguousarray(a).copy() for a in arrays]
+        if inplace:
+            assert all(a.flags["C_CONTIGUOUS"] and a.dtype == np.uint8 for a in outs)
         filts = [np.zeros(a.shape[0], np.uint8) if want_filters else None for a in outs]
         n = len(outs)
         imgs = (HostImage * max(n, 1))()
