@@ -1591,7 +1591,11 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
              * no DPP, and plain VALU/LDS waves sharing a SIMD do not slow each other (profiles/r01_ubench_simd_sharing.txt).
              * Rows that do not meet its preconditions take the round-1 chains below. */
             const bool lead_ok = (prm.engine_mode & 15) != 1 && s + 1 <= 128 && !wrap && big_lead == 0;
-            const bool lead = lead_ok && !(use_legacy && (prm.engine_mode & 15) == 0);
+            /* engine_mode 3 ("mix", a test hook): the two kinds of chains take turns every four rows, whatever the clocks say -- the
+             * adaptive choice (mode 0) depends on measured cycles and would not reproduce a mismatch of one of them */
+            if (lead_ok && (prm.engine_mode & 15) == 3) use_legacy = ((y >> 2) & 1u) != 0u;
+            const bool lead = lead_ok && !(use_legacy && ((prm.engine_mode & 15) == 0 || (prm.engine_mode & 15) == 3));
+            if ((prm.engine_mode & 15) == 3 && lead_ok && !lead) adapt_legacy_rows++;
             const int lead_f = wave == 0 ? 2 : (wave == 1 ? 1 : (wave == 2 ? 3 : (wave == 3 ? 4 : 0)));   /* up | sub | average | paeth | none */
             const bool paired = s + 1 <= 48;
             if (lead) {
@@ -1681,6 +1685,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
                 /* (band-leader rows: the faster of the last two, so that a single slow row -- they exist, 7x the average -- is not a reason to switch) */
                 if (lead) { est_lead = adapt_prev_lead ? min(pp, adapt_last_lead) : pp; adapt_last_lead = pp; }
                 else { est_legacy = (!adapt_prev_lead && est_legacy) ? (est_legacy + pp) >> 1 : pp; adapt_legacy_rows++; }
+
                 adapt_prev_lead = lead;
                 if (est_lead <= PL_ADAPT_SLOW) { use_legacy = false; adapt_since = 0; adapt_backoff = 2u; }
                 else if (est_legacy == 0) use_legacy = true;                       /* first try of the round-1 chains */

@@ -303,7 +303,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     prm.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;   /* test hook, see pl_device.h */
     {
         const char *em = std::getenv("PNGLOSS_HIP_ENGINE");                     /* test hook: "legacy" = round-1 chains only */
-        prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : ((em && std::strcmp(em, "lead") == 0) ? 2 : 0);   /* "lead": never fall back adaptively */
+        prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : ((em && std::strcmp(em, "lead") == 0) ? 2 : ((em && std::strcmp(em, "mix") == 0) ? 3 : 0));   /* "lead": never fall back adaptively; "mix": alternate every four rows */
         if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) prm.engine_mode |= (std::atoi(ff) + 1) << 8;   /* debugging aid */
     }
 

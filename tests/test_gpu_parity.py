@@ -351,6 +351,27 @@ def test_segment_engine_strengths_and_bleeds_with_few_and_many_states(monkeypatc
         assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m, s, b)
 
 
+def test_both_chain_kinds_of_the_workgroup_engine_in_one_image(torch_cuda, monkeypatch):
+    """PNGLOSS_HIP_ENGINE=mix: band-leader chains and round-1 chains take turns every four rows, whatever the cycle counters say
+    (the adaptive choice of the default mode depends on timing and would not reproduce a mismatch of either kind); the engine
+    reports how many rows each kind took, results are the oracle's."""
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "mix")
+    for (w, h, m, s, b) in [(300, 64, 0, 19, 2), (200, 48, 5, 19, 2), (130, 40, 3, 40, 1), (96, 40, 1, 7, 3)]:
+        img = P.synth_rgba(w, h, m, 3)
+        d = torch.from_numpy(img.copy()).cuda()
+        f = torch.zeros(h, dtype=torch.uint8, device="cuda")
+        ctx = P.HipContext()
+        res = ctx.run([(d.data_ptr(), f.data_ptr(), w, h)], s, b, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        info = ctx.engine_info(0)
+        o1, f1 = U.run_port(img, s, b)
+        assert res[0]["status"] == 0 and np.array_equal(d.cpu().numpy(), o1) and np.array_equal(f.cpu().numpy(), f1), (w, h, m, s, b)
+        assert info["engine"] == "workgroup-per-image"
+        assert info["attempts"] >= h // 4 and info["serial_rows"] >= h // 4, info      # band-leader row attempts, rows on the round-1 chains
+        ctx.close()
+
+
 def test_round1_chains_still_match_the_oracle():
     """The round-1 chain formulation stays in the kernel for rows the band-leader chains do not take (q > 128, large incoming
     errors); PNGLOSS_HIP_ENGINE=legacy runs every row through it.  Checked in a fresh process (the hook is read per call)."""
