@@ -1,6 +1,7 @@
 """Randomised parity campaign on the GPU box: HIP path (C ABI) vs the CPU oracle over random shapes, contents, strengths
 and bleed dividers, both row_filters modes, plus the device batch API with mixed images.
-usage: gpu_fuzz.py [seconds] [seed] [big]     (big: shapes up to 1500 x 120, so that histogram counts and error rows grow)"""
+usage: gpu_fuzz.py [seconds] [seed] [big]     (big: shapes up to 1500 x 120, so that histogram counts and error rows grow)
+FUZZ_ENGINES=seg,mix,  pins the row engine case by case (segment-parallel, alternating chain kinds, the library's choice)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -52,8 +53,11 @@ t0 = time.time(); n = 0; bad = 0
 ctx = P.HipContext()
 import torch
 while time.time() - t0 < budget:
-    # every other case pins the band-leader chains (no adaptive fallback to the round-1 chains on slow rows); read per call
-    if n % 2: os.environ["PNGLOSS_HIP_ENGINE"] = "lead"
+    # the row engine is pinned case by case (the variable is read per call): by default every other case the band-leader chains (no
+    # adaptive fallback to the round-1 chains on slow rows); FUZZ_ENGINES="seg,mix," cycles through the named ones ("" = the library's choice)
+    engines = os.environ.get("FUZZ_ENGINES", ",lead").split(",")
+    eng = engines[n % len(engines)]
+    if eng: os.environ["PNGLOSS_HIP_ENGINE"] = eng
     else: os.environ.pop("PNGLOSS_HIP_ENGINE", None)
     if n % 10 == 9:     # device batch of 5 mixed images
         items = [make(rng) for _ in range(5)]
