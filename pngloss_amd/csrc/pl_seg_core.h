@@ -116,6 +116,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define PLS_UNROLL
 #endif
 #define SEG_NFILT 5
+#ifndef SEG_DEBUG_ROW
+#define SEG_DEBUG_ROW(kind, failed, winner, start_none)
+#endif
 #ifndef SEG_DEBUG_COUNT
 #define SEG_DEBUG_COUNT(slot, v)   /* (the CPU harness counts a few things the tests pin) */
 #endif
@@ -2152,6 +2155,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 if (D.kind == SEG_K_COMMIT) { ny = y + 1; if (ny >= H) fin = 1; }
                 if (D.kind == SEG_K_RETRY) retried += cur.s == (uint32_t)P.strength ? 1u : 0u;
                 if (D.kind == SEG_K_ABORT) { st = 65u; fin = 1; }                         /* pngloss_image.c:268-271 aborts here */
+                SEG_DEBUG_ROW(D.kind, D.failed, D.winner, D.start_none);
                 if (D.kind == SEG_K_RESTART)
                     for (int g = 0; g < SEG_NFILT; g++) if ((D.failed >> g) & 1u) { rt++; if (cur.restarts[g] + 1 > SEG_MAX_RESTARTS) ser++; }
                 if (W == 0 || H == 0) fin = 1;
@@ -2159,6 +2163,8 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                 nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt; nxt.dropped_none = dropped;
                 {
                     const uint32_t ne = attempt ? cur.none_eager : 0u;
+                    /* (eager only after none WON a row was tried on a screenshot where none never wins but its bound rarely rules it
+                     * out: 1544 attempts instead of 941 -- the extra start per row costs more than the epochs of the eager rows) */
                     nxt.none_eager = D.start_none ? 16u : ((D.kind == SEG_K_COMMIT || D.kind == SEG_K_RETRY) && ne ? ne - 1u : ne);
                 }
                 if (j.progress && D.kind == SEG_K_COMMIT) PLS_HOST_VISIBLE_STORE(j.progress, ny);

@@ -9,6 +9,20 @@
  */
 static unsigned long long seg_dbg[4][2];   /* [slot]: events, sum */
 #define SEG_DEBUG_COUNT(slot, v) (seg_dbg[slot][0]++, seg_dbg[slot][1] += (v))
+/* per row: which candidates went through an epoch (failed validation) or an extra start, and who won */
+static unsigned seg_row_mask, seg_row_none;
+static unsigned long long seg_epochs[5], seg_epoch_rows[5], seg_epoch_rows_won[5], seg_none_starts, seg_none_started_won, seg_rows;
+static void seg_debug_row(int kind, unsigned failed, int winner, int start_none)
+{
+    if (kind == 1) { for (int f = 0; f < 5; f++) if ((failed >> f) & 1u) { seg_epochs[f]++; seg_row_mask |= 1u << f; } if (start_none) { seg_none_starts++; seg_row_none = 1; } }
+    if (kind == 3) {
+        seg_rows++;
+        for (int f = 0; f < 5; f++) if ((seg_row_mask >> f) & 1u) { seg_epoch_rows[f]++; if (winner == f) seg_epoch_rows_won[f]++; }
+        if (seg_row_none && winner == 0) seg_none_started_won++;
+        seg_row_mask = 0; seg_row_none = 0;
+    }
+}
+#define SEG_DEBUG_ROW(kind, failed, winner, start_none) seg_debug_row((kind), (failed), (winner), (start_none))
 #include "../../pngloss_amd/csrc/pl_seg_core.h"
 
 #include <cstdio>
@@ -100,6 +114,11 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, par, f, (int)vg, smem.data());
     }
     const SegCtl &fc = j.ctl[attempt & 1];
+    if (getenv("SEG_HOST_VERBOSE")) {
+        fprintf(stderr, "seg_host: %llu rows; epochs per candidate (none sub up avg paeth): %llu %llu %llu %llu %llu; rows with an epoch of it: %llu %llu %llu %llu %llu, of which it won: %llu %llu %llu %llu %llu; extra starts of none %llu (won %llu)\n",
+                seg_rows, seg_epochs[0], seg_epochs[1], seg_epochs[2], seg_epochs[3], seg_epochs[4], seg_epoch_rows[0], seg_epoch_rows[1], seg_epoch_rows[2], seg_epoch_rows[3], seg_epoch_rows[4],
+                seg_epoch_rows_won[0], seg_epoch_rows_won[1], seg_epoch_rows_won[2], seg_epoch_rows_won[3], seg_epoch_rows_won[4], seg_none_starts, seg_none_started_won);
+    }
     if (getenv("SEG_HOST_VERBOSE")) fprintf(stderr, "seg_host: replay lanes from an entry state %llu (%.1f px each), from a checkpoint %llu (%.1f px each)\n", seg_dbg[0][0], seg_dbg[0][0] ? (double)seg_dbg[0][1] / seg_dbg[0][0] : 0.0, seg_dbg[1][0], seg_dbg[1][0] ? (double)seg_dbg[1][1] / seg_dbg[1][0] : 0.0);
     if (stats) { stats[0] = (uint32_t)attempt; stats[1] = fc.restarts_total; stats[2] = fc.retried; stats[3] = fc.serial_rows; stats[4] = (uint32_t)j.result[2]; stats[5] = bpp; stats[6] = (uint32_t)P.ns; stats[7] = fc.status; }
     /* unpack (pl_unpack) */
