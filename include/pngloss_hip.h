@@ -236,7 +236,9 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
 
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
- *            (batches).  Chosen per batch by pngloss_hip_optimize_batch_async; PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy pins it (test hook).
+ *            (batches).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model (wide images and small batches go to
+ *            the segment-parallel engine, narrow images and large batches to the other; state sets of up to 1024 chain states, i.e.
+ *            most strength / bleed pairs, rows up to 8192 pixels); PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy|mix pins it (test hook).
  *   info[1]  row attempts (engine 3) / rows on the band-leader chains (engine 0)
  *   info[2]  validation restarts (engine 3) / pixels redone exactly (engine 0)
  *   info[3]  rows finished serially (engine 3) / rows on the round-1 chains by the adaptive choice (engine 0)
