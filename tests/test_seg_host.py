@@ -39,6 +39,17 @@ def test_seg_engine_speculation_is_right_almost_always():
     assert attempts <= 128 + 16 and restarts <= 12 and serial == 0, (attempts, restarts, serial)
 
 
+@pytest.mark.parametrize("s,b,most", [(40, 2, 112), (85, 8, 110), (20, 1, 115)])
+def test_seg_engine_speculation_with_state_sets_enumerated_in_chunks(s, b, most):
+    """the same pin for state sets of 650 .. 955 chain states (measured: 104 / 103 / 107 attempts for 96 rows): the chunked
+    enumeration, the dense transition tables and the wide table stride are right when the attempts stay near one per row"""
+    img = P.synth_rgba(1024, 96, 0, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+    assert int(st[0]) <= most and int(st[3]) == 0, st
+
+
 @pytest.mark.parametrize("flags", [2, 4, 6])
 @pytest.mark.parametrize("w,h,mode,s,b", [(333, 37, 3, 19, 2), (520, 24, 0, 19, 2), (300, 24, 1, 20, 1), (200, 20, 4, 26, 2)])
 def test_seg_engine_chain_fallback_paths(monkeypatch, flags, w, h, mode, s, b):
