@@ -1661,17 +1661,19 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     }
     PLS_SYNC();
     if (prof) tk[4] = PLS_CLOCK();
-    /* -- post pass of this candidate over the group's pixels (optimize_state.c:265-287, 326-342, 492-562): lane = pixel -- */
+    /* -- post pass of this candidate over the group's pixels (optimize_state.c:265-287, 326-342, 492-562): lane = (pixel, channel) -- */
     if (!lazy)
     PLS_THREADS(tid, SEG_THREADS) {
         uint64_t derr = 0; uint32_t cost = 0, hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
-        for (int k = tid; k < NPX; k += SEG_THREADS) {
+        for (int kc = tid; kc < NPX * 4; kc += SEG_THREADS) {
+            const int k = kc >> 2;
+            const uint32_t c = (uint32_t)kc & 3u;
             const uint32_t x = xg0 + (uint32_t)k;
-            if (x >= W) continue;
+            if (x >= W || c >= bpp) continue;
             const uint32_t o = ro[k + 1], ol = ro[k];
             const uint32_t nav4 = na[k + 1], ndv4 = x ? na[k] : 0u;
             const uint32_t oav4 = oa[k + 1], odv4 = x ? oa[k] : 0u;
-            for (uint32_t c = 0; c < bpp; c++) {
+            {
                 const int sh = 8 * (int)c;
                 const int back = seg_cand_byte(cw[(k + 2) * 4 + c]), nl = x ? seg_cand_byte(cw[(k + 1) * 4 + c]) : 0;
                 const int ov = (int)((o >> sh) & 255u), olv = (int)((ol >> sh) & 255u);
