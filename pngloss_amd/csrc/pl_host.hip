@@ -162,7 +162,9 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     PL_CHECK(hipMemcpyAsync(d_params, &params, sizeof(SegParams), hipMemcpyHostToDevice, stream));
     PL_CHECK(hipStreamSynchronize(stream));          /* sj / params are stack and vector memory */
     b.d_sj = d_sj; b.d_params = d_params; b.n = n;
-    b.enum_blocks = (params.small_ok ? 3 * b.max_nseg + 2 * ((b.max_nseg + SEG_SMALL_SEGS - 1) / SEG_SMALL_SEGS) : SEG_NFILT * b.max_nseg) + SEG_NFILT;
+    b.small_ok = params.small_ok != 0;
+    b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
+    if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
     PL_CHECK(hipEventRecord(ctx->ev[1], stream));
     /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */

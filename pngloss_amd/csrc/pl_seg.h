@@ -19,7 +19,8 @@ struct PlSegBatch {
     const SegParams *d_params;
     size_t n;
     uint32_t max_nseg, max_ngrp, max_ncommit;
-    uint32_t enum_blocks;     /* grid of the enumeration kernel: 3 (or 5) x max_nseg + 2 x ceil(max_nseg / SEG_SMALL_SEGS) + 5 first-segment walkers */
+    uint32_t enum_nt;         /* threads of the enumeration's workgroups: 512 or 1024 (SEG_ENUM_NT_SMALL_MAX_NSEG) */
+    bool small_ok;            /* SegParams::small_ok (none / up enumerated with their own small state set) */
 };
 
 /* fills sj[i].bpp from the class the prepare kernels detected */

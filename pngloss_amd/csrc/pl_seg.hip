@@ -34,26 +34,29 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *__restric
     seg_ctl_body(j, *P, attempt, (int)blockIdx.x, seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_enum(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_nseg)
+/* NT threads per workgroup: 1024 (four channels of a segment) or 512 (a channel pair), see SEG_ENUM_NT_SMALL_MAX_NSEG */
+template <int NT>
+__global__ __launch_bounds__(NT) void seg_k_enum(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_nseg)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    /* workgroups [0, nbig * max_nseg): one segment of a filter that looks at the left pixel; behind them: SEG_SMALL_SEGS segments of none / up */
+    /* workgroups [0, nbig * max_nseg * halves): one segment (and channel group) of a filter that looks at the left pixel; behind them:
+     * NT / 128 segments of none / up each; the last five walk the epoch's first segment of one candidate each */
     const bool small_ok = P->small_ok != 0;
     const unsigned nbig = small_ok ? 3u : 5u;
-    if (blockIdx.x < nbig * max_nseg) {
-        const unsigned k = blockIdx.x / max_nseg, seg = blockIdx.x % max_nseg;
+    constexpr unsigned halves = 4 / (NT / SEG_NSP), small_segs = NT / (4 * SEG_NSS);
+    if (blockIdx.x < nbig * max_nseg * halves) {
+        const unsigned k = blockIdx.x / (max_nseg * halves), r = blockIdx.x % (max_nseg * halves), seg = r / halves, chalf = r % halves;
         const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
         if (seg >= j.nseg) return;
-        seg_enum_body(j, *P, par, (int)f, (int)seg, seg_smem);
+        seg_enum_body<NT>(j, *P, par, (int)f, (int)seg, (int)chalf, seg_smem);
     } else if (blockIdx.x < gridDim.x - SEG_NFILT) {
-        const unsigned r = blockIdx.x - nbig * max_nseg, per = (max_nseg + SEG_SMALL_SEGS - 1) / SEG_SMALL_SEGS;
-        const unsigned f = r / per ? 2u : 0u, seg0 = (r % per) * SEG_SMALL_SEGS;
+        const unsigned r = blockIdx.x - nbig * max_nseg * halves, per = (max_nseg + small_segs - 1) / small_segs;
+        const unsigned f = r / per ? 2u : 0u, seg0 = (r % per) * small_segs;
         if (seg0 >= j.nseg) return;
-        seg_enum_small_body(j, *P, par, (int)f, (int)seg0, seg_smem);
+        seg_enum_small_body<NT>(j, *P, par, (int)f, (int)seg0, seg_smem);
     } else {
-        /* the last five workgroups walk the epoch's first segment of one candidate each */
-        seg_first_body(j, *P, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
+        seg_first_body<NT>(j, *P, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
     }
 }
 
@@ -157,7 +160,13 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     const int par = attempt & 1;
     const unsigned n = (unsigned)b.n;
     hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
-    hipLaunchKernelGGL(seg_k_enum, dim3(b.enum_blocks, n), dim3(SEG_THREADS), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
+    {
+        const bool small_ok = b.small_ok;
+        const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);
+        const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
+        if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
+        else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
+    }
     hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     hipLaunchKernelGGL(seg_k_post, dim3(SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP), n), dim3(SEG_THREADS), SEG_SM_POST, stream, b.d_sj, b.d_params, par, b.max_ngrp);

@@ -146,7 +146,12 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* every thread loads one pixel of the group, SEG_GRP * SEG_PARTS * 4 of them walk */
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
-#define SEG_SMALL_SEGS 8           /* segments per enumeration workgroup for them: 8 segments x 4 channels x SEG_NSS lanes */
+#define SEG_SMALL_SEGS 8           /* most segments per enumeration workgroup for them: 8 segments x 4 channels x SEG_NSS lanes (1024 threads) */
+/* The enumeration's workgroups come in two sizes, NT = 1024 threads (4 channels x SEG_NSP lanes) or 512 (a channel pair).  The lighter
+ * ones are faster while a CU gets at most two or three of them (measured per 1080-row frame, 512 against 1024 threads: 1024 pixels wide
+ * 57.6 / 61.2 ms, 1920: 56.8 / 58.4, 2560: 61.3 / 64.4, 3072: 61.6 / 64.6), the larger ones when the lighter pile up (3584: 66.3 / 65.3,
+ * 4096: 68.3 / 66.7, 8192: 88.5 / 87.6).  The launcher picks 512 while all images' segments together are at most this many. */
+#define SEG_ENUM_NT_SMALL_MAX_NSEG 100
 #define SEG_KEYS_MAX 2048
 
 /* what a row attempt decided (seg_ctl_body) */
@@ -691,12 +696,16 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
  * those run the remaining steps -- whole waves fall idle -- then every lane picks up the result of its representative. */
 #define SEG_K1 4
 #define SEG_HT 512
-PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, unsigned char *smem)
+template <int NT>
+PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, int chalf, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
     const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
+    constexpr int NCH = NT / SEG_NSP;                        /* channels of this workgroup: c0 .. c0 + NCH - 1 */
+    const int c0 = chalf * NCH;
+    if ((uint32_t)c0 >= bpp) return;
     const uint32_t x0 = (uint32_t)seg * SEG_L;
     if (x0 >= W) return;                                      /* (the last segment has no successor, but the replay wants its checkpoints) */
     if (cv.start_x && x0 <= cv.start_x) return;       /* an epoch that starts inside the row: its first (partial) segment is walked by
@@ -711,33 +720,33 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint16_t *dense = (uint16_t *)(ht + 4 * SEG_HT);          /* [4][SEG_HT] slot -> rank among the distinct states */
     uint32_t *uniq = (uint32_t *)(dense + 4 * SEG_HT);        /* [4][SEG_NSP] the distinct states, packed */
     uint16_t *res = (uint16_t *)(uniq + 4 * SEG_NSP);         /* [4][SEG_NSP] exit index of each distinct state */
-    uint16_t *lslot = res + 4 * SEG_NSP;                      /* [SEG_THREADS] the hash slot of every lane's state (or 0xffff) */
+    uint16_t *lslot = res + 4 * SEG_NSP;                      /* [NT] the hash slot of every lane's state (or 0xffff) */
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)cv.s);
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long te[5] = { 0, 0, 0, 0, 0 };
     if (prof) te[0] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_THREADS) {
+    PLS_THREADS(tid, NT) {
         if (tid < 8) trflag[tid] = 0u;
-        for (int i = tid; i < 4 * SEG_HT; i += SEG_THREADS) ht[i] = 0xffffffffu;
+        for (int i = tid; i < 4 * SEG_HT; i += NT) ht[i] = 0xffffffffu;
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) {
+    PLS_THREADS(tid, NT) {
         /* requests first, stores behind them (one round trip) */
-        constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
+        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
         uint32_t vt[NTW], vl = 0;
         SegPixRaw vp = seg_pix_raw_zero();
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        if (tid >= 512 && tid < 512 + SEG_L + 1) vp = seg_pix_fetch(row, nab, j.err0, x0 - 1 + (uint32_t)(tid - 512), W);
+        if (tid < SEG_L + 1) vp = seg_pix_fetch(row, nab, j.err0, x0 - 1 + (uint32_t)tid, W);
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
-        if (tid >= 512 && tid < 512 + SEG_L + 1) {
-            seg_pix_split4(px + (tid - 512) * 4, vp, bpp, x0 - 1 + (uint32_t)(tid - 512), W);
-            if ((bpp & 1u) == 0u && (px[(tid - 512) * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
+        if (tid < SEG_L + 1) {
+            seg_pix_split4(px + tid * 4, vp, bpp, x0 - 1 + (uint32_t)tid, W);
+            if ((bpp & 1u) == 0u && (px[tid * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
         }
     }
     PLS_SYNC();
@@ -746,11 +755,11 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     /* -- the first SEG_K1 steps from every state, SEG_NSP states per channel at a time; neighbouring lanes mostly end in the same state,
      *    so only the first lane of a run of equal keys ("head") goes to the hash table with an atomic, the others look their key up
      *    afterwards.  Every entry index gets the DENSE id of its state: that is the segment's entry map -- */
-    uint32_t *keys = (uint32_t *)(lslot + SEG_THREADS);       /* [SEG_THREADS] state key of every lane after SEG_K1 steps, ~0 = none */
+    uint32_t *keys = (uint32_t *)(lslot + NT);       /* [NT] state key of every lane after SEG_K1 steps, ~0 = none */
     SEG_AS_GLB uint16_t *dmap = j.maps + (((size_t)f * j.nseg + seg) * 4) * (size_t)P.nsp;
     for (int i0 = 0; i0 < P.ns; i0 += SEG_NSP) {
-        PLS_THREADS(tid, SEG_THREADS) {
-            const int c = tid / SEG_NSP, i = i0 + tid % SEG_NSP;
+        PLS_THREADS(tid, NT) {
+            const int lc = tid / SEG_NSP, c = c0 + lc, i = i0 + tid % SEG_NSP;
             uint32_t key = 0xffffffffu;
             if ((uint32_t)c < bpp && i < P.ns) {
                 SegState st;
@@ -762,8 +771,8 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
             keys[tid] = key;
         }
         PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) {
-            const int c = tid / SEG_NSP, i = tid % SEG_NSP;
+        PLS_THREADS(tid, NT) {
+            const int c = tid / SEG_NSP, i = tid % SEG_NSP;          /* (local channel: tables of this workgroup) */
             const uint32_t key = keys[tid];
             if (key != 0xffffffffu && (i == 0 || keys[tid - 1] != key)) {
                 uint32_t h = (key * 0x9E3779B1u) >> 23;                            /* 9 bits */
@@ -781,8 +790,8 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
             }
         }
         PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) {
-            const int c = tid / SEG_NSP, i = i0 + tid % SEG_NSP;
+        PLS_THREADS(tid, NT) {
+            const int c = tid / SEG_NSP, gc = c0 + c, i = i0 + tid % SEG_NSP;
             const uint32_t key = keys[tid];
             uint32_t d = 0xffffu;
             if (key != 0xffffffffu) {
@@ -794,19 +803,19 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
                     h = (h + 1) & (SEG_HT - 1);
                 }
             }
-            if ((uint32_t)c < bpp && i < P.ns) dmap[(size_t)c * P.nsp + i] = (uint16_t)d;
+            if ((uint32_t)gc < bpp && i < P.ns) dmap[(size_t)gc * P.nsp + i] = (uint16_t)d;
         }
         PLS_SYNC();
     }
     if (prof) te[2] = PLS_CLOCK();
     /* -- the remaining steps, distinct states only (packed into the first lanes of each channel): dense id -> exit index -- */
-    PLS_THREADS(tid, SEG_THREADS) {
-        /* distinct state i of channel c runs on thread (i >> 6) * 256 + c * 64 + (i & 63): the first 64 of every channel are waves 0..3 of
-         * the workgroup, one per SIMD (waves 0, 4, 8, 12 would share one) */
-        const int c = (tid >> 6) & 3, i = (tid & 63) + 64 * (tid >> 8);
-        const uint32_t D = trflag[1 + c] < SEG_NSP ? trflag[1 + c] : SEG_NSP;
+    PLS_THREADS(tid, NT) {
+        /* distinct state i of (local) channel lc runs on thread (i >> 6) * 64 * NCH + lc * 64 + (i & 63): the first 64 of every channel are the
+         * first NCH waves of the workgroup, one per SIMD (waves 0, 4, 8, 12 would share one) */
+        const int lc = (tid >> 6) % NCH, c = c0 + lc, i = (tid & 63) + 64 * (tid / (64 * NCH));
+        const uint32_t D = trflag[1 + lc] < SEG_NSP ? trflag[1 + lc] : SEG_NSP;
         if ((uint32_t)c < bpp && (uint32_t)i < D) {
-            const uint32_t key = uniq[c * SEG_NSP + i];
+            const uint32_t key = uniq[lc * SEG_NSP + i];
             SegState st;
             st.left = (int)(key & 255u); st.cn = seg_sext8((int)(key >> 8)); st.th = seg_sext8((int)(key >> 16));
             uint32_t out = SEG_INVALID;
@@ -832,41 +841,43 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
 }
 
 /* ---- ENUMERATE, none / up (state = (cn, th), SEG_NSS lanes per channel): task (f, SEG_SMALL_SEGS segments from seg0) -------- */
+template <int NT>
 PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
     const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
-    if ((uint32_t)(seg0 + SEG_SMALL_SEGS) * SEG_L <= cv.start_x) return;
+    constexpr int NSEGS = NT / (4 * SEG_NSS);                 /* segments of this workgroup */
+    if ((uint32_t)(seg0 + NSEGS) * SEG_L <= cv.start_x) return;
     uint32_t *tw = (uint32_t *)smem;
     uint32_t *lut = tw + SEG_TBL_WORDS;
-    SegPix *px = (SegPix *)(lut + 512);                        /* [SEG_SMALL_SEGS][SEG_L][4] */
+    SegPix *px = (SegPix *)(lut + 512);                        /* [NSEGS][SEG_L][4] */
     const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)cv.s);
-    uint32_t *trflag = (uint32_t *)(px + SEG_SMALL_SEGS * SEG_L * 4);
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) *trflag = 0u; }
+    uint32_t *trflag = (uint32_t *)(px + NSEGS * SEG_L * 4);
+    PLS_THREADS(tid, NT) { if (tid == 0) *trflag = 0u; }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) {
-        constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
+    PLS_THREADS(tid, NT) {
+        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
         uint32_t vt[NTW], vl = 0;
         SegPixRaw vp = seg_pix_raw_zero();
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        if (tid < SEG_SMALL_SEGS * SEG_L) vp = seg_pix_fetch(row, nab, j.err0, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+        if (tid < NSEGS * SEG_L) vp = seg_pix_fetch(row, nab, j.err0, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
-        if (tid < SEG_SMALL_SEGS * SEG_L) {
+        if (tid < NSEGS * SEG_L) {
             seg_pix_split4(px + tid * 4, vp, bpp, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
             if ((bpp & 1u) == 0u && (px[tid * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
         }
     }
     PLS_SYNC();
     const bool trx = *trflag != 0u;
-    PLS_THREADS(tid, SEG_THREADS) {
+    PLS_THREADS(tid, NT) {
         const int sl = tid / (4 * SEG_NSS), c = (tid / SEG_NSS) & 3, i = tid % SEG_NSS;
         const uint32_t seg = (uint32_t)seg0 + (uint32_t)sl, x0 = seg * SEG_L;
         if (seg < j.nseg && x0 < W && (x0 > cv.start_x || cv.start_x == 0) && (uint32_t)c < bpp && i < P.ns_small) {
@@ -936,6 +947,7 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
 
 /* ---- FIRST SEGMENT: task (f): the epoch's first (partial) segment has a known entry state, so it is not enumerated but walked,
  * lane = channel, next to the enumeration workgroups (same kernel); out: the index the chain starts from ------------------------ */
+template <int NT>
 PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -954,23 +966,23 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
     const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)cv.s);
-    PLS_THREADS(tid, SEG_THREADS) {
-        constexpr int NTW = (SEG_TBL_WORDS + SEG_THREADS - 1) / SEG_THREADS;
+    PLS_THREADS(tid, NT) {
+        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
         uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
         SegPixRaw vp = seg_pix_raw_zero();
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        if (tid >= 512 && tid < 768) { const int b = tid - 512; vh = j.H0[par * 256 + b]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + b]; vr = j.orig_rank[f * 256 + b]; }
-        if (tid >= 768 && tid < 768 + SEG_L) vp = seg_pix_fetch(row, nab, j.err0, first * SEG_L + (uint32_t)(tid - 768), W);
+        if (tid < 256) { const int b = tid; vh = j.H0[par * 256 + b]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + b]; vr = j.orig_rank[f * 256 + b]; }
+        if (tid >= 256 && tid < 256 + SEG_L) vp = seg_pix_fetch(row, nab, j.err0, first * SEG_L + (uint32_t)(tid - 256), W);
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
-        if (tid >= 512 && tid < 768) { Hf[tid - 512] = vh + vb; rank[tid - 512] = vr; }
-        if (tid >= 768 && tid < 768 + SEG_L) seg_pix_split4(px + (tid - 768) * 4, vp, bpp, first * SEG_L + (uint32_t)(tid - 768), W);
+        if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
+        if (tid >= 256 && tid < 256 + SEG_L) seg_pix_split4(px + (tid - 256) * 4, vp, bpp, first * SEG_L + (uint32_t)(tid - 256), W);
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) {
+    PLS_THREADS(tid, NT) {
         if (tid < 4 && (uint32_t)tid < bpp) {
             const int c = tid;
             SegState st = seg_state_unpack(ctl.state[f][c]);

@@ -104,11 +104,19 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt, bx, smem.data());
         const int par = attempt & 1;
         if (j.ctl[par].finished) break;
+        /* the enumeration's workgroups come in two sizes; the product picks by row width, SEG_HOST_ENUM_NT pins one */
+        int nt = j.nseg <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512 : 1024;
+        if (getenv("SEG_HOST_ENUM_NT")) nt = atoi(getenv("SEG_HOST_ENUM_NT")) == 1024 ? 1024 : 512;
         for (int f = 0; f < SEG_NFILT; f++) {
-            if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += SEG_SMALL_SEGS) seg_enum_small_body(j, P, par, f, (int)sg, smem.data());
-            else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body(j, P, par, f, (int)sg, smem.data());
+            if (nt == 512) {
+                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 4) seg_enum_small_body<512>(j, P, par, f, (int)sg, smem.data());
+                else for (uint32_t sg = 0; sg < j.nseg; sg++) for (int ch = 0; ch < 2; ch++) seg_enum_body<512>(j, P, par, f, (int)sg, ch, smem.data());
+            } else {
+                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 8) seg_enum_small_body<1024>(j, P, par, f, (int)sg, smem.data());
+                else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, par, f, (int)sg, 0, smem.data());
+            }
         }
-        for (int f = 0; f < SEG_NFILT; f++) seg_first_body(j, P, par, f, smem.data());
+        for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, par, f, smem.data()); else seg_first_body<1024>(j, P, par, f, smem.data()); }
         for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, par, f, (int)vg, smem.data());

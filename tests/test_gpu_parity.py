@@ -351,6 +351,18 @@ def test_segment_engine_strengths_and_bleeds_with_few_and_many_states(monkeypatc
         assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m, s, b)
 
 
+@pytest.mark.parametrize("nt", ["512", "1024"])
+def test_segment_engine_both_sizes_of_the_enumeration_workgroups(monkeypatch, nt):
+    """the enumeration's workgroups have 512 threads (a channel pair) for narrow rows / few images and 1024 beyond; PNGLOSS_HIP_ENUM_NT pins one"""
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    monkeypatch.setenv("PNGLOSS_HIP_ENUM_NT", nt)
+    for (w, h, m, s, b) in [(700, 20, 0, 19, 2), (1100, 12, 1, 20, 1), (513, 9, 4, 19, 2), (300, 16, 3, 40, 2), (3300, 6, 0, 19, 2), (200, 30, 5, 7, 3)]:
+        img = P.synth_rgba(w, h, m, 2)
+        o1, f1 = U.run_port(img, s, b)
+        o2, f2 = P.optimize_with_rows(img, s, b)
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2), (w, h, m, s, b)
+
+
 def test_both_chain_kinds_of_the_workgroup_engine_in_one_image(torch_cuda, monkeypatch):
     """PNGLOSS_HIP_ENGINE=mix: band-leader chains and round-1 chains take turns every four rows, whatever the cycle counters say
     (the adaptive choice of the default mode depends on timing and would not reproduce a mismatch of either kind); the engine

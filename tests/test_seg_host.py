@@ -39,6 +39,18 @@ def test_seg_engine_speculation_is_right_almost_always():
     assert attempts <= 128 + 16 and restarts <= 12 and serial == 0, (attempts, restarts, serial)
 
 
+@pytest.mark.parametrize("nt", [512, 1024])
+@pytest.mark.parametrize("w,h,mode,s,b", [(333, 37, 1, 19, 2), (520, 24, 0, 19, 2), (300, 24, 1, 20, 1), (200, 20, 4, 26, 2), (97, 33, 2, 7, 3), (64, 6, 4, 0, 2)])
+def test_seg_engine_both_sizes_of_the_enumeration_workgroups(monkeypatch, nt, w, h, mode, s, b):
+    """the enumeration's workgroups have 512 threads (a channel pair) for rows up to 2560 pixels and 1024 (all four channels) beyond;
+    the harness follows the same rule, SEG_HOST_ENUM_NT pins one"""
+    monkeypatch.setenv("SEG_HOST_ENUM_NT", str(nt))
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+
+
 @pytest.mark.parametrize("s,b,most", [(40, 2, 112), (85, 8, 110), (20, 1, 115)])
 def test_seg_engine_speculation_with_state_sets_enumerated_in_chunks(s, b, most):
     """the same pin for state sets of 650 .. 955 chain states (measured: 104 / 103 / 107 attempts for 96 rows): the chunked
