@@ -26,6 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{out}/{tag}_prof_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].strip()
+            if n.startswith("void "): n = n[5:]
             agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == c: calls[(n, c)] += 1
 print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch")

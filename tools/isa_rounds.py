@@ -26,12 +26,13 @@ def main():
                    check=True, stderr=subprocess.DEVNULL, cwd=os.path.dirname(SRC))
     src = open(asm).read().split("\n")
     detail = sys.argv[1] if len(sys.argv) > 1 else None
+    todo = []
     for name in KERNELS:
-        start = [i for i, l in enumerate(src) if re.match(r"^_ZN12_GLOBAL__N_1[0-9]+" + name + r"EPK.*:", l)]
-        if not start:
-            print(name, "not found")
-            continue
-        a = start[0]
+        for i, l in enumerate(src):
+            m = re.match(r"^_ZN12_GLOBAL__N_1[0-9]+" + name + r"(ILi(\d+)E)?E.*:$", l)
+            if m:
+                todo.append((name + ("<%s>" % m.group(2) if m.group(2) else ""), i))
+    for name, a in todo:
         b = [i for i, l in enumerate(src) if i > a and ".amdhsa_kernel" in l][0]
         body = src[a:b]
         meta = "\n".join(src[b:b + 80])
@@ -51,7 +52,7 @@ def main():
         print("%-13s %5d instructions, stack %s B; loads: %3d vector, %3d scalar, %2d flat; ds_read %3d ds_write %3d; %2d load->wait rounds, %2d of them a single load"
               % (name, sum(1 for l in body if re.match(r"^\t[a-z]", l)), stack.group(1) if stack else "?", count(r"\bglobal_load"), count(r"\bs_load"),
                  count(r"\bflat_(load|store|atomic)"), count(r"\bds_read"), count(r"\bds_write"), len(rounds), sum(1 for r in rounds if r[0] == 1)))
-        if detail == name:
+        if detail and name.startswith(detail):
             for n, where, at in rounds:
                 print("    %2d load(s) from %s -> wait at %s" % (n, ", ".join(where[:6]), at))
 
