@@ -29,7 +29,7 @@ def main():
     todo = []
     for name in KERNELS:
         for i, l in enumerate(src):
-            m = re.match(r"^_ZN12_GLOBAL__N_1[0-9]+" + name + r"(ILi(\d+)E)?E.*:$", l)
+            m = re.match(r"^_ZN12_GLOBAL__N_1[0-9]+" + name + r"(ILi(\d+)E)?E\S*:", l)
             if m:
                 todo.append((name + ("<%s>" % m.group(2) if m.group(2) else ""), i))
     for name, a in todo:
