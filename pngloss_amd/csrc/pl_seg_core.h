@@ -1079,12 +1079,17 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                     ps[q] = useR ? rst[o] : SEG_NOSTATE;
                 }
                 if (starter && kb == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[s0 * mstep32 + idx_first];
+                /* (the dependent loads in a loop of their own: next to their uses, each one waits for itself) */
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
                     const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u), sg = s0 + k;
                     const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                    const uint32_t mv = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
-                    v[q] = valid ? mv : (uint32_t)SEG_INVALID;
+                    v[q] = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
+                }
+                PLS_UNROLL
+                for (int q = 0; q < SEG_CQ; q++) {
+                    const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
+                    v[q] = valid ? v[q] : (uint32_t)SEG_INVALID;
                     ps[q] = valid ? ps[q] : SEG_NOSTATE;
                     widest = dcv[q] > widest ? dcv[q] : widest;
                 }
