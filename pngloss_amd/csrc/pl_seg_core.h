@@ -194,8 +194,16 @@ struct SegCtlView { uint32_t finished, y, s, active, start_x; };
 PLS_HD SegCtlView seg_ctl_view(const SegCtl &c, int f)
 {
     SegCtlView v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* through the constant address space: the block was written by an EARLIER kernel and is only read here, the address is the same
+     * for the whole workgroup -- scalar loads, all five in flight at once, one wait (as vector loads the compiler sinks each to its
+     * first use: three round trips before a workgroup requests anything else) */
+    typedef const __attribute__((address_space(4))) SegCtl *seg_const_ctl;
+    seg_const_ctl cc = (seg_const_ctl)(uintptr_t)&c;
+    v.finished = cc->finished; v.y = cc->y; v.s = cc->s; v.active = cc->active[f]; v.start_x = cc->start_x[f];
+#else
     v.finished = c.finished; v.y = c.y; v.s = c.s; v.active = c.active[f]; v.start_x = c.start_x[f];
-    /* (forcing all five to arrive here -- an empty asm that names them -- was measured 1 % slower than letting the compiler place the waits) */
+#endif
     return v;
 }
 
