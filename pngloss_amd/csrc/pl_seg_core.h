@@ -1307,10 +1307,13 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     PLS_SYNC();
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
         for (int b = tid; b < 256; b += SEG_REPLAY_THREADS) {
-            uint32_t tot = 0;
+            uint32_t tot = 0, cv[SEG_GRP];
+            PLS_UNROLL
+            for (int sl = 0; sl < SEG_GRP; sl++) cv[sl] = cnt[sl * 256 + b];          /* (all reads, then the stores: one wait) */
+            PLS_UNROLL
             for (int sl = 0; sl < SEG_GRP; sl++) {
                 const uint32_t sg = seg0 + (uint32_t)sl;
-                if (sg < nseg && sg >= first) { j.segcnt[((size_t)f * nseg + sg) * 256 + b] = (uint16_t)cnt[sl * 256 + b]; tot += cnt[sl * 256 + b]; }
+                if (sg < nseg && sg >= first) { j.segcnt[((size_t)f * nseg + sg) * 256 + b] = (uint16_t)cv[sl]; tot += cv[sl]; }
             }
             j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
         }
