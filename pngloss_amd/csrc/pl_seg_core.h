@@ -1545,12 +1545,16 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
                 before += (in && (uint32_t)g < grp) ? gv[g] : 0u;
             }
             Hpost[b] = H0[b] + total;
-            for (int r = SEG_VGRP + 1; r <= 2 * SEG_VGRP; r++) before += cum[r * 256 + b];
+            uint32_t add[2 * SEG_VGRP];                                /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
+            PLS_UNROLL
+            for (int r = 1; r <= 2 * SEG_VGRP; r++) add[r - 1] = cum[r * 256 + b];
+            PLS_UNROLL
+            for (int r = SEG_VGRP + 1; r <= 2 * SEG_VGRP; r++) before += add[r - 1];
             uint32_t run = before;
+            PLS_UNROLL
             for (int sl = 0; sl <= SEG_VGRP; sl++) {
-                const uint32_t add = sl < SEG_VGRP ? cum[(sl + 1) * 256 + b] : 0u;
                 cum[sl * 256 + b] = run;
-                run += add;
+                if (sl < SEG_VGRP) run += add[sl];
             }
         }
     }
