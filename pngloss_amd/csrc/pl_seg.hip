@@ -4,11 +4,12 @@
  * The algorithm, its proof obligation (the validation pass) and the kernel bodies live in pl_seg_core.h, which is also compiled
  * for the CPU by tests/c/seg_host.cpp.  Here: the five gfx950 kernels of one row attempt, blockIdx.y = image of the batch,
  *
- *   seg_k_ctl     5 candidate workgroups + 1 image-wide + W/1024 commit workgroups
- *   seg_k_enum    5 x nseg workgroups of 1024 lanes (4 channels x 256 chain states), decision tables + pixel records in LDS
- *   seg_k_chain   5 x 4 workgroups, a row's state maps in LDS (up to 132 KB of the CU's 160 KB), one lookup per segment
- *   seg_k_replay  5 x ngrp workgroups of one wave: lane = (segment, channel)
- *   seg_k_post    5 x ngrp workgroups of 1024 lanes: exact validation of every decision + the row cost sums
+ *   seg_k_ctl     5 x 4 candidate workgroups (each a quarter of a candidate's decision tables) + 1 image-wide + W/256 commit workgroups
+ *   seg_k_enum    3 x nseg workgroups of 1024 lanes (4 channels x 256 chain states; 512 lanes = a channel pair for narrow rows) for the
+ *                 filters that look at the left pixel, 2 x nseg/8 for none / up, 5 first-segment walkers; tables + pixel records in LDS
+ *   seg_k_chain   5 x 4 workgroups, a row's dense transition tables and exit states in LDS (up to 132 KB of the CU's 160 KB)
+ *   seg_k_replay  5 x ngrp workgroups: lane = (segment, quarter, channel), 8 steps each from the enumeration's checkpoints
+ *   seg_k_post    5 x 2 ngrp workgroups of 1024 lanes: exact validation of every decision + the row cost sums
  *
  * and no grid barrier anywhere: consecutive kernels on one stream are the grid-wide synchronisation (1.5-2 us on this machine
  * against 4-7 us for a hand-made in-kernel barrier across 8 XCDs, /opt/skills/guides/MI355X_MICROARCH.md), and every piece of
