@@ -13,11 +13,15 @@
  *       (left = reconstructed byte of x-1,  cn = rem(diff[x-1]) + thr(diff[x-2]),  th = thr(diff[x-1]))
  *   (optimize_state.c:146,172,455,467) -- relative to the data at most 253 states for s = 19, bleed = 2.  So:
  *
- *   ENUMERATE  (seg_enum_body)    every segment of 32 pixels is run from EVERY possible entry state at once (lane = state),
- *                                 giving the segment's state map: entry state -> exit state;
- *   CHAIN      (seg_chain_body)   the maps are composed from the row's true start state: one table lookup per segment
- *                                 instead of 32 dependent pixel steps -- this is where the serial chain of W steps shrinks;
- *   REPLAY     (seg_replay_body)  every segment is run once more from its now known entry state and writes the candidate row;
+ *   ENUMERATE  (seg_enum_body)    every segment of 32 pixels is run from EVERY possible entry state at once (lane = state; up to
+ *                                 1024 states in chunks of 256 lanes); the trajectories merge within a few pixels, so after 4 steps
+ *                                 the distinct states (a few dozen) are given dense ids and only they run on.  Out: entry state ->
+ *                                 dense id, dense id -> exit state, dense id -> state at every quarter of the segment (checkpoints);
+ *   CHAIN      (seg_chain_body)   the dense transition tables of consecutive segments are composed from the row's true start
+ *                                 state: one table lookup per segment instead of 32 dependent pixel steps -- this is where the
+ *                                 serial chain of W steps shrinks;
+ *   REPLAY     (seg_replay_body)  every quarter of every segment is run once more from its now known state (entry state or
+ *                                 checkpoint) and writes the candidate row;
  *   VALIDATE   (seg_post_body)    THE GROUND TRUTH: every decision of the candidate row is re-derived from its predecessors'
  *                                 outputs and checked against the reference's arg-max rule under the exact RUNNING histogram
  *                                 (block counts + in-segment counting).  A row that passes is, by induction over x, exactly
