@@ -100,3 +100,33 @@ def test_seg_engine_seeded_random_images():
             assert np.array_equal(f, wf)
         ran += 1
     assert ran >= 12
+
+
+def test_seg_engine_bodies_clean_under_asan_and_ubsan(tmp_path):
+    """the same kernel bodies built with -fsanitize=address,undefined (every device array of the harness is its own heap block, so an
+    index past an array is a report): a few shapes incl. the widest row the engine takes and state sets enumerated in chunks, run in
+    a child process with the sanitizer runtime preloaded; no report, results equal to the oracle's"""
+    import os
+    import subprocess
+    import sys
+    so = tmp_path / "libseg_host_san.so"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-fno-omit-frame-pointer", "-w", "-o", str(so), os.path.join(U.ROOT, "tests", "c", "seg_host.cpp")], check=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    code = (
+        "import ctypes as C, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import pngloss_amd as P\n"
+        "from tests import util as U\n"
+        "lib = C.CDLL(%r)\n"
+        "lib.seg_host_optimize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint, C.c_long, C.c_void_p]\n"
+        "for (w, h, m, s, b) in [(700, 10, 0, 19, 2), (300, 8, 2, 40, 2), (8192, 2, 0, 19, 2), (333, 7, 3, 19, 2), (33, 5, 5, 7, 3), (3300, 3, 1, 20, 1)]:\n"
+        "    img = P.synth_rgba(w, h, m, 0); out = img.copy(); f = np.zeros(h, np.uint8); st = np.zeros(8, np.uint32)\n"
+        "    rc = lib.seg_host_optimize(out.ctypes.data, w, h, f.ctypes.data, s, b, st.ctypes.data)\n"
+        "    want, wf = U.run_port(img, s, b)\n"
+        "    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf), (w, h, m, s, b)\n"
+        "print('sanitized ok')\n") % (U.ROOT, str(so))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "sanitized ok" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+
