@@ -1047,7 +1047,7 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
     return PNGLOSS_SUCCESS;
 }
 
-const char *pngloss_hip_version(void) { return "pngloss_hip 0.3 (gfx950; row engines: segment-parallel v1 + band-leader v2; seam: pngloss_image.h:14-29)"; }
+const char *pngloss_hip_version(void) { return "pngloss_hip 0.3 (gfx950; row engines: segment-parallel v2 (dense transition tables, checkpoints) + band-leader v2; seam: pngloss_image.h:14-29)"; }
 
 /* ---- the reference's seam ------------------------------------------------------------------------------- */
 
