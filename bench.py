@@ -199,7 +199,7 @@ def bandwidth_kernels():
         with open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")) as fh:
             for f in csv.reader(ln for ln in fh if not ln.startswith("#")):
                 for name, nbytes in alg.items():
-                    if len(f) >= 5 and name + "(" in f[0] and name not in out:
+                    if len(f) >= 5 and (name + "(" in f[0] or name + "<" in f[0]) and name not in out:
                         avg_us = round(float(f[3]) / 1e3, 2)
                         out[name] = {"avg_us": avg_us, "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / avg_us / 1e3, 1),
                                      "frac_of_8TBps": round(nbytes / avg_us / 1e3 / 8000.0, 4)}

@@ -214,6 +214,29 @@ def test_batch_histogram_matches_oracle(torch_cuda):
     ctx.close()
 
 
+@pytest.mark.parametrize("width", [152, 150, 4, 8, 260])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
+def test_original_histogram_every_class_and_both_loaders(torch_cuda, width, mode):
+    """pl_hist (optimize_state.c:66-83) counts four pixels per thread when a row is a whole number of 16-byte quads and pixel by
+    pixel otherwise; every bytes-per-pixel class (generator modes 0, 2, 3, 4 -> 4, 3, 2, 1) through both, against the oracle."""
+    torch = torch_cuda
+    h = 37
+    a = P.synth_rgba(width, h, mode, 5)
+    d = torch.from_numpy(a.copy()).cuda()
+    f = torch.zeros(h, dtype=torch.uint8, device="cuda")
+    ctx = P.HipContext()
+    ctx.run([(d.data_ptr(), f.data_ptr(), width, h)], 19, 2)
+    bpp = {0: 4, 2: 3, 3: 2, 4: 1}[mode]
+    packed = {4: a, 3: a[..., :3], 2: a[..., [1, 3]], 1: a[..., 1:2]}[bpp]
+    want, want_f, hist = U.run_port_packed(np.ascontiguousarray(packed), 19, 2, trace=True)
+    got = d.cpu().numpy()
+    got_packed = {4: got, 3: got[..., :3], 2: got[..., [1, 3]], 1: got[..., 1:2]}[bpp]
+    assert np.array_equal(got_packed, want)
+    assert np.array_equal(f.cpu().numpy(), want_f)
+    assert np.array_equal(ctx.histogram(0), hist)       # (the running histogram after the last row: every tie was broken alike)
+    ctx.close()
+
+
 def test_reference_digests_1080p_frames():
     for e in U.load_digests()["synthetic"]:
         if (e["width"], e["height"]) != (1920, 1080):
