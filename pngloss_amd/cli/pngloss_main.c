@@ -446,6 +446,16 @@ static void *decode_ahead_main(void *arg)
     return NULL;
 }
 
+static void *warm_up_main(void *arg)
+{
+    (void)arg;
+    if (pngloss_hip_device_count() > 0) {                    /* runtime, device context, code objects */
+        pngloss_hip_ctx *c = pngloss_hip_create(-1);
+        if (c) pngloss_hip_destroy(c);
+    }
+    return NULL;
+}
+
 static void decode_ahead_start(struct decode_ahead *d, struct job *jobs, size_t n, const struct options *o)
 {
     d->jobs = jobs; d->n = n; d->o = o; d->seconds = 0;
@@ -495,6 +505,7 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
     }
     if (m) {
         /* every GPU of the node ($PNGLOSS_DEVICES restricts or repeats them): the files of the window are dealt out by size */
+        const double tc0 = now_s();
         if (!*ctx) {
             /* a context (device initialisation, events, arenas) only on as many GPUs as the call has files for */
             const char *envd = getenv("PNGLOSS_DEVICES");
@@ -506,6 +517,7 @@ static pngloss_error run_window(struct job *jobs, size_t n, const struct options
                 *ctx = pngloss_hip_multi_create(list);
             }
         }
+        if (timing) fprintf(stderr, "  [timing] GPU contexts ready after %.3f s\n", now_s() - tc0);
         int rc = !*ctx ? PNGLOSS_HIP_ERROR
                : pngloss_hip_multi_optimize_batch_host(*ctx, imgs, m, (unsigned)o->strength, (long)o->bleed, res,
                                                        o->gpu_deflate ? NULL : lines, o->gpu_deflate ? zs : NULL);
@@ -585,10 +597,14 @@ int main(int argc, char **argv)
      * window is decoded in the background while the current one is on the GPU (pngloss.c:173 is a sequential loop). */
     struct decode_ahead ahead;
     memset(&ahead, 0, sizeof ahead);
+    /* the HIP runtime needs a quarter of a second for its first call: let it be made while the first window is read and decoded */
+    pthread_t warm;
+    const bool warming = total && pthread_create(&warm, NULL, warm_up_main, NULL) == 0;
     decode_ahead_start(&ahead, jobs, total < WINDOW_FILES ? total : WINDOW_FILES, &o);
     for (size_t start = 0; start < total;) {
         size_t n = total - start < WINDOW_FILES ? total - start : WINDOW_FILES;
         decode_ahead_wait(&ahead);
+        if (warming && start == 0) pthread_join(warm, NULL);
         const double decode_seconds = ahead.seconds;
         const size_t next = start + n, next_n = total - next < WINDOW_FILES ? total - next : WINDOW_FILES;
         if (next < total) decode_ahead_start(&ahead, jobs + next, next_n, &o);

@@ -620,6 +620,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
      * copies from pinned memory, one per image (pageable per-image copies were 0.33 s of a 1.6 s window of 256 720p files in round 1).
      * Copies and kernels of a context run on its own non-blocking stream, so that two contexts (the two halves of a window,
      * batch_host) overlap: one half's transfers with the other half's kernels. */
+    const auto ta0 = std::chrono::steady_clock::now();
     if (total > ctx->arena_bytes) {
         if (ctx->d_arena) PL_CHECK(hipFree(ctx->d_arena));
         ctx->d_arena = nullptr; ctx->arena_bytes = 0;
@@ -635,6 +636,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
         ctx->pinned_bytes = want;
     }
     if (!ctx->copy_stream) PL_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (std::getenv("PNGLOSS_HIP_DEBUG_SEAM")) std::fprintf(stderr, "pngloss_hip: host window chunk %d: arena %zu MB + pinned mirror %zu MB ready after %.1f ms\n", my_turn, total >> 20, mirrored >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count());
     char *const arena = ctx->d_arena;
     int rc = PNGLOSS_SUCCESS;
     std::vector<pngloss_hip_image_desc> descs(n);
@@ -762,6 +764,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
             }
         }
         ctx->deflate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (std::getenv("PNGLOSS_HIP_DEBUG_SEAM")) std::fprintf(stderr, "pngloss_hip: host window: deflate stage %.1f ms for %zu images\n", ctx->deflate_ms, dz.size());
     }
     if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
     if (rc == PNGLOSS_SUCCESS && some_aborted) rc = PNGLOSS_INTERNAL_ABORT;

@@ -8,7 +8,7 @@ from PIL import Image
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref", "pngloss_ref_cli")
 OURS = os.path.join(ROOT, "pngloss_amd", "cli", "pngloss")
-n, W, H = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 1280, 720
+n, W, H = int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(os.environ.get("CLI_BENCH_W", 1280)), int(os.environ.get("CLI_BENCH_H", 720))
 with tempfile.TemporaryDirectory() as d:
     files = []
     for i in range(n):
