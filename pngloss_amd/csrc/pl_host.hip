@@ -1000,7 +1000,8 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
     if (!n) return PNGLOSS_SUCCESS;
     PL_CHECK(hipSetDevice(ctx->device));
     std::vector<PrJob> jobs(n);
-    std::vector<size_t> raw_off(n), out_off(n), last_off(n);
+    std::vector<size_t> raw_off(n), out_off(n), last_off(n), prog_off(n);
+    uint32_t max_bands = 0;
     size_t total = align_up(sizeof(PrJob) * n, 256) + align_up(sizeof(int32_t) * n, 256);
     const size_t jobs_bytes = align_up(sizeof(PrJob) * n, 256);
     for (size_t i = 0; i < n; i++) {
@@ -1011,7 +1012,12 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
         }
         raw_off[i] = total; total += align_up(((size_t)jobs[i].F.rowbytes + 1) * src[i].height, 256);
         out_off[i] = total; total += align_up((size_t)src[i].width * src[i].height * 4, 256);
-        last_off[i] = total; total += align_up(jobs[i].F.rowbytes, 256);
+        /* per band of PR_ROWS rows: its last row (for the band below) and a progress word */
+        jobs[i].nbands = (src[i].height + PR_ROWS - 1) / PR_ROWS;
+        jobs[i].lastpitch = (uint32_t)align_up(jobs[i].F.rowbytes, 256);
+        max_bands = std::max(max_bands, jobs[i].nbands);
+        last_off[i] = total; total += (size_t)jobs[i].lastpitch * jobs[i].nbands;
+        prog_off[i] = total; total += align_up(sizeof(uint32_t) * jobs[i].nbands, 256);
     }
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
@@ -1022,11 +1028,13 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
         jobs[i].raw = reinterpret_cast<const uint8_t *>(b + raw_off[i]);
         jobs[i].rgba = reinterpret_cast<uint32_t *>(b + out_off[i]);
         jobs[i].lastrow = reinterpret_cast<uint8_t *>(b + last_off[i]);
+        jobs[i].progress = reinterpret_cast<uint32_t *>(b + prog_off[i]);
+        PL_CHECK(hipMemsetAsync(b + prog_off[i], 0, sizeof(uint32_t) * jobs[i].nbands, nullptr));
         jobs[i].status = d_status + i;
         PL_CHECK(hipMemcpyAsync(b + raw_off[i], src[i].scanlines, ((size_t)jobs[i].F.rowbytes + 1) * src[i].height, hipMemcpyHostToDevice, nullptr));
     }
     PL_CHECK(hipMemcpyAsync(b, jobs.data(), sizeof(PrJob) * n, hipMemcpyHostToDevice, nullptr));
-    PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, nullptr));
+    PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, max_bands, nullptr));
     std::vector<int32_t> st(n);
     for (size_t i = 0; i < n; i++)
         PL_CHECK(hipMemcpyAsync(src[i].rgba, b + out_off[i], (size_t)src[i].width * src[i].height * 4, hipMemcpyDeviceToHost, nullptr));

@@ -62,3 +62,33 @@ def test_device_reader_rejects_what_is_not_png():
     src[0] = L.PngSource(p["scanlines"], p["width"], p["height"], 2, 4, None, 0, None, 0, out.ctypes.data)   # RGB with 4 bits: no such format
     assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 4
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,ctype,depth", [(2000, 700, 6, 8), (4099, 130, 2, 8), (1500, 333, 0, 16), (3000, 200, 4, 8), (5000, 129, 3, 4),
+                                             (241, 64, 6, 8), (240, 65, 6, 8), (7, 1000, 2, 16)])
+def test_device_reader_many_bands_and_blocks(w, h, ctype, depth):
+    """Inverse filtering is defined on any byte stream: random scanlines with random filter types (none, sub, up, average, paeth; mostly
+    the last two, which couple a row to the one above), sized so that an image is many bands of 64 rows -- one wave each, handing
+    its last row to the band below block by block -- and a row many 960-byte blocks.  Expected: the same pixel arithmetic on the CPU
+    (tests/c/pngread_host.cpp, pinned to the reference reader by the fixtures above)."""
+    import ctypes as C
+    rng = np.random.default_rng(w * 131 + h)
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    rowbytes = (w * channels * depth + 7) // 8
+    rows = rng.integers(0, 256, (h, 1 + rowbytes), dtype=np.uint8)
+    rows[:, 0] = rng.choice([0, 1, 2, 3, 4, 3, 4, 4], h)
+    scan = rows.tobytes()
+    plte = bytes(rng.integers(0, 256, 3 * 16, dtype=np.uint8)) if ctype == 3 else None
+    trns = bytes(rng.integers(0, 256, 9, dtype=np.uint8)) if ctype == 3 else None
+    want = np.zeros((h, w, 4), np.uint8)
+    assert U.pngread_host_lib().pngread_host_decode(scan, w, h, ctype, depth, plte, 16 if plte else 0, trns, 9 if trns else 0, want.ctypes.data) == 0
+    got = np.zeros((h, w, 4), np.uint8)
+    src = (L.PngSource * 1)(L.PngSource(scan, w, h, ctype, depth, plte, 16 if plte else 0, trns, 9 if trns else 0, got.ctypes.data))
+    ctx = P.HipContext()
+    lib = P.hip_lib()
+    lib.pngloss_hip_png_decode_batch_host.restype = C.c_int
+    lib.pngloss_hip_png_decode_batch_host.argtypes = [C.c_void_p, C.POINTER(L.PngSource), C.c_size_t]
+    assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 0
+    assert np.array_equal(got, want), np.argwhere((got != want).any(axis=2))[:3].tolist()
+    ctx.close()
