@@ -1019,8 +1019,11 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
         last_off[i] = total; total += (size_t)jobs[i].lastpitch * jobs[i].nbands;
         prog_off[i] = total; total += align_up(sizeof(uint32_t) * jobs[i].nbands, 256);
     }
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
+    const double ms_ws = ms_since();
     char *b = ctx->d_ws;
     int32_t *d_status = reinterpret_cast<int32_t *>(b + jobs_bytes);
     PL_CHECK(hipMemsetAsync(d_status, 0, sizeof(int32_t) * n, nullptr));
@@ -1034,12 +1037,17 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
         PL_CHECK(hipMemcpyAsync(b + raw_off[i], src[i].scanlines, ((size_t)jobs[i].F.rowbytes + 1) * src[i].height, hipMemcpyHostToDevice, nullptr));
     }
     PL_CHECK(hipMemcpyAsync(b, jobs.data(), sizeof(PrJob) * n, hipMemcpyHostToDevice, nullptr));
+    const bool seam_dbg = std::getenv("PNGLOSS_HIP_DEBUG_SEAM") != nullptr;
+    double ms_up = 0, ms_k = 0;
+    if (seam_dbg) { PL_CHECK(hipStreamSynchronize(nullptr)); ms_up = ms_since(); }
     PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, max_bands, nullptr));
+    if (seam_dbg) { PL_CHECK(hipStreamSynchronize(nullptr)); ms_k = ms_since(); }
     std::vector<int32_t> st(n);
     for (size_t i = 0; i < n; i++)
         PL_CHECK(hipMemcpyAsync(src[i].rgba, b + out_off[i], (size_t)src[i].width * src[i].height * 4, hipMemcpyDeviceToHost, nullptr));
     PL_CHECK(hipMemcpyAsync(st.data(), d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, nullptr));
     PL_CHECK(hipStreamSynchronize(nullptr));
+    if (seam_dbg) std::fprintf(stderr, "pngloss_hip: read side: %zu files, workspace %zu MB ready after %.1f ms, upload %.1f ms, unfilter + expand %.1f ms, download %.1f ms\n", n, total >> 20, ms_ws, ms_up - ms_ws, ms_k - ms_up, ms_since() - ms_k);
     for (size_t i = 0; i < n; i++)
         if (st[i]) { std::fprintf(stderr, "pngloss_hip: image %zu: a scanline has a filter type beyond 4 (corrupt stream)\n", i); return 25; }
     return PNGLOSS_SUCCESS;

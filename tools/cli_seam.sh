@@ -13,7 +13,7 @@ for i in range(32): Image.fromarray(P.synth_rgba(1280, 720, 0, i), "RGBA").save(
 PY
 export PNGLOSS_TIMING=1 PNGLOSS_HIP_DEBUG_SEAM=1 PNGLOSS_HIP_DEBUG=1
 echo "== one 4096x4096 file, --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-deflate --ext -gpu.png $D/big.png ) 2>&1 | grep -v "^$" | cut -c1-260
-echo "== the same again"; ( time pngloss_amd/cli/pngloss -f --gpu-deflate --ext -gpu.png $D/big.png ) 2>&1 | grep -v "^$" | cut -c1-260
-echo "== 32 files 1280x720, --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-deflate --ext -gpu.png $D/f*.png ) 2>&1 | grep -v "^$" | cut -c1-260
-echo "== one 4096x4096 file, --gpu-read --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-read --gpu-deflate --ext -gpu.png $D/big.png ) 2>&1 | grep -v "^$" | cut -c1-260
-echo "== 32 files 1280x720, --gpu-read --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-read --gpu-deflate --ext -gpu.png $D/f*.png ) 2>&1 | grep -v "^$" | cut -c1-260
+rm -f $D/*-gpu.png; echo "== the same again"; ( time pngloss_amd/cli/pngloss -f --gpu-deflate --ext -gpu.png $D/big.png ) 2>&1 | grep -v "^$" | cut -c1-260
+rm -f $D/*-gpu.png; echo "== 32 files 1280x720, --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-deflate --ext -gpu.png $D/f*.png ) 2>&1 | grep -v "^$" | cut -c1-260
+rm -f $D/*-gpu.png; echo "== one 4096x4096 file, --gpu-read --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-read --gpu-deflate --ext -gpu.png $D/big.png ) 2>&1 | grep -v "^$" | cut -c1-260
+rm -f $D/*-gpu.png; echo "== 32 files 1280x720, --gpu-read --gpu-deflate"; ( time pngloss_amd/cli/pngloss -f --gpu-read --gpu-deflate --ext -gpu.png $D/f*.png ) 2>&1 | grep -v "^$" | cut -c1-260
