@@ -165,8 +165,10 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const bool small_ok = b.small_ok;
         const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
-        if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
-        else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), SEG_SM_ENUM, stream, b.d_sj, b.d_params, par, b.max_nseg);
+        static const bool enum_lds_bound = getenv("PNGLOSS_HIP_ENUM_LDS") != nullptr;   /* experiment: the generous bound (3 workgroups of 512 per CU) */
+        const size_t enum_lds = enum_lds_bound ? (size_t)SEG_SM_ENUM : (size_t)SEG_SM_ENUM_NT(nt);
+        if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
+        else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
     }
     hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);

@@ -151,11 +151,13 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
 #define SEG_SMALL_SEGS 8           /* most segments per enumeration workgroup for them: 8 segments x 4 channels x SEG_NSS lanes (1024 threads) */
-/* The enumeration's workgroups come in two sizes, NT = 1024 threads (4 channels x SEG_NSP lanes) or 512 (a channel pair).  The lighter
- * ones are faster while a CU gets at most two or three of them (measured per 1080-row frame, 512 against 1024 threads: 1024 pixels wide
- * 57.6 / 61.2 ms, 1920: 56.8 / 58.4, 2560: 61.3 / 64.4, 3072: 61.6 / 64.6), the larger ones when the lighter pile up (3584: 66.3 / 65.3,
- * 4096: 68.3 / 66.7, 8192: 88.5 / 87.6).  The launcher picks 512 while all images' segments together are at most this many. */
-#define SEG_ENUM_NT_SMALL_MAX_NSEG 100
+/* The enumeration's workgroups come in two sizes, NT = 1024 threads (4 channels x SEG_NSP lanes) or 512 (a channel pair).  With the
+ * kernel's LDS request at what the bodies really use (SEG_SM_ENUM_NT: 35.5 KB at 512 threads = four workgroups per CU; the generous bound
+ * of before allowed three, and rows beyond 3200 pixels then needed a second round of workgroups) the lighter ones win or tie for every
+ * single image (engine ms, 512 against 1024 threads: 1920 x 2048: 106.8 / 110.0; 3200 x 2048: 119.1 / 125.3; 4096 x 2048: 119.6 / 121.9;
+ * 6144 x 1024: 68.7 / 72.2; 7168 x 1024: 74.1 / 73.7; 8192 x 1024: 80.4 / 82.5) and for small batches (1920 x 1080 frames, n = 4: 84.5 / 85.3,
+ * n = 8: 116.3 / 115.1, n = 32: 328.5 / 315.1): the launcher picks 512 while all images' segments together are at most this many. */
+#define SEG_ENUM_NT_SMALL_MAX_NSEG 320
 #define SEG_KEYS_MAX 2048
 
 /* what a row attempt decided (seg_ctl_body) */
@@ -666,6 +668,9 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 
 /* shared-memory budgets (bytes) */
 #define SEG_SM_ENUM (SEG_TBL_WORDS * 4 + 2048 + SEG_SMALL_SEGS * SEG_L * 4 * 8 + 64 + 4 * 512 * 4 + 4 * 512 * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + SEG_THREADS * 2 + SEG_THREADS * 4 + 64)
+/* what the enumeration kernel's bodies really carve out for NT threads (seg_enum_body is the largest: tables, pixels, split table, hash table,
+ * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
+#define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
 #define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)

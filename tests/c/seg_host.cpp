@@ -107,16 +107,19 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         /* the enumeration's workgroups come in two sizes; the product picks by row width, SEG_HOST_ENUM_NT pins one */
         int nt = j.nseg <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512 : 1024;
         if (getenv("SEG_HOST_ENUM_NT")) nt = atoi(getenv("SEG_HOST_ENUM_NT")) == 1024 ? 1024 : 512;
+        /* the enumeration kernel is launched with exactly SEG_SM_ENUM_NT(nt) bytes of LDS: the bodies get a buffer of that size here, and the
+         * sanitizer build (tests/test_seg_host.py) sees any byte they touch beyond it */
+        std::vector<unsigned char> esm((size_t)SEG_SM_ENUM_NT(nt), 0x5A);
         for (int f = 0; f < SEG_NFILT; f++) {
             if (nt == 512) {
-                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 4) seg_enum_small_body<512>(j, P, par, f, (int)sg, smem.data());
-                else for (uint32_t sg = 0; sg < j.nseg; sg++) for (int ch = 0; ch < 2; ch++) seg_enum_body<512>(j, P, par, f, (int)sg, ch, smem.data());
+                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 4) seg_enum_small_body<512>(j, P, par, f, (int)sg, esm.data());
+                else for (uint32_t sg = 0; sg < j.nseg; sg++) for (int ch = 0; ch < 2; ch++) seg_enum_body<512>(j, P, par, f, (int)sg, ch, esm.data());
             } else {
-                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 8) seg_enum_small_body<1024>(j, P, par, f, (int)sg, smem.data());
-                else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, par, f, (int)sg, 0, smem.data());
+                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 8) seg_enum_small_body<1024>(j, P, par, f, (int)sg, esm.data());
+                else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, par, f, (int)sg, 0, esm.data());
             }
         }
-        for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, par, f, smem.data()); else seg_first_body<1024>(j, P, par, f, smem.data()); }
+        for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, par, f, esm.data()); else seg_first_body<1024>(j, P, par, f, esm.data()); }
         for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, smem.data());
         for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, par, f, (int)vg, smem.data());

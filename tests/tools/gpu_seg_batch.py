@@ -25,7 +25,7 @@ for n in ns:
 '''
 w, h = int(sys.argv[1]), int(sys.argv[2])
 ns = [int(v) for v in sys.argv[3:]] or [1, 2, 4, 8, 16]
-for eng in ("seg", "wg"):
+for eng in os.environ.get("SEG_BATCH_ENGINES", "seg,wg").split(","):
     print("--- PNGLOSS_HIP_ENGINE=%s  %dx%d" % (eng, w, h))
     r = subprocess.run([sys.executable, "-c", CODE % (ROOT, w, h, ns)], env=dict(os.environ, PNGLOSS_HIP_ENGINE=eng), capture_output=True, text=True, timeout=1500)
     print(r.stdout, r.stderr[-800:] if r.returncode else "")
