@@ -98,11 +98,7 @@ __global__ __launch_bounds__(64) void pr_k_decode(const PrJob *jobs)
                     const int o = xi * (int)bppf;
                     if (bppf == 4) {
                         const uint32_t x4 = *(const uint32_t *)(mine + o), a4 = *(const uint32_t *)(mine + o - 4), b4 = *(const uint32_t *)(up + o), c4 = *(const uint32_t *)(up + o - 4);
-                        uint32_t r4 = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            r4 |= (uint32_t)pr_recon(ft, (int)((x4 >> (8 * k)) & 255u), (int)((a4 >> (8 * k)) & 255u), (int)((b4 >> (8 * k)) & 255u), (int)((c4 >> (8 * k)) & 255u)) << (8 * k);
-                        *(uint32_t *)(mine + o) = r4;
+                        *(uint32_t *)(mine + o) = pr_recon4(ft, x4, a4, b4, c4);
                     } else {
                         for (int k = 0; k < (int)bppf && o + k < nb; k++)
                             mine[o + k] = (uint8_t)pr_recon(ft, mine[o + k], mine[o + k - (int)bppf], up[o + k], up[o + k - (int)bppf]);

@@ -58,6 +58,27 @@ PR_HD int pr_recon(int ft, int x, int a, int b, int c)
     return (x + pred) & 255;
 }
 
+/* the same for the four bytes of a 4-byte pixel at once, without a branch: on the device the 64 rows of a band (= lanes of a wave) have
+ * different filter types, and a switch would run every case one after the other for the whole wave */
+PR_HD uint32_t pr_recon4(int ft, uint32_t x, uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t pae = 0u;
+    for (int k = 0; k < 4; k++) {
+        const int A = (int)((a >> (8 * k)) & 255u), B = (int)((b >> (8 * k)) & 255u), C = (int)((c >> (8 * k)) & 255u);
+        const int da = B - C, db = A - C, dc = da + db;                       /* p - a, p - b, p - c  with  p = a + b - c */
+        const int pa = da < 0 ? -da : da, pb = db < 0 ? -db : db, pc = dc < 0 ? -dc : dc;
+        const int pred = (pa <= pb && pa <= pc) ? A : (pb <= pc ? B : C);
+        pae |= (uint32_t)pred << (8 * k);
+    }
+    const uint32_t avg = (a & b) + (((a ^ b) & 0xfefefefeu) >> 1);           /* per byte floor((a + b) / 2) */
+    uint32_t pred = 0u;
+    pred = ft == 1 ? a : pred;
+    pred = ft == 2 ? b : pred;
+    pred = ft == 3 ? avg : pred;
+    pred = ft == 4 ? pae : pred;
+    return ((x & 0x7f7f7f7fu) + (pred & 0x7f7f7f7fu)) ^ ((x ^ pred) & 0x80808080u);   /* per byte (x + pred) mod 256 */
+}
+
 /* RGBA8 (r | g << 8 | b << 16 | a << 24) of pixel x of an unfiltered row */
 PR_HD uint32_t pr_expand(const PrFormat &F, const uint8_t *row, uint32_t x)
 {

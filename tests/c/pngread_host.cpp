@@ -30,3 +30,20 @@ extern "C" int pngread_host_decode(const unsigned char *scanlines, uint32_t widt
     }
     return 0;
 }
+
+/* pr_recon4 (four bytes at once, branch-free) against pr_recon byte by byte: number of disagreements over n pseudo-random inputs */
+extern "C" int pngread_host_recon4_check(uint32_t n, uint32_t seed)
+{
+    int bad = 0;
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t x = next(), a = (i & 7) == 0 ? next() & 0x01ff01ffu : next(), b = (i & 5) == 0 ? a : next(), c = (i & 3) == 0 ? b : next();
+        for (int ft = 0; ft < 5; ft++) {
+            uint32_t want = 0;
+            for (int k = 0; k < 4; k++) want |= (uint32_t)pr_recon(ft, (x >> (8 * k)) & 255, (a >> (8 * k)) & 255, (b >> (8 * k)) & 255, (c >> (8 * k)) & 255) << (8 * k);
+            bad += pr_recon4(ft, x, a, b, c) != want;
+        }
+    }
+    return bad;
+}

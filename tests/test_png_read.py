@@ -26,6 +26,13 @@ def test_pixel_arithmetic_matches_the_reference_reader():
     assert n == 78
 
 
+def test_four_byte_inverse_filter_matches_the_byte_one():
+    """pr_recon4 (the kernel's branch-free step for 4-byte pixels) == pr_recon on every byte, all five filter types"""
+    lib = U.pngread_host_lib()
+    lib.pngread_host_recon4_check.restype = __import__("ctypes").c_int
+    assert lib.pngread_host_recon4_check(400000, 3) == 0
+
+
 def test_fixture_set_covers_every_png_format():
     names = [n for n, _, _ in U.png_read_fixtures()]
     for ctype, depths in [(0, [1, 2, 4, 8, 16]), (2, [8, 16]), (3, [1, 2, 4, 8]), (4, [8, 16]), (6, [8, 16])]:
