@@ -58,13 +58,36 @@ __global__ __launch_bounds__(64) void pr_k_decode(const PrJob *jobs)
         }
         for (uint32_t b0 = 0; b0 < rowbytes; b0 += PR_BLK, blk++) {
             const int nb = (int)min((uint32_t)PR_BLK, rowbytes - b0);
-            /* raw bytes of the band's rows -> tile rows 1.. (dword loads; the source rows start at odd addresses: unaligned loads) */
-            for (int r = 0; r < nrows; r++) {
-                const uint8_t *src = j.raw + (size_t)(y0 + r) * S + 1 + b0;
-                uint8_t *dst = pr_tile + (size_t)(r + 1) * PR_STRIDE + PR_PAD;
-                for (int i = lane * 4; i < nb; i += 256) {
-                    if (i + 4 <= nb) { uint32_t v; __builtin_memcpy(&v, src + i, 4); *(uint32_t *)(dst + i) = v; }
-                    else for (int k = i; k < nb; k++) dst[k] = src[k];
+            /* raw bytes of the band's rows -> tile rows 1.. (dword loads; the source rows start at odd addresses: unaligned loads).  Eight
+             * rows' requests are issued before the first store, so that a block costs 8 round trips to memory, not 256 */
+            for (int r0 = 0; r0 < nrows; r0 += 8) {
+                uint32_t v[8][4];
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) {
+                    const uint8_t *src = j.raw + (size_t)(y0 + min(r0 + rr, nrows - 1)) * S + 1 + b0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = lane * 4 + q * 256;
+                        v[rr][q] = 0u;
+                        if (i + 4 <= nb) __builtin_memcpy(&v[rr][q], src + i, 4);
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) {
+                    if (r0 + rr >= nrows) continue;
+                    uint8_t *dst = pr_tile + (size_t)(r0 + rr + 1) * PR_STRIDE + PR_PAD;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = lane * 4 + q * 256;
+                        if (i + 4 <= nb) *(uint32_t *)(dst + i) = v[rr][q];
+                    }
+                }
+            }
+            if (nb & 3) {                                   /* the last, partial dword of every row: lane = row */
+                if (lane < nrows) {
+                    const uint8_t *src = j.raw + (size_t)(y0 + lane) * S + 1 + b0;
+                    uint8_t *dst = pr_tile + (size_t)(lane + 1) * PR_STRIDE + PR_PAD;
+                    for (int k = nb & ~3; k < nb; k++) dst[k] = src[k];
                 }
             }
             /* the row above the band: the band above has to be past this block */
