@@ -42,19 +42,15 @@ PR_HD bool pr_valid(int color_type, int depth)
 /* inverse filter of one byte: x = filtered byte, a = left, b = above, c = upper left (reconstructed bytes, 0 outside the image) */
 PR_HD int pr_recon(int ft, int x, int a, int b, int c)
 {
-    int pred;
-    switch (ft) {
-    case 1: pred = a; break;
-    case 2: pred = b; break;
-    case 3: pred = (a + b) >> 1; break;
-    case 4: {
-        const int p = a + b - c;
-        const int pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
-        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-        break;
-    }
-    default: pred = 0; break;
-    }
+    /* selects, not a switch: the rows of a band (lanes of a wave) have different filter types */
+    const int da = b - c, db = a - c, dc = da + db;                           /* p - a, p - b, p - c  with  p = a + b - c */
+    const int pa = da < 0 ? -da : da, pb = db < 0 ? -db : db, pc = dc < 0 ? -dc : dc;
+    const int pae = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+    int pred = 0;
+    pred = ft == 1 ? a : pred;
+    pred = ft == 2 ? b : pred;
+    pred = ft == 3 ? ((a + b) >> 1) : pred;
+    pred = ft == 4 ? pae : pred;
     return (x + pred) & 255;
 }
 
