@@ -10,7 +10,7 @@
  * reads from a per-band row buffer once that band's progress word says the block is there (release / acquire at device scope;
  * workgroups are dispatched in blockIdx order, so the band waited for is always running or done; a bounded wait turns a broken
  * assumption into an error status instead of a hang).  A 4096 x 4096 RGBA file: 64 bands in flight instead of one wave walking
- * them in turn (449 ms -> see profiles/r03_read_side.txt); the band's data goes through LDS in blocks of 960 bytes per row (a multiple of every pixel size
+ * them in turn (449 ms -> 7.5 ms, profiles/r03_read_side.txt); the band's data goes through LDS in blocks of 960 bytes per row (a multiple of every pixel size
  * 1, 2, 3, 4, 6, 8, so blocks cut between pixels), 65 rows (the row above the band first) x 976 bytes = 62 KB.  Neighbouring lanes
  * exchange the "above" bytes through that tile one step apart (wave-synchronous: same wave, program order).  Behind every block all
  * 64 lanes expand its pixels to RGBA8 with coalesced stores.  Images of a batch are independent.
@@ -29,6 +29,52 @@ __device__ __forceinline__ void pr_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* One wavefront step of a lane: the next CH bytes of its row -- a whole number of pixels and of 32-bit words (4 bytes for 1-, 2- and
+ * 4-byte pixels, 12 for 3 and 6, 8 for 8) -- read as words, reconstructed byte after byte in registers (a byte's left neighbour is BPP
+ * bytes back: in this chunk, or in the words in front of it), written back as words.  The row above is complete up to the end of the
+ * same chunk (its lane is one step ahead).  BPP is a template parameter so that every byte index is a constant. */
+template <int BPP>
+__device__ __forceinline__ void pr_step(int ft, uint8_t *mine, const uint8_t *up, int o)
+{
+    constexpr int CH = (BPP == 3 || BPP == 6) ? 12 : (BPP == 8 ? 8 : 4), NW = CH / 4, PW = (BPP + 3) / 4;
+    if (BPP == 4) {
+        const uint32_t x4 = *(const uint32_t *)(mine + o), a4 = *(const uint32_t *)(mine + o - 4), b4 = *(const uint32_t *)(up + o), c4 = *(const uint32_t *)(up + o - 4);
+        *(uint32_t *)(mine + o) = pr_recon4(ft, x4, a4, b4, c4);
+        return;
+    }
+    uint32_t X[NW], B[NW], R[NW], AP[PW], CP[PW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) { X[w] = *(const uint32_t *)(mine + o + 4 * w); B[w] = *(const uint32_t *)(up + o + 4 * w); R[w] = 0u; }
+#pragma unroll
+    for (int w = 0; w < PW; w++) { AP[w] = *(const uint32_t *)(mine + o - 4 * PW + 4 * w); CP[w] = *(const uint32_t *)(up + o - 4 * PW + 4 * w); }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int x = (int)((X[k >> 2] >> (8 * (k & 3))) & 255u), b = (int)((B[k >> 2] >> (8 * (k & 3))) & 255u);
+        int a, c;
+        if (k >= BPP) {
+            const int li = k - BPP;
+            a = (int)((R[li >> 2] >> (8 * (li & 3))) & 255u); c = (int)((B[li >> 2] >> (8 * (li & 3))) & 255u);
+        } else {
+            const int li = 4 * PW + k - BPP;
+            a = (int)((AP[li >> 2] >> (8 * (li & 3))) & 255u); c = (int)((CP[li >> 2] >> (8 * (li & 3))) & 255u);
+        }
+        R[k >> 2] |= (uint32_t)pr_recon(ft, x, a, b, c) << (8 * (k & 3));
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) *(uint32_t *)(mine + o + 4 * w) = R[w];
+}
+
+template <int BPP>
+__device__ __forceinline__ void pr_wavefront(int ft, uint8_t *mine, const uint8_t *up, int npg, int nrows, int lane)
+{
+    constexpr int CH = (BPP == 3 || BPP == 6) ? 12 : (BPP == 8 ? 8 : 4);
+    for (int t = 0; t < npg + nrows - 1; t++) {
+        const int xi = t - lane;
+        if (lane < nrows && xi >= 0 && xi < npg) pr_step<BPP>(ft, mine, up, xi * CH);
+        pr_wave_sync();
+    }
 }
 
 __global__ __launch_bounds__(64) void pr_k_decode(const PrJob *jobs)
@@ -111,23 +157,27 @@ __global__ __launch_bounds__(64) void pr_k_decode(const PrJob *jobs)
                 }
             }
             pr_wave_sync();
-            /* wavefront: lane r reconstructs pixel (t - r) of its row at step t */
-            const int npg = (nb + (int)bppf - 1) / (int)bppf;
+            /* wavefront: lane r reconstructs chunk (t - r) of its row at step t (pr_step: 4, 8 or 12 bytes, a whole number of pixels).  A
+             * partial last chunk of a row's last block runs over stale tile bytes behind nb: never read as pixels, never past the row's 960 */
+            const int ch = (bppf == 3 || bppf == 6) ? 12 : (bppf == 8 ? 8 : 4);
+            const int npg = (nb + ch - 1) / ch;
             uint8_t *mine = pr_tile + (size_t)(lane + 1) * PR_STRIDE + PR_PAD;
             const uint8_t *up = pr_tile + (size_t)lane * PR_STRIDE + PR_PAD;
-            for (int t = 0; t < npg + nrows - 1; t++) {
-                const int xi = t - lane;
-                if (lane < nrows && xi >= 0 && xi < npg) {
-                    const int o = xi * (int)bppf;
-                    if (bppf == 4) {
-                        const uint32_t x4 = *(const uint32_t *)(mine + o), a4 = *(const uint32_t *)(mine + o - 4), b4 = *(const uint32_t *)(up + o), c4 = *(const uint32_t *)(up + o - 4);
-                        *(uint32_t *)(mine + o) = pr_recon4(ft, x4, a4, b4, c4);
-                    } else {
-                        for (int k = 0; k < (int)bppf && o + k < nb; k++)
-                            mine[o + k] = (uint8_t)pr_recon(ft, mine[o + k], mine[o + k - (int)bppf], up[o + k], up[o + k - (int)bppf]);
-                    }
-                }
-                pr_wave_sync();
+            switch (bppf) {                                 /* (outside the loop: one specialised loop per pixel size) */
+            case 1: pr_wavefront<1>(ft, mine, up, npg, nrows, lane); break;
+            case 2: pr_wavefront<2>(ft, mine, up, npg, nrows, lane); break;
+            case 3: pr_wavefront<3>(ft, mine, up, npg, nrows, lane); break;
+            case 4: pr_wavefront<4>(ft, mine, up, npg, nrows, lane); break;
+            case 6: pr_wavefront<6>(ft, mine, up, npg, nrows, lane); break;
+            default: pr_wavefront<8>(ft, mine, up, npg, nrows, lane); break;
+            }
+            /* the band's last row for the band below, published before this block's pixels are expanded: the band below starts on the block meanwhile */
+            if (nrows == PR_ROWS && y0 + PR_ROWS < H) {
+                const uint8_t *src = pr_tile + (size_t)PR_ROWS * PR_STRIDE + PR_PAD;
+                for (int i = lane; i < nb; i += 64) below_row[b0 + i] = src[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) __hip_atomic_store(&j.progress[band], blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             /* expansion of the block's pixels to RGBA8, row after row, lanes along x */
             uint32_t px0, px1;
@@ -138,14 +188,7 @@ __global__ __launch_bounds__(64) void pr_k_decode(const PrJob *jobs)
                 uint32_t *out = j.rgba + (size_t)(y0 + r) * W;
                 for (uint32_t x = px0 + (uint32_t)lane; x < px1; x += 64) out[x] = pr_expand(F, rowp, x);
             }
-            /* the band's last row for the next band; the last pixel of every row becomes the margin of the next block */
-            if (nrows == PR_ROWS && y0 + PR_ROWS < H) {
-                const uint8_t *src = pr_tile + (size_t)PR_ROWS * PR_STRIDE + PR_PAD;
-                for (int i = lane; i < nb; i += 64) below_row[b0 + i] = src[i];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) __hip_atomic_store(&j.progress[band], blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            /* the last pixel of every row becomes the margin of the next block */
             uint8_t keep[8];
             {
                 const uint8_t *src = pr_tile + (size_t)(lane + 1) * PR_STRIDE + PR_PAD + nb - (int)bppf;
