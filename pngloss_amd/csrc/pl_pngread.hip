@@ -6,14 +6,15 @@
  *
  * Unfiltering is a recurrence: byte (x, y) needs the reconstructed bytes at (x - bpp, y), (x, y - 1), (x - bpp, y - 1).  Rows are NOT
  * independent, but row y can run one pixel behind row y - 1: a wavefront.  One wave per BAND of 64 rows (blockIdx.x = band,
- * blockIdx.y = image); lane = row of the band, staggered one pixel; band b runs one block behind band b - 1, whose last row it
+ * blockIdx.y = image); lane = row of the band, staggered one step (4, 8 or 12 bytes: a whole number of pixels and of words, pr_step);
+ * band b runs one block behind band b - 1, whose last row it
  * reads from a per-band row buffer once that band's progress word says the block is there (release / acquire at device scope;
  * workgroups are dispatched in blockIdx order, so the band waited for is always running or done; a bounded wait turns a broken
  * assumption into an error status instead of a hang).  A 4096 x 4096 RGBA file: 64 bands in flight instead of one wave walking
- * them in turn (449 ms -> 7.5 ms, profiles/r03_read_side.txt); the band's data goes through LDS in blocks of 960 bytes per row (a multiple of every pixel size
- * 1, 2, 3, 4, 6, 8, so blocks cut between pixels), 65 rows (the row above the band first) x 976 bytes = 62 KB.  Neighbouring lanes
- * exchange the "above" bytes through that tile one step apart (wave-synchronous: same wave, program order).  Behind every block all
- * 64 lanes expand its pixels to RGBA8 with coalesced stores.  Images of a batch are independent.
+ * them in turn (449 ms -> 7.5 ms, profiles/r03_read_side.txt).  The band's data goes through LDS in blocks of 960 bytes per row (a multiple
+ * of every pixel size 1, 2, 3, 4, 6, 8 and of every step, so blocks cut between pixels), 65 rows (the row above the band first) x 976 bytes = 62 KB.  Neighbouring lanes
+ * exchange the "above" bytes through that tile one step apart (wave-synchronous: same wave, program order).  Behind every block the
+ * band's last row is published, then all 64 lanes expand the block's pixels to RGBA8 with coalesced stores.  Images of a batch are independent.
  */
 #include "pl_device.h"
 #include "pl_pngread.h"
