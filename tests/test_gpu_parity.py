@@ -202,6 +202,29 @@ def test_strength_retry_rows_are_reported(torch_cuda):
         ctx.close()
 
 
+@pytest.mark.parametrize("engine", ["seg", "wg"])
+@pytest.mark.parametrize("shift_words", [1, 2, 3])
+def test_device_pointers_need_only_pixel_alignment(torch_cuda, monkeypatch, engine, shift_words):
+    """the device-resident entry point takes whatever RGBA8 pointer the caller has: a frame that starts 4, 8 or 12 bytes behind a 16-byte
+    boundary (a view into a larger buffer) must give the reference's result -- the kernels' 16-byte loads are an optimisation, not a contract"""
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", engine)
+    w, h = 256, 48
+    a = P.synth_rgba(w, h, 0, 7)
+    big = torch.zeros(w * h + 8, dtype=torch.int32, device="cuda")
+    view = big[shift_words:shift_words + w * h]
+    view.copy_(torch.from_numpy(a.view(np.int32).reshape(-1)).cuda())
+    f = torch.zeros(h, dtype=torch.uint8, device="cuda")
+    ctx = P.HipContext()
+    ctx.run([(view.data_ptr(), f.data_ptr(), w, h)], 19, 2)
+    want, want_f = U.run_port(a, 19, 2)
+    got = view.cpu().numpy().view(np.uint8).reshape(h, w, 4)
+    assert np.array_equal(got, want)
+    assert np.array_equal(f.cpu().numpy(), want_f)
+    assert int(big[:shift_words].abs().sum()) == 0 and int(big[shift_words + w * h:].abs().sum()) == 0     # nothing written outside the frame
+    ctx.close()
+
+
 def test_batch_histogram_matches_oracle(torch_cuda):
     torch = torch_cuda
     a = P.synth_rgba(150, 40, 2, 3)
