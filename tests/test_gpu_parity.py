@@ -225,6 +225,42 @@ def test_device_pointers_need_only_pixel_alignment(torch_cuda, monkeypatch, engi
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_seam_takes_rows_that_are_not_contiguous():
+    """optimize_with_rows (pngloss_image.h:21-25) gets an array of row pointers; the caller's rows need not be contiguous, ordered or
+    evenly spaced: rows placed backwards in a buffer with an odd stride, and a stride-based call with padding
+    behind every row -- both against the oracle, and the bytes between the rows untouched"""
+    import ctypes as C
+    w, h = 150, 37
+    a = P.synth_rgba(w, h, 0, 11)
+    want, want_f = U.run_port(a, 19, 2)
+    stride = w * 4 + 20
+    buf = np.full(h * stride + 64, 0xA5, np.uint8)
+    rows = (C.c_void_p * h)()
+    for y in range(h):
+        off = 8 + (h - 1 - y) * stride                      # row y sits in front of row y - 1
+        buf[off:off + w * 4] = a[y].reshape(-1)
+        rows[y] = buf.ctypes.data + off
+    filt = np.zeros(h, np.uint8)
+    rc = P.hip_lib().optimize_with_rows(rows, w, h, filt.ctypes.data_as(C.c_void_p), False, 19, 2)
+    assert rc == 0
+    for y in range(h):
+        off = 8 + (h - 1 - y) * stride
+        assert np.array_equal(buf[off:off + w * 4].reshape(w, 4), want[y]), y
+        assert (buf[off + w * 4:off + stride] == 0xA5).all()
+    assert np.array_equal(filt, want_f)
+    # optimize_with_stride: the same frame with 12 bytes of padding behind every row (row_filters = NULL mode)
+    want_n, _ = U.run_port(a, 19, 2, filters=False)
+    stride2 = w * 4 + 12
+    buf2 = np.full(h * stride2, 0x5A, np.uint8)
+    for y in range(h):
+        buf2[y * stride2:y * stride2 + w * 4] = a[y].reshape(-1)
+    P.hip_lib().optimize_with_stride(buf2.ctypes.data_as(C.c_void_p), w, h, stride2, False, 19, 2)
+    for y in range(h):
+        assert np.array_equal(buf2[y * stride2:y * stride2 + w * 4].reshape(w, 4), want_n[y]), y
+        assert (buf2[y * stride2 + w * 4:(y + 1) * stride2] == 0x5A).all()
+
+
 def test_batch_histogram_matches_oracle(torch_cuda):
     torch = torch_cuda
     a = P.synth_rgba(150, 40, 2, 3)
