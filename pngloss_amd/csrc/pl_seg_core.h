@@ -671,7 +671,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 /* what the enumeration kernel's bodies really carve out for NT threads (seg_enum_body is the largest: tables, pixels, split table, hash table,
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
-#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + 64)
+#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + (16 + 4) * 64 * 2 + 64)   /* (+ T's spare rows: SEG_CBLK + 4 at SEG_CR_MAX) */
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 2 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
@@ -1051,7 +1051,12 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     seg_lds_u32 dn = idxb + 32;                                /* [ne] dense id inside every enumerated segment */
     seg_lds_u16 G = (seg_lds_u16)(dn + ((nseg + 1) & ~1u));    /* [nblk][stride] composed tables of the blocks */
     seg_lds_u16 T = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;   /* [ns][stride]: T[k] takes a dense id of segment s0+k to one of segment s0+k+1 */
-    seg_lds_u32 R = (seg_lds_u32)(T + (size_t)((ns + 1) & ~1u) * stride);    /* [ns][stride] (useR): exit state of segment s0+k under that id */
+    const uint32_t trows = ((nblk * SEG_CBLK > ns + 2u ? nblk * SEG_CBLK : ns + 2u) + 1u) & ~1u;   /* T's rows: whole blocks, and the row of the absorbing cell (below) */
+    seg_lds_u32 R = (seg_lds_u32)(T + (size_t)trows * stride);                /* [ns][stride] (useR): exit state of segment s0+k under that id */
+    /* At the usual stride the tables hold, instead of the next segment's id d', the INDEX of that id's entry in the next table, ((k + 1) << sh) + d':
+     * a step of the composition is then one load feeding the next load's address -- no compare, no select, no shift-and-add on the dependent
+     * path.  "No successor" is the index of a cell that contains itself (row ns + 1, which no segment owns). */
+    const uint32_t dummy = (ns + 1u) << SEG_CR_SH;
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SEG_AS_GLB uint16_t *maps = j.maps + ((size_t)f * nseg * 4 + c) * (size_t)P.nsp;     /* + sg * 4 * nsp */
@@ -1106,7 +1111,8 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
                     const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                    v[q] = valid ? v[q] : (uint32_t)SEG_INVALID;
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u);
+                    v[q] = pass ? (valid ? v[q] : (uint32_t)SEG_INVALID) : (valid ? ((k + 1u) << SEG_CR_SH) + v[q] : dummy);   /* (an id beyond the stride: the row is gathered again, widest stride) */
                     ps[q] = valid ? ps[q] : SEG_NOSTATE;
                     widest = dcv[q] > widest ? dcv[q] : widest;
                 }
@@ -1119,7 +1125,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                 }
             }
             if (widest > stride || ((eflags & 4) && total)) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], widest); }
+            if (pass == 0) { const uint32_t t = (ns << SEG_CR_SH) + (uint32_t)tid; if (t < (nblk * SEG_CBLK) << SEG_CR_SH && t != dummy) T[t] = (uint16_t)dummy; }   /* rows behind the last table: the walk's last block runs its full length */
             if (starter) {
+                T[dummy] = (uint16_t)dummy;
                 if (total == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[s0 * mstep32_ + idx_first];
                 idxb[29] = idx_first;
                 idxb[28] = dfirst;
@@ -1133,10 +1141,22 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
         stride = 1u << sh; useR = false;
     }
     if (prof) tc[1] = PLS_CLOCK();
+    const bool linked = sh == SEG_CR_SH;                        /* the tables hold indices (usual stride), not ids (widest stride) */
+    const uint32_t gdummy = nblk << SEG_CR_SH;                  /* G's absorbing cell: the row behind its last block */
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        if (linked && tid == 0) G[gdummy] = (uint16_t)gdummy;
         /* block b composes T[b*CBLK .. (b+1)*CBLK - 1]: the id in its first segment -> the id in the next block's first segment */
         for (uint32_t t = (uint32_t)tid; t + stride < (nblk << sh); t += SEG_CHAIN_THREADS) {
             const uint32_t b = t >> sh;
+            if (linked) {
+                uint32_t i = ((b * SEG_CBLK) << sh) + (t & (stride - 1));
+                PLS_UNROLL
+                for (int k = 0; k < SEG_CBLK; k++) i = (uint32_t)T[i];
+                /* what it leads to, as the index of THAT id's entry in the next block's composed table (or G's own absorbing cell): the walk
+                 * over the block heads is a chain of bare loads too */
+                G[t] = (uint16_t)(i == dummy ? gdummy : (((b + 1u) << sh) | (i & (stride - 1))));
+                continue;
+            }
             uint32_t d = t & (stride - 1);
             for (uint32_t k = b * SEG_CBLK; k < (b + 1) * SEG_CBLK; k++) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
             G[t] = (uint16_t)d;
@@ -1147,11 +1167,26 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         if ((uint32_t)tid < nblk) {
             /* thread b: the true id at the head of block b (across the composed tables), then through the block */
-            uint32_t d = idxb[28];
-            for (uint32_t b = 0; b < (uint32_t)tid; b++) d = d == SEG_INVALID ? d : (uint32_t)G[((size_t)b << sh) + d];
-            for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k < ne; k++) {
-                dn[k] = d;
-                if (k < ns) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
+            if (linked) {
+                /* every lane walks the heads of ALL blocks (the same chain of loads in every lane: no lane-dependent loop) and keeps its own */
+                uint32_t g = idxb[28] < stride ? idxb[28] : gdummy, gm = g;
+                for (uint32_t b = 0; b + 1 < nblk; b++) { g = (uint32_t)G[g]; gm = b + 1 == (uint32_t)tid ? g : gm; }
+                uint32_t i = gm == gdummy ? dummy : ((((uint32_t)tid * SEG_CBLK) << sh) | (gm & (stride - 1)));
+                uint32_t at[SEG_CBLK];
+                PLS_UNROLL
+                for (int q = 0; q < SEG_CBLK; q++) { at[q] = i; i = (uint32_t)T[i]; }      /* (rows behind table ns - 1 lead to the absorbing cell) */
+                PLS_UNROLL
+                for (int q = 0; q < SEG_CBLK; q++) {
+                    const uint32_t k = (uint32_t)tid * SEG_CBLK + (uint32_t)q;
+                    if (k < ne) dn[k] = at[q] == dummy ? (uint32_t)SEG_INVALID : (at[q] & (stride - 1));
+                }
+            } else {
+                uint32_t d = idxb[28];
+                for (uint32_t b = 0; b < (uint32_t)tid; b++) d = d == SEG_INVALID ? d : (uint32_t)G[((size_t)b << sh) + d];
+                for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k < ne; k++) {
+                    dn[k] = d;
+                    if (k < ns) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
+                }
             }
         }
     }
