@@ -7,7 +7,7 @@
  *   seg_k_ctl     5 x 4 candidate workgroups (each a quarter of a candidate's decision tables) + 1 image-wide + W/256 commit workgroups
  *   seg_k_enum    3 x nseg x 2 workgroups of 512 lanes (a channel pair x 256 chain states; 1024 lanes = 4 channels for large batches) for the
  *                 filters that look at the left pixel, 2 x nseg/8 for none / up, 5 first-segment walkers; tables + pixel records in LDS
- *   seg_k_chain   5 x 4 workgroups, a row's dense transition tables and exit states in LDS (up to 132 KB of the CU's 160 KB)
+ *   seg_k_chain   5 x 4 workgroups, a row's dense transition tables (linked: an entry is the index of the next table's entry) and exit states in LDS (up to 149 KB of the CU's 160 KB)
  *   seg_k_replay  5 x ngrp workgroups: lane = (segment, quarter, channel), 8 steps each from the enumeration's checkpoints
  *   seg_k_post    5 x 2 ngrp workgroups of 1024 lanes: exact validation of every decision + the row cost sums
  *
