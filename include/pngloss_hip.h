@@ -243,6 +243,7 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
  *   info[2]  validation restarts (engine 3) / pixels redone exactly (engine 0)
  *   info[3]  rows finished serially (engine 3) / rows on the round-1 chains by the adaptive choice (engine 0)
  *   info[4]  rows in which candidate none was ruled out by its cost bound (engine 3)
+ *   info[5]  segments the chain kernel walked step by step because their entry state was in no enumerated set (engine 3)
  * No reference equivalent. */
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8]);
 

@@ -135,7 +135,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) {
         const PlJob &pj = ctx->h_jobs[i];
-        const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1, (uint32_t)params.nsp);
+        const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1, (uint32_t)params.nsp, params.seeded != 0);
         char *base = ctx->d_ws + seg_offs[i];
         SegJob &s = sj[i];
         s.img = pj.img; s.row_filters = pj.row_filters; s.row_ids = pj.row_ids; s.W = pj.width; s.H = pj.height; s.bpp = 0;
@@ -145,7 +145,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
         s.done_counter = static_cast<uint32_t *>(d_words); s.attempt_word = i == 0 ? static_cast<uint32_t *>(d_words) + 1 : nullptr;
         s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
         s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
-        s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps);
+        s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps); s.ehash = reinterpret_cast<uint32_t *>(base + l.ehash);
         s.rout = reinterpret_cast<uint16_t *>(base + l.rout); s.rst = reinterpret_cast<uint32_t *>(base + l.rst); s.rck = reinterpret_cast<uint32_t *>(base + l.rck); s.dnout = reinterpret_cast<uint16_t *>(base + l.dnout); s.dcnt = reinterpret_cast<uint32_t *>(base + l.dcnt);
         s.entry = reinterpret_cast<uint32_t *>(base + l.entry); s.segcnt = reinterpret_cast<uint16_t *>(base + l.segcnt);
         s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt);
@@ -163,6 +163,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     PL_CHECK(hipStreamSynchronize(stream));          /* sj / params are stack and vector memory */
     b.d_sj = d_sj; b.d_params = d_params; b.n = n;
     b.small_ok = params.small_ok != 0;
+    b.seeded = params.seeded != 0;
     b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
     if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
@@ -256,7 +257,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     if (use_seg) {
         seg_jobs_off = total; total += align_up(sizeof(SegJob) * n, 256);
         seg_params_off = total; total += align_up(sizeof(SegParams), 256);
-        for (size_t i = 0; i < n; i++) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1, (uint32_t)seg_params.nsp).total; }
+        for (size_t i = 0; i < n; i++) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1, (uint32_t)seg_params.nsp, seg_params.seeded != 0).total; }
     }
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
@@ -355,8 +356,8 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4] };
         if (r[20] == 3) {
             if (std::getenv("PNGLOSS_HIP_DEBUG"))
-                std::fprintf(stderr, "pngloss_hip: image %zu: segment-parallel engine: %d attempts for %u rows, %d epochs (validation restarts), %d rows finished serially, candidate none dropped by its cost bound %d times, engine %.3f ms\n",
-                             i, r[5], ctx->h_jobs[i].height, r[4], r[6], r[7], ctx->engine_ms);
+                std::fprintf(stderr, "pngloss_hip: image %zu: segment-parallel engine: %d attempts for %u rows, %d epochs (validation restarts), %d rows finished serially, candidate none dropped by its cost bound %d times, %d segments walked step by step by the chain kernel, engine %.3f ms\n",
+                             i, r[5], ctx->h_jobs[i].height, r[4], r[6], r[7], r[17], ctx->engine_ms);
             if (std::getenv("PNGLOSS_HIP_SEGPROF"))
                 std::fprintf(stderr, "pngloss_hip:   validation kernel, slowest workgroup per phase (us): load %.1f  pass1 %.1f  watched bins + pass3 %.1f  none bound %.1f  sums %.1f; pending decisions %d, largest reach %d\n",
                              r[40] / 100.0, r[41] / 100.0, r[42] / 100.0, r[43] / 100.0, r[44] / 100.0, r[46], r[47]);
@@ -1061,7 +1062,7 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
     int32_t r[64] = { 0 };
     PL_CHECK(hipMemcpy(r, ctx->h_jobs[index].result, sizeof r, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) info[i] = 0;
-    if (r[20] == 3) { info[0] = 3; info[1] = r[5]; info[2] = r[4]; info[3] = r[6]; info[4] = r[7]; }
+    if (r[20] == 3) { info[0] = 3; info[1] = r[5]; info[2] = r[4]; info[3] = r[6]; info[4] = r[7]; info[5] = r[17]; }
     else { info[0] = 0; info[1] = r[5]; info[2] = r[4]; info[3] = r[21]; }
     return PNGLOSS_SUCCESS;
 }

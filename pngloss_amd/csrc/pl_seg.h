@@ -8,8 +8,8 @@
 #include "pl_seg_core.h"
 
 /* per-image device workspace of the engine, beyond what PlJob already has (offsets into one 256-B aligned carve) */
-struct PlSegLayout { size_t ctl, base, h0, acc, tables, maps, rout, rst, rck, dnout, dcnt, entry, segcnt, grpcnt, firstidx, rowmm, total; uint32_t nseg, ngrp; };
-PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp);   /* nsp: SegParams::nsp of the (strength, bleed) pair */
+struct PlSegLayout { size_t ctl, base, h0, acc, tables, maps, ehash, rout, rst, rck, dnout, dcnt, entry, segcnt, grpcnt, firstidx, rowmm, total; uint32_t nseg, ngrp; };
+PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded);   /* nsp, seeded: SegParams::nsp / ::seeded of the (strength, bleed) pair */
 
 /* can the engine take this batch?  (chain states of (strength, bleed) fit the lanes, every row fits the chain kernel) */
 bool pl_seg_supported(const uint32_t *widths, size_t n, unsigned strength, long bleed, SegParams *params_out);
@@ -21,6 +21,7 @@ struct PlSegBatch {
     uint32_t max_nseg, max_ngrp, max_ncommit;
     uint32_t enum_nt;         /* threads of the enumeration's workgroups: 512 or 1024 (SEG_ENUM_NT_SMALL_MAX_NSEG) */
     bool small_ok;            /* SegParams::small_ok (none / up enumerated with their own small state set) */
+    bool seeded;              /* SegParams::seeded (seg_k_enum_seeded) */
 };
 
 /* fills sj[i].bpp from the class the prepare kernels detected */

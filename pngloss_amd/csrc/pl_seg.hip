@@ -61,6 +61,23 @@ __global__ __launch_bounds__(NT) void seg_k_enum(const SegJob *__restrict__ sj, 
     }
 }
 
+/* seeded state sets (SegParams::seeded): every filter through seg_enum_seeded_body, one workgroup per (filter, segment, channel group); the
+ * last five walk the epoch's first segment */
+template <int NT>
+__global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_nseg)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    constexpr unsigned halves = 4 / (NT / SEG_NSP);
+    if (blockIdx.x < SEG_NFILT * max_nseg * halves) {
+        const unsigned f = blockIdx.x / (max_nseg * halves), r = blockIdx.x % (max_nseg * halves), seg = r / halves, chalf = r % halves;
+        if (seg >= j.nseg) return;
+        seg_enum_seeded_body<NT>(j, *P, par, (int)f, (int)seg, (int)chalf, seg_smem);
+    } else {
+        seg_first_body<NT>(j, *P, par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves), seg_smem);
+    }
+}
+
 __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
@@ -105,7 +122,7 @@ hipError_t chain_attr()
 
 } // namespace
 
-PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp)
+PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded)
 {
     PlSegLayout l{};
     l.nseg = (width + SEG_L - 1) / SEG_L;
@@ -117,7 +134,8 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp)
     l.h0 = take(2 * 256 * 4);
     l.acc = take(2 * sizeof(SegAcc));
     l.tables = take((size_t)SEG_NFILT * SEG_TBL_WORDS * 4);
-    l.maps = take((size_t)SEG_NFILT * l.nseg * 4 * nsp * 2);
+    l.maps = take(seeded ? 0 : (size_t)SEG_NFILT * l.nseg * 4 * nsp * 2);
+    l.ehash = take(seeded ? (size_t)SEG_NFILT * l.nseg * 4 * SEG_EH_WORDS * 4 : 0);
     l.rout = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 2);
     l.rst = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * 4);
     l.rck = take((size_t)SEG_NFILT * l.nseg * 4 * SEG_NSP * (SEG_PARTS - 1) * 4);
@@ -167,6 +185,11 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
         static const bool enum_lds_bound = getenv("PNGLOSS_HIP_ENUM_LDS") != nullptr;   /* experiment: the generous bound (3 workgroups of 512 per CU) */
         const size_t enum_lds = enum_lds_bound ? (size_t)SEG_SM_ENUM : (size_t)SEG_SM_ENUM_NT(nt);
+        if (b.seeded) {
+            const unsigned sblocks = SEG_NFILT * b.max_nseg * halves + SEG_NFILT;
+            if (nt == 512) hipLaunchKernelGGL(seg_k_enum_seeded<512>, dim3(sblocks, n), dim3(512), (size_t)SEG_SM_ENUM_SEEDED(512), stream, b.d_sj, b.d_params, par, b.max_nseg);
+            else hipLaunchKernelGGL(seg_k_enum_seeded<1024>, dim3(sblocks, n), dim3(1024), (size_t)SEG_SM_ENUM_SEEDED(1024), stream, b.d_sj, b.d_params, par, b.max_nseg);
+        } else
         if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
         else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
     }

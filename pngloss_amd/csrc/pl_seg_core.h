@@ -123,6 +123,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_DEBUG_ROW
 #define SEG_DEBUG_ROW(kind, failed, winner, start_none)
 #endif
+#ifndef SEG_DEBUG_REPAIR
+#define SEG_DEBUG_REPAIR(f, c, sg, est, sid)
+#endif
 #ifndef SEG_DEBUG_COUNT
 #define SEG_DEBUG_COUNT(slot, v)   /* (the CPU harness counts a few things the tests pin) */
 #endif
@@ -138,8 +141,8 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_PL (SEG_L / SEG_PARTS)
 #define SEG_NSP 256              /* lanes per channel in the enumeration; also the most DISTINCT states a segment may have after the dedupe */
 #define SEG_NS_MAX 1024          /* most chain states of a (strength, bleed) pair the engine takes (enumerated in chunks of SEG_NSP) */
-#define SEG_TOFF 320             /* decision tables cover v in [-320, 319] */
-#define SEG_TN 640
+#define SEG_TOFF 384             /* decision tables cover v in [-384, 383]: every v a clamped band can hold (the re-centred prediction lies in orig - 127 .. orig + 128, so lo >= -383, hi <= 382) */
+#define SEG_TN 768
 #define SEG_TBL_WORDS (4 * SEG_TN + 128)  /* pre[2], suf[2], cls[2][256 bytes] */
 #define SEG_INVALID 0xFFFFu
 #define SEG_NOFAIL 0xFFFFFFFFu
@@ -159,6 +162,16 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
  * n = 8: 116.3 / 115.1, n = 32: 328.5 / 315.1): the launcher picks 512 while all images' segments together are at most this many. */
 #define SEG_ENUM_NT_SMALL_MAX_NSEG 320
 #define SEG_KEYS_MAX 2048
+/* SEEDED enumeration (state sets beyond SEG_NS_MAX: s = 85 at bleed 1 has ~10^5 chain states): a segment is not run from every state there is
+ * but from SEG_NSP seeds per channel, started SEG_KIN pixels IN FRONT of the segment -- every possible left byte with the carried terms that go with
+ * it (filters that look at the left pixel), a grid of carried terms (none, up) -- and whatever they have become at the segment's first pixel is
+ * the segment's entry set (measured: oracle/seed_study.c -- the reference's own state is in that set in all but 1e-4 .. 1e-3 of the boundaries; the
+ * chain kernel walks such a segment step by step).  Entry states are found by value, through a small hash table per segment and channel. */
+#define SEG_KIN 32                /* run-in pixels of the seeded enumeration */
+#define SEG_EH 512                /* slots of a segment's entry hash (per channel); a key lives in the SEG_EHW slots from its bucket's first */
+#define SEG_EHW 8
+#define SEG_EH_WORDS (SEG_EH + SEG_EHW - 4)
+#define SEG_EH_EMPTY 0xFFFFFFFFu
 
 /* what a row attempt decided (seg_ctl_body) */
 enum { SEG_K_INIT = 0, SEG_K_RESTART, SEG_K_RETRY, SEG_K_COMMIT, SEG_K_ABORT, SEG_K_FINISHED };
@@ -181,6 +194,11 @@ struct SegParams {
     uint32_t idx0_big, idx0_small; /* entry index of the state a fresh row starts with (nothing carried, boundary record all zero) */
     uint32_t st_small[SEG_NSS];    /* state i -> (cn+128) | (th+128) << 8 */
     uint16_t keylut_small[SEG_KEYS_MAX];   /* (cn+cmax) * (2tmax+1) + th+tmax -> state or SEG_INVALID */
+    /* seeded enumeration (more chain states than SEG_NS_MAX) */
+    int32_t seeded;                /* 1: segments are enumerated from seeds with a run-in (seg_enum_seeded_body), entry states are looked up by value */
+    int32_t kin;                   /* run-in pixels */
+    int32_t nseed_small;           /* seeds of none / up */
+    uint32_t seed_small[SEG_NSP];  /* (cn+128) | (th+128) << 8 */
 };
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
@@ -246,6 +264,7 @@ struct SegJob {
     SEG_AS_GLB SegAcc *acc;              /* [2] */
     SEG_AS_GLB uint32_t *tables;         /* [5][SEG_TBL_WORDS] */
     SEG_AS_GLB uint16_t *maps;           /* [5][nseg][4][nsp]: entry index of a segment -> dense id of its state after the dedupe (0xffff: none) */
+    SEG_AS_GLB uint32_t *ehash;          /* (seeded) [5][nseg][4][SEG_EH_WORDS]: entry hash of a segment: key << 8 | dense id of the entry state, or SEG_EH_EMPTY */
     SEG_AS_GLB uint16_t *rout;           /* [5][nseg][4][SEG_NSP]: dense id -> exit index of the segment (0xffff: left what the tables cover) */
     SEG_AS_GLB uint32_t *rst;            /* [5][nseg][4][SEG_NSP]: dense id -> exit state of the segment, packed (0xffffffff: none) */
     SEG_AS_GLB uint32_t *rck;            /* [5][nseg][4][SEG_NSP][SEG_PARTS-1]: dense id -> state in front of part 1, 2, .. of the segment (0xffffffff: none) */
@@ -356,7 +375,7 @@ PLS_HD SegGeo seg_geo(int s)
 {
     SegGeo g; g.s = s; g.q = s + 1;
     union { float f; uint32_t u; } r; r.f = 1.0f / (float)(s + 1); r.u += 2u; g.rq = r.f;
-    g.fmax = ((SEG_TOFF - 1 - s) / (s + 1)) * (s + 1) + s;      /* largest |filt| whose band lies inside the tables */
+    g.fmax = 1 << 20;                                           /* (the tables cover every clamped band whatever filt is; a band that misses lo..hi altogether needs no lookup) */
     return g;
 }
 PLS_HD int seg_div_q(int a, const SegGeo &g)
@@ -470,7 +489,7 @@ PLS_HD uint32_t seg_step_scan(int f, const SegPix &p, SegState &st, const uint32
 /* ---- decision tables of one candidate filter (enumeration only) --------------------------------------------------------------
  * pre[sgn][v + SEG_TOFF] = leader of [bandlo(v), v], suf[sgn][v + SEG_TOFF] = leader of [v, bandhi(v)] in the band system of that
  * sign (sgn 0: filt >= 0, bands [tq, tq+s]; sgn 1: filt < 0, bands [-tq-s, -tq]); leader = arg-max of (H, rank, -v).
- * entry = (L + 512) | cls[L & 255] << 16, cls = dense class of (H, rank): equal class <=> equal (H, rank), which is what decides
+ * entry = (L + 1024) | cls[L & 255] << 16, cls = dense class of (H, rank): equal class <=> equal (H, rank), which is what decides
  * whether the original symbol takes the place of the leader (optimize_state.c:236-243).  Layout: pre[0] pre[1] suf[0] suf[1] cls. */
 /* shared-memory pointers: naming the address space makes every access a ds_* instruction on the device (a generic pointer that
  * the compiler cannot trace back to LDS becomes a FLAT access: slower, and it ties LDS waits to outstanding global stores) */
@@ -535,7 +554,7 @@ PLS_HD uint32_t seg_step_fast(const SegPix &p, SegState &st, int &bad, seg_lds_c
     key = seg_min(seg_max(key, -SEG_TOFF), SEG_TOFF - 1);
     const uint32_t e = tw[(usesuf ? 2 * SEG_TN : 0) + neg * SEG_TN + key + SEG_TOFF];
     const uint32_t c_os = (uint32_t)cls[neg * 256 + (osym & 255)];
-    const int L = (int)(e & 0xffffu) - 512;
+    const int L = (int)(e & 0xffffu) - 1024;
     const bool tie = osym >= v0 && osym <= v1 && c_os == ((e >> 16) & 255u);
     int v = tie ? osym : L;
     v = degen ? vd : v;
@@ -591,28 +610,49 @@ PLS_HD uint32_t seg_small_encode(const SegParams &P, const SegState &st)
 PLS_HD bool seg_any_decode(const SegParams &P, int f, int i, const SegPix &b, SegState &st) { return seg_is_small(P, f) ? seg_small_decode(P, i, st) : seg_state_decode(P, i, b, st); }
 PLS_HD uint32_t seg_any_encode(const SegParams &P, int f, const SegPix &b, const SegState &st) { return seg_is_small(P, f) ? seg_small_encode(P, st) : seg_state_encode(P, b, st); }
 
-/* ---- host: the constants of a (strength, bleed) pair.  false: more states than the enumeration has lanes ------------------ */
-inline bool seg_build_params(SegParams &P, int strength, int bleed)
+/* seeded enumeration: entry states are found BY VALUE.  Key of a chain state: left | (cn + 128) << 8 | (th + 128) << 16 (24 bits; ~0: the state
+ * has none); a key lives in one of the SEG_EHW slots from the first slot of its bucket (128 buckets of 4 slots, windows overlap), so a lookup
+ * is two aligned 16-byte loads.  Slot word in device memory: key << 8 | dense id. */
+#define SEG_NOKEY 0xFFFFFFFFu
+PLS_HD uint32_t seg_eh_key(int left, int cn, int th)
 {
-    memset(&P, 0, sizeof P);
-    P.strength = strength; P.bleed = bleed;
-    for (int d = -256; d <= 255; d++) {
-        const SegSplit s = seg_split_slow(d, bleed);
-        P.lut_a[d + 256] = ((uint32_t)s.rem & 0xffffu) | ((uint32_t)s.h << 16);
-        P.lut_b[d + 256] = ((uint32_t)s.t & 255u) | (((uint32_t)s.f & 255u) << 8) | (((uint32_t)s.v & 255u) << 16) | ((uint32_t)s.h << 24);
-    }
-    {
-        int rm_ = 0, tm_ = 0;
-        for (int D = 0; D < 256; D++) {
-            const SegSplit a = seg_split_slow(D, bleed), b = seg_split_slow(-D, bleed);
-            rm_ = seg_max(rm_, seg_max(seg_abs(a.rem), seg_abs(b.rem))); tm_ = seg_max(tm_, seg_max(seg_abs(a.h), seg_abs(b.h)));
-            P.rt_max[D] = (uint8_t)seg_min(255, rm_ + tm_);
-        }
-    }
+    if (cn < -128 || cn > 126 || th < -128 || th > 126) return SEG_NOKEY;
+    return (uint32_t)(left & 255) | ((uint32_t)(cn + 128) << 8) | ((uint32_t)(th + 128) << 16);
+}
+PLS_HD uint32_t seg_eh_key_of_packed(uint32_t ps)
+{
+    if (ps == 0xFFFFFFFFu) return SEG_NOKEY;
+    const SegState st = seg_state_unpack(ps);
+    return seg_eh_key(st.left, st.cn, st.th);
+}
+PLS_HD SegState seg_eh_state(uint32_t key) { SegState st; st.left = (int)(key & 255u); st.cn = (int)((key >> 8) & 255u) - 128; st.th = (int)((key >> 16) & 255u) - 128; return st; }
+PLS_HD uint32_t seg_eh_base(uint32_t key) { return ((key * 0x9E3779B1u) >> 25) * 4u; }
+/* dense id of the state with this key among the window's eight slot words, or SEG_INVALID */
+PLS_HD uint32_t seg_eh_match(uint32_t key, const SegVec16 &a, const SegVec16 &b)
+{
+    uint32_t id = SEG_INVALID;
+    if (key == SEG_NOKEY) return id;
+    id = (a.a >> 8) == key ? (a.a & 255u) : id; id = (a.b >> 8) == key ? (a.b & 255u) : id; id = (a.c >> 8) == key ? (a.c & 255u) : id; id = (a.d >> 8) == key ? (a.d & 255u) : id;
+    id = (b.a >> 8) == key ? (b.a & 255u) : id; id = (b.b >> 8) == key ? (b.b & 255u) : id; id = (b.c >> 8) == key ? (b.c & 255u) : id; id = (b.d >> 8) == key ? (b.d & 255u) : id;
+    return id;
+}
+/* (one lookup on its own: the chain's repair path, the host harness) eh: the table of one segment and channel */
+PLS_HD uint32_t seg_eh_lookup(const SEG_AS_GLB uint32_t *eh, uint32_t key)
+{
+    if (key == SEG_NOKEY) return SEG_INVALID;
+    const uint32_t base = seg_eh_base(key);
+    uint32_t id = SEG_INVALID;
+    for (int q = 0; q < SEG_EHW; q++) { const uint32_t w = eh[base + q]; if (w != SEG_EH_EMPTY && (w >> 8) == key) id = w & 255u; }
+    return id;
+}
+
+/* ---- host: the constants of a (strength, bleed) pair ------------------------------------------------------------------------
+ * seg_build_exhaustive: the whole chain-state set (delta, cn, th), when it has at most SEG_NS_MAX members (false otherwise);
+ * seg_build_params: that, or -- for larger sets, or when force_seeded asks for it (tests) -- the constants of the seeded enumeration. */
+inline bool seg_build_exhaustive(SegParams &P, int strength, int bleed)
+{
     if (strength > 127) return false;
-    int rmax = 0, tmax = 0;
-    for (int d = -strength; d <= strength; d++) { const SegSplit s = seg_split_slow(d, bleed); if (seg_abs(s.rem) > rmax) rmax = seg_abs(s.rem); if (seg_abs(s.h) > tmax) tmax = seg_abs(s.h); }
-    P.cmax = rmax + tmax; P.tmax = tmax; P.dmax = strength + P.cmax;
+    const int tmax = P.tmax;
     if (P.dmax > 127 || P.cmax > 127) return false;
     P.keyn = (2 * P.dmax + 1) * (2 * P.cmax + 1) * (2 * P.tmax + 1);
     if (P.keyn > SEG_KEYLUT_MAX) return false;
@@ -660,6 +700,41 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
     }
     return true;
 }
+inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_seeded = false)
+{
+    memset(&P, 0, sizeof P);
+    if (strength < 0 || strength > 255 || bleed < 1 || bleed > 32767) return false;
+    P.strength = strength; P.bleed = bleed;
+    for (int d = -256; d <= 255; d++) {
+        const SegSplit s = seg_split_slow(d, bleed);
+        P.lut_a[d + 256] = ((uint32_t)s.rem & 0xffffu) | ((uint32_t)s.h << 16);
+        P.lut_b[d + 256] = ((uint32_t)s.t & 255u) | (((uint32_t)s.f & 255u) << 8) | (((uint32_t)s.v & 255u) << 16) | ((uint32_t)s.h << 24);
+    }
+    {
+        int rm_ = 0, tm_ = 0;
+        for (int D = 0; D < 256; D++) {
+            const SegSplit a = seg_split_slow(D, bleed), b = seg_split_slow(-D, bleed);
+            rm_ = seg_max(rm_, seg_max(seg_abs(a.rem), seg_abs(b.rem))); tm_ = seg_max(tm_, seg_max(seg_abs(a.h), seg_abs(b.h)));
+            P.rt_max[D] = (uint8_t)seg_min(255, rm_ + tm_);
+        }
+    }
+    int rmax = 0, tmax = 0;
+    for (int d = -strength; d <= strength; d++) { const SegSplit s = seg_split_slow(d, bleed); if (seg_abs(s.rem) > rmax) rmax = seg_abs(s.rem); if (seg_abs(s.h) > tmax) tmax = seg_abs(s.h); }
+    P.cmax = rmax + tmax; P.tmax = tmax; P.dmax = strength + P.cmax;
+    if (!force_seeded && seg_build_exhaustive(P, strength, bleed)) return true;
+    /* seeded: the filters that look at the left pixel take their seeds from the data (seg_enum_seeded_body); none / up, whose state is
+     * (cn, th): every cn, and th on the finest grid that keeps the set within the lanes */
+    P.seeded = 1; P.kin = SEG_KIN;
+    P.ns = 0; P.nsp = 64; P.keyn = 0; P.ns_small = 0; P.small_ok = 0; P.idx0_big = P.idx0_small = (uint32_t)SEG_INVALID;
+    if (P.cmax > 127 || tmax > 127 || 2 * P.cmax + 1 > SEG_NSP) return false;     /* (s = 255 at bleed 1: cmax 66, tmax 24) */
+    int tstep = 1;
+    while ((2 * P.cmax + 1) * (2 * (tmax / tstep) + 1) > SEG_NSP) tstep++;
+    int n = 0;
+    for (int cn = -P.cmax; cn <= P.cmax; cn++)
+        for (int th = -(tmax / tstep) * tstep; th <= tmax; th += tstep) P.seed_small[n++] = (uint32_t)(cn + 128) | ((uint32_t)(th + 128) << 8);
+    P.nseed_small = n;
+    return true;
+}
 
 /* =========================================================================================================================
  * Kernel bodies.  smem: the workgroup's shared memory (device: dynamic LDS; host harness: a scratch buffer).
@@ -671,7 +746,6 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed)
 /* what the enumeration kernel's bodies really carve out for NT threads (seg_enum_body is the largest: tables, pixels, split table, hash table,
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
-#define SEG_SM_CHAIN(nseg) ((size_t)(nseg) * SEG_NSP * 2 + 4096 + ((size_t)(nseg) + 2) * 24 + 128 + ((SEG_MAX_NSEG / 16) + 1) * SEG_NSP * 2 + (16 + 4) * 64 * 2 + 64)   /* (+ T's spare rows: SEG_CBLK + 4 at SEG_CR_MAX) */
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
 #define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 2 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
@@ -857,6 +931,155 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     }
 }
 
+/* ---- ENUMERATE, SEEDED (state sets beyond SEG_NS_MAX; every filter): task (f, seg), NT lanes = NT / SEG_NSP channels x SEG_NSP seeds ----
+ * The seeds start SEG_KIN pixels in front of the segment (at pixel 0, where the state is known, when the row begins within that reach): a
+ * filter that looks at the left pixel gets every left byte within reach of the data, each with the carried terms that go with it when nothing
+ * was carried INTO the boundary pixel; none / up get a grid of carried terms (SegParams::seed_small).  What the seeds have become at the
+ * segment's first pixel -- a few dozen distinct states: the carried terms contract, the left bytes fall into the phases of the band system --
+ * is the segment's ENTRY SET: hashed by value (exported: the chain kernel looks the exit states of the segment in front up in it), given dense
+ * ids, and run through the segment like the distinct states of seg_enum_body.  A state of the reference's own path that is in no entry set
+ * (1e-4 .. 1e-3 of the boundaries, oracle/seed_study.c) costs time, not correctness: the chain kernel walks that segment step by step. */
+#define SEG_SM_ENUM_SEEDED(nt) (SEG_TBL_WORDS * 4 + (SEG_KIN + SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_EH_WORDS * 4 + 4 * SEG_EH_WORDS * 2 + 4 * SEG_NSP * 4 + (nt) * 4 + 128)
+template <int NT>
+PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, int f, int seg, int chalf, unsigned char *smem)
+{
+    const SegCtl &ctl = j.ctl[par];
+    const SegCtlView cv = seg_ctl_view(ctl, f);
+    if (cv.finished || cv.active != 1) return;
+    const uint32_t W = j.W, bpp = j.bpp;
+    constexpr int NCH = NT / SEG_NSP;
+    const int c0 = chalf * NCH;
+    if ((uint32_t)c0 >= bpp) return;
+    const uint32_t x0 = (uint32_t)seg * SEG_L;
+    if (x0 >= W) return;
+    if (cv.start_x && x0 <= cv.start_x) return;               /* (the epoch's first, partial segment is walked: seg_first_body) */
+    const uint32_t kin = (uint32_t)P.kin;
+    const uint32_t xs = x0 >= kin ? x0 - kin : 0u;            /* first pixel of the run-in */
+    const int nrun = (int)(x0 - xs);
+    uint32_t *tw = (uint32_t *)smem;
+    SegPix *px = (SegPix *)(smem + SEG_TBL_WORDS * 4);        /* [(SEG_KIN + SEG_L + 1)][4]: slot 0 = boundary pixel xs-1 */
+    uint32_t *lut = (uint32_t *)(px + (SEG_KIN + SEG_L + 1) * 4);
+    uint32_t *trflag = lut + 512;                             /* [0] some pixel of the window is fully transparent, [1..4] distinct entry states per channel */
+    uint32_t *ht = trflag + 8;                                /* [4][SEG_EH_WORDS] key or ~0 */
+    uint16_t *dense = (uint16_t *)(ht + 4 * SEG_EH_WORDS);    /* [4][SEG_EH_WORDS] slot -> dense id */
+    uint32_t *uniq = (uint32_t *)(dense + 4 * SEG_EH_WORDS);  /* [4][SEG_NSP] the entry states (keys) by dense id */
+    uint32_t *keys = uniq + 4 * SEG_NSP;                      /* [NT] */
+    const uint32_t y = cv.y;
+    const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SegGeo G = seg_geo((int)cv.s);
+    const bool prof = (P.engine_flags & 1) != 0;
+    unsigned long long te[5] = { 0, 0, 0, 0, 0 };
+    if (prof) te[0] = PLS_CLOCK();
+    PLS_THREADS(tid, NT) {
+        if (tid < 8) trflag[tid] = 0u;
+        for (int i = tid; i < 4 * SEG_EH_WORDS; i += NT) ht[i] = SEG_NOKEY;
+    }
+    PLS_SYNC();
+    const int npx = nrun + SEG_L + 1;
+    PLS_THREADS(tid, NT) {
+        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
+        uint32_t vt[NTW], vl = 0;
+        SegPixRaw vp = seg_pix_raw_zero();
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (tid < 512) vl = P.lut_a[tid];
+        if (tid < npx) vp = seg_pix_fetch(row, nab, j.err0, xs - 1 + (uint32_t)tid, W);      /* (xs = 0: slot 0 lies in front of the row -- zeros) */
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        if (tid < 512) lut[tid] = vl;
+        if (tid < npx) {
+            seg_pix_split4(px + tid * 4, vp, bpp, xs - 1 + (uint32_t)tid, W);
+            if ((bpp & 1u) == 0u && (px[tid * 4 + (bpp - 1u)].w >> 24)) PLS_ATOMIC_OR(trflag, 1u);
+        }
+    }
+    PLS_SYNC();
+    const bool trx = trflag[0] != 0u;
+    if (prof) te[1] = PLS_CLOCK();
+    /* -- the seeds, through the run-in -- */
+    PLS_THREADS(tid, NT) {
+        const int lc = tid / SEG_NSP, c = c0 + lc, i = tid % SEG_NSP;
+        uint32_t key = SEG_NOKEY;
+        if ((uint32_t)c < bpp) {
+            SegState st = { 0, 0, 0 };
+            bool ok;
+            if (xs == 0u) ok = i == 0;                                               /* the row's own start */
+            else if (f == 0 || f == 2) {
+                ok = i < P.nseed_small;
+                const uint32_t w = P.seed_small[ok ? i : 0];
+                st.cn = (int)(w & 255u) - 128; st.th = (int)((w >> 8) & 255u) - 128;
+            } else {
+                const SegPix b = px[c];
+                if (b.w >> 24) { ok = i <= 2 * P.tmax; st.cn = i - P.tmax; }         /* a forced transparent alpha in front: byte 0, difference 0 */
+                else {
+                    const int D = (int)(b.w & 255u) + b.e0 - i;                     /* the boundary pixel's difference if nothing was carried into it */
+                    ok = D >= -P.dmax && D <= P.dmax;
+                    int rem = 0, thr = 0;
+                    seg_rem_thr(lut, P.bleed, ok ? D : 0, rem, thr);
+                    st.left = i; st.cn = rem; st.th = thr;
+                }
+            }
+            if (ok) {
+                const int bad = nrun ? seg_run_fast_f(f, trx, px + 4 + c, 4, nrun, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut)) : 0;
+                if (!bad) key = seg_eh_key(st.left, st.cn, st.th);
+            }
+        }
+        keys[tid] = key;
+    }
+    PLS_SYNC();
+    /* -- the entry set: distinct states, hashed by value (only the first lane of a run of equal neighbours inserts) -- */
+    PLS_THREADS(tid, NT) {
+        const int c = tid / SEG_NSP, i = tid % SEG_NSP;
+        const uint32_t key = keys[tid];
+        if (key != SEG_NOKEY && (i == 0 || keys[tid - 1] != key)) {
+            const uint32_t base = seg_eh_base(key);
+            for (int q = 0; q < SEG_EHW; q++) {
+                const uint32_t old = PLS_ATOMIC_CAS(&ht[c * SEG_EH_WORDS + base + q], SEG_NOKEY, key);
+                if (old == SEG_NOKEY) {
+                    const uint32_t d = PLS_ATOMIC_ADD_RET(&trflag[1 + c], 1u);
+                    dense[c * SEG_EH_WORDS + base + q] = (uint16_t)(d < SEG_NSP ? d : 0xffffu);
+                    if (d < SEG_NSP) uniq[c * SEG_NSP + d] = key;
+                    break;
+                }
+                if (old == key) break;
+            }                                                                    /* (a full window: the state gets no id) */
+        }
+    }
+    PLS_SYNC();
+    if (prof) te[2] = PLS_CLOCK();
+    PLS_THREADS(tid, NT) {
+        for (int i = tid; i < NCH * SEG_EH_WORDS; i += NT) {
+            const int lc = i / SEG_EH_WORDS;
+            if ((uint32_t)(c0 + lc) >= bpp) continue;
+            const uint32_t k = ht[i], d = dense[i];
+            j.ehash[(((size_t)f * j.nseg + seg) * 4 + c0) * SEG_EH_WORDS + i] = (k == SEG_NOKEY || d >= SEG_NSP) ? SEG_EH_EMPTY : ((k << 8) | d);
+        }
+    }
+    /* -- the segment itself from every entry state: dense id -> checkpoints, exit state -- */
+    PLS_THREADS(tid, NT) {
+        const int lc = (tid >> 6) % NCH, c = c0 + lc, i = (tid & 63) + 64 * (tid / (64 * NCH));
+        const uint32_t D = trflag[1 + lc] < SEG_NSP ? trflag[1 + lc] : SEG_NSP;
+        if ((uint32_t)c < bpp && (uint32_t)i < D) {
+            SegState st = seg_eh_state(uniq[lc * SEG_NSP + i]);
+            const size_t slot = (((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i;
+            const SegPix *ps = px + (nrun + 1) * 4 + c;
+            int bad = 0;
+            for (int part = 0; part < SEG_PARTS; part++) {
+                if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                bad |= seg_run_fast_f(f, trx, ps + part * SEG_PL * 4, 4, SEG_PL, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            }
+            j.rout[slot] = (uint16_t)0;
+            j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+        }
+        if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
+        if (prof && tid == 0) {
+            te[3] = PLS_CLOCK(); te[4] = te[3];
+            for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
+            PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
+            PLS_ATOMIC_ADD((uint32_t *)&j.result[33], trflag[1] + trflag[2] + trflag[3] + trflag[4]);
+        }
+    }
+}
+
 /* ---- ENUMERATE, none / up (state = (cn, th), SEG_NSS lanes per channel): task (f, SEG_SMALL_SEGS segments from seg0) -------- */
 template <int NT>
 PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
@@ -1014,18 +1237,35 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 }
 
 /* ---- CHAIN: task (f, c): compose the segments from the epoch's start state ----------------------------------------------
- * The enumeration left, per segment: entry index -> dense id of the state after the dedupe (maps), dense id -> exit index (rout) and
- * exit state (rst).  The exit index of segment k IS the entry index of segment k+1 (same reference pixel), so the chain only needs the
- * DENSE transition tables  T_k[d] = maps_{k+1}[rout_k[d]]  (dense id in segment k -> dense id in segment k+1): a few dozen entries per
- * segment whatever the number of chain states, gathered here in parallel.  Composed in blocks of SEG_CBLK segments (every block's
- * composed table for all ids in parallel, then every block walks from the row's start id across the composed tables to its own head
- * and through its segments): 16 + nblk + 16 dependent lookups instead of nseg.  The entry state of segment k+1 is the exit state
- * rst_k[d_k]: nothing to decode. */
+ * The enumeration left, per segment: a way from an entry STATE to its dense id (exhaustive sets: maps, by entry index -- the exit index of
+ * segment k IS the entry index of segment k+1; seeded sets: ehash, by value), dense id -> exit index (rout) and exit state (rst).  The chain
+ * only needs the DENSE transition tables  T_k[d] = id in segment k+1 of the exit of id d of segment k: a few dozen entries per segment
+ * whatever the number of chain states, gathered here in parallel.  Composed in blocks of SEG_CBLK segments (every block's composed table for
+ * all ids in parallel, then every block walks from the start id across the composed tables to its own head and through its segments):
+ * 16 + nblk + 16 dependent lookups instead of nseg.  The entry state of segment k+1 is the exit state rst_k[d_k]: nothing to decode.
+ *
+ * The tables hold, instead of the next segment's id d', the INDEX of that id's entry in the next table, ((k + 1) << sh) + d': a step of
+ * the composition is one load feeding the next load's address -- no compare, no select, no shift-and-add on the dependent path.  "No
+ * successor" is the index of a cell that contains itself (row ntr + 1, which no segment owns).
+ *
+ * A row is taken in PASSES of as many segments as the tables have rows at the stride in use (64 entries per segment for nearly every row of
+ * an exhaustive set: 17 distinct states per segment on average; 128 or 256 for seeded sets and the odd wide segment): rows of any width, and
+ * a pass can start anywhere -- which is how the rare segment whose entry state the enumeration did not cover is handled: the pass ends in
+ * front of it, ONE lane walks it step by step from its known entry state (table steps; exact), looks the exit up in the next segment's
+ * entry set, and the passes go on from there. */
 #define SEG_CBLK 16
 #define SEG_CR_SH 6
 #define SEG_CR_MAX (1 << SEG_CR_SH)                             /* the usual table stride; the exit states are staged in shared memory at this stride */
 #define SEG_NOSTATE 0xFFFFFFFFu
 #define SEG_CQ 8                                                /* gather items in flight per thread */
+#define SEG_CHAIN_CAP 256                                       /* most transitions of a pass (strides 64 and 128) */
+#define SEG_CHAIN_CAP8 224                                      /* ... at stride 256 */
+#define SEG_CHAIN_POS (SEG_CHAIN_CAP + 32)                      /* dn / entL entries */
+#define SEG_CHAIN_TROWS(n) (((n) < SEG_CHAIN_CAP8 ? (n) : SEG_CHAIN_CAP8) + SEG_CBLK + 2)
+#define SEG_CHAIN_TBYTES(n) ((size_t)SEG_CHAIN_TROWS(n) * 512)     /* T (and R behind it at the usual stride) for a row of n segments: the widest stride sets the size */
+#define SEG_CHAIN_GWORDS ((SEG_CHAIN_CAP / SEG_CBLK + 2) * 256 / 2)
+#define SEG_SM_CHAIN(nseg) ((1024 + 32 + 2 * SEG_CHAIN_POS + SEG_CHAIN_GWORDS) * 4 + SEG_CHAIN_TBYTES(nseg) + SEG_TBL_WORDS * 4 + (SEG_L + 1) * 8 + 64)
+PLS_HD uint32_t seg_chain_cap(uint32_t sh) { return sh >= 8 ? (uint32_t)SEG_CHAIN_CAP8 : (uint32_t)SEG_CHAIN_CAP; }
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -1038,223 +1278,252 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     SEG_AS_GLB uint16_t *dnout = j.dnout + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
     if (sx || nseg == 1) { PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) dnout[(size_t)first * 4] = (uint16_t)SEG_INVALID; } }   /* a walked first segment has no checkpoints */
     if (first + 1 >= nseg) return;
-    /* enumerated segments s0 .. nseg-1 (ne of them; a fresh row: from 0); ns = ne - 1 transitions, and as many entry states (of s0+1 .. nseg-1) */
+    /* enumerated segments s0 .. nseg-1 (ne of them; a fresh row: from 0) = POSITIONS 0 .. ns of the chain; ns = ne - 1 transitions */
     const uint32_t s0 = sx ? first + 1 : 0u, ne = nseg - s0, ns = ne - 1;
-    const uint32_t nblk = (ne + SEG_CBLK - 1) / SEG_CBLK;
-    /* table stride: SEG_CR_MAX entries per segment cover nearly every row (measured: 17 distinct states per segment on average);
-     * a row with a segment beyond that is gathered again at the widest stride */
-    uint32_t sh = SEG_CR_SH;
-    uint32_t stride = 1u << sh;
-    bool useR = true;
-    uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512;   /* (slow path only) */
-    seg_lds_u32 idxb = (seg_lds_u32)(Hf + 1024);               /* [32]: [27] most distinct states of a segment (only when [30]), [28] dense id the chain starts with, [29] its entry index, [30] some segment has more distinct states than the stride, [31] slow path needed */
-    seg_lds_u32 dn = idxb + 32;                                /* [ne] dense id inside every enumerated segment */
-    seg_lds_u16 G = (seg_lds_u16)(dn + ((nseg + 1) & ~1u));    /* [nblk][stride] composed tables of the blocks */
-    seg_lds_u16 T = G + (size_t)((SEG_MAX_NSEG / SEG_CBLK) + 1) * SEG_NSP;   /* [ns][stride]: T[k] takes a dense id of segment s0+k to one of segment s0+k+1 */
-    const uint32_t trows = ((nblk * SEG_CBLK > ns + 2u ? nblk * SEG_CBLK : ns + 2u) + 1u) & ~1u;   /* T's rows: whole blocks, and the row of the absorbing cell (below) */
-    seg_lds_u32 R = (seg_lds_u32)(T + (size_t)trows * stride);                /* [ns][stride] (useR): exit state of segment s0+k under that id */
-    /* At the usual stride the tables hold, instead of the next segment's id d', the INDEX of that id's entry in the next table, ((k + 1) << sh) + d':
-     * a step of the composition is then one load feeding the next load's address -- no compare, no select, no shift-and-add on the dependent
-     * path.  "No successor" is the index of a cell that contains itself (row ns + 1, which no segment owns). */
-    const uint32_t dummy = (ns + 1u) << SEG_CR_SH;
+    const bool seeded = P.seeded != 0;
+    seg_lds_u32 Hf = (seg_lds_u32)smem, rank = Hf + 256, lut = Hf + 512;   /* (repair only) */
+    seg_lds_u32 idxb = Hf + 1024;                               /* [32]: [24] repairs, [25] first position without an id, [26] entry state of the pass's first position, [27] most distinct states of a segment,
+                                                                   [28] dense id the pass starts with, [30] some segment has more distinct states than the stride, [31] repair tables loaded */
+    seg_lds_u32 dn = idxb + 32;                                /* [SEG_CHAIN_POS] dense id at every position of the pass */
+    seg_lds_u32 entL = dn + SEG_CHAIN_POS;                     /* [SEG_CHAIN_POS] entry state at every position of the pass (from 1; 0: idxb[26]) */
+    seg_lds_u16 G = (seg_lds_u16)(entL + SEG_CHAIN_POS);       /* [nblk + 1][stride] composed tables of the blocks */
+    seg_lds_u16 T = G + 2 * SEG_CHAIN_GWORDS;                  /* [rows][stride]: T[k] takes a dense id of position k to one of position k+1 */
+    seg_lds_u32 twr = (seg_lds_u32)((SEG_AS_LDS unsigned char *)T + SEG_CHAIN_TBYTES(nseg));   /* (repair only) the candidate's decision tables, then the walked segment's pixel records */
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SEG_AS_GLB uint16_t *maps = j.maps + ((size_t)f * nseg * 4 + c) * (size_t)P.nsp;     /* + sg * 4 * nsp */
+    const SEG_AS_GLB uint32_t *ehash = j.ehash + ((size_t)f * nseg * 4 + c) * SEG_EH_WORDS;    /* + sg * 4 * SEG_EH_WORDS */
     const SEG_AS_GLB uint16_t *rout = j.rout + ((size_t)f * nseg * 4 + c) * SEG_NSP;           /* + sg * 4 * SEG_NSP */
     const SEG_AS_GLB uint32_t *rst = j.rst + ((size_t)f * nseg * 4 + c) * SEG_NSP;
     const SEG_AS_GLB uint32_t *dcnt = j.dcnt + (size_t)f * nseg * 4 + c;                       /* + sg * 4 */
     SEG_AS_GLB uint32_t *entry = j.entry + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
-    const size_t mstep = 4 * (size_t)P.nsp, rstep = 4 * SEG_NSP;
+    const uint32_t mstep32 = 4u * (uint32_t)P.nsp, rstep32 = 4u * SEG_NSP, estep32 = 4u * SEG_EH_WORDS;
     const int nstates = P.ns;
-    const uint32_t eflags = (uint32_t)P.engine_flags, mstep32_ = (uint32_t)mstep;
+    const uint32_t eflags = (uint32_t)P.engine_flags;
     const SegState start0 = { 0, 0, 0 };
     const bool prof = (eflags & 1) != 0;
-    unsigned long long tc[5] = { 0, 0, 0, 0, 0 };
-    if (prof) tc[0] = PLS_CLOCK();
-    /* -- gather: T[k][d] = maps_{k+1}[rout_k[d]] and R[k][d] = the exit state itself (= entry state of segment k+1); per item three
-     *    loads in flight, then one dependent load; SEG_CQ items per thread at a time -- */
+    unsigned long long tacc[4] = { 0, 0, 0, 0 }, tc[5] = { 0, 0, 0, 0, 0 };
     PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid < 32) idxb[tid] = 0u; }
     PLS_SYNC();
-    for (int pass = 0; pass < 2; pass++) {
+    uint32_t sh = seeded ? SEG_CR_SH + 1 : SEG_CR_SH;
+    if (eflags & 4) sh++;                                       /* (test hook: a wider stride than needed) */
+    uint32_t a = 0;                                             /* first position of the pass */
+    bool first_iter = true;
+    uint32_t nwide = 0;
+    for (;;) {
+        const uint32_t ntr = seg_umin(seg_chain_cap(sh), ns - a);
+        if (ntr == 0) {
+            /* only the row's last segment is left (behind a repair): it has the id the repair looked up */
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { const uint32_t d = idxb[28]; dnout[(size_t)(s0 + a) * 4] = (uint16_t)(d < SEG_NSP ? d : SEG_INVALID); } }
+            break;
+        }
+        if (prof) tc[0] = PLS_CLOCK();
+        const uint32_t stride = 1u << sh, npos = ntr + 1u, nblk = (npos + SEG_CBLK - 1) / SEG_CBLK;
+        const bool useR = sh == SEG_CR_SH;
+        seg_lds_u32 R = (seg_lds_u32)(T + (((size_t)nblk * SEG_CBLK + 2) << SEG_CR_SH));   /* [ntr][64] (useR): exit state of position k under that id; behind T's rows at the usual stride */
+        const uint32_t dummy = (ntr + 1u) << sh;
+        /* -- gather: T[k][d] = index of the successor's cell and R[k][d] = the exit state itself (= entry state of position k+1); per item the
+         *    loads that need nothing first, then the dependent ones; SEG_CQ items per thread at a time -- */
         PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            /* (one lane) the state the chain starts from: its loads ride along with the gather's, one level each */
-            const bool starter = pass == 0 && tid == SEG_CHAIN_THREADS - 1;
+            /* (one lane) the state and the id the chain starts from: its loads ride along with the gather's, one level each */
+            const bool starter = first_iter && tid == SEG_CHAIN_THREADS - 1;
             uint32_t fi0 = 0, fi1 = 0, dfirst = SEG_INVALID;
-            if (starter) { fi0 = j.firstidx[(f * 4 + c) * 2]; fi1 = j.firstidx[(f * 4 + c) * 2 + 1]; }
+            if (starter && sx) { fi0 = j.firstidx[(f * 4 + c) * 2]; fi1 = j.firstidx[(f * 4 + c) * 2 + 1]; }
+            const uint32_t start_ps = sx ? fi1 : seg_state_pack(start0);
             const uint32_t idx_first = sx ? fi0 : (seg_is_small(P, f) ? P.idx0_small : P.idx0_big);
-            const uint32_t total = ns << sh;
-            /* item (k, d): k = segment (relative), d = dense id; this thread's items share d and step through k by kstep.  32-bit offsets
+            const uint32_t start_key = seg_eh_key_of_packed(start_ps), start_base = seg_eh_base(start_key);
+            /* item (k, d): k = position of the pass, d = dense id; this thread's items share d and step through k by kstep.  32-bit offsets
              * from uniform bases (the whole gather is bound by the instructions 1024 threads issue on one CU, not by memory) */
             const uint32_t d = (uint32_t)tid & (stride - 1), k0 = (uint32_t)tid >> sh, kstep = (uint32_t)SEG_CHAIN_THREADS >> sh;
-            const uint32_t mstep32 = (uint32_t)mstep, rstep32 = (uint32_t)rstep;
             uint32_t widest = 0;
-            for (uint32_t kb = 0; kb < ns; kb += SEG_CQ * kstep) {
-                /* no branch per item: an item beyond the last segment is clamped onto it and does that segment's work once more (same
-                 * values to the same places) -- 70 scalar branches and their mask arithmetic were half of this block's instructions */
+            for (uint32_t kb = 0; kb < ntr; kb += SEG_CQ * kstep) {
+                /* no branch per item: an item beyond the last transition is clamped onto it and does that one's work once more (same
+                 * values to the same places) */
                 uint32_t dcv[SEG_CQ], r[SEG_CQ], ps[SEG_CQ], v[SEG_CQ];
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
-                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u), sg = s0 + k;
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
                     const uint32_t o = sg * rstep32 + d;
                     dcv[q] = dcnt[sg * 4u];
-                    r[q] = rout[o];
-                    ps[q] = useR ? rst[o] : SEG_NOSTATE;
+                    r[q] = seeded ? 0u : (uint32_t)rout[o];
+                    ps[q] = (useR || seeded) ? rst[o] : SEG_NOSTATE;
                 }
-                if (starter && kb == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[s0 * mstep32 + idx_first];
+                if (starter && kb == 0) {
+                    if (seeded) {
+                        const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (s0 + a) * estep32 + (start_key == SEG_NOKEY ? 0u : start_base));
+                        dfirst = seg_eh_match(start_key, w[0], w[1]);
+                    } else if (idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(s0 + a) * mstep32 + idx_first];
+                }
                 /* (the dependent loads in a loop of their own: next to their uses, each one waits for itself) */
-                PLS_UNROLL
-                for (int q = 0; q < SEG_CQ; q++) {
-                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u), sg = s0 + k;
-                    const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                    v[q] = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
+                if (seeded) {
+                    PLS_UNROLL
+                    for (int q = 0; q < SEG_CQ; q++) {
+                        const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
+                        const uint32_t key = seg_eh_key_of_packed(ps[q]);
+                        const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (sg + 1u) * estep32 + (key == SEG_NOKEY ? 0u : seg_eh_base(key)));
+                        const SegVec16 w0 = w[0], w1 = w[1];
+                        v[q] = (d < dcv[q]) ? seg_eh_match(key, w0, w1) : (uint32_t)SEG_INVALID;
+                    }
+                } else {
+                    PLS_UNROLL
+                    for (int q = 0; q < SEG_CQ; q++) {
+                        const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
+                        const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
+                        const uint32_t m = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
+                        v[q] = valid ? m : (uint32_t)SEG_INVALID;
+                    }
                 }
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
-                    const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u);
-                    v[q] = pass ? (valid ? v[q] : (uint32_t)SEG_INVALID) : (valid ? ((k + 1u) << SEG_CR_SH) + v[q] : dummy);   /* (an id beyond the stride: the row is gathered again, widest stride) */
-                    ps[q] = valid ? ps[q] : SEG_NOSTATE;
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u);
+                    const bool valid = v[q] < SEG_NSP;                  /* (no id: the state left what the tables cover, or the entry set of the next segment does not hold it) */
+                    v[q] = valid ? ((k + 1u) << sh) + v[q] : dummy;   /* (an id beyond the stride: the pass is gathered again, wider) */
+                    ps[q] = (d < dcv[q]) ? ps[q] : SEG_NOSTATE;
                     widest = dcv[q] > widest ? dcv[q] : widest;
                 }
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
-                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ns - 1u);
+                    const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u);
                     const uint32_t t = (k << sh) + d;
                     T[t] = (uint16_t)v[q];
                     if (useR) R[t] = ps[q];
                 }
             }
-            if (widest > stride || ((eflags & 4) && total)) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], widest); }
-            if (pass == 0) { const uint32_t t = (ns << SEG_CR_SH) + (uint32_t)tid; if (t < (nblk * SEG_CBLK) << SEG_CR_SH && t != dummy) T[t] = (uint16_t)dummy; }   /* rows behind the last table: the walk's last block runs its full length */
+            if (widest > stride) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], widest); }
+            /* rows behind the last table (the landing row, then spare rows up to whole blocks): they lead to the absorbing cell */
+            for (uint32_t t = (ntr << sh) + (uint32_t)tid; t < (nblk * SEG_CBLK) << sh; t += SEG_CHAIN_THREADS) T[t] = (uint16_t)dummy;
             if (starter) {
-                T[dummy] = (uint16_t)dummy;
-                if (total == 0 && idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[s0 * mstep32_ + idx_first];
-                idxb[29] = idx_first;
                 idxb[28] = dfirst;
-                entry[(size_t)s0 * 4] = sx ? fi1 : seg_state_pack(start0);
+                idxb[26] = start_ps;
+                entry[(size_t)s0 * 4] = start_ps;
             }
+            if (tid == 0) { T[dummy] = (uint16_t)dummy; idxb[25] = 0xFFFFFFFFu; }
         }
         PLS_SYNC();
-        if (pass == 1 || !idxb[30]) break;
-        sh = SEG_CR_SH + 1;                                     /* (flag 4: test hook) */
-        while ((1u << sh) < idxb[27] && sh < 8) sh++;
-        stride = 1u << sh; useR = false;
-    }
-    if (prof) tc[1] = PLS_CLOCK();
-    const bool linked = sh == SEG_CR_SH;                        /* the tables hold indices (usual stride), not ids (widest stride) */
-    const uint32_t gdummy = nblk << SEG_CR_SH;                  /* G's absorbing cell: the row behind its last block */
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        if (linked && tid == 0) G[gdummy] = (uint16_t)gdummy;
-        /* block b composes T[b*CBLK .. (b+1)*CBLK - 1]: the id in its first segment -> the id in the next block's first segment */
-        for (uint32_t t = (uint32_t)tid; t + stride < (nblk << sh); t += SEG_CHAIN_THREADS) {
-            const uint32_t b = t >> sh;
-            if (linked) {
-                uint32_t i = ((b * SEG_CBLK) << sh) + (t & (stride - 1));
+        if (idxb[30]) {
+            /* some segment of the pass has more distinct states than the stride holds: once more, wider (its last dense ids would alias) */
+            const uint32_t need = idxb[27];
+            PLS_SYNC();
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { idxb[30] = 0u; idxb[27] = 0u; } }
+            PLS_SYNC();
+            while ((1u << sh) < need && sh < 8) sh++;
+            nwide++;
+            continue;
+        }
+        if (prof) tc[1] = PLS_CLOCK();
+        const uint32_t gdummy = nblk << sh;                        /* G's absorbing cell: the row behind its last block */
+        const uint32_t smask = stride - 1u;
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (tid == 0) G[gdummy] = (uint16_t)gdummy;
+            /* block b composes T[b*CBLK .. (b+1)*CBLK - 1]: the id at its first position -> the id at the next block's first position */
+            for (uint32_t t = (uint32_t)tid; t + stride < (nblk << sh); t += SEG_CHAIN_THREADS) {
+                const uint32_t b = t >> sh;
+                uint32_t i = ((b * SEG_CBLK) << sh) + (t & smask);
                 PLS_UNROLL
                 for (int k = 0; k < SEG_CBLK; k++) i = (uint32_t)T[i];
                 /* what it leads to, as the index of THAT id's entry in the next block's composed table (or G's own absorbing cell): the walk
                  * over the block heads is a chain of bare loads too */
-                G[t] = (uint16_t)(i == dummy ? gdummy : (((b + 1u) << sh) | (i & (stride - 1))));
-                continue;
+                G[t] = (uint16_t)(i == dummy ? gdummy : (((b + 1u) << sh) | (i & smask)));
             }
-            uint32_t d = t & (stride - 1);
-            for (uint32_t k = b * SEG_CBLK; k < (b + 1) * SEG_CBLK; k++) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
-            G[t] = (uint16_t)d;
         }
-    }
-    PLS_SYNC();
-    if (prof) tc[2] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        if ((uint32_t)tid < nblk) {
-            /* thread b: the true id at the head of block b (across the composed tables), then through the block */
-            if (linked) {
-                /* every lane walks the heads of ALL blocks (the same chain of loads in every lane: no lane-dependent loop) and keeps its own */
+        PLS_SYNC();
+        if (prof) tc[2] = PLS_CLOCK();
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if ((uint32_t)tid < nblk) {
+                /* thread b: the true id at the head of block b (across the composed tables), then through the block.  Every lane walks the
+                 * heads of ALL blocks (the same chain of loads in every lane: no lane-dependent loop) and keeps its own */
                 uint32_t g = idxb[28] < stride ? idxb[28] : gdummy, gm = g;
                 for (uint32_t b = 0; b + 1 < nblk; b++) { g = (uint32_t)G[g]; gm = b + 1 == (uint32_t)tid ? g : gm; }
-                uint32_t i = gm == gdummy ? dummy : ((((uint32_t)tid * SEG_CBLK) << sh) | (gm & (stride - 1)));
+                uint32_t i = gm == gdummy ? dummy : ((((uint32_t)tid * SEG_CBLK) << sh) | (gm & smask));
                 uint32_t at[SEG_CBLK];
                 PLS_UNROLL
-                for (int q = 0; q < SEG_CBLK; q++) { at[q] = i; i = (uint32_t)T[i]; }      /* (rows behind table ns - 1 lead to the absorbing cell) */
+                for (int q = 0; q < SEG_CBLK; q++) { at[q] = i; i = (uint32_t)T[i]; }      /* (rows behind table ntr - 1 lead to the absorbing cell) */
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CBLK; q++) {
                     const uint32_t k = (uint32_t)tid * SEG_CBLK + (uint32_t)q;
-                    if (k < ne) dn[k] = at[q] == dummy ? (uint32_t)SEG_INVALID : (at[q] & (stride - 1));
-                }
-            } else {
-                uint32_t d = idxb[28];
-                for (uint32_t b = 0; b < (uint32_t)tid; b++) d = d == SEG_INVALID ? d : (uint32_t)G[((size_t)b << sh) + d];
-                for (uint32_t k = (uint32_t)tid * SEG_CBLK; k < ((uint32_t)tid + 1) * SEG_CBLK && k < ne; k++) {
-                    dn[k] = d;
-                    if (k < ns) d = d == SEG_INVALID ? d : (uint32_t)T[((size_t)k << sh) + d];
+                    if (k < npos) dn[k] = at[q] == dummy ? (uint32_t)SEG_INVALID : (at[q] & smask);
                 }
             }
-        }
-    }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-        /* entry state of segment s0+k+1 = exit state of segment s0+k under its id */
-        for (uint32_t k = (uint32_t)tid; k < ne; k += SEG_CHAIN_THREADS) {
-            const uint32_t d = dn[k];
-            dnout[(size_t)(s0 + k) * 4] = (uint16_t)(d < stride ? d : SEG_INVALID);
-            if (k >= ns) continue;
-            uint32_t ps = SEG_NOSTATE;
-            if (d != SEG_INVALID && d < stride) {
-                if (useR) ps = R[((size_t)k << sh) + d];
-                else if (d < dcnt[(size_t)(s0 + k) * 4] && rout[(size_t)(s0 + k) * rstep + d] != SEG_INVALID) ps = rst[(size_t)(s0 + k) * rstep + d];
-            }
-            if (ps == SEG_NOSTATE) idxb[31] = 1u; else entry[(size_t)(s0 + k + 1) * 4] = ps;
-        }
-        if (tid == 0 && (P.engine_flags & 2)) idxb[31] = 1u;     /* (test hook: the serial walk) */
-    }
-    PLS_SYNC();
-    if (prof) tc[3] = PLS_CLOCK();
-    if (idxb[31]) {
-        /* (rare) some state on the path lies outside what the enumeration covers: segment after segment, through its tables where
-         * that works, step by step where it does not */
-        const SegGeo G_ = seg_geo((int)cv.s);
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            if (tid < 256) seg_load_frozen(j, par, f, Hf, rank, tid, 256);
-            if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
         }
         PLS_SYNC();
         PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            if (tid == 0) {
-                uint32_t idx = idxb[29];
-                SegState st = sx ? seg_state_unpack(j.firstidx[(f * 4 + c) * 2 + 1]) : start0;
-                for (uint32_t sg = s0; sg < nseg; sg++) {
-                    entry[(size_t)sg * 4] = seg_state_pack(st);
-                    dnout[(size_t)sg * 4] = (uint16_t)SEG_INVALID;       /* (whole segments from their entry states) */
-                    if (sg + 1 == nseg) break;
-                    bool have = false;
-                    uint32_t nidx = SEG_INVALID;
-                    if (idx != SEG_INVALID && (int)idx < nstates) {
-                        const uint32_t dd = maps[(size_t)sg * mstep + idx];
-                        if (dd != SEG_INVALID && dd < dcnt[(size_t)sg * 4]) {
-                            const uint32_t ps = rst[(size_t)sg * rstep + dd];
-                            if (ps != SEG_NOSTATE) { st = seg_state_unpack(ps); nidx = rout[(size_t)sg * rstep + dd]; have = true; }
-                        }
-                    }
-                    if (!have) {
-                        for (uint32_t x = sg * SEG_L; x < (sg + 1) * SEG_L && x < W; x++) {
-                            const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, c);
-                            (void)seg_step_scan(f, p, st, Hf, nullptr, rank, G_, lut, P.bleed);
-                        }
-                        const SegPix bp = seg_pix_load(row, nab, j.err0, bpp, (sg + 1) * SEG_L - 1, c);
-                        nidx = seg_any_encode(P, f, bp, st);
-                    }
-                    idx = nidx;
-                }
+            /* ids out; entry state of position k+1 = exit state of position k under its id */
+            for (uint32_t k = (uint32_t)tid; k < npos; k += SEG_CHAIN_THREADS) {
+                uint32_t d = dn[k];
+                if ((eflags & 2) && k >= 1u) d = SEG_INVALID;                       /* (test hook: every second segment through the repair) */
+                const uint32_t sg = s0 + a + k;
+                if (d == SEG_INVALID) { PLS_ATOMIC_MIN(&idxb[25], k); continue; }
+                dnout[(size_t)sg * 4] = (uint16_t)d;
+                if (k >= ntr) continue;
+                uint32_t ps = SEG_NOSTATE;
+                if (useR) ps = R[(k << SEG_CR_SH) + d];
+                else if (d < dcnt[(size_t)sg * 4]) ps = rst[(size_t)sg * rstep32 + d];
+                entL[k + 1u] = ps;
+                if (ps != SEG_NOSTATE) entry[(size_t)(sg + 1u) * 4] = ps;
             }
         }
-    }
-    if (prof) {
+        PLS_SYNC();
+        if (prof) { tc[3] = PLS_CLOCK(); for (int q = 0; q < 3; q++) tacc[q] += tc[q + 1] - tc[q]; }
+        uint32_t fb = idxb[25];
+        if (fb == 0xFFFFFFFFu) {
+            /* the whole pass has ids: the next one starts at its landing position */
+            const uint32_t nd = dn[ntr], ne_ = entL[ntr];
+            PLS_SYNC();
+            a += ntr;
+            first_iter = false;
+            if (a >= ns) break;                                    /* (the landing position was the row's last segment: its id is out) */
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { idxb[28] = nd; idxb[26] = ne_; } }
+            PLS_SYNC();
+            continue;
+        }
+        /* -- repair: position fb has no id (its entry state is not in the segment's entry set) -- or position fb - 1 has an id but no exit
+         *    state (its lane left what the tables cover).  That segment is walked step by step from its entry state. -- */
+        if (fb > 0u && entL[fb] == SEG_NOSTATE) fb--;
+        const uint32_t est = fb ? entL[fb] : idxb[26];
+        const bool have_tables = idxb[31] != 0u;
+        PLS_SYNC();
+        const uint32_t kq = a + fb, sgq = s0 + kq;                  /* the position and the segment walked */
+        const uint32_t xq = sgq * SEG_L;
+        SegPix *pxr = (SegPix *)(uint32_t *)(twr + SEG_TBL_WORDS);  /* [SEG_L + 1] */
+        const SegGeo G_ = seg_geo((int)cv.s);
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (!have_tables) {
+                for (int i = tid; i < SEG_TBL_WORDS; i += SEG_CHAIN_THREADS) twr[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+                if (tid < 256) seg_load_frozen(j, par, f, (uint32_t *)Hf, (uint32_t *)rank, tid, 256);
+                if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
+            }
+            if (tid >= 768 && tid < 768 + SEG_L) pxr[tid - 768] = seg_pix_load(row, nab, j.err0, bpp, seg_umin(xq + (uint32_t)(tid - 768), W - 1u), c);
+            if (tid == 0) { SEG_DEBUG_COUNT(2, fb); SEG_DEBUG_REPAIR(f, c, sgq, est, idxb[28]); idxb[31] = 1u; idxb[24]++; dnout[(size_t)sgq * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgq * 4] = est; }
+        }
+        PLS_SYNC();
+        if (kq >= ns) break;                                       /* the row's last segment: the replay walks it from its entry state, nothing follows */
         PLS_THREADS(tid, SEG_CHAIN_THREADS) {
             if (tid == 0) {
-                tc[4] = PLS_CLOCK();
-                for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[8 + q], (int32_t)(tc[q + 1] - tc[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[12 + q], (uint32_t)(tc[q + 1] - tc[q])); }
+                SegState st = seg_state_unpack(est);
+                seg_walk(f, pxr, 1, xq, xq + SEG_L, st, SEG_LDS_CU32(twr), SEG_LDS_CU32(lut), (const uint32_t *)Hf, (const uint32_t *)rank, G_, (const uint32_t *)lut, P.bleed, nullptr, nullptr);
+                const uint32_t nps = seg_state_pack(st);
+                uint32_t nid = SEG_INVALID;
+                if (seeded) nid = seg_eh_lookup(ehash + (size_t)(sgq + 1u) * estep32, seg_eh_key(st.left, st.cn, st.th));
+                else {
+                    const uint32_t idx = seg_any_encode(P, f, pxr[SEG_L - 1], st);
+                    if (idx != SEG_INVALID && (int)idx < nstates) nid = (uint32_t)maps[(size_t)(sgq + 1u) * mstep32 + idx];
+                }
+                if (nid >= SEG_NSP || nid >= dcnt[(size_t)(sgq + 1u) * 4]) nid = SEG_INVALID;
+                entry[(size_t)(sgq + 1u) * 4] = nps;
+                idxb[26] = nps; idxb[28] = nid;
+            }
+        }
+        PLS_SYNC();
+        a = kq + 1u;
+        first_iter = false;
+    }
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        if (tid == 0) {
+            if (idxb[24]) PLS_ATOMIC_ADD((uint32_t *)&j.result[17], idxb[24]);       /* segments walked step by step (reported with the image's result) */
+            if (prof) {
+                for (int q = 0; q < 3; q++) { PLS_ATOMIC_MAX(&j.result[8 + q], (int32_t)tacc[q]); PLS_ATOMIC_ADD((uint32_t *)&j.result[12 + q], (uint32_t)tacc[q]); }
                 PLS_ATOMIC_ADD((uint32_t *)&j.result[16], 1u);
-                PLS_ATOMIC_ADD((uint32_t *)&j.result[17], idxb[31]);
-                PLS_ATOMIC_ADD((uint32_t *)&j.result[18], useR ? 0u : 1u);
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[18], nwide);
             }
         }
     }
@@ -1952,7 +2221,7 @@ PLS_HD void seg_build_tables(SEG_AS_GLB uint32_t *out, seg_lds_u32 H, seg_lds_u3
                     if (k2 > bk) { L = u2; bk = k2; }
                     if (k3 > bk) { L = u3; bk = k3; }
                 }
-                e = (uint32_t)(L + 512) | ((uint32_t)cls[sgn * 256 + (L & 255)] << 16);     /* the class of the leader's key: the first equal bin of its band */
+                e = (uint32_t)(L + 1024) | ((uint32_t)cls[sgn * 256 + (L & 255)] << 16);     /* the class of the leader's key: the first equal bin of its band */
             }
             out[i] = e;
         }
@@ -2251,7 +2520,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
                     uint32_t nz = 0;
                     for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 24; i++) if (i < 8 || i == 20 || !(P.engine_flags & 1)) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
+                    for (int i = 0; i < 24; i++) if (i < 8 || i == 20 || (i != 17 && !(P.engine_flags & 1))) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
                     j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
                     j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
                     if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);

@@ -44,7 +44,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
 {
     if (!W || !H) return 0;
     static SegParams P;
-    if (!seg_build_params(P, (int)strength, (int)bleed)) return 64;
+    if (!seg_build_params(P, (int)strength, (int)bleed, getenv("SEG_HOST_SEEDED") != nullptr)) return 64;
     if (getenv("SEG_HOST_FORCE_FILTER")) P.engine_flags = (atoi(getenv("SEG_HOST_FORCE_FILTER")) + 1) << 8;
     if (getenv("SEG_HOST_FLAGS")) P.engine_flags |= atoi(getenv("SEG_HOST_FLAGS")) & 0xfe;   /* test hooks of the chain kernel (2: slow path, 4: wide stride) */
     /* classify + pack into slots (what pl_classify / pl_repack do on the device) */
@@ -85,6 +85,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.ctl = A.take<SegCtl>(2); j.base = A.take<uint32_t>(2 * 5 * 256); j.H0 = A.take<uint32_t>(2 * 256); j.acc = A.take<SegAcc>(2);
     j.tables = A.take<uint32_t>(5 * SEG_TBL_WORDS);
     j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * P.nsp);
+    j.ehash = A.take<uint32_t>(P.seeded ? (size_t)5 * j.nseg * 4 * SEG_EH_WORDS : 4);
     j.rout = A.take<uint16_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
     j.rst = A.take<uint32_t>((size_t)5 * j.nseg * 4 * SEG_NSP);
     j.rck = A.take<uint32_t>((size_t)5 * j.nseg * 4 * SEG_NSP * (SEG_PARTS - 1));
@@ -110,6 +111,14 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         /* the enumeration kernel is launched with exactly SEG_SM_ENUM_NT(nt) bytes of LDS: the bodies get a buffer of that size here, and the
          * sanitizer build (tests/test_seg_host.py) sees any byte they touch beyond it */
         std::vector<unsigned char> esm((size_t)SEG_SM_ENUM_NT(nt), 0x5A);
+        if (P.seeded) {
+            std::vector<unsigned char> ssm((size_t)SEG_SM_ENUM_SEEDED(nt), 0x5A);
+            for (int f = 0; f < SEG_NFILT; f++)
+                for (uint32_t sg = 0; sg < j.nseg; sg++) {
+                    if (nt == 512) for (int ch = 0; ch < 2; ch++) seg_enum_seeded_body<512>(j, P, par, f, (int)sg, ch, ssm.data());
+                    else seg_enum_seeded_body<1024>(j, P, par, f, (int)sg, 0, ssm.data());
+                }
+        } else
         for (int f = 0; f < SEG_NFILT; f++) {
             if (nt == 512) {
                 if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 4) seg_enum_small_body<512>(j, P, par, f, (int)sg, esm.data());
@@ -134,6 +143,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
                 seg_epoch_rows_won[0], seg_epoch_rows_won[1], seg_epoch_rows_won[2], seg_epoch_rows_won[3], seg_epoch_rows_won[4], seg_none_starts, seg_none_started_won);
     }
     if (getenv("SEG_HOST_VERBOSE")) fprintf(stderr, "seg_host: replay lanes from an entry state %llu (%.1f px each), from a checkpoint %llu (%.1f px each)\n", seg_dbg[0][0], seg_dbg[0][0] ? (double)seg_dbg[0][1] / seg_dbg[0][0] : 0.0, seg_dbg[1][0], seg_dbg[1][0] ? (double)seg_dbg[1][1] / seg_dbg[1][0] : 0.0);
+    if (getenv("SEG_HOST_VERBOSE")) fprintf(stderr, "seg_host: chain repairs (segments walked step by step) %llu\n", seg_dbg[2][0]);
     if (stats) { stats[0] = (uint32_t)attempt; stats[1] = fc.restarts_total; stats[2] = fc.retried; stats[3] = fc.serial_rows; stats[4] = (uint32_t)j.result[2]; stats[5] = bpp; stats[6] = (uint32_t)P.ns; stats[7] = fc.status; }
     /* unpack (pl_unpack) */
     for (size_t i = 0; i < (size_t)W * H; i++) {

@@ -15,6 +15,9 @@ CASES = [(64, 48, m, 19, 2) for m in range(6)] + [
     (80, 12, 1, 19, 32767),
     # state sets enumerated in several chunks of lanes (259 .. 955 states)
     (260, 24, 0, 20, 2), (200, 24, 1, 20, 1), (200, 20, 2, 40, 2), (200, 20, 0, 85, 8), (150, 20, 4, 26, 2), (150, 16, 3, 40, 2),
+    # state sets beyond the lanes (10^4 .. 10^5 chain states): the SEEDED enumeration (run-in from seeds, entry states looked up by value)
+    (200, 20, 0, 85, 1), (200, 20, 1, 85, 2), (200, 16, 5, 40, 1), (150, 12, 3, 255, 1), (130, 16, 2, 160, 1), (97, 12, 4, 200, 3), (300, 10, 0, 128, 2),
+    (33, 6, 1, 85, 1), (1, 3, 1, 85, 1), (64, 6, 5, 255, 2),
 ]
 
 
@@ -63,10 +66,10 @@ def test_seg_engine_speculation_with_state_sets_enumerated_in_chunks(s, b, most)
 
 
 @pytest.mark.parametrize("flags", [2, 4, 6])
-@pytest.mark.parametrize("w,h,mode,s,b", [(333, 37, 3, 19, 2), (520, 24, 0, 19, 2), (300, 24, 1, 20, 1), (200, 20, 4, 26, 2)])
+@pytest.mark.parametrize("w,h,mode,s,b", [(333, 37, 3, 19, 2), (520, 24, 0, 19, 2), (300, 24, 1, 20, 1), (200, 20, 4, 26, 2), (300, 12, 0, 85, 1), (260, 10, 5, 255, 1)])
 def test_seg_engine_chain_fallback_paths(monkeypatch, flags, w, h, mode, s, b):
-    """the chain kernel's rare paths, forced through its test hooks: 2 = the serial walk for states outside the enumeration,
-    4 = the row-wide table stride for rows with more distinct states per segment than the fast stride"""
+    """the chain kernel's rare paths, forced through its test hooks: 2 = every second segment through the repair (a segment whose entry
+    state the enumeration did not cover is walked step by step, the passes go on behind it), 4 = a wider table stride than needed"""
     monkeypatch.setenv("SEG_HOST_FLAGS", str(flags))
     img = P.synth_rgba(w, h, mode, 0)
     rc, out, f, st = U.run_seg_host(img, s, b)
@@ -81,10 +84,35 @@ def test_seg_engine_all_rows_adaptive():
     assert rc == 0 and np.array_equal(out, want)
 
 
-def test_seg_engine_declines_state_sets_it_has_no_lanes_for():
+def test_seg_engine_takes_every_strength_and_bleed():
+    """no (strength, bleed) pair is declined any more: the sets that do not fit the lanes are enumerated from seeds"""
     img = P.synth_rgba(40, 8, 0, 0)
-    rc, out, f, st = U.run_seg_host(img, 85, 2)
-    assert rc == 64          # the product takes the one-workgroup-per-image engine for these
+    for s, b in [(85, 2), (44, 2), (28, 1), (127, 1), (128, 1), (255, 1), (255, 32767), (119, 8)]:
+        rc, out, f, st = U.run_seg_host(img, s, b)
+        want, wf = U.run_port(img, s, b)
+        assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf), (s, b)
+
+
+@pytest.mark.parametrize("s,b,most", [(85, 1, 62), (85, 2, 56), (40, 1, 80)])
+def test_seg_engine_seeded_speculation_is_right_almost_always(s, b, most):
+    """the seeded enumeration's entry sets hold the reference's own state nearly always (measured: 56 / 52 / 72 attempts for 48 rows,
+    at most a handful of segments walked step by step by the chain kernel): wrong seeds, a wrong hash or a wrong lookup would show
+    as attempts or repairs, never as wrong bytes"""
+    img = P.synth_rgba(1024, 48, 0, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+    assert int(st[0]) <= most and int(st[3]) == 0 and int(st[6]) == 0, st
+
+
+@pytest.mark.parametrize("w,h,mode,s,b", [(333, 20, 1, 19, 2), (520, 12, 0, 19, 2), (200, 12, 5, 7, 3), (97, 9, 3, 0, 2), (150, 10, 2, 20, 1)])
+def test_seg_engine_seeded_enumeration_at_small_strengths(monkeypatch, w, h, mode, s, b):
+    """SEG_HOST_SEEDED=1 makes the harness use the seeded enumeration where the exhaustive one would do: same bytes"""
+    monkeypatch.setenv("SEG_HOST_SEEDED", "1")
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and int(st[6]) == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
 
 
 def test_seg_engine_seeded_random_images():
@@ -120,7 +148,7 @@ def test_seg_engine_bodies_clean_under_asan_and_ubsan(tmp_path):
         "from tests import util as U\n"
         "lib = C.CDLL(%r)\n"
         "lib.seg_host_optimize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint, C.c_long, C.c_void_p]\n"
-        "for (w, h, m, s, b) in [(700, 10, 0, 19, 2), (300, 8, 2, 40, 2), (8192, 2, 0, 19, 2), (333, 7, 3, 19, 2), (33, 5, 5, 7, 3), (3300, 3, 1, 20, 1)]:\n"
+        "for (w, h, m, s, b) in [(700, 10, 0, 19, 2), (300, 8, 2, 40, 2), (8192, 2, 0, 19, 2), (333, 7, 3, 19, 2), (33, 5, 5, 7, 3), (3300, 3, 1, 20, 1), (700, 6, 0, 85, 1), (333, 6, 5, 255, 1), (8192, 2, 1, 85, 2)]:\n"
         "    img = P.synth_rgba(w, h, m, 0); out = img.copy(); f = np.zeros(h, np.uint8); st = np.zeros(8, np.uint32)\n"
         "    rc = lib.seg_host_optimize(out.ctypes.data, w, h, f.ctypes.data, s, b, st.ctypes.data)\n"
         "    want, wf = U.run_port(img, s, b)\n"
