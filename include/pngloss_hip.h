@@ -105,8 +105,14 @@ pngloss_hip_ctx *pngloss_hip_create(int device);
 void pngloss_hip_destroy(pngloss_hip_ctx *ctx);
 
 /* Enqueue the whole hot path for n device-resident images on `stream` (a hipStream_t passed as void*, NULL = the
- * default stream).  Images are independent and run concurrently (one workgroup per image in the row engine).
- * Asynchronous: returns after enqueueing; call pngloss_hip_finish() to synchronise and collect results. */
+ * default stream).  Images are independent and run concurrently.
+ * Asynchronous: returns without waiting for the device; call pngloss_hip_finish() to synchronise and collect results.
+ * Work the caller enqueues on `stream` behind this call runs behind the batch.  (Two row engines, chosen per batch: one
+ * workgroup per image -- everything is enqueued on `stream` before the call returns; one image spread over the whole device -- the
+ * number of row attempts depends on the data, so a helper thread of the context feeds them to a stream of the context's own and
+ * `stream` waits for the device-written "images finished" word (hipStreamWaitValue32).  On a device without stream memory operations
+ * the call waits for that thread instead: then, and only then, it blocks for the duration of the row engine.)
+ * One batch per context at a time: the next call must follow pngloss_hip_finish(). */
 int pngloss_hip_optimize_batch_async(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n,
                                      unsigned quantization_strength, long bleed_divider, void *stream);
 

@@ -62,6 +62,15 @@ struct pngloss_hip_ctx {
     std::vector<pngloss_hip_ctx *> peers;   /* further contexts on the same device: the other chunks of a host window (batch_host) */
     std::vector<size_t> chunk_first; /* first image of every chunk of the last split window (chunk 0 is this context's) */
     uint32_t *h_seg_words = nullptr;
+    /* the segment engine's launch loop runs on a helper thread and on a stream of its own (the number of row attempts is decided by the
+     * data): the caller's stream waits for the "images finished" word instead of for the host */
+    hipStream_t seg_stream = nullptr;
+    hipEvent_t ev_prep = nullptr;    /* caller's stream: everything the engine reads is in place */
+    std::thread seg_worker;
+    std::atomic<int> seg_rc{ 0 };
+    std::vector<SegJob> h_sj;        /* (stay alive until the asynchronous copies that read them are done: the next enqueue) */
+    SegParams h_seg_params;
+    int stream_wait_ok = -1;         /* hipStreamWaitValue32 usable on this device (-1: not asked yet) */
     int last_engine = 0;            /* 0 = one workgroup per image (pl_engine), 3 = segment-parallel (pl_seg) */
     long seg_attempts = 0;
 };
@@ -117,27 +126,78 @@ int ensure_ws(pngloss_hip_ctx *ctx, size_t bytes)
 
 struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
 
-/* The segment-parallel engine on the batch in ctx->h_jobs: builds the SegJob table, then enqueues row attempts (five kernels each,
- * pl_seg.hip) until every image has reported that it is finished.  All control flow of the algorithm is on the device; the host
- * only keeps the stream fed, at most SEG_LOOKAHEAD attempts ahead of the attempt the device says it is working on.  Records
- * ev[1]/ev[2] around the engine.  Synchronous up to the end of the engine (the kernels behind it stay asynchronous). */
+/* The segment-parallel engine on the batch in ctx->h_jobs.  All control flow of the algorithm is on the device; the host only keeps
+ * a stream fed with row attempts (five kernels each, pl_seg.hip) until every image has reported that it is finished -- how many that
+ * takes depends on the data.  So that the entry point stays ASYNCHRONOUS, the attempts are launched by a helper thread on a stream of
+ * the context's own, at most SEG_LOOKAHEAD attempts ahead of the one the device says it is working on; the caller's stream is made
+ * to wait for the host-visible "images finished" word (hipStreamWaitValue32), so everything the caller enqueues behind this call
+ * still runs behind the engine.  Records ev[1]/ev[2] around the engine (on the engine's stream). */
+void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
+{
+    constexpr long SEG_LOOKAHEAD = 32;
+    volatile uint32_t *words = ctx->h_seg_words;
+    int rc = PNGLOSS_SUCCESS;
+    const size_t n = b.n;
+    if (hipSetDevice(ctx->device) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    long launched = 0;
+    auto t_last = std::chrono::steady_clock::now();
+    uint32_t seen = 0;
+    int idle = 0;
+    while (rc == PNGLOSS_SUCCESS && words[0] < (uint32_t)n) {
+        const uint32_t at = words[1];
+        if (at != seen) { seen = at; t_last = std::chrono::steady_clock::now(); idle = 0; }
+        if (launched - (long)at > SEG_LOOKAHEAD) {
+            if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
+                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress at attempt %u\n", at);
+                rc = PNGLOSS_HIP_ERROR;
+                break;
+            }
+            /* the device is busy with what is queued: leave the core to others (a row attempt takes 50 - 200 us) */
+            if (++idle < 4) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+            continue;
+        }
+        if (launched > max_attempts) {
+            std::fprintf(stderr, "pngloss_hip: the segment engine needed more than %ld attempts\n", max_attempts);
+            rc = PNGLOSS_HIP_ERROR;
+            break;
+        }
+        if (pl_seg_launch_attempt(b, (int)launched, ctx->seg_stream) != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(hipGetLastError())); rc = PNGLOSS_HIP_ERROR; break; }
+        launched++;
+    }
+    if (hipEventRecord(ctx->ev[2], ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    if (rc != PNGLOSS_SUCCESS) {
+        /* whatever went wrong, the caller's stream must not wait for ever: drain what is queued, then release it */
+        (void)hipStreamSynchronize(ctx->seg_stream);
+        words[0] = (uint32_t)n;
+    }
+    ctx->seg_attempts = launched;
+    ctx->seg_rc.store(rc, std::memory_order_release);
+}
+
 int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const SegParams &params, const std::vector<size_t> &seg_offs,
                    size_t jobs_off, size_t params_off, hipStream_t stream)
 {
-    constexpr long SEG_LOOKAHEAD = 32;
     if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (!ctx->seg_stream) PL_CHECK(hipStreamCreateWithFlags(&ctx->seg_stream, hipStreamNonBlocking));
+    if (!ctx->ev_prep) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    if (ctx->stream_wait_ok < 0) {
+        int can = 0;
+        ctx->stream_wait_ok = (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can) ? 1 : 0;
+        if (std::getenv("PNGLOSS_HIP_NO_STREAM_WAIT")) ctx->stream_wait_ok = 0;     /* test hook: the blocking variant */
+    }
     void *d_words = nullptr;
     PL_CHECK(hipHostGetDevicePointer(&d_words, ctx->h_seg_words, 0));
     volatile uint32_t *words = ctx->h_seg_words;
     words[0] = 0; words[1] = 0;
-    std::vector<SegJob> sj(n);
+    ctx->h_sj.assign(n, SegJob{});
+    ctx->h_seg_params = params;
     PlSegBatch b{};
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) {
         const PlJob &pj = ctx->h_jobs[i];
         const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1, (uint32_t)params.nsp, params.seeded != 0);
         char *base = ctx->d_ws + seg_offs[i];
-        SegJob &s = sj[i];
+        SegJob &s = ctx->h_sj[i];
         s.img = pj.img; s.row_filters = pj.row_filters; s.row_ids = pj.row_ids; s.W = pj.width; s.H = pj.height; s.bpp = 0;
         s.orig_rank = pj.orig_rank; s.cand = reinterpret_cast<uint32_t *>(pj.cand);
         s.err0 = reinterpret_cast<uint32_t *>(pj.err0); s.err1 = reinterpret_cast<uint32_t *>(pj.err1);
@@ -158,42 +218,33 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     if (!b.max_ncommit) b.max_ncommit = 1;
     SegJob *d_sj = reinterpret_cast<SegJob *>(ctx->d_ws + jobs_off);
     SegParams *d_params = reinterpret_cast<SegParams *>(ctx->d_ws + params_off);
-    PL_CHECK(hipMemcpyAsync(d_sj, sj.data(), sizeof(SegJob) * n, hipMemcpyHostToDevice, stream));
-    PL_CHECK(hipMemcpyAsync(d_params, &params, sizeof(SegParams), hipMemcpyHostToDevice, stream));
-    PL_CHECK(hipStreamSynchronize(stream));          /* sj / params are stack and vector memory */
+    PL_CHECK(hipMemcpyAsync(d_sj, ctx->h_sj.data(), sizeof(SegJob) * n, hipMemcpyHostToDevice, stream));
+    PL_CHECK(hipMemcpyAsync(d_params, &ctx->h_seg_params, sizeof(SegParams), hipMemcpyHostToDevice, stream));
     b.d_sj = d_sj; b.d_params = d_params; b.n = n;
     b.small_ok = params.small_ok != 0;
     b.seeded = params.seeded != 0;
     b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
     if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
-    PL_CHECK(hipEventRecord(ctx->ev[1], stream));
+    PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
+    PL_CHECK(hipStreamWaitEvent(ctx->seg_stream, ctx->ev_prep, 0));
+    PL_CHECK(hipEventRecord(ctx->ev[1], ctx->seg_stream));
     /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */
     const long max_attempts = (long)max_h * (2 + SEG_MAX_RESTARTS * SEG_NFILT) + 1024;
-    long launched = 0;
-    auto t_last = std::chrono::steady_clock::now();
-    uint32_t seen = 0;
-    while (words[0] < (uint32_t)n) {
-        const uint32_t at = words[1];
-        if (at != seen) { seen = at; t_last = std::chrono::steady_clock::now(); }
-        if (launched - (long)at > SEG_LOOKAHEAD) {
-            if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
-                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress at attempt %u\n", at);
-                return PNGLOSS_HIP_ERROR;
-            }
-            if (hipStreamQuery(stream) != hipErrorNotReady) { /* the queue ran dry without the word moving: re-read */ }
-            std::this_thread::yield();
-            continue;
-        }
-        if (launched > max_attempts) {
-            std::fprintf(stderr, "pngloss_hip: the segment engine needed more than %ld attempts\n", max_attempts);
-            return PNGLOSS_HIP_ERROR;
-        }
-        PL_CHECK(pl_seg_launch_attempt(b, (int)launched, stream));
-        launched++;
+    ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
+    if (ctx->stream_wait_ok) {
+        /* the caller's stream goes on behind the engine: when every image has counted itself finished */
+        const hipError_t e = hipStreamWaitValue32(stream, d_words, (uint32_t)n, hipStreamWaitValueGte, 0xFFFFFFFFu);
+        if (e != hipSuccess) { (void)hipGetLastError(); ctx->stream_wait_ok = 0; }
     }
-    PL_CHECK(hipEventRecord(ctx->ev[2], stream));
-    ctx->seg_attempts = launched;
+    try { ctx->seg_worker = std::thread(seg_worker_main, ctx, b, max_attempts); }
+    catch (...) { std::fprintf(stderr, "pngloss_hip: cannot start the launch thread\n"); words[0] = (uint32_t)n; return PNGLOSS_HIP_ERROR; }
+    if (!ctx->stream_wait_ok) {
+        /* no stream memory operations on this device: wait for the launch loop here, and order the caller's stream behind the engine's */
+        ctx->seg_worker.join();
+        PL_CHECK(hipStreamWaitEvent(stream, ctx->ev[2], 0));
+        if (ctx->seg_rc.load(std::memory_order_acquire)) return ctx->seg_rc.load();
+    }
     return PNGLOSS_SUCCESS;
 }
 
@@ -210,8 +261,10 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         return PNGLOSS_INVALID_ARGUMENT;
     }
     PL_CHECK(hipSetDevice(ctx->device));
+    if (ctx->seg_worker.joinable()) ctx->seg_worker.join();          /* (a batch that failed half-way) */
     ctx->h_jobs.clear();
     ctx->n_last = 0;
+    ctx->split_last = false;                                         /* (only a split host window sets it again: batch_host) */
     /* drop empty images (the reference's loops simply do nothing for them) */
     std::vector<size_t> offs;
     size_t total = align_up(sizeof(PlJob) * (n ? n : 1), 256);
@@ -221,8 +274,8 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         total += image_ws(images[i].width ? images[i].width : 1, images[i].height).total;
     }
     /* Which row engine: one workgroup per image (pl_engine: batches) or the whole GPU on few images (pl_seg: latency).  The segment
-     * engine needs the chain states of (strength, bleed) to fit its lanes and a row's maps to fit the chain kernel's LDS; it pays
-     * off while the batch leaves it the machine (its work per row is ~250x redundant by design). */
+     * engine takes every strength / bleed pair and rows up to SEG_MAX_WIDTH pixels; it pays off while the batch leaves it the machine
+     * (its work per row is ~250x redundant by design). */
     SegParams seg_params;
     bool use_seg = false;
     uint32_t seg_max_nseg = 1;
@@ -244,13 +297,16 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 seg_rows = std::max(seg_rows, (double)images[i].height);
                 seg_wgs += 3.0 * ((images[i].width + SEG_L - 1) / SEG_L) + 40.0;
             }
-            const double seg_us = seg_rows * (51.0 + 0.032 * seg_wgs);
+            /* (state sets beyond the lanes -- s = 85 at bleed 1 or 2 ... -- are enumerated from seeds with a run-in of one segment: about twice
+             * the enumeration and a wider chain, measured 150 - 190 us per attempt at 8192 pixels against 85 for s = 20) */
+            const bool seeded = pl_seg_supported(nullptr, 0, strength, bleed, &seg_params) && seg_params.seeded;
+            const double seg_us = seg_rows * (seeded ? 95.0 + 0.05 * seg_wgs : 51.0 + 0.032 * seg_wgs);
             worth = seg_us < wg_us;
         }
         if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && worth)
             use_seg = pl_seg_supported(widths.data(), n, strength, bleed, &seg_params);
         if (forced && !use_seg && n)
-            std::fprintf(stderr, "pngloss_hip: PNGLOSS_HIP_ENGINE=seg: strength %u / bleed %ld or a width beyond %d are not covered by the segment engine; using the one-workgroup-per-image engine\n", strength, bleed, SEG_MAX_NSEG * SEG_L);
+            std::fprintf(stderr, "pngloss_hip: PNGLOSS_HIP_ENGINE=seg: a width beyond %u is not covered by the segment engine; using the one-workgroup-per-image engine\n", SEG_MAX_WIDTH);
     }
     std::vector<size_t> seg_offs;
     size_t seg_jobs_off = 0, seg_params_off = 0;
@@ -323,9 +379,18 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     PL_CHECK(pl_launch_engine(d_jobs, n, prm, stream));
     PL_CHECK(hipEventRecord(ctx->ev[2], stream));
     }
-    PL_CHECK(pl_launch_finish(d_jobs, ctx->h_jobs.data(), n, stream));
-    PL_CHECK(pl_launch_emit(d_jobs, ctx->h_jobs.data(), n, stream));
-    PL_CHECK(hipEventRecord(ctx->ev[3], stream));
+    {
+        /* (behind this point the segment engine's launch thread may be running: it is joined before an error is returned) */
+        hipError_t e = pl_launch_finish(d_jobs, ctx->h_jobs.data(), n, stream);
+        if (e == hipSuccess) e = pl_launch_emit(d_jobs, ctx->h_jobs.data(), n, stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev[3], stream);
+        if (e != hipSuccess) {
+            std::fprintf(stderr, "pngloss_hip: enqueueing the kernels behind the row engine failed: %s\n", hipGetErrorString(e));
+            if (ctx->seg_worker.joinable()) ctx->seg_worker.join();
+            if (ctx->seg_stream) (void)hipStreamSynchronize(ctx->seg_stream);
+            return PNGLOSS_HIP_ERROR;
+        }
+    }
     ctx->n_last = n;
     ctx->last_stream = stream;
     ctx->pending = true;
@@ -341,8 +406,15 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         return PNGLOSS_SUCCESS;
     }
     PL_CHECK(hipSetDevice(ctx->device));
+    int seg_rc = PNGLOSS_SUCCESS;
+    if (ctx->seg_worker.joinable()) {
+        ctx->seg_worker.join();
+        seg_rc = ctx->seg_rc.load(std::memory_order_acquire);
+    }
     PL_CHECK(hipEventSynchronize(ctx->ev[3]));
+    if (ctx->last_engine == 3 && ctx->seg_stream) PL_CHECK(hipStreamSynchronize(ctx->seg_stream));   /* (attempts queued behind the last row: they find the images finished) */
     ctx->pending = false;
+    if (seg_rc) return seg_rc;
     float ms = 0.f;
     PL_CHECK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
     ctx->engine_ms = ms;
@@ -553,7 +625,10 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->seg_worker.joinable()) ctx->seg_worker.join();
     if (ctx->pending) (void)hipEventSynchronize(ctx->ev[3]);
+    if (ctx->seg_stream) { (void)hipStreamSynchronize(ctx->seg_stream); (void)hipStreamDestroy(ctx->seg_stream); }
+    if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);

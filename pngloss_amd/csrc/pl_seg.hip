@@ -24,15 +24,18 @@ namespace {
 __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sj[i].bpp = pl_job_bpp(jobs[i]);
+    if (i < n) {
+        sj[i].bpp = pl_job_bpp(jobs[i]);
+        sj[i].ctl[1].magic = 0u;          /* the image's first attempt (parity 0) finds no control block behind it */
+    }
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int attempt)
+__global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     if (blockIdx.x > SEG_CTL_IMG && (blockIdx.x - SEG_CTL_IMG - 1) * SEG_COMMIT_W >= j.W) return;
-    seg_ctl_body(j, *P, attempt, (int)blockIdx.x, seg_smem);
+    seg_ctl_body(j, *P, par, (int)blockIdx.x, seg_smem);
 }
 
 /* NT threads per workgroup: 1024 (four channels of a segment) or 512 (a channel pair), see SEG_ENUM_NT_SMALL_MAX_NSEG */
@@ -113,7 +116,7 @@ hipError_t chain_attr()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 32 || !(done.load(std::memory_order_acquire) & (1u << dev))) {
-        const hipError_t e = hipFuncSetAttribute((const void *)seg_k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_SM_CHAIN(SEG_MAX_NSEG));
+        const hipError_t e = hipFuncSetAttribute((const void *)seg_k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_SM_CHAIN(SEG_CHAIN_CAP + 1));
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
     }
@@ -154,7 +157,7 @@ bool pl_seg_supported(const uint32_t *widths, size_t n, unsigned strength, long 
 {
     if (bleed < 1 || bleed > 32767 || strength > 255) return false;
     for (size_t i = 0; i < n; i++)
-        if ((widths[i] + SEG_L - 1) / SEG_L > SEG_MAX_NSEG) return false;
+        if (widths[i] > SEG_MAX_WIDTH) return false;
     return seg_build_params(*params_out, (int)strength, (int)bleed);
 }
 
@@ -167,7 +170,7 @@ hipError_t pl_seg_launch_resolve(const PlJob *d_jobs, SegJob *d_sj, size_t n, hi
 
 hipError_t pl_seg_launch_control(const PlSegBatch &b, int attempt, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, (unsigned)b.n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
+    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, (unsigned)b.n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt & 1);
     return hipGetLastError();
 }
 
@@ -178,7 +181,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     if (e != hipSuccess) return e;
     const int par = attempt & 1;
     const unsigned n = (unsigned)b.n;
-    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt);
+    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt & 1);
     {
         const bool small_ok = b.small_ok;
         const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);

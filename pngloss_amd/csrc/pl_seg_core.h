@@ -146,8 +146,10 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_TBL_WORDS (4 * SEG_TN + 128)  /* pre[2], suf[2], cls[2][256 bytes] */
 #define SEG_INVALID 0xFFFFu
 #define SEG_NOFAIL 0xFFFFFFFFu
+#define SEG_MAGIC 0x5E6C0DE1u
 #define SEG_MAX_RESTARTS 12      /* epochs per candidate and row before the rest of the row is done serially */
-#define SEG_MAX_NSEG 256              /* the chain kernel keeps a row's maps in shared memory: 256 x 512 B */
+#define SEG_NG_BURST 16              /* group counts a lane requests in one burst (rows up to 8192 pixels); the groups of wider rows are read in a loop behind it */
+#define SEG_MAX_WIDTH (1u << 20)      /* rows the engine takes (libpng's own default limit); the chain kernel walks a row in passes, nothing else depends on the width */
 #define SEG_THREADS 1024
 #define SEG_CHAIN_THREADS 1024
 #define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* every thread loads one pixel of the group, SEG_GRP * SEG_PARTS * 4 of them walk */
@@ -204,6 +206,7 @@ struct SegParams {
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
 struct SegCtl {
     uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts, dropped_none;
+    uint32_t magic;                  /* SEG_MAGIC once a control kernel has written this block: the attempt that finds none behind it is the image's first (the launcher resets the word per batch) */
     uint32_t none_eager;             /* rows for which candidate none is run straight away (its bound did not rule it out lately) */
     uint32_t active[SEG_NFILT];      /* the candidate still has unvalidated pixels (or sums) to produce in this attempt */
     uint32_t start_x[SEG_NFILT];     /* pixels [0, start_x) of the candidate row are validated */
@@ -1354,23 +1357,36 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                         dfirst = seg_eh_match(start_key, w[0], w[1]);
                     } else if (idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(s0 + a) * mstep32 + idx_first];
                 }
-                /* (the dependent loads in a loop of their own: next to their uses, each one waits for itself) */
+                /* (the dependent loads in a loop of their own, all of them requested before the first is used: next to their uses, each one
+                 * waits for itself) */
                 if (seeded) {
+                    /* (two 16-byte loads per item: half of the items at a time, the registers of a 1024-thread workgroup hold no more) */
                     PLS_UNROLL
-                    for (int q = 0; q < SEG_CQ; q++) {
-                        const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
-                        const uint32_t key = seg_eh_key_of_packed(ps[q]);
-                        const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (sg + 1u) * estep32 + (key == SEG_NOKEY ? 0u : seg_eh_base(key)));
-                        const SegVec16 w0 = w[0], w1 = w[1];
-                        v[q] = (d < dcv[q]) ? seg_eh_match(key, w0, w1) : (uint32_t)SEG_INVALID;
+                    for (int h = 0; h < 2; h++) {
+                        SegVec16 w0[SEG_CQ / 2], w1[SEG_CQ / 2];
+                        uint32_t key[SEG_CQ / 2];
+                        PLS_UNROLL
+                        for (int q = 0; q < SEG_CQ / 2; q++) {
+                            const int qq = h * (SEG_CQ / 2) + q;
+                            const uint32_t k = seg_umin(kb + k0 + (uint32_t)qq * kstep, ntr - 1u), sg = s0 + a + k;
+                            key[q] = seg_eh_key_of_packed(ps[qq]);
+                            const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (sg + 1u) * estep32 + (key[q] == SEG_NOKEY ? 0u : seg_eh_base(key[q])));
+                            w0[q] = w[0]; w1[q] = w[1];
+                        }
+                        PLS_UNROLL
+                        for (int q = 0; q < SEG_CQ / 2; q++) { const int qq = h * (SEG_CQ / 2) + q; v[qq] = (d < dcv[qq]) ? seg_eh_match(key[q], w0[q], w1[q]) : (uint32_t)SEG_INVALID; }
                     }
                 } else {
                     PLS_UNROLL
                     for (int q = 0; q < SEG_CQ; q++) {
                         const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
                         const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                        const uint32_t m = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
-                        v[q] = valid ? m : (uint32_t)SEG_INVALID;
+                        v[q] = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
+                    }
+                    PLS_UNROLL
+                    for (int q = 0; q < SEG_CQ; q++) {
+                        const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
+                        v[q] = valid ? v[q] : (uint32_t)SEG_INVALID;
                     }
                 }
                 PLS_UNROLL
@@ -1847,15 +1863,21 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             const int b = tid;
             /* (all groups requested at once, the ones that do not count masked out: a loop with the load inside waits for every one) */
             uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b], total;
-            uint32_t gv[SEG_MAX_NSEG / SEG_GRP];
+            uint32_t gv[SEG_NG_BURST];
             PLS_UNROLL
-            for (int g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) gv[g] = ((uint32_t)g < ngrp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;
+            for (int g = 0; g < SEG_NG_BURST; g++) gv[g] = ((uint32_t)g < ngrp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;
             total = before;
             PLS_UNROLL
-            for (int g = 0; g < SEG_MAX_NSEG / SEG_GRP; g++) {
+            for (int g = 0; g < SEG_NG_BURST; g++) {
                 const bool in = sx < W && (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
                 total += in ? gv[g] : 0u;
                 before += (in && (uint32_t)g < grp) ? gv[g] : 0u;
+            }
+            for (uint32_t g = SEG_NG_BURST; g < ngrp; g++) {                      /* (rows beyond 8192 pixels) */
+                const uint32_t v = j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
+                const bool in = sx < W && g >= fgrp;
+                total += in ? v : 0u;
+                before += (in && g < grp) ? v : 0u;
             }
             Hpost[b] = H0[b] + total;
             uint32_t add[2 * SEG_VGRP];                                /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
@@ -2251,9 +2273,9 @@ PLS_HD void seg_next_hist(const SegDecision &D, seg_lds_u32 spec, seg_lds_u32 Hn
  * Which candidate won is known only after the control block and the sums of the finished attempt have arrived; the candidate words
  * of ALL five are requested in the same burst (they do not depend on the decision), so the winner's are there when it is known.
  * SEG_COMMIT_W lanes work (one wave per SIMD); the other waves of the launch shape only keep the barriers company. */
-PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int cw, unsigned char *smem)
+PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw, unsigned char *smem)
 {
-    const int prev = (attempt & 1) ^ 1;
+    const int prev = par ^ 1;
     const SegCtl &curg = j.ctl[prev];
     const SegAcc &Ag = j.acc[prev];
     const uint32_t W = j.W, H = j.H, bpp = j.bpp;
@@ -2266,31 +2288,6 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long tc0 = 0;
     if (prof) tc0 = PLS_CLOCK();
-    if (attempt == 0) {
-        /* the first row: extremes of the original values (no incoming error yet) */
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) {
-            if (tid < SEG_COMMIT_W) {
-                const uint32_t x = xw0 + (uint32_t)tid;
-                int vmax = -(1 << 30), vmin = 1 << 30;
-                if (x < W && H) {
-                    const uint32_t o = j.img[x];
-                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                    for (uint32_t c = 0; c < bpp; c++) {
-                        if (alpha0 && c == bpp - 1u) continue;
-                        const int v = (int)((o >> (8 * c)) & 255u);
-                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
-                    }
-                }
-                vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-                if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
-            }
-        }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
-        return;
-    }
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < SEG_COMMIT_W) {
             const uint32_t x = xw0 + (uint32_t)tid;
@@ -2330,6 +2327,34 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
     if (prof) tk[0] = PLS_CLOCK();
     seg_lds_ctl_t &cur = *(seg_lds_ctl_t *)ctlc;
     seg_lds_acc_t &A = *(seg_lds_acc_t *)accc;
+    const bool fresh = cur.magic != SEG_MAGIC;                 /* the image's first attempt: nothing behind it (what the burst read is junk) */
+    const int attempt = fresh ? 0 : 1;
+    if (fresh) {
+        /* the first row: extremes of the original values (no incoming error yet) */
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid < SEG_COMMIT_W) {
+                const uint32_t x = xw0 + (uint32_t)tid;
+                int vmax = -(1 << 30), vmin = 1 << 30;
+                if (x < W && H) {
+                    const uint32_t o = j.img[x];
+                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        if (alpha0 && c == bpp - 1u) continue;
+                        const int v = (int)((o >> (8 * c)) & 255u);
+                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                    }
+                }
+                vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+                if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
+        return;
+    }
     const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
     if (D.kind != SEG_K_COMMIT) return;
     if (prof) tk[1] = PLS_CLOCK();
@@ -2402,13 +2427,13 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int attempt, int
     if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const uint32_t dt = (uint32_t)(PLS_CLOCK() - tc0); PLS_ATOMIC_MAX(&j.result[58], (int32_t)dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[62], dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[63], 1u); PLS_ATOMIC_ADD((uint32_t *)&j.result[23], (uint32_t)(tk[0] - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[45], (uint32_t)(tk[1] - tk[0])); PLS_ATOMIC_ADD((uint32_t *)&j.result[54], (uint32_t)(tk[2] - tk[1])); PLS_ATOMIC_ADD((uint32_t *)&j.result[55], (uint32_t)(PLS_CLOCK() - tk[2])); } } }
 }
 
-/* Control kernel of attempt `attempt`: reads what attempt-1 left (control block and sums of parity prev), writes the control block
+/* Control kernel of an attempt (par = its parity): reads what the attempt before left (control block and sums of parity prev), writes the control block
  * of parity par.  bx < SEG_NFILT: candidate bx (epoch setup, decision tables); bx == SEG_NFILT: the image-wide fields;
  * bx > SEG_NFILT: commit of pixels [(bx - SEG_NFILT - 1) * SEG_THREADS, ...) */
-PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int bx, unsigned char *smem)
+PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, unsigned char *smem)
 {
-    if (bx > SEG_CTL_IMG) { seg_ctl_commit(j, P, attempt, bx - SEG_CTL_IMG - 1, smem); return; }
-    const int par = attempt & 1, prev = par ^ 1;
+    if (bx > SEG_CTL_IMG) { seg_ctl_commit(j, P, par, bx - SEG_CTL_IMG - 1, smem); return; }
+    const int prev = par ^ 1;
     const SegCtl &curg = j.ctl[prev];
     SegCtl &nxt = j.ctl[par];
     const SegAcc &Ag = j.acc[prev];
@@ -2424,14 +2449,14 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     seg_lds_u32 spec = stage;                                  /* [SEG_NFILT + 1][256] */
     /* the finished attempt's control block and sums, copied into shared memory by the same burst of loads: everything below reads the copies */
     seg_lds_u32 ctlc = stage + (SEG_NFILT + 1) * 256, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2;
-    if (attempt) {
+    {
         PLS_THREADS(tid, SEG_THREADS) {
-            /* every request of the burst first, the stores behind them */
+            /* every request of the burst first, the stores behind them (the image's first attempt reads junk here and ignores it) */
             const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
             const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
             const uint32_t rword = (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) ? j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)] : 0u;
             constexpr int NSP = ((SEG_NFILT + 1) * 256 + SEG_THREADS - 1) / SEG_THREADS;
-            constexpr int NG = SEG_MAX_NSEG / SEG_GRP;
+            constexpr int NG = SEG_NG_BURST;
             uint32_t bs[NSP], g0[NSP][NG], wsx[NSP];
             PLS_UNROLL
             for (int q = 0; q < NSP; q++) {
@@ -2461,6 +2486,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                         const uint32_t wfg = (wsx[q] / SEG_L) / SEG_GRP;
                         PLS_UNROLL
                         for (int g = 0; g < NG; g++) v += ((uint32_t)g >= wfg && (uint32_t)g < ngrp && wsx[q] < W) ? g0[q][g] : 0u;
+                        for (uint32_t g = NG; g < ngrp; g++) v += (g >= wfg && wsx[q] < W) ? j.grpcnt[((size_t)w * ngrp + g) * 256 + (i & 255)] : 0u;   /* (rows beyond 8192 pixels) */
                     }
                     spec[i] = v;
                 }
@@ -2474,6 +2500,8 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     seg_lds_acc_t &A = *(seg_lds_acc_t *)accc;
     /* one lane decides, the workgroup reads the result (16 waves working it out side by side only take each other's issue slots) */
     seg_lds_u32 dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
+    /* the number of this attempt is kept on the device (the launcher passes parities only: a captured launch sequence can be replayed) */
+    const int attempt = cur.magic != SEG_MAGIC ? 0 : (int)cur.attempts + 1;
     const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
     if (prof) tq2 = PLS_CLOCK();
     const uint32_t y = attempt ? cur.y : 0u;
@@ -2484,7 +2512,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
     if (bx == SEG_CTL_IMG) {
         /* ---- the image-wide fields ---- */
         if (D.kind == SEG_K_FINISHED) {
-            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
+            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts + 1u; nxt.magic = SEG_MAGIC; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
             return;
         }
         if (D.kind != SEG_K_RESTART) seg_next_hist(D, spec, Hn, SEG_THREADS);
@@ -2507,7 +2535,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
                     for (int g = 0; g < SEG_NFILT; g++) if ((D.failed >> g) & 1u) { rt++; if (cur.restarts[g] + 1 > SEG_MAX_RESTARTS) ser++; }
                 if (W == 0 || H == 0) fin = 1;
                 nxt.y = ny; nxt.s = (uint32_t)(s_next < 0 ? 0 : s_next); nxt.status = st; nxt.finished = fin; nxt.retried = retried; nxt.restarts_total = rt;
-                nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt; nxt.dropped_none = dropped;
+                nxt.serial_rows = ser; nxt.attempts = (uint32_t)attempt; nxt.magic = SEG_MAGIC; nxt.dropped_none = dropped;
                 {
                     const uint32_t ne = attempt ? cur.none_eager : 0u;
                     /* (eager only after none WON a row was tried on a screenshot where none never wins but its bound rarely rules it
@@ -2535,7 +2563,6 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int attempt, int b
      *      fields, each builds its share of the decision tables ---- */
     const int f = bx / SEG_TPARTS, tpart = bx % SEG_TPARTS;
     const bool failed = (D.failed >> f) & 1u;
-    if (!attempt) { PLS_THREADS(tid, SEG_THREADS) { for (int b = tid; b < 256; b += SEG_THREADS) rank[b] = j.orig_rank[f * 256 + b]; } }   /* (otherwise it came with the first burst) */
     if (D.kind != SEG_K_RESTART) {
         /* a fresh row attempt: start of the row, no validated prefix */
         seg_next_hist(D, spec, Hn, SEG_THREADS);

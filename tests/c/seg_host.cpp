@@ -40,6 +40,15 @@ struct Arena {
 
 } // namespace
 
+/* what the engine does with a (strength, bleed) pair: out = { supported, seeded, chain states (exhaustive), run-in pixels, cmax, tmax, dmax, seeds of none / up } */
+extern "C" int seg_host_describe(unsigned strength, long bleed, int32_t *out)
+{
+    static SegParams P;
+    const bool ok = seg_build_params(P, (int)strength, (int)bleed);
+    out[0] = ok; out[1] = P.seeded; out[2] = P.ns; out[3] = P.kin; out[4] = P.cmax; out[5] = P.tmax; out[6] = P.dmax; out[7] = P.nseed_small;
+    return ok ? 0 : 64;
+}
+
 extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, unsigned char *row_filters, unsigned strength, long bleed, uint32_t *stats)
 {
     if (!W || !H) return 0;
@@ -81,7 +90,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.old_above = A.take<uint32_t>(W);
     j.final_hist = A.take<uint32_t>(256); j.result = A.take<int32_t>(64); j.progress = nullptr;
     j.nseg = (W + SEG_L - 1) / SEG_L; j.ngrp = (j.nseg + SEG_GRP - 1) / SEG_GRP;
-    if (j.nseg > SEG_MAX_NSEG) return 64;
+    if (W > SEG_MAX_WIDTH) return 64;
     j.ctl = A.take<SegCtl>(2); j.base = A.take<uint32_t>(2 * 5 * 256); j.H0 = A.take<uint32_t>(2 * 256); j.acc = A.take<SegAcc>(2);
     j.tables = A.take<uint32_t>(5 * SEG_TBL_WORDS);
     j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * P.nsp);
@@ -98,11 +107,12 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.rowmm = A.take<int32_t>(2 * ((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W));
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
     const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
+    j.ctl[1].magic = 0u;             /* (seg_k_resolve does this on the device) */
     int attempt = 0;
     const long max_attempts = (long)H * 64 + 1024;
     for (;; attempt++) {
         if (attempt > max_attempts) { fprintf(stderr, "seg_host: no progress\n"); return 65; }
-        for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt, bx, smem.data());
+        for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt & 1, bx, smem.data());
         const int par = attempt & 1;
         if (j.ctl[par].finished) break;
         /* the enumeration's workgroups come in two sizes; the product picks by row width, SEG_HOST_ENUM_NT pins one */

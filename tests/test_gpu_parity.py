@@ -365,19 +365,21 @@ def test_strength_bleed_sweep_8192_matches_reference_digests(torch_cuda):
     torch.cuda.synchronize()
     for c, d, f, (s, b) in zip(ctxs, dev, filt, points):
         e = [e for e in dig if e["width"] == 8192 and e["strength"] == s and (e["bleed"] == b or s == 0)][0]
+        if not os.environ.get("PNGLOSS_HIP_ENGINE"):
+            assert c.engine_info(0)["engine"] == "segment-parallel", (s, b, c.engine_info(0))    # every point of configs[4] is on the fast engine
         assert "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS) == e["out"], (s, b)
         assert "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS) == e["filters"], (s, b)
         c.close()
 
 
 def test_segment_engine_is_the_default_for_single_images_and_reports_what_it_did(torch_cuda):
-    """No engine pinned: a single wide image of a strength/bleed the segment engine has lanes for goes through it (engine_info says
-    so), other strengths and narrow images go to the workgroup engine; all exact."""
+    """No engine pinned: a single wide image goes through the segment engine whatever the strength (engine_info says so: state sets
+    beyond the lanes are enumerated from seeds), narrow images go to the workgroup engine; all exact."""
     torch = torch_cuda
     env_before = os.environ.pop("PNGLOSS_HIP_ENGINE", None)
     try:
         # (a narrow image is faster on the workgroup engine: the segment engine's row attempt costs the same whatever the width)
-        for (w, s, b, want) in [(1000, 19, 2, "segment-parallel"), (1000, 85, 2, "workgroup-per-image"), (200, 19, 2, "workgroup-per-image")]:
+        for (w, s, b, want) in [(1000, 19, 2, "segment-parallel"), (1000, 85, 2, "segment-parallel"), (1000, 255, 1, "segment-parallel"), (200, 19, 2, "workgroup-per-image")]:
             img = P.synth_rgba(w, 70, 0, 4)
             d = torch.from_numpy(img.copy()).cuda()
             f = torch.zeros(70, dtype=torch.uint8, device="cuda")
@@ -387,7 +389,7 @@ def test_segment_engine_is_the_default_for_single_images_and_reports_what_it_did
             info = ctx.engine_info(0)
             assert info["engine"] == want, info
             if want == "segment-parallel":
-                assert info["attempts"] >= 70 and info["serial_rows"] == 0
+                assert info["attempts"] >= 70 and info["serial_rows"] == 0 and info["walked_segments"] <= 250   # (s = 255: the seeds miss the reference's own state in ~0.2 % of the segments)
             o1, f1 = U.run_port(img, s, b)
             assert res[0]["status"] == 0 and np.array_equal(d.cpu().numpy(), o1) and np.array_equal(f.cpu().numpy(), f1)
             ctx.close()

@@ -18,6 +18,8 @@ CASES = [(64, 48, m, 19, 2) for m in range(6)] + [
     # state sets beyond the lanes (10^4 .. 10^5 chain states): the SEEDED enumeration (run-in from seeds, entry states looked up by value)
     (200, 20, 0, 85, 1), (200, 20, 1, 85, 2), (200, 16, 5, 40, 1), (150, 12, 3, 255, 1), (130, 16, 2, 160, 1), (97, 12, 4, 200, 3), (300, 10, 0, 128, 2),
     (33, 6, 1, 85, 1), (1, 3, 1, 85, 1), (64, 6, 5, 255, 2),
+    # rows beyond 8192 pixels: the chain kernel takes them in passes
+    (8300, 2, 0, 19, 2), (8300, 2, 1, 85, 1),
 ]
 
 
