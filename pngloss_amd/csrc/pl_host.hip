@@ -71,6 +71,9 @@ struct pngloss_hip_ctx {
     std::vector<SegJob> h_sj;        /* (stay alive until the asynchronous copies that read them are done: the next enqueue) */
     SegParams h_seg_params;
     int stream_wait_ok = -1;         /* hipStreamWaitValue32 usable on this device (-1: not asked yet) */
+    int seg_prio = 0;
+    bool seg_prio_distinct = false;
+
     int last_engine = 0;            /* 0 = one workgroup per image (pl_engine), 3 = segment-parallel (pl_seg) */
     long seg_attempts = 0;
 };
@@ -131,14 +134,21 @@ struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
  * takes depends on the data.  So that the entry point stays ASYNCHRONOUS, the attempts are launched by a helper thread on a stream of
  * the context's own, at most SEG_LOOKAHEAD attempts ahead of the one the device says it is working on; the caller's stream is made
  * to wait for the host-visible "images finished" word (hipStreamWaitValue32), so everything the caller enqueues behind this call
- * still runs behind the engine.  Records ev[1]/ev[2] around the engine (on the engine's stream). */
+ * still runs behind the engine.  Records ev[1]/ev[2] around the engine (on the engine's stream).
+ * (Measured and dropped: the attempts as an executable hipGraph of 16 x (parity 0, parity 1) -- 160 kernel nodes per launch call: the
+ * same engine time, and 206 - 246 ms of host CPU per 4096x4096 frame against 79 - 94 ms for the plain launches.) */
 void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
 {
-    constexpr long SEG_LOOKAHEAD = 32;
     volatile uint32_t *words = ctx->h_seg_words;
     int rc = PNGLOSS_SUCCESS;
     const size_t n = b.n;
     if (hipSetDevice(ctx->device) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    /* The engine's stream never waits for another stream ON THE DEVICE: streams share a few hardware queues, a queue is served in order,
+     * and the callers' streams hold waits for the finished words -- with twelve contexts, engine j's attempts sat behind engine k's wait
+     * for k's inputs, whose kernels sat behind caller j's wait for engine j.  So this thread waits for the inputs, on the host. */
+    if (rc == PNGLOSS_SUCCESS && hipEventSynchronize(ctx->ev_prep) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    if (rc == PNGLOSS_SUCCESS && hipEventRecord(ctx->ev[1], ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    const long lookahead = 32;                                  /* attempts queued ahead of the one the device works on */
     long launched = 0;
     auto t_last = std::chrono::steady_clock::now();
     uint32_t seen = 0;
@@ -146,7 +156,7 @@ void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
     while (rc == PNGLOSS_SUCCESS && words[0] < (uint32_t)n) {
         const uint32_t at = words[1];
         if (at != seen) { seen = at; t_last = std::chrono::steady_clock::now(); idle = 0; }
-        if (launched - (long)at > SEG_LOOKAHEAD) {
+        if (launched - (long)at > lookahead) {
             if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
                 std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress at attempt %u\n", at);
                 rc = PNGLOSS_HIP_ERROR;
@@ -161,14 +171,16 @@ void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
             rc = PNGLOSS_HIP_ERROR;
             break;
         }
-        if (pl_seg_launch_attempt(b, (int)launched, ctx->seg_stream) != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(hipGetLastError())); rc = PNGLOSS_HIP_ERROR; break; }
+        const hipError_t e = pl_seg_launch_attempt(b, (int)launched, ctx->seg_stream);
+        if (e != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(e)); rc = PNGLOSS_HIP_ERROR; break; }
         launched++;
     }
     if (hipEventRecord(ctx->ev[2], ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     if (rc != PNGLOSS_SUCCESS) {
-        /* whatever went wrong, the caller's stream must not wait for ever: drain what is queued, then release it */
-        (void)hipStreamSynchronize(ctx->seg_stream);
+        /* whatever went wrong, the caller's stream must not wait for ever: release it (the images are NOT finished: the error is
+         * reported by pngloss_hip_finish), then let what is queued drain */
         words[0] = (uint32_t)n;
+        (void)hipStreamSynchronize(ctx->seg_stream);
     }
     ctx->seg_attempts = launched;
     ctx->seg_rc.store(rc, std::memory_order_release);
@@ -178,7 +190,16 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
                    size_t jobs_off, size_t params_off, hipStream_t stream)
 {
     if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 64, hipHostMallocMapped | hipHostMallocCoherent));
-    if (!ctx->seg_stream) PL_CHECK(hipStreamCreateWithFlags(&ctx->seg_stream, hipStreamNonBlocking));
+    if (!ctx->seg_stream) {
+        /* a stream of the HIGHEST priority: streams of one priority share a few hardware queues, and a queue whose head is a caller's
+         * wait for the finished word holds up everything behind it -- the engine's attempts must never sit in such a queue (twelve
+         * contexts with twelve waiting streams deadlocked that way before this stream had a priority of its own) */
+        int least = 0, greatest = 0;
+        PL_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        ctx->seg_prio = greatest;
+        PL_CHECK(hipStreamCreateWithPriority(&ctx->seg_stream, hipStreamNonBlocking, greatest));
+        ctx->seg_prio_distinct = greatest != least;
+    }
     if (!ctx->ev_prep) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     if (ctx->stream_wait_ok < 0) {
         int can = 0;
@@ -227,19 +248,23 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
     PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
-    PL_CHECK(hipStreamWaitEvent(ctx->seg_stream, ctx->ev_prep, 0));
-    PL_CHECK(hipEventRecord(ctx->ev[1], ctx->seg_stream));
     /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */
     const long max_attempts = (long)max_h * (2 + SEG_MAX_RESTARTS * SEG_NFILT) + 1024;
     ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
-    if (ctx->stream_wait_ok) {
+    bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct;
+    if (waiting && stream) {
+        /* (a caller's stream of the engine's own priority could share its queue: no wait on that one) */
+        int prio = 0;
+        if (hipStreamGetPriority(stream, &prio) != hipSuccess || prio == ctx->seg_prio) waiting = false;
+    }
+    if (waiting) {
         /* the caller's stream goes on behind the engine: when every image has counted itself finished */
         const hipError_t e = hipStreamWaitValue32(stream, d_words, (uint32_t)n, hipStreamWaitValueGte, 0xFFFFFFFFu);
-        if (e != hipSuccess) { (void)hipGetLastError(); ctx->stream_wait_ok = 0; }
+        if (e != hipSuccess) { (void)hipGetLastError(); ctx->stream_wait_ok = 0; waiting = false; }
     }
     try { ctx->seg_worker = std::thread(seg_worker_main, ctx, b, max_attempts); }
     catch (...) { std::fprintf(stderr, "pngloss_hip: cannot start the launch thread\n"); words[0] = (uint32_t)n; return PNGLOSS_HIP_ERROR; }
-    if (!ctx->stream_wait_ok) {
+    if (!waiting) {
         /* no stream memory operations on this device: wait for the launch loop here, and order the caller's stream behind the engine's */
         ctx->seg_worker.join();
         PL_CHECK(hipStreamWaitEvent(stream, ctx->ev[2], 0));
