@@ -40,6 +40,7 @@ ALGO_BYTES_PER_PIXEL = 8
 CPU_SAMPLE_ROWS = 1024         # cpu_baseline sample: the top 4096x1024 strip of the same frame
 BUILD_CONTAINER_REFERENCE_MPX = 0.515   # the reference, one thread, full 4096x4096 frame, build container
 BATCH_FRAMES, BATCH_W, BATCH_H = 256, 1920, 1080      # BASELINE.json configs[3]
+KERNEL_STATS = "r04_kernel_trace_stats.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r04_kernel_trace_stats.txt")) else "r03_kernel_trace_stats.txt"
 
 
 def _ref_worker(frame_index):
@@ -172,12 +173,12 @@ def cpu_baseline(frame0):
 
 
 def engine_kernels():
-    """Per-kernel share of the row engine from the committed rocprofv3 kernel trace of this very command
-    (profiles/r03_kernel_trace_stats.txt): calls, average duration, share of the engine's time."""
+    """Per-kernel share of the row engine from the COMMITTED rocprofv3 kernel trace of this command (static: labelled so in the line)
+    (profiles/r0x_kernel_trace_stats.txt): calls, average duration, share of the engine's time."""
     out = {}
     try:
         import csv
-        with open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")) as fh:
+        with open(os.path.join(ROOT, "profiles", KERNEL_STATS)) as fh:
             for f in csv.reader(ln for ln in fh if not ln.startswith("#")):
                 if len(f) >= 5 and "seg_k_" in f[0] and "resolve" not in f[0]:
                     name = f[0].split("seg_k_")[1].split("(")[0]
@@ -185,7 +186,8 @@ def engine_kernels():
     except (OSError, ValueError, IndexError):
         pass
     if out:
-        out["source"] = "profiles/r03_kernel_trace_stats.txt (rocprofv3 --kernel-trace --stats of this command)"
+        out["static"] = True
+        out["source"] = "profiles/%s (a committed rocprofv3 --kernel-trace --stats run of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch --no-sweep` on the builder's GPU box: NOT measured by this invocation)" % KERNEL_STATS
     return out
 
 
@@ -196,7 +198,7 @@ def bandwidth_kernels():
     alg = {"pl_classify": 4 * W * H, "pl_hist": 4 * W * H}   # both read the 4 B/px image once
     try:
         import csv
-        with open(os.path.join(ROOT, "profiles", "r03_kernel_trace_stats.txt")) as fh:
+        with open(os.path.join(ROOT, "profiles", KERNEL_STATS)) as fh:
             for f in csv.reader(ln for ln in fh if not ln.startswith("#")):
                 for name, nbytes in alg.items():
                     if len(f) >= 5 and (name + "(" in f[0] or name + "<" in f[0]) and name not in out:
@@ -206,7 +208,8 @@ def bandwidth_kernels():
     except (OSError, ValueError, IndexError):
         pass
     if out:
-        out["source"] = "profiles/r03_kernel_trace_stats.txt (static; pl_hist is bound by its 20 LDS atomics per pixel, DESIGN.md section 11)"
+        out["static"] = True
+        out["source"] = "profiles/%s (committed rocprofv3 trace, NOT measured by this invocation; pl_hist is bound by its 20 LDS atomics per pixel, DESIGN.md section 11)" % KERNEL_STATS
     return out
 
 
@@ -234,6 +237,75 @@ def run_batch(P, S, torch, ctx_factory, rank, world, local_rank, barrier):
         recs.append(rec)
     ctx.close()
     return dt, eng, recs
+
+
+def run_sweep_8192(P, torch, ctx_factory, golden):
+    """BASELINE.json configs[4]: strength {0, 20, 40, 85} x bleed {1, 2, 8} on the 8192x8192 frame, one point after the other on one
+    GPU: Mpixels/s (wall clock of enqueue .. finish, input resident), the row engine that ran, its fraction of the HBM roofline
+    (8 B/px over the engine's time) and the reference digests of SURVEY.md Appendix B."""
+    w = h = 8192
+    base = torch.from_numpy(P.synth_rgba(w, h, MODE, 0)).cuda()
+    ctx = ctx_factory()
+    pts = []
+    stream = torch.cuda.current_stream().cuda_stream
+    for s in (0, 20, 40, 85):
+        for b in (1, 2, 8):
+            d = base.clone()
+            f = torch.zeros(h, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = ctx.run([(d.data_ptr(), f.data_ptr(), w, h)], s, b, stream=stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            g = [e for e in golden["synthetic"] if e["width"] == w and e["height"] == h and e["strength"] == s and (e["bleed"] == b or s == 0)][0]
+            info = ctx.engine_info(0)
+            ok = res[0]["status"] == 0 and "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS) == g["out"] and "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS) == g["filters"]
+            gbs = ALGO_BYTES_PER_PIXEL * w * h / (ctx.engine_ms * 1e-3) / 1e9
+            pts.append({"strength": s, "bleed": b, "value": round(w * h / dt / 1e6, 2), "engine_ms": round(ctx.engine_ms, 1), "engine": info["engine"],
+                        "attempts": info["attempts"], "epochs": info["restarts"], "walked_segments": info.get("walked_segments", 0),
+                        "roofline_frac": gbs / HBM_PEAK_GBS, "digests_match_reference": bool(ok)})
+            del d, f
+    ctx.close()
+    del base
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE.json configs[4]: one 8192x8192 synthetic RGBA8 frame, strength {0,20,40,85} x bleed {1,2,8}, one GPU, point after point",
+            "unit": "Mpixels/s", "points": pts, "min_value": min(p["value"] for p in pts), "all_on_segment_engine": all(p["engine"] == "segment-parallel" for p in pts),
+            "all_digests_match_reference": all(p["digests_match_reference"] for p in pts),
+            "note": "roofline_frac = 8 B/px * 67.1 Mpx / engine time / 8 TB/s: like the headline, bound by the row-to-row dependency, not by HBM; "
+                    "strengths whose chain-state set exceeds 1024 (85 at bleed 1 and 2, 40 at bleed 1) run the seeded enumeration (DESIGN.md section 4)"}
+
+
+def run_suite_batch(P, torch, ctx_factory, golden):
+    """BASELINE.json configs[2]: the reference's eleven suite images (tests/golden/suite_inputs.npz: what its reader makes of suite/*.png)
+    as ONE device-resident batch at s=19 b=2: whole-batch Mpixels/s, the row engine per image, reference digests."""
+    import numpy as np
+    inputs = np.load(os.path.join(ROOT, "tests", "golden", "suite_inputs.npz"))
+    names = sorted(inputs.files)
+    want = {e["image"]: e for e in golden["suite"]}
+    imgs = [inputs[n] for n in names]
+    ctx = ctx_factory()
+    stream = torch.cuda.current_stream().cuda_stream
+    best = None
+    for rep in range(3):
+        dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+        filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") for a in imgs]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = ctx.run([(d.data_ptr(), f.data_ptr(), a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)], STRENGTH, BLEED, stream=stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, ctx.engine_ms, dev, filt, res, [ctx.engine_info(i) for i in range(len(imgs))])
+    dt, eng, dev, filt, res, infos = best
+    px = sum(a.shape[0] * a.shape[1] for a in imgs)
+    per = []
+    for n, a, d, f, r, info in zip(names, imgs, dev, filt, res, infos):
+        ok = r["status"] == 0 and "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS) == want[n]["out"] and "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS) == want[n]["filters"]
+        per.append({"image": n, "size": [int(a.shape[1]), int(a.shape[0])], "bpp": r["bpp"], "engine": info["engine"], "attempts": info["attempts"], "digests_match_reference": bool(ok)})
+    ctx.close()
+    return {"workload": "BASELINE.json configs[2]: the reference's 11 suite images (2.94 Mpixels, 1/3/4 bytes per pixel) as one device-resident batch, s=19 b=2; best of 3",
+            "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "seconds": round(dt, 4), "engine_ms": round(eng, 2), "images": per,
+            "all_digests_match_reference": all(p["digests_match_reference"] for p in per)}
 
 
 SAT_FRAMES_PER_RANK, SAT_DISTINCT = 512, 32
@@ -274,6 +346,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the configs[3] batch leg and the saturating batch leg")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the configs[4] sweep (8192x8192, 12 points) and the configs[2] suite batch (rank 0, N = 1 only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -443,6 +516,12 @@ def main():
             line["cpu_baseline"] = cpu_baseline(frame)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)
             line["speedup_vs_build_container_reference"] = round(value / BUILD_CONTAINER_REFERENCE_MPX, 2)
+        if world == 1 and not args.no_sweep:
+            for key, fn in (("suite_batch", run_suite_batch), ("sweep_8192", run_sweep_8192)):
+                try:
+                    line[key] = fn(P, torch, lambda: P.HipContext(local_rank), golden)
+                except Exception as exc:          # never lose the headline to a side leg
+                    line[key] = {"error": repr(exc)}
         if batch is not None:
             bt, brecs, engs = batch
             want = {e["frame"]: e for e in golden["synthetic"] if (e["width"], e["height"]) == (BATCH_W, BATCH_H)}

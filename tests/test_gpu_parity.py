@@ -550,6 +550,95 @@ def test_multi_device_host_batch_two_contexts_on_one_device():
     assert all(np.array_equal(x, y) for x, y in zip(outs, outs1)) and all(np.array_equal(x, y) for x, y in zip(filts, filts1))
 
 
+def test_async_entry_returns_at_once_and_overlaps_host_work(torch_cuda, monkeypatch):
+    """pngloss_hip_optimize_batch_async on the segment-parallel engine (whose number of launches depends on the data): the call returns
+    in milliseconds -- a helper thread of the context feeds the attempts to the engine's own stream, the caller's stream waits for the
+    device-written finished word --, host work between _async and _finish overlaps the GPU, a kernel the caller enqueues on its stream
+    behind the call sees the finished image, and the blocking variant (devices without stream memory operations) gives the same bytes."""
+    import time
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    w, h = 2048, 1024
+    img = P.synth_rgba(w, h, 0, 0)
+    want, wf = U.run_port(img, 19, 2)
+    ctx = P.HipContext()
+    st = torch.cuda.Stream()
+    enq, fin = [], []
+    for rep in range(3):
+        d = torch.from_numpy(img.copy()).cuda()
+        f = torch.zeros(h, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.enqueue([(d.data_ptr(), f.data_ptr(), w, h)], 19, 2, stream=st.cuda_stream)
+        t1 = time.perf_counter()
+        with torch.cuda.stream(st):
+            behind = d.clone()                                # enqueued by the caller behind the batch, before _finish
+        time.sleep(0.03)                                      # host work
+        t2 = time.perf_counter()
+        res = ctx.finish()
+        t3 = time.perf_counter()
+        torch.cuda.synchronize()
+        enq.append(t1 - t0); fin.append((t3 - t2, ctx.engine_ms * 1e-3))
+        assert res[0]["status"] == 0 and ctx.engine_info(0)["engine"] == "segment-parallel"
+        assert torch.equal(behind, d), "work enqueued on the caller's stream behind the call ran before the batch had finished"
+        assert np.array_equal(d.cpu().numpy(), want) and np.array_equal(f.cpu().numpy(), wf)
+    full = d.cpu().numpy()
+    assert min(enq[1:]) < 0.005, enq                          # (the first call creates the stream and the thread; measured 0.3 ms afterwards)
+    assert all(fw < eng - 0.015 for fw, eng in fin[1:]), fin  # _finish waited for less than the engine took: the 30 ms of host work overlapped
+    ctx.close()
+    monkeypatch.setenv("PNGLOSS_HIP_NO_STREAM_WAIT", "1")
+    ctx = P.HipContext()
+    d2 = torch.from_numpy(img.copy()).cuda()
+    f2 = torch.zeros(h, dtype=torch.uint8, device="cuda")
+    ctx.run([(d2.data_ptr(), f2.data_ptr(), w, h)], 19, 2, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d2.cpu().numpy(), full) and np.array_equal(f2.cpu().numpy(), f.cpu().numpy())
+    ctx.close()
+
+
+def test_segment_engine_from_two_contexts_and_two_ranks_at_once(torch_cuda, monkeypatch, tmp_path):
+    """What one box can show of a node: the SEGMENT engine (pinned) from two contexts of the C host at once (device list "0,0": two launch
+    threads, two engine streams, two 150 KB chain kernels interleaved on one device), and from two processes (gloo ranks, one HipContext
+    each, frames of pngloss_amd.shard's split) -- digests against the oracle."""
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    imgs = [P.synth_rgba(2048, 256, m, i) for i, m in enumerate((0, 1, 0, 5))]
+    multi = P.HipMulti("0,0")
+    assert multi.count == 2
+    outs, filts, res = multi.run_host(imgs, 19, 2)
+    multi.close()
+    for a, o, f, r in zip(imgs, outs, filts, res):
+        o1, f1 = U.run_port(a, 19, 2)
+        assert r["status"] == 0 and np.array_equal(o, o1) and np.array_equal(f, f1)
+    # two ranks on the one device
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import pngloss_amd as P\n"
+        "from pngloss_amd import shard as S\n"
+        "from tests import util as U\n"
+        "rank = int(os.environ['RANK']); dist.init_process_group('gloo', rank=rank, world_size=2)\n"
+        "os.environ['PNGLOSS_HIP_ENGINE'] = 'seg'\n"
+        "mine = S.contiguous_partition(4, 2)[rank]\n"
+        "frames = [P.synth_rgba(2048, 128, 0, i) for i in mine]\n"
+        "dev = [torch.from_numpy(a.copy()).cuda() for a in frames]; flt = [torch.zeros(128, dtype=torch.uint8, device='cuda') for _ in frames]\n"
+        "ctx = P.HipContext(0)\n"
+        "dist.barrier()\n"
+        "res = ctx.run([(d.data_ptr(), f.data_ptr(), 2048, 128) for d, f in zip(dev, flt)], 19, 2)\n"
+        "assert all(r['status'] == 0 for r in res) and ctx.engine_info(0)['engine'] == 'segment-parallel'\n"
+        "for a, d, f in zip(frames, dev, flt):\n"
+        "    o1, f1 = U.run_port(a, 19, 2)\n"
+        "    assert np.array_equal(d.cpu().numpy(), o1) and np.array_equal(f.cpu().numpy(), f1)\n"
+        "recs = S.gather_records([dict(index=i) for i in mine])\n"
+        "if rank == 0: assert sorted(r['index'] for r in recs) == [0, 1, 2, 3]; print('two ranks ok')\n"
+        "dist.destroy_process_group()\n") % U.ROOT
+    script = tmp_path / "two_ranks.py"
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29579", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "two ranks ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
 def test_every_visible_device_takes_part_when_there_are_several(tmp_path):
     """The REAL multi-device branch (the "0,0" test above shares one GPU): with two or more visible devices, HipMulti(None) opens one
     context per device and every one must come back with its share, bit-exact; and a 2-rank bench.py under torch.distributed.run (RCCL)
