@@ -140,7 +140,7 @@ struct PlEngineParams {
 };
 
 hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
-hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream);
+hipError_t pl_launch_engine(const PlJob *d_jobs, const uint32_t *d_sel, size_t n, PlEngineParams prm, hipStream_t stream);   /* d_sel: n job indices, or null = jobs 0..n-1 */
 int pl_engine_occupancy(void);   /* workgroups of the row engine per CU according to the HIP occupancy query */
 hipError_t pl_launch_finish(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 hipError_t pl_launch_emit(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);

@@ -1519,7 +1519,7 @@ __device__ __forceinline__ PlSplit split_at(const uint4 *cd, long sx, uint32_t W
 #define PL_SM_COMMIT_BYTES (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES)   /* what the commit pass may use of the chains' region */
 #define PL_SM_TOTAL (4096 + PL_SM_UNION + (PL_SM_LEAD_BYTES > PL_SM_LEGACY_BYTES ? PL_SM_LEAD_BYTES : PL_SM_LEGACY_BYTES))
 
-__global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs, PlEngineParams prm)
+__global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs, const uint32_t *sel, PlEngineParams prm)
 {
     /* LDS carve-up (dynamic: the band-leader tables push the total past the 64 KB static limit; gfx950 has 160 KB) */
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1545,7 +1545,7 @@ __global__ __launch_bounds__(PL_ENGINE_THREADS) void pl_engine(const PlJob *jobs
     unsigned char *const lrec = smem + PL_SM_UNION + PL_SM_L_REC;
     uint2 *const lout = (uint2 *)(smem + PL_SM_UNION + PL_SM_L_OUT);
 
-    const PlJob j = jobs[blockIdx.x];
+    const PlJob j = jobs[sel ? sel[blockIdx.x] : blockIdx.x];   /* (sel: the images of a mixed batch that take this engine) */
     const uint32_t W = j.width, H = j.height;
     const uint32_t bpp = pl_job_bpp(j);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1899,7 +1899,7 @@ int pl_engine_occupancy(void)
     return n;
 }
 
-hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, hipStream_t stream)
+hipError_t pl_launch_engine(const PlJob *d_jobs, const uint32_t *d_sel, size_t n, PlEngineParams prm, hipStream_t stream)
 {
     if (!n) return hipSuccess;
     {   /* the attribute belongs to the function ON THE CURRENT DEVICE: remembered per device (a node has up to 8) */
@@ -1917,6 +1917,6 @@ hipError_t pl_launch_engine(const PlJob *d_jobs, size_t n, PlEngineParams prm, h
             if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(pl_engine, dim3((unsigned)n), dim3(PL_ENGINE_THREADS), PL_SM_TOTAL, stream, d_jobs, prm);
+    hipLaunchKernelGGL(pl_engine, dim3((unsigned)n), dim3(PL_ENGINE_THREADS), PL_SM_TOTAL, stream, d_jobs, d_sel, prm);
     return hipGetLastError();
 }

@@ -66,9 +66,11 @@ struct pngloss_hip_ctx {
      * data): the caller's stream waits for the "images finished" word instead of for the host */
     hipStream_t seg_stream = nullptr;
     hipEvent_t ev_prep = nullptr;    /* caller's stream: everything the engine reads is in place */
+    hipEvent_t ev_seg_done = nullptr;/* engine's stream: behind the last attempt the launch thread enqueued */
     std::thread seg_worker;
     std::atomic<int> seg_rc{ 0 };
     std::vector<SegJob> h_sj;        /* (stay alive until the asynchronous copies that read them are done: the next enqueue) */
+    std::vector<uint32_t> h_sel;
     SegParams h_seg_params;
     int stream_wait_ok = -1;         /* hipStreamWaitValue32 usable on this device (-1: not asked yet) */
     int seg_prio = 0;
@@ -134,7 +136,7 @@ struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
  * takes depends on the data.  So that the entry point stays ASYNCHRONOUS, the attempts are launched by a helper thread on a stream of
  * the context's own, at most SEG_LOOKAHEAD attempts ahead of the one the device says it is working on; the caller's stream is made
  * to wait for the host-visible "images finished" word (hipStreamWaitValue32), so everything the caller enqueues behind this call
- * still runs behind the engine.  Records ev[1]/ev[2] around the engine (on the engine's stream).
+ * still runs behind the engine.  (The images of a mixed batch that the other engine takes run on the caller's stream meanwhile.)
  * (Measured and dropped: the attempts as an executable hipGraph of 16 x (parity 0, parity 1) -- 160 kernel nodes per launch call: the
  * same engine time, and 206 - 246 ms of host CPU per 4096x4096 frame against 79 - 94 ms for the plain launches.) */
 void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
@@ -147,7 +149,6 @@ void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
      * and the callers' streams hold waits for the finished words -- with twelve contexts, engine j's attempts sat behind engine k's wait
      * for k's inputs, whose kernels sat behind caller j's wait for engine j.  So this thread waits for the inputs, on the host. */
     if (rc == PNGLOSS_SUCCESS && hipEventSynchronize(ctx->ev_prep) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
-    if (rc == PNGLOSS_SUCCESS && hipEventRecord(ctx->ev[1], ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     const long lookahead = 32;                                  /* attempts queued ahead of the one the device works on */
     long launched = 0;
     auto t_last = std::chrono::steady_clock::now();
@@ -175,7 +176,7 @@ void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
         if (e != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(e)); rc = PNGLOSS_HIP_ERROR; break; }
         launched++;
     }
-    if (hipEventRecord(ctx->ev[2], ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    if (hipEventRecord(ctx->ev_seg_done, ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     if (rc != PNGLOSS_SUCCESS) {
         /* whatever went wrong, the caller's stream must not wait for ever: release it (the images are NOT finished: the error is
          * reported by pngloss_hip_finish), then let what is queued drain */
@@ -186,9 +187,10 @@ void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
     ctx->seg_rc.store(rc, std::memory_order_release);
 }
 
-int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const SegParams &params, const std::vector<size_t> &seg_offs,
-                   size_t jobs_off, size_t params_off, hipStream_t stream)
+int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<uint32_t> &list, const SegParams &params, const std::vector<size_t> &seg_offs,
+                   size_t jobs_off, size_t params_off, hipStream_t stream, const uint32_t *d_sel, size_t n_wg, const PlEngineParams &prm)
 {
+    const size_t n = list.size();                              /* the images of the batch this engine takes */
     if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 64, hipHostMallocMapped | hipHostMallocCoherent));
     if (!ctx->seg_stream) {
         /* a stream of the HIGHEST priority: streams of one priority share a few hardware queues, and a queue whose head is a caller's
@@ -201,6 +203,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
         ctx->seg_prio_distinct = greatest != least;
     }
     if (!ctx->ev_prep) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    if (!ctx->ev_seg_done) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_seg_done, hipEventDisableTiming));
     if (ctx->stream_wait_ok < 0) {
         int can = 0;
         ctx->stream_wait_ok = (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can) ? 1 : 0;
@@ -215,10 +218,11 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     PlSegBatch b{};
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) {
-        const PlJob &pj = ctx->h_jobs[i];
+        const PlJob &pj = ctx->h_jobs[list[i]];
         const PlSegLayout l = pl_seg_layout(pj.width ? pj.width : 1, (uint32_t)params.nsp, params.seeded != 0);
         char *base = ctx->d_ws + seg_offs[i];
         SegJob &s = ctx->h_sj[i];
+        s.job_index = list[i];
         s.img = pj.img; s.row_filters = pj.row_filters; s.row_ids = pj.row_ids; s.W = pj.width; s.H = pj.height; s.bpp = 0;
         s.orig_rank = pj.orig_rank; s.cand = reinterpret_cast<uint32_t *>(pj.cand);
         s.err0 = reinterpret_cast<uint32_t *>(pj.err0); s.err1 = reinterpret_cast<uint32_t *>(pj.err1);
@@ -248,6 +252,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
     PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
+    if (n_wg) PL_CHECK(pl_launch_engine(d_jobs, d_sel, n_wg, prm, stream));      /* (a mixed batch: the other engine's images, side by side with this one's) */
     /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */
     const long max_attempts = (long)max_h * (2 + SEG_MAX_RESTARTS * SEG_NFILT) + 1024;
     ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
@@ -267,7 +272,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, size_t n, const Se
     if (!waiting) {
         /* no stream memory operations on this device: wait for the launch loop here, and order the caller's stream behind the engine's */
         ctx->seg_worker.join();
-        PL_CHECK(hipStreamWaitEvent(stream, ctx->ev[2], 0));
+        PL_CHECK(hipStreamWaitEvent(stream, ctx->ev_seg_done, 0));
         if (ctx->seg_rc.load(std::memory_order_acquire)) return ctx->seg_rc.load();
     }
     return PNGLOSS_SUCCESS;
@@ -298,47 +303,72 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         offs.push_back(total);
         total += image_ws(images[i].width ? images[i].width : 1, images[i].height).total;
     }
-    /* Which row engine: one workgroup per image (pl_engine: batches) or the whole GPU on few images (pl_seg: latency).  The segment
-     * engine takes every strength / bleed pair and rows up to SEG_MAX_WIDTH pixels; it pays off while the batch leaves it the machine
-     * (its work per row is ~250x redundant by design). */
+    /* Which row engine, IMAGE BY IMAGE: one workgroup for the image (pl_engine: batches, narrow images) or the image spread over the
+     * whole GPU (pl_seg: few wide images).  The segment engine takes every strength / bleed pair and rows up to SEG_MAX_WIDTH pixels;
+     * it pays off while the batch leaves it the machine (its work per row is ~250x redundant by design).  In a mixed batch the two
+     * engines run side by side -- the segment engine's images in one launch sequence (blockIdx.y = image) on the engine's own stream,
+     * the others as one workgroup each on the caller's.
+     * Cost model (measured on 1 .. 64 frames of 512x512 and 1920x1080, tests/tools/gpu_seg_batch.py): a row
+     * attempt of the segment engine takes ~51 us plus ~0.032 us per workgroup of its widest kernel (about 3 per segment and 40 more per
+     * image), whatever the width, and there are as many attempts as the tallest of its images has rows; the workgroup engine ~0.18 us
+     * per pixel of its largest image, all images side by side (256 CUs).  State sets beyond the lanes (s = 85 at bleed 1 or 2 ...) are
+     * enumerated from seeds with a run-in of one segment: about twice the enumeration and a wider chain.  Greedy: the images go to the
+     * segment engine in the order of their cost on the other one, as long as that shortens the batch. */
     SegParams seg_params;
-    bool use_seg = false;
-    uint32_t seg_max_nseg = 1;
+    std::vector<uint8_t> on_seg(n, 0);
+    size_t n_seg = 0;
     {
         const char *em = std::getenv("PNGLOSS_HIP_ENGINE");
-        std::vector<uint32_t> widths(n);
-        for (size_t i = 0; i < n; i++) { widths[i] = images[i].width; seg_max_nseg = std::max(seg_max_nseg, (images[i].width + SEG_L - 1) / SEG_L); }
         const bool forced = em && std::strcmp(em, "seg") == 0;
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
-        /* Cost model (measured on 1 .. 64 frames of 512x512 and 1920x1080, tests/tools/gpu_seg_batch.py): a row
-         * attempt of the segment engine takes ~51 us plus ~0.032 us per workgroup of its widest kernel (about 3 per segment and 40
-         * more per image), whatever the width; the workgroup engine ~0.18 us per pixel of its largest image, all images side by
-         * side.  So: wide images and small batches to the former, narrow images (< ~400 pixels) and large batches to the latter. */
-        bool worth = forced;
-        if (!worth && n * (size_t)seg_max_nseg <= 4096) {
-            double wg_us = 0, seg_rows = 0, seg_wgs = 0;
-            for (size_t i = 0; i < n; i++) {
-                wg_us = std::max(wg_us, 0.18 * (double)images[i].width * (double)images[i].height);
-                seg_rows = std::max(seg_rows, (double)images[i].height);
-                seg_wgs += 3.0 * ((images[i].width + SEG_L - 1) / SEG_L) + 40.0;
+        bool seg_ok = n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
+        if (seg_ok) {
+            const double a_us = seg_params.seeded ? 95.0 : 51.0, w_us = seg_params.seeded ? 0.05 : 0.032;
+            auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
+            std::vector<size_t> order;
+            for (size_t i = 0; i < n; i++)
+                if (images[i].width && images[i].height && images[i].width <= SEG_MAX_WIDTH) order.push_back(i);
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return wg_cost(x) > wg_cost(y); });
+            if (forced) { for (size_t i : order) on_seg[i] = 1; n_seg = order.size(); }
+            else {
+                /* wg side: the largest image left sets its time (or the sum over 256 CUs when there are more images than CUs) */
+                double wg_sum = 0;
+                for (size_t i = 0; i < n; i++) wg_sum += wg_cost(i);
+                double seg_rows = 0, seg_wgs = 0, seg_segs = 0;
+                auto batch_us = [&](size_t k, double rows, double wgs, double wsum) {   /* the first k images of `order` on the segment engine */
+                    const double wg_us = k < order.size() ? std::max(wg_cost(order[k]), wsum / 256.0) : wsum / 256.0;
+                    return std::max(wg_us, k ? rows * (a_us + w_us * wgs) : 0.0);
+                };
+                double best = batch_us(0, 0, 0, wg_sum);
+                size_t best_k = 0;
+                double wsum = wg_sum;
+                for (size_t k = 1; k <= order.size(); k++) {
+                    const size_t i = order[k - 1];
+                    seg_rows = std::max(seg_rows, (double)images[i].height);
+                    seg_wgs += 3.0 * ((images[i].width + SEG_L - 1) / SEG_L) + 40.0;
+                    seg_segs += (images[i].width + SEG_L - 1) / SEG_L;
+                    wsum -= wg_cost(i);
+                    if (seg_segs > 4096) break;
+                    const double t = batch_us(k, seg_rows, seg_wgs, wsum);
+                    if (t < best) { best = t; best_k = k; }
+                }
+                for (size_t k = 0; k < best_k; k++) on_seg[order[k]] = 1;
+                n_seg = best_k;
             }
-            /* (state sets beyond the lanes -- s = 85 at bleed 1 or 2 ... -- are enumerated from seeds with a run-in of one segment: about twice
-             * the enumeration and a wider chain, measured 150 - 190 us per attempt at 8192 pixels against 85 for s = 20) */
-            const bool seeded = pl_seg_supported(nullptr, 0, strength, bleed, &seg_params) && seg_params.seeded;
-            const double seg_us = seg_rows * (seeded ? 95.0 + 0.05 * seg_wgs : 51.0 + 0.032 * seg_wgs);
-            worth = seg_us < wg_us;
         }
-        if (n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && worth)
-            use_seg = pl_seg_supported(widths.data(), n, strength, bleed, &seg_params);
-        if (forced && !use_seg && n)
-            std::fprintf(stderr, "pngloss_hip: PNGLOSS_HIP_ENGINE=seg: a width beyond %u is not covered by the segment engine; using the one-workgroup-per-image engine\n", SEG_MAX_WIDTH);
+        if (forced && !n_seg && n)
+            std::fprintf(stderr, "pngloss_hip: PNGLOSS_HIP_ENGINE=seg: nothing in this batch for the segment engine (widths beyond %u?); using the one-workgroup-per-image engine\n", SEG_MAX_WIDTH);
     }
+    const bool use_seg = n_seg != 0;
+    std::vector<uint32_t> seg_list, wg_list;
+    for (size_t i = 0; i < n; i++) (on_seg[i] ? seg_list : wg_list).push_back((uint32_t)i);
     std::vector<size_t> seg_offs;
-    size_t seg_jobs_off = 0, seg_params_off = 0;
+    size_t seg_jobs_off = 0, seg_params_off = 0, sel_off = 0;
     if (use_seg) {
-        seg_jobs_off = total; total += align_up(sizeof(SegJob) * n, 256);
+        seg_jobs_off = total; total += align_up(sizeof(SegJob) * n_seg, 256);
         seg_params_off = total; total += align_up(sizeof(SegParams), 256);
-        for (size_t i = 0; i < n; i++) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1, (uint32_t)seg_params.nsp, seg_params.seeded != 0).total; }
+        sel_off = total; total += align_up(sizeof(uint32_t) * (wg_list.size() ? wg_list.size() : 1), 256);
+        for (uint32_t i : seg_list) { seg_offs.push_back(total); total += pl_seg_layout(images[i].width ? images[i].width : 1, (uint32_t)seg_params.nsp, seg_params.seeded != 0).total; }
     }
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
@@ -394,16 +424,22 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
     PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));
     ctx->last_engine = use_seg ? 3 : 0;
+    PL_CHECK(hipEventRecord(ctx->ev[1], stream));
+    /* the images of the one-workgroup-per-image engine: all of them, or -- a mixed batch -- those the segment engine did not get; they
+     * run on the caller's stream while the segment engine works on its own */
+    const uint32_t *d_sel = nullptr;
+    if (use_seg && !wg_list.empty()) {
+        ctx->h_sel = wg_list;
+        PL_CHECK(hipMemcpyAsync(ctx->d_ws + sel_off, ctx->h_sel.data(), sizeof(uint32_t) * wg_list.size(), hipMemcpyHostToDevice, stream));
+        d_sel = reinterpret_cast<const uint32_t *>(ctx->d_ws + sel_off);
+    }
     if (use_seg) {
         if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) seg_params.engine_flags = (std::atoi(ff) + 1) << 8;   /* debugging aid */
         if (std::getenv("PNGLOSS_HIP_SEGPROF")) seg_params.engine_flags |= 1;                                                   /* phase clocks of the validation kernel */
-        rc = run_seg_engine(ctx, d_jobs, n, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream);
+        rc = run_seg_engine(ctx, d_jobs, seg_list, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream, d_sel, wg_list.size(), prm);
         if (rc) return rc;
-    } else {
-    PL_CHECK(hipEventRecord(ctx->ev[1], stream));
-    PL_CHECK(pl_launch_engine(d_jobs, n, prm, stream));
+    } else PL_CHECK(pl_launch_engine(d_jobs, nullptr, n, prm, stream));
     PL_CHECK(hipEventRecord(ctx->ev[2], stream));
-    }
     {
         /* (behind this point the segment engine's launch thread may be running: it is joined before an error is returned) */
         hipError_t e = pl_launch_finish(d_jobs, ctx->h_jobs.data(), n, stream);
@@ -654,6 +690,7 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     if (ctx->pending) (void)hipEventSynchronize(ctx->ev[3]);
     if (ctx->seg_stream) { (void)hipStreamSynchronize(ctx->seg_stream); (void)hipStreamDestroy(ctx->seg_stream); }
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+    if (ctx->ev_seg_done) (void)hipEventDestroy(ctx->ev_seg_done);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);

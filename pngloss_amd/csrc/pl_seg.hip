@@ -25,7 +25,7 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        sj[i].bpp = pl_job_bpp(jobs[i]);
+        sj[i].bpp = pl_job_bpp(jobs[sj[i].job_index]);
         sj[i].ctl[1].magic = 0u;          /* the image's first attempt (parity 0) finds no control block behind it */
     }
 }

@@ -252,6 +252,7 @@ struct SegJob {
     SEG_AS_GLB uint8_t *row_ids;
     uint32_t W, H;
     uint32_t bpp;             /* resolved by the launcher kernel (seg_resolve) / the host harness */
+    uint32_t job_index;       /* which image of the batch (a mixed batch gives this engine a subset) */
     const SEG_AS_GLB uint32_t *orig_rank;/* [5][256] */
     SEG_AS_GLB uint32_t *cand;           /* [5][W][4]: byte | (diff16 & 0xffff) << 8 | bin << 24 */
     SEG_AS_GLB uint32_t *err0, *err1;    /* [W][2]: 4 x int16 */
@@ -1444,94 +1445,120 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
         }
         PLS_SYNC();
         if (prof) tc[2] = PLS_CLOCK();
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            if ((uint32_t)tid < nblk) {
-                /* thread b: the true id at the head of block b (across the composed tables), then through the block.  Every lane walks the
-                 * heads of ALL blocks (the same chain of loads in every lane: no lane-dependent loop) and keeps its own */
-                uint32_t g = idxb[28] < stride ? idxb[28] : gdummy, gm = g;
-                for (uint32_t b = 0; b + 1 < nblk; b++) { g = (uint32_t)G[g]; gm = b + 1 == (uint32_t)tid ? g : gm; }
-                uint32_t i = gm == gdummy ? dummy : ((((uint32_t)tid * SEG_CBLK) << sh) | (gm & smask));
-                uint32_t at[SEG_CBLK];
-                PLS_UNROLL
-                for (int q = 0; q < SEG_CBLK; q++) { at[q] = i; i = (uint32_t)T[i]; }      /* (rows behind table ntr - 1 lead to the absorbing cell) */
-                PLS_UNROLL
-                for (int q = 0; q < SEG_CBLK; q++) {
-                    const uint32_t k = (uint32_t)tid * SEG_CBLK + (uint32_t)q;
-                    if (k < npos) dn[k] = at[q] == dummy ? (uint32_t)SEG_INVALID : (at[q] & smask);
+        /* -- walk: from position pos0 of the pass (0; behind a repair: the position behind the walked segment -- the tables gathered for the
+         *    pass are still good, only the walk is done again from there), whose id is idxb[28] and whose entry state idxb[26] -- */
+        uint32_t pos0 = 0;
+        bool done = false, next_pass = false;
+        for (;;) {
+            const uint32_t bq = pos0 / SEG_CBLK, off = pos0 % SEG_CBLK;
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+                if ((uint32_t)tid >= bq && (uint32_t)tid < nblk) {
+                    /* thread b: the true id at the head of block b (across the composed tables), then through the block.  Every lane walks the
+                     * heads of ALL blocks (the same chain of loads in every lane: no lane-dependent loop) and keeps its own */
+                    const uint32_t sid = idxb[28];
+                    uint32_t g, b0 = bq;
+                    if (off == 0u) g = sid < stride ? ((bq << sh) | sid) : gdummy;
+                    else {
+                        /* (behind a repair) first to the end of the block the walk starts inside: the same chain in every lane, lane bq keeps it */
+                        uint32_t i = sid < stride ? ((pos0 << sh) | sid) : dummy;
+                        for (uint32_t q = off; q < SEG_CBLK; q++) {
+                            const uint32_t k = bq * SEG_CBLK + q;
+                            if ((uint32_t)tid == bq && k < npos) dn[k] = i == dummy ? (uint32_t)SEG_INVALID : (i & smask);
+                            i = (uint32_t)T[i];
+                        }
+                        b0 = bq + 1u;
+                        g = i == dummy ? gdummy : ((b0 << sh) | (i & smask));
+                    }
+                    uint32_t gm = g;
+                    for (uint32_t b = b0; b + 1 < nblk; b++) { g = (uint32_t)G[g]; gm = b + 1 == (uint32_t)tid ? g : gm; }
+                    if ((uint32_t)tid >= b0) {
+                        uint32_t i = gm == gdummy ? dummy : ((((uint32_t)tid * SEG_CBLK) << sh) | (gm & smask));
+                        uint32_t at[SEG_CBLK];
+                        PLS_UNROLL
+                        for (int q = 0; q < SEG_CBLK; q++) { at[q] = i; i = (uint32_t)T[i]; }      /* (rows behind table ntr - 1 lead to the absorbing cell) */
+                        PLS_UNROLL
+                        for (int q = 0; q < SEG_CBLK; q++) {
+                            const uint32_t k = (uint32_t)tid * SEG_CBLK + (uint32_t)q;
+                            if (k < npos) dn[k] = at[q] == dummy ? (uint32_t)SEG_INVALID : (at[q] & smask);
+                        }
+                    }
                 }
             }
-        }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            /* ids out; entry state of position k+1 = exit state of position k under its id */
-            for (uint32_t k = (uint32_t)tid; k < npos; k += SEG_CHAIN_THREADS) {
-                uint32_t d = dn[k];
-                if ((eflags & 2) && k >= 1u) d = SEG_INVALID;                       /* (test hook: every second segment through the repair) */
-                const uint32_t sg = s0 + a + k;
-                if (d == SEG_INVALID) { PLS_ATOMIC_MIN(&idxb[25], k); continue; }
-                dnout[(size_t)sg * 4] = (uint16_t)d;
-                if (k >= ntr) continue;
-                uint32_t ps = SEG_NOSTATE;
-                if (useR) ps = R[(k << SEG_CR_SH) + d];
-                else if (d < dcnt[(size_t)sg * 4]) ps = rst[(size_t)sg * rstep32 + d];
-                entL[k + 1u] = ps;
-                if (ps != SEG_NOSTATE) entry[(size_t)(sg + 1u) * 4] = ps;
-            }
-        }
-        PLS_SYNC();
-        if (prof) { tc[3] = PLS_CLOCK(); for (int q = 0; q < 3; q++) tacc[q] += tc[q + 1] - tc[q]; }
-        uint32_t fb = idxb[25];
-        if (fb == 0xFFFFFFFFu) {
-            /* the whole pass has ids: the next one starts at its landing position */
-            const uint32_t nd = dn[ntr], ne_ = entL[ntr];
             PLS_SYNC();
-            a += ntr;
-            first_iter = false;
-            if (a >= ns) break;                                    /* (the landing position was the row's last segment: its id is out) */
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { idxb[28] = nd; idxb[26] = ne_; } }
-            PLS_SYNC();
-            continue;
-        }
-        /* -- repair: position fb has no id (its entry state is not in the segment's entry set) -- or position fb - 1 has an id but no exit
-         *    state (its lane left what the tables cover).  That segment is walked step by step from its entry state. -- */
-        if (fb > 0u && entL[fb] == SEG_NOSTATE) fb--;
-        const uint32_t est = fb ? entL[fb] : idxb[26];
-        const bool have_tables = idxb[31] != 0u;
-        PLS_SYNC();
-        const uint32_t kq = a + fb, sgq = s0 + kq;                  /* the position and the segment walked */
-        const uint32_t xq = sgq * SEG_L;
-        SegPix *pxr = (SegPix *)(uint32_t *)(twr + SEG_TBL_WORDS);  /* [SEG_L + 1] */
-        const SegGeo G_ = seg_geo((int)cv.s);
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            if (!have_tables) {
-                for (int i = tid; i < SEG_TBL_WORDS; i += SEG_CHAIN_THREADS) twr[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
-                if (tid < 256) seg_load_frozen(j, par, f, (uint32_t *)Hf, (uint32_t *)rank, tid, 256);
-                if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
-            }
-            if (tid >= 768 && tid < 768 + SEG_L) pxr[tid - 768] = seg_pix_load(row, nab, j.err0, bpp, seg_umin(xq + (uint32_t)(tid - 768), W - 1u), c);
-            if (tid == 0) { SEG_DEBUG_COUNT(2, fb); SEG_DEBUG_REPAIR(f, c, sgq, est, idxb[28]); idxb[31] = 1u; idxb[24]++; dnout[(size_t)sgq * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgq * 4] = est; }
-        }
-        PLS_SYNC();
-        if (kq >= ns) break;                                       /* the row's last segment: the replay walks it from its entry state, nothing follows */
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
-            if (tid == 0) {
-                SegState st = seg_state_unpack(est);
-                seg_walk(f, pxr, 1, xq, xq + SEG_L, st, SEG_LDS_CU32(twr), SEG_LDS_CU32(lut), (const uint32_t *)Hf, (const uint32_t *)rank, G_, (const uint32_t *)lut, P.bleed, nullptr, nullptr);
-                const uint32_t nps = seg_state_pack(st);
-                uint32_t nid = SEG_INVALID;
-                if (seeded) nid = seg_eh_lookup(ehash + (size_t)(sgq + 1u) * estep32, seg_eh_key(st.left, st.cn, st.th));
-                else {
-                    const uint32_t idx = seg_any_encode(P, f, pxr[SEG_L - 1], st);
-                    if (idx != SEG_INVALID && (int)idx < nstates) nid = (uint32_t)maps[(size_t)(sgq + 1u) * mstep32 + idx];
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+                /* ids out; entry state of position k+1 = exit state of position k under its id */
+                for (uint32_t k = pos0 + (uint32_t)tid; k < npos; k += SEG_CHAIN_THREADS) {
+                    uint32_t d = dn[k];
+                    if ((eflags & 2) && k >= pos0 + 1u) d = SEG_INVALID;                  /* (test hook: every second segment through the repair) */
+                    const uint32_t sg = s0 + a + k;
+                    if (d == SEG_INVALID) { PLS_ATOMIC_MIN(&idxb[25], k); continue; }
+                    dnout[(size_t)sg * 4] = (uint16_t)d;
+                    if (k >= ntr) continue;
+                    uint32_t ps = SEG_NOSTATE;
+                    if (useR) ps = R[(k << SEG_CR_SH) + d];
+                    else if (d < dcnt[(size_t)sg * 4]) ps = rst[(size_t)sg * rstep32 + d];
+                    entL[k + 1u] = ps;
+                    if (ps != SEG_NOSTATE) entry[(size_t)(sg + 1u) * 4] = ps;
                 }
-                if (nid >= SEG_NSP || nid >= dcnt[(size_t)(sgq + 1u) * 4]) nid = SEG_INVALID;
-                entry[(size_t)(sgq + 1u) * 4] = nps;
-                idxb[26] = nps; idxb[28] = nid;
             }
+            PLS_SYNC();
+            if (prof && pos0 == 0u) { tc[3] = PLS_CLOCK(); for (int q = 0; q < 3; q++) tacc[q] += tc[q + 1] - tc[q]; }
+            uint32_t fb = idxb[25];
+            if (fb == 0xFFFFFFFFu) {
+                /* the rest of the pass has ids: the next one starts at its landing position */
+                const uint32_t nd = dn[ntr], ne_ = entL[ntr];
+                PLS_SYNC();
+                a += ntr;
+                if (a >= ns) { done = true; break; }                   /* (the landing position was the row's last segment: its id is out) */
+                PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { idxb[28] = nd; idxb[26] = ne_; } }
+                PLS_SYNC();
+                next_pass = true;
+                break;
+            }
+            /* -- repair: position fb has no id (its entry state is not in the segment's entry set) -- or position fb - 1 has an id but no exit
+             *    state (its lane left what the tables cover).  That segment is walked step by step from its entry state. -- */
+            if (fb > pos0 && entL[fb] == SEG_NOSTATE) fb--;
+            const uint32_t est = fb > pos0 ? entL[fb] : idxb[26];
+            const bool have_tables = idxb[31] != 0u;
+            PLS_SYNC();
+            const uint32_t kq = a + fb, sgq = s0 + kq;                  /* the position and the segment walked */
+            const uint32_t xq = sgq * SEG_L;
+            SegPix *pxr = (SegPix *)(uint32_t *)(twr + SEG_TBL_WORDS);  /* [SEG_L + 1] */
+            const SegGeo G_ = seg_geo((int)cv.s);
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+                if (!have_tables) {
+                    for (int i = tid; i < SEG_TBL_WORDS; i += SEG_CHAIN_THREADS) twr[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+                    if (tid < 256) seg_load_frozen(j, par, f, (uint32_t *)Hf, (uint32_t *)rank, tid, 256);
+                    if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
+                }
+                if (tid >= 768 && tid < 768 + SEG_L) pxr[tid - 768] = seg_pix_load(row, nab, j.err0, bpp, seg_umin(xq + (uint32_t)(tid - 768), W - 1u), c);
+                if (tid == 0) { SEG_DEBUG_COUNT(2, fb); SEG_DEBUG_REPAIR(f, c, sgq, est, idxb[28]); idxb[31] = 1u; idxb[24]++; idxb[25] = 0xFFFFFFFFu; dnout[(size_t)sgq * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgq * 4] = est; }
+            }
+            PLS_SYNC();
+            if (kq >= ns) { done = true; break; }                      /* the row's last segment: the replay walks it from its entry state, nothing follows */
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+                if (tid == 0) {
+                    SegState st = seg_state_unpack(est);
+                    seg_walk(f, pxr, 1, xq, xq + SEG_L, st, SEG_LDS_CU32(twr), SEG_LDS_CU32(lut), (const uint32_t *)Hf, (const uint32_t *)rank, G_, (const uint32_t *)lut, P.bleed, nullptr, nullptr);
+                    const uint32_t nps = seg_state_pack(st);
+                    uint32_t nid = SEG_INVALID;
+                    if (seeded) nid = seg_eh_lookup(ehash + (size_t)(sgq + 1u) * estep32, seg_eh_key(st.left, st.cn, st.th));
+                    else {
+                        const uint32_t idx = seg_any_encode(P, f, pxr[SEG_L - 1], st);
+                        if (idx != SEG_INVALID && (int)idx < nstates) nid = (uint32_t)maps[(size_t)(sgq + 1u) * mstep32 + idx];
+                    }
+                    if (nid >= SEG_NSP || nid >= dcnt[(size_t)(sgq + 1u) * 4]) nid = SEG_INVALID;
+                    entry[(size_t)(sgq + 1u) * 4] = nps;
+                    idxb[26] = nps; idxb[28] = nid;
+                }
+            }
+            PLS_SYNC();
+            if (fb + 1u > ntr) { a = kq + 1u; next_pass = true; break; }   /* (the walked segment was the pass's landing position: the next pass starts behind it) */
+            pos0 = fb + 1u;                                                /* the pass's tables hold what lies behind: walk on from there */
         }
-        PLS_SYNC();
-        a = kq + 1u;
         first_iter = false;
+        if (done) break;
+        (void)next_pass;
     }
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         if (tid == 0) {
