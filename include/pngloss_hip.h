@@ -239,6 +239,10 @@ typedef struct {
 } pngloss_hip_png_source;
 
 int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n);
+/* The same with a status per image (status: n ints or NULL): every image is decoded and downloaded whatever happens to the others, a damaged
+ * one gets 25 in its slot (an internal failure PNGLOSS_HIP_ERROR) and the call returns the worst code -- the reference, too, fails only the
+ * damaged file (/root/reference/src/pngloss.c:196-204).  Not while a batch is in flight on the context (PNGLOSS_INVALID_ARGUMENT). */
+int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status);
 
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image

@@ -49,14 +49,23 @@ bool png_stream_read(const char *path, png_stream_source *out)
                 out->bit_depth = body[8]; out->color_type = body[9];
                 if (body[10] != 0 || body[11] != 0 || body[12] != 0) { bad = true; break; }      /* interlace (Adam7): libpng's */
                 if (!out->width || !out->height || out->width > 0x7fffffffu / 8 || out->height > 0x7fffffffu / 8) { bad = true; break; }
+                /* libpng's own user limits (1,000,000 each way) and the reference's size check (rwpng.c:287: rowbytes > INT_MAX / height) stay
+                 * libpng's and the reference's to report */
+                if (out->width > 1000000u || out->height > 1000000u || (uint64_t)out->width * 4u > (uint64_t)0x7fffffff / out->height) { bad = true; break; }
             } else if (memcmp(tag, "PLTE", 4) == 0) {
                 if (seen_idat || n % 3 || n > 768 || out->palette_entries) { bad = true; break; }
                 memcpy(out->palette, body, n); out->palette_entries = n / 3;
             } else if (memcmp(tag, "tRNS", 4) == 0) {
                 if (seen_idat || n > 256 || out->has_trns) { bad = true; break; }
+                /* libpng discards as benign errors: a tRNS in front of the PLTE of a palette image, one with more entries than the palette,
+                 * one of the wrong length for gray (2) or RGB (6) -- such files are read by libpng, which knows what it does with them */
+                if (out->color_type == 3 && (!out->palette_entries || n > out->palette_entries)) { bad = true; break; }
+                if ((out->color_type == 0 && n != 2) || (out->color_type == 2 && n != 6)) { bad = true; break; }
                 memcpy(out->trns, body, n); out->trns_bytes = n; out->has_trns = true;
             } else if (memcmp(tag, "gAMA", 4) == 0) {
                 if (seen_idat || n != 4 || out->has_gama) { bad = true; break; }
+                /* (a gAMA behind the PLTE, or of value 0, is ignored by libpng: the reference then keeps its default tag) */
+                if (out->palette_entries || be32(body) == 0) { bad = true; break; }
                 out->has_gama = true; out->gamma = be32(body) / 100000.0;
             } else if (memcmp(tag, "sRGB", 4) == 0) {
                 if (seen_idat || n != 1) { bad = true; break; }

@@ -424,10 +424,16 @@ static void decode_window_on_device(struct job *jobs, size_t n, const struct opt
                                                j->src.has_trns ? j->src.trns : NULL, j->src.trns_bytes, j->in.rgba_data };
             who[k++] = i;
         }
-        if (rc == PNGLOSS_SUCCESS) rc = pngloss_hip_png_decode_batch_host(g_read_ctx, src, m);
-        for (size_t q = 0; q < k; q++)
-            if (rc != PNGLOSS_SUCCESS) { say(&jobs[who[q]], "  error: cannot decode image %s on the GPU (%d)\n", leaf(jobs[who[q]].in_name), rc); jobs[who[q]].status = (pngloss_error)rc; }
-        free(src); free(who);
+        /* a status per file: a damaged file fails alone, like under the reference's one-file-at-a-time loop (pngloss.c:196-204) */
+        int *st = calloc(m, sizeof *st);
+        if (!st && rc == PNGLOSS_SUCCESS) rc = PNGLOSS_OUT_OF_MEMORY_ERROR;
+        int brc = rc;
+        if (rc == PNGLOSS_SUCCESS) brc = pngloss_hip_png_decode_batch_host_status(g_read_ctx, src, m, st);
+        for (size_t q = 0; q < k; q++) {
+            const int one = rc != PNGLOSS_SUCCESS ? rc : (st[q] ? st[q] : ((brc != PNGLOSS_SUCCESS && brc != 25 && brc != PNGLOSS_HIP_ERROR) ? brc : PNGLOSS_SUCCESS));
+            if (one != PNGLOSS_SUCCESS) { say(&jobs[who[q]], "  error: cannot decode image %s on the GPU (%d)\n", leaf(jobs[who[q]].in_name), one); jobs[who[q]].status = (pngloss_error)one; }
+        }
+        free(src); free(who); free(st);
     }
     for (size_t i = 0; i < n; i++) {
         if (!jobs[i].src.scanlines) continue;

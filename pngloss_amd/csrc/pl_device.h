@@ -126,6 +126,21 @@ __device__ __forceinline__ int pl_channel_of_plane(uint32_t bpp, int p)
 }
 __device__ __forceinline__ int pl_plane_of_channel(uint32_t bpp, int c) { return (bpp == 2 && c == 1) ? 3 : c; }
 
+/* A kernel launched with more than 64 KB of dynamic LDS must be opted in with hipFuncAttributeMaxDynamicSharedMemorySize -- an attribute of
+ * the function ON THE CURRENT DEVICE: remembered per device in a bit mask the call site owns (a node has up to 8 devices). */
+#include <atomic>
+inline hipError_t pl_lds_optin(const void *func, size_t bytes, std::atomic<unsigned> &done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= 32 || !(done.load(std::memory_order_acquire) & (1u << dev))) {
+        const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+
 /* launchers implemented in pl_prepost.hip / pl_engine.hip (host side) */
 struct PlEngineParams {
     int strength;

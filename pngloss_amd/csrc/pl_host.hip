@@ -1134,8 +1134,19 @@ int pngloss_hip_last_histogram(pngloss_hip_ctx *ctx, size_t index, uint32_t *his
 
 int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n)
 {
+    return pngloss_hip_png_decode_batch_host_status(ctx, src, n, nullptr);
+}
+
+int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status)
+{
     if (!ctx || (!src && n)) return PNGLOSS_INVALID_ARGUMENT;
+    if (status) for (size_t i = 0; i < n; i++) status[i] = PNGLOSS_SUCCESS;
     if (!n) return PNGLOSS_SUCCESS;
+    if (ctx->pending) {
+        /* (the workspace this call carves up belongs to the batch in flight) */
+        std::fprintf(stderr, "pngloss_hip: a batch is in flight on this context; call pngloss_hip_finish first\n");
+        return PNGLOSS_INVALID_ARGUMENT;
+    }
     PL_CHECK(hipSetDevice(ctx->device));
     std::vector<PrJob> jobs(n);
     std::vector<size_t> raw_off(n), out_off(n), last_off(n), prog_off(n);
@@ -1186,9 +1197,17 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
     PL_CHECK(hipMemcpyAsync(st.data(), d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, nullptr));
     PL_CHECK(hipStreamSynchronize(nullptr));
     if (seam_dbg) std::fprintf(stderr, "pngloss_hip: read side: %zu files, workspace %zu MB ready after %.1f ms, upload %.1f ms, unfilter + expand %.1f ms, download %.1f ms\n", n, total >> 20, ms_ws, ms_up - ms_ws, ms_k - ms_up, ms_since() - ms_k);
-    for (size_t i = 0; i < n; i++)
-        if (st[i]) { std::fprintf(stderr, "pngloss_hip: image %zu: a scanline has a filter type beyond 4 (corrupt stream)\n", i); return 25; }
-    return PNGLOSS_SUCCESS;
+    /* every image has been decoded and downloaded; the ones that failed say so -- one damaged file does not take the window with it */
+    int worst = PNGLOSS_SUCCESS;
+    for (size_t i = 0; i < n; i++) {
+        if (!st[i]) continue;
+        const int code = st[i] == 25 ? 25 : PNGLOSS_HIP_ERROR;
+        if (st[i] == 25) std::fprintf(stderr, "pngloss_hip: image %zu: a scanline has a filter type beyond 4 (corrupt stream)\n", i);
+        else std::fprintf(stderr, "pngloss_hip: image %zu: the row bands of the decoder lost step (internal error %d)\n", i, st[i]);
+        if (status) status[i] = code;
+        if (worst == PNGLOSS_SUCCESS || code == PNGLOSS_HIP_ERROR) worst = code;
+    }
+    return worst;
 }
 
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8])

@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64) void pr_k_decode(const PrJob *jobs)
             pr_wave_sync();
         }
     }
-    if (__builtin_amdgcn_ballot_w64(bad != 0) && lane == 0) *j.status = 25;       /* LIBPNG_FATAL_ERROR (rwpng.h:33): a filter type beyond 4 */
+    /* status of the image: 25 = LIBPNG_FATAL_ERROR (rwpng.h:33): a filter type beyond 4; 64 = the band above never reported (an internal
+     * error, not a damaged file) -- the larger code wins when bands disagree */
+    if (__builtin_amdgcn_ballot_w64(bad == 2) && lane == 0) atomicMax(j.status, 64);
+    else if (__builtin_amdgcn_ballot_w64(bad == 1) && lane == 0) atomicMax(j.status, 25);
 }
 
 } // namespace

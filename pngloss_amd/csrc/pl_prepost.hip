@@ -245,8 +245,8 @@ template <int REP, int NT>
 hipError_t launch_hist_v(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream, unsigned wgs_per_image_cap)
 {
     constexpr size_t lds = (size_t)REP * PL_NFILT * PL_NSYM * sizeof(uint32_t);
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&pl_hist<REP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return attr;
+    static std::atomic<unsigned> optin{ 0 };                  /* (per device: pl_lds_optin) */
+    if (lds > 65536) { const hipError_t attr = pl_lds_optin(reinterpret_cast<const void *>(&pl_hist<REP, NT>), lds, optin); if (attr != hipSuccess) return attr; }
     size_t max_px = 1;
     for (size_t i = 0; i < n; i++) {
         const size_t px = (size_t)h_jobs[i].width * h_jobs[i].height;

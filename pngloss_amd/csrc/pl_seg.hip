@@ -109,19 +109,15 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_k_post(const SegJob *__restri
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+/* the kernels of the engine whose dynamic LDS can exceed 64 KB: opted in per device (pl_lds_optin) */
 hipError_t chain_attr()
 {
-    /* the attribute belongs to the function ON THE CURRENT DEVICE: remembered per device (a node has up to 8) */
-    static std::atomic<unsigned> done{ 0 };
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (dev < 0 || dev >= 32 || !(done.load(std::memory_order_acquire) & (1u << dev))) {
-        const hipError_t e = hipFuncSetAttribute((const void *)seg_k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_SM_CHAIN(SEG_CHAIN_CAP + 1));
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_release);
-    }
-    return hipSuccess;
+    static std::atomic<unsigned> done_chain{ 0 }, done_post{ 0 };
+    hipError_t e = pl_lds_optin((const void *)seg_k_chain, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
+    if (e == hipSuccess && SEG_SM_POST > 65536) e = pl_lds_optin((const void *)seg_k_post, SEG_SM_POST, done_post);
+    return e;
 }
+static_assert(SEG_SM_CTL <= 65536 && SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536, "these kernels are launched without an LDS opt-in");
 
 } // namespace
 

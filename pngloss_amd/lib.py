@@ -123,7 +123,7 @@ ABI_SYMBOLS = (
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
     "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit",
     "pngloss_hip_optimize_batch_host_zlib", "pngloss_hip_zlib_bound", "pngloss_hip_last_deflate_ms", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
-    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_png_decode_batch_host", "pngloss_hip_version",
+    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_png_decode_batch_host", "pngloss_hip_png_decode_batch_host_status", "pngloss_hip_version",
     "pngloss_hip_multi_create", "pngloss_hip_multi_destroy", "pngloss_hip_multi_count", "pngloss_hip_multi_split",
     "pngloss_hip_multi_optimize_batch_host",
 )
@@ -372,6 +372,20 @@ class HipContext:
         self._lib.pngloss_hip_png_decode_batch_host.restype = C.c_int
         _check(self._lib.pngloss_hip_png_decode_batch_host(self._ctx, src, len(parsed)), "png_decode")
         return outs
+
+    def png_decode_status(self, files):
+        """pngloss_hip_png_decode_batch_host_status: like png_decode, but a damaged file only fails itself.  Returns (outs, status list, return code)."""
+        parsed = [parse_png(f) for f in files]
+        outs = [np.zeros((p["height"], p["width"], 4), np.uint8) for p in parsed]
+        src = (PngSource * max(1, len(parsed)))()
+        for i, (p, o) in enumerate(zip(parsed, outs)):
+            src[i] = PngSource(p["scanlines"], p["width"], p["height"], p["ctype"], p["depth"], p["plte"], len(p["plte"]) // 3 if p["plte"] else 0,
+                               p["trns"], len(p["trns"]) if p["trns"] else 0, o.ctypes.data)
+        st = (C.c_int * max(1, len(parsed)))()
+        self._lib.pngloss_hip_png_decode_batch_host_status.argtypes = [C.c_void_p, C.POINTER(PngSource), C.c_size_t, C.POINTER(C.c_int)]
+        self._lib.pngloss_hip_png_decode_batch_host_status.restype = C.c_int
+        rc = self._lib.pngloss_hip_png_decode_batch_host_status(self._ctx, src, len(parsed), st)
+        return outs, list(st)[:len(parsed)], rc
 
     def engine_info(self, index=0):
         """pngloss_hip_last_engine_info: dict(engine, attempts, restarts, serial_rows, none_dropped) for image `index`."""

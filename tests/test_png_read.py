@@ -72,6 +72,35 @@ def test_device_reader_rejects_what_is_not_png():
 
 
 @pytest.mark.gpu
+def test_device_reader_one_damaged_file_fails_alone():
+    """A window of files with ONE damaged stream (a filter type beyond 4): pngloss_hip_png_decode_batch_host_status reports 25 for that
+    file only, the others come back decoded -- the reference's loop, too, fails only the damaged file (pngloss.c:196-204)."""
+    fx = [f for f in U.png_read_fixtures() if f[0].startswith("t6_d8") or f[0].startswith("t2_d8")][:4]
+    assert len(fx) >= 3
+    ctx = P.HipContext()
+    good_outs = ctx.png_decode([f[1] for f in fx])
+    # damage the second file's first scanline: rebuild a PNG around the altered scanlines is not needed -- patch the parsed bytes
+    parsed = [L.parse_png(f[1]) for f in fx]
+    rows = bytearray(parsed[1]["scanlines"]); rows[0] = 9
+    outs = [np.zeros((p["height"], p["width"], 4), np.uint8) for p in parsed]
+    src = (L.PngSource * len(parsed))()
+    for i, (p, o) in enumerate(zip(parsed, outs)):
+        sc = bytes(rows) if i == 1 else p["scanlines"]
+        src[i] = L.PngSource(sc, p["width"], p["height"], p["ctype"], p["depth"], p["plte"], len(p["plte"]) // 3 if p["plte"] else 0, p["trns"], len(p["trns"]) if p["trns"] else 0, o.ctypes.data)
+    import ctypes as C
+    st = (C.c_int * len(parsed))()
+    lib = P.hip_lib()
+    lib.pngloss_hip_png_decode_batch_host_status.restype = C.c_int
+    lib.pngloss_hip_png_decode_batch_host_status.argtypes = [C.c_void_p, C.POINTER(L.PngSource), C.c_size_t, C.POINTER(C.c_int)]
+    rc = lib.pngloss_hip_png_decode_batch_host_status(ctx._ctx, src, len(parsed), st)
+    assert rc == 25 and list(st) == [0, 25] + [0] * (len(parsed) - 2)
+    for i, (o, g) in enumerate(zip(outs, good_outs)):
+        if i != 1:
+            assert np.array_equal(o, g), fx[i][0]
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("w,h,ctype,depth", [(2000, 700, 6, 8), (4099, 130, 2, 8), (1500, 333, 0, 16), (3000, 200, 4, 8), (5000, 129, 3, 4),
                                              (241, 64, 6, 8), (240, 65, 6, 8), (7, 1000, 2, 16)])
 def test_device_reader_many_bands_and_blocks(w, h, ctype, depth):
