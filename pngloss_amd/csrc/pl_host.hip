@@ -436,6 +436,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     if (use_seg) {
         if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) seg_params.engine_flags = (std::atoi(ff) + 1) << 8;   /* debugging aid */
         if (std::getenv("PNGLOSS_HIP_SEGPROF")) seg_params.engine_flags |= 1;                                                   /* phase clocks of the validation kernel */
+        if (const char *k = std::getenv("PNGLOSS_HIP_KIN")) { const int v = std::atoi(k); if (seg_params.seeded && v >= 0 && v <= SEG_KIN) seg_params.kin = v; }   /* experiment: run-in pixels of the seeded enumeration */
         rc = run_seg_engine(ctx, d_jobs, seg_list, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream, d_sel, wg_list.size(), prm);
         if (rc) return rc;
     } else PL_CHECK(pl_launch_engine(d_jobs, nullptr, n, prm, stream));

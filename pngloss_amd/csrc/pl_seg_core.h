@@ -169,7 +169,7 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
  * it (filters that look at the left pixel), a grid of carried terms (none, up) -- and whatever they have become at the segment's first pixel is
  * the segment's entry set (measured: oracle/seed_study.c -- the reference's own state is in that set in all but 1e-4 .. 1e-3 of the boundaries; the
  * chain kernel walks such a segment step by step).  Entry states are found by value, through a small hash table per segment and channel. */
-#define SEG_KIN 32                /* run-in pixels of the seeded enumeration */
+#define SEG_KIN 32                /* most run-in pixels of the seeded enumeration (SegParams::kin: 16 .. 32 by the size of the carried terms) */
 #define SEG_EH 512                /* slots of a segment's entry hash (per channel); a key lives in the SEG_EHW slots from its bucket's first */
 #define SEG_EHW 8
 #define SEG_EH_WORDS (SEG_EH + SEG_EHW - 4)
@@ -728,7 +728,10 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
     if (!force_seeded && seg_build_exhaustive(P, strength, bleed)) return true;
     /* seeded: the filters that look at the left pixel take their seeds from the data (seg_enum_seeded_body); none / up, whose state is
      * (cn, th): every cn, and th on the finest grid that keeps the set within the lanes */
-    P.seeded = 1; P.kin = SEG_KIN;
+    /* run-in: the carried terms must have contracted when the seeds reach the segment -- the larger they can be, the longer it takes.
+     * Measured on 8192-pixel rows (a miss costs the chain kernel ~16 us, a run-in pixel ~0.4 us of every enumeration workgroup): s = 85 at
+     * bleed 2 and s = 40 at bleed 1 (cmax 12) are fastest with 16 pixels, s = 85 at bleed 1 (cmax 23) with 24 (profiles/r04_seg_coverage.txt) */
+    P.seeded = 1; P.kin = P.cmax <= 12 ? 16 : (P.cmax <= 24 ? 24 : SEG_KIN);
     P.ns = 0; P.nsp = 64; P.keyn = 0; P.ns_small = 0; P.small_ok = 0; P.idx0_big = P.idx0_small = (uint32_t)SEG_INVALID;
     if (P.cmax > 127 || tmax > 127 || 2 * P.cmax + 1 > SEG_NSP) return false;     /* (s = 255 at bleed 1: cmax 66, tmax 24) */
     int tstep = 1;

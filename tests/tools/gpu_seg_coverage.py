@@ -23,7 +23,7 @@ def describe(s, b):
 
 
 print("# segment-parallel engine: (strength, bleed) coverage -- seg_build_params (pl_seg_core.h) for every strength 0..255")
-print("# mode: E<n> = exhaustive enumeration of n chain states (<= 1024), S = seeded enumeration (256 seeds per channel, run-in 32 pixels)")
+print("# mode: E<n> = exhaustive enumeration of n chain states (<= 1024), S = seeded enumeration (256 seeds per channel, run-in 16 .. 32 pixels by the size of the carried terms)")
 for b in (1, 2, 3, 4, 8, 16, 32767):
     runs, prev, start = [], None, 0
     for s in range(256):
@@ -38,7 +38,7 @@ for b in (1, 2, 3, 4, 8, 16, 32767):
 print("# selected pairs: strength bleed mode states cmax tmax dmax")
 for s, b in [(19, 2), (20, 1), (20, 2), (20, 8), (40, 1), (40, 2), (40, 8), (85, 1), (85, 2), (85, 8), (99, 2), (128, 1), (255, 1), (255, 2)]:
     rc, o = describe(s, b)
-    print("  s=%3d b=%d: %s states=%d cmax=%d tmax=%d dmax=%d" % (s, b, "unsupported" if rc else ("seeded" if o[1] else "exhaustive"), o[2], o[4], o[5], o[6]))
+    print("  s=%3d b=%d: %s states=%d run-in=%d cmax=%d tmax=%d dmax=%d" % (s, b, "unsupported" if rc else ("seeded" if o[1] else "exhaustive"), o[2], o[3], o[4], o[5], o[6]))
 
 try:
     import torch
