@@ -233,7 +233,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps); s.ehash = reinterpret_cast<uint32_t *>(base + l.ehash);
         s.rout = reinterpret_cast<uint16_t *>(base + l.rout); s.rst = reinterpret_cast<uint32_t *>(base + l.rst); s.rck = reinterpret_cast<uint32_t *>(base + l.rck); s.dnout = reinterpret_cast<uint16_t *>(base + l.dnout); s.dcnt = reinterpret_cast<uint32_t *>(base + l.dcnt);
         s.entry = reinterpret_cast<uint32_t *>(base + l.entry); s.segcnt = reinterpret_cast<uint16_t *>(base + l.segcnt);
-        s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt);
+        s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt); s.grpleft = reinterpret_cast<uint32_t *>(base + l.grpleft);
         s.firstidx = reinterpret_cast<uint32_t *>(base + l.firstidx); s.rowmm = reinterpret_cast<int32_t *>(base + l.rowmm);
         s.nseg = pj.width ? l.nseg : 0; s.ngrp = pj.width ? l.ngrp : 0;
         b.max_nseg = std::max(b.max_nseg, l.nseg); b.max_ngrp = std::max(b.max_ngrp, l.ngrp);

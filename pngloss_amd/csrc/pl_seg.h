@@ -8,7 +8,7 @@
 #include "pl_seg_core.h"
 
 /* per-image device workspace of the engine, beyond what PlJob already has (offsets into one 256-B aligned carve) */
-struct PlSegLayout { size_t ctl, base, h0, acc, tables, maps, ehash, rout, rst, rck, dnout, dcnt, entry, segcnt, grpcnt, firstidx, rowmm, total; uint32_t nseg, ngrp; };
+struct PlSegLayout { size_t ctl, base, h0, acc, tables, maps, ehash, rout, rst, rck, dnout, dcnt, entry, segcnt, grpcnt, grpleft, firstidx, rowmm, total; uint32_t nseg, ngrp; };
 PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded);   /* nsp, seeded: SegParams::nsp / ::seeded of the (strength, bleed) pair */
 
 /* can the engine take this batch?  (chain states of (strength, bleed) fit the lanes, every row fits the chain kernel) */

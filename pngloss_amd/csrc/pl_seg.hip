@@ -143,6 +143,7 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded)
     l.entry = take((size_t)SEG_NFILT * l.nseg * 4 * 4);
     l.segcnt = take((size_t)SEG_NFILT * l.nseg * 256 * 2);
     l.grpcnt = take((size_t)SEG_NFILT * l.ngrp * 256 * 4);
+    l.grpleft = take((size_t)SEG_NFILT * l.ngrp * 4);
     l.firstidx = take(SEG_NFILT * 4 * 2 * 4);
     l.rowmm = take(((size_t)(width + SEG_COMMIT_W - 1) / SEG_COMMIT_W) * 8);
     l.total = o;

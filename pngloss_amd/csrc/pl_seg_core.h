@@ -235,16 +235,16 @@ PLS_HD SegCtlView seg_ctl_view(const SegCtl &c, int f)
 }
 
 struct SegAcc {
-    uint64_t derr[SEG_NFILT];
-    uint32_t cost[SEG_NFILT];
-    uint32_t hs[SEG_NFILT][SEG_NFILT];
+    uint64_t derr[SEG_NFILT];           /* derivative error of the candidate row (seg_row_sums) */
+    uint32_t hs[SEG_NFILT][SEG_NFILT];  /* sums of libpng's heuristic over the candidate row */
+    uint32_t pad_;
     uint32_t fail[SEG_NFILT];        /* smallest failing decision index x*4+c, or SEG_NOFAIL */
     uint32_t lb_valid;               /* workgroups that contributed to none_lb (must reach ngrp) */
-    uint64_t none_lb;                /* lower bound of candidate none's row cost (seg_post_body) */
+    uint64_t none_lb;                /* lower bound of candidate none's row cost (seg_row_sums) */
 };
 
 static_assert(sizeof(SegCtl) / 4 <= 128 && sizeof(SegAcc) / 4 <= 128, "the control kernel copies both with 128 lanes each");
-static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 40 <= 4 * SEG_TN, "they live in the table staging area, below the classes (and the decision behind them)");
+static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 48 <= 4 * SEG_TN, "they live in the table staging area, below the classes (and the decision behind them)");
 
 struct SegJob {
     SEG_AS_GLB uint32_t *img;            /* slots image (pl_device.h) */
@@ -277,6 +277,7 @@ struct SegJob {
     SEG_AS_GLB uint32_t *entry;          /* [5][nseg][4] */
     SEG_AS_GLB uint16_t *segcnt;         /* [5][nseg][256] */
     SEG_AS_GLB uint32_t *grpcnt;         /* [5][ngrp][256] */
+    SEG_AS_GLB uint32_t *grpleft;        /* [5][ngrp]: the new bytes (one per channel) the row sums of a group took for the pixel in front of it, when that pixel was another workgroup's (seg_row_sums; checked by the validation) */
     SEG_AS_GLB uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
     SEG_AS_GLB int32_t *rowmm;           /* [ceil(W / SEG_COMMIT_W)][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
     uint32_t nseg, ngrp;
@@ -755,7 +756,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
 #define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
-#define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 2 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
+#define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 2 + (SEG_NFILT + 1) * 256 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad > 0 when the lane left the tables */
 template <int F, bool TRX>
@@ -1575,6 +1576,149 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     }
 }
 
+/* ---- the row's SUMS of one candidate, group by group: the replay's workgroups, behind their walk ---------------------------------
+ * What the row decision (seg_decide_cand) wants from the pixels of a candidate row besides its bump counts: the derivative error
+ * (optimize_state.c:265-287) and the sums of libpng's heuristic (:492-562) -- neither depends on a histogram, so they are taken here, from
+ * the candidate words this workgroup has just written (and, in a later epoch of the row, from the validated words in front of it).  The
+ * entropy cost (:326-342) needs no pixel at all: the symbol a pixel is charged for is the bin it bumped, so the row's cost is
+ * sum over bins of n * (33 + clz(H0 + n)) with n the row's bumps of the bin (seg_entropy_costs, control kernel).
+ * The new left neighbour of the group's FIRST pixel belongs to the workgroup in front; it is taken from the entry state of the group's
+ * first segment (the chain kernel's), recorded in grpleft, and the validation kernel checks the record against the byte that was written.
+ * Candidate none (f = 0) also gets the LOWER BOUND of its row cost here (see seg_none_reach), run or not. */
+PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int m);
+PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, int grp, const SegCtlView &cv, bool lazy, bool walked,
+                         const uint32_t *lane, uint32_t *scr, uint32_t *scr2)
+{
+    const uint32_t W = j.W, bpp = j.bpp, sx = cv.start_x, y = cv.y;
+    const uint32_t x0g = (uint32_t)grp * SEG_GRP * SEG_L;
+    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    uint32_t *nbw = scr;                                       /* [SEG_REPLAY_THREADS] the new bytes of every pixel of the group, one word each */
+    uint32_t *rm = scr + SEG_REPLAY_THREADS;                   /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
+    uint32_t *red = rm + 768;                                  /* [16] reductions: derr lo/hi, hs[5], left bytes of the first pixel, -, -, lb lo/hi, reach, -, max, min */
+    uint32_t *h0s = red + 16;                                  /* [256] the committed histogram */
+    uint32_t *cwl = scr2;                                      /* [SEG_REPLAY_THREADS][4] candidate words of the group */
+    const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
+    SegAcc &A = j.acc[par];
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
+    PLS_SYNC();
+    if (!lazy) {
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            const uint32_t x = x0g + (uint32_t)tid;
+            SegVec16 w; w.a = w.b = w.c = w.d = 0u;
+            if (x < W) w = *(const SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x) * 4);
+            cwl[tid * 4 + 0] = w.a; cwl[tid * 4 + 1] = w.b; cwl[tid * 4 + 2] = w.c; cwl[tid * 4 + 3] = w.d;
+            nbw[tid] = (w.a & 255u) | ((w.b & 255u) << 8) | ((w.c & 255u) << 16) | ((w.d & 255u) << 24);
+            if (tid == 0 && x0g) {
+                uint32_t lw = 0;
+                if (x0g <= sx) {                               /* the pixel in front is validated: its word is final */
+                    const SegVec16 v = *(const SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x0g - 1) * 4);
+                    lw = (v.a & 255u) | ((v.b & 255u) << 8) | ((v.c & 255u) << 16) | ((v.d & 255u) << 24);
+                } else {                                       /* the left byte of the entry states this group's walkers started from (walked: always, here) */
+                    for (uint32_t c = 0; c < bpp; c++) lw |= (walked ? (lane[2 * c] & 255u) : 0u) << (8 * c);
+                    j.grpleft[(size_t)f * j.ngrp + grp] = lw;
+                }
+                red[7] = lw;
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            const uint32_t x = x0g + (uint32_t)tid;
+            uint64_t derr = 0; uint32_t hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
+            if (x < W) {
+                const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
+                const uint32_t nav4 = nab ? nab[x] : 0u, ndv4 = (nab && x) ? nab[x - 1] : 0u;
+                const uint32_t oav4 = y ? j.old_above[x] : 0u, odv4 = (y && x) ? j.old_above[x - 1] : 0u;
+                const uint32_t nb = nbw[tid], nlw = tid ? nbw[tid - 1] : red[7];
+                for (uint32_t c = 0; c < bpp; c++) {
+                    const int sh = 8 * (int)c;
+                    const int back = (int)((nb >> sh) & 255u), nl = x ? (int)((nlw >> sh) & 255u) : 0;
+                    const int ov = (int)((o >> sh) & 255u), olv = (int)((ol >> sh) & 255u);
+                    const int nav = (int)((nav4 >> sh) & 255u), ndv = (int)((ndv4 >> sh) & 255u), oav = (int)((oav4 >> sh) & 255u), odv = (int)((odv4 >> sh) & 255u);
+                    const int da = (oav - ov) - (nav - back), dd = (odv - ov) - (ndv - back), dl = (olv - ov) - (nl - back);
+                    const uint32_t wgt = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
+                    derr += (uint64_t)(wgt * (uint32_t)(da * da + dd * dd + dl * dl));
+                    if (adaptive) {
+                        const int preds[SEG_NFILT] = { 0, nl, nav, (nav + nl) >> 1, seg_paeth(nav, ndv, nl) };
+                        for (int g = 0; g < SEG_NFILT; g++) { const int bb = (back - preds[g]) & 255; hs[g] += (uint32_t)(bb < 128 ? bb : 256 - bb); }
+                    }
+                }
+            }
+            derr = pls_wave_sum_u64(derr);
+            if (adaptive) for (int g = 0; g < SEG_NFILT; g++) hs[g] = pls_wave_sum_u32(hs[g]);
+            if (PLS_WAVE_LEADER(tid)) {
+                PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
+                if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&red[2 + g], hs[g]);
+            }
+        }
+        PLS_SYNC();
+    }
+    /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
+     *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
+     *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
+    int R = -1;
+    if (f == 0 && j.rowmm) {
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            /* the row's extremes of orig + incoming error: one pair per commit workgroup, read side by side */
+            const int nc = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
+            if (tid < 64) {
+                int M = -(1 << 30), m = 1 << 30;
+                for (int i = tid; i < nc; i += 64) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
+                M = pls_wave_max_i(M); m = pls_wave_min_i(m);
+                PLS_ATOMIC_MAX_U(&red[14], 0x80000000u ^ (uint32_t)M); PLS_ATOMIC_MIN(&red[15], 0x80000000u ^ (uint32_t)m);
+            }
+            if (tid >= 64 && tid < 64 + 256) h0s[tid - 64] = j.H0[par * 256 + (tid - 64)];
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid == 0) red[12] = (uint32_t)seg_none_reach(j, P, (int)cv.s, (int)(red[14] ^ 0x80000000u), (int)(red[15] ^ 0x80000000u)); }
+        PLS_SYNC();
+        R = (int)red[12];
+        if (R >= 0) {
+            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+                for (int i = tid; i < 768; i += SEG_REPLAY_THREADS) {
+                    const int centre = i - 256;
+                    const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
+                    uint32_t m = 0;
+                    for (int b = lo; b <= hi; b++) m = h0s[b] > m ? h0s[b] : m;
+                    rm[i] = m;
+                }
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+                uint64_t lb = 0;
+                const uint32_t rowbumps = W * bpp;
+                const uint32_t x = x0g + (uint32_t)tid;
+                if (x < W) {
+                    const uint32_t o = row[x];
+                    const uint32_t e[2] = { j.err0[2 * (size_t)x], j.err0[2 * (size_t)x + 1] };
+                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        uint32_t hmax;
+                        if (alpha0 && c == bpp - 1u) hmax = h0s[0];                        /* forced symbol 0 */
+                        else {
+                            const int centre = (int)((o >> (8 * c)) & 255u) + seg_err_plane(e, seg_plane_of_channel(bpp, (int)c));
+                            hmax = rm[seg_min(seg_max(centre, -256), 511) + 256];
+                        }
+                        const uint32_t fr = hmax + rowbumps;
+                        lb += 33u + (uint32_t)__builtin_clz(fr ? fr : 1u);
+                    }
+                }
+                lb = pls_wave_sum_u64(lb);
+                if (PLS_WAVE_LEADER(tid) && lb) PLS_ATOMIC_ADD64((uint64_t *)&red[10], lb);
+            }
+            PLS_SYNC();
+        }
+    }
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        if (tid == 0) {
+            if (!lazy) {
+                PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
+                if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[2 + g]);
+            }
+            if (f == 0 && R >= 0) { PLS_ATOMIC_ADD64(&A.none_lb, *(uint64_t *)&red[10]); PLS_ATOMIC_ADD(&A.lb_valid, 1u); }
+        }
+    }
+}
+
 /* ---- REPLAY: task (f, grp): lane = (segment of the group, part of the segment, channel) -----------------------------------
  * A lane starts from a state it knows: part 0 from the segment's entry state, part p from the checkpoint the enumeration left for
  * the segment's dense id.  A part without a checkpoint is walked by the lane in front of it. */
@@ -1582,13 +1726,14 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
 {
     const SegCtl &ctl = j.ctl[par];
     const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
-    if (cv.finished || cv.active != 1) return;
+    if (cv.finished) return;
+    const bool lazy = f == 0 && cv.active == 2;               /* candidate none, not run yet: only its cost bound is wanted */
+    if (!lazy && cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = cv.start_x;
-    if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
     const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
-    if (seg0 + SEG_GRP <= first) return;                      /* the whole group is validated already */
+    const bool walk = !lazy && sx < W && seg0 + SEG_GRP > first;   /* (else: the whole group is validated already -- its share of the row's sums is still wanted) */
     uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
     SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_GRP][SEG_L][4] */
     uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
@@ -1596,6 +1741,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)cv.s);
+    if (walk) {
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
         /* Order of the requests: the walkers' dense ids, then everything the block stages (tables, frozen histogram, pixels), then the
          * checkpoints and entry states (which wait for the dense ids only); the stores to shared memory behind all of them. */
@@ -1677,6 +1823,9 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
             j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
         }
     }
+    PLS_SYNC();
+    }
+    seg_row_sums(j, P, par, f, grp, cv, lazy, walk, lane, tw, (uint32_t *)px);
 }
 
 /* Validation of one decision d = (pixel k of the group) * 4 + channel.  mode 0: with the block bounds only -- returns 1 good, 0 bad,
@@ -1806,14 +1955,15 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
 {
     const SegCtl &ctl = j.ctl[par];
     const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
-    if (cv.finished || !cv.active) return;
+    if (cv.finished || cv.active != 1) return;                 /* (candidate none while it is lazy has no row to validate) */
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
     const uint32_t sx = cv.start_x;
+    if (sx >= W) return;                                       /* (a row finished serially by the control kernel: exact by construction) */
     const uint32_t first = sx / SEG_L, fgrp = first / SEG_GRP;
     const uint32_t seg0 = (uint32_t)vg * SEG_VGRP;             /* vg: validation group = SEG_VGRP segments (half a replay group) */
     const uint32_t grp = seg0 / SEG_GRP, segp = grp * SEG_GRP;  /* the replay group it lies in, and that group's first segment */
     constexpr int NPX = SEG_VGRP * SEG_L;                       /* pixels of a group */
-    uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256, *Hpost = H0 + 512;
+    uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256;
     uint32_t *cum = H0 + 768;                                  /* [(2 * SEG_VGRP + 1)][256]: bumps in front of each segment of the group */
     uint32_t *cw = cum + (2 * SEG_VGRP + 1) * 256;             /* (rows SEG_VGRP+1 ..: the bumps of the replay group's segments in front of this half) */                  /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
     uint32_t *red = cw + (NPX + 2) * 4;                        /* reductions: derr lo/hi, cost, hs[5], fail, lb lo/hi */
@@ -1833,9 +1983,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     const uint32_t y = cv.y;
     const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
     const SegGeo G = seg_geo((int)cv.s);
-    const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
     const uint32_t xg0 = seg0 * SEG_L;
-    const bool lazy = cv.active == 2;                       /* candidate none, not run yet: only its cost bound is wanted */
     const bool prof = (P.engine_flags & 1) != 0;                /* debugging: phase clocks (100 MHz ticks) into result[40..], max over the workgroups */
     unsigned long long tk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (prof) tk[0] = PLS_CLOCK();
@@ -1843,7 +1991,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         /* every request first, the stores to shared memory behind them: one round trip instead of one per statement (the compiler
          * cannot move a load in front of an earlier store through a generic pointer) */
         constexpr int NCW = ((NPX + 2) * 4 + SEG_THREADS - 1) / SEG_THREADS;
-        uint32_t vh0 = 0, vrank = 0, vlut = 0, vcw[NCW], vro = 0, vna = 0, voa = 0, ve0a = 0, ve0b = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        uint32_t vh0 = 0, vrank = 0, vlut = 0, vcw[NCW], vro = 0, vna = 0, vgl = 0, ve0a = 0, ve0b = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (tid < 256) { vh0 = j.H0[par * 256 + tid]; vrank = j.orig_rank[f * 256 + tid]; }
         if (tid >= 256 && tid < 768) vlut = P.lut_a[tid - 256];
         PLS_UNROLL
@@ -1857,8 +2005,8 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             const bool in = x >= 0 && x < (long)W;
             vro = in ? row[x] : 0u;
             vna = (in && nab) ? nab[x] : 0u;
-            voa = (in && y) ? j.old_above[x] : 0u;
         }
+        if (tid == 9) vgl = j.grpleft[(size_t)f * ngrp + grp];
         if (tid >= 512 && tid - 512 < NPX) {
             const uint32_t x = xg0 + (uint32_t)(tid - 512);
             ve0a = x < W ? j.err0[2 * (size_t)x] : 0u;
@@ -1876,11 +2024,11 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
             }
         }
         if (tid < 256) { H0[tid] = vh0; rank[tid] = vrank; }
-        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : 0u;
+        if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : (tid == 9 ? vgl : 0u);
         if (tid >= 256 && tid < 768) lut[tid - 256] = vlut;
         PLS_UNROLL
         for (int q = 0; q < NCW; q++) { const int i = tid + q * SEG_THREADS; if (i < (NPX + 2) * 4) cw[i] = vcw[q]; }
-        if (tid <= NPX) { ro[tid] = vro; na[tid] = vna; oa[tid] = voa; }
+        if (tid <= NPX) { ro[tid] = vro; na[tid] = vna; }
         if (tid >= 512 && tid - 512 < NPX) { e0[2 * (tid - 512)] = ve0a; e0[2 * (tid - 512) + 1] = ve0b; }
         {
             uint32_t *dst = cum + (sl + 1) * 256 + 4 * q4;
@@ -1892,24 +2040,19 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         if (tid < 256) {
             const int b = tid;
             /* (all groups requested at once, the ones that do not count masked out: a loop with the load inside waits for every one) */
-            uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b], total;
+            uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b];
             uint32_t gv[SEG_NG_BURST];
             PLS_UNROLL
-            for (int g = 0; g < SEG_NG_BURST; g++) gv[g] = ((uint32_t)g < ngrp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;
-            total = before;
+            for (int g = 0; g < SEG_NG_BURST; g++) gv[g] = ((uint32_t)g < grp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;   /* (grp < ngrp) */
             PLS_UNROLL
             for (int g = 0; g < SEG_NG_BURST; g++) {
-                const bool in = sx < W && (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
-                total += in ? gv[g] : 0u;
+                const bool in = (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
                 before += (in && (uint32_t)g < grp) ? gv[g] : 0u;
             }
-            for (uint32_t g = SEG_NG_BURST; g < ngrp; g++) {                      /* (rows beyond 8192 pixels) */
+            for (uint32_t g = SEG_NG_BURST; g < grp && g < ngrp; g++) {           /* (rows beyond 8192 pixels) */
                 const uint32_t v = j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
-                const bool in = sx < W && g >= fgrp;
-                total += in ? v : 0u;
-                before += (in && g < grp) ? v : 0u;
+                before += g >= fgrp ? v : 0u;
             }
-            Hpost[b] = H0[b] + total;
             uint32_t add[2 * SEG_VGRP];                                /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
             PLS_UNROLL
             for (int r = 1; r <= 2 * SEG_VGRP; r++) add[r - 1] = cum[r * 256 + b];
@@ -1925,7 +2068,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     }
     PLS_SYNC();
     if (prof) tk[1] = PLS_CLOCK();
-    if (!lazy) {
+    {
     /* -- validation: lane = decision.  Pass 1 settles what the block bounds can settle and marks the bins of the others ("watched");
      *    pass 2 counts, per segment, the bumps of each watched bin in front of every decision; pass 3 settles the rest exactly. -- */
     SegVal V;
@@ -2002,114 +2145,23 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         }
     }
     }
-    if (prof) { tk[3] = PLS_CLOCK(); if (lazy) tk[2] = tk[3]; }
-    /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
-     *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
-     *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { red[14] = 0x80000000u ^ (uint32_t)(-(1 << 30)); red[15] = 0x80000000u ^ (uint32_t)(1 << 30); } }   /* (biased: unsigned max / min) */
-    PLS_SYNC();
+    if (prof) tk[3] = PLS_CLOCK();
+    /* the left bytes the row sums took for the pixel in front of this replay group (seg_row_sums) against what was written there */
     PLS_THREADS(tid, SEG_THREADS) {
-        /* the row's extremes of orig + incoming error: one pair per commit workgroup, read side by side */
-        const int nc = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
-        if (f == 0 && j.rowmm && tid < 64) {
-            int M = -(1 << 30), m = 1 << 30;
-            for (int i = tid; i < nc; i += 64) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
-            M = pls_wave_max_i(M); m = pls_wave_min_i(m);
-            PLS_ATOMIC_MAX_U(&red[14], 0x80000000u ^ (uint32_t)M); PLS_ATOMIC_MIN(&red[15], 0x80000000u ^ (uint32_t)m);
-        }
-    }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) red[12] = (uint32_t)(f == 0 ? seg_none_reach(j, P, (int)cv.s, (int)(red[14] ^ 0x80000000u), (int)(red[15] ^ 0x80000000u)) : -1); }
-    PLS_SYNC();
-    const int R = (int)red[12];
-    if (f == 0 && R >= 0) {
-        PLS_THREADS(tid, SEG_THREADS) {
-            if (tid < 768) {
-                const int centre = tid - 256;
-                const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
-                uint32_t m = 0;
-                for (int b = lo; b <= hi; b++) m = H0[b] > m ? H0[b] : m;
-                rm[tid] = m;
-            }
-        }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) {
-            uint64_t lb = 0;
-            const uint32_t rowbumps = W * bpp;
-            for (int k = tid; k < NPX; k += SEG_THREADS) {
-                const uint32_t x = xg0 + (uint32_t)k;
-                if (x >= W) continue;
-                const uint32_t o = ro[k + 1];
-                const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                for (uint32_t c = 0; c < bpp; c++) {
-                    uint32_t hmax;
-                    if (alpha0 && c == bpp - 1u) hmax = H0[0];                         /* forced symbol 0 */
-                    else {
-                        const int centre = (int)((o >> (8 * c)) & 255u) + seg_err_plane(e0 + 2 * k, seg_plane_of_channel(bpp, (int)c));
-                        hmax = rm[seg_min(seg_max(centre, -256), 511) + 256];
-                    }
-                    const uint32_t fr = hmax + rowbumps;
-                    lb += 33u + (uint32_t)__builtin_clz(fr ? fr : 1u);
-                }
-            }
-            lb = pls_wave_sum_u64(lb);
-            if (PLS_WAVE_LEADER(tid) && lb) PLS_ATOMIC_ADD64((uint64_t *)&red[10], lb);
-        }
-    }
-    PLS_SYNC();
-    if (prof) tk[4] = PLS_CLOCK();
-    /* -- post pass of this candidate over the group's pixels (optimize_state.c:265-287, 326-342, 492-562): lane = (pixel, channel) -- */
-    if (!lazy)
-    PLS_THREADS(tid, SEG_THREADS) {
-        uint64_t derr = 0; uint32_t cost = 0, hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
-        for (int kc = tid; kc < NPX * 4; kc += SEG_THREADS) {
-            const int k = kc >> 2;
-            const uint32_t c = (uint32_t)kc & 3u;
-            const uint32_t x = xg0 + (uint32_t)k;
-            if (x >= W || c >= bpp) continue;
-            const uint32_t o = ro[k + 1], ol = ro[k];
-            const uint32_t nav4 = na[k + 1], ndv4 = x ? na[k] : 0u;
-            const uint32_t oav4 = oa[k + 1], odv4 = x ? oa[k] : 0u;
-            {
-                const int sh = 8 * (int)c;
-                const int back = seg_cand_byte(cw[(k + 2) * 4 + c]), nl = x ? seg_cand_byte(cw[(k + 1) * 4 + c]) : 0;
-                const int ov = (int)((o >> sh) & 255u), olv = (int)((ol >> sh) & 255u);
-                const int nav = (int)((nav4 >> sh) & 255u), ndv = (int)((ndv4 >> sh) & 255u), oav = (int)((oav4 >> sh) & 255u), odv = (int)((odv4 >> sh) & 255u);
-                const int da = (oav - ov) - (nav - back), dd = (odv - ov) - (ndv - back), dl = (olv - ov) - (nl - back);
-                const uint32_t wgt = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
-                derr += (uint64_t)(wgt * (uint32_t)(da * da + dd * dd + dl * dl));
-                const int preds[SEG_NFILT] = { 0, nl, nav, (nav + nl) >> 1, seg_paeth(nav, ndv, nl) };
-                const uint32_t fr = Hpost[(back - preds[f]) & 255];
-                cost += fr ? 33u + (uint32_t)__builtin_clz(fr) : 0u;
-                if (adaptive)
-                    for (int g = 0; g < SEG_NFILT; g++) { const int bb = (back - preds[g]) & 255; hs[g] += (uint32_t)(bb < 128 ? bb : 256 - bb); }
-            }
-        }
-        derr = pls_wave_sum_u64(derr); cost = pls_wave_sum_u32(cost);
-        if (adaptive) for (int g = 0; g < SEG_NFILT; g++) hs[g] = pls_wave_sum_u32(hs[g]);
-        if (PLS_WAVE_LEADER(tid)) {
-            PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
-            PLS_ATOMIC_ADD(&red[2], cost);
-            if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&red[3 + g], hs[g]);
+        if (tid < 4 && (uint32_t)tid < bpp && seg0 == segp && xg0 > sx && xg0 > 0u) {
+            if (seg_cand_byte(cw[1 * 4 + tid]) != (int)((red[9] >> (8 * tid)) & 255u)) PLS_ATOMIC_MIN(&red[8], xg0 * 4u + (uint32_t)tid);
         }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid == 0) {
             SegAcc &A = j.acc[par];
-            if (!lazy) {
-                PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
-                PLS_ATOMIC_ADD(&A.cost[f], red[2]);
-                for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[3 + g]);
-                if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
-            }
-            if (f == 0 && R >= 0) { PLS_ATOMIC_ADD64(&A.none_lb, *(uint64_t *)&red[10]); PLS_ATOMIC_ADD(&A.lb_valid, 1u); }
+            if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
             if (prof) {
-                tk[5] = PLS_CLOCK();
+                tk[4] = PLS_CLOCK(); tk[5] = tk[4];
                 for (int q = 0; q < 5; q++) { PLS_ATOMIC_MAX(&j.result[40 + q], (int32_t)(tk[q + 1] - tk[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[48 + q], (uint32_t)(tk[q + 1] - tk[q])); }
                 PLS_ATOMIC_ADD((uint32_t *)&j.result[53], 1u);
                 PLS_ATOMIC_ADD((uint32_t *)&j.result[46], red[13]);                     /* pending decisions (pass 3) */
-                PLS_ATOMIC_MAX(&j.result[47], (int32_t)(f == 0 ? R : 0));
             }
         }
     }
@@ -2127,14 +2179,14 @@ struct SegDecision {
 static_assert(offsetof(SegDecision, cost) == 24, "seg_ctl_body reads cost[f] out of the shared copy by word index");
 struct SegCandDec { uint64_t cost; uint32_t state; uint32_t pad_; };      /* state 0: cost is final (or ~0: no acceptable row), 1: lazy (none, not run yet), 2: failed validation */
 template <class CT, class AT>
-PLS_HD SegCandDec seg_decide_cand(const SegJob &j, const SegParams &P, CT &cur, AT &A, int f)
+PLS_HD SegCandDec seg_decide_cand(const SegJob &j, const SegParams &P, CT &cur, AT &A, int f, uint32_t ecost)
 {
     SegCandDec r; r.cost = ~0ull; r.state = 0; r.pad_ = 0;
     if (!cur.active[f]) { r.cost = cur.cost[f]; return r; }
     if (cur.active[f] == 2) { r.state = 1; return r; }                             /* candidate none, not run yet */
     if (A.fail[f] != SEG_NOFAIL) { r.state = 2; return r; }
     const bool adaptive = !j.row_filters || cur.y == 0;
-    uint64_t cst = A.derr[f] / 128u + A.cost[f];                                  /* optimize_state.c:360 */
+    uint64_t cst = A.derr[f] / 128u + ecost;                                      /* optimize_state.c:360 (ecost: seg_entropy_costs) */
     if (adaptive) {
         int bestg = 0;
         for (int g = 1; g < SEG_NFILT; g++) if (A.hs[f][g] < A.hs[f][bestg]) bestg = g;
@@ -2167,7 +2219,7 @@ PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int a
          * errors are all that is committed.) */
         uint64_t best_other = ~0ull;
         for (int f = 1; f < SEG_NFILT; f++) if (!((D.failed >> f) & 1u) && D.cost[f] < best_other) best_other = D.cost[f];
-        if (A.lb_valid == (j.nseg + SEG_VGRP - 1) / SEG_VGRP && best_other < A.none_lb) {
+        if (A.lb_valid == j.ngrp && best_other < A.none_lb) {
             D.failed &= ~1u; D.cost[0] = ~0ull; D.dropped_none = 1; lazy0 = false;
             any_failed = D.failed != 0;
         }
@@ -2183,16 +2235,80 @@ PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int a
     else D.kind = cur.s == 0 ? SEG_K_ABORT : SEG_K_RETRY;                           /* pngloss_image.c:266-274 */
     return D;
 }
+/* ---- what a candidate's row has bumped, and what that costs ------------------------------------------------------------------------
+ * spec[w][b] (w < SEG_NFILT) = every bump of bin b by candidate w's row: the validated prefix (base) + the groups from its epoch's first on
+ * (the replay's counts); spec[SEG_NFILT][b] = the committed histogram.  Requested before the decision is known (it says which candidate's
+ * bumps become the next histogram), by `nt` loader lanes t = 0 .. nt-1, NSP = ceil(1536 / nt) items each: requests, then stores. */
+template <int NSP> struct SegSpecRegs { uint32_t bs[NSP], g0[NSP][SEG_NG_BURST], wsx[NSP]; };
+template <int NSP>
+PLS_HD void seg_spec_request(const SegJob &j, int prev, const SegCtl &curg, int t, int nt, SegSpecRegs<NSP> &r)
+{
+    const uint32_t ngrp = j.ngrp;
+    PLS_UNROLL
+    for (int q = 0; q < NSP; q++) {
+        const int i = t + q * nt, w = i >> 8, b = i & 255;
+        r.bs[q] = 0; r.wsx[q] = 0;
+        PLS_UNROLL
+        for (int g = 0; g < SEG_NG_BURST; g++) r.g0[q][g] = 0u;
+        if (i < (SEG_NFILT + 1) * 256) {
+            if (w == SEG_NFILT) r.bs[q] = j.H0[prev * 256 + b];
+            else {
+                r.bs[q] = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
+                r.wsx[q] = curg.start_x[w];
+                PLS_UNROLL
+                for (int g = 0; g < SEG_NG_BURST; g++) if ((uint32_t)g < ngrp) r.g0[q][g] = j.grpcnt[((size_t)w * ngrp + g) * 256 + b];
+            }
+        }
+    }
+}
+template <int NSP>
+PLS_HD void seg_spec_store(const SegJob &j, int t, int nt, const SegSpecRegs<NSP> &r, seg_lds_u32 spec)
+{
+    const uint32_t ngrp = j.ngrp, W = j.W;
+    PLS_UNROLL
+    for (int q = 0; q < NSP; q++) {
+        const int i = t + q * nt, w = i >> 8;
+        if (i < (SEG_NFILT + 1) * 256) {
+            uint32_t v = r.bs[q];
+            if (w != SEG_NFILT) {
+                const uint32_t wfg = (r.wsx[q] / SEG_L) / SEG_GRP;
+                PLS_UNROLL
+                for (int g = 0; g < SEG_NG_BURST; g++) v += ((uint32_t)g >= wfg && (uint32_t)g < ngrp && r.wsx[q] < W) ? r.g0[q][g] : 0u;
+                for (uint32_t g = SEG_NG_BURST; g < ngrp; g++) v += (g >= wfg && r.wsx[q] < W) ? j.grpcnt[((size_t)w * ngrp + g) * 256 + (i & 255)] : 0u;   /* (rows beyond 8192 pixels) */
+            }
+            spec[i] = v;
+        }
+    }
+}
+/* The entropy cost of every candidate row (optimize_state.c:326-342): a pixel is charged 64 - floor(log2 H[symbol]) = 33 + clz(H[symbol]) under
+ * the histogram AFTER the row, and its symbol is the bin it bumped (:251-254 -- the stored byte minus the same prediction), so the row costs
+ * sum over bins of n * (33 + clz(H0 + n)), n = the row's bumps of the bin: no pass over the pixels.  ecost: SEG_NFILT (8) words of shared
+ * memory; all `nt` threads (a multiple of 256: a wave's items are one candidate's). */
+PLS_HD void seg_entropy_costs(seg_lds_u32 spec, seg_lds_u32 ecost, int nt)
+{
+    PLS_THREADS(tid, nt) { if (tid < 8) ecost[tid] = 0u; }
+    PLS_SYNC();
+    PLS_THREADS(tid, nt) {
+        for (int i = tid; i < SEG_NFILT * 256; i += nt) {
+            const uint32_t n = spec[i], h = spec[SEG_NFILT * 256 + (i & 255)] + n;
+            uint32_t v = n ? n * (33u + (uint32_t)__builtin_clz(h)) : 0u;
+            v = pls_wave_sum_u32(v);
+            if (PLS_WAVE_LEADER(tid) && v) PLS_ATOMIC_ADD(&ecost[i >> 8], v);
+        }
+    }
+    PLS_SYNC();
+}
+
 /* the whole workgroup: lanes 0..4 step 1, lane 0 step 2; the result in shared memory (dshare: 16 words, cdw: 20 words in front of it) */
 /* the control block, the sums and the decision in shared memory, with the address space in the type (ds_* instead of FLAT accesses) */
 typedef SEG_AS_LDS const SegCtl seg_lds_ctl_t;
 typedef SEG_AS_LDS const SegAcc seg_lds_acc_t;
 /* the whole workgroup: lanes 0..4 step 1, lane 0 step 2; the result in shared memory (dshare: 16 words, cdw: 20 words behind it) */
-PLS_HD SegDecision seg_decide_wg(const SegJob &j, const SegParams &P, int attempt, seg_lds_ctl_t &cur, seg_lds_acc_t &A, seg_lds_u32 cdw, seg_lds_u32 dshare, int nt)
+PLS_HD SegDecision seg_decide_wg(const SegJob &j, const SegParams &P, int attempt, seg_lds_ctl_t &cur, seg_lds_acc_t &A, seg_lds_u32 ecost, seg_lds_u32 cdw, seg_lds_u32 dshare, int nt)
 {
     PLS_THREADS(tid, nt) {
         if (tid < SEG_NFILT && attempt) {
-            const SegCandDec r = seg_decide_cand(j, P, cur, A, tid);
+            const SegCandDec r = seg_decide_cand(j, P, cur, A, tid, ecost[tid]);
             cdw[4 * tid] = (uint32_t)r.cost; cdw[4 * tid + 1] = (uint32_t)(r.cost >> 32); cdw[4 * tid + 2] = r.state; cdw[4 * tid + 3] = 0u;
         }
     }
@@ -2312,8 +2428,10 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
     SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                /* [0] max, [1] min of orig + incoming error over this workgroup's pixels of the COMING row */
     seg_lds_u32 lutb = (seg_lds_u32)smem + 8;                  /* [512] next-rows terms of the split */
     seg_lds_u32 ctlc = lutb + 512, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2, dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
-    seg_lds_u32 cw5 = dshare + 40;                             /* [SEG_NFILT][(SEG_COMMIT_W + 4)][4] every candidate's words of this workgroup's pixels, two more on either side; the winner's become their terms */
+    seg_lds_u32 ecost = dshare + 40;                           /* [8] entropy cost of every candidate row */
+    seg_lds_u32 cw5 = dshare + 48;                             /* [SEG_NFILT][(SEG_COMMIT_W + 4)][4] every candidate's words of this workgroup's pixels, two more on either side; the winner's become their terms */
     seg_lds_u32 ext = cw5 + SEG_NFILT * (SEG_COMMIT_W + 4) * 4;/* [SEG_COMMIT_W][2]: err1 */
+    seg_lds_u32 spec = ext + SEG_COMMIT_W * 2;                 /* [SEG_NFILT + 1][256] the bumps of every candidate's row, the committed histogram (for the row costs: seg_entropy_costs) */
     const uint32_t xw0 = (uint32_t)cw * SEG_COMMIT_W;
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long tc0 = 0;
@@ -2350,6 +2468,12 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
             if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
             lutb[tid] = lb0; lutb[tid + SEG_COMMIT_W] = lb1;
             if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; }
+        } else {
+            /* (the lanes that have no pixel) what every candidate's row bumped: the decision wants the row costs */
+            constexpr int NLD = SEG_THREADS - SEG_COMMIT_W, NSP = ((SEG_NFILT + 1) * 256 + NLD - 1) / NLD;
+            SegSpecRegs<NSP> sr;
+            seg_spec_request<NSP>(j, prev, curg, tid - SEG_COMMIT_W, NLD, sr);
+            seg_spec_store<NSP>(j, tid - SEG_COMMIT_W, NLD, sr, spec);
         }
     }
     PLS_SYNC();
@@ -2385,7 +2509,8 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
         PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
         return;
     }
-    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
+    seg_entropy_costs(spec, ecost, SEG_THREADS);
+    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, ecost, dshare + 16, dshare, SEG_THREADS);
     if (D.kind != SEG_K_COMMIT) return;
     if (prof) tk[1] = PLS_CLOCK();
     const int winner = D.winner;
@@ -2486,41 +2611,12 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
             const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
             const uint32_t rword = (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) ? j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)] : 0u;
             constexpr int NSP = ((SEG_NFILT + 1) * 256 + SEG_THREADS - 1) / SEG_THREADS;
-            constexpr int NG = SEG_NG_BURST;
-            uint32_t bs[NSP], g0[NSP][NG], wsx[NSP];
-            PLS_UNROLL
-            for (int q = 0; q < NSP; q++) {
-                const int i = tid + q * SEG_THREADS, w = i >> 8, b = i & 255;
-                bs[q] = 0; wsx[q] = 0;
-                PLS_UNROLL
-                for (int g = 0; g < NG; g++) g0[q][g] = 0u;
-                if (i < (SEG_NFILT + 1) * 256) {
-                    if (w == SEG_NFILT) bs[q] = j.H0[prev * 256 + b];
-                    else {
-                        bs[q] = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
-                        wsx[q] = curg.start_x[w];
-                        PLS_UNROLL
-                        for (int g = 0; g < NG; g++) if ((uint32_t)g < ngrp) g0[q][g] = j.grpcnt[((size_t)w * ngrp + g) * 256 + b];
-                    }
-                }
-            }
+            SegSpecRegs<NSP> sr;
+            seg_spec_request<NSP>(j, prev, curg, tid, SEG_THREADS, sr);
             if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
             if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
             if (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) rank[tid - 256] = rword;
-            PLS_UNROLL
-            for (int q = 0; q < NSP; q++) {
-                const int i = tid + q * SEG_THREADS, w = i >> 8;
-                if (i < (SEG_NFILT + 1) * 256) {
-                    uint32_t v = bs[q];
-                    if (w != SEG_NFILT) {
-                        const uint32_t wfg = (wsx[q] / SEG_L) / SEG_GRP;
-                        PLS_UNROLL
-                        for (int g = 0; g < NG; g++) v += ((uint32_t)g >= wfg && (uint32_t)g < ngrp && wsx[q] < W) ? g0[q][g] : 0u;
-                        for (uint32_t g = NG; g < ngrp; g++) v += (g >= wfg && wsx[q] < W) ? j.grpcnt[((size_t)w * ngrp + g) * 256 + (i & 255)] : 0u;   /* (rows beyond 8192 pixels) */
-                    }
-                    spec[i] = v;
-                }
-            }
+            seg_spec_store<NSP>(j, tid, SEG_THREADS, sr, spec);
         }
     }
     PLS_SYNC();
@@ -2532,7 +2628,9 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
     seg_lds_u32 dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
     /* the number of this attempt is kept on the device (the launcher passes parities only: a captured launch sequence can be replayed) */
     const int attempt = cur.magic != SEG_MAGIC ? 0 : (int)cur.attempts + 1;
-    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, dshare + 16, dshare, SEG_THREADS);
+    seg_lds_u32 ecost = dshare + 40;                            /* [8] entropy cost of every candidate row */
+    seg_entropy_costs(spec, ecost, SEG_THREADS);
+    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, ecost, dshare + 16, dshare, SEG_THREADS);
     if (prof) tq2 = PLS_CLOCK();
     const uint32_t y = attempt ? cur.y : 0u;
     int s_next = attempt ? (int)cur.s : P.strength;

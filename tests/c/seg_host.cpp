@@ -103,6 +103,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.entry = A.take<uint32_t>((size_t)5 * j.nseg * 4);
     j.segcnt = A.take<uint16_t>((size_t)5 * j.nseg * 256);
     j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);
+    j.grpleft = A.take<uint32_t>((size_t)5 * j.ngrp);
     j.firstidx = A.take<uint32_t>(5 * 4 * 2);
     j.rowmm = A.take<int32_t>(2 * ((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W));
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
