@@ -225,8 +225,8 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         s.job_index = list[i];
         s.img = pj.img; s.row_filters = pj.row_filters; s.row_ids = pj.row_ids; s.W = pj.width; s.H = pj.height; s.bpp = 0;
         s.orig_rank = pj.orig_rank; s.cand = reinterpret_cast<uint32_t *>(pj.cand);
-        s.err0 = reinterpret_cast<uint32_t *>(pj.err0); s.err1 = reinterpret_cast<uint32_t *>(pj.err1);
-        s.old_above = pj.old_above; s.final_hist = pj.final_hist; s.result = pj.result; s.progress = pj.progress;
+        s.err0 = reinterpret_cast<uint32_t *>(base + l.err0); s.err1 = reinterpret_cast<uint32_t *>(base + l.err1); s.rowcopy = reinterpret_cast<uint32_t *>(base + l.rowcopy);
+        s.final_hist = pj.final_hist; s.result = pj.result; s.progress = pj.progress;
         s.done_counter = static_cast<uint32_t *>(d_words); s.attempt_word = i == 0 ? static_cast<uint32_t *>(d_words) + 1 : nullptr;
         s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
         s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
@@ -254,7 +254,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
     if (n_wg) PL_CHECK(pl_launch_engine(d_jobs, d_sel, n_wg, prm, stream));      /* (a mixed batch: the other engine's images, side by side with this one's) */
     /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */
-    const long max_attempts = (long)max_h * (2 + SEG_MAX_RESTARTS * SEG_NFILT) + 1024;
+    const long max_attempts = (long)max_h * (2 + 2 * SEG_MAX_RESTARTS * SEG_NFILT) + 1024;   /* (an epoch costs two: the attempt that was under way when the validation failed is void) */
     ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
     bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct;
     if (waiting && stream) {

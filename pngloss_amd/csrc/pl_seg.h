@@ -8,7 +8,7 @@
 #include "pl_seg_core.h"
 
 /* per-image device workspace of the engine, beyond what PlJob already has (offsets into one 256-B aligned carve) */
-struct PlSegLayout { size_t ctl, base, h0, acc, tables, maps, ehash, rout, rst, rck, dnout, dcnt, entry, segcnt, grpcnt, grpleft, firstidx, rowmm, total; uint32_t nseg, ngrp; };
+struct PlSegLayout { size_t ctl, base, h0, acc, err0, err1, rowcopy, tables, maps, ehash, rout, rst, rck, dnout, dcnt, entry, segcnt, grpcnt, grpleft, firstidx, rowmm, total; uint32_t nseg, ngrp; };
 PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded);   /* nsp, seeded: SegParams::nsp / ::seeded of the (strength, bleed) pair */
 
 /* can the engine take this batch?  (chain states of (strength, bleed) fit the lanes, every row fits the chain kernel) */
@@ -26,9 +26,7 @@ struct PlSegBatch {
 
 /* fills sj[i].bpp from the class the prepare kernels detected */
 hipError_t pl_seg_launch_resolve(const PlJob *d_jobs, SegJob *d_sj, size_t n, hipStream_t stream);
-/* one attempt = control, enumerate, chain, replay, validate+post */
+/* one attempt = [control + validation of the attempt before], enumerate, chain, replay (attempt: counted by the caller, any starting point that is a multiple of 3) */
 hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t stream);
-/* control kernel only (the attempt after the last row's: writes the final control block) */
-hipError_t pl_seg_launch_control(const PlSegBatch &b, int attempt, hipStream_t stream);
 
 #endif

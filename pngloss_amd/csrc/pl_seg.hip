@@ -26,16 +26,27 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         sj[i].bpp = pl_job_bpp(jobs[sj[i].job_index]);
-        sj[i].ctl[1].magic = 0u;          /* the image's first attempt (parity 0) finds no control block behind it */
+        sj[i].ctl[2].magic = 0u;          /* the image's first attempt (copy 0) finds no attempt behind it: no control block, */
+        sj[i].acc[2].failmask = 0u;       /* ... no failed validation */
     }
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
+/* First launch of attempt k: its CONTROL workgroups (blockIdx.x < nctl: decide the attempt before optimistically, commit, prepare this one) and, side by
+ * side with them, the VALIDATION workgroups of the attempt before (copy kv): the proof of what is being decided arrives one launch later and
+ * takes nothing off the critical path (seg_ctl_body says what happens when it fails). */
+__global__ __launch_bounds__(SEG_THREADS, 8) void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int k, unsigned nctl, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    if (blockIdx.x > SEG_CTL_IMG && (blockIdx.x - SEG_CTL_IMG - 1) * SEG_COMMIT_W >= j.W) return;
-    seg_ctl_body(j, *P, par, (int)blockIdx.x, seg_smem);
+    if (blockIdx.x < nctl) {
+        if (blockIdx.x > SEG_CTL_IMG && (blockIdx.x - SEG_CTL_IMG - 1) * SEG_COMMIT_W >= j.W) return;
+        seg_ctl_body(j, *P, k, (int)blockIdx.x, seg_smem);
+        return;
+    }
+    /* validation groups are half replay groups: max_ngrp * (SEG_GRP / SEG_VGRP) workgroups per candidate */
+    const unsigned bx = blockIdx.x - nctl, per = max_ngrp * (SEG_GRP / SEG_VGRP), f = bx / per, vg = bx % per;
+    if (vg * SEG_VGRP >= j.nseg) return;
+    seg_post_body(j, *P, seg_k_prev(k), (int)f, (int)vg, seg_smem);
 }
 
 /* NT threads per workgroup: 1024 (four channels of a segment) or 512 (a channel pair), see SEG_ENUM_NT_SMALL_MAX_NSEG */
@@ -97,27 +108,17 @@ __global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob 
     seg_replay_body(j, *P, par, (int)f, (int)grp, seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_k_post(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
-{
-    extern __shared__ __align__(16) unsigned char seg_smem[];
-    const SegJob j = sj[blockIdx.y];
-    /* validation groups are half replay groups: max_ngrp * (SEG_GRP / SEG_VGRP) workgroups per candidate */
-    const unsigned per = max_ngrp * (SEG_GRP / SEG_VGRP), f = blockIdx.x / per, vg = blockIdx.x % per;
-    if (vg * SEG_VGRP >= j.nseg) return;
-    seg_post_body(j, *P, par, (int)f, (int)vg, seg_smem);
-}
-
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 /* the kernels of the engine whose dynamic LDS can exceed 64 KB: opted in per device (pl_lds_optin) */
 hipError_t chain_attr()
 {
-    static std::atomic<unsigned> done_chain{ 0 }, done_post{ 0 };
+    static std::atomic<unsigned> done_chain{ 0 }, done_ctl{ 0 };
     hipError_t e = pl_lds_optin((const void *)seg_k_chain, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
-    if (e == hipSuccess && SEG_SM_POST > 65536) e = pl_lds_optin((const void *)seg_k_post, SEG_SM_POST, done_post);
+    if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl, SEG_SM_CTLVAL, done_ctl);
     return e;
 }
-static_assert(SEG_SM_CTL <= 65536 && SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536, "these kernels are launched without an LDS opt-in");
+static_assert(SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536, "these kernels are launched without an LDS opt-in");
 
 } // namespace
 
@@ -128,10 +129,13 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded)
     l.ngrp = (l.nseg + SEG_GRP - 1) / SEG_GRP;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align256(o + (bytes ? bytes : 4)); return at; };
-    l.ctl = take(2 * sizeof(SegCtl));
-    l.base = take(2 * SEG_NFILT * 256 * 4);
-    l.h0 = take(2 * 256 * 4);
-    l.acc = take(2 * sizeof(SegAcc));
+    l.ctl = take(3 * sizeof(SegCtl));
+    l.base = take(3 * SEG_NFILT * 256 * 4);
+    l.h0 = take(3 * 256 * 4);
+    l.acc = take(3 * sizeof(SegAcc));
+    l.err0 = take((size_t)width * 16);
+    l.err1 = take((size_t)width * 16);
+    l.rowcopy = take((size_t)width * 12);
     l.tables = take((size_t)SEG_NFILT * SEG_TBL_WORDS * 4);
     l.maps = take(seeded ? 0 : (size_t)SEG_NFILT * l.nseg * 4 * nsp * 2);
     l.ehash = take(seeded ? (size_t)SEG_NFILT * l.nseg * 4 * SEG_EH_WORDS * 4 : 0);
@@ -145,7 +149,7 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded)
     l.grpcnt = take((size_t)SEG_NFILT * l.ngrp * 256 * 4);
     l.grpleft = take((size_t)SEG_NFILT * l.ngrp * 4);
     l.firstidx = take(SEG_NFILT * 4 * 2 * 4);
-    l.rowmm = take(((size_t)(width + SEG_COMMIT_W - 1) / SEG_COMMIT_W) * 8);
+    l.rowmm = take(((size_t)(width + SEG_COMMIT_W - 1) / SEG_COMMIT_W) * 16);
     l.total = o;
     return l;
 }
@@ -165,20 +169,17 @@ hipError_t pl_seg_launch_resolve(const PlJob *d_jobs, SegJob *d_sj, size_t n, hi
     return hipGetLastError();
 }
 
-hipError_t pl_seg_launch_control(const PlSegBatch &b, int attempt, hipStream_t stream)
-{
-    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, (unsigned)b.n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt & 1);
-    return hipGetLastError();
-}
-
 hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t stream)
 {
     if (!b.n) return hipSuccess;
     hipError_t e = chain_attr();
     if (e != hipSuccess) return e;
-    const int par = attempt & 1;
+    const int par = attempt % 3;                               /* which copy of the control block / sums / histogram / prefix bumps the attempt writes */
     const unsigned n = (unsigned)b.n;
-    hipLaunchKernelGGL(seg_k_ctl, dim3(SEG_CTL_IMG + 1 + b.max_ncommit, n), dim3(SEG_THREADS), SEG_SM_CTL, stream, b.d_sj, b.d_params, attempt & 1);
+    {
+        const unsigned nctl = SEG_CTL_IMG + 1 + b.max_ncommit, nval = SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
+        hipLaunchKernelGGL(seg_k_ctl, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
+    }
     {
         const bool small_ok = b.small_ok;
         const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);
@@ -195,6 +196,5 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     }
     hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
-    hipLaunchKernelGGL(seg_k_post, dim3(SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP), n), dim3(SEG_THREADS), SEG_SM_POST, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();
 }

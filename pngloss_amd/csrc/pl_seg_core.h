@@ -205,9 +205,12 @@ struct SegParams {
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
 struct SegCtl {
-    uint32_t y, s, status, finished, retried, restarts_total, serial_rows, attempts, dropped_none;
+    uint32_t y, s, status;
+    uint32_t finished;               /* 0: rows left; 1: the last row is committed, its validation still out (seg_ctl_body decides OPTIMISTICALLY, see there); 2: finished for good */
+    uint32_t retried, restarts_total, serial_rows, attempts, dropped_none;
     uint32_t magic;                  /* SEG_MAGIC once a control kernel has written this block: the attempt that finds none behind it is the image's first (the launcher resets the word per batch) */
     uint32_t none_eager;             /* rows for which candidate none is run straight away (its bound did not rule it out lately) */
+    uint32_t ignore;                 /* bit f: the decision this block came from does not depend on candidate f's row of the attempt before being valid (none, ruled out by its bound) */
     uint32_t active[SEG_NFILT];      /* the candidate still has unvalidated pixels (or sums) to produce in this attempt */
     uint32_t start_x[SEG_NFILT];     /* pixels [0, start_x) of the candidate row are validated */
     uint32_t state[SEG_NFILT][4];    /* chain state in front of start_x: left | (cn+128) << 8 | (th+128) << 16 */
@@ -218,33 +221,20 @@ struct SegCtl {
 /* the fields of the control block a workgroup branches on, in one burst of loads (read one by one where they are needed, each
  * `if` waits for its own round trip to device memory) */
 struct SegCtlView { uint32_t finished, y, s, active, start_x; };
-PLS_HD SegCtlView seg_ctl_view(const SegCtl &c, int f)
-{
-    SegCtlView v;
-#if defined(__HIP_DEVICE_COMPILE__)
-    /* through the constant address space: the block was written by an EARLIER kernel and is only read here, the address is the same
-     * for the whole workgroup -- scalar loads, all five in flight at once, one wait (as vector loads the compiler sinks each to its
-     * first use: three round trips before a workgroup requests anything else) */
-    typedef const __attribute__((address_space(4))) SegCtl *seg_const_ctl;
-    seg_const_ctl cc = (seg_const_ctl)(uintptr_t)&c;
-    v.finished = cc->finished; v.y = cc->y; v.s = cc->s; v.active = cc->active[f]; v.start_x = cc->start_x[f];
-#else
-    v.finished = c.finished; v.y = c.y; v.s = c.s; v.active = c.active[f]; v.start_x = c.start_x[f];
-#endif
-    return v;
-}
+struct SegJob;
+PLS_HD SegCtlView seg_ctl_view(const SegJob &j, int k, int f);
 
 struct SegAcc {
     uint64_t derr[SEG_NFILT];           /* derivative error of the candidate row (seg_row_sums) */
     uint32_t hs[SEG_NFILT][SEG_NFILT];  /* sums of libpng's heuristic over the candidate row */
-    uint32_t pad_;
     uint32_t fail[SEG_NFILT];        /* smallest failing decision index x*4+c, or SEG_NOFAIL */
+    uint32_t failmask;               /* bit f: candidate f's row failed validation (set by the validation workgroups, one launch behind the attempt) */
     uint32_t lb_valid;               /* workgroups that contributed to none_lb (must reach ngrp) */
     uint64_t none_lb;                /* lower bound of candidate none's row cost (seg_row_sums) */
 };
 
 static_assert(sizeof(SegCtl) / 4 <= 128 && sizeof(SegAcc) / 4 <= 128, "the control kernel copies both with 128 lanes each");
-static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 48 <= 4 * SEG_TN, "they live in the table staging area, below the classes (and the decision behind them)");
+static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 56 <= 4 * SEG_TN, "they live in the table staging area, below the classes (and the decision behind them)");
 
 struct SegJob {
     SEG_AS_GLB uint32_t *img;            /* slots image (pl_device.h) */
@@ -255,17 +245,18 @@ struct SegJob {
     uint32_t job_index;       /* which image of the batch (a mixed batch gives this engine a subset) */
     const SEG_AS_GLB uint32_t *orig_rank;/* [5][256] */
     SEG_AS_GLB uint32_t *cand;           /* [5][W][4]: byte | (diff16 & 0xffff) << 8 | bin << 24 */
-    SEG_AS_GLB uint32_t *err0, *err1;    /* [W][2]: 4 x int16 */
-    SEG_AS_GLB uint32_t *old_above;      /* [W] */
+    SEG_AS_GLB uint32_t *err0, *err1;    /* [2][W][2]: 4 x int16; by the parity of the row they belong to (seg_e0 / seg_e1) */
+    SEG_AS_GLB uint32_t *rowcopy;        /* [3][W]: the ORIGINAL pixels of rows y-1, y, y+1 (row r in copy r % 3): the image row itself is committed in place while
+                                            the validation of that very row is still running, and a row attempt that is repeated wants its originals back */
     SEG_AS_GLB uint32_t *final_hist;     /* [256] */
     SEG_AS_GLB int32_t *result;          /* [64] */
     SEG_AS_GLB uint32_t *progress;       /* or null: host-visible word that receives the number of finished rows (-v display) */
     SEG_AS_GLB uint32_t *done_counter;   /* or null: host-visible word, +1 when this image is finished (the host stops enqueueing attempts) */
     SEG_AS_GLB uint32_t *attempt_word;   /* or null: host-visible word that receives the number of the attempt being started (launch throttle) */
-    SEG_AS_GLB SegCtl *ctl;              /* [2] */
-    SEG_AS_GLB uint32_t *base;           /* [2][5][256] bumps of the validated prefix [0, start_x) */
-    SEG_AS_GLB uint32_t *H0;             /* [2][256] committed histogram */
-    SEG_AS_GLB SegAcc *acc;              /* [2] */
+    SEG_AS_GLB SegCtl *ctl;              /* [3]: by attempt % 3, like base, H0, acc */
+    SEG_AS_GLB uint32_t *base;           /* [3][5][256] bumps of the validated prefix [0, start_x) */
+    SEG_AS_GLB uint32_t *H0;             /* [3][256] committed histogram */
+    SEG_AS_GLB SegAcc *acc;              /* [3] */
     SEG_AS_GLB uint32_t *tables;         /* [5][SEG_TBL_WORDS] */
     SEG_AS_GLB uint16_t *maps;           /* [5][nseg][4][nsp]: entry index of a segment -> dense id of its state after the dedupe (0xffff: none) */
     SEG_AS_GLB uint32_t *ehash;          /* (seeded) [5][nseg][4][SEG_EH_WORDS]: entry hash of a segment: key << 8 | dense id of the entry state, or SEG_EH_EMPTY */
@@ -279,9 +270,45 @@ struct SegJob {
     SEG_AS_GLB uint32_t *grpcnt;         /* [5][ngrp][256] */
     SEG_AS_GLB uint32_t *grpleft;        /* [5][ngrp]: the new bytes (one per channel) the row sums of a group took for the pixel in front of it, when that pixel was another workgroup's (seg_row_sums; checked by the validation) */
     SEG_AS_GLB uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
-    SEG_AS_GLB int32_t *rowmm;           /* [ceil(W / SEG_COMMIT_W)][2]: max and min of orig + incoming error over the pixels of a commit workgroup, current row */
+    SEG_AS_GLB int32_t *rowmm;           /* [2][ceil(W / SEG_COMMIT_W)][2]: max and min of orig + incoming error over the pixels of a commit workgroup; by row parity (seg_rowmm) */
     uint32_t nseg, ngrp;
 };
+
+/* what belongs to row y (see SegJob) */
+PLS_HD SEG_AS_GLB uint32_t *seg_row_orig(const SegJob &j, uint32_t y) { return j.rowcopy + (size_t)(y % 3u) * j.W; }
+PLS_HD SEG_AS_GLB uint32_t *seg_e0(const SegJob &j, uint32_t y) { return j.err0 + (size_t)(y & 1u) * 2u * j.W; }
+PLS_HD SEG_AS_GLB uint32_t *seg_e1(const SegJob &j, uint32_t y) { return j.err1 + (size_t)(y & 1u) * 2u * j.W; }
+PLS_HD SEG_AS_GLB int32_t *seg_rowmm(const SegJob &j, uint32_t y) { return j.rowmm + (size_t)(y & 1u) * 2u * ((j.W + SEG_COMMIT_W - 1) / SEG_COMMIT_W); }
+/* attempt a keeps its control block, sums, histogram and prefix bumps in copy a % 3: the one before, the one two before */
+PLS_HD int seg_k_prev(int k) { return k == 0 ? 2 : k - 1; }
+PLS_HD int seg_k_prev2(int k) { return k == 2 ? 0 : k + 1; }
+
+/* The fields of attempt k's control block that a workgroup of that attempt branches on.  `finished` also stands for "nothing to do":
+ * the attempt is VOID -- a candidate row of the attempt before it failed validation after that row's decision had been taken (the
+ * validation runs one launch behind, seg_ctl_body), and the decision depended on it -- or there is no such attempt (the launch in front
+ * of an image's first). */
+PLS_HD SegCtlView seg_ctl_view(const SegJob &j, int k, int f)
+{
+    SegCtlView v;
+    const int kp = seg_k_prev(k);
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* through the constant address space: the blocks were written by EARLIER kernels and are only read here, the addresses are the same
+     * for the whole workgroup -- scalar loads, all in flight at once, one wait (as vector loads the compiler sinks each to its
+     * first use: three round trips before a workgroup requests anything else) */
+    typedef const __attribute__((address_space(4))) SegCtl *seg_const_ctl;
+    typedef const __attribute__((address_space(4))) SegAcc *seg_const_acc;
+    seg_const_ctl cc = (seg_const_ctl)(uintptr_t)&j.ctl[k];
+    seg_const_acc ca = (seg_const_acc)(uintptr_t)&j.acc[kp];
+    const uint32_t fin = cc->finished, magic = cc->magic, ign = cc->ignore, fm = ca->failmask;
+    v.y = cc->y; v.s = cc->s; v.active = cc->active[f]; v.start_x = cc->start_x[f];
+#else
+    const SegCtl &c = j.ctl[k];
+    const uint32_t fin = c.finished, magic = c.magic, ign = c.ignore, fm = j.acc[kp].failmask;
+    v.y = c.y; v.s = c.s; v.active = c.active[f]; v.start_x = c.start_x[f];
+#endif
+    v.finished = (fin != 0u || magic != SEG_MAGIC || (fm & ~ign) != 0u) ? 1u : 0u;
+    return v;
+}
 
 /* ---- small pure helpers -------------------------------------------------------------------------------------------------- */
 PLS_HD int seg_sext8(int v) { return (int)(int8_t)(uint8_t)(v & 0xff); }
@@ -755,8 +782,9 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
-#define SEG_SM_POST (256 * 4 * 3 + (SEG_GRP + 1) * 256 * 4 + (SEG_GRP * SEG_L + 2) * 4 * 4 + 64 * 4 + 2048 + 3 * (SEG_GRP * SEG_L + 2) * 4 + SEG_GRP * SEG_L * 8 + 768 * 4 + 128 + 256 + SEG_GRP * SEG_L * 4 + SEG_GRP * (SEG_L * 4 + 4) + 8 * (SEG_GRP * (SEG_L + 1) + 8) * 4 + 2 * 20 * 16 + 2048 + 64)
-#define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 2 + (SEG_NFILT + 1) * 256 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
+#define SEG_SM_POST ((768 + (2 * SEG_VGRP + 1) * 256 + (SEG_VGRP * SEG_L + 2) * 4 + 64 + 512 + 3 * (SEG_VGRP * SEG_L + 2) + 2 * SEG_VGRP * SEG_L + 768 + 32 + 64 + SEG_VGRP * SEG_L + SEG_VGRP * (SEG_L + 1) + 8 * (SEG_VGRP * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands) */
+#define SEG_SM_CTLVAL (SEG_SM_CTL > SEG_SM_POST ? SEG_SM_CTL : SEG_SM_POST)   /* the first launch of an attempt carries control and validation workgroups */
+#define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 4 + (SEG_NFILT + 1) * 256 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad > 0 when the lane left the tables */
 template <int F, bool TRX>
@@ -798,8 +826,7 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
 template <int NT>
 PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, int chalf, unsigned char *smem)
 {
-    const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     constexpr int NCH = NT / SEG_NSP;                        /* channels of this workgroup: c0 .. c0 + NCH - 1 */
@@ -821,7 +848,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint16_t *res = (uint16_t *)(uniq + 4 * SEG_NSP);         /* [4][SEG_NSP] exit index of each distinct state */
     uint16_t *lslot = res + 4 * SEG_NSP;                      /* [NT] the hash slot of every lane's state (or 0xffff) */
     const uint32_t y = cv.y;
-    const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long te[5] = { 0, 0, 0, 0, 0 };
@@ -839,7 +866,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        if (tid < SEG_L + 1) vp = seg_pix_fetch(row, nab, j.err0, x0 - 1 + (uint32_t)tid, W);
+        if (tid < SEG_L + 1) vp = seg_pix_fetch(row, nab, e0g, x0 - 1 + (uint32_t)tid, W);
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
@@ -951,8 +978,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
 template <int NT>
 PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, int f, int seg, int chalf, unsigned char *smem)
 {
-    const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);
+    const SegCtlView cv = seg_ctl_view(j, par, f);
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     constexpr int NCH = NT / SEG_NSP;
@@ -973,7 +999,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, i
     uint32_t *uniq = (uint32_t *)(dense + 4 * SEG_EH_WORDS);  /* [4][SEG_NSP] the entry states (keys) by dense id */
     uint32_t *keys = uniq + 4 * SEG_NSP;                      /* [NT] */
     const uint32_t y = cv.y;
-    const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long te[5] = { 0, 0, 0, 0, 0 };
@@ -991,7 +1017,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, i
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        if (tid < npx) vp = seg_pix_fetch(row, nab, j.err0, xs - 1 + (uint32_t)tid, W);      /* (xs = 0: slot 0 lies in front of the row -- zeros) */
+        if (tid < npx) vp = seg_pix_fetch(row, nab, e0g, xs - 1 + (uint32_t)tid, W);      /* (xs = 0: slot 0 lies in front of the row -- zeros) */
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
@@ -1092,8 +1118,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, i
 template <int NT>
 PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
 {
-    const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     constexpr int NSEGS = NT / (4 * SEG_NSS);                 /* segments of this workgroup */
@@ -1102,7 +1127,7 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
     uint32_t *lut = tw + SEG_TBL_WORDS;
     SegPix *px = (SegPix *)(lut + 512);                        /* [NSEGS][SEG_L][4] */
     const uint32_t y = cv.y;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     uint32_t *trflag = (uint32_t *)(px + NSEGS * SEG_L * 4);
     PLS_THREADS(tid, NT) { if (tid == 0) *trflag = 0u; }
@@ -1114,7 +1139,7 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, in
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        if (tid < NSEGS * SEG_L) vp = seg_pix_fetch(row, nab, j.err0, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
+        if (tid < NSEGS * SEG_L) vp = seg_pix_fetch(row, nab, e0g, (uint32_t)seg0 * SEG_L + (uint32_t)tid, W);
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
@@ -1199,7 +1224,7 @@ template <int NT>
 PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = cv.start_x;
@@ -1212,7 +1237,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
     SegPix *px = (SegPix *)(rank + 256);                      /* [SEG_L][4] */
     const unsigned long long tf0 = (P.engine_flags & 1) ? PLS_CLOCK() : 0ull;
     const uint32_t y = cv.y;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     PLS_THREADS(tid, NT) {
         constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
@@ -1222,7 +1247,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
         if (tid < 256) { const int b = tid; vh = j.H0[par * 256 + b]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + b]; vr = j.orig_rank[f * 256 + b]; }
-        if (tid >= 256 && tid < 256 + SEG_L) vp = seg_pix_fetch(row, nab, j.err0, first * SEG_L + (uint32_t)(tid - 256), W);
+        if (tid >= 256 && tid < 256 + SEG_L) vp = seg_pix_fetch(row, nab, e0g, first * SEG_L + (uint32_t)(tid - 256), W);
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
@@ -1276,8 +1301,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 PLS_HD uint32_t seg_chain_cap(uint32_t sh) { return sh >= 8 ? (uint32_t)SEG_CHAIN_CAP8 : (uint32_t)SEG_CHAIN_CAP; }
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
-    const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = cv.start_x;
@@ -1298,7 +1322,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     seg_lds_u16 T = G + 2 * SEG_CHAIN_GWORDS;                  /* [rows][stride]: T[k] takes a dense id of position k to one of position k+1 */
     seg_lds_u32 twr = (seg_lds_u32)((SEG_AS_LDS unsigned char *)T + SEG_CHAIN_TBYTES(nseg));   /* (repair only) the candidate's decision tables, then the walked segment's pixel records */
     const uint32_t y = cv.y;
-    const SEG_AS_GLB uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SEG_AS_GLB uint16_t *maps = j.maps + ((size_t)f * nseg * 4 + c) * (size_t)P.nsp;     /* + sg * 4 * nsp */
     const SEG_AS_GLB uint32_t *ehash = j.ehash + ((size_t)f * nseg * 4 + c) * SEG_EH_WORDS;    /* + sg * 4 * SEG_EH_WORDS */
     const SEG_AS_GLB uint16_t *rout = j.rout + ((size_t)f * nseg * 4 + c) * SEG_NSP;           /* + sg * 4 * SEG_NSP */
@@ -1535,7 +1559,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
                     if (tid < 256) seg_load_frozen(j, par, f, (uint32_t *)Hf, (uint32_t *)rank, tid, 256);
                     if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
                 }
-                if (tid >= 768 && tid < 768 + SEG_L) pxr[tid - 768] = seg_pix_load(row, nab, j.err0, bpp, seg_umin(xq + (uint32_t)(tid - 768), W - 1u), c);
+                if (tid >= 768 && tid < 768 + SEG_L) pxr[tid - 768] = seg_pix_load(row, nab, e0g, bpp, seg_umin(xq + (uint32_t)(tid - 768), W - 1u), c);
                 if (tid == 0) { SEG_DEBUG_COUNT(2, fb); SEG_DEBUG_REPAIR(f, c, sgq, est, idxb[28]); idxb[31] = 1u; idxb[24]++; idxb[25] = 0xFFFFFFFFu; dnout[(size_t)sgq * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgq * 4] = est; }
             }
             PLS_SYNC();
@@ -1591,13 +1615,15 @@ PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, in
 {
     const uint32_t W = j.W, bpp = j.bpp, sx = cv.start_x, y = cv.y;
     const uint32_t x0g = (uint32_t)grp * SEG_GRP * SEG_L;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     uint32_t *nbw = scr;                                       /* [SEG_REPLAY_THREADS] the new bytes of every pixel of the group, one word each */
     uint32_t *rm = scr + SEG_REPLAY_THREADS;                   /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
     uint32_t *red = rm + 768;                                  /* [16] reductions: derr lo/hi, hs[5], left bytes of the first pixel, -, -, lb lo/hi, reach, -, max, min */
     uint32_t *h0s = red + 16;                                  /* [256] the committed histogram */
     uint32_t *cwl = scr2;                                      /* [SEG_REPLAY_THREADS][4] candidate words of the group */
     const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
+    const uint32_t *oab = y ? seg_row_orig(j, y - 1u) : nullptr; /* the ORIGINAL row above */
+    const int32_t *rmm = seg_rowmm(j, y);
     SegAcc &A = j.acc[par];
     PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
     PLS_SYNC();
@@ -1627,7 +1653,7 @@ PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, in
             if (x < W) {
                 const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
                 const uint32_t nav4 = nab ? nab[x] : 0u, ndv4 = (nab && x) ? nab[x - 1] : 0u;
-                const uint32_t oav4 = y ? j.old_above[x] : 0u, odv4 = (y && x) ? j.old_above[x - 1] : 0u;
+                const uint32_t oav4 = y ? oab[x] : 0u, odv4 = (y && x) ? oab[x - 1] : 0u;
                 const uint32_t nb = nbw[tid], nlw = tid ? nbw[tid - 1] : red[7];
                 for (uint32_t c = 0; c < bpp; c++) {
                     const int sh = 8 * (int)c;
@@ -1662,7 +1688,7 @@ PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, in
             const int nc = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
             if (tid < 64) {
                 int M = -(1 << 30), m = 1 << 30;
-                for (int i = tid; i < nc; i += 64) { M = seg_max(M, j.rowmm[2 * i]); m = seg_min(m, j.rowmm[2 * i + 1]); }
+                for (int i = tid; i < nc; i += 64) { M = seg_max(M, rmm[2 * i]); m = seg_min(m, rmm[2 * i + 1]); }
                 M = pls_wave_max_i(M); m = pls_wave_min_i(m);
                 PLS_ATOMIC_MAX_U(&red[14], 0x80000000u ^ (uint32_t)M); PLS_ATOMIC_MIN(&red[15], 0x80000000u ^ (uint32_t)m);
             }
@@ -1689,7 +1715,7 @@ PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, in
                 const uint32_t x = x0g + (uint32_t)tid;
                 if (x < W) {
                     const uint32_t o = row[x];
-                    const uint32_t e[2] = { j.err0[2 * (size_t)x], j.err0[2 * (size_t)x + 1] };
+                    const uint32_t e[2] = { e0g[2 * (size_t)x], e0g[2 * (size_t)x + 1] };
                     const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
                     for (uint32_t c = 0; c < bpp; c++) {
                         uint32_t hmax;
@@ -1725,7 +1751,7 @@ PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, in
 PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished) return;
     const bool lazy = f == 0 && cv.active == 2;               /* candidate none, not run yet: only its cost bound is wanted */
     if (!lazy && cv.active != 1) return;
@@ -1739,7 +1765,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
     uint32_t *lane = cnt + SEG_GRP * 256;                     /* [SEG_GRP * SEG_PARTS * 4][2]: start state, first | end pixel << 16 (or ~0: idle) */
     const uint32_t y = cv.y;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     if (walk) {
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
@@ -1757,7 +1783,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
         for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
         if (tid < 256) { vh = j.H0[par * 256 + tid]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + tid]; vr = j.orig_rank[f * 256 + tid]; }
-        const SegPixRaw vp = seg_pix_fetch(row, nab, j.err0, seg0 * SEG_L + (uint32_t)tid, W);
+        const SegPixRaw vp = seg_pix_fetch(row, nab, e0g, seg0 * SEG_L + (uint32_t)tid, W);
         uint32_t ck[SEG_PARTS - 1], ent = 0;
         PLS_UNROLL
         for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = 0xFFFFFFFFu;
@@ -1953,8 +1979,7 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int
  * the bound cannot tell. */
 PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, int vg, unsigned char *smem)
 {
-    const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(ctl, f);                /* (the fields this workgroup branches on, requested together) */
+    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;                 /* (candidate none while it is lazy has no row to validate) */
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
     const uint32_t sx = cv.start_x;
@@ -1981,7 +2006,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     uint32_t *btop = pcw + SEG_WATCH * SEG_PC_STRIDE;          /* [2][SEG_NBAND][4] */
     uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
     const uint32_t y = cv.y;
-    const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+    const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     const uint32_t xg0 = seg0 * SEG_L;
     const bool prof = (P.engine_flags & 1) != 0;                /* debugging: phase clocks (100 MHz ticks) into result[40..], max over the workgroups */
@@ -2009,8 +2034,8 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
         if (tid == 9) vgl = j.grpleft[(size_t)f * ngrp + grp];
         if (tid >= 512 && tid - 512 < NPX) {
             const uint32_t x = xg0 + (uint32_t)(tid - 512);
-            ve0a = x < W ? j.err0[2 * (size_t)x] : 0u;
-            ve0b = x < W ? j.err0[2 * (size_t)x + 1] : 0u;
+            ve0a = x < W ? e0g[2 * (size_t)x] : 0u;
+            ve0b = x < W ? e0g[2 * (size_t)x + 1] : 0u;
         }
         /* bump counts per segment of the group, staged (one 8-byte load per thread), prefix below */
         const int sl = tid >> 6, q4 = tid & 63;
@@ -2156,7 +2181,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid == 0) {
             SegAcc &A = j.acc[par];
-            if (red[8] != SEG_NOFAIL) PLS_ATOMIC_MIN(&A.fail[f], red[8]);
+            if (red[8] != SEG_NOFAIL) { PLS_ATOMIC_MIN(&A.fail[f], red[8]); PLS_ATOMIC_OR(&A.failmask, 1u << f); }
             if (prof) {
                 tk[4] = PLS_CLOCK(); tk[5] = tk[4];
                 for (int q = 0; q < 5; q++) { PLS_ATOMIC_MAX(&j.result[40 + q], (int32_t)(tk[q + 1] - tk[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[48 + q], (uint32_t)(tk[q + 1] - tk[q])); }
@@ -2172,19 +2197,22 @@ struct SegDecision {
     int kind, winner, dropped_none, start_none, keep_lazy;
     uint32_t failed;                /* bit f: candidate f failed validation in the attempt just finished */
     uint64_t cost[SEG_NFILT];
+    uint32_t ignore, pad_;          /* bit f: whether candidate f's row of that attempt is valid does not matter to this decision */
 };
+static_assert(sizeof(SegDecision) / 4 <= 20, "seg_decide_wg shares it through 20 words");
 
 /* what the attempt that just finished (control block `cur`, sums `A`) means -- in two steps, so that five lanes can look at a
  * candidate each before one lane draws the conclusion.  Step 1, candidate f: its row cost, or why it has none yet. */
 static_assert(offsetof(SegDecision, cost) == 24, "seg_ctl_body reads cost[f] out of the shared copy by word index");
 struct SegCandDec { uint64_t cost; uint32_t state; uint32_t pad_; };      /* state 0: cost is final (or ~0: no acceptable row), 1: lazy (none, not run yet), 2: failed validation */
+/* optimistic: the validation of the attempt is still out (it runs next to this decision): every row is taken for valid */
 template <class CT, class AT>
-PLS_HD SegCandDec seg_decide_cand(const SegJob &j, const SegParams &P, CT &cur, AT &A, int f, uint32_t ecost)
+PLS_HD SegCandDec seg_decide_cand(const SegJob &j, const SegParams &P, CT &cur, AT &A, int f, uint32_t ecost, bool optimistic)
 {
     SegCandDec r; r.cost = ~0ull; r.state = 0; r.pad_ = 0;
     if (!cur.active[f]) { r.cost = cur.cost[f]; return r; }
     if (cur.active[f] == 2) { r.state = 1; return r; }                             /* candidate none, not run yet */
-    if (A.fail[f] != SEG_NOFAIL) { r.state = 2; return r; }
+    if (!optimistic && A.fail[f] != SEG_NOFAIL) { r.state = 2; return r; }
     const bool adaptive = !j.row_filters || cur.y == 0;
     uint64_t cst = A.derr[f] / 128u + ecost;                                      /* optimize_state.c:360 (ecost: seg_entropy_costs) */
     if (adaptive) {
@@ -2198,10 +2226,10 @@ PLS_HD SegCandDec seg_decide_cand(const SegJob &j, const SegParams &P, CT &cur, 
 }
 /* Step 2: the conclusion.  Every workgroup of the control kernel comes to the same one. */
 template <class CT, class AT, class DT>
-PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int attempt, CT &cur, AT &A, DT *cd)
+PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int attempt, CT &cur, AT &A, DT *cd, bool optimistic)
 {
     SegDecision D;
-    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0; D.dropped_none = 0; D.start_none = 0; D.keep_lazy = 0;
+    D.kind = SEG_K_INIT; D.winner = -1; D.failed = 0; D.dropped_none = 0; D.start_none = 0; D.keep_lazy = 0; D.ignore = 0; D.pad_ = 0;
     for (int f = 0; f < SEG_NFILT; f++) D.cost[f] = ~0ull;
     if (attempt == 0) return D;
     if (cur.finished) { D.kind = SEG_K_FINISHED; return D; }
@@ -2212,7 +2240,8 @@ PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int a
         if (cd[f].state == 2) { D.failed |= 1u << f; any_failed = true; continue; }
         D.cost[f] = cd[f].cost;
     }
-    if (((D.failed & 1u) || lazy0) && !(P.engine_flags >> 8)) {
+    const bool none_unsure = optimistic && cur.active[0] == 1u;     /* none was run, and whether its row is valid is not known yet */
+    if (((D.failed & 1u) || lazy0 || none_unsure) && !(P.engine_flags >> 8)) {
         /* Candidate none failed validation, or has not been run at all (lazy).  Its row cost is at least none_lb (seg_post_body); it has
          * the lowest index, so it wins ties (pngloss_image.c:257) and loses only to a strictly cheaper row: if one exists already, none
          * cannot be the winner whatever its exact row would be -- running it (again) is not worth it.  (The winner's row, histogram and
@@ -2221,6 +2250,7 @@ PLS_HD SegDecision seg_decide_combine(const SegJob &j, const SegParams &P, int a
         for (int f = 1; f < SEG_NFILT; f++) if (!((D.failed >> f) & 1u) && D.cost[f] < best_other) best_other = D.cost[f];
         if (A.lb_valid == j.ngrp && best_other < A.none_lb) {
             D.failed &= ~1u; D.cost[0] = ~0ull; D.dropped_none = 1; lazy0 = false;
+            D.ignore |= 1u;
             any_failed = D.failed != 0;
         }
     }
@@ -2280,6 +2310,29 @@ PLS_HD void seg_spec_store(const SegJob &j, int t, int nt, const SegSpecRegs<NSP
         }
     }
 }
+/* (rare) the same for the attempt TWO before, when the one before turned out void: control block, sums and spec once more, plainly */
+PLS_HD void seg_ctl_reload(const SegJob &j, int prev, seg_lds_u32 ctlc, seg_lds_u32 accc, seg_lds_u32 spec, int nt)
+{
+    const uint32_t ngrp = j.ngrp, W = j.W;
+    PLS_SYNC();
+    PLS_THREADS(tid, nt) {
+        if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = ((const SEG_AS_GLB uint32_t *)&j.ctl[prev])[tid];
+        if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = ((const SEG_AS_GLB uint32_t *)&j.acc[prev])[tid - 128];
+        for (int i = tid; i < (SEG_NFILT + 1) * 256; i += nt) {
+            const int w = i >> 8, b = i & 255;
+            uint32_t v;
+            if (w == SEG_NFILT) v = j.H0[prev * 256 + b];
+            else {
+                v = j.base[((size_t)prev * SEG_NFILT + w) * 256 + b];
+                const uint32_t wsx = j.ctl[prev].start_x[w], wfg = (wsx / SEG_L) / SEG_GRP;
+                for (uint32_t g = wfg; g < ngrp && wsx < W; g++) v += j.grpcnt[((size_t)w * ngrp + g) * 256 + b];
+            }
+            spec[i] = v;
+        }
+    }
+    PLS_SYNC();
+}
+
 /* The entropy cost of every candidate row (optimize_state.c:326-342): a pixel is charged 64 - floor(log2 H[symbol]) = 33 + clz(H[symbol]) under
  * the histogram AFTER the row, and its symbol is the bin it bumped (:251-254 -- the stored byte minus the same prediction), so the row costs
  * sum over bins of n * (33 + clz(H0 + n)), n = the row's bumps of the bin: no pass over the pixels.  ecost: SEG_NFILT (8) words of shared
@@ -2304,11 +2357,11 @@ PLS_HD void seg_entropy_costs(seg_lds_u32 spec, seg_lds_u32 ecost, int nt)
 typedef SEG_AS_LDS const SegCtl seg_lds_ctl_t;
 typedef SEG_AS_LDS const SegAcc seg_lds_acc_t;
 /* the whole workgroup: lanes 0..4 step 1, lane 0 step 2; the result in shared memory (dshare: 16 words, cdw: 20 words behind it) */
-PLS_HD SegDecision seg_decide_wg(const SegJob &j, const SegParams &P, int attempt, seg_lds_ctl_t &cur, seg_lds_acc_t &A, seg_lds_u32 ecost, seg_lds_u32 cdw, seg_lds_u32 dshare, int nt)
+PLS_HD SegDecision seg_decide_wg(const SegJob &j, const SegParams &P, int attempt, seg_lds_ctl_t &cur, seg_lds_acc_t &A, seg_lds_u32 ecost, seg_lds_u32 cdw, seg_lds_u32 dshare, int nt, bool optimistic)
 {
     PLS_THREADS(tid, nt) {
         if (tid < SEG_NFILT && attempt) {
-            const SegCandDec r = seg_decide_cand(j, P, cur, A, tid, ecost[tid]);
+            const SegCandDec r = seg_decide_cand(j, P, cur, A, tid, ecost[tid], optimistic);
             cdw[4 * tid] = (uint32_t)r.cost; cdw[4 * tid + 1] = (uint32_t)(r.cost >> 32); cdw[4 * tid + 2] = r.state; cdw[4 * tid + 3] = 0u;
         }
     }
@@ -2317,7 +2370,7 @@ PLS_HD SegDecision seg_decide_wg(const SegJob &j, const SegParams &P, int attemp
         if (tid == 0) {
             SegCandDec cd[SEG_NFILT];
             for (int f = 0; f < SEG_NFILT; f++) { cd[f].cost = (uint64_t)cdw[4 * f] | ((uint64_t)cdw[4 * f + 1] << 32); cd[f].state = cdw[4 * f + 2]; cd[f].pad_ = 0; }
-            const SegDecision D = seg_decide_combine(j, P, attempt, cur, A, cd);
+            const SegDecision D = seg_decide_combine(j, P, attempt, cur, A, cd, optimistic);
             uint32_t w[sizeof(SegDecision) / 4];
             memcpy(w, &D, sizeof D);
             for (int i = 0; i < (int)(sizeof(SegDecision) / 4); i++) dshare[i] = w[i];
@@ -2421,62 +2474,69 @@ PLS_HD void seg_next_hist(const SegDecision &D, seg_lds_u32 spec, seg_lds_u32 Hn
  * SEG_COMMIT_W lanes work (one wave per SIMD); the other waves of the launch shape only keep the barriers company. */
 PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw, unsigned char *smem)
 {
-    const int prev = par ^ 1;
-    const SegCtl &curg = j.ctl[prev];
-    const SegAcc &Ag = j.acc[prev];
+    const int k1 = seg_k_prev(par), k2 = seg_k_prev2(par);
     const uint32_t W = j.W, H = j.H, bpp = j.bpp;
     SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                /* [0] max, [1] min of orig + incoming error over this workgroup's pixels of the COMING row */
     seg_lds_u32 lutb = (seg_lds_u32)smem + 8;                  /* [512] next-rows terms of the split */
     seg_lds_u32 ctlc = lutb + 512, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2, dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
-    seg_lds_u32 ecost = dshare + 40;                           /* [8] entropy cost of every candidate row */
-    seg_lds_u32 cw5 = dshare + 48;                             /* [SEG_NFILT][(SEG_COMMIT_W + 4)][4] every candidate's words of this workgroup's pixels, two more on either side; the winner's become their terms */
-    seg_lds_u32 ext = cw5 + SEG_NFILT * (SEG_COMMIT_W + 4) * 4;/* [SEG_COMMIT_W][2]: err1 */
-    seg_lds_u32 spec = ext + SEG_COMMIT_W * 2;                 /* [SEG_NFILT + 1][256] the bumps of every candidate's row, the committed histogram (for the row costs: seg_entropy_costs) */
+    seg_lds_u32 ecost = dshare + 40;                           /* [8] entropy cost of every candidate row; [48]: failmask of the attempt two before */
+    seg_lds_u32 cw5 = dshare + 56;                             /* [SEG_NFILT][(SEG_COMMIT_W + 4)][4] every candidate's words of this workgroup's pixels, two more on either side; the winner's become their terms */
+    seg_lds_u32 ext = cw5 + SEG_NFILT * (SEG_COMMIT_W + 4) * 4;/* [2][SEG_COMMIT_W][2]: err1 of either row parity (which row is committed is in the control block these loads ride along with) */
+    seg_lds_u32 spec = ext + SEG_COMMIT_W * 4;                 /* [SEG_NFILT + 1][256] the bumps of every candidate's row, the committed histogram (for the row costs: seg_entropy_costs) */
     const uint32_t xw0 = (uint32_t)cw * SEG_COMMIT_W;
     const bool prof = (P.engine_flags & 1) != 0;
     unsigned long long tc0 = 0;
     if (prof) tc0 = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_THREADS) {
-        if (tid < SEG_COMMIT_W) {
-            const uint32_t x = xw0 + (uint32_t)tid;
-            const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
-            const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
-            const uint32_t lb0 = P.lut_b[tid], lb1 = P.lut_b[tid + SEG_COMMIT_W];
-            const long xh = tid < 2 ? (long)xw0 - 2 + tid : (long)xw0 + SEG_COMMIT_W + (tid - 2);     /* (threads 0..3) the halo pixel */
-            /* every request first, then the stores: a loop that loads and stores turn by turn waits for each load on its own */
-            uint32_t w5[SEG_NFILT][4], h5[SEG_NFILT][4];
-            const bool inrow = x < W, halo = tid < 4 && xh >= 0 && xh < (long)W;
-            PLS_UNROLL
-            for (int f = 0; f < SEG_NFILT; f++) {
+    /* (which attempt this one follows: see seg_ctl_body) */
+    {
+        const SegCtl &curg = j.ctl[k1];
+        const SegAcc &Ag = j.acc[k1];
+        PLS_THREADS(tid, SEG_THREADS) {
+            if (tid < SEG_COMMIT_W) {
+                const uint32_t x = xw0 + (uint32_t)tid;
+                const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
+                const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
+                const uint32_t fmw = tid == 0 ? j.acc[k2].failmask : 0u;
+                const uint32_t lb0 = P.lut_b[tid], lb1 = P.lut_b[tid + SEG_COMMIT_W];
+                const long xh = tid < 2 ? (long)xw0 - 2 + tid : (long)xw0 + SEG_COMMIT_W + (tid - 2);     /* (threads 0..3) the halo pixel */
+                /* every request first, then the stores: a loop that loads and stores turn by turn waits for each load on its own */
+                uint32_t w5[SEG_NFILT][4], h5[SEG_NFILT][4];
+                const bool inrow = x < W, halo = tid < 4 && xh >= 0 && xh < (long)W;
                 PLS_UNROLL
-                for (int q = 0; q < 4; q++) {
-                    w5[f][q] = inrow ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
-                    h5[f][q] = halo ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
+                for (int f = 0; f < SEG_NFILT; f++) {
+                    PLS_UNROLL
+                    for (int q = 0; q < 4; q++) {
+                        w5[f][q] = inrow ? j.cand[((size_t)f * W + x) * 4 + q] : 0u;
+                        h5[f][q] = halo ? j.cand[((size_t)f * W + (size_t)xh) * 4 + q] : 0u;
+                    }
                 }
-            }
-            const uint32_t e1a = inrow ? j.err1[2 * (size_t)x] : 0u, e1b = inrow ? j.err1[2 * (size_t)x + 1] : 0u;
-            PLS_UNROLL
-            for (int f = 0; f < SEG_NFILT; f++) {
+                uint32_t e1v[4] = { 0, 0, 0, 0 };
+                if (inrow) { e1v[0] = j.err1[2 * (size_t)x]; e1v[1] = j.err1[2 * (size_t)x + 1]; e1v[2] = j.err1[2 * ((size_t)W + x)]; e1v[3] = j.err1[2 * ((size_t)W + x) + 1]; }
                 PLS_UNROLL
-                for (int q = 0; q < 4; q++) {
-                    cw5[(f * (SEG_COMMIT_W + 4) + tid + 2) * 4 + q] = w5[f][q];
-                    if (tid < 4) cw5[(f * (SEG_COMMIT_W + 4) + (tid < 2 ? tid : SEG_COMMIT_W + tid)) * 4 + q] = h5[f][q];
+                for (int f = 0; f < SEG_NFILT; f++) {
+                    PLS_UNROLL
+                    for (int q = 0; q < 4; q++) {
+                        cw5[(f * (SEG_COMMIT_W + 4) + tid + 2) * 4 + q] = w5[f][q];
+                        if (tid < 4) cw5[(f * (SEG_COMMIT_W + 4) + (tid < 2 ? tid : SEG_COMMIT_W + tid)) * 4 + q] = h5[f][q];
+                    }
                 }
+                ext[tid * 2 + 0] = e1v[0]; ext[tid * 2 + 1] = e1v[1]; ext[(SEG_COMMIT_W + tid) * 2 + 0] = e1v[2]; ext[(SEG_COMMIT_W + tid) * 2 + 1] = e1v[3];
+                lutb[tid] = lb0; lutb[tid + SEG_COMMIT_W] = lb1;
+                if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; dshare[48] = fmw; }
+                if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
+                if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
+            } else {
+                /* (the lanes that have no pixel) what every candidate's row bumped: the decision wants the row costs */
+                constexpr int NLD = SEG_THREADS - SEG_COMMIT_W, NSP = ((SEG_NFILT + 1) * 256 + NLD - 1) / NLD;
+                SegSpecRegs<NSP> sr;
+                seg_spec_request<NSP>(j, k1, curg, tid - SEG_COMMIT_W, NLD, sr);
+                seg_spec_store<NSP>(j, tid - SEG_COMMIT_W, NLD, sr, spec);
             }
-            ext[tid * 2 + 0] = e1a; ext[tid * 2 + 1] = e1b;
-            if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
-            if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
-            lutb[tid] = lb0; lutb[tid + SEG_COMMIT_W] = lb1;
-            if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; }
-        } else {
-            /* (the lanes that have no pixel) what every candidate's row bumped: the decision wants the row costs */
-            constexpr int NLD = SEG_THREADS - SEG_COMMIT_W, NSP = ((SEG_NFILT + 1) * 256 + NLD - 1) / NLD;
-            SegSpecRegs<NSP> sr;
-            seg_spec_request<NSP>(j, prev, curg, tid - SEG_COMMIT_W, NLD, sr);
-            seg_spec_store<NSP>(j, tid - SEG_COMMIT_W, NLD, sr, spec);
         }
     }
     PLS_SYNC();
+    const bool redo = ((seg_lds_ctl_t *)ctlc)->magic == SEG_MAGIC && (dshare[48] & ~((seg_lds_ctl_t *)ctlc)->ignore) != 0u;
+    if (redo) seg_ctl_reload(j, k2, ctlc, accc, spec, SEG_THREADS);
     unsigned long long tk[4] = { 0, 0, 0, 0 };
     if (prof) tk[0] = PLS_CLOCK();
     seg_lds_ctl_t &cur = *(seg_lds_ctl_t *)ctlc;
@@ -2484,7 +2544,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
     const bool fresh = cur.magic != SEG_MAGIC;                 /* the image's first attempt: nothing behind it (what the burst read is junk) */
     const int attempt = fresh ? 0 : 1;
     if (fresh) {
-        /* the first row: extremes of the original values (no incoming error yet) */
+        /* the first row: its originals into rowcopy, their extremes (no incoming error yet) */
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
         PLS_SYNC();
@@ -2494,6 +2554,9 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
                 int vmax = -(1 << 30), vmin = 1 << 30;
                 if (x < W && H) {
                     const uint32_t o = j.img[x];
+                    seg_row_orig(j, 0u)[x] = o;
+                    SEG_AS_GLB uint32_t *e00 = seg_e0(j, 0u), *e10 = seg_e1(j, 0u);      /* nothing has been diffused into the first row */
+                    e00[2 * (size_t)x] = 0u; e00[2 * (size_t)x + 1] = 0u; e10[2 * (size_t)x] = 0u; e10[2 * (size_t)x + 1] = 0u;
                     const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
                     for (uint32_t c = 0; c < bpp; c++) {
                         if (alpha0 && c == bpp - 1u) continue;
@@ -2506,11 +2569,11 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
             }
         }
         PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
+        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { SEG_AS_GLB int32_t *rm0 = seg_rowmm(j, 0u); rm0[2 * cw] = mm[0]; rm0[2 * cw + 1] = mm[1]; } }
         return;
     }
     seg_entropy_costs(spec, ecost, SEG_THREADS);
-    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, ecost, dshare + 16, dshare, SEG_THREADS);
+    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, ecost, dshare + 20, dshare, SEG_THREADS, !redo);
     if (D.kind != SEG_K_COMMIT) return;
     if (prof) tk[1] = PLS_CLOCK();
     const int winner = D.winner;
@@ -2518,6 +2581,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
     const uint32_t keep = bpp >= 4 ? 0xffffffffu : ((1u << (8 * bpp)) - 1u);
     const uint32_t y = cur.y, ynext = y + 1;
     uint32_t *rowp = j.img + (size_t)y * W;
+    SEG_AS_GLB uint32_t *e0n = seg_e0(j, ynext), *e1n = seg_e1(j, ynext);
     seg_lds_u32 npx = cw5 + ((winner + 1) % SEG_NFILT) * (SEG_COMMIT_W + 4) * 4;     /* (a loser's tile) the row's new pixel */
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < SEG_COMMIT_W) {
@@ -2536,8 +2600,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
             int vmax = -(1 << 30), vmin = 1 << 30;
             if (x < W) {
                 const uint32_t onext = ynext < H ? j.img[(size_t)ynext * W + x] : 0u;
-                const uint32_t oldrow = rowp[x];
-                const uint32_t e1[2] = { ext[tid * 2 + 0], ext[tid * 2 + 1] };
+                const uint32_t e1[2] = { ext[((y & 1u) * SEG_COMMIT_W + tid) * 2 + 0], ext[((y & 1u) * SEG_COMMIT_W + tid) * 2 + 1] };
                 /* error rows: err0'[x] = err1[x] + t(x+2)+f(x+1)+v(x)+f(x-1)+t(x-2), err1'[x] = t(x+1)+h(x)+t(x-1) (optimize_state.c:446-465) */
                 uint32_t n0[4], n1[4];
                 for (int p = 0; p < 4; p++) {
@@ -2556,11 +2619,13 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
                     n0[p] = (uint32_t)(seg_err_plane(e1, p) + c1) & 0xffffu;     /* int16 wrap-on-store */
                     n1[p] = (uint32_t)c2 & 0xffffu;
                 }
-                j.old_above[x] = oldrow;
+                /* the image row in place (its originals stay in rowcopy for the validation that runs next to this, and for a repetition);
+                 * the coming row's originals, incoming errors and extremes into the copies of ITS parity */
                 rowp[x] = npx[tid];
-                j.err0[2 * (size_t)x] = n0[0] | (n0[1] << 16); j.err0[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
-                j.err1[2 * (size_t)x] = n1[0] | (n1[1] << 16); j.err1[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
+                e0n[2 * (size_t)x] = n0[0] | (n0[1] << 16); e0n[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
+                e1n[2 * (size_t)x] = n1[0] | (n1[1] << 16); e1n[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
                 if (ynext < H) {
+                    seg_row_orig(j, ynext)[x] = onext;
                     const bool alpha0 = (bpp & 1u) == 0u && ((onext >> (8u * (bpp - 1u))) & 255u) == 0u;
                     for (uint32_t c = 0; c < bpp; c++) {
                         if (alpha0 && c == bpp - 1u) continue;
@@ -2578,7 +2643,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
         }
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { j.rowmm[2 * cw] = mm[0]; j.rowmm[2 * cw + 1] = mm[1]; } }
+    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { SEG_AS_GLB int32_t *rmn = seg_rowmm(j, ynext); rmn[2 * cw] = mm[0]; rmn[2 * cw + 1] = mm[1]; } }
     if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const uint32_t dt = (uint32_t)(PLS_CLOCK() - tc0); PLS_ATOMIC_MAX(&j.result[58], (int32_t)dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[62], dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[63], 1u); PLS_ATOMIC_ADD((uint32_t *)&j.result[23], (uint32_t)(tk[0] - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[45], (uint32_t)(tk[1] - tk[0])); PLS_ATOMIC_ADD((uint32_t *)&j.result[54], (uint32_t)(tk[2] - tk[1])); PLS_ATOMIC_ADD((uint32_t *)&j.result[55], (uint32_t)(PLS_CLOCK() - tk[2])); } } }
 }
 
@@ -2588,10 +2653,18 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
 PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, unsigned char *smem)
 {
     if (bx > SEG_CTL_IMG) { seg_ctl_commit(j, P, par, bx - SEG_CTL_IMG - 1, smem); return; }
-    const int prev = par ^ 1;
-    const SegCtl &curg = j.ctl[prev];
+    /* WHICH attempt this one follows.  Normally the one before it (copy k1), whose validation is still running -- in this very launch
+     * (seg_k_ctl carries the validation workgroups of the attempt before next to the control workgroups of this one) -- so the decision
+     * is taken OPTIMISTICALLY: every candidate row is assumed valid (they are in all but a handful of rows per image), the winner is
+     * committed and the next row prepared while the proof is still out.  Everything the validation (and a repetition of the row)
+     * reads is left alone: the commit writes the image row in place but the row's originals live in rowcopy, the error rows and the
+     * row's extremes are double buffered by row parity, control block / sums / histogram / prefix bumps are kept three deep.
+     * If that proof FAILED -- failmask of the attempt two before (k2), known by now, minus what the decision one before said it does not
+     * depend on -- the attempt one before was void (its workgroups saw the same words and did nothing): this one follows the attempt
+     * two before instead, with the failures known (an epoch for the failed candidates, as ever).  The words that tell ride along with
+     * the burst of loads; the rare repetition pays a second burst. */
+    const int k1 = seg_k_prev(par), k2 = seg_k_prev2(par);
     SegCtl &nxt = j.ctl[par];
-    const SegAcc &Ag = j.acc[prev];
     const uint32_t W = j.W, H = j.H, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
     seg_lds_u32 Hn = (seg_lds_u32)smem, rank = Hn + 256, scratch = Hn + 512, basen = Hn + 768;   /* 4 x 256 words */
     seg_lds_u32 stage = Hn + 1024;                               /* SEG_TBL_WORDS: a candidate's tables before they go out; the commit workgroups keep the split table here */
@@ -2604,33 +2677,40 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
     seg_lds_u32 spec = stage;                                  /* [SEG_NFILT + 1][256] */
     /* the finished attempt's control block and sums, copied into shared memory by the same burst of loads: everything below reads the copies */
     seg_lds_u32 ctlc = stage + (SEG_NFILT + 1) * 256, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2;
+    seg_lds_u32 dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;  /* [20] the decision, [20] the candidates' verdicts, [8] entropy costs, [4] which attempt is followed */
+    int prev = k1;
     {
+        const SegCtl &curg = j.ctl[k1];
+        const SegAcc &Ag = j.acc[k1];
         PLS_THREADS(tid, SEG_THREADS) {
             /* every request of the burst first, the stores behind them (the image's first attempt reads junk here and ignores it) */
             const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
             const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
             const uint32_t rword = (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) ? j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)] : 0u;
+            const uint32_t fmw = tid == 512 ? j.acc[k2].failmask : 0u;
             constexpr int NSP = ((SEG_NFILT + 1) * 256 + SEG_THREADS - 1) / SEG_THREADS;
             SegSpecRegs<NSP> sr;
-            seg_spec_request<NSP>(j, prev, curg, tid, SEG_THREADS, sr);
+            seg_spec_request<NSP>(j, k1, curg, tid, SEG_THREADS, sr);
             if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
             if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
             if (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) rank[tid - 256] = rword;
+            if (tid == 512) dshare[48] = fmw;
             seg_spec_store<NSP>(j, tid, SEG_THREADS, sr, spec);
         }
     }
     PLS_SYNC();
+    const bool redo = ((seg_lds_ctl_t *)ctlc)->magic == SEG_MAGIC && (dshare[48] & ~((seg_lds_ctl_t *)ctlc)->ignore) != 0u;
+    if (redo) { prev = k2; seg_ctl_reload(j, k2, ctlc, accc, spec, SEG_THREADS); }
     unsigned long long tq1 = 0, tq2 = 0;
     if (prof) tq1 = PLS_CLOCK();
     seg_lds_ctl_t &cur = *(seg_lds_ctl_t *)ctlc;
     seg_lds_acc_t &A = *(seg_lds_acc_t *)accc;
     /* one lane decides, the workgroup reads the result (16 waves working it out side by side only take each other's issue slots) */
-    seg_lds_u32 dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
-    /* the number of this attempt is kept on the device (the launcher passes parities only: a captured launch sequence can be replayed) */
-    const int attempt = cur.magic != SEG_MAGIC ? 0 : (int)cur.attempts + 1;
+    /* the number of this attempt is kept on the device (the launcher passes the copy index only) */
+    const int attempt = cur.magic != SEG_MAGIC ? 0 : (int)cur.attempts + (redo ? 2 : 1);
     seg_lds_u32 ecost = dshare + 40;                            /* [8] entropy cost of every candidate row */
     seg_entropy_costs(spec, ecost, SEG_THREADS);
-    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, ecost, dshare + 16, dshare, SEG_THREADS);
+    const SegDecision D = seg_decide_wg(j, P, attempt, cur, A, ecost, dshare + 20, dshare, SEG_THREADS, !redo);
     if (prof) tq2 = PLS_CLOCK();
     const uint32_t y = attempt ? cur.y : 0u;
     int s_next = attempt ? (int)cur.s : P.strength;
@@ -2640,7 +2720,29 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
     if (bx == SEG_CTL_IMG) {
         /* ---- the image-wide fields ---- */
         if (D.kind == SEG_K_FINISHED) {
-            PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 1; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = cur.attempts + 1u; nxt.magic = SEG_MAGIC; nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt); } }
+            /* every row is committed.  finished == 1: the last row's validation was still out when that was written -- it has passed (else this
+             * attempt would follow the one two before): the image is finished for good, and says so */
+            PLS_THREADS(tid, SEG_THREADS) {
+                if (tid < (int)(sizeof(SegAcc) / 4)) ((uint32_t *)&j.acc[par])[tid] = 0u;
+                if (tid >= 256 && tid < 512 && cur.finished == 1u) Hn[tid - 256] = j.H0[prev * 256 + (tid - 256)];
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, SEG_THREADS) {
+                if (tid == 0) {
+                    nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 2; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = (uint32_t)attempt; nxt.magic = SEG_MAGIC;
+                    nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; nxt.ignore = 0u;
+                    if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt);
+                    if (cur.finished == 1u) {
+                        /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
+                        uint32_t nz = 0;
+                        for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
+                        for (int i = 0; i < 24; i++) if (i < 8 || i == 20 || (i != 17 && !(P.engine_flags & 1))) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
+                        j.result[0] = (int32_t)cur.status; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)cur.retried;
+                        j.result[4] = (int32_t)cur.restarts_total; j.result[5] = (int32_t)cur.attempts; j.result[6] = (int32_t)cur.serial_rows; j.result[7] = (int32_t)cur.dropped_none; j.result[20] = 3;   /* engine id: segment-parallel */
+                        if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
+                    }
+                }
+            }
             return;
         }
         if (D.kind != SEG_K_RESTART) seg_next_hist(D, spec, Hn, SEG_THREADS);
@@ -2672,15 +2774,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
                 }
                 if (j.progress && D.kind == SEG_K_COMMIT) PLS_HOST_VISIBLE_STORE(j.progress, ny);
                 if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt);
-                if (fin) {
-                    /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
-                    uint32_t nz = 0;
-                    for (int b = 0; b < 256; b++) { j.final_hist[b] = Hn[b]; nz += Hn[b] != 0; }
-                    for (int i = 0; i < 24; i++) if (i < 8 || i == 20 || (i != 17 && !(P.engine_flags & 1))) j.result[i] = 0;   /* (8..18: the chain kernel's phase clocks) */
-                    j.result[0] = (int32_t)st; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = (int32_t)retried;
-                    j.result[4] = (int32_t)rt; j.result[5] = (int32_t)attempt; j.result[6] = (int32_t)ser; j.result[7] = (int32_t)dropped; j.result[20] = 3;   /* engine id: segment-parallel */
-                    if (j.done_counter) PLS_HOST_VISIBLE_ADD(j.done_counter, 1u);
-                }
+                nxt.ignore = redo ? 0u : D.ignore;           /* (the epilogue waits for the last row's validation: the attempt that finds finished == 1) */
             }
         }
         return;
@@ -2755,7 +2849,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) {
             if (tid == 0) {
-                const uint32_t *row = j.img + (size_t)y * W, *nab = y ? row - W : nullptr;
+                const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
                 uint32_t *cd = j.cand + (size_t)f * W * 4;
                 for (uint32_t x = (uint32_t)seg_max((int)(sgp * SEG_L), (int)sx); x < xp; x++) for (uint32_t c = 0; c < bpp; c++) basen[seg_cand_bin(cd[(size_t)x * 4 + c])]++;
                 const uint32_t xend = serial ? W : xp + 1;
@@ -2769,7 +2863,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
                 /* the reference's own order: channel after channel against the running histogram H0 + basen (optimize_state.c:212-254) */
                 for (uint32_t x = xp; x < xend; x++)
                     for (uint32_t c = 0; c < bpp; c++) {
-                        const SegPix p = seg_pix_load(row, nab, j.err0, bpp, x, (int)c);
+                        const SegPix p = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
                         const uint32_t w = seg_step_scan(f, p, st[c], Hn, basen, rank, G, P.lut_a, P.bleed);
                         cd[(size_t)x * 4 + c] = w;
                         basen[seg_cand_bin(w)]++;

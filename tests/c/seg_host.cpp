@@ -85,13 +85,12 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.row_ids = A.take<uint8_t>(H);
     j.orig_rank = rank.data();
     j.cand = A.take<uint32_t>((size_t)5 * W * 4);
-    j.err0 = A.take<uint32_t>((size_t)W * 2); j.err1 = A.take<uint32_t>((size_t)W * 2);
-    for (size_t i = 0; i < (size_t)W * 2; i++) j.err0[i] = j.err1[i] = 0;            /* pl_init zeroes these */
-    j.old_above = A.take<uint32_t>(W);
+    j.err0 = A.take<uint32_t>((size_t)W * 4); j.err1 = A.take<uint32_t>((size_t)W * 4);   /* (by row parity; the first control kernel zeroes what row 0 reads) */
+    j.rowcopy = A.take<uint32_t>((size_t)W * 3);
     j.final_hist = A.take<uint32_t>(256); j.result = A.take<int32_t>(64); j.progress = nullptr;
     j.nseg = (W + SEG_L - 1) / SEG_L; j.ngrp = (j.nseg + SEG_GRP - 1) / SEG_GRP;
     if (W > SEG_MAX_WIDTH) return 64;
-    j.ctl = A.take<SegCtl>(2); j.base = A.take<uint32_t>(2 * 5 * 256); j.H0 = A.take<uint32_t>(2 * 256); j.acc = A.take<SegAcc>(2);
+    j.ctl = A.take<SegCtl>(3); j.base = A.take<uint32_t>(3 * 5 * 256); j.H0 = A.take<uint32_t>(3 * 256); j.acc = A.take<SegAcc>(3);
     j.tables = A.take<uint32_t>(5 * SEG_TBL_WORDS);
     j.maps = A.take<uint16_t>((size_t)5 * j.nseg * 4 * P.nsp);
     j.ehash = A.take<uint32_t>(P.seeded ? (size_t)5 * j.nseg * 4 * SEG_EH_WORDS : 4);
@@ -105,17 +104,24 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);
     j.grpleft = A.take<uint32_t>((size_t)5 * j.ngrp);
     j.firstidx = A.take<uint32_t>(5 * 4 * 2);
-    j.rowmm = A.take<int32_t>(2 * ((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W));
+    j.rowmm = A.take<int32_t>(4 * ((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W));
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
     const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
-    j.ctl[1].magic = 0u;             /* (seg_k_resolve does this on the device) */
+    j.ctl[2].magic = 0u; j.acc[2].failmask = 0u;   /* (seg_k_resolve does this on the device: the first attempt finds no attempt behind it) */
     int attempt = 0;
     const long max_attempts = (long)H * 64 + 1024;
+    /* One attempt = four launches: [control of this attempt + validation of the attempt before], enumerate, chain, replay.  The two halves of
+     * the first launch run side by side on the device; here one after the other, in either order (SEG_HOST_VAL_FIRST): neither may depend on it. */
+    const bool val_first = getenv("SEG_HOST_VAL_FIRST") != nullptr;
     for (;; attempt++) {
         if (attempt > max_attempts) { fprintf(stderr, "seg_host: no progress\n"); return 65; }
-        for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, attempt & 1, bx, smem.data());
-        const int par = attempt & 1;
-        if (j.ctl[par].finished) break;
+        const int par = attempt % 3, kv = (par + 2) % 3;
+        std::vector<unsigned char> cvsm((size_t)SEG_SM_CTLVAL, 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
+        for (int half = 0; half < 2; half++) {
+            if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, par, bx, cvsm.data()); }
+            else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, kv, f, (int)vg, cvsm.data()); }
+        }
+        if (j.ctl[par].finished == 2u) break;
         /* the enumeration's workgroups come in two sizes; the product picks by row width, SEG_HOST_ENUM_NT pins one */
         int nt = j.nseg <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512 : 1024;
         if (getenv("SEG_HOST_ENUM_NT")) nt = atoi(getenv("SEG_HOST_ENUM_NT")) == 1024 ? 1024 : 512;
@@ -144,10 +150,9 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
             std::vector<unsigned char> csm((size_t)SEG_SM_CHAIN(j.nseg), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, csm.data());
         }
-        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, smem.data());
-        for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, par, f, (int)vg, smem.data());
+        { std::vector<unsigned char> rsm((size_t)SEG_SM_REPLAY, 0x5A); for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, rsm.data()); }
     }
-    const SegCtl &fc = j.ctl[attempt & 1];
+    const SegCtl &fc = j.ctl[attempt % 3];
     if (getenv("SEG_HOST_VERBOSE")) {
         fprintf(stderr, "seg_host: %llu rows; epochs per candidate (none sub up avg paeth): %llu %llu %llu %llu %llu; rows with an epoch of it: %llu %llu %llu %llu %llu, of which it won: %llu %llu %llu %llu %llu; extra starts of none %llu (won %llu)\n",
                 seg_rows, seg_epochs[0], seg_epochs[1], seg_epochs[2], seg_epochs[3], seg_epochs[4], seg_epoch_rows[0], seg_epoch_rows[1], seg_epoch_rows[2], seg_epoch_rows[3], seg_epoch_rows[4],

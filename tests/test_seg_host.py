@@ -35,13 +35,14 @@ def test_seg_engine_bodies_match_oracle(w, h, mode, s, b):
 def test_seg_engine_speculation_is_right_almost_always():
     """The validation pass makes every result exact whatever the speculation did -- a bug in the tables, the maps or the chain shows
     only as extra attempts.  So the attempt count is pinned: a 1024-wide frame needs one attempt per row plus a handful of epochs
-    (measured: 133 attempts for 128 rows; candidate none is ruled out by its cost bound in most rows)."""
+    (measured: 138 attempts for 128 rows, 5 epochs -- an epoch costs two attempts since the validation runs one launch behind: the attempt
+    under way when it fails is void; candidate none is ruled out by its cost bound in most rows)."""
     img = P.synth_rgba(1024, 128, 0, 0)
     rc, out, f, st = U.run_seg_host(img, 19, 2)
     want, wf = U.run_port(img, 19, 2)
     assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
     attempts, restarts, serial = int(st[0]), int(st[1]), int(st[3])
-    assert attempts <= 128 + 16 and restarts <= 12 and serial == 0, (attempts, restarts, serial)
+    assert attempts <= 128 + 24 and restarts <= 12 and serial == 0, (attempts, restarts, serial)
 
 
 @pytest.mark.parametrize("nt", [512, 1024])
@@ -56,9 +57,9 @@ def test_seg_engine_both_sizes_of_the_enumeration_workgroups(monkeypatch, nt, w,
     assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
 
 
-@pytest.mark.parametrize("s,b,most", [(40, 2, 112), (85, 8, 110), (20, 1, 115)])
+@pytest.mark.parametrize("s,b,most", [(40, 2, 124), (85, 8, 118), (20, 1, 130)])
 def test_seg_engine_speculation_with_state_sets_enumerated_in_chunks(s, b, most):
-    """the same pin for state sets of 650 .. 955 chain states (measured: 104 / 103 / 107 attempts for 96 rows): the chunked
+    """the same pin for state sets of 650 .. 955 chain states (measured: 112 / 106 / 118 attempts for 96 rows, 10 / 3 / 11 epochs of two attempts each): the chunked
     enumeration, the dense transition tables and the wide table stride are right when the attempts stay near one per row"""
     img = P.synth_rgba(1024, 96, 0, 0)
     rc, out, f, st = U.run_seg_host(img, s, b)
@@ -95,9 +96,9 @@ def test_seg_engine_takes_every_strength_and_bleed():
         assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf), (s, b)
 
 
-@pytest.mark.parametrize("s,b,most", [(85, 1, 62), (85, 2, 56), (40, 1, 80)])
+@pytest.mark.parametrize("s,b,most", [(85, 1, 74), (85, 2, 64), (40, 1, 108)])
 def test_seg_engine_seeded_speculation_is_right_almost_always(s, b, most):
-    """the seeded enumeration's entry sets hold the reference's own state nearly always (measured: 56 / 52 / 72 attempts for 48 rows,
+    """the seeded enumeration's entry sets hold the reference's own state nearly always (measured: 66 / 58 / 98 attempts for 48 rows with 9 / 3 / 30 epochs of two attempts each,
     at most a handful of segments walked step by step by the chain kernel): wrong seeds, a wrong hash or a wrong lookup would show
     as attempts or repairs, never as wrong bytes"""
     img = P.synth_rgba(1024, 48, 0, 0)
@@ -160,3 +161,18 @@ def test_seg_engine_bodies_clean_under_asan_and_ubsan(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "sanitized ok" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
 
+
+
+@pytest.mark.parametrize("w,h,mode,s,b", [(333, 37, 1, 19, 2), (600, 12, 5, 19, 2), (520, 16, 3, 19, 2), (200, 20, 0, 85, 1), (97, 33, 2, 7, 3), (1, 7, 1, 19, 2), (150, 12, 3, 255, 1)])
+def test_seg_engine_validation_and_control_in_either_order(monkeypatch, w, h, mode, s, b):
+    """the validation of an attempt runs in the SAME launch as the control workgroups that decide on it (optimistically), so neither may read
+    what the other writes: the harness runs the two halves of that launch one after the other -- here validation first, everywhere else
+    control first; a hazard (the committed row, the shifted error rows, the next control block seen by the validation, or its verdict seen
+    by the decision) would change bytes or attempts in one of the orders"""
+    img = P.synth_rgba(w, h, mode, 0)
+    rc0, out0, f0, st0 = U.run_seg_host(img, s, b)
+    monkeypatch.setenv("SEG_HOST_VAL_FIRST", "1")
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and rc0 == 0 and np.array_equal(out, want) and np.array_equal(f, wf) and np.array_equal(out0, want)
+    assert list(st) == list(st0)
