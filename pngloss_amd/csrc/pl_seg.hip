@@ -96,6 +96,7 @@ __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *_
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
+    if (blockIdx.x == SEG_NFILT * 4) { seg_extremes_body(j, *P, par, seg_smem); return; }      /* (the spare workgroup: the row's extremes for none's bound) */
     seg_chain_body(j, *P, par, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), seg_smem);
 }
 
@@ -149,7 +150,7 @@ PlSegLayout pl_seg_layout(uint32_t width, uint32_t nsp, bool seeded)
     l.grpcnt = take((size_t)SEG_NFILT * l.ngrp * 256 * 4);
     l.grpleft = take((size_t)SEG_NFILT * l.ngrp * 4);
     l.firstidx = take(SEG_NFILT * 4 * 2 * 4);
-    l.rowmm = take(((size_t)(width + SEG_COMMIT_W - 1) / SEG_COMMIT_W) * 16);
+    l.rowmm = take(16);
     l.total = o;
     return l;
 }
@@ -177,7 +178,8 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     const int par = attempt % 3;                               /* which copy of the control block / sums / histogram / prefix bumps the attempt writes */
     const unsigned n = (unsigned)b.n;
     {
-        const unsigned nctl = SEG_CTL_IMG + 1 + b.max_ncommit, nval = SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
+        static const bool no_val = getenv("PNGLOSS_HIP_EXPERIMENT_NO_VALIDATION") != nullptr;   /* TIMING EXPERIMENT ONLY (results are not validated: wrong where a row would have failed): what the control workgroups take alone */
+        const unsigned nctl = SEG_CTL_IMG + 1 + b.max_ncommit, nval = no_val ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
         hipLaunchKernelGGL(seg_k_ctl, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
     }
     {
@@ -194,7 +196,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
         else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
     }
-    hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();
 }

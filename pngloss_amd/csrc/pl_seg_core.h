@@ -120,6 +120,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define PLS_UNROLL
 #endif
 #define SEG_NFILT 5
+#ifndef SEG_EXPERIMENT_REPLAY_CLOCKS
+#define SEG_EXPERIMENT_REPLAY_CLOCKS 0   /* (1: an experiment build in which the REPLAY's phase clocks take the enumeration's slots of the result record; tools/replay_clocks.sh) */
+#endif
 #ifndef SEG_DEBUG_ROW
 #define SEG_DEBUG_ROW(kind, failed, winner, start_none)
 #endif
@@ -270,7 +273,7 @@ struct SegJob {
     SEG_AS_GLB uint32_t *grpcnt;         /* [5][ngrp][256] */
     SEG_AS_GLB uint32_t *grpleft;        /* [5][ngrp]: the new bytes (one per channel) the row sums of a group took for the pixel in front of it, when that pixel was another workgroup's (seg_row_sums; checked by the validation) */
     SEG_AS_GLB uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
-    SEG_AS_GLB int32_t *rowmm;           /* [2][ceil(W / SEG_COMMIT_W)][2]: max and min of orig + incoming error over the pixels of a commit workgroup; by row parity (seg_rowmm) */
+    SEG_AS_GLB int32_t *rowmm;           /* [2][2]: max and min of orig + incoming error over the row (seg_extremes_body, the chain launch's spare workgroup; by row parity: seg_rowmm) */
     uint32_t nseg, ngrp;
 };
 
@@ -278,7 +281,7 @@ struct SegJob {
 PLS_HD SEG_AS_GLB uint32_t *seg_row_orig(const SegJob &j, uint32_t y) { return j.rowcopy + (size_t)(y % 3u) * j.W; }
 PLS_HD SEG_AS_GLB uint32_t *seg_e0(const SegJob &j, uint32_t y) { return j.err0 + (size_t)(y & 1u) * 2u * j.W; }
 PLS_HD SEG_AS_GLB uint32_t *seg_e1(const SegJob &j, uint32_t y) { return j.err1 + (size_t)(y & 1u) * 2u * j.W; }
-PLS_HD SEG_AS_GLB int32_t *seg_rowmm(const SegJob &j, uint32_t y) { return j.rowmm + (size_t)(y & 1u) * 2u * ((j.W + SEG_COMMIT_W - 1) / SEG_COMMIT_W); }
+PLS_HD SEG_AS_GLB int32_t *seg_rowmm(const SegJob &j, uint32_t y) { return j.rowmm + (size_t)(y & 1u) * 2u; }
 /* attempt a keeps its control block, sums, histogram and prefix bumps in copy a % 3: the one before, the one two before */
 PLS_HD int seg_k_prev(int k) { return k == 0 ? 2 : k - 1; }
 PLS_HD int seg_k_prev2(int k) { return k == 2 ? 0 : k + 1; }
@@ -781,7 +784,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
 /* what the enumeration kernel's bodies really carve out for NT threads (seg_enum_body is the largest: tables, pixels, split table, hash table,
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
-#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + 64)
+#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + SEG_GRP * SEG_L * 16 + (SEG_GRP * SEG_L + 3) * 4 + 64)
 #define SEG_SM_POST ((768 + (2 * SEG_VGRP + 1) * 256 + (SEG_VGRP * SEG_L + 2) * 4 + 64 + 512 + 3 * (SEG_VGRP * SEG_L + 2) + 2 * SEG_VGRP * SEG_L + 768 + 32 + 64 + SEG_VGRP * SEG_L + SEG_VGRP * (SEG_L + 1) + 8 * (SEG_VGRP * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands) */
 #define SEG_SM_CTLVAL (SEG_SM_CTL > SEG_SM_POST ? SEG_SM_CTL : SEG_SM_POST)   /* the first launch of an attempt carries control and validation workgroups */
 #define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 4 + (SEG_NFILT + 1) * 256 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
@@ -957,7 +960,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
             j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
         }
         if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
-        if (prof && tid == 0) {
+        if (prof && tid == 0 && !SEG_EXPERIMENT_REPLAY_CLOCKS) {
             te[3] = PLS_CLOCK(); te[4] = te[3];
             for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
             PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
@@ -1105,7 +1108,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, i
             j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
         }
         if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
-        if (prof && tid == 0) {
+        if (prof && tid == 0 && !SEG_EXPERIMENT_REPLAY_CLOCKS) {
             te[3] = PLS_CLOCK(); te[4] = te[3];
             for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
             PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
@@ -1600,154 +1603,49 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     }
 }
 
-/* ---- the row's SUMS of one candidate, group by group: the replay's workgroups, behind their walk ---------------------------------
- * What the row decision (seg_decide_cand) wants from the pixels of a candidate row besides its bump counts: the derivative error
- * (optimize_state.c:265-287) and the sums of libpng's heuristic (:492-562) -- neither depends on a histogram, so they are taken here, from
- * the candidate words this workgroup has just written (and, in a later epoch of the row, from the validated words in front of it).  The
- * entropy cost (:326-342) needs no pixel at all: the symbol a pixel is charged for is the bin it bumped, so the row's cost is
- * sum over bins of n * (33 + clz(H0 + n)) with n the row's bumps of the bin (seg_entropy_costs, control kernel).
- * The new left neighbour of the group's FIRST pixel belongs to the workgroup in front; it is taken from the entry state of the group's
- * first segment (the chain kernel's), recorded in grpleft, and the validation kernel checks the record against the byte that was written.
- * Candidate none (f = 0) also gets the LOWER BOUND of its row cost here (see seg_none_reach), run or not. */
-PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int m);
-PLS_HD void seg_row_sums(const SegJob &j, const SegParams &P, int par, int f, int grp, const SegCtlView &cv, bool lazy, bool walked,
-                         const uint32_t *lane, uint32_t *scr, uint32_t *scr2)
-{
-    const uint32_t W = j.W, bpp = j.bpp, sx = cv.start_x, y = cv.y;
-    const uint32_t x0g = (uint32_t)grp * SEG_GRP * SEG_L;
-    const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
-    uint32_t *nbw = scr;                                       /* [SEG_REPLAY_THREADS] the new bytes of every pixel of the group, one word each */
-    uint32_t *rm = scr + SEG_REPLAY_THREADS;                   /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
-    uint32_t *red = rm + 768;                                  /* [16] reductions: derr lo/hi, hs[5], left bytes of the first pixel, -, -, lb lo/hi, reach, -, max, min */
-    uint32_t *h0s = red + 16;                                  /* [256] the committed histogram */
-    uint32_t *cwl = scr2;                                      /* [SEG_REPLAY_THREADS][4] candidate words of the group */
-    const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
-    const uint32_t *oab = y ? seg_row_orig(j, y - 1u) : nullptr; /* the ORIGINAL row above */
-    const int32_t *rmm = seg_rowmm(j, y);
-    SegAcc &A = j.acc[par];
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
-    PLS_SYNC();
-    if (!lazy) {
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-            const uint32_t x = x0g + (uint32_t)tid;
-            SegVec16 w; w.a = w.b = w.c = w.d = 0u;
-            if (x < W) w = *(const SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x) * 4);
-            cwl[tid * 4 + 0] = w.a; cwl[tid * 4 + 1] = w.b; cwl[tid * 4 + 2] = w.c; cwl[tid * 4 + 3] = w.d;
-            nbw[tid] = (w.a & 255u) | ((w.b & 255u) << 8) | ((w.c & 255u) << 16) | ((w.d & 255u) << 24);
-            if (tid == 0 && x0g) {
-                uint32_t lw = 0;
-                if (x0g <= sx) {                               /* the pixel in front is validated: its word is final */
-                    const SegVec16 v = *(const SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x0g - 1) * 4);
-                    lw = (v.a & 255u) | ((v.b & 255u) << 8) | ((v.c & 255u) << 16) | ((v.d & 255u) << 24);
-                } else {                                       /* the left byte of the entry states this group's walkers started from (walked: always, here) */
-                    for (uint32_t c = 0; c < bpp; c++) lw |= (walked ? (lane[2 * c] & 255u) : 0u) << (8 * c);
-                    j.grpleft[(size_t)f * j.ngrp + grp] = lw;
-                }
-                red[7] = lw;
-            }
-        }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-            const uint32_t x = x0g + (uint32_t)tid;
-            uint64_t derr = 0; uint32_t hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
-            if (x < W) {
-                const uint32_t o = row[x], ol = x ? row[x - 1] : 0u;
-                const uint32_t nav4 = nab ? nab[x] : 0u, ndv4 = (nab && x) ? nab[x - 1] : 0u;
-                const uint32_t oav4 = y ? oab[x] : 0u, odv4 = (y && x) ? oab[x - 1] : 0u;
-                const uint32_t nb = nbw[tid], nlw = tid ? nbw[tid - 1] : red[7];
-                for (uint32_t c = 0; c < bpp; c++) {
-                    const int sh = 8 * (int)c;
-                    const int back = (int)((nb >> sh) & 255u), nl = x ? (int)((nlw >> sh) & 255u) : 0;
-                    const int ov = (int)((o >> sh) & 255u), olv = (int)((ol >> sh) & 255u);
-                    const int nav = (int)((nav4 >> sh) & 255u), ndv = (int)((ndv4 >> sh) & 255u), oav = (int)((oav4 >> sh) & 255u), odv = (int)((odv4 >> sh) & 255u);
-                    const int da = (oav - ov) - (nav - back), dd = (odv - ov) - (ndv - back), dl = (olv - ov) - (nl - back);
-                    const uint32_t wgt = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
-                    derr += (uint64_t)(wgt * (uint32_t)(da * da + dd * dd + dl * dl));
-                    if (adaptive) {
-                        const int preds[SEG_NFILT] = { 0, nl, nav, (nav + nl) >> 1, seg_paeth(nav, ndv, nl) };
-                        for (int g = 0; g < SEG_NFILT; g++) { const int bb = (back - preds[g]) & 255; hs[g] += (uint32_t)(bb < 128 ? bb : 256 - bb); }
-                    }
-                }
-            }
-            derr = pls_wave_sum_u64(derr);
-            if (adaptive) for (int g = 0; g < SEG_NFILT; g++) hs[g] = pls_wave_sum_u32(hs[g]);
-            if (PLS_WAVE_LEADER(tid)) {
-                PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
-                if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&red[2 + g], hs[g]);
-            }
-        }
-        PLS_SYNC();
-    }
-    /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
-     *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
-     *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
-    int R = -1;
-    if (f == 0 && j.rowmm) {
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-            /* the row's extremes of orig + incoming error: one pair per commit workgroup, read side by side */
-            const int nc = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
-            if (tid < 64) {
-                int M = -(1 << 30), m = 1 << 30;
-                for (int i = tid; i < nc; i += 64) { M = seg_max(M, rmm[2 * i]); m = seg_min(m, rmm[2 * i + 1]); }
-                M = pls_wave_max_i(M); m = pls_wave_min_i(m);
-                PLS_ATOMIC_MAX_U(&red[14], 0x80000000u ^ (uint32_t)M); PLS_ATOMIC_MIN(&red[15], 0x80000000u ^ (uint32_t)m);
-            }
-            if (tid >= 64 && tid < 64 + 256) h0s[tid - 64] = j.H0[par * 256 + (tid - 64)];
-        }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid == 0) red[12] = (uint32_t)seg_none_reach(j, P, (int)cv.s, (int)(red[14] ^ 0x80000000u), (int)(red[15] ^ 0x80000000u)); }
-        PLS_SYNC();
-        R = (int)red[12];
-        if (R >= 0) {
-            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-                for (int i = tid; i < 768; i += SEG_REPLAY_THREADS) {
-                    const int centre = i - 256;
-                    const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
-                    uint32_t m = 0;
-                    for (int b = lo; b <= hi; b++) m = h0s[b] > m ? h0s[b] : m;
-                    rm[i] = m;
-                }
-            }
-            PLS_SYNC();
-            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-                uint64_t lb = 0;
-                const uint32_t rowbumps = W * bpp;
-                const uint32_t x = x0g + (uint32_t)tid;
-                if (x < W) {
-                    const uint32_t o = row[x];
-                    const uint32_t e[2] = { e0g[2 * (size_t)x], e0g[2 * (size_t)x + 1] };
-                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                    for (uint32_t c = 0; c < bpp; c++) {
-                        uint32_t hmax;
-                        if (alpha0 && c == bpp - 1u) hmax = h0s[0];                        /* forced symbol 0 */
-                        else {
-                            const int centre = (int)((o >> (8 * c)) & 255u) + seg_err_plane(e, seg_plane_of_channel(bpp, (int)c));
-                            hmax = rm[seg_min(seg_max(centre, -256), 511) + 256];
-                        }
-                        const uint32_t fr = hmax + rowbumps;
-                        lb += 33u + (uint32_t)__builtin_clz(fr ? fr : 1u);
-                    }
-                }
-                lb = pls_wave_sum_u64(lb);
-                if (PLS_WAVE_LEADER(tid) && lb) PLS_ATOMIC_ADD64((uint64_t *)&red[10], lb);
-            }
-            PLS_SYNC();
-        }
-    }
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-        if (tid == 0) {
-            if (!lazy) {
-                PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
-                if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[2 + g]);
-            }
-            if (f == 0 && R >= 0) { PLS_ATOMIC_ADD64(&A.none_lb, *(uint64_t *)&red[10]); PLS_ATOMIC_ADD(&A.lb_valid, 1u); }
-        }
-    }
-}
-
 /* ---- REPLAY: task (f, grp): lane = (segment of the group, part of the segment, channel) -----------------------------------
  * A lane starts from a state it knows: part 0 from the segment's entry state, part p from the checkpoint the enumeration left for
- * the segment's dense id.  A part without a checkpoint is walked by the lane in front of it. */
+ * the segment's dense id.  A part without a checkpoint is walked by the lane in front of it.  The walkers write into shared memory;
+ * behind them every thread takes ONE pixel of the group: it stores the pixel's four candidate words (one 16-byte store) and adds the pixel
+ * to the row's SUMS -- what the row decision (seg_decide_cand) wants from the pixels of a candidate row besides its bump counts: the
+ * derivative error (optimize_state.c:265-287) and the sums of libpng's heuristic (:492-562).  Neither depends on a histogram.  (The
+ * entropy cost, :326-342, needs no pixel at all: seg_entropy_costs.)  In a later epoch of the row the validated words in front of the epoch
+ * are read back for the sums.  The new left neighbour of the group's FIRST pixel belongs to the workgroup in front: it is taken from the
+ * entry state of the group's first segment (the chain kernel's), recorded in grpleft, and the validation checks the record against the
+ * byte that was written.  Candidate none (f = 0) also gets the LOWER BOUND of its row cost here (see seg_none_reach), run or not. */
+PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int m);
+
+/* ---- EXTREMES: one workgroup per image, next to the chain's (it has nothing to do with them: the launch has room): the largest and the
+ * smallest orig + incoming error over the row's channels (a forced transparent alpha aside), which bound how far candidate none's bytes
+ * can overshoot 0..255 (seg_none_reach); read by the replay's workgroups of candidate none in the next launch. */
+PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, int par, unsigned char *smem)
+{
+    const SegCtlView cv = seg_ctl_view(j, par, 0);
+    if (cv.finished || !j.rowmm) return;
+    const uint32_t W = j.W, bpp = j.bpp, y = cv.y;
+    const uint32_t *row = seg_row_orig(j, y), *e0g = seg_e0(j, y);
+    uint32_t *mm = (uint32_t *)smem;                            /* [0] max, [1] min, biased (unsigned compare) */
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { mm[0] = 0x80000000u ^ (uint32_t)(-(1 << 30)); mm[1] = 0x80000000u ^ (uint32_t)(1 << 30); } }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        int vmax = -(1 << 30), vmin = 1 << 30;
+        for (uint32_t x = (uint32_t)tid; x < W; x += SEG_CHAIN_THREADS) {
+            const uint32_t o = row[x];
+            const uint32_t e[2] = { e0g[2 * (size_t)x], e0g[2 * (size_t)x + 1] };
+            const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
+            for (uint32_t c = 0; c < bpp; c++) {
+                if (alpha0 && c == bpp - 1u) continue;
+                const int v = (int)((o >> (8 * c)) & 255u) + seg_err_plane(e, seg_plane_of_channel(bpp, (int)c));
+                vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+            }
+        }
+        vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
+        if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_U(&mm[0], 0x80000000u ^ (uint32_t)vmax); PLS_ATOMIC_MIN(&mm[1], 0x80000000u ^ (uint32_t)vmin); }
+    }
+    PLS_SYNC();
+    PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { SEG_AS_GLB int32_t *rmm = seg_rowmm(j, y); rmm[0] = (int)(mm[0] ^ 0x80000000u); rmm[1] = (int)(mm[1] ^ 0x80000000u); } }
+}
+
 PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -1758,20 +1656,30 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = cv.start_x;
     const uint32_t first = sx / SEG_L;
-    const uint32_t seg0 = (uint32_t)grp * SEG_GRP;
+    const uint32_t seg0 = (uint32_t)grp * SEG_GRP, x0g = seg0 * SEG_L;
     const bool walk = !lazy && sx < W && seg0 + SEG_GRP > first;   /* (else: the whole group is validated already -- its share of the row's sums is still wanted) */
     uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
     SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_GRP][SEG_L][4] */
     uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
     uint32_t *lane = cnt + SEG_GRP * 256;                     /* [SEG_GRP * SEG_PARTS * 4][2]: start state, first | end pixel << 16 (or ~0: idle) */
+    uint32_t *cwl = lane + SEG_GRP * SEG_PARTS * 4 * 2;       /* [SEG_REPLAY_THREADS][4] the group's candidate words */
+    uint32_t *oaL = cwl + SEG_REPLAY_THREADS * 4;             /* [SEG_REPLAY_THREADS + 1] the ORIGINAL row above, from the pixel in front of the group; [+1] the original pixel in front of the group, [+2] its new bytes */
+    /* (behind the walk, in the tables' place) */
+    uint32_t *rm = tw;                                         /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
+    uint32_t *red = rm + 768;                                  /* [16] reductions: derr lo/hi, hs[5], -, -, -, lb lo/hi, reach, -, max, min */
+    uint32_t *h0s = red + 16;                                  /* [256] the committed histogram */
     const uint32_t y = cv.y;
     const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
+    const uint32_t *oab = y ? seg_row_orig(j, y - 1u) : nullptr; /* the ORIGINAL row above */
     const SegGeo G = seg_geo((int)cv.s);
-    if (walk) {
+    const bool adaptive = !j.row_filters || y == 0;           /* pngloss_image.c:210 */
+    const bool rprof = SEG_EXPERIMENT_REPLAY_CLOCKS && (P.engine_flags & 1) != 0 && walk && grp == 3;
+    unsigned long long tr_[6] = { 0, 0, 0, 0, 0, 0 };
+    if (rprof) tr_[0] = PLS_CLOCK();
     PLS_THREADS(tid, SEG_REPLAY_THREADS) {
         /* Order of the requests: the walkers' dense ids, then everything the block stages (tables, frozen histogram, pixels), then the
          * checkpoints and entry states (which wait for the dense ids only); the stores to shared memory behind all of them. */
-        const bool walker = tid < SEG_GRP * SEG_PARTS * 4;
+        const bool walker = walk && tid < SEG_GRP * SEG_PARTS * 4;
         const int sl = tid / (SEG_PARTS * 4), part = (tid >> 2) % SEG_PARTS, c = tid & 3;
         const uint32_t sg = seg0 + (uint32_t)sl;
         const bool live = walker && sg < nseg && sg >= first && (uint32_t)c < bpp;
@@ -1780,10 +1688,17 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
         constexpr int NTW = (SEG_TBL_WORDS + SEG_REPLAY_THREADS - 1) / SEG_REPLAY_THREADS;
         uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
-        if (tid < 512) vl = P.lut_a[tid];
-        if (tid < 256) { vh = j.H0[par * 256 + tid]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + tid]; vr = j.orig_rank[f * 256 + tid]; }
-        const SegPixRaw vp = seg_pix_fetch(row, nab, e0g, seg0 * SEG_L + (uint32_t)tid, W);
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; vt[q] = (walk && i < SEG_TBL_WORDS) ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (walk && tid < 512) vl = P.lut_a[tid];
+        if (walk && tid < 256) { vh = j.H0[par * 256 + tid]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + tid]; vr = j.orig_rank[f * 256 + tid]; }
+        const uint32_t x = x0g + (uint32_t)tid;
+        const SegPixRaw vp = seg_pix_fetch(row, nab, e0g, x, W);
+        /* for the sums: the original row above; what lies in front of the group (lane 0); the validated words of an epoch that starts further right */
+        const uint32_t voa = (!lazy && oab && x < W) ? oab[x] : 0u;
+        uint32_t voa0 = 0, vol0 = 0;
+        SegVec16 vw, vw0; vw.a = vw.b = vw.c = vw.d = 0u; vw0 = vw;
+        if (!lazy && tid == 0 && x0g) { voa0 = oab ? oab[x0g - 1] : 0u; vol0 = row[x0g - 1]; if (x0g <= sx) vw0 = *(const SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x0g - 1) * 4); }
+        if (!lazy && x < W && (x < sx || !walk)) vw = *(const SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x) * 4);
         uint32_t ck[SEG_PARTS - 1], ent = 0;
         PLS_UNROLL
         for (int q = 0; q < SEG_PARTS - 1; q++) ck[q] = 0xFFFFFFFFu;
@@ -1812,46 +1727,162 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
                 PLS_UNROLL
                 for (int q = SEG_PARTS - 1; q >= 1; q--)
                     if (q > part && ck[q - 1] != 0xFFFFFFFFu && x0 + (uint32_t)q * SEG_PL < xend && x0 + (uint32_t)q * SEG_PL > xa) xe = x0 + (uint32_t)q * SEG_PL;
-                range = (xa - seg0 * SEG_L) | ((xe - seg0 * SEG_L) << 16);
+                range = (xa - x0g) | ((xe - x0g) << 16);
                 SEG_DEBUG_COUNT(part ? 1 : 0, xe - xa);
             }
         }
-        if (walker) { lane[2 * tid] = st0; lane[2 * tid + 1] = range; }
-        PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
-        if (tid < 512) lut[tid] = vl;
-        if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
-        for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_THREADS) cnt[i] = 0u;
-        seg_pix_split4(px + tid * 4, vp, bpp, seg0 * SEG_L + (uint32_t)tid, W);
-    }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-        if (tid < SEG_GRP * SEG_PARTS * 4 && lane[2 * tid + 1] != 0xFFFFFFFFu) {
-            const int sl = tid / (SEG_PARTS * 4), c = tid & 3;
-            SegState st = seg_state_unpack(lane[2 * tid]);
-            const uint32_t ra = lane[2 * tid + 1] & 0xffffu, re = lane[2 * tid + 1] >> 16;       /* pixels of the group */
-            const uint32_t xa = seg0 * SEG_L + ra, xe = seg0 * SEG_L + re;
-            seg_walk(f, px + ra * 4 + c, 4, xa, xe, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed,
-                     j.cand + ((size_t)f * W + xa) * 4 + c, cnt + sl * 256);
+        if (tid < SEG_GRP * SEG_PARTS * 4) { lane[2 * tid] = st0; lane[2 * tid + 1] = range; }
+        if (walk) {
+            PLS_UNROLL
+            for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+            if (tid < 512) lut[tid] = vl;
+            if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
+            for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_THREADS) cnt[i] = 0u;
+        }
+        seg_pix_split4(px + tid * 4, vp, bpp, x, W);
+        oaL[tid + 1] = voa;
+        cwl[tid * 4 + 0] = vw.a; cwl[tid * 4 + 1] = vw.b; cwl[tid * 4 + 2] = vw.c; cwl[tid * 4 + 3] = vw.d;
+        if (tid == 0) {
+            oaL[0] = voa0; oaL[SEG_REPLAY_THREADS + 1] = vol0;
+            oaL[SEG_REPLAY_THREADS + 2] = (vw0.a & 255u) | ((vw0.b & 255u) << 8) | ((vw0.c & 255u) << 16) | ((vw0.d & 255u) << 24);
         }
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-        for (int b = tid; b < 256; b += SEG_REPLAY_THREADS) {
-            uint32_t tot = 0, cv[SEG_GRP];
-            PLS_UNROLL
-            for (int sl = 0; sl < SEG_GRP; sl++) cv[sl] = cnt[sl * 256 + b];          /* (all reads, then the stores: one wait) */
-            PLS_UNROLL
-            for (int sl = 0; sl < SEG_GRP; sl++) {
-                const uint32_t sg = seg0 + (uint32_t)sl;
-                if (sg < nseg && sg >= first) { j.segcnt[((size_t)f * nseg + sg) * 256 + b] = (uint16_t)cv[sl]; tot += cv[sl]; }
+    if (rprof) tr_[1] = PLS_CLOCK();
+    if (walk) {
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            if (tid < SEG_GRP * SEG_PARTS * 4 && lane[2 * tid + 1] != 0xFFFFFFFFu) {
+                const int sl = tid / (SEG_PARTS * 4), c = tid & 3;
+                SegState st = seg_state_unpack(lane[2 * tid]);
+                const uint32_t ra = lane[2 * tid + 1] & 0xffffu, re = lane[2 * tid + 1] >> 16;       /* pixels of the group */
+                seg_walk(f, px + ra * 4 + c, 4, x0g + ra, x0g + re, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed, cwl + ra * 4 + c, cnt + sl * 256);
             }
-            j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
+        }
+        PLS_SYNC();
+        if (rprof) tr_[2] = PLS_CLOCK();
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            for (int b = tid; b < 256; b += SEG_REPLAY_THREADS) {
+                uint32_t tot = 0, cvs[SEG_GRP];
+                PLS_UNROLL
+                for (int sl = 0; sl < SEG_GRP; sl++) cvs[sl] = cnt[sl * 256 + b];          /* (all reads, then the stores: one wait) */
+                PLS_UNROLL
+                for (int sl = 0; sl < SEG_GRP; sl++) {
+                    const uint32_t sg = seg0 + (uint32_t)sl;
+                    if (sg < nseg && sg >= first) { j.segcnt[((size_t)f * nseg + sg) * 256 + b] = (uint16_t)cvs[sl]; tot += cvs[sl]; }
+                }
+                j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
+            }
+        }
+    }
+    SegAcc &A = j.acc[par];
+    if (rprof) tr_[3] = PLS_CLOCK();
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
+    PLS_SYNC();
+    if (!lazy) {
+        /* -- every thread its pixel: the words out (what the walkers have just written), the pixel's share of the sums -- */
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            const uint32_t x = x0g + (uint32_t)tid;
+            uint64_t derr = 0; uint32_t hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
+            if (x < W) {
+                SegVec16 w; w.a = cwl[tid * 4 + 0]; w.b = cwl[tid * 4 + 1]; w.c = cwl[tid * 4 + 2]; w.d = cwl[tid * 4 + 3];
+                if (walk && x >= sx) *(SEG_AS_GLB SegVec16 *)(j.cand + ((size_t)f * W + x) * 4) = w;
+                /* the new bytes of the pixel in front: the thread's neighbour's; for the group's first pixel the validated word in front of it, or
+                 * (another workgroup is writing it now) the left bytes of the entry states this group's walkers started from */
+                uint32_t lw[4];
+                if (tid) { PLS_UNROLL for (int c = 0; c < 4; c++) lw[c] = cwl[(tid - 1) * 4 + c] & 255u; }
+                else {
+                    uint32_t l0 = 0;
+                    if (x0g && x0g <= sx) l0 = oaL[SEG_REPLAY_THREADS + 2];
+                    else if (x0g) {
+                        for (uint32_t c = 0; c < bpp; c++) l0 |= (walk ? (lane[2 * c] & 255u) : 0u) << (8 * c);
+                        j.grpleft[(size_t)f * j.ngrp + grp] = l0;
+                    }
+                    PLS_UNROLL for (int c = 0; c < 4; c++) lw[c] = (l0 >> (8 * c)) & 255u;
+                }
+                const uint32_t wv[4] = { w.a, w.b, w.c, w.d };
+                const uint32_t oav4 = oaL[tid + 1], odv4 = oaL[tid];                       /* (zero on the first row; the slot in front of pixel 0 holds zero) */
+                for (uint32_t c = 0; c < bpp; c++) {
+                    const int sh = 8 * (int)c;
+                    const SegPix pc = px[tid * 4 + c];
+                    const int back = (int)(wv[c] & 255u), nl = x ? (int)lw[c] : 0;
+                    const int ov = (int)(pc.w & 255u), nav = (int)((pc.w >> 8) & 255u), ndv = (int)((pc.w >> 16) & 255u);
+                    const int olv = tid ? (int)(px[(tid - 1) * 4 + c].w & 255u) : (int)((oaL[SEG_REPLAY_THREADS + 1] >> sh) & 255u);
+                    const int oav = (int)((oav4 >> sh) & 255u), odv = (int)((odv4 >> sh) & 255u);
+                    const int da = (oav - ov) - (nav - back), dd = (odv - ov) - (ndv - back), dl = (olv - ov) - (nl - back);
+                    const uint32_t wgt = (bpp <= 2 && c == 0) ? 3u : 1u;      /* gray is replicated into r,g,b (color_delta.c:11-26) */
+                    derr += (uint64_t)(wgt * (uint32_t)(da * da + dd * dd + dl * dl));
+                    if (adaptive) {
+                        const int preds[SEG_NFILT] = { 0, nl, nav, (nav + nl) >> 1, seg_paeth(nav, ndv, nl) };
+                        for (int g = 0; g < SEG_NFILT; g++) { const int bb = (back - preds[g]) & 255; hs[g] += (uint32_t)(bb < 128 ? bb : 256 - bb); }
+                    }
+                }
+            }
+            derr = pls_wave_sum_u64(derr);
+            if (adaptive) for (int g = 0; g < SEG_NFILT; g++) hs[g] = pls_wave_sum_u32(hs[g]);
+            if (PLS_WAVE_LEADER(tid)) {
+                PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
+                if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&red[2 + g], hs[g]);
+            }
+        }
+    }
+    /* -- candidate none only: a LOWER BOUND of its row cost that needs no chain (see seg_none_reach).  Every symbol of none is the
+     *    reconstructed byte itself, which lies within R of orig + incoming error (clamped to 0..255); its cost is at least the cost
+     *    of the most frequent bin within that reach after the row: 33 + clz(max H0 + all bumps of the row). -- */
+    int R = -1;
+    if (f == 0 && j.rowmm) {
+        const int32_t *rmm = seg_rowmm(j, y);
+        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            /* the row's extremes of orig + incoming error (seg_extremes_body, the launch before) */
+            if (tid == 0) red[12] = (uint32_t)seg_none_reach(j, P, (int)cv.s, rmm[0], rmm[1]);
+            if (tid >= 64 && tid < 64 + 256) h0s[tid - 64] = j.H0[par * 256 + (tid - 64)];
+        }
+        PLS_SYNC();
+        R = (int)red[12];
+        if (R >= 0) {
+            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+                for (int i = tid; i < 768; i += SEG_REPLAY_THREADS) {
+                    const int centre = i - 256;
+                    const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
+                    uint32_t m = 0;
+                    for (int b = lo; b <= hi; b++) m = h0s[b] > m ? h0s[b] : m;
+                    rm[i] = m;
+                }
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+                uint64_t lb = 0;
+                const uint32_t rowbumps = W * bpp;
+                const uint32_t x = x0g + (uint32_t)tid;
+                if (x < W) {
+                    for (uint32_t c = 0; c < bpp; c++) {
+                        const SegPix pc = px[tid * 4 + c];
+                        uint32_t hmax;
+                        if (pc.w >> 24) hmax = h0s[0];                                      /* forced symbol 0 (the alpha of a fully transparent pixel) */
+                        else hmax = rm[seg_min(seg_max((int)(pc.w & 255u) + pc.e0, -256), 511) + 256];
+                        const uint32_t fr = hmax + rowbumps;
+                        lb += 33u + (uint32_t)__builtin_clz(fr ? fr : 1u);
+                    }
+                }
+                lb = pls_wave_sum_u64(lb);
+                if (PLS_WAVE_LEADER(tid) && lb) PLS_ATOMIC_ADD64((uint64_t *)&red[10], lb);
+            }
         }
     }
     PLS_SYNC();
+    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        if (tid == 0) {
+            if (!lazy) {
+                PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
+                if (adaptive) for (int g = 0; g < SEG_NFILT; g++) PLS_ATOMIC_ADD(&A.hs[f][g], red[2 + g]);
+            }
+            if (f == 0 && R >= 0) { PLS_ATOMIC_ADD64(&A.none_lb, *(uint64_t *)&red[10]); PLS_ATOMIC_ADD(&A.lb_valid, 1u); }
+            if (rprof) {
+                tr_[4] = PLS_CLOCK();
+                for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(tr_[q + 1] - tr_[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(tr_[q + 1] - tr_[q])); }
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
+            }
+        }
     }
-    seg_row_sums(j, P, par, f, grp, cv, lazy, walk, lane, tw, (uint32_t *)px);
 }
 
 /* Validation of one decision d = (pixel k of the group) * 4 + channel.  mode 0: with the block bounds only -- returns 1 good, 0 bad,
@@ -2336,17 +2367,22 @@ PLS_HD void seg_ctl_reload(const SegJob &j, int prev, seg_lds_u32 ctlc, seg_lds_
 /* The entropy cost of every candidate row (optimize_state.c:326-342): a pixel is charged 64 - floor(log2 H[symbol]) = 33 + clz(H[symbol]) under
  * the histogram AFTER the row, and its symbol is the bin it bumped (:251-254 -- the stored byte minus the same prediction), so the row costs
  * sum over bins of n * (33 + clz(H0 + n)), n = the row's bumps of the bin: no pass over the pixels.  ecost: SEG_NFILT (8) words of shared
- * memory; all `nt` threads (a multiple of 256: a wave's items are one candidate's). */
+ * memory, zeroed by the caller in front of its last barrier. */
 PLS_HD void seg_entropy_costs(seg_lds_u32 spec, seg_lds_u32 ecost, int nt)
 {
-    PLS_THREADS(tid, nt) { if (tid < 8) ecost[tid] = 0u; }
-    PLS_SYNC();
+    /* (ecost was zeroed in front of the barrier behind the burst) one wave per candidate, four bins a lane */
     PLS_THREADS(tid, nt) {
-        for (int i = tid; i < SEG_NFILT * 256; i += nt) {
-            const uint32_t n = spec[i], h = spec[SEG_NFILT * 256 + (i & 255)] + n;
-            uint32_t v = n ? n * (33u + (uint32_t)__builtin_clz(h)) : 0u;
+        if (tid < SEG_NFILT * 64) {
+            const int f = tid >> 6, lane = tid & 63;
+            uint32_t v = 0;
+            PLS_UNROLL
+            for (int q = 0; q < 4; q++) {
+                const int b = lane + 64 * q;
+                const uint32_t n = spec[f * 256 + b], h = spec[SEG_NFILT * 256 + b] + n;
+                v += n ? n * (33u + (uint32_t)__builtin_clz(h)) : 0u;
+            }
             v = pls_wave_sum_u32(v);
-            if (PLS_WAVE_LEADER(tid) && v) PLS_ATOMIC_ADD(&ecost[i >> 8], v);
+            if (PLS_WAVE_LEADER(tid) && v) PLS_ATOMIC_ADD(&ecost[f], v);
         }
     }
     PLS_SYNC();
@@ -2476,7 +2512,6 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
 {
     const int k1 = seg_k_prev(par), k2 = seg_k_prev2(par);
     const uint32_t W = j.W, H = j.H, bpp = j.bpp;
-    SEG_AS_LDS int *mm = (SEG_AS_LDS int *)smem;                /* [0] max, [1] min of orig + incoming error over this workgroup's pixels of the COMING row */
     seg_lds_u32 lutb = (seg_lds_u32)smem + 8;                  /* [512] next-rows terms of the split */
     seg_lds_u32 ctlc = lutb + 512, accc = ctlc + (sizeof(SegCtl) + 7) / 8 * 2, dshare = accc + (sizeof(SegAcc) + 7) / 8 * 2;
     seg_lds_u32 ecost = dshare + 40;                           /* [8] entropy cost of every candidate row; [48]: failmask of the attempt two before */
@@ -2522,7 +2557,8 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
                 }
                 ext[tid * 2 + 0] = e1v[0]; ext[tid * 2 + 1] = e1v[1]; ext[(SEG_COMMIT_W + tid) * 2 + 0] = e1v[2]; ext[(SEG_COMMIT_W + tid) * 2 + 1] = e1v[3];
                 lutb[tid] = lb0; lutb[tid + SEG_COMMIT_W] = lb1;
-                if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; dshare[48] = fmw; }
+                if (tid == 0) dshare[48] = fmw;
+                if (tid < 8) ecost[tid] = 0u;
                 if (tid < (int)(sizeof(SegCtl) / 4)) ctlc[tid] = cword;
                 if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
             } else {
@@ -2544,32 +2580,17 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
     const bool fresh = cur.magic != SEG_MAGIC;                 /* the image's first attempt: nothing behind it (what the burst read is junk) */
     const int attempt = fresh ? 0 : 1;
     if (fresh) {
-        /* the first row: its originals into rowcopy, their extremes (no incoming error yet) */
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { mm[0] = -(1 << 30); mm[1] = 1 << 30; } }
-        PLS_SYNC();
+        /* the first row: its originals into rowcopy; nothing has been diffused into it */
         PLS_THREADS(tid, SEG_THREADS) {
             if (tid < SEG_COMMIT_W) {
                 const uint32_t x = xw0 + (uint32_t)tid;
-                int vmax = -(1 << 30), vmin = 1 << 30;
                 if (x < W && H) {
-                    const uint32_t o = j.img[x];
-                    seg_row_orig(j, 0u)[x] = o;
-                    SEG_AS_GLB uint32_t *e00 = seg_e0(j, 0u), *e10 = seg_e1(j, 0u);      /* nothing has been diffused into the first row */
+                    seg_row_orig(j, 0u)[x] = j.img[x];
+                    SEG_AS_GLB uint32_t *e00 = seg_e0(j, 0u), *e10 = seg_e1(j, 0u);
                     e00[2 * (size_t)x] = 0u; e00[2 * (size_t)x + 1] = 0u; e10[2 * (size_t)x] = 0u; e10[2 * (size_t)x + 1] = 0u;
-                    const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-                    for (uint32_t c = 0; c < bpp; c++) {
-                        if (alpha0 && c == bpp - 1u) continue;
-                        const int v = (int)((o >> (8 * c)) & 255u);
-                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
-                    }
                 }
-                vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-                if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
             }
         }
-        PLS_SYNC();
-        PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { SEG_AS_GLB int32_t *rm0 = seg_rowmm(j, 0u); rm0[2 * cw] = mm[0]; rm0[2 * cw + 1] = mm[1]; } }
         return;
     }
     seg_entropy_costs(spec, ecost, SEG_THREADS);
@@ -2597,7 +2618,6 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < SEG_COMMIT_W) {
             const uint32_t x = xw0 + (uint32_t)tid;
-            int vmax = -(1 << 30), vmin = 1 << 30;
             if (x < W) {
                 const uint32_t onext = ynext < H ? j.img[(size_t)ynext * W + x] : 0u;
                 const uint32_t e1[2] = { ext[((y & 1u) * SEG_COMMIT_W + tid) * 2 + 0], ext[((y & 1u) * SEG_COMMIT_W + tid) * 2 + 1] };
@@ -2620,30 +2640,18 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
                     n1[p] = (uint32_t)c2 & 0xffffu;
                 }
                 /* the image row in place (its originals stay in rowcopy for the validation that runs next to this, and for a repetition);
-                 * the coming row's originals, incoming errors and extremes into the copies of ITS parity */
+                 * the coming row's originals and incoming errors into the copies of ITS parity */
                 rowp[x] = npx[tid];
                 e0n[2 * (size_t)x] = n0[0] | (n0[1] << 16); e0n[2 * (size_t)x + 1] = n0[2] | (n0[3] << 16);
                 e1n[2 * (size_t)x] = n1[0] | (n1[1] << 16); e1n[2 * (size_t)x + 1] = n1[2] | (n1[3] << 16);
-                if (ynext < H) {
-                    seg_row_orig(j, ynext)[x] = onext;
-                    const bool alpha0 = (bpp & 1u) == 0u && ((onext >> (8u * (bpp - 1u))) & 255u) == 0u;
-                    for (uint32_t c = 0; c < bpp; c++) {
-                        if (alpha0 && c == bpp - 1u) continue;
-                        const int v = (int)((onext >> (8 * c)) & 255u) + seg_sext16((int)n0[seg_plane_of_channel(bpp, (int)c)]);
-                        vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
-                    }
-                }
+                if (ynext < H) seg_row_orig(j, ynext)[x] = onext;
             }
-            vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
-            if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_I(&mm[0], vmax); PLS_ATOMIC_MIN_I(&mm[1], vmin); }
             if (cw == 0 && tid == 0) {
                 if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << winner);          /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
                 j.row_ids[y] = (uint8_t)winner;
             }
         }
     }
-    PLS_SYNC();
-    PLS_THREADS(tid, SEG_THREADS) { if (tid == 0 && j.rowmm) { SEG_AS_GLB int32_t *rmn = seg_rowmm(j, ynext); rmn[2 * cw] = mm[0]; rmn[2 * cw + 1] = mm[1]; } }
     if (prof) { PLS_THREADS(tid, SEG_THREADS) { if (tid == 0) { const uint32_t dt = (uint32_t)(PLS_CLOCK() - tc0); PLS_ATOMIC_MAX(&j.result[58], (int32_t)dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[62], dt); PLS_ATOMIC_ADD((uint32_t *)&j.result[63], 1u); PLS_ATOMIC_ADD((uint32_t *)&j.result[23], (uint32_t)(tk[0] - tc0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[45], (uint32_t)(tk[1] - tk[0])); PLS_ATOMIC_ADD((uint32_t *)&j.result[54], (uint32_t)(tk[2] - tk[1])); PLS_ATOMIC_ADD((uint32_t *)&j.result[55], (uint32_t)(PLS_CLOCK() - tk[2])); } } }
 }
 
@@ -2695,6 +2703,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
             if (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) accc[tid - 128] = aword;
             if (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) rank[tid - 256] = rword;
             if (tid == 512) dshare[48] = fmw;
+            if (tid >= 520 && tid < 528) dshare[40 + tid - 520] = 0u;     /* (the entropy costs) */
             seg_spec_store<NSP>(j, tid, SEG_THREADS, sr, spec);
         }
     }

@@ -104,7 +104,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.grpcnt = A.take<uint32_t>((size_t)5 * j.ngrp * 256);
     j.grpleft = A.take<uint32_t>((size_t)5 * j.ngrp);
     j.firstidx = A.take<uint32_t>(5 * 4 * 2);
-    j.rowmm = A.take<int32_t>(4 * ((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W));
+    j.rowmm = A.take<int32_t>(4);
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
     const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
     j.ctl[2].magic = 0u; j.acc[2].failmask = 0u;   /* (seg_k_resolve does this on the device: the first attempt finds no attempt behind it) */
@@ -149,6 +149,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         {   /* the chain kernel's LDS is sized by the row's segments: the same size here (the sanitizer build sees an overrun) */
             std::vector<unsigned char> csm((size_t)SEG_SM_CHAIN(j.nseg), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, csm.data());
+            seg_extremes_body(j, P, par, csm.data());
         }
         { std::vector<unsigned char> rsm((size_t)SEG_SM_REPLAY, 0x5A); for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, rsm.data()); }
     }
