@@ -466,7 +466,8 @@ def main():
         achieved = ALGO_BYTES_PER_PIXEL * px / (eng_ms * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch from the last committed rocprofv3 PMC passes (tools/pmc_to_json.py)
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["traffic_bytes"]
+            tj = [f for f in ("r04_pmc_traffic.json", "pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            traffic = json.load(open(os.path.join(ROOT, "profiles", tj)))["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
         line = {
@@ -479,7 +480,7 @@ def main():
                                    "row_filters requested; device-resident in, device-resident out",
                        "images_per_gpu": 1, "parallelism": f"image-parallel x{world}, no data-path collective"},
             "bit_exact_vs_reference_digest": bool(bit_exact),
-            "roofline": {"bound": "hbm", "kernel": "row engine: " + str(engine_info.get("engine")) + (" (seg_k_ctl, seg_k_enum, seg_k_chain, seg_k_replay, seg_k_post per row attempt)" if engine_info.get("engine") == "segment-parallel" else " (pl_engine)"),
+            "roofline": {"bound": "hbm", "kernel": "row engine: " + str(engine_info.get("engine")) + (" (four launches per row attempt: seg_k_ctl [control of this attempt + validation of the attempt before, side by side], seg_k_enum, seg_k_chain, seg_k_replay)" if engine_info.get("engine") == "segment-parallel" else " (pl_engine)"),
                          "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "engine_ms_per_launch": round(eng_ms, 3),
@@ -490,10 +491,10 @@ def main():
                                          "note": "secondary, honest bound (SURVEY 8d): the rows of an image are strictly serial (the winner of row y seeds "
                                                  "row y+1), and so is a row's x-chain in the reference.  The segment-parallel engine cuts the x-chain into "
                                                  "32-pixel segments (state enumeration + map composition + exact validation, DESIGN.md section 4), so what is "
-                                                 "left in series is H row attempts of five dependent kernels each"},
+                                                 "left in series is H row attempts of four dependent launches each; the exact validation of an attempt runs next to the control kernel of the next one (the decision is optimistic, a failed validation voids the attempt under way)"},
                          "note": "bound by the row-to-row dependency chain (DESIGN.md), not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB "
                                  "per engine run, measured with HIP events around the engine's launches on the launch stream; traffic = "
-                                 "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
+                                 "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (static: the committed profiles/r04_pmc_traffic.json, not measured by this invocation)"},
             "bandwidth_kernels": bandwidth_kernels(),
         }
         line["transfers"] = {"h2d_ms": round(h2d_ms, 3), "d2h_ms": round(d2h_ms, 3), "bytes_each_way": W * H * 4,

@@ -244,6 +244,43 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
  * damaged file (/root/reference/src/pngloss.c:196-204).  Not while a batch is in flight on the context (PNGLOSS_INVALID_ARGUMENT). */
 int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status);
 
+/* DEVICE-RESIDENT hand-over ("fuse with K0"): the same decode, but the RGBA8 images STAY in device memory -- in a frame
+ * arena of the context, apart from the workspace the optimiser uses -- and d_rgba[i] receives their device pointers (width * height * 4 bytes,
+ * 256-byte aligned), which go straight into pngloss_hip_image_desc.d_rgba of pngloss_hip_optimize_batch[_async] on the same context: the pixels
+ * never travel back to the host between the reader and the optimiser (the classify / histogram kernels read what the expansion kernel
+ * wrote).  src[i].rgba is not used (may be NULL).  The frames are valid until the next decode on this context, or its destruction; the
+ * optimiser rewrites them in place.  Everything is enqueued on `stream` (a hipStream_t, NULL = the default stream); the call returns when the
+ * statuses have arrived (the decode itself takes milliseconds).  status: n ints or NULL, as above.  Replaces the part of
+ * /root/reference/src/rwpng.c:179-400 behind the inflate, like pngloss_hip_png_decode_batch_host. */
+int pngloss_hip_png_decode_batch_device(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, void **d_rgba, int *status, void *stream);
+
+/* The same from the COMPRESSED image data: the inflate, too, runs on the device -- one wave per file (pngloss_amd/csrc/pl_inflate_core.h: stored,
+ * fixed and dynamic blocks, the 32 KB window in shared memory, Adler-32 checked), for the files of a window, whose streams are independent.
+ * This replaces ALL of the reader behind the chunk walk (/root/reference/src/rwpng.c:179-400: libpng's png_read_image = zlib inflate + inverse
+ * filters + transformations); what goes up is the file's compressed bytes, what comes out stays on the device.
+ *   zstream   the concatenated payloads of the file's IDAT chunks (one zlib stream), zbytes of them
+ * A stream the device inflater does not take (damaged, preset dictionary, size mismatch ...) gets status 25 and the call returns 25: read that
+ * file on the host.  One wave decodes ~10 MB/s: this pays for windows of many files, not for one large image (use the scanline form, with zlib
+ * on host threads, for those). */
+typedef struct {
+    const unsigned char *zstream;
+    size_t zbytes;
+    uint32_t width, height;
+    uint8_t color_type, bit_depth;
+    const unsigned char *palette;
+    uint32_t palette_entries;
+    const unsigned char *trns;
+    uint32_t trns_bytes;
+} pngloss_hip_png_zsource;
+
+int pngloss_hip_png_decode_batch_device_z(pngloss_hip_ctx *ctx, const pngloss_hip_png_zsource *zsrc, size_t n, void **d_rgba, int *status, void *stream);
+
+/* Page-locked host memory for what goes up to the device (the inflated scanlines handed to the decode calls, images handed to the host
+ * batches): a copy from it is one DMA, a copy from pageable memory is staged by the runtime (33 ms against 1.3 ms for 64 MiB, bench.py
+ * `transfers`).  NULL when the runtime has none to give; pngloss_hip_pinned_free(NULL) is a no-op. */
+void *pngloss_hip_pinned_alloc(size_t bytes);
+void pngloss_hip_pinned_free(void *p);
+
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
  *            (batches).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model (wide images and small batches go to
@@ -256,6 +293,15 @@ int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss
  *   info[5]  segments the chain kernel walked step by step because their entry state was in no enumerated set (engine 3)
  * No reference equivalent. */
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8]);
+
+/* Options of a context (not while a batch is in flight).  Known: name "engine", value
+ *   "auto"    (default) the row engine is chosen image by image from the cost model (see pngloss_hip_last_engine_info)
+ *   "seg"     the segment-parallel engine for every image it takes (any strength / bleed; rows up to 2^20 pixels)
+ *   "wg"      one workgroup per image (band-leader chains); "lead" / "legacy": its chain variants (diagnostics)
+ *   "mix"     alternate the two engines over the images of a batch (diagnostics)
+ * The environment variable PNGLOSS_HIP_ENGINE (the tests' hook) is read only while this option is at "auto".
+ * Returns PNGLOSS_SUCCESS or PNGLOSS_INVALID_ARGUMENT (unknown name or value).  Results never depend on the engine. */
+int pngloss_hip_set_option(pngloss_hip_ctx *ctx, const char *name, const char *value);
 
 /* Library / device identification string (static storage). */
 const char *pngloss_hip_version(void);

@@ -9,6 +9,7 @@
 #include "pl_device.h"
 #include "pl_deflate.h"
 #include "pl_pngread.h"
+#include "pl_inflate.h"
 #define SEG_PLAIN_POINTERS   /* host plumbing only: SegJob is filled here, never dereferenced */
 #include "pl_seg.h"
 
@@ -22,6 +23,7 @@
 #include <thread>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #define PL_CHECK(expr)                                                                                           \
@@ -51,6 +53,9 @@ struct pngloss_hip_ctx {
     size_t arena_bytes = 0;
     char *h_pinned = nullptr;
     size_t pinned_bytes = 0;
+    std::string opt_engine;          /* pngloss_hip_set_option("engine", ...): empty = the cost model (or, for tests, $PNGLOSS_HIP_ENGINE) */
+    char *d_frames = nullptr;        /* device frames of pngloss_hip_png_decode_batch_device: decoded RGBA8 that stays on the device for the optimiser */
+    size_t frames_bytes = 0;
     hipStream_t copy_stream = nullptr;
     double upload_ms = -1.0, download_ms = -1.0;
     /* -v progress display of the single-image seam: a host-mapped word the engine writes the finished row count to */
@@ -254,7 +259,10 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
     if (n_wg) PL_CHECK(pl_launch_engine(d_jobs, d_sel, n_wg, prm, stream));      /* (a mixed batch: the other engine's images, side by side with this one's) */
     /* every row needs one attempt, every epoch one more; a bound far above anything real stops a runaway loop */
-    const long max_attempts = (long)max_h * (2 + 2 * SEG_MAX_RESTARTS * SEG_NFILT) + 1024;   /* (an epoch costs two: the attempt that was under way when the validation failed is void) */
+    /* every row needs one attempt per strength it is tried at (pngloss_image.c:266-274: down to 0 in the worst case), every epoch two more (the
+     * attempt under way when its validation fails is void): a bound far above anything real, there to stop a runaway loop -- the stall
+     * detector of the launch thread is the other net.  (Seen: 1813 attempts for a 63 x 2 image at strength 200, all rows adaptive.) */
+    const long max_attempts = (long)std::min<double>(2.0e9, (double)max_h * ((double)params.strength + 1.0) * (2.0 + 2.0 * SEG_MAX_RESTARTS * SEG_NFILT) + 1024.0);
     ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
     bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct;
     if (waiting && stream) {
@@ -318,12 +326,12 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     std::vector<uint8_t> on_seg(n, 0);
     size_t n_seg = 0;
     {
-        const char *em = std::getenv("PNGLOSS_HIP_ENGINE");
+        const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();   /* (the option of the ABI first; the environment variable is the tests' hook) */
         const bool forced = em && std::strcmp(em, "seg") == 0;
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
         bool seg_ok = n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
-            const double a_us = seg_params.seeded ? 95.0 : 51.0, w_us = seg_params.seeded ? 0.05 : 0.032;
+            const double a_us = seg_params.seeded ? 88.0 : 44.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches, 50.6 us at 424 workgroups) */
             auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
             std::vector<size_t> order;
             for (size_t i = 0; i < n; i++)
@@ -416,7 +424,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     prm.r29 = 2.0f * recip_up_host(9);
     prm.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;   /* test hook, see pl_device.h */
     {
-        const char *em = std::getenv("PNGLOSS_HIP_ENGINE");                     /* test hook: "legacy" = round-1 chains only */
+        const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();   /* "legacy" = round-1 chains only */
         prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : ((em && std::strcmp(em, "lead") == 0) ? 2 : ((em && std::strcmp(em, "mix") == 0) ? 3 : 0));   /* "lead": never fall back adaptively; "mix": alternate every four rows */
         if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) prm.engine_mode |= (std::atoi(ff) + 1) << 8;   /* debugging aid */
     }
@@ -697,6 +705,7 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->h_progress) (void)hipHostFree(ctx->h_progress);
     if (ctx->h_seg_words) (void)hipHostFree(ctx->h_seg_words);
@@ -1138,10 +1147,17 @@ int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_pn
     return pngloss_hip_png_decode_batch_host_status(ctx, src, n, nullptr);
 }
 
-int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status)
+} /* extern "C" */
+namespace {
+/* d_out == nullptr: the decoded images are downloaded to src[i].rgba.  Else they STAY on the device, in the context's frame arena (apart
+ * from the workspace the optimiser carves up), and d_out[i] receives their device pointers. */
+/* zs != nullptr: src[i].scanlines is not used; the scanlines are INFLATED ON THE DEVICE from zs[i] (the concatenated IDAT payloads), one wave per file */
+struct ZRef { const unsigned char *z; size_t bytes; };
+int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status, void **d_out, hipStream_t stream, const ZRef *zs = nullptr)
 {
     if (!ctx || (!src && n)) return PNGLOSS_INVALID_ARGUMENT;
     if (status) for (size_t i = 0; i < n; i++) status[i] = PNGLOSS_SUCCESS;
+    if (d_out) for (size_t i = 0; i < n; i++) d_out[i] = nullptr;
     if (!n) return PNGLOSS_SUCCESS;
     if (ctx->pending) {
         /* (the workspace this call carves up belongs to the batch in flight) */
@@ -1150,18 +1166,23 @@ int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss
     }
     PL_CHECK(hipSetDevice(ctx->device));
     std::vector<PrJob> jobs(n);
-    std::vector<size_t> raw_off(n), out_off(n), last_off(n), prog_off(n);
+    std::vector<size_t> raw_off(n), out_off(n), last_off(n), prog_off(n), z_off(n);
     uint32_t max_bands = 0;
-    size_t total = align_up(sizeof(PrJob) * n, 256) + align_up(sizeof(int32_t) * n, 256);
-    const size_t jobs_bytes = align_up(sizeof(PrJob) * n, 256);
+    size_t total = align_up(sizeof(PrJob) * n, 256) + 2 * align_up(sizeof(int32_t) * n, 256) + align_up(sizeof(PliStream) * n, 256), ftotal = 0;
+    const size_t jobs_bytes = align_up(sizeof(PrJob) * n, 256), st_bytes = align_up(sizeof(int32_t) * n, 256);
     for (size_t i = 0; i < n; i++) {
-        if (!src[i].scanlines || !src[i].rgba) return PNGLOSS_INVALID_ARGUMENT;
+        if ((!zs && !src[i].scanlines) || (zs && (!zs[i].z || zs[i].bytes < 6 || zs[i].bytes > 0xFFFFFFF0u)) || (!d_out && !src[i].rgba)) return PNGLOSS_INVALID_ARGUMENT;
         if (!pr_format(jobs[i].F, src[i].width, src[i].height, src[i].color_type, src[i].bit_depth, src[i].palette, src[i].palette_entries, src[i].trns, src[i].trns_bytes)) {
             std::fprintf(stderr, "pngloss_hip: image %zu: colour type %d with bit depth %d (or an empty image / a palette image without PLTE) is not a PNG format\n", i, src[i].color_type, src[i].bit_depth);
             return PNGLOSS_INVALID_ARGUMENT;
         }
         raw_off[i] = total; total += align_up(((size_t)jobs[i].F.rowbytes + 1) * src[i].height, 256);
-        out_off[i] = total; total += align_up((size_t)src[i].width * src[i].height * 4, 256);
+        if (zs) {
+            if (((size_t)jobs[i].F.rowbytes + 1) * src[i].height > 0xFFFFFFF0u) return PNGLOSS_INVALID_ARGUMENT;     /* (32-bit positions in the inflater) */
+            z_off[i] = total; total += align_up(zs[i].bytes + 16, 256);
+        }
+        const size_t out_bytes = align_up((size_t)src[i].width * src[i].height * 4, 256);
+        if (d_out) { out_off[i] = ftotal; ftotal += out_bytes; } else { out_off[i] = total; total += out_bytes; }
         /* per band of PR_ROWS rows: its last row (for the band below) and a progress word */
         jobs[i].nbands = (src[i].height + PR_ROWS - 1) / PR_ROWS;
         jobs[i].lastpitch = (uint32_t)align_up(jobs[i].F.rowbytes, 256);
@@ -1173,34 +1194,64 @@ int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss
     auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
+    if (d_out && ftotal > ctx->frames_bytes) {
+        if (ctx->d_frames) PL_CHECK(hipFree(ctx->d_frames));
+        ctx->d_frames = nullptr; ctx->frames_bytes = 0;
+        const size_t want = align_up(ftotal + ftotal / 4, 1 << 20);
+        PL_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_frames), want));
+        ctx->frames_bytes = want;
+    }
     const double ms_ws = ms_since();
-    char *b = ctx->d_ws;
-    int32_t *d_status = reinterpret_cast<int32_t *>(b + jobs_bytes);
-    PL_CHECK(hipMemsetAsync(d_status, 0, sizeof(int32_t) * n, nullptr));
+    char *b = ctx->d_ws, *fb = d_out ? ctx->d_frames : ctx->d_ws;
+    int32_t *d_status = reinterpret_cast<int32_t *>(b + jobs_bytes), *d_zstatus = reinterpret_cast<int32_t *>(b + jobs_bytes + st_bytes);
+    PliStream *d_zjobs = reinterpret_cast<PliStream *>(b + jobs_bytes + 2 * st_bytes);
+    std::vector<PliStream> zjobs(zs ? n : 0);
+    PL_CHECK(hipMemsetAsync(d_status, 0, 2 * st_bytes, stream));
     for (size_t i = 0; i < n; i++) {
         jobs[i].raw = reinterpret_cast<const uint8_t *>(b + raw_off[i]);
-        jobs[i].rgba = reinterpret_cast<uint32_t *>(b + out_off[i]);
+        jobs[i].rgba = reinterpret_cast<uint32_t *>(fb + out_off[i]);
         jobs[i].lastrow = reinterpret_cast<uint8_t *>(b + last_off[i]);
         jobs[i].progress = reinterpret_cast<uint32_t *>(b + prog_off[i]);
-        PL_CHECK(hipMemsetAsync(b + prog_off[i], 0, sizeof(uint32_t) * jobs[i].nbands, nullptr));
+        PL_CHECK(hipMemsetAsync(b + prog_off[i], 0, sizeof(uint32_t) * jobs[i].nbands, stream));
         jobs[i].status = d_status + i;
-        PL_CHECK(hipMemcpyAsync(b + raw_off[i], src[i].scanlines, ((size_t)jobs[i].F.rowbytes + 1) * src[i].height, hipMemcpyHostToDevice, nullptr));
+        /* (from pinned memory -- pngloss_hip_pinned_alloc -- this is one DMA; from pageable memory the runtime stages it: 33 ms against 1.3 for 64 MiB) */
+        if (zs) {
+            PL_CHECK(hipMemcpyAsync(b + z_off[i], zs[i].z, zs[i].bytes, hipMemcpyHostToDevice, stream));
+            zjobs[i].z = reinterpret_cast<const uint8_t *>(b + z_off[i]); zjobs[i].zbytes = (uint32_t)zs[i].bytes;
+            zjobs[i].out = reinterpret_cast<uint8_t *>(b + raw_off[i]); zjobs[i].expect = (uint32_t)(((size_t)jobs[i].F.rowbytes + 1) * src[i].height);
+            zjobs[i].status = d_zstatus + i;
+        } else
+        PL_CHECK(hipMemcpyAsync(b + raw_off[i], src[i].scanlines, ((size_t)jobs[i].F.rowbytes + 1) * src[i].height, hipMemcpyHostToDevice, stream));
     }
-    PL_CHECK(hipMemcpyAsync(b, jobs.data(), sizeof(PrJob) * n, hipMemcpyHostToDevice, nullptr));
+    PL_CHECK(hipMemcpyAsync(b, jobs.data(), sizeof(PrJob) * n, hipMemcpyHostToDevice, stream));
+    if (zs) {
+        PL_CHECK(hipMemcpyAsync(d_zjobs, zjobs.data(), sizeof(PliStream) * n, hipMemcpyHostToDevice, stream));
+        PL_CHECK(pl_launch_inflate(d_zjobs, n, stream));
+    }
     const bool seam_dbg = std::getenv("PNGLOSS_HIP_DEBUG_SEAM") != nullptr;
     double ms_up = 0, ms_k = 0;
-    if (seam_dbg) { PL_CHECK(hipStreamSynchronize(nullptr)); ms_up = ms_since(); }
-    PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, max_bands, nullptr));
-    if (seam_dbg) { PL_CHECK(hipStreamSynchronize(nullptr)); ms_k = ms_since(); }
-    std::vector<int32_t> st(n);
-    for (size_t i = 0; i < n; i++)
-        PL_CHECK(hipMemcpyAsync(src[i].rgba, b + out_off[i], (size_t)src[i].width * src[i].height * 4, hipMemcpyDeviceToHost, nullptr));
-    PL_CHECK(hipMemcpyAsync(st.data(), d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, nullptr));
-    PL_CHECK(hipStreamSynchronize(nullptr));
-    if (seam_dbg) std::fprintf(stderr, "pngloss_hip: read side: %zu files, workspace %zu MB ready after %.1f ms, upload %.1f ms, unfilter + expand %.1f ms, download %.1f ms\n", n, total >> 20, ms_ws, ms_up - ms_ws, ms_k - ms_up, ms_since() - ms_k);
-    /* every image has been decoded and downloaded; the ones that failed say so -- one damaged file does not take the window with it */
+    if (seam_dbg) { PL_CHECK(hipStreamSynchronize(stream)); ms_up = ms_since(); }
+    PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, max_bands, stream));
+    if (seam_dbg) { PL_CHECK(hipStreamSynchronize(stream)); ms_k = ms_since(); }
+    std::vector<int32_t> st(n), zst(n, 0);
+    if (zs) PL_CHECK(hipMemcpyAsync(zst.data(), d_zstatus, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream));
+    if (!d_out)
+        for (size_t i = 0; i < n; i++)
+            PL_CHECK(hipMemcpyAsync(src[i].rgba, b + out_off[i], (size_t)src[i].width * src[i].height * 4, hipMemcpyDeviceToHost, stream));
+    PL_CHECK(hipMemcpyAsync(st.data(), d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream));
+    PL_CHECK(hipStreamSynchronize(stream));
+    if (seam_dbg) std::fprintf(stderr, "pngloss_hip: read side: %zu files, workspace %zu MB ready after %.1f ms, upload %.1f ms, unfilter + expand %.1f ms, %s %.1f ms\n", n, (total + ftotal) >> 20, ms_ws, ms_up - ms_ws, ms_k - ms_up, d_out ? "status (the frames stay on the device)" : "download", ms_since() - ms_k);
+    /* every image has been decoded (and downloaded); the ones that failed say so -- one damaged file does not take the window with it */
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < n; i++) {
+        if (d_out) d_out[i] = fb + out_off[i];
+        if (zst[i]) {
+            /* the stream is not one the device inflater takes (damaged, or beyond what it checks): the caller reads the file on the host */
+            std::fprintf(stderr, "pngloss_hip: image %zu: the device inflater stopped (code %d): corrupt or unusual zlib stream\n", i, zst[i]);
+            if (status) status[i] = 25;
+            if (worst == PNGLOSS_SUCCESS) worst = 25;
+            continue;
+        }
         if (!st[i]) continue;
         const int code = st[i] == 25 ? 25 : PNGLOSS_HIP_ERROR;
         if (st[i] == 25) std::fprintf(stderr, "pngloss_hip: image %zu: a scanline has a filter type beyond 4 (corrupt stream)\n", i);
@@ -1210,6 +1261,53 @@ int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss
     }
     return worst;
 }
+} // namespace
+extern "C" {
+
+int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status)
+{
+    return png_decode_common(ctx, src, n, status, nullptr, nullptr);
+}
+
+int pngloss_hip_png_decode_batch_device(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, void **d_rgba, int *status, void *stream)
+{
+    if (!d_rgba && n) return PNGLOSS_INVALID_ARGUMENT;
+    return png_decode_common(ctx, src, n, status, d_rgba, static_cast<hipStream_t>(stream));
+}
+
+int pngloss_hip_png_decode_batch_device_z(pngloss_hip_ctx *ctx, const pngloss_hip_png_zsource *zsrc, size_t n, void **d_rgba, int *status, void *stream)
+{
+    if ((!d_rgba || !zsrc) && n) return PNGLOSS_INVALID_ARGUMENT;
+    std::vector<pngloss_hip_png_source> src(n);
+    std::vector<ZRef> zs(n);
+    for (size_t i = 0; i < n; i++) {
+        src[i] = pngloss_hip_png_source{ nullptr, zsrc[i].width, zsrc[i].height, zsrc[i].color_type, zsrc[i].bit_depth, zsrc[i].palette, zsrc[i].palette_entries, zsrc[i].trns, zsrc[i].trns_bytes, nullptr };
+        zs[i] = ZRef{ zsrc[i].zstream, zsrc[i].zbytes };
+    }
+    return png_decode_common(ctx, src.data(), n, status, d_rgba, static_cast<hipStream_t>(stream), zs.data());
+}
+
+int pngloss_hip_set_option(pngloss_hip_ctx *ctx, const char *name, const char *value)
+{
+    if (!ctx || !name || !value) return PNGLOSS_INVALID_ARGUMENT;
+    if (ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
+    if (std::strcmp(name, "engine") == 0) {
+        static const char *const known[] = { "auto", "seg", "wg", "lead", "legacy", "mix" };
+        for (const char *k : known)
+            if (std::strcmp(value, k) == 0) { ctx->opt_engine = std::strcmp(value, "auto") == 0 ? "" : value; return PNGLOSS_SUCCESS; }
+        return PNGLOSS_INVALID_ARGUMENT;
+    }
+    return PNGLOSS_INVALID_ARGUMENT;
+}
+
+void *pngloss_hip_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void pngloss_hip_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8])
 {

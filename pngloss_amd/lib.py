@@ -54,7 +54,7 @@ class PngSource(C.Structure):
 
 def parse_png(data):
     """Chunk walk + inflate of a PNG file (what pngloss_amd/cli/png_stream_reader.c does in C with zlib): dict(width, height, depth, ctype,
-    interlace, plte, trns, scanlines).  Host work by design: the inflate is a serial bit stream."""
+    interlace, plte, trns, zstream, scanlines)."""
     import struct
     import zlib
     data = bytes(data)
@@ -75,8 +75,14 @@ def parse_png(data):
             idat.append(body)
         elif tag == b"IEND":
             break
-    out["scanlines"] = zlib.decompress(b"".join(idat))
+    out["zstream"] = b"".join(idat)
+    out["scanlines"] = zlib.decompress(out["zstream"])
     return out
+
+
+class PngZSource(C.Structure):
+    _fields_ = [("zstream", C.c_char_p), ("zbytes", C.c_size_t), ("width", C.c_uint32), ("height", C.c_uint32), ("color_type", C.c_uint8), ("bit_depth", C.c_uint8),
+                ("palette", C.c_char_p), ("palette_entries", C.c_uint32), ("trns", C.c_char_p), ("trns_bytes", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -123,7 +129,7 @@ ABI_SYMBOLS = (
     "pngloss_hip_device_count", "pngloss_hip_create", "pngloss_hip_destroy", "pngloss_hip_optimize_batch_async",
     "pngloss_hip_finish", "pngloss_hip_optimize_batch", "pngloss_hip_optimize_batch_host", "pngloss_hip_optimize_batch_host_emit",
     "pngloss_hip_optimize_batch_host_zlib", "pngloss_hip_zlib_bound", "pngloss_hip_last_deflate_ms", "pngloss_hip_last_engine_ms", "pngloss_hip_last_total_ms",
-    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_png_decode_batch_host", "pngloss_hip_png_decode_batch_host_status", "pngloss_hip_version",
+    "pngloss_hip_last_histogram", "pngloss_hip_last_engine_info", "pngloss_hip_png_decode_batch_host", "pngloss_hip_png_decode_batch_host_status", "pngloss_hip_png_decode_batch_device", "pngloss_hip_png_decode_batch_device_z", "pngloss_hip_pinned_alloc", "pngloss_hip_pinned_free", "pngloss_hip_set_option", "pngloss_hip_version",
     "pngloss_hip_multi_create", "pngloss_hip_multi_destroy", "pngloss_hip_multi_count", "pngloss_hip_multi_split",
     "pngloss_hip_multi_optimize_batch_host",
 )
@@ -276,6 +282,12 @@ class HipContext:
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        """pngloss_hip_set_option: e.g. ("engine", "seg" | "wg" | "auto")"""
+        self._lib.pngloss_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        self._lib.pngloss_hip_set_option.restype = C.c_int
+        _check(self._lib.pngloss_hip_set_option(self._ctx, name.encode(), value.encode()), "set_option")
+
     def enqueue(self, images, strength=19, bleed=2, stream=0):
         """images: sequence of (d_rgba_ptr, d_filters_ptr_or_0, width, height). Asynchronous."""
         n = len(images)
@@ -372,6 +384,66 @@ class HipContext:
         self._lib.pngloss_hip_png_decode_batch_host.restype = C.c_int
         _check(self._lib.pngloss_hip_png_decode_batch_host(self._ctx, src, len(parsed)), "png_decode")
         return outs
+
+    def png_decode_device(self, files, stream=0, pinned=True):
+        """pngloss_hip_png_decode_batch_device: the decoded RGBA8 frames STAY on the device.  Returns a list of (device pointer, width, height)
+        ready for enqueue()/run() on this context, and the status list.  pinned: the inflated scanlines go up from page-locked memory
+        (pngloss_hip_pinned_alloc), as the command line tool does."""
+        parsed = [parse_png(f) for f in files]
+        n = len(parsed)
+        src = (PngSource * max(1, n))()
+        self._lib.pngloss_hip_pinned_alloc.argtypes = [C.c_size_t]
+        self._lib.pngloss_hip_pinned_alloc.restype = C.c_void_p
+        self._lib.pngloss_hip_pinned_free.argtypes = [C.c_void_p]
+        self._lib.pngloss_hip_pinned_free.restype = None
+        staged = []
+        for i, p in enumerate(parsed):
+            if p["interlace"]:
+                raise ValueError("interlaced PNG files are read with libpng, not on the device")
+            sl = p["scanlines"]
+            if pinned and len(sl):
+                buf = self._lib.pngloss_hip_pinned_alloc(len(sl))
+                if not buf:
+                    raise RuntimeError("pngloss_hip_pinned_alloc failed")
+                C.memmove(buf, sl, len(sl))
+                staged.append(buf)
+                sl = C.cast(buf, C.c_char_p)
+            src[i] = PngSource(sl, p["width"], p["height"], p["ctype"], p["depth"], p["plte"], len(p["plte"]) // 3 if p["plte"] else 0,
+                               p["trns"], len(p["trns"]) if p["trns"] else 0, None)
+        ptrs = (C.c_void_p * max(1, n))()
+        st = (C.c_int * max(1, n))()
+        self._lib.pngloss_hip_png_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(PngSource), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+        self._lib.pngloss_hip_png_decode_batch_device.restype = C.c_int
+        try:
+            rc = self._lib.pngloss_hip_png_decode_batch_device(self._ctx, src, n, ptrs, st, stream or None)
+        finally:
+            for b in staged:
+                self._lib.pngloss_hip_pinned_free(b)
+        if rc not in (0, 25):
+            _check(rc, "png_decode_device")
+        return [(ptrs[i], parsed[i]["width"], parsed[i]["height"]) for i in range(n)], list(st)[:n]
+
+    def png_decode_device_z(self, files, stream=0, zstreams=None):
+        """pngloss_hip_png_decode_batch_device_z: the compressed image data goes up, inflate + inverse filters + expansion run on the device, the
+        RGBA8 frames stay there.  Returns ([(device pointer, width, height)], status list, return code).  zstreams: replaces the files' own
+        streams (tests hand damaged ones in)."""
+        parsed = [parse_png(f) for f in files]
+        n = len(parsed)
+        src = (PngZSource * max(1, n))()
+        keep = []
+        for i, p in enumerate(parsed):
+            z = zstreams[i] if zstreams is not None else p["zstream"]
+            keep.append(z)
+            src[i] = PngZSource(z, len(z), p["width"], p["height"], p["ctype"], p["depth"], p["plte"], len(p["plte"]) // 3 if p["plte"] else 0,
+                                p["trns"], len(p["trns"]) if p["trns"] else 0)
+        ptrs = (C.c_void_p * max(1, n))()
+        st = (C.c_int * max(1, n))()
+        self._lib.pngloss_hip_png_decode_batch_device_z.argtypes = [C.c_void_p, C.POINTER(PngZSource), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+        self._lib.pngloss_hip_png_decode_batch_device_z.restype = C.c_int
+        rc = self._lib.pngloss_hip_png_decode_batch_device_z(self._ctx, src, n, ptrs, st, stream or None)
+        if rc not in (0, 25):
+            _check(rc, "png_decode_device_z")
+        return [(ptrs[i], parsed[i]["width"], parsed[i]["height"]) for i in range(n)], list(st)[:n], rc
 
     def png_decode_status(self, files):
         """pngloss_hip_png_decode_batch_host_status: like png_decode, but a damaged file only fails itself.  Returns (outs, status list, return code)."""

@@ -1,0 +1,19 @@
+/*
+ * inflate_host.cpp -- TEST INFRASTRUCTURE: the device inflater's body (pngloss_amd/csrc/pl_inflate_core.h, the same source hipcc compiles
+ * into pl_inflate.hip's kernel) run on the CPU with lane loops, so that the CPU suite can check it against zlib without a GPU.
+ * Never shipped, never loaded by the product.
+ *   inflate_host(z, zbytes, out, expect) -> 0 or a PLI_E_* code
+ */
+#include "../../pngloss_amd/csrc/pl_inflate_core.h"
+#include <vector>
+#include <cstring>
+
+extern "C" int inflate_host(const unsigned char *z, unsigned zbytes, unsigned char *out, unsigned expect)
+{
+    static PliShared S;
+    std::memset(&S, 0x5A, sizeof S);          /* nothing may rely on zeroed shared memory */
+    int32_t status = -1;
+    PliStream st{ z, zbytes, out, expect, &status };
+    pli_inflate(st, S);
+    return status;
+}

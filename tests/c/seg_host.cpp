@@ -109,7 +109,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
     j.ctl[2].magic = 0u; j.acc[2].failmask = 0u;   /* (seg_k_resolve does this on the device: the first attempt finds no attempt behind it) */
     int attempt = 0;
-    const long max_attempts = (long)H * 64 + 1024;
+    const long max_attempts = (long)H * ((long)strength + 1) * (2 + 2 * SEG_MAX_RESTARTS * SEG_NFILT) + 1024;   /* (the product's bound: pl_host.hip) */
     /* One attempt = four launches: [control of this attempt + validation of the attempt before], enumerate, chain, replay.  The two halves of
      * the first launch run side by side on the device; here one after the other, in either order (SEG_HOST_VAL_FIRST): neither may depend on it. */
     const bool val_first = getenv("SEG_HOST_VAL_FIRST") != nullptr;

@@ -727,3 +727,15 @@ def test_emitted_png_scanlines(torch_cuda):
             assert np.array_equal(ids, want_ids), (a.shape, want_filters)
             assert np.array_equal(rows, want_rows), (a.shape, want_filters)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,s,b,filters", [("r4_many_attempts_s200_b32767_null", 200, 32767, False), ("r4_many_attempts_s255_b3_ids", 255, 3, True)])
+def test_segment_engine_tiny_images_that_need_very_many_attempts(monkeypatch, key, s, b, filters):
+    """the two cases of tests/test_seg_host.py::test_seg_engine_tiny_images_that_need_very_many_attempts through the C ABI on the device
+    (the launch thread's bound on the attempts now counts the strength retries)"""
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    img = U.load_npz("fuzz_regressions.npz")[key]
+    out, f = P.optimize_with_rows(img, s, b, want_filters=filters)
+    want, wf = U.run_port(img, s, b, filters)
+    assert np.array_equal(out, want) and (not filters or np.array_equal(f, wf))

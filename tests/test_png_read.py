@@ -128,3 +128,93 @@ def test_device_reader_many_bands_and_blocks(w, h, ctype, depth):
     assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 0
     assert np.array_equal(got, want), np.argwhere((got != want).any(axis=2))[:3].tolist()
     ctx.close()
+
+
+def _device_bytes(ptr, nbytes):
+    """nbytes from a raw device pointer (hipMemcpy of the HIP runtime this process has already loaded)."""
+    import ctypes as C
+    path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]
+    hip = C.CDLL(path)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    out = np.zeros(nbytes, np.uint8)
+    assert hip.hipMemcpy(out.ctypes.data, ptr, nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    return out
+
+
+@pytest.mark.gpu
+def test_device_frames_go_from_the_reader_to_the_optimiser_without_leaving_the_device():
+    """SURVEY 8 f.2, "fuse with K0": pngloss_hip_png_decode_batch_device leaves the decoded RGBA8 of the whole fixture set (67 generated files of
+    every colour type / bit depth + the reference's eleven suite files) in the context's frame arena; the frames (i) equal the REAL reference
+    reader's output and (ii) are handed, as device pointers, straight to the batched optimiser of the same context, whose result equals the
+    oracle's on the reference reader's pixels.  The inflated scanlines go up from page-locked memory (pngloss_hip_pinned_alloc)."""
+    import torch
+    fx = U.png_read_fixtures()
+    ctx = P.HipContext()
+    frames, st = ctx.png_decode_device([png for _, png, _ in fx])
+    assert len(frames) == 78 and not any(st)
+    for (name, _, want), (ptr, w, h) in zip(fx, frames):
+        assert (h, w) == want.shape[:2] and ptr % 256 == 0, name
+        assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), want), name
+    # the suite files (and a few generated ones): optimise the frames where they are
+    pick = [i for i, f in enumerate(fx) if f[0].startswith("suite_")] + list(range(0, 67, 11))
+    filt = [torch.zeros(fx[i][2].shape[0], dtype=torch.uint8, device="cuda") for i in pick]
+    res = ctx.run([(frames[i][0], f.data_ptr(), frames[i][1], frames[i][2]) for i, f in zip(pick, filt)], 19, 2)
+    torch.cuda.synchronize()
+    for i, f, r in zip(pick, filt, res):
+        want, wf = U.run_port(fx[i][2], 19, 2)
+        ptr, w, h = frames[i]
+        assert r["status"] == 0, fx[i][0]
+        assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), want), fx[i][0]
+        assert np.array_equal(f.cpu().numpy(), wf), fx[i][0]
+    # pageable scanlines work too (the runtime stages them); a second decode reuses the arena
+    frames2, st2 = ctx.png_decode_device([fx[3][1], fx[70][1]], pinned=False)
+    assert not any(st2)
+    for (ptr, w, h), k in zip(frames2, (3, 70)):
+        assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), fx[k][2])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_inflate_from_file_bytes_to_the_reference_readers_pixels():
+    """SURVEY 8 f.2 in full: from the FILE'S COMPRESSED BYTES to RGBA8 on the device -- inflate (one wave per file, pl_inflate_core.h), inverse
+    filters and expansion -- for the 67 generated files and the reference's eleven suite files in one batch; the frames equal the REAL
+    reference reader's output and feed the optimiser where they are.  A damaged stream fails alone (status 25: that file goes to the host)."""
+    import torch
+    import zlib
+    fx = U.png_read_fixtures()
+    ctx = P.HipContext()
+    frames, st, rc = ctx.png_decode_device_z([png for _, png, _ in fx])
+    assert rc == 0 and not any(st) and len(frames) == 78
+    for (name, _, want), (ptr, w, h) in zip(fx, frames):
+        assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), want), name
+    pick = [i for i, f in enumerate(fx) if f[0] in ("suite_rose", "suite_david", "suite_tux")]
+    filt = [torch.zeros(fx[i][2].shape[0], dtype=torch.uint8, device="cuda") for i in pick]
+    res = ctx.run([(frames[i][0], f.data_ptr(), frames[i][1], frames[i][2]) for i, f in zip(pick, filt)], 19, 2)
+    torch.cuda.synchronize()
+    for i, f, r in zip(pick, filt, res):
+        want, wf = U.run_port(fx[i][2], 19, 2)
+        ptr, w, h = frames[i]
+        assert r["status"] == 0 and np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), want) and np.array_equal(f.cpu().numpy(), wf), fx[i][0]
+    # other encoders' streams of the same scanlines: stored blocks, fixed codes, Huffman only, small windows, many blocks
+    sub = [fx[k] for k in (2, 40, 70, 75)]
+    for kw in (dict(level=0), dict(level=9, strategy=zlib.Z_FIXED), dict(level=9, strategy=zlib.Z_HUFFMAN_ONLY), dict(level=1), dict(level=9, wbits=9)):
+        zs = []
+        for _, png, _ in sub:
+            co = zlib.compressobj(**kw)
+            zs.append(co.compress(L.parse_png(png)["scanlines"]) + co.flush())
+        fr, st, rc = ctx.png_decode_device_z([png for _, png, _ in sub], zstreams=zs)
+        assert rc == 0 and not any(st), kw
+        for (name, _, want), (ptr, w, h) in zip(sub, fr):
+            assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), want), (name, kw)
+    # one damaged stream among good ones
+    good = [f[1] for f in fx[:6]]
+    zs = [L.parse_png(g)["zstream"] for g in good]
+    zs[2] = zs[2][:len(zs[2]) // 2] + bytes(len(zs[2]) - len(zs[2]) // 2)          # second half zeroed
+    zs[4] = zs[4][:-1] + bytes([zs[4][-1] ^ 0x55])                                    # wrong Adler-32
+    fr, st, rc = ctx.png_decode_device_z(good, zstreams=zs)
+    assert rc == 25 and st[2] == 25 and st[4] == 25 and not any(st[k] for k in (0, 1, 3, 5))
+    for k in (0, 1, 3, 5):
+        ptr, w, h = fr[k]
+        assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), fx[k][2])
+    ctx.close()

@@ -176,3 +176,15 @@ def test_seg_engine_validation_and_control_in_either_order(monkeypatch, w, h, mo
     want, wf = U.run_port(img, s, b)
     assert rc == 0 and rc0 == 0 and np.array_equal(out, want) and np.array_equal(f, wf) and np.array_equal(out0, want)
     assert list(st) == list(st0)
+
+
+@pytest.mark.parametrize("key,s,b,filters", [("r4_many_attempts_s200_b32767_null", 200, 32767, False), ("r4_many_attempts_s255_b3_ids", 255, 3, True)])
+def test_seg_engine_tiny_images_that_need_very_many_attempts(key, s, b, filters):
+    """Two cases of the round-4 parity campaign on the GPU box (tests/tools/gpu_fuzz.py, seed 42): 63 x 2 and 17 x 2 pixels at strengths 200 / 255,
+    where nearly every row attempt fails validation (a histogram of a few counts: every bump flips a tie), every strength down to the one that
+    passes libpng's heuristic is tried, and an epoch costs two attempts -- 1813 and 1267 attempts.  The launcher's bound on the attempts (a
+    runaway stop, not a budget) had not counted the strength retries: the library gave up with PNGLOSS_HIP_ERROR.  Inputs: tests/golden/fuzz_regressions.npz."""
+    img = U.load_npz("fuzz_regressions.npz")[key]
+    rc, out, f, st = U.run_seg_host(img, s, b, filters)
+    want, wf = U.run_port(img, s, b, filters)
+    assert rc == 0 and np.array_equal(out, want) and (not filters or np.array_equal(f, wf)), st

@@ -72,7 +72,14 @@ while time.time() - t0 < budget:
     else:
         img, s, b, filt = make(rng)
         o1, f1 = U.run_port(img, s, b, filt)
-        o2, f2 = P.optimize_with_rows(img, s, b, want_filters=filt)
+        try:
+            o2, f2 = P.optimize_with_rows(img, s, b, want_filters=filt)
+        except RuntimeError as exc:       # the library refused or failed: say which case, keep it, go on
+            bad += 1
+            np.save(f"gpurun_out/fuzz_error_{n}.npy", img)
+            print("ERROR", n, img.shape, s, b, filt, "engine", repr(eng), exc, flush=True)
+            n += 1
+            continue
         if not (np.array_equal(o1, o2) and (not filt or np.array_equal(f1, f2))):
             bad += 1
             np.save(f"gpurun_out/fuzz_fail_{n}.npy", img)

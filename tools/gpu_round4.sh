@@ -30,7 +30,8 @@ if has trace; then
 fi
 if has pmc; then
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_prof_$C -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 $BENCHARGS > $OUT/${TAG}_prof_$C.log 2>&1
+    # (counter collection serialises the dispatches of all queues: the caller's stream must not hold a wait for the engine's "finished" word in front of them -- the blocking variant of the entry)
+    PNGLOSS_HIP_NO_STREAM_WAIT=1 rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_prof_$C -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 $BENCHARGS > $OUT/${TAG}_prof_$C.log 2>&1
   done
   python - "$OUT" "$TAG" > $OUT/${TAG}_pmc_fetch_write.txt <<'PY'
 import csv, glob, collections, json, sys
@@ -43,14 +44,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if n.startswith("void "): n = n[5:]
             agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == c: calls[(n, c)] += 1
-print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch --no-sweep")
+print("# PNGLOSS_HIP_NO_STREAM_WAIT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch --no-sweep")
 print("# summed over the dispatches of each kernel during ONE engine run of the 4096x4096 frame (s=19 b=2); raw counter units (KB; FETCH_SIZE counts 64 B per 128 B request on gfx950)")
 print("%-28s %10s %16s %16s" % ("kernel", "dispatches", "FETCH_SIZE", "WRITE_SIZE"))
 for n in sorted(agg, key=lambda k: -agg[k]["FETCH_SIZE"]):
     print("%-28s %10d %16.1f %16.1f" % (n[:28], calls[(n, "FETCH_SIZE")], agg[n]["FETCH_SIZE"], agg[n]["WRITE_SIZE"]))
 seg = [n for n in agg if n.startswith("seg_k_")]
 ef = sum(agg[n]["FETCH_SIZE"] for n in seg); ew = sum(agg[n]["WRITE_SIZE"] for n in seg)
-res = {"round": tag, "kernel": "segment-parallel row engine (seg_k_ctl + seg_k_enum + seg_k_chain + seg_k_replay + seg_k_post, all dispatches of one engine run)",
+res = {"round": tag, "kernel": "segment-parallel row engine (seg_k_ctl [control + validation] + seg_k_enum + seg_k_chain + seg_k_replay, all dispatches of one engine run)",
        "workload": "4096x4096 RGBA8 s=19 b=2", "FETCH_SIZE_KB_raw": ef, "WRITE_SIZE_KB_raw": ew, "fetch_correction": 2.0, "write_correction": 1.0,
        "traffic_bytes": int((ef * 2.0 + ew) * 1024), "algorithmic_bytes": 8 * 4096 * 4096,
        "note": "FETCH_SIZE x2 (gfx950: 64 B per 128 B request, MI355X_MICROARCH.md; the same factor the 64 MiB copy calibrated in rounds 1-2). The engine keeps its working set (state maps, decision tables, candidate rows: a few MB per row attempt) in L2/MALL and re-reads it every row attempt: traffic is what reaches the memory side of L2, not the algorithmic 8 B/px"}
@@ -80,7 +81,7 @@ cols = ["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIV
 print("# rocprofv3 --kernel-trace --pmc <counters> -- python tests/tools/gpu_seg_time.py 4096 512 0 19 2 1   (%s; separate passes per counter group;" % box)
 print("# averages per dispatch of each kernel of the segment engine AS IT SHIPS (seg_k_enum<512> for this width), summed over the device as rocprofv3 reports them; no profiling switch of the library set)")
 print("%-12s" % "kernel" + "".join("%22s" % c for c in cols) + "%12s" % "LdsLatency")
-for k in ("ctl", "enum<512>", "enum<1024>", "chain", "replay", "post"):
+for k in ("ctl", "enum<512>", "enum<1024>", "chain", "replay"):
     if k not in agg: continue
     v = {c: agg[k][c] / max(1, len(disp[(k, c)])) for c in cols}
     lat = v["SQ_INST_LEVEL_LDS"] / v["SQ_INSTS_LDS"] if v["SQ_INSTS_LDS"] else 0
