@@ -92,12 +92,13 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
     }
 }
 
+template <bool SEEDED>
 __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     if (blockIdx.x == SEG_NFILT * 4) { seg_extremes_body(j, *P, par, seg_smem); return; }      /* (the spare workgroup: the row's extremes for none's bound) */
-    seg_chain_body(j, *P, par, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), seg_smem);
+    seg_chain_body<SEEDED>(j, *P, par, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), seg_smem);
 }
 
 __global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
@@ -115,7 +116,9 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 hipError_t chain_attr()
 {
     static std::atomic<unsigned> done_chain{ 0 }, done_ctl{ 0 };
-    hipError_t e = pl_lds_optin((const void *)seg_k_chain, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
+    static std::atomic<unsigned> done_chain_s{ 0 };
+    hipError_t e = pl_lds_optin((const void *)seg_k_chain<false>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
+    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
     if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl, SEG_SM_CTLVAL, done_ctl);
     return e;
 }
@@ -196,7 +199,8 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
         else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
     }
-    hipLaunchKernelGGL(seg_k_chain, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    if (b.seeded) hipLaunchKernelGGL(seg_k_chain<true>, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    else hipLaunchKernelGGL(seg_k_chain<false>, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();
 }

@@ -1302,6 +1302,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 #define SEG_CHAIN_GWORDS ((SEG_CHAIN_CAP / SEG_CBLK + 2) * 256 / 2)
 #define SEG_SM_CHAIN(nseg) ((1024 + 32 + 2 * SEG_CHAIN_POS + SEG_CHAIN_GWORDS) * 4 + SEG_CHAIN_TBYTES(nseg) + SEG_TBL_WORDS * 4 + (SEG_L + 1) * 8 + 64)
 PLS_HD uint32_t seg_chain_cap(uint32_t sh) { return sh >= 8 ? (uint32_t)SEG_CHAIN_CAP8 : (uint32_t)SEG_CHAIN_CAP; }
+template <bool SEEDED>
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
 {
     const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
@@ -1315,7 +1316,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, 
     if (first + 1 >= nseg) return;
     /* enumerated segments s0 .. nseg-1 (ne of them; a fresh row: from 0) = POSITIONS 0 .. ns of the chain; ns = ne - 1 transitions */
     const uint32_t s0 = sx ? first + 1 : 0u, ne = nseg - s0, ns = ne - 1;
-    const bool seeded = P.seeded != 0;
+    constexpr bool seeded = SEEDED;                             /* (= P.seeded: two kernels, so that the exhaustive sets' gather does not carry the seeded one's registers) */
     seg_lds_u32 Hf = (seg_lds_u32)smem, rank = Hf + 256, lut = Hf + 512;   /* (repair only) */
     seg_lds_u32 idxb = Hf + 1024;                               /* [32]: [24] repairs, [25] first position without an id, [26] entry state of the pass's first position, [27] most distinct states of a segment,
                                                                    [28] dense id the pass starts with, [30] some segment has more distinct states than the stride, [31] repair tables loaded */

@@ -148,7 +148,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, par, f, esm.data()); else seg_first_body<1024>(j, P, par, f, esm.data()); }
         {   /* the chain kernel's LDS is sized by the row's segments: the same size here (the sanitizer build sees an overrun) */
             std::vector<unsigned char> csm((size_t)SEG_SM_CHAIN(j.nseg), 0x5A);
-            for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) seg_chain_body(j, P, par, f, c, csm.data());
+            for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) { if (P.seeded) seg_chain_body<true>(j, P, par, f, c, csm.data()); else seg_chain_body<false>(j, P, par, f, c, csm.data()); }
             seg_extremes_body(j, P, par, csm.data());
         }
         { std::vector<unsigned char> rsm((size_t)SEG_SM_REPLAY, 0x5A); for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, rsm.data()); }
