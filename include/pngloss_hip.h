@@ -260,8 +260,8 @@ int pngloss_hip_png_decode_batch_device(pngloss_hip_ctx *ctx, const pngloss_hip_
  * filters + transformations); what goes up is the file's compressed bytes, what comes out stays on the device.
  *   zstream   the concatenated payloads of the file's IDAT chunks (one zlib stream), zbytes of them
  * A stream the device inflater does not take (damaged, preset dictionary, size mismatch ...) gets status 25 and the call returns 25: read that
- * file on the host.  One wave decodes ~10 MB/s: this pays for windows of many files, not for one large image (use the scanline form, with zlib
- * on host threads, for those). */
+ * file on the host.  One wave decodes ~3 MB/s (profiles/r04_read_side.txt; zlib: ~250 MB/s per host thread): this pays only when a call brings well over
+ * a thousand files; otherwise use the scanline form above, with zlib on host threads. */
 typedef struct {
     const unsigned char *zstream;
     size_t zbytes;

@@ -50,13 +50,14 @@ __device__ __forceinline__ uint64_t pli_wave_sum(uint64_t v) { for (int o = 32; 
 #define PLI_PIECE 4096u           /* what leaves the window at a time */
 #define PLI_IN 16384u             /* staged input */
 #define PLI_LBITS 10
+#define PLI_WAVE_COPY 32u         /* matches from this length on are copied by the whole wave */
 #define PLI_DBITS 9
 enum { PLI_OK = 0, PLI_E_HEADER = 1, PLI_E_BLOCK = 2, PLI_E_CODES = 3, PLI_E_SYMBOL = 4, PLI_E_DIST = 5, PLI_E_SIZE = 6, PLI_E_ADLER = 7, PLI_E_INPUT = 8 };
 
 /* shared memory of one stream */
 struct PliShared {
     uint8_t win[PLI_WIN];
-    uint8_t in[PLI_IN + 16];
+    union { uint8_t in[PLI_IN + 16]; uint32_t in32[PLI_IN / 4 + 4]; };
     uint32_t ltab[1u << PLI_LBITS];   /* symbol | length << 16; 0: a longer code */
     uint32_t dtab[1u << PLI_DBITS];
     uint16_t lcount[16], dcount[16];  /* codes per length */
@@ -64,6 +65,8 @@ struct PliShared {
     uint16_t loffs[16], doffs[16];    /* index of a length's first symbol in lsym / dsym */
     uint16_t lsym[288], dsym[32];     /* symbols in canonical order */
     uint8_t lens[320];                /* code lengths of the block: literal/length codes, then distance codes */
+    uint16_t lbase[32], dbase[32];    /* RFC 1951 3.2.5: base of a length / distance code and its extra bits (from constant memory once: a lookup there */
+    uint8_t lext[32], dext[32];       /*  costs a round trip to device memory per use) */
     uint32_t tok[8];                  /* lane 0 -> wave: [0] kind, [1] length, [2] distance, [3] error, [4] hlit, [5] hdist */
     uint64_t red[2];
 };
@@ -82,7 +85,9 @@ PLI_HD uint32_t pli_rev(uint32_t code, int len) { uint32_t r = 0; for (int i = 0
 
 /* the decoder's bit reader (lane 0): bytes come from the staged input, `ip` = next byte of the stage, `iend` = bytes in it */
 struct PliBits { uint64_t buf; int n; uint32_t ip, iend; };
-PLI_HD void pli_refill(PliBits &b, const uint8_t *in) { while (b.n <= 56 && b.ip < b.iend) { b.buf |= (uint64_t)in[b.ip++] << b.n; b.n += 8; } }
+/* at most 32 bits short: four bytes at once -- two aligned words of the stage (one round trip to shared memory), shifted to the byte position;
+ * byte by byte only at the stage's end.  (A symbol with its extra bits takes at most 28 bits: one refill in front of each is enough.)
+ * (S, not a pointer into it: through a plain pointer the accesses become FLAT ones, several times slower than ds_read) */
 PLI_HD uint32_t pli_peek(const PliBits &b, int k) { return (uint32_t)(b.buf & ((1ull << k) - 1ull)); }
 PLI_HD void pli_drop(PliBits &b, int k) { b.buf >>= k; b.n -= k; }
 
@@ -125,18 +130,31 @@ PLI_HD bool pli_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *fir
     return true;
 }
 
-/* one symbol: direct table, else canonically bit by bit (lane 0).  -1: no such code / out of input */
-PLI_HD int pli_symbol(PliBits &b, const uint8_t *in, const uint32_t *tab, int tbits, const uint16_t *count, const uint16_t *first, const uint16_t *offs, const uint16_t *sym)
+PLI_HD void pli_refill(PliBits &b, const PliShared &S)
 {
-    pli_refill(b, in);
-    const uint32_t e = tab[pli_peek(b, tbits)];
+    if (b.n <= 32 && b.ip + 4u <= b.iend) {
+        const uint32_t i = b.ip >> 2;
+        const uint64_t two = (uint64_t)S.in32[i] | ((uint64_t)S.in32[i + 1] << 32);      /* (the stage has 16 bytes of slack behind it) */
+        b.buf |= ((two >> (8u * (b.ip & 3u))) & 0xffffffffull) << b.n;
+        b.ip += 4u; b.n += 32;
+    }
+    while (b.n <= 56 && b.ip < b.iend && b.iend - b.ip < 4u) { b.buf |= (uint64_t)S.in[b.ip++] << b.n; b.n += 8; }
+}
+
+/* one symbol: direct table, else canonically bit by bit (lane 0).  DIST: the distance alphabet.  -1: no such code / out of input */
+template <bool DIST>
+PLI_HD int pli_symbol(PliBits &b, const PliShared &S)
+{
+    pli_refill(b, S);
+    const uint32_t e = DIST ? S.dtab[pli_peek(b, PLI_DBITS)] : S.ltab[pli_peek(b, PLI_LBITS)];
     if (e) { const int l = (int)(e >> 16); if (l > b.n) return -1; pli_drop(b, l); return (int)(e & 0xffffu); }
     uint32_t code = 0;
     for (int l = 1; l < 16; l++) {
         if (b.n < l) return -1;
         code = (code << 1) | (uint32_t)((b.buf >> (l - 1)) & 1u);
-        const uint32_t d = code - (uint32_t)first[l];
-        if (code >= (uint32_t)first[l] && d < (uint32_t)count[l]) { pli_drop(b, l); return (int)sym[offs[l] + d]; }
+        const uint32_t first = DIST ? S.dfirst[l] : S.lfirst[l], count = DIST ? S.dcount[l] : S.lcount[l];
+        const uint32_t d = code - first;
+        if (code >= first && d < count) { pli_drop(b, l); return (int)(DIST ? S.dsym[S.doffs[l] + d] : S.lsym[S.loffs[l] + d]); }
     }
     return -1;
 }
@@ -207,11 +225,12 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
         PLI_SYNC();
     };
 
+    PLI_LANES(lane) { if (lane < 29) { S.lbase[lane] = lbase[lane]; S.lext[lane] = lext[lane]; } if (lane < 30) { S.dbase[lane] = dbase[lane]; S.dext[lane] = dext[lane]; } }
     PLI_LANE0(lane) { S.tok[6] = 0; S.tok[7] = 0; S.tok[3] = 0; }
     stage();
     /* zlib header (RFC 1950): deflate, window <= 32K, no preset dictionary, check bits */
     PLI_LANE0(lane) {
-        pli_refill(B, S.in);
+        pli_refill(B, S);
         if (B.n < 16) S.tok[3] = PLI_E_HEADER;
         else {
             const uint32_t cmf = pli_peek(B, 8), flg = (uint32_t)((B.buf >> 8) & 255u);
@@ -225,7 +244,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
         /* ---- block header (lane 0); a dynamic block's code lengths too ---- */
         PLI_LANE0(lane) {
             S.tok[0] = 0; S.tok[3] = 0;
-            pli_refill(B, S.in);
+            pli_refill(B, S);
             if (B.n < 3) {
                 if (zpos < zbytes) { S.tok[0] = PLI_T_INPUT; }
                 else S.tok[3] = PLI_E_INPUT;
@@ -239,7 +258,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                     if (btype == 3u) S.tok[3] = PLI_E_BLOCK;
                     else if (btype == 0u) {
                         pli_drop(B, B.n & 7);                       /* to the byte boundary */
-                        pli_refill(B, S.in);
+                        pli_refill(B, S);
                         if (B.n < 32) S.tok[3] = PLI_E_INPUT;
                         else {
                             const uint32_t len = pli_peek(B, 16), nlen = (uint32_t)((B.buf >> 16) & 0xffffu);
@@ -257,7 +276,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                         for (int i = 0; i < 32; i++) S.lens[288 + i] = 5;         /* (30 and 31 never occur in a valid stream: checked at the symbol) */
                         S.tok[4] = 288; S.tok[5] = 32;
                     } else {
-                        pli_refill(B, S.in);
+                        pli_refill(B, S);
                         const uint32_t hlit = pli_peek(B, 5) + 257u, hdist = (uint32_t)((B.buf >> 5) & 31u) + 1u, hclen = (uint32_t)((B.buf >> 10) & 15u) + 4u;
                         pli_drop(B, 14);
                         if (hlit > 286u || hdist > 30u) S.tok[3] = PLI_E_CODES;
@@ -265,7 +284,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                             /* the code-length code: 19 symbols of 3 bits, a 7-bit table in the distance table's place */
                             uint8_t cl[19];
                             for (int i = 0; i < 19; i++) cl[i] = 0;
-                            for (uint32_t i = 0; i < hclen; i++) { pli_refill(B, S.in); cl[clorder[i]] = (uint8_t)pli_peek(B, 3); pli_drop(B, 3); }
+                            for (uint32_t i = 0; i < hclen; i++) { pli_refill(B, S); cl[clorder[i]] = (uint8_t)pli_peek(B, 3); pli_drop(B, 3); }
                             int left = 1, tot = 0; uint16_t cnt[8], fst[8];
                             for (int l = 0; l < 8; l++) cnt[l] = 0;
                             for (int i = 0; i < 19; i++) cnt[cl[i]]++;
@@ -287,7 +306,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                                 uint32_t i = 0; const uint32_t nn = hlit + hdist;
                                 int prevl = 0;
                                 while (i < nn && !S.tok[3]) {
-                                    pli_refill(B, S.in);
+                                    pli_refill(B, S);
                                     const uint32_t e = S.dtab[pli_peek(B, 7)];
                                     if (!e || (int)(e >> 16) > B.n) { S.tok[3] = PLI_E_CODES; break; }
                                     pli_drop(B, (int)(e >> 16));
@@ -333,7 +352,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
             PLI_SYNC();
             const uint32_t frac = S.tok[5];
             stage();
-            PLI_LANE0(lane) { B.buf = 0; B.n = 0; if (frac) { pli_refill(B, S.in); pli_drop(B, 8 - (int)frac); } }
+            PLI_LANE0(lane) { B.buf = 0; B.n = 0; if (frac) { pli_refill(B, S); pli_drop(B, 8 - (int)frac); } }
             continue;
         }
         final_block = S.tok[1] != 0;
@@ -375,7 +394,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                     for (;;) {
                         /* (input: a symbol with its extra bits is at most 48 bits; refills stop at the stage's end) */
                         if (B.iend - B.ip < 8u && zpos < zbytes) { S.tok[0] = PLI_T_INPUT; break; }
-                        const int s = pli_symbol(B, S.in, S.ltab, PLI_LBITS, S.lcount, S.lfirst, S.loffs, S.lsym);
+                        const int s = pli_symbol<false>(B, S);
                         if (s < 0) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_SYMBOL; break; }
                         if (s < 256) {
                             if (pos >= expect) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_SIZE; break; }
@@ -386,17 +405,28 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                         }
                         if (s == 256) { S.tok[0] = PLI_T_END; break; }
                         if (s > 285) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_SYMBOL; break; }
-                        pli_refill(B, S.in);
-                        const uint32_t len = lbase[s - 257] + pli_peek(B, lext[s - 257]);
-                        pli_drop(B, lext[s - 257]);
-                        const int d = pli_symbol(B, S.in, S.dtab, PLI_DBITS, S.dcount, S.dfirst, S.doffs, S.dsym);
+                        pli_refill(B, S);
+                        const uint32_t lx = S.lext[s - 257];
+                        const uint32_t len = S.lbase[s - 257] + pli_peek(B, (int)lx);
+                        pli_drop(B, (int)lx);
+                        const int d = pli_symbol<true>(B, S);
                         if (d < 0 || d > 29) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_SYMBOL; break; }
-                        pli_refill(B, S.in);
-                        const uint32_t dist = dbase[d] + pli_peek(B, dext[d]);
-                        pli_drop(B, dext[d]);
+                        pli_refill(B, S);
+                        const uint32_t dx = S.dext[d];
+                        const uint32_t dist = S.dbase[d] + pli_peek(B, (int)dx);
+                        pli_drop(B, (int)dx);
                         if (B.n < 0) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_INPUT; break; }
                         if (dist > pos) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_DIST; break; }
                         if (pos + len > expect) { S.tok[0] = PLI_T_ERROR; S.tok[3] = PLI_E_SIZE; break; }
+                        if (len < PLI_WAVE_COPY) {
+                            /* a short match (most are): by lane 0 itself, byte after byte (an overlap copies what it has just written) -- handing it to
+                             * the wave costs two barriers and a round of tokens, ~1500 cycles against ~70 a byte here */
+                            for (uint32_t k = 0; k < len; k++) S.win[(pos + k) & (PLI_WIN - 1)] = S.win[(pos - dist + k) & (PLI_WIN - 1)];
+                            const uint32_t before = pos / PLI_PIECE;
+                            pos += len;
+                            if (pos / PLI_PIECE != before) { S.tok[0] = PLI_T_FLUSH; break; }
+                            continue;
+                        }
                         S.tok[0] = PLI_T_MATCH; S.tok[1] = len; S.tok[2] = dist;
                         break;
                     }
@@ -419,7 +449,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                     PLI_SYNC();
                     const uint32_t frac = S.tok[5];
                     stage();
-                    PLI_LANE0(lane) { B.buf = 0; B.n = 0; if (frac) { pli_refill(B, S.in); pli_drop(B, 8 - (int)frac); } }
+                    PLI_LANE0(lane) { B.buf = 0; B.n = 0; if (frac) { pli_refill(B, S); pli_drop(B, 8 - (int)frac); } }
                     continue;
                 }
                 /* a match: a byte a lane; source pos - dist + (k mod dist) lies behind pos whatever the overlap */
@@ -448,7 +478,7 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                 pli_drop(B, B.n & 7);
                 uint32_t want = 0; bool have = true;
                 for (int i = 0; i < 4; i++) {
-                    pli_refill(B, S.in);
+                    pli_refill(B, S);
                     if (B.n < 8) { have = false; break; }
                     want = (want << 8) | pli_peek(B, 8); pli_drop(B, 8);
                 }
