@@ -97,8 +97,8 @@ __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *_
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    if (blockIdx.x == SEG_NFILT * 4) { seg_extremes_body(j, *P, par, seg_smem); return; }      /* (the spare workgroup: the row's extremes for none's bound) */
-    seg_chain_body<SEEDED>(j, *P, par, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), seg_smem);
+    if (blockIdx.x == 0) { seg_extremes_body(j, *P, par, seg_smem); return; }      /* (the spare workgroup, dispatched first: the row's extremes for none's bound) */
+    seg_chain_body<SEEDED>(j, *P, par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
 }
 
 __global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)

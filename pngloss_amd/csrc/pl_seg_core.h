@@ -1630,14 +1630,20 @@ PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, int par, unsi
     PLS_SYNC();
     PLS_THREADS(tid, SEG_CHAIN_THREADS) {
         int vmax = -(1 << 30), vmin = 1 << 30;
-        for (uint32_t x = (uint32_t)tid; x < W; x += SEG_CHAIN_THREADS) {
-            const uint32_t o = row[x];
-            const uint32_t e[2] = { e0g[2 * (size_t)x], e0g[2 * (size_t)x + 1] };
-            const bool alpha0 = (bpp & 1u) == 0u && ((o >> (8u * (bpp - 1u))) & 255u) == 0u;
-            for (uint32_t c = 0; c < bpp; c++) {
-                if (alpha0 && c == bpp - 1u) continue;
-                const int v = (int)((o >> (8 * c)) & 255u) + seg_err_plane(e, seg_plane_of_channel(bpp, (int)c));
-                vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+        /* four pixels per thread and turn, every request in front of the first use (pixels beyond the row are clamped onto its last: they change nothing) */
+        for (uint32_t x0 = (uint32_t)tid; x0 < W; x0 += 4u * SEG_CHAIN_THREADS) {
+            uint32_t o[4], ea[4], eb[4];
+            PLS_UNROLL
+            for (int q = 0; q < 4; q++) { const uint32_t x = seg_umin(x0 + (uint32_t)q * SEG_CHAIN_THREADS, W - 1u); o[q] = row[x]; ea[q] = e0g[2 * (size_t)x]; eb[q] = e0g[2 * (size_t)x + 1]; }
+            PLS_UNROLL
+            for (int q = 0; q < 4; q++) {
+                const uint32_t e[2] = { ea[q], eb[q] };
+                const bool alpha0 = (bpp & 1u) == 0u && ((o[q] >> (8u * (bpp - 1u))) & 255u) == 0u;
+                for (uint32_t c = 0; c < bpp; c++) {
+                    if (alpha0 && c == bpp - 1u) continue;
+                    const int v = (int)((o[q] >> (8 * c)) & 255u) + seg_err_plane(e, seg_plane_of_channel(bpp, (int)c));
+                    vmax = seg_max(vmax, v); vmin = seg_min(vmin, v);
+                }
             }
         }
         vmax = pls_wave_max_i(vmax); vmin = pls_wave_min_i(vmin);
@@ -1818,7 +1824,8 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f,
                     }
                 }
             }
-            derr = pls_wave_sum_u64(derr);
+            /* (a pixel's share is at most 4 channels x 3 weights x 3 squares of 510: a wave's sum fits 32 bits -- half the shuffles of a 64-bit one) */
+            derr = (uint64_t)pls_wave_sum_u32((uint32_t)derr);
             if (adaptive) for (int g = 0; g < SEG_NFILT; g++) hs[g] = pls_wave_sum_u32(hs[g]);
             if (PLS_WAVE_LEADER(tid)) {
                 PLS_ATOMIC_ADD64((uint64_t *)&red[0], derr);
