@@ -247,6 +247,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     }
     if (!b.max_ncommit) b.max_ncommit = 1;
     SegJob *d_sj = reinterpret_cast<SegJob *>(ctx->d_ws + jobs_off);
+    for (size_t i = 0; i < n; i++) ctx->h_sj[i].self = d_sj + i;
     SegParams *d_params = reinterpret_cast<SegParams *>(ctx->d_ws + params_off);
     PL_CHECK(hipMemcpyAsync(d_sj, ctx->h_sj.data(), sizeof(SegJob) * n, hipMemcpyHostToDevice, stream));
     PL_CHECK(hipMemcpyAsync(d_params, &ctx->h_seg_params, sizeof(SegParams), hipMemcpyHostToDevice, stream));

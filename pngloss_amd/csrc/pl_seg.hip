@@ -21,6 +21,19 @@
 
 namespace {
 
+/* a workgroup's view of attempt k (SegCtlView) straight from the record in device memory: every address follows from the kernel's arguments, so
+ * these scalar loads travel with the loads of the record itself -- no second round trip before the workgroup knows whether it has work */
+__device__ __forceinline__ SegCtlView seg_view_of(const SegJob *rec, int k, int f)
+{
+    typedef const __attribute__((address_space(4))) SegJob *seg_const_job;
+    seg_const_job c = (seg_const_job)(uintptr_t)rec;
+    SegCtlView v;
+    const uint32_t fin = c->v[k].finished, magic = c->v[k].magic, ign = c->v[k].ignore, fm = c->vfail[seg_k_prev(k)];
+    v.y = c->v[k].y; v.s = c->v[k].s; v.active = c->v[k].active[f]; v.start_x = c->v[k].start_x[f];
+    v.finished = (fin != 0u || magic != SEG_MAGIC || (fm & ~ign) != 0u) ? 1u : 0u;
+    return v;
+}
+
 __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,6 +41,7 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
         sj[i].bpp = pl_job_bpp(jobs[sj[i].job_index]);
         sj[i].ctl[2].magic = 0u;          /* the image's first attempt (copy 0) finds no attempt behind it: no control block, */
         sj[i].acc[2].failmask = 0u;       /* ... no failed validation */
+        for (int k = 0; k < 3; k++) { sj[i].v[k].magic = 0u; sj[i].v[k].finished = 0u; sj[i].v[k].ignore = 0u; sj[i].vfail[k] = 0u; }   /* (the same in the record's own copies) */
     }
 }
 
@@ -46,7 +60,7 @@ __global__ __launch_bounds__(SEG_THREADS, 8) void seg_k_ctl(const SegJob *__rest
     /* validation groups are half replay groups: max_ngrp * (SEG_GRP / SEG_VGRP) workgroups per candidate */
     const unsigned bx = blockIdx.x - nctl, per = max_ngrp * (SEG_GRP / SEG_VGRP), f = bx / per, vg = bx % per;
     if (vg * SEG_VGRP >= j.nseg) return;
-    seg_post_body(j, *P, seg_k_prev(k), (int)f, (int)vg, seg_smem);
+    seg_post_body(j, *P, seg_view_of(sj + blockIdx.y, seg_k_prev(k), (int)f), seg_k_prev(k), (int)f, (int)vg, seg_smem);
 }
 
 /* NT threads per workgroup: 1024 (four channels of a segment) or 512 (a channel pair), see SEG_ENUM_NT_SMALL_MAX_NSEG */
@@ -64,14 +78,14 @@ __global__ __launch_bounds__(NT) void seg_k_enum(const SegJob *__restrict__ sj, 
         const unsigned k = blockIdx.x / (max_nseg * halves), r = blockIdx.x % (max_nseg * halves), seg = r / halves, chalf = r % halves;
         const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
         if (seg >= j.nseg) return;
-        seg_enum_body<NT>(j, *P, par, (int)f, (int)seg, (int)chalf, seg_smem);
+        seg_enum_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)seg, (int)chalf, seg_smem);
     } else if (blockIdx.x < gridDim.x - SEG_NFILT) {
         const unsigned r = blockIdx.x - nbig * max_nseg * halves, per = (max_nseg + small_segs - 1) / small_segs;
         const unsigned f = r / per ? 2u : 0u, seg0 = (r % per) * small_segs;
         if (seg0 >= j.nseg) return;
-        seg_enum_small_body<NT>(j, *P, par, (int)f, (int)seg0, seg_smem);
+        seg_enum_small_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)seg0, seg_smem);
     } else {
-        seg_first_body<NT>(j, *P, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
+        seg_first_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT))), par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
     }
 }
 
@@ -86,9 +100,9 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
     if (blockIdx.x < SEG_NFILT * max_nseg * halves) {
         const unsigned f = blockIdx.x / (max_nseg * halves), r = blockIdx.x % (max_nseg * halves), seg = r / halves, chalf = r % halves;
         if (seg >= j.nseg) return;
-        seg_enum_seeded_body<NT>(j, *P, par, (int)f, (int)seg, (int)chalf, seg_smem);
+        seg_enum_seeded_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)seg, (int)chalf, seg_smem);
     } else {
-        seg_first_body<NT>(j, *P, par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves), seg_smem);
+        seg_first_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves)), par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves), seg_smem);
     }
 }
 
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *_
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    if (blockIdx.x == 0) { seg_extremes_body(j, *P, par, seg_smem); return; }      /* (the spare workgroup, dispatched first: the row's extremes for none's bound) */
-    seg_chain_body<SEEDED>(j, *P, par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
+    if (blockIdx.x == 0) { seg_extremes_body(j, *P, seg_view_of(sj + blockIdx.y, par, 0), par, seg_smem); return; }      /* (the spare workgroup, dispatched first: the row's extremes for none's bound) */
+    seg_chain_body<SEEDED>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)((blockIdx.x - 1) >> 2)), par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
 }
 
 __global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob 
     const SegJob j = sj[blockIdx.y];
     const unsigned f = blockIdx.x / max_ngrp, grp = blockIdx.x % max_ngrp;
     if (grp >= j.ngrp) return;
-    seg_replay_body(j, *P, par, (int)f, (int)grp, seg_smem);
+    seg_replay_body(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
 }
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }

@@ -239,6 +239,13 @@ struct SegAcc {
 static_assert(sizeof(SegCtl) / 4 <= 128 && sizeof(SegAcc) / 4 <= 128, "the control kernel copies both with 128 lanes each");
 static_assert((SEG_NFILT + 1) * 256 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 56 <= 4 * SEG_TN, "they live in the table staging area, below the classes (and the decision behind them)");
 
+/* What the workgroups of an attempt branch on, kept INSIDE the job record (three deep, like the control blocks): the record is the first thing
+ * every workgroup loads, so these fields arrive with it -- one round trip to device memory less at the head of every kernel than reading them
+ * from the control block behind the record's pointer.  Written by the control workgroups (and the fail masks by the validation) next to the
+ * control block's own fields.  The kernels build a workgroup's SegCtlView from the record IN MEMORY (pl_seg.hip:seg_view_of: scalar loads whose
+ * addresses need nothing but the kernel's arguments, in flight together with the record itself) and hand it to the body; the CPU harness calls
+ * seg_ctl_view. */
+struct SegViewRec { uint32_t finished, y, s, ignore, magic, pad_; uint32_t active[SEG_NFILT], start_x[SEG_NFILT]; };
 struct SegJob {
     SEG_AS_GLB uint32_t *img;            /* slots image (pl_device.h) */
     SEG_AS_GLB uint8_t *row_filters;     /* or null */
@@ -275,6 +282,9 @@ struct SegJob {
     SEG_AS_GLB uint32_t *firstidx;       /* [5][4][2]: exit index of the epoch's first (partial) segment | packed state when it has none */
     SEG_AS_GLB int32_t *rowmm;           /* [2][2]: max and min of orig + incoming error over the row (seg_extremes_body, the chain launch's spare workgroup; by row parity: seg_rowmm) */
     uint32_t nseg, ngrp;
+    SEG_AS_GLB SegJob *self;             /* where this record lives (device memory): the writers of the fields below */
+    SegViewRec v[3];                     /* by attempt % 3 */
+    uint32_t vfail[3], vpad_;            /* bit f: candidate f's row of that attempt failed validation (= SegAcc::failmask) */
 };
 
 /* what belongs to row y (see SegJob) */
@@ -293,23 +303,9 @@ PLS_HD int seg_k_prev2(int k) { return k == 2 ? 0 : k + 1; }
 PLS_HD SegCtlView seg_ctl_view(const SegJob &j, int k, int f)
 {
     SegCtlView v;
-    const int kp = seg_k_prev(k);
-#if defined(__HIP_DEVICE_COMPILE__)
-    /* through the constant address space: the blocks were written by EARLIER kernels and are only read here, the addresses are the same
-     * for the whole workgroup -- scalar loads, all in flight at once, one wait (as vector loads the compiler sinks each to its
-     * first use: three round trips before a workgroup requests anything else) */
-    typedef const __attribute__((address_space(4))) SegCtl *seg_const_ctl;
-    typedef const __attribute__((address_space(4))) SegAcc *seg_const_acc;
-    seg_const_ctl cc = (seg_const_ctl)(uintptr_t)&j.ctl[k];
-    seg_const_acc ca = (seg_const_acc)(uintptr_t)&j.acc[kp];
-    const uint32_t fin = cc->finished, magic = cc->magic, ign = cc->ignore, fm = ca->failmask;
-    v.y = cc->y; v.s = cc->s; v.active = cc->active[f]; v.start_x = cc->start_x[f];
-#else
-    const SegCtl &c = j.ctl[k];
-    const uint32_t fin = c.finished, magic = c.magic, ign = c.ignore, fm = j.acc[kp].failmask;
-    v.y = c.y; v.s = c.s; v.active = c.active[f]; v.start_x = c.start_x[f];
-#endif
-    v.finished = (fin != 0u || magic != SEG_MAGIC || (fm & ~ign) != 0u) ? 1u : 0u;
+    const SegViewRec &V = j.v[k];
+    v.y = V.y; v.s = V.s; v.active = V.active[f]; v.start_x = V.start_x[f];
+    v.finished = (V.finished != 0u || V.magic != SEG_MAGIC || (j.vfail[seg_k_prev(k)] & ~V.ignore) != 0u) ? 1u : 0u;
     return v;
 }
 
@@ -827,9 +823,8 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
 #define SEG_K1 4
 #define SEG_HT 512
 template <int NT>
-PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, int seg, int chalf, unsigned char *smem)
+PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int seg, int chalf, unsigned char *smem)
 {
-    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     constexpr int NCH = NT / SEG_NSP;                        /* channels of this workgroup: c0 .. c0 + NCH - 1 */
@@ -979,9 +974,8 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, int par, int f, i
  * (1e-4 .. 1e-3 of the boundaries, oracle/seed_study.c) costs time, not correctness: the chain kernel walks that segment step by step. */
 #define SEG_SM_ENUM_SEEDED(nt) (SEG_TBL_WORDS * 4 + (SEG_KIN + SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_EH_WORDS * 4 + 4 * SEG_EH_WORDS * 2 + 4 * SEG_NSP * 4 + (nt) * 4 + 128)
 template <int NT>
-PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, int f, int seg, int chalf, unsigned char *smem)
+PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int seg, int chalf, unsigned char *smem)
 {
-    const SegCtlView cv = seg_ctl_view(j, par, f);
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     constexpr int NCH = NT / SEG_NSP;
@@ -1119,9 +1113,8 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, int par, i
 
 /* ---- ENUMERATE, none / up (state = (cn, th), SEG_NSS lanes per channel): task (f, SEG_SMALL_SEGS segments from seg0) -------- */
 template <int NT>
-PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, int par, int f, int seg0, unsigned char *smem)
+PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int seg0, unsigned char *smem)
 {
-    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp;
     constexpr int NSEGS = NT / (4 * SEG_NSS);                 /* segments of this workgroup */
@@ -1224,10 +1217,9 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
 /* ---- FIRST SEGMENT: task (f): the epoch's first (partial) segment has a known entry state, so it is not enumerated but walked,
  * lane = channel, next to the enumeration workgroups (same kernel); out: the index the chain starts from ------------------------ */
 template <int NT>
-PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, unsigned char *smem)
+PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = cv.start_x;
@@ -1303,9 +1295,8 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, int par, int f, 
 #define SEG_SM_CHAIN(nseg) ((1024 + 32 + 2 * SEG_CHAIN_POS + SEG_CHAIN_GWORDS) * 4 + SEG_CHAIN_TBYTES(nseg) + SEG_TBL_WORDS * 4 + (SEG_L + 1) * 8 + 64)
 PLS_HD uint32_t seg_chain_cap(uint32_t sh) { return sh >= 8 ? (uint32_t)SEG_CHAIN_CAP8 : (uint32_t)SEG_CHAIN_CAP; }
 template <bool SEEDED>
-PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, int par, int f, int c, unsigned char *smem)
+PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int c, unsigned char *smem)
 {
-    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg;
     const uint32_t sx = cv.start_x;
@@ -1619,9 +1610,8 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int
 /* ---- EXTREMES: one workgroup per image, next to the chain's (it has nothing to do with them: the launch has room): the largest and the
  * smallest orig + incoming error over the row's channels (a forced transparent alpha aside), which bound how far candidate none's bytes
  * can overshoot 0..255 (seg_none_reach); read by the replay's workgroups of candidate none in the next launch. */
-PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, int par, unsigned char *smem)
+PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, unsigned char *smem)
 {
-    const SegCtlView cv = seg_ctl_view(j, par, 0);
     if (cv.finished || !j.rowmm) return;
     const uint32_t W = j.W, bpp = j.bpp, y = cv.y;
     const uint32_t *row = seg_row_orig(j, y), *e0g = seg_e0(j, y);
@@ -1653,10 +1643,9 @@ PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, int par, unsi
     PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { SEG_AS_GLB int32_t *rmm = seg_rowmm(j, y); rmm[0] = (int)(mm[0] ^ 0x80000000u); rmm[1] = (int)(mm[1] ^ 0x80000000u); } }
 }
 
-PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, int par, int f, int grp, unsigned char *smem)
+PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
-    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished) return;
     const bool lazy = f == 0 && cv.active == 2;               /* candidate none, not run yet: only its cost bound is wanted */
     if (!lazy && cv.active != 1) return;
@@ -2016,9 +2005,8 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int
  * front of a decision: validated prefix (base) + whole groups + whole segments (counts written by the replay) + the earlier
  * decisions of its own segment (counted here).  Cheap bound first (counts at the segment's start and end), exact count only when
  * the bound cannot tell. */
-PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, int vg, unsigned char *smem)
+PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int vg, unsigned char *smem)
 {
-    const SegCtlView cv = seg_ctl_view(j, par, f);                /* (the fields this workgroup branches on, requested together) */
     if (cv.finished || cv.active != 1) return;                 /* (candidate none while it is lazy has no row to validate) */
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, ngrp = j.ngrp;
     const uint32_t sx = cv.start_x;
@@ -2220,7 +2208,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, int par, int f, i
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid == 0) {
             SegAcc &A = j.acc[par];
-            if (red[8] != SEG_NOFAIL) { PLS_ATOMIC_MIN(&A.fail[f], red[8]); PLS_ATOMIC_OR(&A.failmask, 1u << f); }
+            if (red[8] != SEG_NOFAIL) { PLS_ATOMIC_MIN(&A.fail[f], red[8]); PLS_ATOMIC_OR(&A.failmask, 1u << f); PLS_ATOMIC_OR(&j.self->vfail[par], 1u << f); }
             if (prof) {
                 tk[4] = PLS_CLOCK(); tk[5] = tk[4];
                 for (int q = 0; q < 5; q++) { PLS_ATOMIC_MAX(&j.result[40 + q], (int32_t)(tk[q + 1] - tk[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[48 + q], (uint32_t)(tk[q + 1] - tk[q])); }
@@ -2748,6 +2736,8 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
                 if (tid == 0) {
                     nxt.y = cur.y; nxt.s = cur.s; nxt.status = cur.status; nxt.finished = 2; nxt.retried = cur.retried; nxt.restarts_total = cur.restarts_total; nxt.attempts = (uint32_t)attempt; nxt.magic = SEG_MAGIC;
                     nxt.serial_rows = cur.serial_rows; nxt.dropped_none = cur.dropped_none; nxt.none_eager = cur.none_eager; nxt.ignore = 0u;
+                    { SEG_AS_GLB SegViewRec &VW = j.self->v[par]; VW.finished = 2u; VW.y = cur.y; VW.s = cur.s; VW.ignore = 0u; VW.magic = SEG_MAGIC; }
+                    j.self->vfail[par] = 0u;
                     if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt);
                     if (cur.finished == 1u) {
                         /* epilogue: final histogram + result record (pngloss_image.c:311-325) */
@@ -2792,6 +2782,8 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
                 if (j.progress && D.kind == SEG_K_COMMIT) PLS_HOST_VISIBLE_STORE(j.progress, ny);
                 if (j.attempt_word) PLS_HOST_VISIBLE_STORE(j.attempt_word, (uint32_t)attempt);
                 nxt.ignore = redo ? 0u : D.ignore;           /* (the epilogue waits for the last row's validation: the attempt that finds finished == 1) */
+                { SEG_AS_GLB SegViewRec &VW = j.self->v[par]; VW.finished = fin; VW.y = ny; VW.s = (uint32_t)(s_next < 0 ? 0 : s_next); VW.ignore = redo ? 0u : D.ignore; VW.magic = SEG_MAGIC; }
+                j.self->vfail[par] = 0u;
             }
         }
         return;
@@ -2817,6 +2809,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
                     /* candidate none starts lazy: its cost bound first, the chain only if that cannot rule it out (seg_decide_combine) */
                     nxt.active[f] = (f == 0 && j.rowmm && !(P.engine_flags >> 8) && !(P.engine_flags & 2) && !(attempt && cur.none_eager)) ? 2u : 1u;
                     nxt.start_x[f] = 0; nxt.restarts[f] = 0; nxt.cost[f] = ~0ull;
+                    j.self->v[par].active[f] = nxt.active[f]; j.self->v[par].start_x[f] = 0u;
                     for (int c = 0; c < 4; c++) nxt.state[f][c] = seg_state_pack(SegState{ 0, 0, 0 });
                 }
             }
@@ -2829,6 +2822,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
             for (int b = tid; b < 256; b += SEG_THREADS) { Hn[b] = j.H0[prev * 256 + b]; if (tpart == 0) j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u; }
             if (tid == 0 && tpart == 0) {
                 nxt.active[0] = D.start_none ? 1u : 2u; nxt.start_x[0] = 0; nxt.restarts[0] = 0; nxt.cost[0] = ~0ull;
+                j.self->v[par].active[0] = D.start_none ? 1u : 2u; j.self->v[par].start_x[0] = 0u;
                 for (int c = 0; c < 4; c++) nxt.state[0][c] = seg_state_pack(SegState{ 0, 0, 0 });
             }
         }
@@ -2843,6 +2837,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
             for (int b = tid; b < 256; b += SEG_THREADS) j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = j.base[((size_t)prev * SEG_NFILT + f) * 256 + b];
             if (tid == 0) {
                 nxt.active[f] = 0; nxt.start_x[f] = cur.start_x[f]; nxt.restarts[f] = cur.restarts[f];
+                j.self->v[par].active[f] = 0u; j.self->v[par].start_x[f] = cur.start_x[f];
                 for (int c = 0; c < 4; c++) nxt.state[f][c] = cur.state[f][c];
                 nxt.cost[f] = (uint64_t)dshare[6 + 2 * f] | ((uint64_t)dshare[7 + 2 * f] << 32);     /* D.cost[f], from shared memory: indexing the copy in registers with f would send it to the stack */
             }
@@ -2888,6 +2883,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
                 for (uint32_t c = 0; c < 4; c++) nxt.state[f][c] = c < bpp ? seg_state_pack(st[c]) : 0u;
                 nxt.start_x[f] = xend;
                 nxt.active[f] = 1; nxt.restarts[f] = cur.restarts[f] + 1; nxt.cost[f] = ~0ull;
+                j.self->v[par].active[f] = 1u; j.self->v[par].start_x[f] = xend;
             }
         }
         PLS_SYNC();

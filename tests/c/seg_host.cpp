@@ -107,6 +107,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.rowmm = A.take<int32_t>(4);
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
     const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
+    j.self = &j; for (int k = 0; k < 3; k++) { j.v[k].magic = 0u; j.v[k].finished = 0u; j.v[k].ignore = 0u; j.vfail[k] = 0u; }
     j.ctl[2].magic = 0u; j.acc[2].failmask = 0u;   /* (seg_k_resolve does this on the device: the first attempt finds no attempt behind it) */
     int attempt = 0;
     const long max_attempts = (long)H * ((long)strength + 1) * (2 + 2 * SEG_MAX_RESTARTS * SEG_NFILT) + 1024;   /* (the product's bound: pl_host.hip) */
@@ -119,7 +120,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         std::vector<unsigned char> cvsm((size_t)SEG_SM_CTLVAL, 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
         for (int half = 0; half < 2; half++) {
             if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG + 1 + ncommit; bx++) seg_ctl_body(j, P, par, bx, cvsm.data()); }
-            else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, kv, f, (int)vg, cvsm.data()); }
+            else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
         }
         if (j.ctl[par].finished == 2u) break;
         /* the enumeration's workgroups come in two sizes; the product picks by row width, SEG_HOST_ENUM_NT pins one */
@@ -132,26 +133,26 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
             std::vector<unsigned char> ssm((size_t)SEG_SM_ENUM_SEEDED(nt), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++)
                 for (uint32_t sg = 0; sg < j.nseg; sg++) {
-                    if (nt == 512) for (int ch = 0; ch < 2; ch++) seg_enum_seeded_body<512>(j, P, par, f, (int)sg, ch, ssm.data());
-                    else seg_enum_seeded_body<1024>(j, P, par, f, (int)sg, 0, ssm.data());
+                    if (nt == 512) for (int ch = 0; ch < 2; ch++) seg_enum_seeded_body<512>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, ch, ssm.data());
+                    else seg_enum_seeded_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, 0, ssm.data());
                 }
         } else
         for (int f = 0; f < SEG_NFILT; f++) {
             if (nt == 512) {
-                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 4) seg_enum_small_body<512>(j, P, par, f, (int)sg, esm.data());
-                else for (uint32_t sg = 0; sg < j.nseg; sg++) for (int ch = 0; ch < 2; ch++) seg_enum_body<512>(j, P, par, f, (int)sg, ch, esm.data());
+                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 4) seg_enum_small_body<512>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, esm.data());
+                else for (uint32_t sg = 0; sg < j.nseg; sg++) for (int ch = 0; ch < 2; ch++) seg_enum_body<512>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, ch, esm.data());
             } else {
-                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 8) seg_enum_small_body<1024>(j, P, par, f, (int)sg, esm.data());
-                else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, par, f, (int)sg, 0, esm.data());
+                if (seg_is_small(P, f)) for (uint32_t sg = 0; sg < j.nseg; sg += 8) seg_enum_small_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, esm.data());
+                else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, 0, esm.data());
             }
         }
-        for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, par, f, esm.data()); else seg_first_body<1024>(j, P, par, f, esm.data()); }
+        for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
         {   /* the chain kernel's LDS is sized by the row's segments: the same size here (the sanitizer build sees an overrun) */
             std::vector<unsigned char> csm((size_t)SEG_SM_CHAIN(j.nseg), 0x5A);
-            for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) { if (P.seeded) seg_chain_body<true>(j, P, par, f, c, csm.data()); else seg_chain_body<false>(j, P, par, f, c, csm.data()); }
-            seg_extremes_body(j, P, par, csm.data());
+            for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) { if (P.seeded) seg_chain_body<true>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data()); else seg_chain_body<false>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data()); }
+            seg_extremes_body(j, P, seg_ctl_view(j, par, 0), par, csm.data());
         }
-        { std::vector<unsigned char> rsm((size_t)SEG_SM_REPLAY, 0x5A); for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, par, f, (int)g, rsm.data()); }
+        { std::vector<unsigned char> rsm((size_t)SEG_SM_REPLAY, 0x5A); for (int f = 0; f < SEG_NFILT; f++) for (uint32_t g = 0; g < j.ngrp; g++) seg_replay_body(j, P, seg_ctl_view(j, par, f), par, f, (int)g, rsm.data()); }
     }
     const SegCtl &fc = j.ctl[attempt % 3];
     if (getenv("SEG_HOST_VERBOSE")) {
