@@ -318,7 +318,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
      * engines run side by side -- the segment engine's images in one launch sequence (blockIdx.y = image) on the engine's own stream,
      * the others as one workgroup each on the caller's.
      * Cost model (measured on 1 .. 64 frames of 512x512 and 1920x1080, tests/tools/gpu_seg_batch.py): a row
-     * attempt of the segment engine takes ~51 us plus ~0.032 us per workgroup of its widest kernel (about 3 per segment and 40 more per
+     * attempt of the segment engine takes ~38 us plus ~0.032 us per workgroup of its widest kernel (about 3 per segment and 40 more per
      * image), whatever the width, and there are as many attempts as the tallest of its images has rows; the workgroup engine ~0.18 us
      * per pixel of its largest image, all images side by side (256 CUs).  State sets beyond the lanes (s = 85 at bleed 1 or 2 ...) are
      * enumerated from seeds with a run-in of one segment: about twice the enumeration and a wider chain.  Greedy: the images go to the
@@ -332,7 +332,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
         bool seg_ok = n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
-            const double a_us = seg_params.seeded ? 88.0 : 44.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches, 50.6 us at 424 workgroups) */
+            const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
             auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
             std::vector<size_t> order;
             for (size_t i = 0; i < n; i++)

@@ -1841,7 +1841,15 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
                     const int centre = i - 256;
                     const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
                     uint32_t m = 0;
-                    for (int b = lo; b <= hi; b++) m = h0s[b] > m ? h0s[b] : m;
+                    /* eight reads in flight per turn (indices past the range are clamped onto its end: they change nothing); one read a turn waits
+                     * for each of up to 2R + 1 = 50 and more on its own -- these workgroups were as long as the walkers' */
+                    for (int b = lo; b <= hi; b += 8) {
+                        uint32_t h[8];
+                        PLS_UNROLL
+                        for (int q = 0; q < 8; q++) h[q] = h0s[seg_min(b + q, hi)];
+                        PLS_UNROLL
+                        for (int q = 0; q < 8; q++) m = h[q] > m ? h[q] : m;
+                    }
                     rm[i] = m;
                 }
             }
