@@ -290,7 +290,8 @@ void pngloss_hip_pinned_free(void *p);
  *   info[2]  validation restarts (engine 3) / pixels redone exactly (engine 0)
  *   info[3]  rows finished serially (engine 3) / rows on the round-1 chains by the adaptive choice (engine 0)
  *   info[4]  rows in which candidate none was ruled out by its cost bound (engine 3)
- *   info[5]  segments the chain kernel walked step by step because their entry state was in no enumerated set (engine 3)
+ *   info[5]  segments whose entry state was in no enumerated set (engine 3): walked step by step by the chain kernel (seeded state sets), or the
+ *            places where a row was broken off and resumed in an epoch (exhaustive state sets: next to never)
  * No reference equivalent. */
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8]);
 

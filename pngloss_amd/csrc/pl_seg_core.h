@@ -1538,6 +1538,32 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 next_pass = true;
                 break;
             }
+            if (!seeded) {
+                /* Exhaustive state sets: a position without an id is next to never seen (a lane that left what the tables cover), and the code of
+                 * the repair below costs this kernel 0.9 us on every row by merely being in it (registers, 100 more spilled scalars).  So this
+                 * instantiation has none: the row BREAKS here.  The segment in question is left to the replay (which walks a segment without
+                 * checkpoints from its entry state), and the pixel behind it is reported as this candidate's first failed decision: an epoch starts
+                 * there, as behind any failed validation (seg_ctl_body) -- exact, and two attempts instead of 16 us on the rare row. */
+                if (fb > pos0 && entL[fb] == SEG_NOSTATE) fb--;
+                const uint32_t estb = fb > pos0 ? entL[fb] : idxb[26];
+                PLS_SYNC();
+                const uint32_t kqb = a + fb, sgb = s0 + kqb;
+                PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+                    if (tid == 0) {
+                        SEG_DEBUG_COUNT(2, fb);
+                        idxb[24]++;
+                        dnout[(size_t)sgb * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgb * 4] = estb;
+                        const uint32_t xfail = (sgb + 1u) * SEG_L;
+                        if (kqb < ns && xfail < W) {
+                            PLS_ATOMIC_MIN(&j.acc[par].fail[f], xfail * 4u + (uint32_t)c);
+                            PLS_ATOMIC_OR(&j.acc[par].failmask, 1u << f);
+                            PLS_ATOMIC_OR(&j.self->vfail[par], 1u << f);
+                        }
+                    }
+                }
+                done = true;
+                break;
+            }
             /* -- repair: position fb has no id (its entry state is not in the segment's entry set) -- or position fb - 1 has an id but no exit
              *    state (its lane left what the tables cover).  That segment is walked step by step from its entry state. -- */
             if (fb > pos0 && entL[fb] == SEG_NOSTATE) fb--;
