@@ -48,7 +48,15 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
 /* First launch of attempt k: its CONTROL workgroups (blockIdx.x < nctl: decide the attempt before optimistically, commit, prepare this one) and, side by
  * side with them, the VALIDATION workgroups of the attempt before (copy kv): the proof of what is being decided arrives one launch later and
  * takes nothing off the critical path (seg_ctl_body says what happens when it fails). */
-__global__ __launch_bounds__(SEG_THREADS, 8) void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int k, unsigned nctl, unsigned max_ngrp)
+#ifndef SEG_EXPERIMENT_NO_VAL_CODE
+#define SEG_EXPERIMENT_NO_VAL_CODE 0      /* (1: TIMING EXPERIMENT -- the control kernel without the validation's code in it; results unvalidated) */
+#endif
+#if SEG_EXPERIMENT_NO_VAL_CODE
+#define SEG_CTL_BOUNDS __launch_bounds__(SEG_THREADS)
+#else
+#define SEG_CTL_BOUNDS __launch_bounds__(SEG_THREADS, 8)
+#endif
+__global__ SEG_CTL_BOUNDS void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int k, unsigned nctl, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
@@ -57,6 +65,9 @@ __global__ __launch_bounds__(SEG_THREADS, 8) void seg_k_ctl(const SegJob *__rest
         seg_ctl_body(j, *P, k, (int)blockIdx.x, seg_smem);
         return;
     }
+#if SEG_EXPERIMENT_NO_VAL_CODE
+    return;
+#endif
     /* validation groups are half replay groups: max_ngrp * (SEG_GRP / SEG_VGRP) workgroups per candidate */
     const unsigned bx = blockIdx.x - nctl, per = max_ngrp * (SEG_GRP / SEG_VGRP), f = bx / per, vg = bx % per;
     if (vg * SEG_VGRP >= j.nseg) return;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *_
     seg_chain_body<SEEDED>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)((blockIdx.x - 1) >> 2)), par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_REPLAY_THREADS) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
+__global__ __launch_bounds__(SEG_REPLAY_NT) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
@@ -215,6 +226,6 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     }
     if (b.seeded) hipLaunchKernelGGL(seg_k_chain<true>, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     else hipLaunchKernelGGL(seg_k_chain<false>, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
-    hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_THREADS), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
+    hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_NT), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();
 }

@@ -155,7 +155,8 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_MAX_WIDTH (1u << 20)      /* rows the engine takes (libpng's own default limit); the chain kernel walks a row in passes, nothing else depends on the width */
 #define SEG_THREADS 1024
 #define SEG_CHAIN_THREADS 1024
-#define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* every thread loads one pixel of the group, SEG_GRP * SEG_PARTS * 4 of them walk */
+#define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* pixels of a replay group: the first SEG_REPLAY_THREADS threads of the workgroup take one each, SEG_GRP * SEG_PARTS * 4 of them walk */
+#define SEG_REPLAY_NT (2 * SEG_REPLAY_THREADS) /* threads of the replay's workgroups: the second half helps with the staging and takes the bump counts while the first takes the sums */
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
 #define SEG_SMALL_SEGS 8           /* most segments per enumeration workgroup for them: 8 segments x 4 channels x SEG_NSS lanes (1024 threads) */
@@ -1698,7 +1699,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     const bool rprof = SEG_EXPERIMENT_REPLAY_CLOCKS && (P.engine_flags & 1) != 0 && walk && grp == 3;
     unsigned long long tr_[6] = { 0, 0, 0, 0, 0, 0 };
     if (rprof) tr_[0] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+    PLS_THREADS(tid, SEG_REPLAY_NT) {
         /* Order of the requests: the walkers' dense ids, then everything the block stages (tables, frozen histogram, pixels), then the
          * checkpoints and entry states (which wait for the dense ids only); the stores to shared memory behind all of them. */
         const bool walker = walk && tid < SEG_GRP * SEG_PARTS * 4;
@@ -1707,13 +1708,14 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         const bool live = walker && sg < nseg && sg >= first && (uint32_t)c < bpp;
         const size_t sc = ((size_t)f * nseg + (live ? sg : 0u)) * 4 + c;
         const uint32_t d = live ? (uint32_t)j.dnout[sc] : SEG_INVALID;
-        constexpr int NTW = (SEG_TBL_WORDS + SEG_REPLAY_THREADS - 1) / SEG_REPLAY_THREADS;
+        constexpr int NTW = (SEG_TBL_WORDS + SEG_REPLAY_NT - 1) / SEG_REPLAY_NT;
         uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; vt[q] = (walk && i < SEG_TBL_WORDS) ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_NT; vt[q] = (walk && i < SEG_TBL_WORDS) ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (walk && tid < 512) vl = P.lut_a[tid];
         if (walk && tid < 256) { vh = j.H0[par * 256 + tid]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + tid]; vr = j.orig_rank[f * 256 + tid]; }
-        const uint32_t x = x0g + (uint32_t)tid;
+        const bool pixlane = tid < SEG_REPLAY_THREADS;            /* (the first half of the workgroup has a pixel of the group each; the second half helps with the staging and takes the counts) */
+        const uint32_t x = pixlane ? x0g + (uint32_t)tid : W;
         const SegPixRaw vp = seg_pix_fetch(row, nab, e0g, x, W);
         /* for the sums: the original row above; what lies in front of the group (lane 0); the validated words of an epoch that starts further right */
         const uint32_t voa = (!lazy && oab && x < W) ? oab[x] : 0u;
@@ -1756,14 +1758,16 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         if (tid < SEG_GRP * SEG_PARTS * 4) { lane[2 * tid] = st0; lane[2 * tid + 1] = range; }
         if (walk) {
             PLS_UNROLL
-            for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_THREADS; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+            for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
             if (tid < 512) lut[tid] = vl;
             if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
-            for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_THREADS) cnt[i] = 0u;
+            for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_NT) cnt[i] = 0u;
         }
-        seg_pix_split4(px + tid * 4, vp, bpp, x, W);
-        oaL[tid + 1] = voa;
-        cwl[tid * 4 + 0] = vw.a; cwl[tid * 4 + 1] = vw.b; cwl[tid * 4 + 2] = vw.c; cwl[tid * 4 + 3] = vw.d;
+        if (pixlane) {
+            seg_pix_split4(px + tid * 4, vp, bpp, x, W);
+            oaL[tid + 1] = voa;
+            cwl[tid * 4 + 0] = vw.a; cwl[tid * 4 + 1] = vw.b; cwl[tid * 4 + 2] = vw.c; cwl[tid * 4 + 3] = vw.d;
+        }
         if (tid == 0) {
             oaL[0] = voa0; oaL[SEG_REPLAY_THREADS + 1] = vol0;
             oaL[SEG_REPLAY_THREADS + 2] = (vw0.a & 255u) | ((vw0.b & 255u) << 8) | ((vw0.c & 255u) << 16) | ((vw0.d & 255u) << 24);
@@ -1772,7 +1776,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     PLS_SYNC();
     if (rprof) tr_[1] = PLS_CLOCK();
     if (walk) {
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        PLS_THREADS(tid, SEG_REPLAY_NT) {
             if (tid < SEG_GRP * SEG_PARTS * 4 && lane[2 * tid + 1] != 0xFFFFFFFFu) {
                 const int sl = tid / (SEG_PARTS * 4), c = tid & 3;
                 SegState st = seg_state_unpack(lane[2 * tid]);
@@ -1782,8 +1786,17 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         }
         PLS_SYNC();
         if (rprof) tr_[2] = PLS_CLOCK();
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-            for (int b = tid; b < 256; b += SEG_REPLAY_THREADS) {
+    }
+    SegAcc &A = j.acc[par];
+    if (rprof) tr_[3] = PLS_CLOCK();
+    PLS_THREADS(tid, SEG_REPLAY_NT) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
+    PLS_SYNC();
+    {
+        /* -- the first half of the workgroup: every thread its pixel: the words out (what the walkers have just written), the pixel's share of the
+         *    sums; a quarter meanwhile: the bump counts per segment and group, a bin a thread -- */
+        PLS_THREADS(tid, SEG_REPLAY_NT) {
+            if (walk && tid >= SEG_REPLAY_THREADS && tid < SEG_REPLAY_THREADS + 256) {
+                const int b = tid - SEG_REPLAY_THREADS;
                 uint32_t tot = 0, cvs[SEG_GRP];
                 PLS_UNROLL
                 for (int sl = 0; sl < SEG_GRP; sl++) cvs[sl] = cnt[sl * 256 + b];          /* (all reads, then the stores: one wait) */
@@ -1794,16 +1807,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
                 }
                 j.grpcnt[((size_t)f * j.ngrp + grp) * 256 + b] = tot;
             }
-        }
-    }
-    SegAcc &A = j.acc[par];
-    if (rprof) tr_[3] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
-    PLS_SYNC();
-    if (!lazy) {
-        /* -- every thread its pixel: the words out (what the walkers have just written), the pixel's share of the sums -- */
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-            const uint32_t x = x0g + (uint32_t)tid;
+            const uint32_t x = (!lazy && tid < SEG_REPLAY_THREADS) ? x0g + (uint32_t)tid : W;
             uint64_t derr = 0; uint32_t hs[SEG_NFILT] = { 0, 0, 0, 0, 0 };
             if (x < W) {
                 SegVec16 w; w.a = cwl[tid * 4 + 0]; w.b = cwl[tid * 4 + 1]; w.c = cwl[tid * 4 + 2]; w.d = cwl[tid * 4 + 3];
@@ -1854,7 +1858,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     int R = -1;
     if (f == 0 && j.rowmm) {
         const int32_t *rmm = seg_rowmm(j, y);
-        PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+        PLS_THREADS(tid, SEG_REPLAY_NT) {
             /* the row's extremes of orig + incoming error (seg_extremes_body, the launch before) */
             if (tid == 0) red[12] = (uint32_t)seg_none_reach(j, P, (int)cv.s, rmm[0], rmm[1]);
             if (tid >= 64 && tid < 64 + 256) h0s[tid - 64] = j.H0[par * 256 + (tid - 64)];
@@ -1862,8 +1866,8 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         PLS_SYNC();
         R = (int)red[12];
         if (R >= 0) {
-            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
-                for (int i = tid; i < 768; i += SEG_REPLAY_THREADS) {
+            PLS_THREADS(tid, SEG_REPLAY_NT) {
+                for (int i = tid; i < 768; i += SEG_REPLAY_NT) {
                     const int centre = i - 256;
                     const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
                     uint32_t m = 0;
@@ -1880,10 +1884,10 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
                 }
             }
             PLS_SYNC();
-            PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+            PLS_THREADS(tid, SEG_REPLAY_NT) {
                 uint64_t lb = 0;
                 const uint32_t rowbumps = W * bpp;
-                const uint32_t x = x0g + (uint32_t)tid;
+                const uint32_t x = tid < SEG_REPLAY_THREADS ? x0g + (uint32_t)tid : W;
                 if (x < W) {
                     for (uint32_t c = 0; c < bpp; c++) {
                         const SegPix pc = px[tid * 4 + c];
@@ -1900,7 +1904,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         }
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_REPLAY_THREADS) {
+    PLS_THREADS(tid, SEG_REPLAY_NT) {
         if (tid == 0) {
             if (!lazy) {
                 PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
