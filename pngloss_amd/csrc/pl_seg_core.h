@@ -574,10 +574,11 @@ PLS_HD uint32_t seg_step_fast(const SegPix &p, SegState &st, int &bad, seg_lds_c
     const int osym = seg_sext8(orig - pred), lo = osym - orig, hi = lo + 255;
     const int filt = osym + seg_sext16(p.e0 + st.cn);
     const int neg = filt < 0 ? 1 : 0;
-    const int af = neg ? -filt : filt;
-    const int t = seg_div_q(af, g);
-    const int tq = seg_mul24(t, g.q);
-    const int bandlo = neg ? -tq - g.s : tq, bandhi = bandlo + g.s;
+    /* the band of filt (optimize_state.c:186-193): [tq, tq + s] with tq = trunc(filt / q) * q for filt >= 0, [tq - s, tq] for filt < 0 -- the
+     * truncating division SIGNED (the float reciprocal is exact for |filt| < 2^17, and symmetric), so that no |filt|, no negation and no select
+     * lie on the step's dependent path: three instructions less per step than through the absolute value */
+    const int tq = seg_mul24(seg_div_q(filt, g), g.q);
+    const int bandlo = tq - (neg ? g.s : 0), bandhi = bandlo + g.s;
     const int v0 = seg_max(bandlo, lo), v1 = seg_min(bandhi, hi);
     const bool degen = v0 > v1;                                /* the whole band lies outside [lo, hi]: the clamp leaves lo or hi */
     const int vd = bandhi < lo ? lo : hi;
@@ -596,7 +597,7 @@ PLS_HD uint32_t seg_step_fast(const SegPix &p, SegState &st, int &bad, seg_lds_c
         back = tr ? 0 : back; diff = tr ? 0 : diff; bin = tr ? ((0 - pred) & 255) : bin;
     }
     const int ad = diff < 0 ? -diff : diff;
-    bad = seg_max(bad, seg_max(af - g.fmax, ad - 255));        /* > 0: outside what the tables cover */
+    bad = seg_max(bad, ad - 255);                              /* > 0: outside what the split table covers (the decision tables cover every clamped band whatever filt is) */
     const uint32_t le = lut[(diff + 256) & 511];
     st.left = back; st.cn = seg_sext16((int)le) + st.th; st.th = (int)le >> 16;
     return seg_cand_pack(back, diff, bin);

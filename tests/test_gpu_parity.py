@@ -739,3 +739,27 @@ def test_segment_engine_tiny_images_that_need_very_many_attempts(monkeypatch, ke
     out, f = P.optimize_with_rows(img, s, b, want_filters=filters)
     want, wf = U.run_port(img, s, b, filters)
     assert np.array_equal(out, want) and (not filters or np.array_equal(f, wf))
+
+
+@pytest.mark.gpu
+def test_engine_option_of_the_abi_pins_the_row_engine(torch_cuda, monkeypatch):
+    """pngloss_hip_set_option(ctx, "engine", ...) -- the ABI's switch for what PNGLOSS_HIP_ENGINE does for the tests: same bytes either way,
+    pngloss_hip_last_engine_info says which engine ran; unknown names and values are refused."""
+    torch = torch_cuda
+    monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
+    img = P.synth_rgba(640, 96, 0, 2)
+    want, wf = U.run_port(img, 19, 2)
+    ctx = P.HipContext()
+    seen = []
+    for value in ("seg", "wg", "auto"):
+        ctx.set_option("engine", value)
+        d = torch.from_numpy(img.copy()).cuda()
+        f = torch.zeros(img.shape[0], dtype=torch.uint8, device="cuda")
+        res = ctx.run([(d.data_ptr(), f.data_ptr(), img.shape[1], img.shape[0])], 19, 2)
+        torch.cuda.synchronize()
+        assert res[0]["status"] == 0 and np.array_equal(d.cpu().numpy(), want) and np.array_equal(f.cpu().numpy(), wf), value
+        seen.append(ctx.engine_info(0)["engine"])
+    assert seen[0] == "segment-parallel" and seen[1] == "workgroup-per-image"
+    lib = P.hip_lib()
+    assert lib.pngloss_hip_set_option(ctx._ctx, b"engine", b"fastest") == 4 and lib.pngloss_hip_set_option(ctx._ctx, b"colour", b"seg") == 4
+    ctx.close()
