@@ -519,8 +519,8 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
                 std::fprintf(stderr, "pngloss_hip:   ... table build, average (us): keys %.2f, classes %.2f, entries + write %.2f\n",
                              (uint32_t)r[37] / 100.0 / (uint32_t)r[61], (uint32_t)r[38] / 100.0 / (uint32_t)r[61], (uint32_t)r[39] / 100.0 / (uint32_t)r[61]);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[32])
-                std::fprintf(stderr, "pngloss_hip:   enumeration workgroups (us), slowest / average: load %.1f / %.2f  first %d steps + dedupe %.1f / %.2f  remaining steps %.1f / %.2f  map %.1f / %.2f; distinct states per channel after the dedupe %.1f; first-segment walker %.1f / %.2f\n",
-                             r[24] / 100.0, (uint32_t)r[28] / 100.0 / (uint32_t)r[32], SEG_K1, r[25] / 100.0, (uint32_t)r[29] / 100.0 / (uint32_t)r[32], r[26] / 100.0, (uint32_t)r[30] / 100.0 / (uint32_t)r[32],
+                std::fprintf(stderr, "pngloss_hip:   enumeration workgroups (us), slowest / average: load %.1f / %.2f  first steps (%d, or %d for a state set of one chunk) + dedupe %.1f / %.2f  remaining steps %.1f / %.2f  map %.1f / %.2f; distinct states per channel after the dedupe %.1f; first-segment walker %.1f / %.2f\n",
+                             r[24] / 100.0, (uint32_t)r[28] / 100.0 / (uint32_t)r[32], SEG_K1, SEG_K1_ONE_CHUNK, r[25] / 100.0, (uint32_t)r[29] / 100.0 / (uint32_t)r[32], r[26] / 100.0, (uint32_t)r[30] / 100.0 / (uint32_t)r[32],
                              r[27] / 100.0, (uint32_t)r[31] / 100.0 / (uint32_t)r[32], (uint32_t)r[33] / 4.0 / (uint32_t)r[32], r[34] / 100.0, r[36] ? (uint32_t)r[35] / 100.0 / (uint32_t)r[36] : 0.0);
             if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[16])
                 std::fprintf(stderr, "pngloss_hip:   chain workgroups (us), slowest / average: gather %.1f / %.2f  compose %.1f / %.2f  walk %.1f / %.2f  tail %.1f / %.2f; %u runs, %u through the serial walk, %u at the wide stride\n",

@@ -61,6 +61,7 @@
 #define PLS_ATOMIC_OR(p, v) atomicOr((p), (v))
 #define PLS_ATOMIC_CAS(p, cmp, v) atomicCAS((p), (cmp), (v))
 #define PLS_ATOMIC_ADD_RET(p, v) atomicAdd((p), (v))
+#define PLS_ATOMIC_EXCH(p, v) atomicExch((p), (v))
 #define PLS_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define PLS_CLOCK() wall_clock64()
 #define PLS_ATOMIC_MAX(p, v) atomicMax((p), (v))
@@ -84,6 +85,7 @@ inline uint32_t pls_host_cas(uint32_t *p, uint32_t cmp, uint32_t v) { const uint
 inline uint32_t pls_host_add_ret(uint32_t *p, uint32_t v) { const uint32_t old = *p; *p += v; return old; }
 #define PLS_ATOMIC_CAS(p, cmp, v) pls_host_cas((p), (cmp), (v))
 #define PLS_ATOMIC_ADD_RET(p, v) pls_host_add_ret((p), (v))
+#define PLS_ATOMIC_EXCH(p, v) (*(p) = (v))
 #define PLS_ATOMIC_ADD64(p, v) (*(p) += (v))
 /* the CPU harness runs one "thread" at a time: every thread is its own wave */
 #define PLS_CLOCK() 0ull
@@ -120,6 +122,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define PLS_UNROLL
 #endif
 #define SEG_NFILT 5
+#ifndef SEG_EXPERIMENT_WG_SPAN
+#define SEG_EXPERIMENT_WG_SPAN 0    /* experiment build (tools/replay_clocks.sh, EXP_DEFS=-DSEG_EXPERIMENT_WG_SPAN=1): when the enumeration's workgroups start and end, relative to the launch's first */
+#endif
 #ifndef SEG_EXPERIMENT_REPLAY_CLOCKS
 #define SEG_EXPERIMENT_REPLAY_CLOCKS 0   /* (1: an experiment build in which the REPLAY's phase clocks take the enumeration's slots of the result record; tools/replay_clocks.sh) */
 #endif
@@ -822,7 +827,10 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
  * bytes): after SEG_K1 steps the lanes of a channel hold far fewer DISTINCT states than lanes.  They are deduplicated through a small
  * hash table in shared memory (exact: full keys are compared), the distinct ones are packed into the first lanes of the channel and only
  * those run the remaining steps -- whole waves fall idle -- then every lane picks up the result of its representative. */
-#define SEG_K1 4
+#define SEG_K1 4                 /* steps before the dedupe when the state set comes in several chunks of SEG_NSP lanes */
+#define SEG_K1_ONE_CHUNK 2       /* ... when it fits one chunk (no more distinct states than lanes, whatever they are): measured on the headline frame,
+                                    steps before the dedupe 1 / 2 / 3 / 4 / 6 -> enumeration 20.6 (and the chain 15.9: too many distinct states) / 18.6 / 19.2 / 19.7 / 20.0 us */
+PLS_HD int seg_k1(int ns) { return ns <= SEG_NSP ? SEG_K1_ONE_CHUNK : SEG_K1; }
 #define SEG_HT 512
 template <int NT>
 PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int seg, int chalf, unsigned char *smem)
@@ -850,9 +858,11 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
-    const bool prof = (P.engine_flags & 1) != 0;
+    const bool span = SEG_EXPERIMENT_WG_SPAN && (P.engine_flags & 1) != 0 && (cv.y & 3u) == 0u;
+    const bool prof = !SEG_EXPERIMENT_WG_SPAN && (P.engine_flags & 1) != 0;
     unsigned long long te[5] = { 0, 0, 0, 0, 0 };
-    if (prof) te[0] = PLS_CLOCK();
+    if (prof || span) te[0] = PLS_CLOCK();
+    if (span && f == 1 && seg == 0 && chalf == 0) { PLS_THREADS(tid, NT) { if (tid == 0) PLS_ATOMIC_EXCH((uint32_t *)&j.result[47], (uint32_t)te[0]); } }   /* (the launch's first workgroup) */
     PLS_THREADS(tid, NT) {
         if (tid < 8) trflag[tid] = 0u;
         for (int i = tid; i < 4 * SEG_HT; i += NT) ht[i] = 0xffffffffu;
@@ -882,6 +892,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
      *    so only the first lane of a run of equal keys ("head") goes to the hash table with an atomic, the others look their key up
      *    afterwards.  Every entry index gets the DENSE id of its state: that is the segment's entry map -- */
     uint32_t *keys = (uint32_t *)(lslot + NT);       /* [NT] state key of every lane after SEG_K1 steps, ~0 = none */
+    const int K1 = seg_k1(P.ns);
     SEG_AS_GLB uint16_t *dmap = j.maps + (((size_t)f * j.nseg + seg) * 4) * (size_t)P.nsp;
     for (int i0 = 0; i0 < P.ns; i0 += SEG_NSP) {
         PLS_THREADS(tid, NT) {
@@ -890,7 +901,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
             if ((uint32_t)c < bpp && i < P.ns) {
                 SegState st;
                 if (seg_state_decode(P, i, px[c], st)) {
-                    const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                    const int bad = seg_run_fast_f(f, trx, px + 4 + c, 4, K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
                     if (!bad && st.cn >= -128 && st.cn <= 127) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16);
                 }
             }
@@ -936,10 +947,17 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
     if (prof) te[2] = PLS_CLOCK();
     /* -- the remaining steps, distinct states only (packed into the first lanes of each channel): dense id -> exit index -- */
     PLS_THREADS(tid, NT) {
-        /* distinct state i of (local) channel lc runs on thread (i >> 6) * 64 * NCH + lc * 64 + (i & 63): the first 64 of every channel are the
-         * first NCH waves of the workgroup, one per SIMD (waves 0, 4, 8, 12 would share one) */
-        const int lc = (tid >> 6) % NCH, c = c0 + lc, i = (tid & 63) + 64 * (tid / (64 * NCH));
-        const uint32_t D = trflag[1 + lc] < SEG_NSP ? trflag[1 + lc] : SEG_NSP;
+        /* the distinct states of the workgroup's channels PACKED into its first lanes, channel behind channel: a dozen states per channel are one wave
+         * for all of them, and what this phase costs is the instruction issue of the waves that have a live lane (the workgroups of a CU share its
+         * four SIMDs: waves x steps is the currency, the other waves end here) */
+        uint32_t Dc[NCH];
+        for (int k = 0; k < NCH; k++) Dc[k] = trflag[1 + k] < SEG_NSP ? trflag[1 + k] : SEG_NSP;
+        int lc = 0, i = tid;
+        uint32_t D = Dc[0];
+        PLS_UNROLL
+        for (int k = 0; k + 1 < NCH; k++) if (lc == k && (uint32_t)i >= Dc[k]) { i -= (int)Dc[k]; lc = k + 1; D = Dc[k + 1]; }
+        const int c = c0 + lc;
+        if (tid < NCH && (uint32_t)(c0 + tid) < bpp) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c0 + tid] = Dc[tid];
         if ((uint32_t)c < bpp && (uint32_t)i < D) {
             const uint32_t key = uniq[lc * SEG_NSP + i];
             SegState st;
@@ -947,7 +965,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
             uint32_t out = SEG_INVALID;
             /* to the end of part 0, then part by part: the state at every cut is a checkpoint the replay starts a lane from */
             const size_t slot = (((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i;
-            int bad = seg_run_fast_f(f, trx, px + (1 + SEG_K1) * 4 + c, 4, SEG_PL - SEG_K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            int bad = seg_run_fast_f(f, trx, px + (1 + K1) * 4 + c, 4, SEG_PL - K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
             for (int part = 1; part < SEG_PARTS; part++) {
                 j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
                 bad |= seg_run_fast_f(f, trx, px + (1 + part * SEG_PL) * 4 + c, 4, SEG_PL, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
@@ -956,12 +974,31 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
             j.rout[slot] = (uint16_t)out;
             j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
         }
-        if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
         if (prof && tid == 0 && !SEG_EXPERIMENT_REPLAY_CLOCKS) {
             te[3] = PLS_CLOCK(); te[4] = te[3];
             for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
             PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
             PLS_ATOMIC_ADD((uint32_t *)&j.result[33], trflag[1] + trflag[2] + trflag[3] + trflag[4]);
+        }
+    }
+    if (span) {
+        PLS_SYNC();
+        PLS_THREADS(tid, NT) {
+            if (tid == 0) {
+                /* start and end of this workgroup against the start of the launch's first; slots of the phase clocks: "load" = start, "first steps" = end, "remaining" = duration */
+                const uint32_t ref = PLS_ATOMIC_ADD_RET((uint32_t *)&j.result[47], 0u);
+                const int32_t ds = (int32_t)((uint32_t)te[0] - ref), de = (int32_t)((uint32_t)PLS_CLOCK() - ref);
+                if (ds >= 0 && de < 4000) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const int32_t simd = (int32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);      /* HW_ID.SIMD_ID of the workgroup's wave 0 */
+#else
+                    const int32_t simd = 0;
+#endif
+                    const int32_t v[4] = { ds, de, de - ds, simd * 100 };
+                    for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], v[q]); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)v[q]); }
+                    PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
+                }
+            }
         }
     }
 }

@@ -9,5 +9,5 @@ mkdir -p /tmp/exp_build
 for f in pl_prepost pl_engine pl_seg pl_pngread pl_inflate pl_emit pl_deflate pl_host; do
   if [ $f = pl_seg ]; then /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${EXP_DEFS:--DSEG_EXPERIMENT_REPLAY_CLOCKS=1} -c $f.hip -o /tmp/exp_build/$f.o; else cp $f.o /tmp/exp_build/$f.o; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libpngloss_hip_exp.so /tmp/exp_build/*.o
-ls -la libpngloss_hip_exp.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ${EXP_LIB:-libpngloss_hip_exp.so} /tmp/exp_build/*.o
+ls -la ${EXP_LIB:-libpngloss_hip_exp.so}
