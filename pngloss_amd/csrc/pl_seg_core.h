@@ -957,7 +957,7 @@ PLS_HD void seg_enum_body(const SegJob &j, const SegParams &P, const SegCtlView 
         PLS_UNROLL
         for (int k = 0; k + 1 < NCH; k++) if (lc == k && (uint32_t)i >= Dc[k]) { i -= (int)Dc[k]; lc = k + 1; D = Dc[k + 1]; }
         const int c = c0 + lc;
-        if (tid < NCH && (uint32_t)(c0 + tid) < bpp) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c0 + tid] = Dc[tid];
+        if (tid < NCH && (uint32_t)(c0 + tid) < bpp) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c0 + tid] = trflag[1 + tid] < SEG_NSP ? trflag[1 + tid] : SEG_NSP;
         if ((uint32_t)c < bpp && (uint32_t)i < D) {
             const uint32_t key = uniq[lc * SEG_NSP + i];
             SegState st;
@@ -1126,8 +1126,15 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
     }
     /* -- the segment itself from every entry state: dense id -> checkpoints, exit state -- */
     PLS_THREADS(tid, NT) {
-        const int lc = (tid >> 6) % NCH, c = c0 + lc, i = (tid & 63) + 64 * (tid / (64 * NCH));
-        const uint32_t D = trflag[1 + lc] < SEG_NSP ? trflag[1 + lc] : SEG_NSP;
+        /* (the entry states of the workgroup's channels packed into its first lanes, like the distinct states of seg_enum_body) */
+        uint32_t Dc[NCH];
+        for (int k = 0; k < NCH; k++) Dc[k] = trflag[1 + k] < SEG_NSP ? trflag[1 + k] : SEG_NSP;
+        int lc = 0, i = tid;
+        uint32_t D = Dc[0];
+        PLS_UNROLL
+        for (int k = 0; k + 1 < NCH; k++) if (lc == k && (uint32_t)i >= Dc[k]) { i -= (int)Dc[k]; lc = k + 1; D = Dc[k + 1]; }
+        const int c = c0 + lc;
+        if (tid < NCH && (uint32_t)(c0 + tid) < bpp) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c0 + tid] = trflag[1 + tid] < SEG_NSP ? trflag[1 + tid] : SEG_NSP;
         if ((uint32_t)c < bpp && (uint32_t)i < D) {
             SegState st = seg_eh_state(uniq[lc * SEG_NSP + i]);
             const size_t slot = (((size_t)f * j.nseg + seg) * 4 + c) * SEG_NSP + i;
@@ -1140,7 +1147,6 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
             j.rout[slot] = (uint16_t)0;
             j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
         }
-        if ((uint32_t)c < bpp && i == 0) j.dcnt[((size_t)f * j.nseg + seg) * 4 + c] = D;
         if (prof && tid == 0 && !SEG_EXPERIMENT_REPLAY_CLOCKS) {
             te[3] = PLS_CLOCK(); te[4] = te[3];
             for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
