@@ -569,42 +569,49 @@ PLS_HD int seg_mul24(int a, int b)
     return a * b;
 #endif
 }
+PLS_HD bool seg_bad(int acc) { return ((uint32_t)acc >> 11) != 0u; }      /* what seg_step_fast accumulates: did any step leave the split table? */
 template <int F, bool TRX>
 PLS_HD uint32_t seg_step_fast(const SegPix &p, SegState &st, int &bad, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
 {
     /* TRX: the range holds a fully transparent pixel (optimize_state.c:158-164): only then the forced-alpha selects are compiled in.
-     * bad accumulates max(|filt| - fmax, |diff| - 255 ...) > 0 as a sign test: one max per quantity and step */
+     * bad accumulates (OR) the split table's offset of every step: seg_bad() tells whether one of them lay outside the table */
     const int orig = (int)(p.w & 255u), above = (int)((p.w >> 8) & 255u), diag = (int)((p.w >> 16) & 255u);
     const int pred = seg_predict_t<F>(above, diag, st.left);
     const int osym = seg_sext8(orig - pred), lo = osym - orig, hi = lo + 255;
     const int filt = osym + seg_sext16(p.e0 + st.cn);
-    const int neg = filt < 0 ? 1 : 0;
+    const int sgn = filt >> 31;                                 /* -1 for filt < 0 (arithmetic shift): selects the sign's tables by masking */
     /* the band of filt (optimize_state.c:186-193): [tq, tq + s] with tq = trunc(filt / q) * q for filt >= 0, [tq - s, tq] for filt < 0 -- the
      * truncating division SIGNED (the float reciprocal is exact for |filt| < 2^17, and symmetric), so that no |filt|, no negation and no select
-     * lie on the step's dependent path: three instructions less per step than through the absolute value */
+     * lie on the step's dependent path */
     const int tq = seg_mul24(seg_div_q(filt, g), g.q);
-    const int bandlo = tq - (neg ? g.s : 0), bandhi = bandlo + g.s;
+    const int bandlo = tq - (sgn & g.s), bandhi = bandlo + g.s;
     const int v0 = seg_max(bandlo, lo), v1 = seg_min(bandhi, hi);
-    const bool degen = v0 > v1;                                /* the whole band lies outside [lo, hi]: the clamp leaves lo or hi */
-    const int vd = bandhi < lo ? lo : hi;
+    const bool degen = v0 > v1;                                /* the whole band lies outside [lo, hi]: the clamp leaves lo (band below: v0 == lo) or hi */
+    const int vd = seg_min(v0, hi);
     const bool usesuf = v0 > bandlo;
     int key = usesuf ? v0 : v1;
-    key = seg_min(seg_max(key, -SEG_TOFF), SEG_TOFF - 1);
-    const uint32_t e = tw[(usesuf ? 2 * SEG_TN : 0) + neg * SEG_TN + key + SEG_TOFF];
-    const uint32_t c_os = (uint32_t)cls[neg * 256 + (osym & 255)];
+#if !defined(__HIP_DEVICE_COMPILE__)
+    key = seg_min(seg_max(key, -SEG_TOFF), SEG_TOFF - 1);      /* (only a degenerate band can point beyond the tables, and its entry is not used: on the device the read
+                                                                   beyond the workgroup's shared memory returns zero -- one instruction less per step) */
+#endif
+    const uint32_t e = tw[(usesuf ? 2 * SEG_TN : 0) + (sgn & SEG_TN) + key + SEG_TOFF];
+    const uint32_t c_os = (uint32_t)cls[(osym & 255) | (sgn & 256)];
     const int L = (int)(e & 0xffffu) - 1024;
     const bool tie = osym >= v0 && osym <= v1 && c_os == ((e >> 16) & 255u);
     int v = tie ? osym : L;
     v = degen ? vd : v;
-    int back = v - lo, diff = seg_sext16(filt - v), bin = v & 255;
+    int back = v - lo, d32 = filt - v, bin = v & 255;
     if (TRX) {
         const bool tr = (p.w >> 24) != 0;
-        back = tr ? 0 : back; diff = tr ? 0 : diff; bin = tr ? ((0 - pred) & 255) : bin;
+        back = tr ? 0 : back; d32 = tr ? 0 : d32; bin = tr ? ((0 - pred) & 255) : bin;
     }
-    const int ad = diff < 0 ? -diff : diff;
-    bad = seg_max(bad, ad - 255);                              /* > 0: outside what the split table covers (the decision tables cover every clamped band whatever filt is) */
-    const uint32_t le = lut[(diff + 256) & 511];
+    /* the split table covers diff in [-256, 255]: its byte offset is (4 * diff + 1024) & 0x7fc, and every bit of 4 * diff + 1024 above that, in any
+     * step, says that the lane left the table (seg_bad): one OR per step instead of an absolute value, a subtraction and a maximum */
+    const int t4 = (int)((uint32_t)d32 << 2) + 1024;
+    bad |= t4;
+    const uint32_t le = *(seg_lds_cu32)((seg_lds_cu8)lut + (t4 & 0x7fc));
     st.left = back; st.cn = seg_sext16((int)le) + st.th; st.th = (int)le >> 16;
+    const int diff = seg_sext16(d32);
     return seg_cand_pack(back, diff, bin);
 }
 
@@ -803,7 +810,7 @@ PLS_HD int seg_run_fast(const SegPix *px, int pstride, int n, SegState &st, seg_
         (void)seg_step_fast<F, TRX>(p, st, bad, tw, cls, g, lut);
         p = pn;
     }
-    return bad > 0;
+    return seg_bad(bad) ? 1 : 0;
 }
 template <bool TRX>
 PLS_HD int seg_run_fast_t(int f, const SegPix *px, int pstride, int n, SegState &st, seg_lds_cu32 tw, seg_lds_cu8 cls, const SegGeo &g, seg_lds_cu32 lut)
@@ -1247,7 +1254,7 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
         if (out) out[(size_t)(x - xa) * 4] = w;
         if (cnt) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(w)], 1u);
     }
-    if (bad > 0) {
+    if (seg_bad(bad)) {
         /* (rare) take the bumps back and do the range again by scanning */
         if (cnt && out) for (uint32_t x = xa; x < xe; x++) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(out[(size_t)(x - xa) * 4])], 0u - 1u);
         st = st0;
