@@ -835,8 +835,12 @@ PLS_HD int seg_run_fast_f(int f, bool trx, const SegPix *px, int pstride, int n,
  * hash table in shared memory (exact: full keys are compared), the distinct ones are packed into the first lanes of the channel and only
  * those run the remaining steps -- whole waves fall idle -- then every lane picks up the result of its representative. */
 #define SEG_K1 4                 /* steps before the dedupe when the state set comes in several chunks of SEG_NSP lanes */
-#define SEG_K1_ONE_CHUNK 2       /* ... when it fits one chunk (no more distinct states than lanes, whatever they are): measured on the headline frame,
-                                    steps before the dedupe 1 / 2 / 3 / 4 / 6 -> enumeration 20.6 (and the chain 15.9: too many distinct states) / 18.6 / 19.2 / 19.7 / 20.0 us */
+#ifndef SEG_K1_ONE_CHUNK
+#define SEG_K1_ONE_CHUNK 4       /* ... when it fits one chunk.  Measured on the headline frame (profiles/r04_enum_variants.txt), enumeration us for 1 / 2 / 3 / 4 / 6
+                                    steps before the dedupe: one wave per channel behind it 20.6 (and the chain 15.9: too many distinct states) / 18.6 / 19.2 / 19.7 / 20.0;
+                                    both channels packed into the first lanes (as shipped) - / 17.4 / 18.5 / 16.7 / 17.3 (5 steps: 16.9) -- after two steps the two
+                                    channels' ~35 + 35 distinct states no longer fit one wave, after four their ~17 + 17 do */
+#endif
 PLS_HD int seg_k1(int ns) { return ns <= SEG_NSP ? SEG_K1_ONE_CHUNK : SEG_K1; }
 #define SEG_HT 512
 template <int NT>
