@@ -40,7 +40,34 @@ ALGO_BYTES_PER_PIXEL = 8
 CPU_SAMPLE_ROWS = 1024         # cpu_baseline sample: the top 4096x1024 strip of the same frame
 BUILD_CONTAINER_REFERENCE_MPX = 0.515   # the reference, one thread, full 4096x4096 frame, build container
 BATCH_FRAMES, BATCH_W, BATCH_H = 256, 1920, 1080      # BASELINE.json configs[3]
-KERNEL_STATS = "r04_kernel_trace_stats.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r04_kernel_trace_stats.txt")) else "r03_kernel_trace_stats.txt"
+def _newest_profile(suffix):
+    for r in ("r05", "r04", "r03"):
+        if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{suffix}")):
+            return f"{r}_{suffix}"
+    return f"r03_{suffix}"
+
+
+KERNEL_STATS = _newest_profile("kernel_trace_stats.txt")
+PMC_TRAFFIC = _newest_profile("pmc_traffic.json")
+RANK_SHARES = (32, 64, 128)     # frames of configs[3] one rank holds at N = 8, 4, 2
+
+
+def profile_stamp(name):
+    """source_digest / head a committed profile was taken at (tools/gpu_round5.sh writes them into the file's first lines; round <= 4 files have none)."""
+    out = {"file": "profiles/" + name, "source_digest": None, "head": None}
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            txt = fh.read(4096)
+        import re
+        m = re.search(r"source_digest[=\":\s]+([0-9a-f]{16})", txt)
+        if m:
+            out["source_digest"] = m.group(1)
+        m = re.search(r"head[=\":\s]+([0-9a-f]{7,40}(?:-dirty)?)", txt)
+        if m:
+            out["head"] = m.group(1)
+    except OSError:
+        pass
+    return out
 
 
 def _ref_worker(frame_index):
@@ -61,6 +88,27 @@ def _ref_worker(frame_index):
     t = time.perf_counter()
     rc = fn(rows, w, h, filt.ctypes.data, False, STRENGTH, BLEED)
     return rc, w * h, time.perf_counter() - t
+
+
+def _full_frame_worker(q):
+    """The REAL reference (or the port), one thread, on the FULL 4096x4096 frame the metric is quoted on (~18 s of host time): started before the GPU
+    batch legs and collected behind them, so that it adds nothing to the wall clock of the default run."""
+    import numpy as np
+    import pngloss_amd as P
+    sig = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libpngloss_ref.so")
+    if os.path.exists(ref_path):
+        lib = C.CDLL(ref_path); fn = lib.optimize_with_rows; kind = "reference"
+    else:
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "libpngloss_port.so")); fn = lib.port_optimize_with_rows; kind = "port"
+    fn.argtypes = sig; fn.restype = C.c_int
+    buf = P.synth_rgba(W, H, MODE, 0)
+    filt = np.zeros(H, np.uint8)
+    rows = (C.c_void_p * H)(*[buf.ctypes.data + y * W * 4 for y in range(H)])
+    t = time.perf_counter()
+    rc = fn(rows, W, H, filt.ctypes.data, False, STRENGTH, BLEED)
+    dt = time.perf_counter() - t
+    q.put(dict(rc=rc, seconds=dt, kind=kind, out="%016x" % P.fnv1a64(buf, P.SURVEY_FNV_BASIS), filters="%016x" % P.fnv1a64(filt, P.SURVEY_FNV_BASIS)))
 
 
 def _warm_worker(i):
@@ -213,6 +261,18 @@ def bandwidth_kernels():
     return out
 
 
+def _known_1080p():
+    """frame -> reference digests of configs[3] frames (tests/golden/digests.json: 0, 1, 255; digests_1080p.json: twenty more)"""
+    try:
+        from tests import util as TU
+        return TU.load_digests_1080p()
+    except Exception:
+        return {}
+
+
+BATCH_KNOWN = _known_1080p() or {0: None, 1: None, 255: None}
+
+
 def run_batch(P, S, torch, ctx_factory, rank, world, local_rank, barrier):
     """BASELINE.json configs[3]: 256 x 1920x1080 frames over `world` ranks, one device-resident batch per rank."""
     mine = S.contiguous_partition(BATCH_FRAMES, world)[rank]
@@ -231,7 +291,7 @@ def run_batch(P, S, torch, ctx_factory, rank, world, local_rank, barrier):
     recs = []
     for i, d, f, r in zip(mine, dev, filt, res):
         rec = dict(index=i, status=r["status"])
-        if i in (0, 1, 255):
+        if i in BATCH_KNOWN:
             rec["out"] = "%016x" % P.fnv1a64(d.cpu().numpy(), P.SURVEY_FNV_BASIS)
             rec["filters"] = "%016x" % P.fnv1a64(f.cpu().numpy(), P.SURVEY_FNV_BASIS)
         recs.append(rec)
@@ -308,6 +368,42 @@ def run_suite_batch(P, torch, ctx_factory, golden):
             "all_digests_match_reference": all(p["digests_match_reference"] for p in per)}
 
 
+def run_rank_shares(P, torch, ctx_factory, want):
+    """What ONE rank of a node holds of BASELINE.json configs[3] at N = 8, 4, 2 -- the first 32, 64, 128 of the 256 frames -- as one device-resident
+    batch on THIS GPU, best of two runs each; digests of every frame of the share the real reference has digests for.  The caller turns the rates
+    into `projected_strong_scaling` = N x rate(256 / N frames) / rate(256 frames): what configs[3] can gain from N GPUs if nothing else gets in
+    the way (the N-GPU run itself is the driver's)."""
+    nmax = max(RANK_SHARES)
+    base = [torch.from_numpy(P.synth_rgba(BATCH_W, BATCH_H, MODE, i)).cuda() for i in range(nmax)]
+    ctx = ctx_factory()
+    stream = torch.cuda.current_stream().cuda_stream
+    out = []
+    for n in RANK_SHARES:
+        best = None
+        for rep in range(2):
+            dev = [b.clone() for b in base[:n]]
+            filt = [torch.zeros(BATCH_H, dtype=torch.uint8, device="cuda") for _ in dev]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = ctx.run([(d.data_ptr(), f.data_ptr(), BATCH_W, BATCH_H) for d, f in zip(dev, filt)], STRENGTH, BLEED, stream=stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, ctx.engine_ms, dev, filt, res, ctx.engine_info(0), ctx.engine_info(n - 1))
+        dt, eng, dev, filt, res, info0, info1 = best
+        known = [i for i in range(n) if i in want]
+        ok = all(r["status"] == 0 for r in res) and all(
+            "%016x" % P.fnv1a64(dev[i].cpu().numpy(), P.SURVEY_FNV_BASIS) == want[i]["out"] and "%016x" % P.fnv1a64(filt[i].cpu().numpy(), P.SURVEY_FNV_BASIS) == want[i]["filters"] for i in known)
+        out.append({"frames": n, "n_gpus_it_stands_for": BATCH_FRAMES // n, "value": round(n * BATCH_W * BATCH_H / dt / 1e6, 2), "seconds": round(dt, 4),
+                    "engine_ms": round(eng, 2), "engine": info0["engine"] if info0["engine"] == info1["engine"] else "mixed", "attempts": info0["attempts"],
+                    "digests_match_reference": bool(ok), "digests_checked_frames": known})
+        del dev, filt
+    ctx.close()
+    del base
+    torch.cuda.empty_cache()
+    return out
+
+
 SAT_FRAMES_PER_RANK, SAT_DISTINCT = 512, 32
 
 
@@ -346,6 +442,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the configs[3] batch leg and the saturating batch leg")
+    ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: only the 4096x1024 strip, not the full 4096x4096 frame (the full frame is ~18 s of ONE host core, run beside the GPU batch legs)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the configs[4] sweep (8192x8192, 12 points) and the configs[2] suite batch (rank 0, N = 1 only)")
     args = ap.parse_args()
 
@@ -428,9 +525,19 @@ def main():
         print(f"bench.py: record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
         records = rec if rank == 0 else rec
 
+    # ---- cpu_baseline on the configuration the metric is quoted on: the reference on the FULL frame, one host core, beside the GPU legs below ----
+    full_proc = full_q = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_full_frame:
+        import multiprocessing as mp
+        mpc = mp.get_context("spawn")       # (not fork: this process holds a HIP context)
+        full_q = mpc.Queue()
+        full_proc = mpc.Process(target=_full_frame_worker, args=(full_q,), daemon=True)
+        full_proc.start()
+
     # ---- the image-batch leg (BASELINE.json configs[3]); outside the timed region of `value` ----
     batch = None
     batch_sat = None
+    shares = None
     if not args.no_batch:
         del work, filt
         torch.cuda.empty_cache()
@@ -455,6 +562,12 @@ def main():
             print(f"bench.py: saturating batch record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
             sall = [dict(index=rank, engine_ms=seng, recs=srecs, engine=sinfo)]
         batch_sat = (float(ts.item()), sall)
+        if rank == 0 and world == 1:
+            want1080 = {k: v for k, v in BATCH_KNOWN.items() if v}
+            try:
+                shares = run_rank_shares(P, torch, lambda: P.HipContext(local_rank), want1080)
+            except Exception as exc:          # never lose the headline to a side leg
+                shares = {"error": repr(exc)}
 
     if rank == 0:
         golden = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -466,8 +579,7 @@ def main():
         achieved = ALGO_BYTES_PER_PIXEL * px / (eng_ms * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch from the last committed rocprofv3 PMC passes (tools/pmc_to_json.py)
         try:
-            tj = [f for f in ("r04_pmc_traffic.json", "pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
-            traffic = json.load(open(os.path.join(ROOT, "profiles", tj)))["traffic_bytes"]
+            traffic = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)))["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
         line = {
@@ -494,9 +606,19 @@ def main():
                                                  "left in series is H row attempts of four dependent launches each; the exact validation of an attempt runs next to the control kernel of the next one (the decision is optimistic, a failed validation voids the attempt under way)"},
                          "note": "bound by the row-to-row dependency chain (DESIGN.md), not by HBM; algorithmic bytes = 8 B/px * 16.78 Mpx = 134.2 MB "
                                  "per engine run, measured with HIP events around the engine's launches on the launch stream; traffic = "
-                                 "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (static: the committed profiles/r04_pmc_traffic.json, not measured by this invocation)"},
+                                 "FETCH_SIZE*2 + WRITE_SIZE of separate rocprofv3 --pmc passes (static: the committed profiles/" + PMC_TRAFFIC + ", not measured by this invocation)"},
             "bandwidth_kernels": bandwidth_kernels(),
         }
+        # the static blocks above quote committed profiles: say what code they were taken at, and whether that is the code running now
+        cur = P.source_digest()
+        stamps = [profile_stamp(KERNEL_STATS), profile_stamp(PMC_TRAFFIC)]
+        line["static_profiles"] = {"current_source_digest": cur, "files": stamps,
+                                   "stale": [st["file"] for st in stamps if st["source_digest"] != cur],
+                                   "note": "source_digest = sha256 over pngloss_amd/csrc/*.{hip,h,c} (pngloss_amd.source_digest); a file listed under `stale` was profiled at other "
+                                           "kernel sources than the ones this line was measured with (round <= 4 profiles carry no stamp and always count as stale)"}
+        line["static_profile_head"] = stamps[0]["head"]
+        if line["static_profiles"]["stale"]:
+            print("bench.py: WARNING: static profile blocks come from other sources than this tree: %s" % ", ".join(line["static_profiles"]["stale"]), file=sys.stderr)
         line["transfers"] = {"h2d_ms": round(h2d_ms, 3), "d2h_ms": round(d2h_ms, 3), "bytes_each_way": W * H * 4,
                              "note": "pinned 64 MiB frame over PCIe, outside the timed region; with both legs one step "
                                      "would take %.1f ms" % (elapsed_max / args.steps * 1e3 + h2d_ms + d2h_ms)}
@@ -515,7 +637,20 @@ def main():
             except Exception as exc:          # informational only
                 line["write_side"] = {"error": repr(exc)}
             line["cpu_baseline"] = cpu_baseline(frame)
-            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)
+            line["speedup_vs_cpu_baseline_strip"] = round(value / line["cpu_baseline"]["value"], 2)
+            line["speedup_vs_cpu_baseline"] = line["speedup_vs_cpu_baseline_strip"]
+            if full_proc is not None:
+                try:
+                    ff = full_q.get(timeout=180)
+                    full_proc.join(timeout=10)
+                    assert ff["rc"] == 0
+                    fv = W * H / ff["seconds"] / 1e6
+                    line["cpu_baseline"]["full_frame"] = {"value": round(fv, 4), "unit": "Mpixels/s", "cores": 1, "kind": ff["kind"], "seconds": round(ff["seconds"], 2),
+                                                          "sample": f"the whole {W}x{H} frame the metric is quoted on, s={STRENGTH} b={BLEED}, one thread, run beside the GPU batch legs of this invocation",
+                                                          "digests_match_reference": ff["out"] == g["out"] and ff["filters"] == g["filters"]}
+                    line["speedup_vs_cpu_baseline"] = round(value / fv, 2)          # the like-for-like ratio: full frame against full frame
+                except Exception as exc:          # informational only
+                    line["cpu_baseline"]["full_frame"] = {"error": repr(exc)}
             line["speedup_vs_build_container_reference"] = round(value / BUILD_CONTAINER_REFERENCE_MPX, 2)
         if world == 1 and not args.no_sweep:
             for key, fn in (("suite_batch", run_suite_batch), ("sweep_8192", run_sweep_8192)):
@@ -526,6 +661,7 @@ def main():
         if batch is not None:
             bt, brecs, engs = batch
             want = {e["frame"]: e for e in golden["synthetic"] if (e["width"], e["height"]) == (BATCH_W, BATCH_H)}
+            want.update({k: v for k, v in BATCH_KNOWN.items() if v})
             checked = [r for r in brecs if "out" in r]
             line["batch"] = {"workload": f"BASELINE.json configs[3]: {BATCH_FRAMES} synthetic {BATCH_W}x{BATCH_H} RGBA8 frames, s={STRENGTH} b={BLEED}, "
                                          f"contiguous split over {world} GPU(s), one device-resident batch per rank (strong scaling of a fixed batch)",
@@ -534,6 +670,17 @@ def main():
                              "all_status_ok": all(r["status"] == 0 for r in brecs) and len(brecs) == BATCH_FRAMES,
                              "digests_match_reference": bool(checked) and all(r["out"] == want[r["index"]]["out"] and r["filters"] == want[r["index"]]["filters"] for r in checked),
                              "digests_checked_frames": [r["index"] for r in checked]}
+        if shares is not None and batch is not None:
+            r256 = BATCH_FRAMES * BATCH_W * BATCH_H / batch[0] / 1e6
+            if isinstance(shares, list):
+                line["batch_rank_share"] = {"workload": f"the share ONE rank holds of BASELINE.json configs[3] at N = 8 / 4 / 2: the first 32 / 64 / 128 of its {BATCH_FRAMES} frames ({BATCH_W}x{BATCH_H}, s={STRENGTH} b={BLEED}) "
+                                                        "as one device-resident batch on this GPU, best of 2", "unit": "Mpixels/s", "shares": shares, "rate_256_frames_one_gpu": round(r256, 2),
+                                            "projected_strong_scaling": {str(BATCH_FRAMES // sh["frames"]): round(BATCH_FRAMES // sh["frames"] * sh["value"] / r256, 2) for sh in shares},
+                                            "all_digests_match_reference": all(sh["digests_match_reference"] for sh in shares),
+                                            "note": "projected_strong_scaling[N] = N x rate(256/N frames on one GPU) / rate(256 frames on one GPU): the speed-up configs[3] can get from N GPUs "
+                                                    "(image-level sharding, no data-path collective), measured on ONE GPU; the N-GPU run is the driver's"}
+            else:
+                line["batch_rank_share"] = shares
         if batch_sat is not None:
             st, sall = batch_sat
             want = {e["frame"]: e for e in golden["synthetic"] if (e["width"], e["height"]) == (BATCH_W, BATCH_H)}

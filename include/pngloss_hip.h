@@ -241,7 +241,9 @@ typedef struct {
 int pngloss_hip_png_decode_batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n);
 /* The same with a status per image (status: n ints or NULL): every image is decoded and downloaded whatever happens to the others, a damaged
  * one gets 25 in its slot (an internal failure PNGLOSS_HIP_ERROR) and the call returns the worst code -- the reference, too, fails only the
- * damaged file (/root/reference/src/pngloss.c:196-204).  Not while a batch is in flight on the context (PNGLOSS_INVALID_ARGUMENT). */
+ * damaged file (/root/reference/src/pngloss.c:196-204).  Not while a batch is in flight on the context (PNGLOSS_INVALID_ARGUMENT).
+ * A failure of the batch AS A WHOLE (bad argument, allocation, copy, launch, device fault: nothing was decoded) puts the call's return value
+ * into EVERY status[i] (and NULL into every d_rgba[i] of the device forms): status[i] == 0 always means "image i is decoded". */
 int pngloss_hip_png_decode_batch_host_status(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status);
 
 /* DEVICE-RESIDENT hand-over ("fuse with K0"): the same decode, but the RGBA8 images STAY in device memory -- in a frame
@@ -260,7 +262,7 @@ int pngloss_hip_png_decode_batch_device(pngloss_hip_ctx *ctx, const pngloss_hip_
  * filters + transformations); what goes up is the file's compressed bytes, what comes out stays on the device.
  *   zstream   the concatenated payloads of the file's IDAT chunks (one zlib stream), zbytes of them
  * A stream the device inflater does not take (damaged, preset dictionary, size mismatch ...) gets status 25 and the call returns 25: read that
- * file on the host.  One wave decodes ~3 MB/s (profiles/r04_read_side.txt; zlib: ~250 MB/s per host thread): this pays only when a call brings well over
+ * file on the host (so does a stream shorter than 6 bytes or beyond 4 GiB -- that file only).  One wave decodes ~3 MB/s (profiles/r04_read_side.txt; zlib: ~250 MB/s per host thread): this pays only when a call brings well over
  * a thousand files; otherwise use the scanline form above, with zlib on host threads. */
 typedef struct {
     const unsigned char *zstream;

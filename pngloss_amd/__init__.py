@@ -12,6 +12,7 @@ from .lib import (  # noqa: F401
     HipContext,
     HipMulti,
     multi_split,
+    source_digest,
     build,
     hip_lib,
     optimize_with_rows,
@@ -23,6 +24,6 @@ from .lib import (  # noqa: F401
 from .synth import SURVEY_FNV_BASIS, fnv1a64, synth_rgba  # noqa: F401
 
 __all__ = [
-    "PNG_FILTER_FLAGS", "HipContext", "HipMulti", "multi_split", "build", "hip_lib", "synth_lib", "optimize_with_rows", "optimize_with_stride",
+    "PNG_FILTER_FLAGS", "HipContext", "HipMulti", "multi_split", "source_digest", "build", "hip_lib", "synth_lib", "optimize_with_rows", "optimize_with_stride",
     "optimize_for_average_filter", "optimize_image", "synth_rgba", "fnv1a64", "SURVEY_FNV_BASIS",
 ]

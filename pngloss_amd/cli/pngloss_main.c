@@ -429,8 +429,12 @@ static void decode_window_on_device(struct job *jobs, size_t n, const struct opt
         if (!st && rc == PNGLOSS_SUCCESS) rc = PNGLOSS_OUT_OF_MEMORY_ERROR;
         int brc = rc;
         if (rc == PNGLOSS_SUCCESS) brc = pngloss_hip_png_decode_batch_host_status(g_read_ctx, src, m, st);
+        /* a failure of the batch as a whole arrives in every st[q] (pngloss_hip.h); a return code that no st[q] explains is treated the same
+         * way -- never take a file for decoded on the strength of st[q] == 0 alone */
+        int explained = 0;
+        for (size_t q = 0; q < k && rc == PNGLOSS_SUCCESS; q++) if (st[q]) explained = 1;
         for (size_t q = 0; q < k; q++) {
-            const int one = rc != PNGLOSS_SUCCESS ? rc : (st[q] ? st[q] : ((brc != PNGLOSS_SUCCESS && brc != 25 && brc != PNGLOSS_HIP_ERROR) ? brc : PNGLOSS_SUCCESS));
+            const int one = rc != PNGLOSS_SUCCESS ? rc : (st[q] ? st[q] : ((brc != PNGLOSS_SUCCESS && !explained) ? brc : PNGLOSS_SUCCESS));
             if (one != PNGLOSS_SUCCESS) { say(&jobs[who[q]], "  error: cannot decode image %s on the GPU (%d)\n", leaf(jobs[who[q]].in_name), one); jobs[who[q]].status = (pngloss_error)one; }
         }
         free(src); free(who); free(st);

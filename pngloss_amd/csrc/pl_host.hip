@@ -1154,12 +1154,15 @@ namespace {
  * from the workspace the optimiser carves up), and d_out[i] receives their device pointers. */
 /* zs != nullptr: src[i].scanlines is not used; the scanlines are INFLATED ON THE DEVICE from zs[i] (the concatenated IDAT payloads), one wave per file */
 struct ZRef { const unsigned char *z; size_t bytes; };
-int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status, void **d_out, hipStream_t stream, const ZRef *zs = nullptr)
+/* per_image: set once the batch as a whole went through -- from there on the return value is the worst PER-IMAGE status and status[] explains it.
+ * A return before that point is a failure of the WHOLE batch (bad argument, allocation, copy, launch, device fault): png_decode_common then
+ * writes that code into every status[i], so that a caller who looks at status[] alone never takes an undecoded image for a decoded one. */
+int png_decode_body(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status, void **d_out, hipStream_t stream, const ZRef *zs, bool &per_image)
 {
     if (!ctx || (!src && n)) return PNGLOSS_INVALID_ARGUMENT;
     if (status) for (size_t i = 0; i < n; i++) status[i] = PNGLOSS_SUCCESS;
     if (d_out) for (size_t i = 0; i < n; i++) d_out[i] = nullptr;
-    if (!n) return PNGLOSS_SUCCESS;
+    if (!n) { per_image = true; return PNGLOSS_SUCCESS; }
     if (ctx->pending) {
         /* (the workspace this call carves up belongs to the batch in flight) */
         std::fprintf(stderr, "pngloss_hip: a batch is in flight on this context; call pngloss_hip_finish first\n");
@@ -1168,11 +1171,17 @@ int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, s
     PL_CHECK(hipSetDevice(ctx->device));
     std::vector<PrJob> jobs(n);
     std::vector<size_t> raw_off(n), out_off(n), last_off(n), prog_off(n), z_off(n);
+    static const unsigned char bad_stream[6] = { 0, 0, 0, 0, 0, 0 };       /* (CMF 0: not deflate) */
+    std::vector<ZRef> zsub(zs ? n : 0);
     uint32_t max_bands = 0;
     size_t total = align_up(sizeof(PrJob) * n, 256) + 2 * align_up(sizeof(int32_t) * n, 256) + align_up(sizeof(PliStream) * n, 256), ftotal = 0;
     const size_t jobs_bytes = align_up(sizeof(PrJob) * n, 256), st_bytes = align_up(sizeof(int32_t) * n, 256);
     for (size_t i = 0; i < n; i++) {
-        if ((!zs && !src[i].scanlines) || (zs && (!zs[i].z || zs[i].bytes < 6 || zs[i].bytes > 0xFFFFFFF0u)) || (!d_out && !src[i].rgba)) return PNGLOSS_INVALID_ARGUMENT;
+        if ((!zs && !src[i].scanlines) || (zs && !zs[i].z) || (!d_out && !src[i].rgba)) return PNGLOSS_INVALID_ARGUMENT;
+        /* a stream too short to be zlib's (header + one block + Adler-32) or beyond the inflater's 32-bit positions is THAT file's problem: it gets
+         * status 25 like any other stream the inflater refuses (it is handed a six-byte stream with an invalid header), the batch goes on */
+        if (zs && (zs[i].bytes < 6 || zs[i].bytes > 0xFFFFFFF0u)) zsub[i] = ZRef{ bad_stream, sizeof bad_stream };
+        else if (zs) zsub[i] = zs[i];
         if (!pr_format(jobs[i].F, src[i].width, src[i].height, src[i].color_type, src[i].bit_depth, src[i].palette, src[i].palette_entries, src[i].trns, src[i].trns_bytes)) {
             std::fprintf(stderr, "pngloss_hip: image %zu: colour type %d with bit depth %d (or an empty image / a palette image without PLTE) is not a PNG format\n", i, src[i].color_type, src[i].bit_depth);
             return PNGLOSS_INVALID_ARGUMENT;
@@ -1180,7 +1189,7 @@ int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, s
         raw_off[i] = total; total += align_up(((size_t)jobs[i].F.rowbytes + 1) * src[i].height, 256);
         if (zs) {
             if (((size_t)jobs[i].F.rowbytes + 1) * src[i].height > 0xFFFFFFF0u) return PNGLOSS_INVALID_ARGUMENT;     /* (32-bit positions in the inflater) */
-            z_off[i] = total; total += align_up(zs[i].bytes + 16, 256);
+            z_off[i] = total; total += align_up(zsub[i].bytes + 16, 256);
         }
         const size_t out_bytes = align_up((size_t)src[i].width * src[i].height * 4, 256);
         if (d_out) { out_off[i] = ftotal; ftotal += out_bytes; } else { out_off[i] = total; total += out_bytes; }
@@ -1217,8 +1226,8 @@ int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, s
         jobs[i].status = d_status + i;
         /* (from pinned memory -- pngloss_hip_pinned_alloc -- this is one DMA; from pageable memory the runtime stages it: 33 ms against 1.3 for 64 MiB) */
         if (zs) {
-            PL_CHECK(hipMemcpyAsync(b + z_off[i], zs[i].z, zs[i].bytes, hipMemcpyHostToDevice, stream));
-            zjobs[i].z = reinterpret_cast<const uint8_t *>(b + z_off[i]); zjobs[i].zbytes = (uint32_t)zs[i].bytes;
+            PL_CHECK(hipMemcpyAsync(b + z_off[i], zsub[i].z, zsub[i].bytes, hipMemcpyHostToDevice, stream));
+            zjobs[i].z = reinterpret_cast<const uint8_t *>(b + z_off[i]); zjobs[i].zbytes = (uint32_t)zsub[i].bytes;
             zjobs[i].out = reinterpret_cast<uint8_t *>(b + raw_off[i]); zjobs[i].expect = (uint32_t)(((size_t)jobs[i].F.rowbytes + 1) * src[i].height);
             zjobs[i].status = d_zstatus + i;
         } else
@@ -1243,6 +1252,7 @@ int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, s
     PL_CHECK(hipStreamSynchronize(stream));
     if (seam_dbg) std::fprintf(stderr, "pngloss_hip: read side: %zu files, workspace %zu MB ready after %.1f ms, upload %.1f ms, unfilter + expand %.1f ms, %s %.1f ms\n", n, (total + ftotal) >> 20, ms_ws, ms_up - ms_ws, ms_k - ms_up, d_out ? "status (the frames stay on the device)" : "download", ms_since() - ms_k);
     /* every image has been decoded (and downloaded); the ones that failed say so -- one damaged file does not take the window with it */
+    per_image = true;
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < n; i++) {
         if (d_out) d_out[i] = fb + out_off[i];
@@ -1261,6 +1271,17 @@ int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, s
         if (worst == PNGLOSS_SUCCESS || code == PNGLOSS_HIP_ERROR) worst = code;
     }
     return worst;
+}
+int png_decode_common(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, size_t n, int *status, void **d_out, hipStream_t stream, const ZRef *zs = nullptr)
+{
+    bool per_image = false;
+    const int rc = png_decode_body(ctx, src, n, status, d_out, stream, zs, per_image);
+    if (!per_image && rc != PNGLOSS_SUCCESS) {
+        /* the batch as a whole failed: nothing in rgba / d_out is a decoded image */
+        if (status) for (size_t i = 0; i < n; i++) status[i] = rc;
+        if (d_out) for (size_t i = 0; i < n; i++) d_out[i] = nullptr;
+    }
+    return rc;
 }
 } // namespace
 extern "C" {

@@ -102,7 +102,7 @@ PLI_HD bool pli_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *fir
     cnt[0] = 0;
     int left = 1, total = 0;
     for (int l = 1; l < 16; l++) { left = (left << 1) - (int)cnt[l]; if (left < 0) return false; total += cnt[l]; }
-    if (left > 0 && !(single_ok && total <= 1)) return false;
+    if (left > 0 && !(single_ok && (total == 0 || (total == 1 && cnt[1] == 1)))) return false;     /* zlib's inftrees.c: an incomplete set passes only as no code at all or ONE code of length 1 */
     uint32_t code = 0; uint16_t o = 0;
     fst[0] = 0; off[0] = 0;
     for (int l = 1; l < 16; l++) { code = (code + cnt[l - 1]) << 1; fst[l] = (uint16_t)code; off[l] = o; o = (uint16_t)(o + cnt[l]); }
@@ -456,7 +456,11 @@ PLI_HD void pli_inflate(const PliStream &st, PliShared &S)
                 {
                     const uint32_t len = S.tok[1], dist = S.tok[2];
                     PLI_LANES(lane) {
-                        if (dist >= len) { for (uint32_t k = (uint32_t)lane; k < len; k += PLI_NL) S.win[(pos + k) & (PLI_WIN - 1)] = S.win[(pos - dist + k) & (PLI_WIN - 1)]; }
+                        /* dist + len beyond the window: slot (pos + k) & mask of a late byte IS the source slot of an earlier one (zlib never emits
+                         * such a match -- its distances end at 32506 --, libdeflate and zopfli do).  The wave's lock step would still read before it
+                         * writes, the host harness (a lane after the other) would not: one lane copies in order, which is LZ77's own definition */
+                        if (dist + len > PLI_WIN) { if (lane == 0) for (uint32_t k = 0; k < len; k++) S.win[(pos + k) & (PLI_WIN - 1)] = S.win[(pos - dist + k) & (PLI_WIN - 1)]; }
+                        else if (dist >= len) { for (uint32_t k = (uint32_t)lane; k < len; k += PLI_NL) S.win[(pos + k) & (PLI_WIN - 1)] = S.win[(pos - dist + k) & (PLI_WIN - 1)]; }
                         else { for (uint32_t k = (uint32_t)lane; k < len; k += PLI_NL) S.win[(pos + k) & (PLI_WIN - 1)] = S.win[(pos - dist + (k % dist)) & (PLI_WIN - 1)]; }
                     }
                     PLI_SYNC();

@@ -2,14 +2,14 @@
  * pl_seg.hip -- kernels and launcher of the SEGMENT-PARALLEL row engine: one image spread over the whole MI355X.
  *
  * The algorithm, its proof obligation (the validation pass) and the kernel bodies live in pl_seg_core.h, which is also compiled
- * for the CPU by tests/c/seg_host.cpp.  Here: the five gfx950 kernels of one row attempt, blockIdx.y = image of the batch,
+ * for the CPU by tests/c/seg_host.cpp.  Here: the four gfx950 kernels of one row attempt, blockIdx.y = image of the batch,
  *
  *   seg_k_ctl     5 x 4 candidate workgroups (each a quarter of a candidate's decision tables) + 1 image-wide + W/256 commit workgroups
  *   seg_k_enum    3 x nseg x 2 workgroups of 512 lanes (a channel pair x 256 chain states; 1024 lanes = 4 channels for large batches) for the
  *                 filters that look at the left pixel, 2 x nseg/8 for none / up, 5 first-segment walkers; tables + pixel records in LDS
  *   seg_k_chain   5 x 4 workgroups, a row's dense transition tables (linked: an entry is the index of the next table's entry) and exit states in LDS (up to 149 KB of the CU's 160 KB)
  *   seg_k_replay  5 x ngrp workgroups: lane = (segment, quarter, channel), 8 steps each from the enumeration's checkpoints
- *   seg_k_post    5 x 2 ngrp workgroups of 1024 lanes: exact validation of every decision + the row cost sums
+ *   (the exact validation of every decision -- seg_post_body, 5 x 2 ngrp workgroups of 1024 lanes -- rides in seg_k_ctl's launch, one attempt behind)
  *
  * and no grid barrier anywhere: consecutive kernels on one stream are the grid-wide synchronisation (1.5-2 us on this machine
  * against 4-7 us for a hand-made in-kernel barrier across 8 XCDs, /opt/skills/guides/MI355X_MICROARCH.md), and every piece of
@@ -206,16 +206,16 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     const int par = attempt % 3;                               /* which copy of the control block / sums / histogram / prefix bumps the attempt writes */
     const unsigned n = (unsigned)b.n;
     {
-        static const bool no_val = getenv("PNGLOSS_HIP_EXPERIMENT_NO_VALIDATION") != nullptr;   /* TIMING EXPERIMENT ONLY (results are not validated: wrong where a row would have failed): what the control workgroups take alone */
-        const unsigned nctl = SEG_CTL_IMG + 1 + b.max_ncommit, nval = no_val ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
+        /* (the validation workgroups can be left out at COMPILE time only -- SEG_EXPERIMENT_NO_VAL_CODE, a timing experiment whose results are unvalidated;
+         *  the shipped library has no run-time switch that changes what it computes) */
+        const unsigned nctl = SEG_CTL_IMG + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
         hipLaunchKernelGGL(seg_k_ctl, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
     }
     {
         const bool small_ok = b.small_ok;
         const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
-        static const bool enum_lds_bound = getenv("PNGLOSS_HIP_ENUM_LDS") != nullptr;   /* experiment: the generous bound (3 workgroups of 512 per CU) */
-        const size_t enum_lds = enum_lds_bound ? (size_t)SEG_SM_ENUM : (size_t)SEG_SM_ENUM_NT(nt);
+        const size_t enum_lds = (size_t)SEG_SM_ENUM_NT(nt);
         if (b.seeded) {
             const unsigned sblocks = SEG_NFILT * b.max_nseg * halves + SEG_NFILT;
             if (nt == 512) hipLaunchKernelGGL(seg_k_enum_seeded<512>, dim3(sblocks, n), dim3(512), (size_t)SEG_SM_ENUM_SEEDED(512), stream, b.d_sj, b.d_params, par, b.max_nseg);

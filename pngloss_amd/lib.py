@@ -473,6 +473,21 @@ class HipContext:
         return h
 
 
+def source_digest():
+    """16 hex digits over the text of every kernel / host source of the library (csrc/*.hip, *.h, *.c, sorted by name): what a committed profile was
+    taken AT.  tools/gpu_round5.sh stamps every profiles/r05_* file with it and bench.py compares the stamp of the static blocks it quotes with
+    the tree it runs from (no .git travels to the GPU box, a content digest does)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".c")):
+            h.update(name.encode() + b"\0")
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def multi_split(shapes, parts):
     """pngloss_hip_multi_split (the C host's LPT split) for a list of (width, height); returns owner indices.  No GPU needed."""
     lib = hip_lib()

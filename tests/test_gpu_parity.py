@@ -763,3 +763,69 @@ def test_engine_option_of_the_abi_pins_the_row_engine(torch_cuda, monkeypatch):
     lib = P.hip_lib()
     assert lib.pngloss_hip_set_option(ctx._ctx, b"engine", b"fastest") == 4 and lib.pngloss_hip_set_option(ctx._ctx, b"colour", b"seg") == 4
     ctx.close()
+
+
+def _configs3_frames(indices):
+    return [P.synth_rgba(1920, 1080, 0, i) for i in indices]
+
+
+def test_configs3_all_256_frames_in_one_batch_match_reference_digests(torch_cuda):
+    """BASELINE.json configs[3] as the TEST SUITE exercises it: all 256 frames of 1920x1080 (generator mode 0, frame = 0..255) in ONE device-resident
+    batch at s=19 b=2, the library's own choice of engine; every status 0, and pixels + filter IDs of the 23 frames whose digests the real reference
+    gave (tests/golden/digests.json, digests_1080p.json) equal to them."""
+    torch = torch_cuda
+    want = U.load_digests_1080p()
+    assert len(want) >= 8
+    dev, filt = [], []
+    for i in range(256):
+        dev.append(torch.from_numpy(P.synth_rgba(1920, 1080, 0, i)).cuda())
+        filt.append(torch.zeros(1080, dtype=torch.uint8, device="cuda"))
+    ctx = P.HipContext()
+    res = ctx.run([(d.data_ptr(), f.data_ptr(), 1920, 1080) for d, f in zip(dev, filt)], 19, 2)
+    torch.cuda.synchronize()
+    assert len(res) == 256 and all(r["status"] == 0 and r["bpp"] == 4 for r in res)
+    for i, e in sorted(want.items()):
+        assert "%016x" % P.fnv1a64(dev[i].cpu().numpy(), P.SURVEY_FNV_BASIS) == e["out"], i
+        assert "%016x" % P.fnv1a64(filt[i].cpu().numpy(), P.SURVEY_FNV_BASIS) == e["filters"], i
+    ctx.close()
+
+
+@pytest.mark.parametrize("share", [32, 64])
+def test_configs3_rank_shares_match_reference_digests(torch_cuda, share):
+    """What ONE rank of an N = 8 / N = 4 node gets of configs[3] (shard.contiguous_partition: 32 / 64 consecutive frames), run here as the LAST rank's
+    share (it holds frame 255 and four or five more frames with reference digests) and as the FIRST rank's."""
+    torch = torch_cuda
+    from pngloss_amd import shard as S
+    want = U.load_digests_1080p()
+    parts = S.contiguous_partition(256, 256 // share)
+    ctx = P.HipContext()
+    for mine in (parts[-1], parts[0]):
+        dev = [torch.from_numpy(P.synth_rgba(1920, 1080, 0, i)).cuda() for i in mine]
+        filt = [torch.zeros(1080, dtype=torch.uint8, device="cuda") for _ in mine]
+        res = ctx.run([(d.data_ptr(), f.data_ptr(), 1920, 1080) for d, f in zip(dev, filt)], 19, 2)
+        torch.cuda.synchronize()
+        assert all(r["status"] == 0 for r in res)
+        known = [i for i in mine if i in want]
+        assert len(known) >= 3
+        for i in known:
+            k = i - mine[0]
+            assert "%016x" % P.fnv1a64(dev[k].cpu().numpy(), P.SURVEY_FNV_BASIS) == want[i]["out"], i
+            assert "%016x" % P.fnv1a64(filt[k].cpu().numpy(), P.SURVEY_FNV_BASIS) == want[i]["filters"], i
+    ctx.close()
+
+
+def test_configs3_on_eight_contexts_of_one_device_like_a_node_of_eight():
+    """Multi-GPU readiness a one-GPU box can prove: pngloss_hip_multi with devices "0,0,0,0,0,0,0,0" -- EIGHT contexts, eight host threads, eight launch
+    threads on the one device -- takes configs[3]'s 256 frames from host memory, deals them out (32 each: equal sizes), and every frame with a reference
+    digest comes back equal to it.  (On a node the same call opens one context per GPU; nothing else differs.)"""
+    want = U.load_digests_1080p()
+    imgs = _configs3_frames(range(256))
+    assert sorted(np.bincount(P.multi_split([(1920, 1080)] * 256, 8)).tolist()) == [32] * 8
+    multi = P.HipMulti("0,0,0,0,0,0,0,0")
+    assert multi.count == 8
+    outs, filts, res = multi.run_host(imgs, 19, 2)
+    multi.close()
+    assert all(r["status"] == 0 for r in res)
+    for i, e in sorted(want.items()):
+        assert "%016x" % P.fnv1a64(outs[i], P.SURVEY_FNV_BASIS) == e["out"], i
+        assert "%016x" % P.fnv1a64(filts[i], P.SURVEY_FNV_BASIS) == e["filters"], i

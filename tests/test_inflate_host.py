@@ -94,3 +94,42 @@ def test_inflater_refuses_what_is_wrong():
     assert run(_inputs()["rand"][:5000], 100000)[0] != 0                         # not a stream at all
     co = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_DEFAULT_STRATEGY, d[:1000])
     assert run(co.compress(d) + co.flush(), len(d))[0] == 1                      # preset dictionary
+
+
+def _far_match_stream(dist, length=258, prefix_len=32768, lit=None):
+    """A hand-built zlib stream (zlib itself never emits distances beyond 32506; libdeflate and zopfli do): `prefix_len` random bytes in stored
+    blocks, then ONE fixed-Huffman block holding a single match (length 258 = code 285, distance code 29 + 13 extra bits) and the end code."""
+    rng = np.random.default_rng(dist)
+    if lit is None:
+        lit = rng.integers(0, 256, prefix_len, dtype=np.uint8).tobytes()
+    out = bytearray(b"\x78\x01")
+    for i in range(0, len(lit), 65535):
+        part = lit[i:i + 65535]
+        out += bytes([0]) + len(part).to_bytes(2, "little") + (len(part) ^ 0xFFFF).to_bytes(2, "little") + part
+    bits = []
+
+    def put(v, n, msb_first=False):
+        for k in (range(n - 1, -1, -1) if msb_first else range(n)):
+            bits.append((v >> k) & 1)
+    put(1, 1); put(1, 2)                                   # BFINAL, BTYPE = 01 (fixed codes)
+    assert length == 258 and 24577 <= dist <= 32768
+    put(0xC0 + (285 - 280), 8, True)                       # length code 285, no extra bits
+    put(29, 5, True); put(dist - 24577, 13)                # distance code 29 (24577..32768), extra bits LSB first
+    put(0, 7, True)                                        # end of block (256)
+    while len(bits) % 8:
+        bits.append(0)
+    out += bytes(sum(b << k for k, b in enumerate(bits[i:i + 8])) for i in range(0, len(bits), 8))
+    data = bytearray(lit)
+    for k in range(length):
+        data.append(data[len(data) - dist])
+    out += zlib.adler32(bytes(data)).to_bytes(4, "big")
+    assert zlib.decompress(bytes(out)) == bytes(data)      # (zlib's inflate accepts what its deflate never writes)
+    return bytes(out), bytes(data)
+
+
+@pytest.mark.parametrize("dist", [32768, 32767, 32768 - 100, 32768 - 257, 32768 - 258])
+def test_inflater_match_whose_destination_wraps_onto_its_source(dist):
+    # dist + len > 32768: in the 32 KB ring the slot a late byte is written to is the slot an earlier byte was read from
+    z, want = _far_match_stream(dist)
+    rc, out = run(z, len(want))
+    assert rc == 0 and out == want

@@ -218,3 +218,33 @@ def test_device_inflate_from_file_bytes_to_the_reference_readers_pixels():
         ptr, w, h = fr[k]
         assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), fx[k][2])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_inflate_match_whose_destination_wraps_onto_its_source():
+    """Matches with dist + len > 32768 (libdeflate / zopfli emit them, zlib's deflate never does): in the 32 KB ring the slot a late byte of the match
+    is written to is the slot an earlier byte was read from.  A 336x98 gray image whose 33026 scanline bytes are 32768 literal bytes + one such match
+    (hand-built streams, tests/test_inflate_host.py::_far_match_stream), inflated and unfiltered on the device."""
+    import struct
+    import zlib
+    from tests.test_inflate_host import _far_match_stream
+    w, h = 336, 98
+    assert (w + 1) * h == 32768 + 258
+    rng = np.random.default_rng(5)
+    lit = bytearray(rng.integers(0, 256, 32768, dtype=np.uint8).tobytes())
+    for r in range(0, 32768, w + 1):
+        lit[r] = 0                                              # filter type byte of every row: none
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    ctx = P.HipContext()
+    for dist in (32768, 32767, 32768 - 100, 32768 - 258):
+        z, scan = _far_match_stream(dist, lit=bytes(lit))
+        assert all(scan[r] == 0 for r in range(0, len(scan), w + 1))
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", z) + chunk(b"IEND", b"")
+        fr, st, rc = ctx.png_decode_device_z([png])
+        assert rc == 0 and st == [0], dist
+        g = np.frombuffer(scan, np.uint8).reshape(h, w + 1)[:, 1:]
+        want = np.stack([g, g, g, np.full_like(g, 255)], axis=2)
+        assert np.array_equal(_device_bytes(fr[0][0], w * h * 4).reshape(h, w, 4), want), dist
+    ctx.close()

@@ -111,6 +111,15 @@ def load_digests():
         return json.load(fh)
 
 
+def load_digests_1080p():
+    """frame -> reference digests of BASELINE.json configs[3]'s 1920x1080 frames: 0, 1, 255 from digests.json and the twenty of
+    digests_1080p.json (tests/golden/make_frames_1080p.py: the real reference in the build container)."""
+    want = {e["frame"]: e for e in load_digests()["synthetic"] if (e["width"], e["height"]) == (1920, 1080)}
+    with open(os.path.join(GOLDEN, "digests_1080p.json")) as fh:
+        want.update({e["frame"]: e for e in json.load(fh)["frames"]})
+    return want
+
+
 def seeded_cases(seed=7, n=24):
     """Random RGBA images covering all four byte-per-pixel classes, transparency, extreme strengths and bleeds."""
     rng = np.random.default_rng(seed)
