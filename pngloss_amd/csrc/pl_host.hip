@@ -36,6 +36,7 @@
         }                                                                                                        \
     } while (0)
 
+#define SEG_MAX_GROUPS 4
 struct pngloss_hip_ctx {
     int device = 0;
     /* one device arena, regrown on demand, carved per batch */
@@ -70,6 +71,9 @@ struct pngloss_hip_ctx {
     /* the segment engine's launch loop runs on a helper thread and on a stream of its own (the number of row attempts is decided by the
      * data): the caller's stream waits for the "images finished" word instead of for the host */
     hipStream_t seg_stream = nullptr;
+    hipStream_t seg_gstream[SEG_MAX_GROUPS] = { nullptr, nullptr, nullptr, nullptr };   /* [0] = seg_stream: one stream per GROUP of a batch's images (run_seg_engine) */
+    hipEvent_t ev_seg_gdone[SEG_MAX_GROUPS] = { nullptr, nullptr, nullptr, nullptr };
+    int seg_groups = 1;
     hipEvent_t ev_prep = nullptr;    /* caller's stream: everything the engine reads is in place */
     hipEvent_t ev_seg_done = nullptr;/* engine's stream: behind the last attempt the launch thread enqueued */
     std::thread seg_worker;
@@ -144,51 +148,63 @@ struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
  * still runs behind the engine.  (The images of a mixed batch that the other engine takes run on the caller's stream meanwhile.)
  * (Measured and dropped: the attempts as an executable hipGraph of 16 x (parity 0, parity 1) -- 160 kernel nodes per launch call: the
  * same engine time, and 206 - 246 ms of host CPU per 4096x4096 frame against 79 - 94 ms for the plain launches.) */
-void seg_worker_main(pngloss_hip_ctx *ctx, PlSegBatch b, long max_attempts)
+struct SegGroups { PlSegBatch b[SEG_MAX_GROUPS]; int n = 1; };
+void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
 {
+    /* words: [2g] images of group g that are finished, [2g + 1] the attempt group g's first image is working on */
     volatile uint32_t *words = ctx->h_seg_words;
     int rc = PNGLOSS_SUCCESS;
-    const size_t n = b.n;
     if (hipSetDevice(ctx->device) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
-    /* The engine's stream never waits for another stream ON THE DEVICE: streams share a few hardware queues, a queue is served in order,
+    /* The engine's streams never wait for another stream ON THE DEVICE: streams share a few hardware queues, a queue is served in order,
      * and the callers' streams hold waits for the finished words -- with twelve contexts, engine j's attempts sat behind engine k's wait
      * for k's inputs, whose kernels sat behind caller j's wait for engine j.  So this thread waits for the inputs, on the host. */
     if (rc == PNGLOSS_SUCCESS && hipEventSynchronize(ctx->ev_prep) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     const long lookahead = 32;                                  /* attempts queued ahead of the one the device works on */
-    long launched = 0;
+    long launched[SEG_MAX_GROUPS] = { 0, 0, 0, 0 };
     auto t_last = std::chrono::steady_clock::now();
-    uint32_t seen = 0;
+    uint32_t seen[SEG_MAX_GROUPS] = { 0, 0, 0, 0 };
     int idle = 0;
-    while (rc == PNGLOSS_SUCCESS && words[0] < (uint32_t)n) {
-        const uint32_t at = words[1];
-        if (at != seen) { seen = at; t_last = std::chrono::steady_clock::now(); idle = 0; }
-        if (launched - (long)at > lookahead) {
-            if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
-                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress at attempt %u\n", at);
+    for (;;) {
+        if (rc != PNGLOSS_SUCCESS) break;
+        bool all_done = true, any_launched = false;
+        for (int g = 0; g < gs.n && rc == PNGLOSS_SUCCESS; g++) {
+            if (words[2 * g] >= (uint32_t)gs.b[g].n) continue;       /* this group's images are finished */
+            all_done = false;
+            const uint32_t at = words[2 * g + 1];
+            if (at != seen[g]) { seen[g] = at; t_last = std::chrono::steady_clock::now(); idle = 0; }
+            if (launched[g] - (long)at > lookahead) continue;       /* the device is busy with what is queued for this group */
+            if (launched[g] > max_attempts) {
+                std::fprintf(stderr, "pngloss_hip: the segment engine needed more than %ld attempts\n", max_attempts);
                 rc = PNGLOSS_HIP_ERROR;
                 break;
             }
-            /* the device is busy with what is queued: leave the core to others (a row attempt takes 50 - 200 us) */
+            const hipError_t e = pl_seg_launch_attempt(gs.b[g], (int)launched[g], ctx->seg_gstream[g]);
+            if (e != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(e)); rc = PNGLOSS_HIP_ERROR; break; }
+            launched[g]++;
+            any_launched = true;
+        }
+        if (all_done || rc != PNGLOSS_SUCCESS) break;
+        if (!any_launched) {
+            if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
+                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress (attempts %u %u %u %u)\n", seen[0], seen[1], seen[2], seen[3]);
+                rc = PNGLOSS_HIP_ERROR;
+                break;
+            }
+            /* every group has its look-ahead queued: leave the core to others (a row attempt takes 50 - 200 us) */
             if (++idle < 4) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
-            continue;
         }
-        if (launched > max_attempts) {
-            std::fprintf(stderr, "pngloss_hip: the segment engine needed more than %ld attempts\n", max_attempts);
-            rc = PNGLOSS_HIP_ERROR;
-            break;
-        }
-        const hipError_t e = pl_seg_launch_attempt(b, (int)launched, ctx->seg_stream);
-        if (e != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(e)); rc = PNGLOSS_HIP_ERROR; break; }
-        launched++;
     }
-    if (hipEventRecord(ctx->ev_seg_done, ctx->seg_stream) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    for (int g = 0; g < gs.n; g++)
+        if (hipEventRecord(ctx->ev_seg_gdone[g], ctx->seg_gstream[g]) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     if (rc != PNGLOSS_SUCCESS) {
         /* whatever went wrong, the caller's stream must not wait for ever: release it (the images are NOT finished: the error is
          * reported by pngloss_hip_finish), then let what is queued drain */
-        words[0] = (uint32_t)n;
-        (void)hipStreamSynchronize(ctx->seg_stream);
+        for (int g = 0; g < gs.n; g++) words[2 * g] = (uint32_t)gs.b[g].n;
+        for (int g = 0; g < gs.n; g++) (void)hipStreamSynchronize(ctx->seg_gstream[g]);
     }
-    ctx->seg_attempts = launched;
+    long mx = 0;
+    for (int g = 0; g < gs.n; g++) mx = std::max(mx, launched[g]);
+    ctx->seg_attempts = mx;
     ctx->seg_rc.store(rc, std::memory_order_release);
 }
 
@@ -206,9 +222,28 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         ctx->seg_prio = greatest;
         PL_CHECK(hipStreamCreateWithPriority(&ctx->seg_stream, hipStreamNonBlocking, greatest));
         ctx->seg_prio_distinct = greatest != least;
+        ctx->seg_gstream[0] = ctx->seg_stream;
     }
     if (!ctx->ev_prep) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
-    if (!ctx->ev_seg_done) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_seg_done, hipEventDisableTiming));
+    if (!ctx->ev_seg_done) { PL_CHECK(hipEventCreateWithFlags(&ctx->ev_seg_done, hipEventDisableTiming)); ctx->ev_seg_gdone[0] = ctx->ev_seg_done; }
+    /* GROUPS: a batch's images in up to SEG_MAX_GROUPS launch sequences on as many streams.  An attempt is four dependent launches with a latency floor
+     * each (the enumeration's dependent steps above all: 75 us with units); images of ONE sequence sit through every floor together, images of different
+     * sequences fill each other's floors.  One launch thread feeds all of them. */
+    int ngroups = 1;
+    {
+        size_t segs = 0;
+        for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
+        /* (measured, profiles/r05_unit_groups.txt: two sequences 1.2x one from 16 frames of 1080p on, three another 2-5 %, FOUR collapse -- 250 ms for 8 frames
+         *  against 113: with the caller's stream they outnumber the hardware queues a process gets.  Two: a second context on the device must still fit) */
+        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = 2;
+        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
+        ngroups = (int)std::min<size_t>((size_t)ngroups, n);
+    }
+    for (int g = 1; g < ngroups; g++) {
+        if (!ctx->seg_gstream[g]) PL_CHECK(hipStreamCreateWithPriority(&ctx->seg_gstream[g], hipStreamNonBlocking, ctx->seg_prio));
+        if (!ctx->ev_seg_gdone[g]) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_seg_gdone[g], hipEventDisableTiming));
+    }
+    ctx->seg_groups = ngroups;
     if (ctx->stream_wait_ok < 0) {
         int can = 0;
         ctx->stream_wait_ok = (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can) ? 1 : 0;
@@ -217,10 +252,26 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     void *d_words = nullptr;
     PL_CHECK(hipHostGetDevicePointer(&d_words, ctx->h_seg_words, 0));
     volatile uint32_t *words = ctx->h_seg_words;
-    words[0] = 0; words[1] = 0;
+    for (int q = 0; q < 2 * SEG_MAX_GROUPS; q++) words[q] = 0;
+    /* group g = images [gfirst[g], gfirst[g + 1]) of `list` (in the batch's order: equal shares) */
+    size_t gfirst[SEG_MAX_GROUPS + 1];
+    for (int g = 0; g <= ngroups; g++) gfirst[g] = n * (size_t)g / (size_t)ngroups;
+    auto group_of = [&](size_t i) { int g = 0; while (g + 1 < ngroups && i >= gfirst[g + 1]) g++; return g; };
     ctx->h_sj.assign(n, SegJob{});
     ctx->h_seg_params = params;
-    PlSegBatch b{};
+    {
+        /* Enumeration in UNITS of SEG_UNIT segments (seg_enum_unit_body): less than half the instructions per row, a dependent path SEG_UNIT times as long.
+         * It pays when the batch is what keeps the GPU busy, not the latency of one row: from a handful of images on.  Results do not depend on it (the
+         * validation is the ground truth either way); PNGLOSS_HIP_SEG_UNIT=0 / 1 pins it for tests and timing. */
+        size_t segs = 0;
+        for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
+        const bool can = !params.seeded && params.ns <= SEG_NSP;       /* (state sets of one chunk of lanes: with more, the distinct states of a workgroup's pairs outgrow its lanes) */
+        bool units = can && segs > SEG_UNIT_MIN_SEGS;
+        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_UNIT")) units = can && std::atoi(e) != 0;
+        ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
+    }
+    SegGroups gs;
+    gs.n = ngroups;
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) {
         const PlJob &pj = ctx->h_jobs[list[i]];
@@ -232,7 +283,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         s.orig_rank = pj.orig_rank; s.cand = reinterpret_cast<uint32_t *>(pj.cand);
         s.err0 = reinterpret_cast<uint32_t *>(base + l.err0); s.err1 = reinterpret_cast<uint32_t *>(base + l.err1); s.rowcopy = reinterpret_cast<uint32_t *>(base + l.rowcopy);
         s.final_hist = pj.final_hist; s.result = pj.result; s.progress = pj.progress;
-        s.done_counter = static_cast<uint32_t *>(d_words); s.attempt_word = i == 0 ? static_cast<uint32_t *>(d_words) + 1 : nullptr;
+        { const int g = group_of(i); s.done_counter = static_cast<uint32_t *>(d_words) + 2 * g; s.attempt_word = i == gfirst[g] ? static_cast<uint32_t *>(d_words) + 2 * g + 1 : nullptr; }
         s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
         s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
         s.tables = reinterpret_cast<uint32_t *>(base + l.tables); s.maps = reinterpret_cast<uint16_t *>(base + l.maps); s.ehash = reinterpret_cast<uint32_t *>(base + l.ehash);
@@ -241,21 +292,26 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         s.grpcnt = reinterpret_cast<uint32_t *>(base + l.grpcnt); s.grpleft = reinterpret_cast<uint32_t *>(base + l.grpleft);
         s.firstidx = reinterpret_cast<uint32_t *>(base + l.firstidx); s.rowmm = reinterpret_cast<int32_t *>(base + l.rowmm);
         s.nseg = pj.width ? l.nseg : 0; s.ngrp = pj.width ? l.ngrp : 0;
-        b.max_nseg = std::max(b.max_nseg, l.nseg); b.max_ngrp = std::max(b.max_ngrp, l.ngrp);
-        b.max_ncommit = std::max(b.max_ncommit, (pj.width + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
+        PlSegBatch &bg = gs.b[group_of(i)];
+        bg.max_nseg = std::max(bg.max_nseg, l.nseg); bg.max_ngrp = std::max(bg.max_ngrp, l.ngrp);
+        bg.max_ncommit = std::max(bg.max_ncommit, (pj.width + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
         max_h = std::max(max_h, pj.height);
     }
-    if (!b.max_ncommit) b.max_ncommit = 1;
     SegJob *d_sj = reinterpret_cast<SegJob *>(ctx->d_ws + jobs_off);
     for (size_t i = 0; i < n; i++) ctx->h_sj[i].self = d_sj + i;
     SegParams *d_params = reinterpret_cast<SegParams *>(ctx->d_ws + params_off);
     PL_CHECK(hipMemcpyAsync(d_sj, ctx->h_sj.data(), sizeof(SegJob) * n, hipMemcpyHostToDevice, stream));
     PL_CHECK(hipMemcpyAsync(d_params, &ctx->h_seg_params, sizeof(SegParams), hipMemcpyHostToDevice, stream));
-    b.d_sj = d_sj; b.d_params = d_params; b.n = n;
-    b.small_ok = params.small_ok != 0;
-    b.seeded = params.seeded != 0;
-    b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
-    if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
+    for (int g = 0; g < ngroups; g++) {
+        PlSegBatch &b = gs.b[g];
+        if (!b.max_ncommit) b.max_ncommit = 1;
+        b.d_sj = d_sj + gfirst[g]; b.d_params = d_params; b.n = gfirst[g + 1] - gfirst[g];
+        b.small_ok = params.small_ok != 0;
+        b.seeded = params.seeded != 0;
+        b.unit = (uint32_t)ctx->h_seg_params.unit;
+        b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
+        if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
+    }
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
     PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
     if (n_wg) PL_CHECK(pl_launch_engine(d_jobs, d_sel, n_wg, prm, stream));      /* (a mixed batch: the other engine's images, side by side with this one's) */
@@ -273,15 +329,17 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     }
     if (waiting) {
         /* the caller's stream goes on behind the engine: when every image has counted itself finished */
-        const hipError_t e = hipStreamWaitValue32(stream, d_words, (uint32_t)n, hipStreamWaitValueGte, 0xFFFFFFFFu);
-        if (e != hipSuccess) { (void)hipGetLastError(); ctx->stream_wait_ok = 0; waiting = false; }
+        for (int g = 0; g < ngroups && waiting; g++) {
+            const hipError_t e = hipStreamWaitValue32(stream, static_cast<uint32_t *>(d_words) + 2 * g, (uint32_t)gs.b[g].n, hipStreamWaitValueGte, 0xFFFFFFFFu);
+            if (e != hipSuccess) { (void)hipGetLastError(); ctx->stream_wait_ok = 0; waiting = false; }     /* (a wait already enqueued is satisfied when its group finishes: harmless) */
+        }
     }
-    try { ctx->seg_worker = std::thread(seg_worker_main, ctx, b, max_attempts); }
-    catch (...) { std::fprintf(stderr, "pngloss_hip: cannot start the launch thread\n"); words[0] = (uint32_t)n; return PNGLOSS_HIP_ERROR; }
+    try { ctx->seg_worker = std::thread(seg_worker_main, ctx, gs, max_attempts); }
+    catch (...) { std::fprintf(stderr, "pngloss_hip: cannot start the launch thread\n"); for (int g = 0; g < ngroups; g++) words[2 * g] = (uint32_t)gs.b[g].n; return PNGLOSS_HIP_ERROR; }
     if (!waiting) {
         /* no stream memory operations on this device: wait for the launch loop here, and order the caller's stream behind the engine's */
         ctx->seg_worker.join();
-        PL_CHECK(hipStreamWaitEvent(stream, ctx->ev_seg_done, 0));
+        for (int g = 0; g < ngroups; g++) PL_CHECK(hipStreamWaitEvent(stream, ctx->ev_seg_gdone[g], 0));
         if (ctx->seg_rc.load(std::memory_order_acquire)) return ctx->seg_rc.load();
     }
     return PNGLOSS_SUCCESS;
@@ -458,7 +516,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         if (e != hipSuccess) {
             std::fprintf(stderr, "pngloss_hip: enqueueing the kernels behind the row engine failed: %s\n", hipGetErrorString(e));
             if (ctx->seg_worker.joinable()) ctx->seg_worker.join();
-            if (ctx->seg_stream) (void)hipStreamSynchronize(ctx->seg_stream);
+            for (int g = 0; g < SEG_MAX_GROUPS; g++) if (ctx->seg_gstream[g]) (void)hipStreamSynchronize(ctx->seg_gstream[g]);
             return PNGLOSS_HIP_ERROR;
         }
     }
@@ -483,7 +541,7 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
         seg_rc = ctx->seg_rc.load(std::memory_order_acquire);
     }
     PL_CHECK(hipEventSynchronize(ctx->ev[3]));
-    if (ctx->last_engine == 3 && ctx->seg_stream) PL_CHECK(hipStreamSynchronize(ctx->seg_stream));   /* (attempts queued behind the last row: they find the images finished) */
+    if (ctx->last_engine == 3) for (int g = 0; g < SEG_MAX_GROUPS; g++) if (ctx->seg_gstream[g]) PL_CHECK(hipStreamSynchronize(ctx->seg_gstream[g]));   /* (attempts queued behind the last row: they find the images finished) */
     ctx->pending = false;
     if (seg_rc) return seg_rc;
     float ms = 0.f;
@@ -698,7 +756,8 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->seg_worker.joinable()) ctx->seg_worker.join();
     if (ctx->pending) (void)hipEventSynchronize(ctx->ev[3]);
-    if (ctx->seg_stream) { (void)hipStreamSynchronize(ctx->seg_stream); (void)hipStreamDestroy(ctx->seg_stream); }
+    for (int g = 0; g < SEG_MAX_GROUPS; g++) if (ctx->seg_gstream[g]) { (void)hipStreamSynchronize(ctx->seg_gstream[g]); (void)hipStreamDestroy(ctx->seg_gstream[g]); }
+    for (int g = 1; g < SEG_MAX_GROUPS; g++) if (ctx->ev_seg_gdone[g]) (void)hipEventDestroy(ctx->ev_seg_gdone[g]);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_seg_done) (void)hipEventDestroy(ctx->ev_seg_done);
     for (auto &e : ctx->ev)

@@ -117,6 +117,31 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
     }
 }
 
+/* enumeration in UNITS (batches; SegParams::unit = SEG_UNIT): first the filters that look at the left pixel (their workgroups are the long ones: `perb`
+ * workgroups of SEG_UNC (unit, channel) pairs per candidate), then none / up -- with their small state set (when it exists) segment by segment, `pers`
+ * workgroups of 24 (segment, channel) pairs --, and the five walkers of an epoch's first unit */
+__global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    const SegJob j = sj[blockIdx.y];
+    const bool small_ok = P->small_ok != 0;
+    const unsigned nbig = small_ok ? 3u : 5u, nb = nbig * perb, ns = small_ok ? 2u * pers : 0u;
+    if (blockIdx.x >= nb + ns) {
+        seg_first_body<SEG_UNT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - nb - ns)), par, (int)(blockIdx.x - nb - ns), seg_smem);
+        return;
+    }
+    if (blockIdx.x < nb) {
+        const unsigned k = blockIdx.x / perb, grp = blockIdx.x % perb;
+        const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
+        if (grp * SEG_UNC >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
+        seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
+    } else {
+        const unsigned r = blockIdx.x - nb, f = r / pers ? 2u : 0u, grp = r % pers;
+        if (grp * SEG_UNC_SMALL >= j.nseg * j.bpp) return;
+        seg_enum_unit_body<SEG_NSS, 1, SEG_UNC_SMALL>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
+    }
+}
+
 template <bool SEEDED>
 __global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
@@ -147,7 +172,8 @@ hipError_t chain_attr()
     if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl, SEG_SM_CTLVAL, done_ctl);
     return e;
 }
-static_assert(SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536, "these kernels are launched without an LDS opt-in");
+static_assert(SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536 && SEG_SM_ENUM_UNIT <= 65536, "these kernels are launched without an LDS opt-in");
+static_assert((SEG_TBL_WORDS + 1024 + 512) * 4 + SEG_UNIT * SEG_L * 4 * 8 <= SEG_SM_ENUM_UNIT && (SEG_TBL_WORDS + 1024 + 512) * 4 + SEG_L * 4 * 8 <= SEG_SM_ENUM_NT(512), "seg_first_body's carve fits the enumeration kernels' LDS");
 
 } // namespace
 
@@ -216,6 +242,11 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
         const size_t enum_lds = (size_t)SEG_SM_ENUM_NT(nt);
+        if (b.unit > 1 && !b.seeded) {
+            const unsigned perb = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (b.max_nseg * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
+            const unsigned blocks = (small_ok ? 3 * perb + 2 * pers : SEG_NFILT * perb) + SEG_NFILT;
+            hipLaunchKernelGGL(seg_k_enum_unit, dim3(blocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers);
+        } else
         if (b.seeded) {
             const unsigned sblocks = SEG_NFILT * b.max_nseg * halves + SEG_NFILT;
             if (nt == 512) hipLaunchKernelGGL(seg_k_enum_seeded<512>, dim3(sblocks, n), dim3(512), (size_t)SEG_SM_ENUM_SEEDED(512), stream, b.d_sj, b.d_params, par, b.max_nseg);

@@ -140,6 +140,13 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_L
 #define SEG_L 32                 /* pixels per segment (16 was measured: enumeration -5 us, chain +5 us, no gain) */
 #endif
+#ifndef SEG_UNIT
+#define SEG_UNIT 3               /* segments per enumeration UNIT when the launcher asks for units (SegParams::unit; batches).  Measured (profiles/r05_unit_groups.txt): 2, 3, 4 within 3 % of each other from 16 frames of 1080p on, 3 best at 32 and 64; 8 loses below 64 frames */
+#endif
+#define SEG_UNIT_MIN_SEGS 320    /* the launcher enumerates in units when the batch's images have more segments than this between them (six frames of 1920 pixels) */
+#define SEG_UNC 12               /* (unit, channel) pairs per workgroup of the unit enumeration */
+#define SEG_UNT 1024             /* its threads */
+#define SEG_UPOOL 1024           /* ... and the most distinct states its pairs may have between them (one lane each) */
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
 #define SEG_VGRP 8                /* segments per VALIDATION workgroup (half a replay group: one decision per thread, twice the CUs) */
 #define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
@@ -210,6 +217,10 @@ struct SegParams {
     int32_t kin;                   /* run-in pixels */
     int32_t nseed_small;           /* seeds of none / up */
     uint32_t seed_small[SEG_NSP];  /* (cn+128) | (th+128) << 8 */
+    /* enumeration in UNITS (batches, exhaustive state sets only): 1 = every segment is enumerated on its own (one image: the shortest dependent path);
+     * SEG_UNIT = a run of SEG_UNIT segments is enumerated as one (seg_enum_unit_body): from every state only at its first pixel, its distinct states
+     * run on through all its segments.  Set by the launcher (seg_build_params leaves 1). */
+    int32_t unit;
 };
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
@@ -639,6 +650,9 @@ PLS_HD uint32_t seg_state_encode(const SegParams &P, const SegPix &b, const SegS
 
 /* none / up: the state is (cn, th) */
 PLS_HD bool seg_is_small(const SegParams &P, int f) { return P.small_ok && (f == 0 || f == 2); }
+/* segments per enumeration unit of candidate f (SegParams::unit): none / up with their small state set keep single segments -- their few states cost next to
+ * nothing per segment, and a short dependent path lets their workgroups make room for the long ones */
+PLS_HD uint32_t seg_unit_of(const SegParams &P, int f) { return (P.unit > 1 && !P.seeded && !seg_is_small(P, f)) ? (uint32_t)P.unit : 1u; }
 PLS_HD bool seg_small_decode(const SegParams &P, int i, SegState &st)
 {
     if (i >= P.ns_small) return false;
@@ -749,7 +763,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
 {
     memset(&P, 0, sizeof P);
     if (strength < 0 || strength > 255 || bleed < 1 || bleed > 32767) return false;
-    P.strength = strength; P.bleed = bleed;
+    P.strength = strength; P.bleed = bleed; P.unit = 1;
     for (int d = -256; d <= 255; d++) {
         const SegSplit s = seg_split_slow(d, bleed);
         P.lut_a[d + 256] = ((uint32_t)s.rem & 0xffffu) | ((uint32_t)s.h << 16);
@@ -1228,6 +1242,200 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCt
     }
 }
 
+/* ---- ENUMERATE IN UNITS (batches; exhaustive state sets): task (f, group of SEG_UNC pairs (unit, channel)) --------------------------------------
+ * What a batch pays for is not the length of the dependent path but the instructions its waves issue and the workgroups a CU can hold.  So:
+ *   - a UNIT is SEG_UNIT consecutive segments.  It is run from EVERY state only at its first pixel (SEG_K1 steps, LANES states per pair at a time,
+ *     then the dedupe of seg_enum_body); the distinct states that are left (a dozen or two) run on through ALL its segments, leaving the same
+ *     records per segment as seg_enum_body -- checkpoints at every part, the exit state of every segment -- with the unit's dense id in every
+ *     one of them, and the exit INDEX (the next unit's entry) only at its end.  The 253-state start is paid once per unit, not once per segment;
+ *   - a workgroup takes SEG_UNC pairs (unit, channel) of ONE candidate, from the row's linear list unit * bpp + channel -- in turns of as many
+ *     pairs as its 1024 lanes hold states for -- and then packs the distinct states of ALL its pairs into its first lanes: ~200 lanes = four
+ *     waves that share one copy of the candidate's tables (12.8 KB) instead of one or two half-empty waves per 35 KB workgroup;
+ *   - none / up (LANES = 32: their state is (cn, th)) go through the same body, dedupe included (~3 distinct states per pair instead of 17 lanes), but
+ *     segment by segment (UNIT = 1, 24 pairs a workgroup: seg_unit_of): units would save them nothing worth having, and their short workgroups fill
+ *     the CUs' slots between the long ones instead of holding one each for a whole unit.
+ * The chain kernel composes UNITS (seg_chain_body reads SegParams::unit); replay and validation do not know the difference. */
+#define SEG_UNC_SMALL 24          /* (segment, channel) pairs per workgroup for none / up with their small state set (UNIT = 1) */
+#define SEG_UNPX ((SEG_UNC * (SEG_UNIT * SEG_L + 1)) > (SEG_UNC_SMALL * (SEG_L + 1)) ? (SEG_UNC * (SEG_UNIT * SEG_L + 1)) : (SEG_UNC_SMALL * (SEG_L + 1)))   /* pixel records of a workgroup's pairs */
+#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UNPX * 8 + 2048 * 4 + 2048 * 2 + 1024 * 4 + SEG_UPOOL * 4 + SEG_UNT * 4 + 256)
+template <int LANES, int UNIT, int NC>
+PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int grp, unsigned char *smem)
+{
+    if (cv.finished || cv.active != 1) return;
+    constexpr int NT = SEG_UNT, HT = 2 * LANES;
+    constexpr int CPR = NT / LANES < NC ? NT / LANES : NC;      /* pairs per turn of the first phase */
+    constexpr int ROUNDS = (NC + CPR - 1) / CPR;
+    constexpr uint32_t E = UNIT, UL = E * SEG_L, NPX = UL + 1;
+    static_assert(CPR * HT <= 2048 && CPR * LANES <= 1024 && NC <= 24 && NC * (UNIT * SEG_L + 1) <= SEG_UNPX, "hash tables, per-turn lists, pixel records and the bookkeeping words are sized for this");
+    const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, nunit = (nseg + E - 1) / E, ncombo = nunit * bpp;
+    const uint32_t q0 = (uint32_t)grp * NC;
+    if (q0 >= ncombo) return;
+    const uint32_t sx = cv.start_x;
+    /* an epoch that starts inside the row: the unit that holds its first pixel (and everything in front) is walked by seg_first_body */
+    { const uint32_t ql = seg_umin(q0 + NC, ncombo) - 1u; if (sx && (ql / bpp) * UL <= sx) return; }
+    uint32_t *tw = (uint32_t *)smem;
+    uint32_t *lut = tw + SEG_TBL_WORDS;
+    SegPix *px = (SegPix *)(lut + 512);                       /* [NC][NPX]: one channel's records of a pair, slot 0 = the boundary pixel in front of the unit */
+    uint32_t *ht = (uint32_t *)(px + SEG_UNPX);               /* [CPR][HT] key or ~0 (this turn) */
+    uint16_t *dense = (uint16_t *)(ht + 2048);                /* [CPR][HT] slot -> dense id */
+    uint32_t *uniqr = (uint32_t *)(dense + 2048);             /* [CPR][LANES] this turn's distinct states by dense id */
+    uint32_t *pool = uniqr + 1024;                            /* [SEG_UPOOL] the distinct states of all pairs, pair behind pair */
+    uint32_t *keys = pool + SEG_UPOOL;                        /* [NT] */
+    uint32_t *misc = keys + NT;                               /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total) */
+    const uint32_t y = cv.y;
+    const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
+    const SegGeo G = seg_geo((int)cv.s);
+    const int nstates = seg_is_small(P, f) ? P.ns_small : P.ns;
+    PLS_THREADS(tid, NT) { if (tid < 64) misc[tid] = 0u; }
+    PLS_SYNC();
+    PLS_THREADS(tid, NT) {
+        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT, NPI = (NC * (int)NPX + NT - 1) / NT;
+        uint32_t vt[NTW], vl = 0;
+        SegPix vp[NPI];
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        if (tid < 512) vl = P.lut_a[tid];
+        PLS_UNROLL
+        for (int q = 0; q < NPI; q++) {
+            const uint32_t t = (uint32_t)tid + (uint32_t)q * NT, k = t / NPX, pq = t % NPX, cq = q0 + k;
+            vp[q] = seg_pix_make(0, 0, 0, 0, 0);
+            if (k < (uint32_t)NC && cq < ncombo) {
+                const uint32_t u = cq / bpp, c = cq % bpp, x = u * UL + pq - 1u;          /* (pq = 0 in front of the row: wraps beyond W -- a zero record) */
+                if (x < W) vp[q] = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
+            }
+        }
+        PLS_UNROLL
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+        if (tid < 512) lut[tid] = vl;
+        PLS_UNROLL
+        for (int q = 0; q < NPI; q++) {
+            const uint32_t t = (uint32_t)tid + (uint32_t)q * NT;
+            if (t < (uint32_t)NC * NPX) { px[t] = vp[q]; if (vp[q].w >> 24) PLS_ATOMIC_OR(&misc[0], 1u); }
+        }
+    }
+    PLS_SYNC();
+    const bool trx = misc[0] != 0u;
+    const int K1 = seg_k1(nstates);
+    /* -- first phase, a turn of CPR pairs at a time: SEG_K1 steps from every state, the dedupe, the pair's entry map (entry index -> dense id) -- */
+    for (int r = 0; r < ROUNDS; r++) {
+        PLS_THREADS(tid, NT) {
+            for (int i = tid; i < CPR * HT; i += NT) ht[i] = 0xffffffffu;
+            if (tid < CPR) misc[8 + tid] = 0u;
+        }
+        PLS_SYNC();
+        for (int i0 = 0; i0 < nstates; i0 += LANES) {
+            PLS_THREADS(tid, NT) {
+                const int kk = tid / LANES, k = r * CPR + kk, i = i0 + tid % LANES;
+                const uint32_t cq = q0 + (uint32_t)k;
+                uint32_t key = 0xffffffffu;
+                if (kk < CPR && k < NC && cq < ncombo && i < nstates && !(sx && (cq / bpp) * UL <= sx)) {
+                    const SegPix *pk = px + (size_t)k * NPX;
+                    SegState st;
+                    if (seg_any_decode(P, f, i, pk[0], st)) {
+                        const int bad = seg_run_fast_f(f, trx, pk + 1, 1, K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                        if (!bad && st.cn >= -128 && st.cn <= 127) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16);
+                    }
+                }
+                keys[tid] = key;
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, NT) {
+                const int kk = tid / LANES, i = tid % LANES;
+                const uint32_t key = keys[tid];
+                if (kk < CPR && key != 0xffffffffu && (i == 0 || keys[tid - 1] != key)) {
+                    uint32_t h = ((key * 0x9E3779B1u) >> 16) & (uint32_t)(HT - 1);
+                    for (int probe = 0; probe < HT; probe++) {
+                        const uint32_t old = PLS_ATOMIC_CAS(&ht[kk * HT + h], 0xffffffffu, key);
+                        if (old == 0xffffffffu) {
+                            const uint32_t d = PLS_ATOMIC_ADD_RET(&misc[8 + kk], 1u);
+                            dense[kk * HT + h] = (uint16_t)(d < (uint32_t)LANES ? d : 0xffffu);
+                            if (d < (uint32_t)LANES) uniqr[kk * LANES + d] = key;
+                            break;
+                        }
+                        if (old == key) break;
+                        h = (h + 1) & (uint32_t)(HT - 1);
+                    }
+                }
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, NT) {
+                const int kk = tid / LANES, k = r * CPR + kk, i = i0 + tid % LANES;
+                const uint32_t cq = q0 + (uint32_t)k;
+                if (kk < CPR && k < NC && cq < ncombo && i < nstates && !(sx && (cq / bpp) * UL <= sx)) {
+                    const uint32_t key = keys[tid];
+                    uint32_t d = 0xffffu;
+                    if (key != 0xffffffffu) {
+                        uint32_t h = ((key * 0x9E3779B1u) >> 16) & (uint32_t)(HT - 1);
+                        for (int probe = 0; probe < HT; probe++) {
+                            const uint32_t at = ht[kk * HT + h];
+                            if (at == key) { d = dense[kk * HT + h]; break; }
+                            if (at == 0xffffffffu) break;
+                            h = (h + 1) & (uint32_t)(HT - 1);
+                        }
+                    }
+                    const uint32_t u = cq / bpp, c = cq % bpp;
+                    j.maps[(((size_t)f * nseg + (size_t)u * E) * 4 + c) * (size_t)P.nsp + i] = (uint16_t)d;
+                }
+            }
+            PLS_SYNC();
+        }
+        /* the turn's lists into the pool, pair behind pair (a pair whose states the pool has no room for keeps what fits: the ids beyond get no lane,
+         * dcnt says so, and the chain treats them like any state that left the tables) */
+        PLS_THREADS(tid, NT) {
+            if (tid == 0) {
+                for (int kk = 0; kk < CPR; kk++) {
+                    const int k = r * CPR + kk;
+                    if (k >= NC) break;
+                    uint32_t D = misc[8 + kk] < (uint32_t)LANES ? misc[8 + kk] : (uint32_t)LANES;
+                    const uint32_t b0 = misc[32 + k];
+                    if (b0 + D > SEG_UPOOL) D = SEG_UPOOL - b0;
+                    misc[8 + kk] = D;
+                    misc[32 + k + 1] = b0 + D;
+                }
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, NT) {
+            const int kk = tid / LANES, k = r * CPR + kk, i = tid % LANES;
+            if (kk < CPR && k < NC && (uint32_t)i < misc[8 + kk]) pool[misc[32 + k] + (uint32_t)i] = uniqr[kk * LANES + i];
+        }
+        PLS_SYNC();
+    }
+    /* -- second phase: the distinct states of all pairs, one lane each, through every segment of their unit -- */
+    PLS_THREADS(tid, NT) {
+        const uint32_t total = misc[32 + NC];
+        if (tid < NC) {
+            const uint32_t cq = q0 + (uint32_t)tid;
+            if (cq < ncombo && !(sx && (cq / bpp) * UL <= sx)) {
+                const uint32_t u = cq / bpp, c = cq % bpp, D = misc[32 + tid + 1] - misc[32 + tid];
+                for (uint32_t sg = u * E; sg < seg_umin(u * E + E, nseg); sg++) j.dcnt[((size_t)f * nseg + sg) * 4 + c] = D;
+            }
+        }
+        if ((uint32_t)tid < total) {
+            int k = 0;
+            PLS_UNROLL
+            for (int q = 1; q < NC; q++) k += (uint32_t)tid >= misc[32 + q] ? 1 : 0;
+            const uint32_t i = (uint32_t)tid - misc[32 + k], cq = q0 + (uint32_t)k, u = cq / bpp, c = cq % bpp;
+            const uint32_t key = pool[tid];
+            SegState st;
+            st.left = (int)(key & 255u); st.cn = seg_sext8((int)(key >> 8)); st.th = seg_sext8((int)(key >> 16));
+            const SegPix *pk = px + (size_t)k * NPX;
+            const uint32_t sg0 = u * E, nsg = seg_umin(E, nseg - sg0);
+            int bad = 0;
+            for (uint32_t sl = 0; sl < nsg; sl++) {
+                const size_t slot = (((size_t)f * nseg + sg0 + sl) * 4 + c) * SEG_NSP + i;
+                for (int part = 0; part < SEG_PARTS; part++) {
+                    if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                    const int skip = (sl == 0 && part == 0) ? K1 : 0;
+                    bad |= seg_run_fast_f(f, trx, pk + 1 + sl * SEG_L + part * SEG_PL + skip, 1, SEG_PL - skip, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                }
+                j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                if (sl + 1 == nsg) j.rout[slot] = (uint16_t)(bad ? (uint32_t)SEG_INVALID : seg_any_encode(P, f, pk[(sl + 1) * SEG_L], st));
+            }
+        }
+    }
+}
+
 /* frozen histogram of candidate f in this attempt: H0 + base[f] */
 PLS_HD void seg_load_frozen(const SegJob &j, int par, int f, uint32_t *Hf, uint32_t *rank, int tid, int nt)
 {
@@ -1282,10 +1490,15 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
     if (sx >= W || sx == 0) return;                           /* a fresh row needs no walk: its segment 0 is enumerated */
     const uint32_t first = sx / SEG_L;
     if (first + 1 >= nseg) return;                            /* no segment behind it */
+    /* enumeration in units (SegParams::unit > 1): the walk goes on to the end of the UNIT that holds the epoch's first pixel -- the enumeration starts
+     * with the unit behind it -- and leaves the entry state of every segment it crosses (the replay walks those from there: no checkpoints) */
+    const uint32_t E = seg_unit_of(P, f), ulast = seg_umin((first / E) * E + E - 1u, nseg - 1u);
+    const uint32_t wend = seg_umin(ulast, nseg - 2u);         /* last segment walked: the row's last segment has nothing behind it */
+    const uint32_t npix = (wend - first + 1u) * SEG_L;
     uint32_t *tw = (uint32_t *)smem;
     uint32_t *lut = tw + SEG_TBL_WORDS;
     uint32_t *Hf = lut + 512, *rank = Hf + 256;
-    SegPix *px = (SegPix *)(rank + 256);                      /* [SEG_L][4] */
+    SegPix *px = (SegPix *)(rank + 256);                      /* [npix][4]: up to a unit's pixels */
     const unsigned long long tf0 = (P.engine_flags & 1) ? PLS_CLOCK() : 0ull;
     const uint32_t y = cv.y;
     const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
@@ -1298,21 +1511,30 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
         if (tid < 256) { const int b = tid; vh = j.H0[par * 256 + b]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + b]; vr = j.orig_rank[f * 256 + b]; }
-        if (tid >= 256 && tid < 256 + SEG_L) vp = seg_pix_fetch(row, nab, e0g, first * SEG_L + (uint32_t)(tid - 256), W);
+        static_assert(256 + SEG_UNIT * SEG_L <= NT, "a unit's pixels are staged by the threads behind the first 256");
+        if (tid >= 256 && (uint32_t)(tid - 256) < npix) vp = seg_pix_fetch(row, nab, e0g, first * SEG_L + (uint32_t)(tid - 256), W);
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
         if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
-        if (tid >= 256 && tid < 256 + SEG_L) seg_pix_split4(px + (tid - 256) * 4, vp, bpp, first * SEG_L + (uint32_t)(tid - 256), W);
+        if (tid >= 256 && (uint32_t)(tid - 256) < npix) seg_pix_split4(px + (tid - 256) * 4, vp, bpp, first * SEG_L + (uint32_t)(tid - 256), W);
     }
     PLS_SYNC();
     PLS_THREADS(tid, NT) {
         if (tid < 4 && (uint32_t)tid < bpp) {
             const int c = tid;
             SegState st = seg_state_unpack(ctl.state[f][c]);
-            const uint32_t fend = (first + 1) * SEG_L;         /* < W: there is a segment behind */
-            seg_walk(f, px + (sx - first * SEG_L) * 4 + c, 4, sx, fend, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed, nullptr, nullptr);
-            const uint32_t idx = seg_any_encode(P, f, px[(SEG_L - 1) * 4 + c], st);
+            for (uint32_t sg = first; sg <= wend; sg++) {
+                const uint32_t xa = sg == first ? sx : sg * SEG_L, xe = (sg + 1u) * SEG_L;         /* xe < W: there is a segment behind */
+                seg_walk(f, px + (xa - first * SEG_L) * 4 + c, 4, xa, xe, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed, nullptr, nullptr);
+                if (sg + 1u <= ulast) {
+                    /* the next segment belongs to the walked unit: its entry state for the replay (no dense id: no checkpoints) */
+                    j.entry[((size_t)f * nseg + sg + 1u) * 4 + c] = seg_state_pack(st);
+                    j.dnout[((size_t)f * nseg + sg + 1u) * 4 + c] = (uint16_t)SEG_INVALID;
+                }
+            }
+            /* (when the walked unit is the row's last there is no enumerated unit behind it and the chain does not read this) */
+            const uint32_t idx = seg_any_encode(P, f, px[(npix - 1u) * 4 + c], st);
             j.firstidx[(f * 4 + c) * 2] = idx;
             j.firstidx[(f * 4 + c) * 2 + 1] = seg_state_pack(st);
             if ((P.engine_flags & 1) && tid == 0) { const unsigned long long t1 = PLS_CLOCK(); PLS_ATOMIC_MAX(&j.result[34], (int32_t)(t1 - tf0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[35], (uint32_t)(t1 - tf0)); PLS_ATOMIC_ADD((uint32_t *)&j.result[36], 1u); }
@@ -1361,9 +1583,16 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
     SEG_AS_GLB uint16_t *dnout = j.dnout + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
     if (sx || nseg == 1) { PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) dnout[(size_t)first * 4] = (uint16_t)SEG_INVALID; } }   /* a walked first segment has no checkpoints */
     if (first + 1 >= nseg) return;
-    /* enumerated segments s0 .. nseg-1 (ne of them; a fresh row: from 0) = POSITIONS 0 .. ns of the chain; ns = ne - 1 transitions */
-    const uint32_t s0 = sx ? first + 1 : 0u, ne = nseg - s0, ns = ne - 1;
     constexpr bool seeded = SEEDED;                             /* (= P.seeded: two kernels, so that the exhaustive sets' gather does not carry the seeded one's registers) */
+    /* The chain composes UNITS: E = SegParams::unit segments enumerated as one (seg_enum_unit_body; 1: every segment on its own, and always for seeded
+     * sets).  Unit u = segments u * E .. : its entry map and distinct-state count sit at its FIRST segment (SEGF), its exit index and exit state at
+     * its LAST (SEGL); every segment of it carries the unit's dense id, the entry state of an inner segment is the exit state of the one in front. */
+    const uint32_t E = seeded ? 1u : seg_unit_of(P, f), nunit = (nseg + E - 1u) / E, ufirst = first / E;
+#define SEGF(u) ((u) * E)
+#define SEGL(u) (seg_umin((u) * E + E, nseg) - 1u)
+    if (sx && ufirst + 1 >= nunit) return;                      /* no unit behind the walked one (seg_first_body left the entry states of its segments) */
+    /* enumerated units s0 .. nunit-1 (ne of them; a fresh row: from 0) = POSITIONS 0 .. ns of the chain; ns = ne - 1 transitions */
+    const uint32_t s0 = sx ? ufirst + 1 : 0u, ne = nunit - s0, ns = ne - 1;
     seg_lds_u32 Hf = (seg_lds_u32)smem, rank = Hf + 256, lut = Hf + 512;   /* (repair only) */
     seg_lds_u32 idxb = Hf + 1024;                               /* [32]: [24] repairs, [25] first position without an id, [26] entry state of the pass's first position, [27] most distinct states of a segment,
                                                                    [28] dense id the pass starts with, [30] some segment has more distinct states than the stride, [31] repair tables loaded */
@@ -1388,6 +1617,36 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
     unsigned long long tacc[4] = { 0, 0, 0, 0 }, tc[5] = { 0, 0, 0, 0, 0 };
     PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid < 32) idxb[tid] = 0u; }
     PLS_SYNC();
+    if (ns == 0) {
+        /* ONE enumerated unit (the row's last, behind a walked one -- or the whole of a short row): nothing to compose, its id is the start state's */
+        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            if (tid == 0) {
+                const uint32_t start_ps = sx ? j.firstidx[(f * 4 + c) * 2 + 1] : seg_state_pack(start0);
+                uint32_t d = SEG_INVALID;
+                if (seeded) d = seg_eh_lookup(ehash + (size_t)SEGF(s0) * estep32, seg_eh_key_of_packed(start_ps));
+                else {
+                    const uint32_t idx = sx ? j.firstidx[(f * 4 + c) * 2] : (seg_is_small(P, f) ? P.idx0_small : P.idx0_big);
+                    if (idx != SEG_INVALID && (int)idx < nstates) d = (uint32_t)maps[(size_t)SEGF(s0) * mstep32 + idx];
+                }
+                const uint32_t dc = dcnt[(size_t)SEGF(s0) * 4];
+                if (d >= SEG_NSP || d >= dc) d = SEG_INVALID;
+                entry[(size_t)SEGF(s0) * 4] = start_ps;
+                for (uint32_t sg = SEGF(s0); sg <= SEGL(s0); sg++) {
+                    dnout[(size_t)sg * 4] = (uint16_t)d;
+                    if (sg > SEGF(s0) && d != SEG_INVALID) entry[(size_t)sg * 4] = rst[(size_t)(sg - 1u) * rstep32 + d];
+                }
+                /* without an id the unit's first segment is walked by the replay from its entry state; what lies behind it in the unit has no state
+                 * to start from: reported as this candidate's first failed decision (an epoch starts there, as behind any failed validation) */
+                const uint32_t xfail = (SEGF(s0) + 1u) * SEG_L;
+                if (d == SEG_INVALID && SEGL(s0) > SEGF(s0) && xfail < W) {
+                    PLS_ATOMIC_MIN(&j.acc[par].fail[f], xfail * 4u + (uint32_t)c);
+                    PLS_ATOMIC_OR(&j.acc[par].failmask, 1u << f);
+                    PLS_ATOMIC_OR(&j.self->vfail[par], 1u << f);
+                }
+            }
+        }
+        return;
+    }
     uint32_t sh = seeded ? SEG_CR_SH + 1 : SEG_CR_SH;
     if (eflags & 4) sh++;                                       /* (test hook: a wider stride than needed) */
     uint32_t a = 0;                                             /* first position of the pass */
@@ -1397,7 +1656,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
         const uint32_t ntr = seg_umin(seg_chain_cap(sh), ns - a);
         if (ntr == 0) {
             /* only the row's last segment is left (behind a repair): it has the id the repair looked up */
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { const uint32_t d = idxb[28]; dnout[(size_t)(s0 + a) * 4] = (uint16_t)(d < SEG_NSP ? d : SEG_INVALID); } }
+            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { const uint32_t d = idxb[28]; dnout[(size_t)SEGF(s0 + a) * 4] = (uint16_t)(d < SEG_NSP ? d : SEG_INVALID); } }   /* (seeded sets: E = 1) */
             break;
         }
         if (prof) tc[0] = PLS_CLOCK();
@@ -1426,8 +1685,8 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 PLS_UNROLL
                 for (int q = 0; q < SEG_CQ; q++) {
                     const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
-                    const uint32_t o = sg * rstep32 + d;
-                    dcv[q] = dcnt[sg * 4u];
+                    const uint32_t o = SEGL(sg) * rstep32 + d;
+                    dcv[q] = dcnt[SEGF(sg) * 4u];
                     r[q] = seeded ? 0u : (uint32_t)rout[o];
                     ps[q] = (useR || seeded) ? rst[o] : SEG_NOSTATE;
                 }
@@ -1435,7 +1694,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     if (seeded) {
                         const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (s0 + a) * estep32 + (start_key == SEG_NOKEY ? 0u : start_base));
                         dfirst = seg_eh_match(start_key, w[0], w[1]);
-                    } else if (idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[(s0 + a) * mstep32 + idx_first];
+                    } else if (idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[SEGF(s0 + a) * mstep32 + idx_first];
                 }
                 /* (the dependent loads in a loop of their own, all of them requested before the first is used: next to their uses, each one
                  * waits for itself) */
@@ -1461,7 +1720,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     for (int q = 0; q < SEG_CQ; q++) {
                         const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
                         const bool valid = d < dcv[q] && r[q] != SEG_INVALID && (int)r[q] < nstates;
-                        v[q] = maps[(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (segment sg + 1 <= nseg - 1 is enumerated: its row exists) */
+                        v[q] = maps[SEGF(sg + 1u) * mstep32 + (valid ? r[q] : 0u)];       /* (unit sg + 1 <= nunit - 1 is enumerated: its row exists) */
                     }
                     PLS_UNROLL
                     for (int q = 0; q < SEG_CQ; q++) {
@@ -1491,7 +1750,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             if (starter) {
                 idxb[28] = dfirst;
                 idxb[26] = start_ps;
-                entry[(size_t)s0 * 4] = start_ps;
+                entry[(size_t)SEGF(s0) * 4] = start_ps;
             }
             if (tid == 0) { T[dummy] = (uint16_t)dummy; idxb[25] = 0xFFFFFFFFu; }
         }
@@ -1571,13 +1830,21 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     if ((eflags & 2) && k >= pos0 + 1u) d = SEG_INVALID;                  /* (test hook: every second segment through the repair) */
                     const uint32_t sg = s0 + a + k;
                     if (d == SEG_INVALID) { PLS_ATOMIC_MIN(&idxb[25], k); continue; }
-                    dnout[(size_t)sg * 4] = (uint16_t)d;
+                    dnout[(size_t)SEGF(sg) * 4] = (uint16_t)d;
+                    if (E > 1u) {
+                        /* the unit's inner segments: the same id, entry state = exit state of the segment in front under it */
+                        const bool have = d < dcnt[(size_t)SEGF(sg) * 4];
+                        for (uint32_t si = SEGF(sg) + 1u; si <= SEGL(sg); si++) {
+                            dnout[(size_t)si * 4] = (uint16_t)d;
+                            entry[(size_t)si * 4] = have ? rst[(size_t)(si - 1u) * rstep32 + d] : SEG_NOSTATE;
+                        }
+                    }
                     if (k >= ntr) continue;
                     uint32_t ps = SEG_NOSTATE;
                     if (useR) ps = R[(k << SEG_CR_SH) + d];
-                    else if (d < dcnt[(size_t)sg * 4]) ps = rst[(size_t)sg * rstep32 + d];
+                    else if (d < dcnt[(size_t)SEGF(sg) * 4]) ps = rst[(size_t)SEGL(sg) * rstep32 + d];
                     entL[k + 1u] = ps;
-                    if (ps != SEG_NOSTATE) entry[(size_t)(sg + 1u) * 4] = ps;
+                    if (ps != SEG_NOSTATE) entry[(size_t)SEGF(sg + 1u) * 4] = ps;
                 }
             }
             PLS_SYNC();
@@ -1603,14 +1870,15 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 if (fb > pos0 && entL[fb] == SEG_NOSTATE) fb--;
                 const uint32_t estb = fb > pos0 ? entL[fb] : idxb[26];
                 PLS_SYNC();
-                const uint32_t kqb = a + fb, sgb = s0 + kqb;
+                const uint32_t kqb = a + fb, sgb = SEGF(s0 + kqb);      /* (the unit's FIRST segment: the replay walks that one from the entry state; with units, what
+                                                                            lies behind it in the unit has no state to start from either) */
                 PLS_THREADS(tid, SEG_CHAIN_THREADS) {
                     if (tid == 0) {
                         SEG_DEBUG_COUNT(2, fb);
                         idxb[24]++;
                         dnout[(size_t)sgb * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgb * 4] = estb;
                         const uint32_t xfail = (sgb + 1u) * SEG_L;
-                        if (kqb < ns && xfail < W) {
+                        if ((kqb < ns || E > 1u) && xfail < W) {
                             PLS_ATOMIC_MIN(&j.acc[par].fail[f], xfail * 4u + (uint32_t)c);
                             PLS_ATOMIC_OR(&j.acc[par].failmask, 1u << f);
                             PLS_ATOMIC_OR(&j.self->vfail[par], 1u << f);
@@ -1675,6 +1943,8 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             }
         }
     }
+#undef SEGF
+#undef SEGL
 }
 
 /* ---- REPLAY: task (f, grp): lane = (segment of the group, part of the segment, channel) -----------------------------------

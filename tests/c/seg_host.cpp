@@ -56,6 +56,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     if (!seg_build_params(P, (int)strength, (int)bleed, getenv("SEG_HOST_SEEDED") != nullptr)) return 64;
     if (getenv("SEG_HOST_FORCE_FILTER")) P.engine_flags = (atoi(getenv("SEG_HOST_FORCE_FILTER")) + 1) << 8;
     if (getenv("SEG_HOST_FLAGS")) P.engine_flags |= atoi(getenv("SEG_HOST_FLAGS")) & 0xfe;   /* test hooks of the chain kernel (2: slow path, 4: wide stride) */
+    if (getenv("SEG_HOST_UNIT") && atoi(getenv("SEG_HOST_UNIT")) && !P.seeded && (P.ns <= SEG_NSP || atoi(getenv("SEG_HOST_UNIT")) > 1)) P.unit = SEG_UNIT;   /* enumeration in units, as the launcher asks for batches (seg_enum_unit_body) */
     /* classify + pack into slots (what pl_classify / pl_repack do on the device) */
     bool gray = true, opaque = true;
     for (size_t i = 0; i < (size_t)W * H; i++) { const unsigned char *p = rgba + 4 * i; gray &= p[0] == p[1] && p[1] == p[2]; opaque &= p[3] == 255; }
@@ -129,6 +130,16 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         /* the enumeration kernel is launched with exactly SEG_SM_ENUM_NT(nt) bytes of LDS: the bodies get a buffer of that size here, and the
          * sanitizer build (tests/test_seg_host.py) sees any byte they touch beyond it */
         std::vector<unsigned char> esm((size_t)SEG_SM_ENUM_NT(nt), 0x5A);
+        if (P.unit > 1) {
+            /* pl_seg.hip:seg_k_enum_unit: per candidate `per` workgroups of SEG_UNC (unit, channel) pairs, then the five walkers -- with the kernel's LDS size */
+            std::vector<unsigned char> usm((size_t)SEG_SM_ENUM_UNIT, 0x5A);
+            const uint32_t perb = (((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (j.nseg * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
+            for (int f = 0; f < SEG_NFILT; f++) {
+                if (seg_is_small(P, f)) { for (uint32_t g = 0; g < pers; g++) if (g * SEG_UNC_SMALL < j.nseg * j.bpp) seg_enum_unit_body<SEG_NSS, 1, SEG_UNC_SMALL>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
+                else { for (uint32_t g = 0; g < perb; g++) if (g * SEG_UNC < ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
+            }
+            for (int f = 0; f < SEG_NFILT; f++) seg_first_body<SEG_UNT>(j, P, seg_ctl_view(j, par, f), par, f, usm.data());
+        } else
         if (P.seeded) {
             std::vector<unsigned char> ssm((size_t)SEG_SM_ENUM_SEEDED(nt), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++)
@@ -146,7 +157,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
                 else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, 0, esm.data());
             }
         }
-        for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
+        if (P.unit <= 1) for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
         {   /* the chain kernel's LDS is sized by the row's segments: the same size here (the sanitizer build sees an overrun) */
             std::vector<unsigned char> csm((size_t)SEG_SM_CHAIN(j.nseg), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) { if (P.seeded) seg_chain_body<true>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data()); else seg_chain_body<false>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data()); }

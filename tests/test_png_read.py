@@ -64,7 +64,9 @@ def test_device_reader_rejects_what_is_not_png():
     out = np.zeros((p["height"], p["width"], 4), np.uint8)
     src = (L.PngSource * 1)(L.PngSource(bytes(bad_rows), p["width"], p["height"], p["ctype"], p["depth"], None, 0, None, 0, out.ctypes.data))
     lib = P.hip_lib()
-    lib.pngloss_hip_png_decode_batch_host.restype = __import__("ctypes").c_int
+    import ctypes as C
+    lib.pngloss_hip_png_decode_batch_host.argtypes = [C.c_void_p, C.POINTER(L.PngSource), C.c_size_t]      # (set here too: the test must not depend on an earlier one having called the wrapper)
+    lib.pngloss_hip_png_decode_batch_host.restype = C.c_int
     assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 25
     src[0] = L.PngSource(p["scanlines"], p["width"], p["height"], 2, 4, None, 0, None, 0, out.ctypes.data)   # RGB with 4 bits: no such format
     assert lib.pngloss_hip_png_decode_batch_host(ctx._ctx, src, 1) == 4

@@ -188,3 +188,52 @@ def test_seg_engine_tiny_images_that_need_very_many_attempts(key, s, b, filters)
     rc, out, f, st = U.run_seg_host(img, s, b, filters)
     want, wf = U.run_port(img, s, b, filters)
     assert rc == 0 and np.array_equal(out, want) and (not filters or np.array_equal(f, wf)), st
+
+
+UNIT_CASES = [(64, 48, m, 19, 2) for m in range(6)] + [
+    (200, 40, 0, 19, 2), (333, 37, 1, 19, 2), (130, 20, 5, 19, 4), (1, 1, 1, 19, 2), (5, 1, 1, 19, 2), (1, 7, 1, 19, 2), (33, 5, 3, 19, 2), (97, 33, 2, 7, 3),
+    (127, 9, 0, 19, 2), (128, 9, 0, 19, 2), (129, 9, 4, 19, 2), (511, 6, 0, 19, 2), (513, 6, 1, 19, 2), (640, 8, 3, 19, 2), (96, 20, 0, 3, 1), (80, 12, 1, 19, 32767),
+    (1600, 6, 0, 19, 2), (8300, 2, 0, 19, 2),
+    (95, 7, 0, 19, 2), (191, 5, 1, 19, 2), (192, 5, 0, 19, 2), (193, 5, 5, 19, 2), (289, 4, 2, 19, 2), (384, 4, 3, 19, 2),     # around SEG_UNIT * 32 pixels and the twelve pairs of a workgroup
+]
+
+
+@pytest.mark.parametrize("w,h,mode,s,b", UNIT_CASES)
+def test_seg_engine_enumeration_in_units_matches_oracle(monkeypatch, w, h, mode, s, b):
+    """What the launcher asks for when a BATCH keeps the GPU busy (SegParams::unit = SEG_UNIT; pl_host.hip): runs of four segments enumerated as one unit
+    -- from every state only at the unit's first pixel, the distinct states through all its segments, twelve (unit, channel) pairs per workgroup, none / up
+    through the same body with their own small state set -- and the chain kernel composing units.  Widths around the unit (128 pixels) and the
+    workgroup's twelve pairs, every byte-per-pixel class, rows that need epochs (their first unit is walked) and the strength retry."""
+    monkeypatch.setenv("SEG_HOST_UNIT", "1")
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+
+
+@pytest.mark.parametrize("filters", [True, False])
+def test_seg_engine_units_cost_no_attempts(monkeypatch, filters):
+    """the attempt count is what a wrong map, id or entry state would show in (the validation makes the bytes right whatever happens): enumeration in units
+    takes exactly the attempts the per-segment enumeration takes"""
+    img = P.synth_rgba(1024, 96, 0, 0)
+    want, wf = U.run_port(img, 19, 2, filters=filters)
+    res = {}
+    for unit in ("0", "1"):
+        monkeypatch.setenv("SEG_HOST_UNIT", unit)
+        rc, out, f, st = U.run_seg_host(img, 19, 2, filters=filters)
+        assert rc == 0 and np.array_equal(out, want)
+        if filters:
+            assert np.array_equal(f, wf)
+        res[unit] = (int(st[0]), int(st[1]), int(st[3]))
+    assert res["1"][0] <= res["0"][0] + 2 and res["1"][2] == 0, res
+
+
+def test_seg_engine_units_with_a_state_set_of_several_chunks(monkeypatch):
+    """(the launcher does not pick units for such sets -- the distinct states of twelve pairs outgrow a workgroup's lanes and the surplus costs epochs --,
+    but the body must stay exact there: SEG_HOST_UNIT=2 forces it)"""
+    monkeypatch.setenv("SEG_HOST_UNIT", "2")
+    for (w, h, mode, s, b) in [(260, 12, 0, 20, 2), (200, 10, 2, 40, 2)]:
+        img = P.synth_rgba(w, h, mode, 0)
+        rc, out, f, st = U.run_seg_host(img, s, b)
+        want, wf = U.run_port(img, s, b)
+        assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
