@@ -269,6 +269,8 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         bool units = can && segs > SEG_UNIT_MIN_SEGS;
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_UNIT")) units = can && std::atoi(e) != 0;
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
+        ctx->h_seg_params.tparts = units ? 1 : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
+        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_TPARTS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) ctx->h_seg_params.tparts = v; }   /* (timing / test hook) */
     }
     SegGroups gs;
     gs.n = ngroups;
@@ -309,6 +311,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         b.small_ok = params.small_ok != 0;
         b.seeded = params.seeded != 0;
         b.unit = (uint32_t)ctx->h_seg_params.unit;
+        b.tparts = (uint32_t)ctx->h_seg_params.tparts;
         b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
         if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
     }

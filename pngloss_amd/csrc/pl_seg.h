@@ -22,6 +22,7 @@ struct PlSegBatch {
     uint32_t enum_nt;         /* threads of the enumeration's workgroups: 512 or 1024 (SEG_ENUM_NT_SMALL_MAX_NSEG) */
     bool small_ok;            /* SegParams::small_ok (none / up enumerated with their own small state set) */
     bool seeded;              /* SegParams::seeded (seg_k_enum_seeded) */
+    uint32_t tparts;          /* SegParams::tparts */
     uint32_t unit;            /* SegParams::unit: 1, or SEG_UNIT = enumeration in units (seg_k_enum_unit; batches) */
 };
 

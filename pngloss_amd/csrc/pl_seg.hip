@@ -61,7 +61,8 @@ __global__ SEG_CTL_BOUNDS void seg_k_ctl(const SegJob *__restrict__ sj, const Se
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     if (blockIdx.x < nctl) {
-        if (blockIdx.x > SEG_CTL_IMG && (blockIdx.x - SEG_CTL_IMG - 1) * SEG_COMMIT_W >= j.W) return;
+        const unsigned ctl_img = (unsigned)SEG_CTL_IMG_OF(*P);
+        if (blockIdx.x > ctl_img && (blockIdx.x - ctl_img - 1) * SEG_COMMIT_W >= j.W) return;
         seg_ctl_body(j, *P, k, (int)blockIdx.x, seg_smem);
         return;
     }
@@ -137,27 +138,28 @@ __global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restr
         seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
     } else {
         const unsigned r = blockIdx.x - nb, f = r / pers ? 2u : 0u, grp = r % pers;
-        if (grp * SEG_UNC_SMALL >= j.nseg * j.bpp) return;
-        seg_enum_unit_body<SEG_NSS, 1, SEG_UNC_SMALL>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
+        if (grp * SEG_UNC_SMALL >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
+        seg_enum_unit_body<SEG_NSS, SEG_UNIT, SEG_UNC_SMALL>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
     }
 }
 
-template <bool SEEDED>
-__global__ __launch_bounds__(SEG_CHAIN_THREADS) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
+template <bool SEEDED, int CT>
+__global__ __launch_bounds__(CT) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
-    if (blockIdx.x == 0) { seg_extremes_body(j, *P, seg_view_of(sj + blockIdx.y, par, 0), par, seg_smem); return; }      /* (the spare workgroup, dispatched first: the row's extremes for none's bound) */
-    seg_chain_body<SEEDED>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)((blockIdx.x - 1) >> 2)), par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
+    if (blockIdx.x == 0) { seg_extremes_body<CT>(j, *P, seg_view_of(sj + blockIdx.y, par, 0), par, seg_smem); return; }      /* (the spare workgroup, dispatched first: the row's extremes for none's bound) */
+    seg_chain_body<SEEDED, CT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)((blockIdx.x - 1) >> 2)), par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
 }
 
-__global__ __launch_bounds__(SEG_REPLAY_NT) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
+template <int RNT>
+__global__ __launch_bounds__(RNT) void seg_k_replay(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     const unsigned f = blockIdx.x / max_ngrp, grp = blockIdx.x % max_ngrp;
     if (grp >= j.ngrp) return;
-    seg_replay_body(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
+    seg_replay_body<RNT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
 }
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -167,8 +169,10 @@ hipError_t chain_attr()
 {
     static std::atomic<unsigned> done_chain{ 0 }, done_ctl{ 0 };
     static std::atomic<unsigned> done_chain_s{ 0 };
-    hipError_t e = pl_lds_optin((const void *)seg_k_chain<false>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
-    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
+    static std::atomic<unsigned> done_chain_u{ 0 };
+    hipError_t e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
+    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS_UNIT>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_u);
+    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true, SEG_CHAIN_THREADS>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
     if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl, SEG_SM_CTLVAL, done_ctl);
     return e;
 }
@@ -234,7 +238,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     {
         /* (the validation workgroups can be left out at COMPILE time only -- SEG_EXPERIMENT_NO_VAL_CODE, a timing experiment whose results are unvalidated;
          *  the shipped library has no run-time switch that changes what it computes) */
-        const unsigned nctl = SEG_CTL_IMG + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
+        const unsigned nctl = SEG_NFILT * b.tparts + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
         hipLaunchKernelGGL(seg_k_ctl, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
     }
     {
@@ -243,7 +247,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
         const size_t enum_lds = (size_t)SEG_SM_ENUM_NT(nt);
         if (b.unit > 1 && !b.seeded) {
-            const unsigned perb = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (b.max_nseg * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
+            const unsigned perb = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
             const unsigned blocks = (small_ok ? 3 * perb + 2 * pers : SEG_NFILT * perb) + SEG_NFILT;
             hipLaunchKernelGGL(seg_k_enum_unit, dim3(blocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers);
         } else
@@ -255,8 +259,10 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
         else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
     }
-    if (b.seeded) hipLaunchKernelGGL(seg_k_chain<true>, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
-    else hipLaunchKernelGGL(seg_k_chain<false>, dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
-    hipLaunchKernelGGL(seg_k_replay, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_NT), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
+    if (b.seeded) hipLaunchKernelGGL((seg_k_chain<true, SEG_CHAIN_THREADS>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    else if (b.unit > 1) hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS_UNIT>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS_UNIT), SEG_SM_CHAIN_X((b.max_nseg + b.unit - 1) / b.unit), stream, b.d_sj, b.d_params, par);
+    else hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN_X(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    if (b.unit > 1) hipLaunchKernelGGL(seg_k_replay<SEG_REPLAY_NT_BATCH>, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_NT_BATCH), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
+    else hipLaunchKernelGGL(seg_k_replay<SEG_REPLAY_NT>, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_NT), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();
 }

@@ -151,7 +151,7 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_VGRP 8                /* segments per VALIDATION workgroup (half a replay group: one decision per thread, twice the CUs) */
 #define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
 #define SEG_COMMIT_W 256           /* control kernel: pixels per commit workgroup */
-#define SEG_CTL_IMG (SEG_NFILT * SEG_TPARTS)      /* blockIdx.x of the image-wide workgroup; the commit workgroups follow */
+#define SEG_CTL_IMG_OF(P) (SEG_NFILT * (P).tparts)      /* blockIdx.x of the image-wide workgroup; the commit workgroups follow */
 #define SEG_PARTS 4               /* the replay cuts a segment into this many parts: the enumeration leaves the state at every cut (checkpoints) */
 #define SEG_PL (SEG_L / SEG_PARTS)
 #define SEG_NSP 256              /* lanes per channel in the enumeration; also the most DISTINCT states a segment may have after the dedupe */
@@ -166,8 +166,10 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_NG_BURST 16              /* group counts a lane requests in one burst (rows up to 8192 pixels); the groups of wider rows are read in a loop behind it */
 #define SEG_MAX_WIDTH (1u << 20)      /* rows the engine takes (libpng's own default limit); the chain kernel walks a row in passes, nothing else depends on the width */
 #define SEG_THREADS 1024
-#define SEG_CHAIN_THREADS 1024
+#define SEG_CHAIN_THREADS 1024       /* the chain kernel's workgroups for one image (the gather of 256 transitions x 64 ids wants the lanes) ... */
+#define SEG_CHAIN_THREADS_UNIT 256   /* ... and when the row is composed in units (batches: a third of the transitions, and a CU holds two workgroups of 1024 threads but eight of 256) */
 #define SEG_REPLAY_THREADS (SEG_GRP * SEG_L)   /* pixels of a replay group: the first SEG_REPLAY_THREADS threads of the workgroup take one each, SEG_GRP * SEG_PARTS * 4 of them walk */
+#define SEG_REPLAY_NT_BATCH SEG_REPLAY_THREADS  /* ... of batches composed in units: a CU holds two workgroups of 1024 threads, but three of 512 with the 50 KB they ask for */
 #define SEG_REPLAY_NT (2 * SEG_REPLAY_THREADS) /* threads of the replay's workgroups: the second half helps with the staging and takes the bump counts while the first takes the sums */
 #define SEG_KEYLUT_MAX 8192
 #define SEG_NSS 32                /* lanes per channel for none / up */
@@ -221,6 +223,9 @@ struct SegParams {
      * SEG_UNIT = a run of SEG_UNIT segments is enumerated as one (seg_enum_unit_body): from every state only at its first pixel, its distinct states
      * run on through all its segments.  Set by the launcher (seg_build_params leaves 1). */
     int32_t unit;
+    /* control kernel: workgroups that share the build of one candidate's decision tables: SEG_TPARTS (one image: the build is on the critical path of
+     * every row), 1 for batches (a quarter of the control workgroups: what a batch pays for is workgroups, not the length of one) */
+    int32_t tparts;
 };
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
@@ -650,9 +655,9 @@ PLS_HD uint32_t seg_state_encode(const SegParams &P, const SegPix &b, const SegS
 
 /* none / up: the state is (cn, th) */
 PLS_HD bool seg_is_small(const SegParams &P, int f) { return P.small_ok && (f == 0 || f == 2); }
-/* segments per enumeration unit of candidate f (SegParams::unit): none / up with their small state set keep single segments -- their few states cost next to
- * nothing per segment, and a short dependent path lets their workgroups make room for the long ones */
-PLS_HD uint32_t seg_unit_of(const SegParams &P, int f) { return (P.unit > 1 && !P.seeded && !seg_is_small(P, f)) ? (uint32_t)P.unit : 1u; }
+/* segments per enumeration unit of candidate f (SegParams::unit).  (none / up with their small state set segment by segment -- short workgroups between the
+ * long ones -- was measured: 106.7 against 100.5 us for 32 frames of 1080p, and their chains then compose three times as many tables: every candidate in units) */
+PLS_HD uint32_t seg_unit_of(const SegParams &P, int f) { (void)f; return (P.unit > 1 && !P.seeded) ? (uint32_t)P.unit : 1u; }
 PLS_HD bool seg_small_decode(const SegParams &P, int i, SegState &st)
 {
     if (i >= P.ns_small) return false;
@@ -763,7 +768,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
 {
     memset(&P, 0, sizeof P);
     if (strength < 0 || strength > 255 || bleed < 1 || bleed > 32767) return false;
-    P.strength = strength; P.bleed = bleed; P.unit = 1;
+    P.strength = strength; P.bleed = bleed; P.unit = 1; P.tparts = SEG_TPARTS;
     for (int d = -256; d <= 255; d++) {
         const SegSplit s = seg_split_slow(d, bleed);
         P.lut_a[d + 256] = ((uint32_t)s.rem & 0xffffu) | ((uint32_t)s.h << 16);
@@ -808,7 +813,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
 /* what the enumeration kernel's bodies really carve out for NT threads (seg_enum_body is the largest: tables, pixels, split table, hash table,
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
-#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 * 4 + SEG_GRP * SEG_PARTS * 4 * 8 + SEG_GRP * SEG_L * 16 + (SEG_GRP * SEG_L + 3) * 4 + 64)
+#define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 + SEG_GRP * SEG_PARTS * 4 * 8 + SEG_GRP * SEG_L * 16 + (SEG_GRP * SEG_L + 3) * 4 + 64)
 #define SEG_SM_POST ((768 + (2 * SEG_VGRP + 1) * 256 + (SEG_VGRP * SEG_L + 2) * 4 + 64 + 512 + 3 * (SEG_VGRP * SEG_L + 2) + 2 * SEG_VGRP * SEG_L + 768 + 32 + 64 + SEG_VGRP * SEG_L + SEG_VGRP * (SEG_L + 1) + 8 * (SEG_VGRP * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands) */
 #define SEG_SM_CTLVAL (SEG_SM_CTL > SEG_SM_POST ? SEG_SM_CTL : SEG_SM_POST)   /* the first launch of an attempt carries control and validation workgroups */
 #define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 4 + (SEG_NFILT + 1) * 256 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
@@ -1251,13 +1256,17 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCt
  *   - a workgroup takes SEG_UNC pairs (unit, channel) of ONE candidate, from the row's linear list unit * bpp + channel -- in turns of as many
  *     pairs as its 1024 lanes hold states for -- and then packs the distinct states of ALL its pairs into its first lanes: ~200 lanes = four
  *     waves that share one copy of the candidate's tables (12.8 KB) instead of one or two half-empty waves per 35 KB workgroup;
- *   - none / up (LANES = 32: their state is (cn, th)) go through the same body, dedupe included (~3 distinct states per pair instead of 17 lanes), but
- *     segment by segment (UNIT = 1, 24 pairs a workgroup: seg_unit_of): units would save them nothing worth having, and their short workgroups fill
- *     the CUs' slots between the long ones instead of holding one each for a whole unit.
+ *   - none / up (LANES = 32: their state is (cn, th)) go through the same body, dedupe included: ~3 distinct states per pair instead of 17 lanes,
+ *     24 pairs a workgroup.
  * The chain kernel composes UNITS (seg_chain_body reads SegParams::unit); replay and validation do not know the difference. */
-#define SEG_UNC_SMALL 24          /* (segment, channel) pairs per workgroup for none / up with their small state set (UNIT = 1) */
-#define SEG_UNPX ((SEG_UNC * (SEG_UNIT * SEG_L + 1)) > (SEG_UNC_SMALL * (SEG_L + 1)) ? (SEG_UNC * (SEG_UNIT * SEG_L + 1)) : (SEG_UNC_SMALL * (SEG_L + 1)))   /* pixel records of a workgroup's pairs */
-#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UNPX * 8 + 2048 * 4 + 2048 * 2 + 1024 * 4 + SEG_UPOOL * 4 + SEG_UNT * 4 + 256)
+#define SEG_UNC_SMALL 24          /* (unit, channel) pairs per workgroup for none / up with their small state set */
+#define SEG_UNPX (SEG_UNC_SMALL * (SEG_UNIT * SEG_L + 1))   /* pixel records of a workgroup's pairs */
+/* LDS of the unit enumeration: tables, split table, the pool, the first records of every pair, bookkeeping -- and ONE region that holds the first phase's
+ * scratch (hash tables, per-turn lists, keys: 20 KB) and then, for the second phase, the pairs' full pixel records: 40 KB = four workgroups per CU (the
+ * first version carved both side by side: 52 KB, three per CU, and the CUs' slots, not their issue, set the kernel's time) */
+#define SEG_UN_K1MAX 4
+#define SEG_UN_SCRATCH (2048 * 4 + 2048 * 2 + 1024 * 4 + SEG_UNT * 4)
+#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UPOOL * 4 + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1) * 8 + 256 + (SEG_UN_SCRATCH > SEG_UNPX * 8 ? SEG_UN_SCRATCH : SEG_UNPX * 8))
 template <int LANES, int UNIT, int NC>
 PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int grp, unsigned char *smem)
 {
@@ -1273,15 +1282,20 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     const uint32_t sx = cv.start_x;
     /* an epoch that starts inside the row: the unit that holds its first pixel (and everything in front) is walked by seg_first_body */
     { const uint32_t ql = seg_umin(q0 + NC, ncombo) - 1u; if (sx && (ql / bpp) * UL <= sx) return; }
+    constexpr uint32_t NP1 = SEG_UN_K1MAX + 1;                /* records of a pair the first phase reads: the boundary pixel and SEG_K1 more */
     uint32_t *tw = (uint32_t *)smem;
     uint32_t *lut = tw + SEG_TBL_WORDS;
-    SegPix *px = (SegPix *)(lut + 512);                       /* [NC][NPX]: one channel's records of a pair, slot 0 = the boundary pixel in front of the unit */
-    uint32_t *ht = (uint32_t *)(px + SEG_UNPX);               /* [CPR][HT] key or ~0 (this turn) */
+    uint32_t *pool = lut + 512;                               /* [SEG_UPOOL] the distinct states of all pairs, pair behind pair */
+    SegPix *px1 = (SegPix *)(pool + SEG_UPOOL);               /* [NC][NP1]: one channel's first records of a pair, slot 0 = the boundary pixel in front of the unit */
+    uint32_t *misc = (uint32_t *)(px1 + SEG_UNC_SMALL * NP1); /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total) */
+    /* first phase: */
+    uint32_t *ht = misc + 64;                                 /* [CPR][HT] key or ~0 (this turn) */
     uint16_t *dense = (uint16_t *)(ht + 2048);                /* [CPR][HT] slot -> dense id */
     uint32_t *uniqr = (uint32_t *)(dense + 2048);             /* [CPR][LANES] this turn's distinct states by dense id */
-    uint32_t *pool = uniqr + 1024;                            /* [SEG_UPOOL] the distinct states of all pairs, pair behind pair */
-    uint32_t *keys = pool + SEG_UPOOL;                        /* [NT] */
-    uint32_t *misc = keys + NT;                               /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total) */
+    uint32_t *keys = uniqr + 1024;                            /* [NT] */
+    /* second phase, in the same place: */
+    SegPix *px = (SegPix *)(misc + 64);                       /* [NC][NPX]: all records of a pair */
+    static_assert(SEG_K1 <= SEG_UN_K1MAX && SEG_K1_ONE_CHUNK <= SEG_UN_K1MAX, "the first phase's records");
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
@@ -1289,32 +1303,27 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     PLS_THREADS(tid, NT) { if (tid < 64) misc[tid] = 0u; }
     PLS_SYNC();
     PLS_THREADS(tid, NT) {
-        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT, NPI = (NC * (int)NPX + NT - 1) / NT;
+        constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
+        static_assert(NC * (SEG_UN_K1MAX + 1) <= NT, "one first-phase record per thread");
         uint32_t vt[NTW], vl = 0;
-        SegPix vp[NPI];
+        SegPix vp = seg_pix_make(0, 0, 0, 0, 0);
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; vt[q] = i < SEG_TBL_WORDS ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (tid < 512) vl = P.lut_a[tid];
-        PLS_UNROLL
-        for (int q = 0; q < NPI; q++) {
-            const uint32_t t = (uint32_t)tid + (uint32_t)q * NT, k = t / NPX, pq = t % NPX, cq = q0 + k;
-            vp[q] = seg_pix_make(0, 0, 0, 0, 0);
+        {
+            const uint32_t k = (uint32_t)tid / NP1, pq = (uint32_t)tid % NP1, cq = q0 + k;
             if (k < (uint32_t)NC && cq < ncombo) {
                 const uint32_t u = cq / bpp, c = cq % bpp, x = u * UL + pq - 1u;          /* (pq = 0 in front of the row: wraps beyond W -- a zero record) */
-                if (x < W) vp[q] = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
+                if (x < W) vp = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
             }
         }
         PLS_UNROLL
         for (int q = 0; q < NTW; q++) { const int i = tid + q * NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
         if (tid < 512) lut[tid] = vl;
-        PLS_UNROLL
-        for (int q = 0; q < NPI; q++) {
-            const uint32_t t = (uint32_t)tid + (uint32_t)q * NT;
-            if (t < (uint32_t)NC * NPX) { px[t] = vp[q]; if (vp[q].w >> 24) PLS_ATOMIC_OR(&misc[0], 1u); }
-        }
+        if ((uint32_t)tid < (uint32_t)NC * NP1) { px1[tid] = vp; if (vp.w >> 24) PLS_ATOMIC_OR(&misc[0], 1u); }
     }
     PLS_SYNC();
-    const bool trx = misc[0] != 0u;
+    const bool trx1 = misc[0] != 0u;
     const int K1 = seg_k1(nstates);
     /* -- first phase, a turn of CPR pairs at a time: SEG_K1 steps from every state, the dedupe, the pair's entry map (entry index -> dense id) -- */
     for (int r = 0; r < ROUNDS; r++) {
@@ -1329,10 +1338,10 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
                 const uint32_t cq = q0 + (uint32_t)k;
                 uint32_t key = 0xffffffffu;
                 if (kk < CPR && k < NC && cq < ncombo && i < nstates && !(sx && (cq / bpp) * UL <= sx)) {
-                    const SegPix *pk = px + (size_t)k * NPX;
+                    const SegPix *pk = px1 + (size_t)k * NP1;
                     SegState st;
                     if (seg_any_decode(P, f, i, pk[0], st)) {
-                        const int bad = seg_run_fast_f(f, trx, pk + 1, 1, K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                        const int bad = seg_run_fast_f(f, trx1, pk + 1, 1, K1, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
                         if (!bad && st.cn >= -128 && st.cn <= 127) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16);
                     }
                 }
@@ -1401,6 +1410,27 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
         }
         PLS_SYNC();
     }
+    /* -- the pairs' full records, where the first phase's scratch was (nobody reads that any more: a barrier lies behind its last use) -- */
+    PLS_THREADS(tid, NT) {
+        constexpr int NPI = (NC * (int)NPX + NT - 1) / NT;
+        SegPix vp[NPI];
+        PLS_UNROLL
+        for (int q = 0; q < NPI; q++) {
+            const uint32_t t = (uint32_t)tid + (uint32_t)q * NT, k = t / NPX, pq = t % NPX, cq = q0 + k;
+            vp[q] = seg_pix_make(0, 0, 0, 0, 0);
+            if (k < (uint32_t)NC && cq < ncombo && misc[32 + k + 1] != misc[32 + k]) {            /* (a pair without a lane needs no records) */
+                const uint32_t u = cq / bpp, c = cq % bpp, x = u * UL + pq - 1u;
+                if (x < W) vp[q] = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
+            }
+        }
+        PLS_UNROLL
+        for (int q = 0; q < NPI; q++) {
+            const uint32_t t = (uint32_t)tid + (uint32_t)q * NT;
+            if (t < (uint32_t)NC * NPX) { px[t] = vp[q]; if (vp[q].w >> 24) PLS_ATOMIC_OR(&misc[0], 1u); }
+        }
+    }
+    PLS_SYNC();
+    const bool trx = misc[0] != 0u;
     /* -- second phase: the distinct states of all pairs, one lane each, through every segment of their unit -- */
     PLS_THREADS(tid, NT) {
         const uint32_t total = misc[32 + NC];
@@ -1445,8 +1475,13 @@ PLS_HD void seg_load_frozen(const SegJob &j, int par, int f, uint32_t *Hf, uint3
     }
 }
 
+/* bump counters of ONE segment, four bins a word (a segment has at most SEG_L * 4 = 128 decisions: a byte holds its count of any bin) -- a quarter of the
+ * shared memory of a word per bin, which is what lets a CU hold three replay workgroups instead of two */
+PLS_HD void seg_cnt_add(uint32_t *cnt, int bin, uint32_t v) { PLS_ATOMIC_ADD(&cnt[bin >> 2], v << (8 * (bin & 3))); }
+PLS_HD uint32_t seg_cnt_get(const uint32_t *cnt, int bin) { return (cnt[bin >> 2] >> (8 * (bin & 3))) & 255u; }
+static_assert(SEG_L * 4 <= 255, "a segment's bump count of a bin fits a byte");
 /* pixels [xa, xe) of one channel from state st: the table steps, and if a lane leaves what the tables cover, once more by scanning.
- * out: candidate words (stride 4 words per pixel) or null; cnt: bump counters (256) or null. */
+ * out: candidate words (stride 4 words per pixel) or null; cnt: the segment's bump counters (seg_cnt_add: 64 words) or null. */
 PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t xe, SegState &st, seg_lds_cu32 tw, seg_lds_cu32 lut, const uint32_t *Hf,
                      const uint32_t *rank, const SegGeo &G, const uint32_t *lut_g, int bleed, uint32_t *out, uint32_t *cnt)
 {
@@ -1464,16 +1499,16 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
         default: w = seg_step_fast<0, true>(p, st, bad, tw, cls, G, lut); break;
         }
         if (out) out[(size_t)(x - xa) * 4] = w;
-        if (cnt) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(w)], 1u);
+        if (cnt) seg_cnt_add(cnt, seg_cand_bin(w), 1u);
     }
     if (seg_bad(bad)) {
         /* (rare) take the bumps back and do the range again by scanning */
-        if (cnt && out) for (uint32_t x = xa; x < xe; x++) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(out[(size_t)(x - xa) * 4])], 0u - 1u);
+        if (cnt && out) for (uint32_t x = xa; x < xe; x++) seg_cnt_add(cnt, seg_cand_bin(out[(size_t)(x - xa) * 4]), 0u - 1u);
         st = st0;
         for (uint32_t x = xa; x < xe; x++) {
             const uint32_t w = seg_step_scan(f, px[(size_t)(x - xa) * pstride], st, Hf, nullptr, rank, G, lut_g, bleed);
             if (out) out[(size_t)(x - xa) * 4] = w;
-            if (cnt) PLS_ATOMIC_ADD(&cnt[seg_cand_bin(w)], 1u);
+            if (cnt) seg_cnt_add(cnt, seg_cand_bin(w), 1u);
         }
     }
 }
@@ -1571,8 +1606,10 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
 #define SEG_CHAIN_TBYTES(n) ((size_t)SEG_CHAIN_TROWS(n) * 512)     /* T (and R behind it at the usual stride) for a row of n segments: the widest stride sets the size */
 #define SEG_CHAIN_GWORDS ((SEG_CHAIN_CAP / SEG_CBLK + 2) * 256 / 2)
 #define SEG_SM_CHAIN(nseg) ((1024 + 32 + 2 * SEG_CHAIN_POS + SEG_CHAIN_GWORDS) * 4 + SEG_CHAIN_TBYTES(nseg) + SEG_TBL_WORDS * 4 + (SEG_L + 1) * 8 + 64)
+/* (exhaustive state sets: no repair path, so no tables and pixel records behind T; npos = the row's chain positions: units) */
+#define SEG_SM_CHAIN_X(npos) ((1024 + 32 + 2 * SEG_CHAIN_POS + SEG_CHAIN_GWORDS) * 4 + SEG_CHAIN_TBYTES(npos) + 64)
 PLS_HD uint32_t seg_chain_cap(uint32_t sh) { return sh >= 8 ? (uint32_t)SEG_CHAIN_CAP8 : (uint32_t)SEG_CHAIN_CAP; }
-template <bool SEEDED>
+template <bool SEEDED, int CT>
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int c, unsigned char *smem)
 {
     if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
@@ -1581,7 +1618,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
     if (sx >= W) return;
     const uint32_t first = sx / SEG_L;
     SEG_AS_GLB uint16_t *dnout = j.dnout + (size_t)f * nseg * 4 + c;                           /* + sg * 4 */
-    if (sx || nseg == 1) { PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) dnout[(size_t)first * 4] = (uint16_t)SEG_INVALID; } }   /* a walked first segment has no checkpoints */
+    if (sx || nseg == 1) { PLS_THREADS(tid, CT) { if (tid == 0) dnout[(size_t)first * 4] = (uint16_t)SEG_INVALID; } }   /* a walked first segment has no checkpoints */
     if (first + 1 >= nseg) return;
     constexpr bool seeded = SEEDED;                             /* (= P.seeded: two kernels, so that the exhaustive sets' gather does not carry the seeded one's registers) */
     /* The chain composes UNITS: E = SegParams::unit segments enumerated as one (seg_enum_unit_body; 1: every segment on its own, and always for seeded
@@ -1600,7 +1637,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
     seg_lds_u32 entL = dn + SEG_CHAIN_POS;                     /* [SEG_CHAIN_POS] entry state at every position of the pass (from 1; 0: idxb[26]) */
     seg_lds_u16 G = (seg_lds_u16)(entL + SEG_CHAIN_POS);       /* [nblk + 1][stride] composed tables of the blocks */
     seg_lds_u16 T = G + 2 * SEG_CHAIN_GWORDS;                  /* [rows][stride]: T[k] takes a dense id of position k to one of position k+1 */
-    seg_lds_u32 twr = (seg_lds_u32)((SEG_AS_LDS unsigned char *)T + SEG_CHAIN_TBYTES(nseg));   /* (repair only) the candidate's decision tables, then the walked segment's pixel records */
+    seg_lds_u32 twr = (seg_lds_u32)((SEG_AS_LDS unsigned char *)T + SEG_CHAIN_TBYTES(nseg));   /* (repair only: seeded sets, whose launch asks for SEG_SM_CHAIN) the candidate's decision tables, then the walked segment's pixel records */
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SEG_AS_GLB uint16_t *maps = j.maps + ((size_t)f * nseg * 4 + c) * (size_t)P.nsp;     /* + sg * 4 * nsp */
@@ -1615,11 +1652,11 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
     const SegState start0 = { 0, 0, 0 };
     const bool prof = (eflags & 1) != 0;
     unsigned long long tacc[4] = { 0, 0, 0, 0 }, tc[5] = { 0, 0, 0, 0, 0 };
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid < 32) idxb[tid] = 0u; }
+    PLS_THREADS(tid, CT) { if (tid < 32) idxb[tid] = 0u; }
     PLS_SYNC();
     if (ns == 0) {
         /* ONE enumerated unit (the row's last, behind a walked one -- or the whole of a short row): nothing to compose, its id is the start state's */
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        PLS_THREADS(tid, CT) {
             if (tid == 0) {
                 const uint32_t start_ps = sx ? j.firstidx[(f * 4 + c) * 2 + 1] : seg_state_pack(start0);
                 uint32_t d = SEG_INVALID;
@@ -1656,7 +1693,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
         const uint32_t ntr = seg_umin(seg_chain_cap(sh), ns - a);
         if (ntr == 0) {
             /* only the row's last segment is left (behind a repair): it has the id the repair looked up */
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { const uint32_t d = idxb[28]; dnout[(size_t)SEGF(s0 + a) * 4] = (uint16_t)(d < SEG_NSP ? d : SEG_INVALID); } }   /* (seeded sets: E = 1) */
+            PLS_THREADS(tid, CT) { if (tid == 0) { const uint32_t d = idxb[28]; dnout[(size_t)SEGF(s0 + a) * 4] = (uint16_t)(d < SEG_NSP ? d : SEG_INVALID); } }   /* (seeded sets: E = 1) */
             break;
         }
         if (prof) tc[0] = PLS_CLOCK();
@@ -1666,9 +1703,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
         const uint32_t dummy = (ntr + 1u) << sh;
         /* -- gather: T[k][d] = index of the successor's cell and R[k][d] = the exit state itself (= entry state of position k+1); per item the
          *    loads that need nothing first, then the dependent ones; SEG_CQ items per thread at a time -- */
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        PLS_THREADS(tid, CT) {
             /* (one lane) the state and the id the chain starts from: its loads ride along with the gather's, one level each */
-            const bool starter = first_iter && tid == SEG_CHAIN_THREADS - 1;
+            const bool starter = first_iter && tid == CT - 1;
             uint32_t fi0 = 0, fi1 = 0, dfirst = SEG_INVALID;
             if (starter && sx) { fi0 = j.firstidx[(f * 4 + c) * 2]; fi1 = j.firstidx[(f * 4 + c) * 2 + 1]; }
             const uint32_t start_ps = sx ? fi1 : seg_state_pack(start0);
@@ -1676,7 +1713,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             const uint32_t start_key = seg_eh_key_of_packed(start_ps), start_base = seg_eh_base(start_key);
             /* item (k, d): k = position of the pass, d = dense id; this thread's items share d and step through k by kstep.  32-bit offsets
              * from uniform bases (the whole gather is bound by the instructions 1024 threads issue on one CU, not by memory) */
-            const uint32_t d = (uint32_t)tid & (stride - 1), k0 = (uint32_t)tid >> sh, kstep = (uint32_t)SEG_CHAIN_THREADS >> sh;
+            const uint32_t d = (uint32_t)tid & (stride - 1), k0 = (uint32_t)tid >> sh, kstep = (uint32_t)CT >> sh;
             uint32_t widest = 0;
             for (uint32_t kb = 0; kb < ntr; kb += SEG_CQ * kstep) {
                 /* no branch per item: an item beyond the last transition is clamped onto it and does that one's work once more (same
@@ -1746,7 +1783,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             }
             if (widest > stride) { idxb[30] = 1u; PLS_ATOMIC_MAX_U(&idxb[27], widest); }
             /* rows behind the last table (the landing row, then spare rows up to whole blocks): they lead to the absorbing cell */
-            for (uint32_t t = (ntr << sh) + (uint32_t)tid; t < (nblk * SEG_CBLK) << sh; t += SEG_CHAIN_THREADS) T[t] = (uint16_t)dummy;
+            for (uint32_t t = (ntr << sh) + (uint32_t)tid; t < (nblk * SEG_CBLK) << sh; t += CT) T[t] = (uint16_t)dummy;
             if (starter) {
                 idxb[28] = dfirst;
                 idxb[26] = start_ps;
@@ -1759,7 +1796,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             /* some segment of the pass has more distinct states than the stride holds: once more, wider (its last dense ids would alias) */
             const uint32_t need = idxb[27];
             PLS_SYNC();
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { idxb[30] = 0u; idxb[27] = 0u; } }
+            PLS_THREADS(tid, CT) { if (tid == 0) { idxb[30] = 0u; idxb[27] = 0u; } }
             PLS_SYNC();
             while ((1u << sh) < need && sh < 8) sh++;
             nwide++;
@@ -1768,10 +1805,10 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
         if (prof) tc[1] = PLS_CLOCK();
         const uint32_t gdummy = nblk << sh;                        /* G's absorbing cell: the row behind its last block */
         const uint32_t smask = stride - 1u;
-        PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+        PLS_THREADS(tid, CT) {
             if (tid == 0) G[gdummy] = (uint16_t)gdummy;
             /* block b composes T[b*CBLK .. (b+1)*CBLK - 1]: the id at its first position -> the id at the next block's first position */
-            for (uint32_t t = (uint32_t)tid; t + stride < (nblk << sh); t += SEG_CHAIN_THREADS) {
+            for (uint32_t t = (uint32_t)tid; t + stride < (nblk << sh); t += CT) {
                 const uint32_t b = t >> sh;
                 uint32_t i = ((b * SEG_CBLK) << sh) + (t & smask);
                 PLS_UNROLL
@@ -1789,7 +1826,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
         bool done = false, next_pass = false;
         for (;;) {
             const uint32_t bq = pos0 / SEG_CBLK, off = pos0 % SEG_CBLK;
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            PLS_THREADS(tid, CT) {
                 if ((uint32_t)tid >= bq && (uint32_t)tid < nblk) {
                     /* thread b: the true id at the head of block b (across the composed tables), then through the block.  Every lane walks the
                      * heads of ALL blocks (the same chain of loads in every lane: no lane-dependent loop) and keeps its own */
@@ -1823,9 +1860,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 }
             }
             PLS_SYNC();
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            PLS_THREADS(tid, CT) {
                 /* ids out; entry state of position k+1 = exit state of position k under its id */
-                for (uint32_t k = pos0 + (uint32_t)tid; k < npos; k += SEG_CHAIN_THREADS) {
+                for (uint32_t k = pos0 + (uint32_t)tid; k < npos; k += CT) {
                     uint32_t d = dn[k];
                     if ((eflags & 2) && k >= pos0 + 1u) d = SEG_INVALID;                  /* (test hook: every second segment through the repair) */
                     const uint32_t sg = s0 + a + k;
@@ -1856,7 +1893,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 PLS_SYNC();
                 a += ntr;
                 if (a >= ns) { done = true; break; }                   /* (the landing position was the row's last segment: its id is out) */
-                PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { idxb[28] = nd; idxb[26] = ne_; } }
+                PLS_THREADS(tid, CT) { if (tid == 0) { idxb[28] = nd; idxb[26] = ne_; } }
                 PLS_SYNC();
                 next_pass = true;
                 break;
@@ -1872,7 +1909,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 PLS_SYNC();
                 const uint32_t kqb = a + fb, sgb = SEGF(s0 + kqb);      /* (the unit's FIRST segment: the replay walks that one from the entry state; with units, what
                                                                             lies behind it in the unit has no state to start from either) */
-                PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+                PLS_THREADS(tid, CT) {
                     if (tid == 0) {
                         SEG_DEBUG_COUNT(2, fb);
                         idxb[24]++;
@@ -1898,9 +1935,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             const uint32_t xq = sgq * SEG_L;
             SegPix *pxr = (SegPix *)(uint32_t *)(twr + SEG_TBL_WORDS);  /* [SEG_L + 1] */
             const SegGeo G_ = seg_geo((int)cv.s);
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            PLS_THREADS(tid, CT) {
                 if (!have_tables) {
-                    for (int i = tid; i < SEG_TBL_WORDS; i += SEG_CHAIN_THREADS) twr[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
+                    for (int i = tid; i < SEG_TBL_WORDS; i += CT) twr[i] = j.tables[(size_t)f * SEG_TBL_WORDS + i];
                     if (tid < 256) seg_load_frozen(j, par, f, (uint32_t *)Hf, (uint32_t *)rank, tid, 256);
                     if (tid >= 256 && tid < 768) lut[tid - 256] = P.lut_a[tid - 256];
                 }
@@ -1909,7 +1946,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
             }
             PLS_SYNC();
             if (kq >= ns) { done = true; break; }                      /* the row's last segment: the replay walks it from its entry state, nothing follows */
-            PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+            PLS_THREADS(tid, CT) {
                 if (tid == 0) {
                     SegState st = seg_state_unpack(est);
                     seg_walk(f, pxr, 1, xq, xq + SEG_L, st, SEG_LDS_CU32(twr), SEG_LDS_CU32(lut), (const uint32_t *)Hf, (const uint32_t *)rank, G_, (const uint32_t *)lut, P.bleed, nullptr, nullptr);
@@ -1933,7 +1970,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
         if (done) break;
         (void)next_pass;
     }
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+    PLS_THREADS(tid, CT) {
         if (tid == 0) {
             if (idxb[24]) PLS_ATOMIC_ADD((uint32_t *)&j.result[17], idxb[24]);       /* segments walked step by step (reported with the image's result) */
             if (prof) {
@@ -1962,21 +1999,22 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int
 /* ---- EXTREMES: one workgroup per image, next to the chain's (it has nothing to do with them: the launch has room): the largest and the
  * smallest orig + incoming error over the row's channels (a forced transparent alpha aside), which bound how far candidate none's bytes
  * can overshoot 0..255 (seg_none_reach); read by the replay's workgroups of candidate none in the next launch. */
+template <int CT>
 PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, unsigned char *smem)
 {
     if (cv.finished || !j.rowmm) return;
     const uint32_t W = j.W, bpp = j.bpp, y = cv.y;
     const uint32_t *row = seg_row_orig(j, y), *e0g = seg_e0(j, y);
     uint32_t *mm = (uint32_t *)smem;                            /* [0] max, [1] min, biased (unsigned compare) */
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { mm[0] = 0x80000000u ^ (uint32_t)(-(1 << 30)); mm[1] = 0x80000000u ^ (uint32_t)(1 << 30); } }
+    PLS_THREADS(tid, CT) { if (tid == 0) { mm[0] = 0x80000000u ^ (uint32_t)(-(1 << 30)); mm[1] = 0x80000000u ^ (uint32_t)(1 << 30); } }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) {
+    PLS_THREADS(tid, CT) {
         int vmax = -(1 << 30), vmin = 1 << 30;
         /* four pixels per thread and turn, every request in front of the first use (pixels beyond the row are clamped onto its last: they change nothing) */
-        for (uint32_t x0 = (uint32_t)tid; x0 < W; x0 += 4u * SEG_CHAIN_THREADS) {
+        for (uint32_t x0 = (uint32_t)tid; x0 < W; x0 += 4u * CT) {
             uint32_t o[4], ea[4], eb[4];
             PLS_UNROLL
-            for (int q = 0; q < 4; q++) { const uint32_t x = seg_umin(x0 + (uint32_t)q * SEG_CHAIN_THREADS, W - 1u); o[q] = row[x]; ea[q] = e0g[2 * (size_t)x]; eb[q] = e0g[2 * (size_t)x + 1]; }
+            for (int q = 0; q < 4; q++) { const uint32_t x = seg_umin(x0 + (uint32_t)q * CT, W - 1u); o[q] = row[x]; ea[q] = e0g[2 * (size_t)x]; eb[q] = e0g[2 * (size_t)x + 1]; }
             PLS_UNROLL
             for (int q = 0; q < 4; q++) {
                 const uint32_t e[2] = { ea[q], eb[q] };
@@ -1992,9 +2030,10 @@ PLS_HD void seg_extremes_body(const SegJob &j, const SegParams &P, const SegCtlV
         if (PLS_WAVE_LEADER(tid)) { PLS_ATOMIC_MAX_U(&mm[0], 0x80000000u ^ (uint32_t)vmax); PLS_ATOMIC_MIN(&mm[1], 0x80000000u ^ (uint32_t)vmin); }
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_CHAIN_THREADS) { if (tid == 0) { SEG_AS_GLB int32_t *rmm = seg_rowmm(j, y); rmm[0] = (int)(mm[0] ^ 0x80000000u); rmm[1] = (int)(mm[1] ^ 0x80000000u); } }
+    PLS_THREADS(tid, CT) { if (tid == 0) { SEG_AS_GLB int32_t *rmm = seg_rowmm(j, y); rmm[0] = (int)(mm[0] ^ 0x80000000u); rmm[1] = (int)(mm[1] ^ 0x80000000u); } }
 }
 
+template <int RNT>
 PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int grp, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -2008,8 +2047,8 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     const bool walk = !lazy && sx < W && seg0 + SEG_GRP > first;   /* (else: the whole group is validated already -- its share of the row's sums is still wanted) */
     uint32_t *Hf = (uint32_t *)smem, *rank = Hf + 256, *lut = Hf + 512, *tw = Hf + 1024;
     SegPix *px = (SegPix *)(tw + SEG_TBL_WORDS);              /* [SEG_GRP][SEG_L][4] */
-    uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][256] */
-    uint32_t *lane = cnt + SEG_GRP * 256;                     /* [SEG_GRP * SEG_PARTS * 4][2]: start state, first | end pixel << 16 (or ~0: idle) */
+    uint32_t *cnt = (uint32_t *)(px + SEG_GRP * SEG_L * 4);   /* [SEG_GRP][64]: four bins a word (seg_cnt_add) */
+    uint32_t *lane = cnt + SEG_GRP * 64;                      /* [SEG_GRP * SEG_PARTS * 4][2]: start state, first | end pixel << 16 (or ~0: idle) */
     uint32_t *cwl = lane + SEG_GRP * SEG_PARTS * 4 * 2;       /* [SEG_REPLAY_THREADS][4] the group's candidate words */
     uint32_t *oaL = cwl + SEG_REPLAY_THREADS * 4;             /* [SEG_REPLAY_THREADS + 1] the ORIGINAL row above, from the pixel in front of the group; [+1] the original pixel in front of the group, [+2] its new bytes */
     /* (behind the walk, in the tables' place) */
@@ -2024,7 +2063,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     const bool rprof = SEG_EXPERIMENT_REPLAY_CLOCKS && (P.engine_flags & 1) != 0 && walk && grp == 3;
     unsigned long long tr_[6] = { 0, 0, 0, 0, 0, 0 };
     if (rprof) tr_[0] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_REPLAY_NT) {
+    PLS_THREADS(tid, RNT) {
         /* Order of the requests: the walkers' dense ids, then everything the block stages (tables, frozen histogram, pixels), then the
          * checkpoints and entry states (which wait for the dense ids only); the stores to shared memory behind all of them. */
         const bool walker = walk && tid < SEG_GRP * SEG_PARTS * 4;
@@ -2033,10 +2072,10 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         const bool live = walker && sg < nseg && sg >= first && (uint32_t)c < bpp;
         const size_t sc = ((size_t)f * nseg + (live ? sg : 0u)) * 4 + c;
         const uint32_t d = live ? (uint32_t)j.dnout[sc] : SEG_INVALID;
-        constexpr int NTW = (SEG_TBL_WORDS + SEG_REPLAY_NT - 1) / SEG_REPLAY_NT;
+        constexpr int NTW = (SEG_TBL_WORDS + RNT - 1) / RNT;
         uint32_t vt[NTW], vl = 0, vh = 0, vb = 0, vr = 0;
         PLS_UNROLL
-        for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_NT; vt[q] = (walk && i < SEG_TBL_WORDS) ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
+        for (int q = 0; q < NTW; q++) { const int i = tid + q * RNT; vt[q] = (walk && i < SEG_TBL_WORDS) ? j.tables[(size_t)f * SEG_TBL_WORDS + i] : 0u; }
         if (walk && tid < 512) vl = P.lut_a[tid];
         if (walk && tid < 256) { vh = j.H0[par * 256 + tid]; vb = j.base[((size_t)par * SEG_NFILT + f) * 256 + tid]; vr = j.orig_rank[f * 256 + tid]; }
         const bool pixlane = tid < SEG_REPLAY_THREADS;            /* (the first half of the workgroup has a pixel of the group each; the second half helps with the staging and takes the counts) */
@@ -2083,10 +2122,10 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         if (tid < SEG_GRP * SEG_PARTS * 4) { lane[2 * tid] = st0; lane[2 * tid + 1] = range; }
         if (walk) {
             PLS_UNROLL
-            for (int q = 0; q < NTW; q++) { const int i = tid + q * SEG_REPLAY_NT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
+            for (int q = 0; q < NTW; q++) { const int i = tid + q * RNT; if (i < SEG_TBL_WORDS) tw[i] = vt[q]; }
             if (tid < 512) lut[tid] = vl;
             if (tid < 256) { Hf[tid] = vh + vb; rank[tid] = vr; }
-            for (int i = tid; i < SEG_GRP * 256; i += SEG_REPLAY_NT) cnt[i] = 0u;
+            for (int i = tid; i < SEG_GRP * 64; i += RNT) cnt[i] = 0u;
         }
         if (pixlane) {
             seg_pix_split4(px + tid * 4, vp, bpp, x, W);
@@ -2101,12 +2140,12 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     PLS_SYNC();
     if (rprof) tr_[1] = PLS_CLOCK();
     if (walk) {
-        PLS_THREADS(tid, SEG_REPLAY_NT) {
+        PLS_THREADS(tid, RNT) {
             if (tid < SEG_GRP * SEG_PARTS * 4 && lane[2 * tid + 1] != 0xFFFFFFFFu) {
                 const int sl = tid / (SEG_PARTS * 4), c = tid & 3;
                 SegState st = seg_state_unpack(lane[2 * tid]);
                 const uint32_t ra = lane[2 * tid + 1] & 0xffffu, re = lane[2 * tid + 1] >> 16;       /* pixels of the group */
-                seg_walk(f, px + ra * 4 + c, 4, x0g + ra, x0g + re, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed, cwl + ra * 4 + c, cnt + sl * 256);
+                seg_walk(f, px + ra * 4 + c, 4, x0g + ra, x0g + re, st, SEG_LDS_CU32(tw), SEG_LDS_CU32(lut), Hf, rank, G, lut, P.bleed, cwl + ra * 4 + c, cnt + sl * 64);
             }
         }
         PLS_SYNC();
@@ -2114,17 +2153,18 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     }
     SegAcc &A = j.acc[par];
     if (rprof) tr_[3] = PLS_CLOCK();
-    PLS_THREADS(tid, SEG_REPLAY_NT) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
+    PLS_THREADS(tid, RNT) { if (tid < 16) red[tid] = tid == 14 ? (0x80000000u ^ (uint32_t)(-(1 << 30))) : (tid == 15 ? (0x80000000u ^ (uint32_t)(1 << 30)) : 0u); }   /* ([14], [15] biased: unsigned max / min) */
     PLS_SYNC();
     {
         /* -- the first half of the workgroup: every thread its pixel: the words out (what the walkers have just written), the pixel's share of the
          *    sums; a quarter meanwhile: the bump counts per segment and group, a bin a thread -- */
-        PLS_THREADS(tid, SEG_REPLAY_NT) {
-            if (walk && tid >= SEG_REPLAY_THREADS && tid < SEG_REPLAY_THREADS + 256) {
-                const int b = tid - SEG_REPLAY_THREADS;
+        PLS_THREADS(tid, RNT) {
+            /* (the counts: 256 threads of the workgroup's second half -- or, in the 512-thread version of batches, the first 256, ahead of their pixel) */
+            if (walk && tid >= RNT - SEG_REPLAY_THREADS && tid < RNT - SEG_REPLAY_THREADS + 256) {
+                const int b = tid - (RNT - SEG_REPLAY_THREADS);
                 uint32_t tot = 0, cvs[SEG_GRP];
                 PLS_UNROLL
-                for (int sl = 0; sl < SEG_GRP; sl++) cvs[sl] = cnt[sl * 256 + b];          /* (all reads, then the stores: one wait) */
+                for (int sl = 0; sl < SEG_GRP; sl++) cvs[sl] = seg_cnt_get(cnt + sl * 64, b);          /* (all reads, then the stores: one wait) */
                 PLS_UNROLL
                 for (int sl = 0; sl < SEG_GRP; sl++) {
                     const uint32_t sg = seg0 + (uint32_t)sl;
@@ -2183,7 +2223,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
     int R = -1;
     if (f == 0 && j.rowmm) {
         const int32_t *rmm = seg_rowmm(j, y);
-        PLS_THREADS(tid, SEG_REPLAY_NT) {
+        PLS_THREADS(tid, RNT) {
             /* the row's extremes of orig + incoming error (seg_extremes_body, the launch before) */
             if (tid == 0) red[12] = (uint32_t)seg_none_reach(j, P, (int)cv.s, rmm[0], rmm[1]);
             if (tid >= 64 && tid < 64 + 256) h0s[tid - 64] = j.H0[par * 256 + (tid - 64)];
@@ -2191,8 +2231,8 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         PLS_SYNC();
         R = (int)red[12];
         if (R >= 0) {
-            PLS_THREADS(tid, SEG_REPLAY_NT) {
-                for (int i = tid; i < 768; i += SEG_REPLAY_NT) {
+            PLS_THREADS(tid, RNT) {
+                for (int i = tid; i < 768; i += RNT) {
                     const int centre = i - 256;
                     const int lo = seg_min(seg_max(centre - R, 0), 255), hi = seg_min(seg_max(centre + R, 0), 255);
                     uint32_t m = 0;
@@ -2209,7 +2249,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
                 }
             }
             PLS_SYNC();
-            PLS_THREADS(tid, SEG_REPLAY_NT) {
+            PLS_THREADS(tid, RNT) {
                 uint64_t lb = 0;
                 const uint32_t rowbumps = W * bpp;
                 const uint32_t x = tid < SEG_REPLAY_THREADS ? x0g + (uint32_t)tid : W;
@@ -2229,7 +2269,7 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
         }
     }
     PLS_SYNC();
-    PLS_THREADS(tid, SEG_REPLAY_NT) {
+    PLS_THREADS(tid, RNT) {
         if (tid == 0) {
             if (!lazy) {
                 PLS_ATOMIC_ADD64(&A.derr[f], *(uint64_t *)&red[0]);
@@ -3019,6 +3059,7 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
  * bx > SEG_NFILT: commit of pixels [(bx - SEG_NFILT - 1) * SEG_THREADS, ...) */
 PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, unsigned char *smem)
 {
+    const int SEG_CTL_IMG = SEG_CTL_IMG_OF(P), TPARTS = P.tparts;
     if (bx > SEG_CTL_IMG) { seg_ctl_commit(j, P, par, bx - SEG_CTL_IMG - 1, smem); return; }
     /* WHICH attempt this one follows.  Normally the one before it (copy k1), whose validation is still running -- in this very launch
      * (seg_k_ctl carries the validation workgroups of the attempt before next to the control workgroups of this one) -- so the decision
@@ -3053,7 +3094,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
             /* every request of the burst first, the stores behind them (the image's first attempt reads junk here and ignores it) */
             const uint32_t cword = tid < (int)(sizeof(SegCtl) / 4) ? ((const uint32_t *)&curg)[tid] : 0u;
             const uint32_t aword = (tid >= 128 && tid < 128 + (int)(sizeof(SegAcc) / 4)) ? ((const uint32_t *)&Ag)[tid - 128] : 0u;
-            const uint32_t rword = (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) ? j.orig_rank[(bx / SEG_TPARTS) * 256 + (tid - 256)] : 0u;
+            const uint32_t rword = (bx < SEG_CTL_IMG && tid >= 256 && tid < 512) ? j.orig_rank[(bx / TPARTS) * 256 + (tid - 256)] : 0u;
             const uint32_t fmw = tid == 512 ? j.acc[k2].failmask : 0u;
             constexpr int NSP = ((SEG_NFILT + 1) * 256 + SEG_THREADS - 1) / SEG_THREADS;
             SegSpecRegs<NSP> sr;
@@ -3155,7 +3196,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
 
     /* ---- candidate f: SEG_TPARTS workgroups; all of them follow the decision and the new histogram, workgroup 0 writes the control
      *      fields, each builds its share of the decision tables ---- */
-    const int f = bx / SEG_TPARTS, tpart = bx % SEG_TPARTS;
+    const int f = bx / TPARTS, tpart = bx % TPARTS;
     const bool failed = (D.failed >> f) & 1u;
     if (D.kind != SEG_K_RESTART) {
         /* a fresh row attempt: start of the row, no validated prefix */
@@ -3164,7 +3205,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
         const int sn = s_next < 0 ? 0 : s_next;
         unsigned long long tc1 = 0;
         if (prof) tc1 = PLS_CLOCK();
-        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS, tpart, SEG_TPARTS, prof ? &j.result[37] : nullptr);
+        seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, sn, sn + 1, SEG_THREADS, tpart, TPARTS, prof ? &j.result[37] : nullptr);
         PLS_THREADS(tid, SEG_THREADS) {
             if (tpart == 0) {
                 for (int b = tid; b < 256; b += SEG_THREADS) j.base[((size_t)par * SEG_NFILT + f) * 256 + b] = 0u;
@@ -3190,7 +3231,7 @@ PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, u
             }
         }
         PLS_SYNC();
-        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, (int)cur.s, (int)cur.s + 1, SEG_THREADS, tpart, SEG_TPARTS);
+        if (D.start_none) seg_build_tables(j.tables + (size_t)f * SEG_TBL_WORDS, Hn, rank, scratch, stage, (int)cur.s, (int)cur.s + 1, SEG_THREADS, tpart, TPARTS);
         return;
     }
     if (tpart) return;                                        /* (an epoch inside the row is set up by one workgroup) */
