@@ -270,7 +270,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_UNIT")) units = can && std::atoi(e) != 0;
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
         ctx->h_seg_params.tparts = units ? 1 : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
-        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_TPARTS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) ctx->h_seg_params.tparts = v; }   /* (timing / test hook) */
+        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_TPARTS")) { const int v = std::atoi(e); if (v == 1 || v == SEG_TPARTS) ctx->h_seg_params.tparts = v; }   /* (timing / test hook) */
     }
     SegGroups gs;
     gs.n = ngroups;
@@ -394,6 +394,14 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         bool seg_ok = n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
             const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
+            /* round 5: a batch whose images have more than SEG_UNIT_MIN_SEGS segments between them is enumerated in UNITS, in two launch groups, with the
+             * small workgroups of batches (run_seg_engine): an attempt then takes ~45 us + 0.015 us per workgroup-unit, but not less than ~95 us (the
+             * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
+            const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
+            auto attempt_us = [&](double wgs, double segs) {
+                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(95.0, 45.0 + 0.015 * wgs);
+                return a_us + w_us * wgs;
+            };
             auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
             std::vector<size_t> order;
             for (size_t i = 0; i < n; i++)
@@ -405,11 +413,11 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 double wg_sum = 0;
                 for (size_t i = 0; i < n; i++) wg_sum += wg_cost(i);
                 double seg_rows = 0, seg_wgs = 0, seg_segs = 0;
-                auto batch_us = [&](size_t k, double rows, double wgs, double wsum) {   /* the first k images of `order` on the segment engine */
+                auto batch_us = [&](size_t k, double rows, double wgs, double wsum, double segs) {   /* the first k images of `order` on the segment engine */
                     const double wg_us = k < order.size() ? std::max(wg_cost(order[k]), wsum / 256.0) : wsum / 256.0;
-                    return std::max(wg_us, k ? rows * (a_us + w_us * wgs) : 0.0);
+                    return std::max(wg_us, k ? rows * attempt_us(wgs, segs) : 0.0);
                 };
-                double best = batch_us(0, 0, 0, wg_sum);
+                double best = batch_us(0, 0, 0, wg_sum, 0);
                 size_t best_k = 0;
                 double wsum = wg_sum;
                 for (size_t k = 1; k <= order.size(); k++) {
@@ -418,8 +426,8 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                     seg_wgs += 3.0 * ((images[i].width + SEG_L - 1) / SEG_L) + 40.0;
                     seg_segs += (images[i].width + SEG_L - 1) / SEG_L;
                     wsum -= wg_cost(i);
-                    if (seg_segs > 4096) break;
-                    const double t = batch_us(k, seg_rows, seg_wgs, wsum);
+                    if (seg_segs > 8192) break;
+                    const double t = batch_us(k, seg_rows, seg_wgs, wsum, seg_segs);
                     if (t < best) { best = t; best_k = k; }
                 }
                 for (size_t k = 0; k < best_k; k++) on_seg[order[k]] = 1;

@@ -56,14 +56,15 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
 #else
 #define SEG_CTL_BOUNDS __launch_bounds__(SEG_THREADS, 8)
 #endif
+template <int TPARTS>
 __global__ SEG_CTL_BOUNDS void seg_k_ctl(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int k, unsigned nctl, unsigned max_ngrp)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     if (blockIdx.x < nctl) {
-        const unsigned ctl_img = (unsigned)SEG_CTL_IMG_OF(*P);
+        constexpr unsigned ctl_img = SEG_NFILT * TPARTS;
         if (blockIdx.x > ctl_img && (blockIdx.x - ctl_img - 1) * SEG_COMMIT_W >= j.W) return;
-        seg_ctl_body(j, *P, k, (int)blockIdx.x, seg_smem);
+        seg_ctl_body<TPARTS>(j, *P, k, (int)blockIdx.x, seg_smem);
         return;
     }
 #if SEG_EXPERIMENT_NO_VAL_CODE
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(NT) void seg_k_enum(const SegJob *__restrict__ sj, 
         if (seg0 >= j.nseg) return;
         seg_enum_small_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)seg0, seg_smem);
     } else {
-        seg_first_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT))), par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
+        seg_first_body<NT, false>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT))), par, (int)(blockIdx.x - (gridDim.x - SEG_NFILT)), seg_smem);
     }
 }
 
@@ -114,13 +115,14 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
         if (seg >= j.nseg) return;
         seg_enum_seeded_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)seg, (int)chalf, seg_smem);
     } else {
-        seg_first_body<NT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves)), par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves), seg_smem);
+        seg_first_body<NT, false>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves)), par, (int)(blockIdx.x - SEG_NFILT * max_nseg * halves), seg_smem);
     }
 }
 
 /* enumeration in UNITS (batches; SegParams::unit = SEG_UNIT): first the filters that look at the left pixel (their workgroups are the long ones: `perb`
  * workgroups of SEG_UNC (unit, channel) pairs per candidate), then none / up -- with their small state set (when it exists) segment by segment, `pers`
  * workgroups of 24 (segment, channel) pairs --, and the five walkers of an epoch's first unit */
+template <int UNIT>
 __global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restr
     const bool small_ok = P->small_ok != 0;
     const unsigned nbig = small_ok ? 3u : 5u, nb = nbig * perb, ns = small_ok ? 2u * pers : 0u;
     if (blockIdx.x >= nb + ns) {
-        seg_first_body<SEG_UNT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - nb - ns)), par, (int)(blockIdx.x - nb - ns), seg_smem);
+        seg_first_body<SEG_UNT, true>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - nb - ns)), par, (int)(blockIdx.x - nb - ns), seg_smem);
         return;
     }
     if (blockIdx.x < nb) {
@@ -143,13 +145,13 @@ __global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restr
     }
 }
 
-template <bool SEEDED, int CT>
+template <bool SEEDED, int CT, bool UNITS>
 __global__ __launch_bounds__(CT) void seg_k_chain(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     if (blockIdx.x == 0) { seg_extremes_body<CT>(j, *P, seg_view_of(sj + blockIdx.y, par, 0), par, seg_smem); return; }      /* (the spare workgroup, dispatched first: the row's extremes for none's bound) */
-    seg_chain_body<SEEDED, CT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)((blockIdx.x - 1) >> 2)), par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
+    seg_chain_body<SEEDED, CT, UNITS>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)((blockIdx.x - 1) >> 2)), par, (int)((blockIdx.x - 1) >> 2), (int)((blockIdx.x - 1) & 3), seg_smem);
 }
 
 template <int RNT>
@@ -162,6 +164,22 @@ __global__ __launch_bounds__(RNT) void seg_k_replay(const SegJob *__restrict__ s
     seg_replay_body<RNT>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
 }
 
+/* The ORDER of the kernels in the code object, pinned: the one-image kernels first, in the order round 4's library had them, the kernels of batches behind
+ * them.  (Measured, profiles/r05_code_layout.txt: with the batch kernels emitted in between, the control kernel -- byte for byte the same instructions --
+ * took 0.45 us longer per launch, the enumeration 0.5: the headline lost 3 %.) */
+template __global__ void seg_k_ctl<SEG_TPARTS>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
+template __global__ void seg_k_replay<SEG_REPLAY_NT>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+template __global__ void seg_k_chain<false, SEG_CHAIN_THREADS, false>(const SegJob *__restrict__, const SegParams *__restrict__, int);
+template __global__ void seg_k_chain<true, SEG_CHAIN_THREADS, false>(const SegJob *__restrict__, const SegParams *__restrict__, int);
+template __global__ void seg_k_enum_seeded<512>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+template __global__ void seg_k_enum_seeded<1024>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+template __global__ void seg_k_enum<512>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+template __global__ void seg_k_enum<1024>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+template __global__ void seg_k_ctl<1>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
+template __global__ void seg_k_enum_unit<SEG_UNIT>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
+template __global__ void seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>(const SegJob *__restrict__, const SegParams *__restrict__, int);
+template __global__ void seg_k_replay<SEG_REPLAY_NT_BATCH>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 /* the kernels of the engine whose dynamic LDS can exceed 64 KB: opted in per device (pl_lds_optin) */
@@ -170,10 +188,12 @@ hipError_t chain_attr()
     static std::atomic<unsigned> done_chain{ 0 }, done_ctl{ 0 };
     static std::atomic<unsigned> done_chain_s{ 0 };
     static std::atomic<unsigned> done_chain_u{ 0 };
-    hipError_t e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
-    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS_UNIT>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_u);
-    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true, SEG_CHAIN_THREADS>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
-    if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl, SEG_SM_CTLVAL, done_ctl);
+    hipError_t e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS, false>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain);
+    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_u);
+    if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true, SEG_CHAIN_THREADS, false>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
+    static std::atomic<unsigned> done_ctl1{ 0 };
+    if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl<SEG_TPARTS>, SEG_SM_CTLVAL, done_ctl);
+    if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl<1>, SEG_SM_CTLVAL, done_ctl1);
     return e;
 }
 static_assert(SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536 && SEG_SM_ENUM_UNIT <= 65536, "these kernels are launched without an LDS opt-in");
@@ -239,7 +259,8 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         /* (the validation workgroups can be left out at COMPILE time only -- SEG_EXPERIMENT_NO_VAL_CODE, a timing experiment whose results are unvalidated;
          *  the shipped library has no run-time switch that changes what it computes) */
         const unsigned nctl = SEG_NFILT * b.tparts + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
-        hipLaunchKernelGGL(seg_k_ctl, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
+        if (b.tparts == 1) hipLaunchKernelGGL(seg_k_ctl<1>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
+        else hipLaunchKernelGGL(seg_k_ctl<SEG_TPARTS>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
     }
     {
         const bool small_ok = b.small_ok;
@@ -249,7 +270,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         if (b.unit > 1 && !b.seeded) {
             const unsigned perb = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
             const unsigned blocks = (small_ok ? 3 * perb + 2 * pers : SEG_NFILT * perb) + SEG_NFILT;
-            hipLaunchKernelGGL(seg_k_enum_unit, dim3(blocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers);
+            hipLaunchKernelGGL(seg_k_enum_unit<SEG_UNIT>, dim3(blocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers);
         } else
         if (b.seeded) {
             const unsigned sblocks = SEG_NFILT * b.max_nseg * halves + SEG_NFILT;
@@ -259,9 +280,9 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
         else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
     }
-    if (b.seeded) hipLaunchKernelGGL((seg_k_chain<true, SEG_CHAIN_THREADS>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
-    else if (b.unit > 1) hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS_UNIT>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS_UNIT), SEG_SM_CHAIN_X((b.max_nseg + b.unit - 1) / b.unit), stream, b.d_sj, b.d_params, par);
-    else hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN_X(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    if (b.seeded) hipLaunchKernelGGL((seg_k_chain<true, SEG_CHAIN_THREADS, false>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
+    else if (b.unit > 1) hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS_UNIT), SEG_SM_CHAIN_X((b.max_nseg + b.unit - 1) / b.unit), stream, b.d_sj, b.d_params, par);
+    else hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS, false>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN_X(b.max_nseg), stream, b.d_sj, b.d_params, par);
     if (b.unit > 1) hipLaunchKernelGGL(seg_k_replay<SEG_REPLAY_NT_BATCH>, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_NT_BATCH), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     else hipLaunchKernelGGL(seg_k_replay<SEG_REPLAY_NT>, dim3(SEG_NFILT * b.max_ngrp, n), dim3(SEG_REPLAY_NT), SEG_SM_REPLAY, stream, b.d_sj, b.d_params, par, b.max_ngrp);
     return hipGetLastError();

@@ -144,7 +144,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_UNIT 3               /* segments per enumeration UNIT when the launcher asks for units (SegParams::unit; batches).  Measured (profiles/r05_unit_groups.txt): 2, 3, 4 within 3 % of each other from 16 frames of 1080p on, 3 best at 32 and 64; 8 loses below 64 frames */
 #endif
 #define SEG_UNIT_MIN_SEGS 320    /* the launcher enumerates in units when the batch's images have more segments than this between them (six frames of 1920 pixels) */
-#define SEG_UNC 12               /* (unit, channel) pairs per workgroup of the unit enumeration */
+#ifndef SEG_UNC
+#define SEG_UNC 10               /* (unit, channel) pairs per workgroup of the unit enumeration (measured 9 / 10 / 11 / 12: 175.9 / 163.5 / 166.8 / 170.4 ms for 32 frames of 1080p: ~170 distinct states = three waves, and 80 pairs of a 1920-pixel row = 8 workgroups) */
+#endif
 #define SEG_UNT 1024             /* its threads */
 #define SEG_UPOOL 1024           /* ... and the most distinct states its pairs may have between them (one lane each) */
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
@@ -1515,7 +1517,7 @@ PLS_HD void seg_walk(int f, const SegPix *px, int pstride, uint32_t xa, uint32_t
 
 /* ---- FIRST SEGMENT: task (f): the epoch's first (partial) segment has a known entry state, so it is not enumerated but walked,
  * lane = channel, next to the enumeration workgroups (same kernel); out: the index the chain starts from ------------------------ */
-template <int NT>
+template <int NT, bool UNITS>
 PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, unsigned char *smem)
 {
     const SegCtl &ctl = j.ctl[par];
@@ -1527,7 +1529,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
     if (first + 1 >= nseg) return;                            /* no segment behind it */
     /* enumeration in units (SegParams::unit > 1): the walk goes on to the end of the UNIT that holds the epoch's first pixel -- the enumeration starts
      * with the unit behind it -- and leaves the entry state of every segment it crosses (the replay walks those from there: no checkpoints) */
-    const uint32_t E = seg_unit_of(P, f), ulast = seg_umin((first / E) * E + E - 1u, nseg - 1u);
+    const uint32_t E = UNITS ? seg_unit_of(P, f) : 1u, ulast = seg_umin((first / E) * E + E - 1u, nseg - 1u);   /* (!UNITS: the per-segment enumeration's kernels, where E = 1 folds all of this away) */
     const uint32_t wend = seg_umin(ulast, nseg - 2u);         /* last segment walked: the row's last segment has nothing behind it */
     const uint32_t npix = (wend - first + 1u) * SEG_L;
     uint32_t *tw = (uint32_t *)smem;
@@ -1609,7 +1611,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
 /* (exhaustive state sets: no repair path, so no tables and pixel records behind T; npos = the row's chain positions: units) */
 #define SEG_SM_CHAIN_X(npos) ((1024 + 32 + 2 * SEG_CHAIN_POS + SEG_CHAIN_GWORDS) * 4 + SEG_CHAIN_TBYTES(npos) + 64)
 PLS_HD uint32_t seg_chain_cap(uint32_t sh) { return sh >= 8 ? (uint32_t)SEG_CHAIN_CAP8 : (uint32_t)SEG_CHAIN_CAP; }
-template <bool SEEDED, int CT>
+template <bool SEEDED, int CT, bool UNITS>
 PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int c, unsigned char *smem)
 {
     if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
@@ -1624,9 +1626,10 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
     /* The chain composes UNITS: E = SegParams::unit segments enumerated as one (seg_enum_unit_body; 1: every segment on its own, and always for seeded
      * sets).  Unit u = segments u * E .. : its entry map and distinct-state count sit at its FIRST segment (SEGF), its exit index and exit state at
      * its LAST (SEGL); every segment of it carries the unit's dense id, the entry state of an inner segment is the exit state of the one in front. */
-    const uint32_t E = seeded ? 1u : seg_unit_of(P, f), nunit = (nseg + E - 1u) / E, ufirst = first / E;
-#define SEGF(u) ((u) * E)
-#define SEGL(u) (seg_umin((u) * E + E, nseg) - 1u)
+    /* (UNITS: a kernel of its own -- with E = 1 a constant, the one-image chain pays nothing for the units: no load of SegParams::unit at its head, no division) */
+    const uint32_t E = (seeded || !UNITS) ? 1u : seg_unit_of(P, f), nunit = (nseg + E - 1u) / E, ufirst = first / E;
+#define SEGF(u) (E == 1u ? (u) : (u) * E)
+#define SEGL(u) (E == 1u ? (u) : seg_umin((u) * E + E, nseg) - 1u)
     if (sx && ufirst + 1 >= nunit) return;                      /* no unit behind the walked one (seg_first_body left the entry states of its segments) */
     /* enumerated units s0 .. nunit-1 (ne of them; a fresh row: from 0) = POSITIONS 0 .. ns of the chain; ns = ne - 1 transitions */
     const uint32_t s0 = sx ? ufirst + 1 : 0u, ne = nunit - s0, ns = ne - 1;
@@ -3057,9 +3060,10 @@ PLS_HD void seg_ctl_commit(const SegJob &j, const SegParams &P, int par, int cw,
 /* Control kernel of an attempt (par = its parity): reads what the attempt before left (control block and sums of parity prev), writes the control block
  * of parity par.  bx < SEG_NFILT: candidate bx (epoch setup, decision tables); bx == SEG_NFILT: the image-wide fields;
  * bx > SEG_NFILT: commit of pixels [(bx - SEG_NFILT - 1) * SEG_THREADS, ...) */
+template <int TPARTS>
 PLS_HD void seg_ctl_body(const SegJob &j, const SegParams &P, int par, int bx, unsigned char *smem)
 {
-    const int SEG_CTL_IMG = SEG_CTL_IMG_OF(P), TPARTS = P.tparts;
+    constexpr int SEG_CTL_IMG = SEG_NFILT * TPARTS;          /* (= SEG_CTL_IMG_OF(P): the launcher picks the instantiation by SegParams::tparts) */
     if (bx > SEG_CTL_IMG) { seg_ctl_commit(j, P, par, bx - SEG_CTL_IMG - 1, smem); return; }
     /* WHICH attempt this one follows.  Normally the one before it (copy k1), whose validation is still running -- in this very launch
      * (seg_k_ctl carries the validation workgroups of the attempt before next to the control workgroups of this one) -- so the decision

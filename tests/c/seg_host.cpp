@@ -57,7 +57,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     if (getenv("SEG_HOST_FORCE_FILTER")) P.engine_flags = (atoi(getenv("SEG_HOST_FORCE_FILTER")) + 1) << 8;
     if (getenv("SEG_HOST_FLAGS")) P.engine_flags |= atoi(getenv("SEG_HOST_FLAGS")) & 0xfe;   /* test hooks of the chain kernel (2: slow path, 4: wide stride) */
     if (getenv("SEG_HOST_UNIT") && atoi(getenv("SEG_HOST_UNIT")) && !P.seeded && (P.ns <= SEG_NSP || atoi(getenv("SEG_HOST_UNIT")) > 1)) { P.unit = SEG_UNIT; P.tparts = 1; }
-    if (getenv("SEG_HOST_TPARTS")) P.tparts = atoi(getenv("SEG_HOST_TPARTS")) == 1 ? 1 : (atoi(getenv("SEG_HOST_TPARTS")) == 2 ? 2 : 4);   /* enumeration in units, as the launcher asks for batches (seg_enum_unit_body) */
+    if (getenv("SEG_HOST_TPARTS")) P.tparts = atoi(getenv("SEG_HOST_TPARTS")) == 1 ? 1 : SEG_TPARTS;   /* enumeration in units, as the launcher asks for batches (seg_enum_unit_body) */
     /* classify + pack into slots (what pl_classify / pl_repack do on the device) */
     bool gray = true, opaque = true;
     for (size_t i = 0; i < (size_t)W * H; i++) { const unsigned char *p = rgba + 4 * i; gray &= p[0] == p[1] && p[1] == p[2]; opaque &= p[3] == 255; }
@@ -121,7 +121,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         const int par = attempt % 3, kv = (par + 2) % 3;
         std::vector<unsigned char> cvsm((size_t)SEG_SM_CTLVAL, 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
         for (int half = 0; half < 2; half++) {
-            if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG_OF(P) + 1 + ncommit; bx++) seg_ctl_body(j, P, par, bx, cvsm.data()); }
+            if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG_OF(P) + 1 + ncommit; bx++) { if (P.tparts == 1) seg_ctl_body<1>(j, P, par, bx, cvsm.data()); else seg_ctl_body<SEG_TPARTS>(j, P, par, bx, cvsm.data()); } }
             else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
         }
         if (j.ctl[par].finished == 2u) break;
@@ -139,7 +139,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
                 if (seg_is_small(P, f)) { for (uint32_t g = 0; g < pers; g++) if (g * SEG_UNC_SMALL < ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) seg_enum_unit_body<SEG_NSS, SEG_UNIT, SEG_UNC_SMALL>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
                 else { for (uint32_t g = 0; g < perb; g++) if (g * SEG_UNC < ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
             }
-            for (int f = 0; f < SEG_NFILT; f++) seg_first_body<SEG_UNT>(j, P, seg_ctl_view(j, par, f), par, f, usm.data());
+            for (int f = 0; f < SEG_NFILT; f++) seg_first_body<SEG_UNT, true>(j, P, seg_ctl_view(j, par, f), par, f, usm.data());
         } else
         if (P.seeded) {
             std::vector<unsigned char> ssm((size_t)SEG_SM_ENUM_SEEDED(nt), 0x5A);
@@ -158,13 +158,13 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
                 else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, 0, esm.data());
             }
         }
-        if (P.unit <= 1) for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
+        if (P.unit <= 1) for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
         {   /* the chain kernel's LDS is sized by the row's segments: the same size here (the sanitizer build sees an overrun) */
             std::vector<unsigned char> csm(P.seeded ? (size_t)SEG_SM_CHAIN(j.nseg) : (size_t)SEG_SM_CHAIN_X(P.unit > 1 ? (j.nseg + P.unit - 1) / P.unit : j.nseg), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) {
-                if (P.seeded) seg_chain_body<true, SEG_CHAIN_THREADS>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data());
-                else if (P.unit > 1) seg_chain_body<false, SEG_CHAIN_THREADS_UNIT>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data());
-                else seg_chain_body<false, SEG_CHAIN_THREADS>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data());
+                if (P.seeded) seg_chain_body<true, SEG_CHAIN_THREADS, false>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data());
+                else if (P.unit > 1) seg_chain_body<false, SEG_CHAIN_THREADS_UNIT, true>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data());
+                else seg_chain_body<false, SEG_CHAIN_THREADS, false>(j, P, seg_ctl_view(j, par, f), par, f, c, csm.data());
             }
             if (P.unit > 1) seg_extremes_body<SEG_CHAIN_THREADS_UNIT>(j, P, seg_ctl_view(j, par, 0), par, csm.data()); else seg_extremes_body<SEG_CHAIN_THREADS>(j, P, seg_ctl_view(j, par, 0), par, csm.data());
         }
