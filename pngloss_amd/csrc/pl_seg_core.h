@@ -134,6 +134,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_DEBUG_REPAIR
 #define SEG_DEBUG_REPAIR(f, c, sg, est, sid)
 #endif
+#ifndef SEG_DEBUG_STATE
+#define SEG_DEBUG_STATE(f, k, sl, i, ps)   /* (the CPU harness can count the distinct states of a pair at every segment's end: how fast a unit's states keep merging) */
+#endif
 #ifndef SEG_DEBUG_COUNT
 #define SEG_DEBUG_COUNT(slot, v)   /* (the CPU harness counts a few things the tests pin) */
 #endif
@@ -144,10 +147,15 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_UNIT 3               /* segments per enumeration UNIT when the launcher asks for units (SegParams::unit; batches).  Measured (profiles/r05_unit_groups.txt): 2, 3, 4 within 3 % of each other from 16 frames of 1080p on, 3 best at 32 and 64; 8 loses below 64 frames */
 #endif
 #define SEG_UNIT_MIN_SEGS 320    /* the launcher enumerates in units when the batch's images have more segments than this between them (six frames of 1920 pixels) */
+#if !defined(SEG_UNC) && SEG_UNIT > 6
+#define SEG_UNC 7                /* (longer units: fewer pairs, so that their pixel records fit the 16 KB the workgroup's shared memory has for them) */
+#endif
 #ifndef SEG_UNC
 #define SEG_UNC 10               /* (unit, channel) pairs per workgroup of the unit enumeration (measured 9 / 10 / 11 / 12: 175.9 / 163.5 / 166.8 / 170.4 ms for 32 frames of 1080p: ~170 distinct states = three waves, and 80 pairs of a 1920-pixel row = 8 workgroups) */
 #endif
-#define SEG_UNT 1024             /* its threads */
+#ifndef SEG_UNT
+#define SEG_UNT 512              /* its threads (512 against 1024, 1080p frames: 157.7 against 161.4 ms at 32, 249.2 against 281.4 at 64, 460.6 against 511.3 at 128: the CU starts four workgroups at once instead of two) */
+#endif
 #define SEG_UPOOL 1024           /* ... and the most distinct states its pairs may have between them (one lane each) */
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
 #define SEG_VGRP 8                /* segments per VALIDATION workgroup (half a replay group: one decision per thread, twice the CUs) */
@@ -1261,14 +1269,27 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCt
  *   - none / up (LANES = 32: their state is (cn, th)) go through the same body, dedupe included: ~3 distinct states per pair instead of 17 lanes,
  *     24 pairs a workgroup.
  * The chain kernel composes UNITS (seg_chain_body reads SegParams::unit); replay and validation do not know the difference. */
-#define SEG_UNC_SMALL 24          /* (unit, channel) pairs per workgroup for none / up with their small state set */
+#define SEG_UNC_SMALL (SEG_UNIT <= 3 ? 20 : (SEG_UNIT <= 4 ? 15 : (SEG_UNIT <= 6 ? 10 : 7)))          /* (unit, channel) pairs per workgroup for none / up with their small state set */
 #define SEG_UNPX (SEG_UNC_SMALL * (SEG_UNIT * SEG_L + 1))   /* pixel records of a workgroup's pairs */
 /* LDS of the unit enumeration: tables, split table, the pool, the first records of every pair, bookkeeping -- and ONE region that holds the first phase's
  * scratch (hash tables, per-turn lists, keys: 20 KB) and then, for the second phase, the pairs' full pixel records: 40 KB = four workgroups per CU (the
  * first version carved both side by side: 52 KB, three per CU, and the CUs' slots, not their issue, set the kernel's time) */
 #define SEG_UN_K1MAX 4
 #define SEG_UN_SCRATCH (2048 * 4 + 2048 * 2 + 1024 * 4 + SEG_UNT * 4)
-#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UPOOL * 4 + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1) * 8 + 256 + (SEG_UN_SCRATCH > SEG_UNPX * 8 ? SEG_UN_SCRATCH : SEG_UNPX * 8))
+#define SEG_UN_PHASE2 (SEG_UNPX * 8 + SEG_UPOOL * 4)      /* the pairs' records and the second list of distinct states (behind the unit's first segment) */
+#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UPOOL * 4 + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1) * 8 + 512 + (SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2))
+/* set bits among bits [a, b) of a bit array */
+PLS_HD uint32_t seg_bits_count(const uint32_t *bits, uint32_t a, uint32_t b)
+{
+    uint32_t n = 0;
+    for (uint32_t w = a >> 5; w <= (b ? (b - 1u) >> 5 : 0u) && a < b; w++) {
+        uint32_t m = bits[w];
+        if (w == (a >> 5)) m &= 0xFFFFFFFFu << (a & 31u);
+        if (w == ((b - 1u) >> 5) && (b & 31u)) m &= 0xFFFFFFFFu >> (32u - (b & 31u));
+        n += (uint32_t)__builtin_popcount(m);
+    }
+    return n;
+}
 template <int LANES, int UNIT, int NC>
 PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int grp, unsigned char *smem)
 {
@@ -1289,20 +1310,27 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     uint32_t *lut = tw + SEG_TBL_WORDS;
     uint32_t *pool = lut + 512;                               /* [SEG_UPOOL] the distinct states of all pairs, pair behind pair */
     SegPix *px1 = (SegPix *)(pool + SEG_UPOOL);               /* [NC][NP1]: one channel's first records of a pair, slot 0 = the boundary pixel in front of the unit */
-    uint32_t *misc = (uint32_t *)(px1 + SEG_UNC_SMALL * NP1); /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total) */
+    uint32_t *misc = (uint32_t *)(px1 + SEG_UNC_SMALL * NP1); /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total),
+                                                                 [64 + k] the same for the SECOND list (.. [64 + NC] = its total), [96 .. 127] one bit per lane: it represents a state of the second list */
     /* first phase: */
-    uint32_t *ht = misc + 64;                                 /* [CPR][HT] key or ~0 (this turn) */
+    uint32_t *ht = misc + 128;                                /* [CPR][HT] key or ~0 (this turn) */
     uint16_t *dense = (uint16_t *)(ht + 2048);                /* [CPR][HT] slot -> dense id */
     uint32_t *uniqr = (uint32_t *)(dense + 2048);             /* [CPR][LANES] this turn's distinct states by dense id */
     uint32_t *keys = uniqr + 1024;                            /* [NT] */
     /* second phase, in the same place: */
-    SegPix *px = (SegPix *)(misc + 64);                       /* [NC][NPX]: all records of a pair */
+    SegPix *px = (SegPix *)(misc + 128);                      /* [NC][NPX]: all records of a pair */
+    uint32_t *pool2 = (uint32_t *)(px + SEG_UNPX);            /* [SEG_UPOOL] the states that are still distinct behind the unit's first segment, at the pairs' places of the first list */
     static_assert(SEG_K1 <= SEG_UN_K1MAX && SEG_K1_ONE_CHUNK <= SEG_UN_K1MAX, "the first phase's records");
     const uint32_t y = cv.y;
     const SEG_AS_GLB uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
     const SegGeo G = seg_geo((int)cv.s);
     const int nstates = seg_is_small(P, f) ? P.ns_small : P.ns;
-    PLS_THREADS(tid, NT) { if (tid < 64) misc[tid] = 0u; }
+    /* phase clocks (PNGLOSS_HIP_SEGPROF; the workgroups of the filters that look at the left pixel): the enumeration's slots of the result record --
+     * "load" = staging, "first steps + dedupe" = the first phase's turns, "remaining steps" = the unit's first segment, "map" = second dedupe + the rest of the unit */
+    const bool prof = (P.engine_flags & 1) != 0 && LANES == SEG_NSP;
+    unsigned long long te[5] = { 0, 0, 0, 0, 0 };
+    if (prof) te[0] = PLS_CLOCK();
+    PLS_THREADS(tid, NT) { if (tid < 128) misc[tid] = 0u; }
     PLS_SYNC();
     PLS_THREADS(tid, NT) {
         constexpr int NTW = (SEG_TBL_WORDS + NT - 1) / NT;
@@ -1326,6 +1354,7 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     }
     PLS_SYNC();
     const bool trx1 = misc[0] != 0u;
+    if (prof) te[1] = PLS_CLOCK();
     const int K1 = seg_k1(nstates);
     /* -- first phase, a turn of CPR pairs at a time: SEG_K1 steps from every state, the dedupe, the pair's entry map (entry index -> dense id) -- */
     for (int r = 0; r < ROUNDS; r++) {
@@ -1412,6 +1441,7 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
         }
         PLS_SYNC();
     }
+    if (prof) te[2] = PLS_CLOCK();
     /* -- the pairs' full records, where the first phase's scratch was (nobody reads that any more: a barrier lies behind its last use) -- */
     PLS_THREADS(tid, NT) {
         constexpr int NPI = (NC * (int)NPX + NT - 1) / NT;
@@ -1433,7 +1463,13 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     }
     PLS_SYNC();
     const bool trx = misc[0] != 0u;
-    /* -- second phase: the distinct states of all pairs, one lane each, through every segment of their unit -- */
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* From here on only the first misc[32 + NC] lanes have work.  The waves behind them END here: a workgroup of 16 waves keeps 16 of the CU's 32 wave slots
+     * as long as its waves sit in the barriers below -- with them gone the CU takes the next workgroup (measured: profiles/r05_unit_groups.txt).  A barrier
+     * counts the waves that have not ended, so the ones that stay are not held up. */
+    if ((threadIdx.x & ~63u) >= misc[32 + NC]) return;
+#endif
+    /* -- second phase: the distinct states of all pairs, one lane each, through the unit's FIRST segment -- */
     PLS_THREADS(tid, NT) {
         const uint32_t total = misc[32 + NC];
         if (tid < NC) {
@@ -1453,16 +1489,102 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
             st.left = (int)(key & 255u); st.cn = seg_sext8((int)(key >> 8)); st.th = seg_sext8((int)(key >> 16));
             const SegPix *pk = px + (size_t)k * NPX;
             const uint32_t sg0 = u * E, nsg = seg_umin(E, nseg - sg0);
+            const size_t slot = (((size_t)f * nseg + sg0) * 4 + c) * SEG_NSP + i;
             int bad = 0;
-            for (uint32_t sl = 0; sl < nsg; sl++) {
-                const size_t slot = (((size_t)f * nseg + sg0 + sl) * 4 + c) * SEG_NSP + i;
-                for (int part = 0; part < SEG_PARTS; part++) {
-                    if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
-                    const int skip = (sl == 0 && part == 0) ? K1 : 0;
-                    bad |= seg_run_fast_f(f, trx, pk + 1 + sl * SEG_L + part * SEG_PL + skip, 1, SEG_PL - skip, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            for (int part = 0; part < SEG_PARTS; part++) {
+                if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                const int skip = part == 0 ? K1 : 0;
+                bad |= seg_run_fast_f(f, trx, pk + 1 + part * SEG_PL + skip, 1, SEG_PL - skip, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+            }
+            const uint32_t ps0 = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+            j.rst[slot] = ps0;
+            SEG_DEBUG_STATE(f, (long)cv.y * 100000 + (long)cq, 0, i, ps0);
+            if (nsg == 1u) j.rout[slot] = (uint16_t)(bad ? (uint32_t)SEG_INVALID : seg_any_encode(P, f, pk[SEG_L], st));
+            pool[tid] = nsg > 1u ? ps0 : 0xFFFFFFFFu;         /* (the lane's start key is used up: its place takes the state it has reached) */
+        }
+    }
+    if (prof) { PLS_SYNC(); te[3] = PLS_CLOCK(); }
+    if (E > 1u) {
+        /* -- the states keep merging (measured on the CPU harness, profiles/r05_state_merging.txt: of the ~17 states a pair has four pixels into its unit,
+         *    ONE is left at the first segment's end for none / up / average, one to two for paeth, 2 .. 18 for sub).  So the lanes are deduplicated once
+         *    more there: a lane whose state no earlier lane of its pair has represents it (one bit a lane), the representatives get the ids of a SECOND
+         *    list, rout of the unit's first segment takes an id of the first list to its id in the second, and only the second list runs on. -- */
+        PLS_SYNC();
+        PLS_THREADS(tid, NT) {
+            const uint32_t total = misc[32 + NC];
+            if ((uint32_t)tid < total) {
+                const uint32_t ps = pool[tid];
+                if (ps != 0xFFFFFFFFu) {
+                    int k = 0;
+                    PLS_UNROLL
+                    for (int q = 1; q < NC; q++) k += (uint32_t)tid >= misc[32 + q] ? 1 : 0;
+                    uint32_t rep = (uint32_t)tid;
+                    for (uint32_t jj = misc[32 + k]; jj < (uint32_t)tid; jj++) if (pool[jj] == ps) { rep = jj; break; }
+                    if (rep == (uint32_t)tid) PLS_ATOMIC_OR(&misc[96 + (tid >> 5)], 1u << (tid & 31));
                 }
-                j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
-                if (sl + 1 == nsg) j.rout[slot] = (uint16_t)(bad ? (uint32_t)SEG_INVALID : seg_any_encode(P, f, pk[(sl + 1) * SEG_L], st));
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, NT) {
+            const uint32_t total = misc[32 + NC];
+            if ((uint32_t)tid < total) {
+                int k = 0;
+                PLS_UNROLL
+                for (int q = 1; q < NC; q++) k += (uint32_t)tid >= misc[32 + q] ? 1 : 0;
+                const uint32_t b0 = misc[32 + k], i = (uint32_t)tid - b0, cq = q0 + (uint32_t)k, u = cq / bpp, c = cq % bpp;
+                const uint32_t sg0 = u * E, nsg = seg_umin(E, nseg - sg0);
+                if (nsg > 1u) {
+                    const uint32_t ps = pool[tid];
+                    uint32_t dB = SEG_INVALID;
+                    if (ps != 0xFFFFFFFFu) {
+                        uint32_t rep = (uint32_t)tid;
+                        for (uint32_t jj = b0; jj < (uint32_t)tid; jj++) if (pool[jj] == ps) { rep = jj; break; }
+                        dB = seg_bits_count(misc + 96, b0, rep);
+                        if (rep == (uint32_t)tid) pool2[b0 + dB] = ps;
+                    }
+                    j.rout[(((size_t)f * nseg + sg0) * 4 + c) * SEG_NSP + i] = (uint16_t)dB;
+                }
+                if (i == 0u) misc[64 + k] = nsg > 1u ? seg_bits_count(misc + 96, b0, misc[32 + k + 1]) : 0u;
+            }
+        }
+        PLS_SYNC();
+        PLS_THREADS(tid, NT) {
+            if (tid == 0) { uint32_t run = 0; for (int k = 0; k < NC; k++) { const uint32_t cnt2 = misc[64 + k]; misc[64 + k] = run; run += cnt2; } misc[64 + NC] = run; }
+        }
+        PLS_SYNC();
+        /* -- third phase: the second list through the rest of the unit -- */
+        PLS_THREADS(tid, NT) {
+            const uint32_t total2 = misc[64 + NC];
+            if ((uint32_t)tid < total2) {
+                int k = 0;
+                PLS_UNROLL
+                for (int q = 1; q < NC; q++) k += (uint32_t)tid >= misc[64 + q] ? 1 : 0;
+                const uint32_t i = (uint32_t)tid - misc[64 + k], cq = q0 + (uint32_t)k, u = cq / bpp, c = cq % bpp;
+                SegState st = seg_state_unpack(pool2[misc[32 + k] + i]);
+                const SegPix *pk = px + (size_t)k * NPX;
+                const uint32_t sg0 = u * E, nsg = seg_umin(E, nseg - sg0);
+                int bad = 0;
+                for (uint32_t sl = 1; sl < nsg; sl++) {
+                    const size_t slot = (((size_t)f * nseg + sg0 + sl) * 4 + c) * SEG_NSP + i;
+                    for (int part = 0; part < SEG_PARTS; part++) {
+                        if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                        bad |= seg_run_fast_f(f, trx, pk + 1 + sl * SEG_L + part * SEG_PL, 1, SEG_PL, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                    }
+                    j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+                    SEG_DEBUG_STATE(f, (long)cv.y * 100000 + (long)cq, sl, i, bad ? 0xFFFFFFFFu : seg_state_pack(st));
+                    if (sl + 1 == nsg) j.rout[slot] = (uint16_t)(bad ? (uint32_t)SEG_INVALID : seg_any_encode(P, f, pk[(sl + 1) * SEG_L], st));
+                }
+            }
+        }
+    }
+    if (prof) {
+        PLS_SYNC();
+        PLS_THREADS(tid, NT) {
+            if (tid == 0) {
+                te[4] = PLS_CLOCK();
+                for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
+                PLS_ATOMIC_ADD((uint32_t *)&j.result[33], 4u * misc[32 + NC] / (uint32_t)NC);
             }
         }
     }
@@ -1671,9 +1793,16 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 const uint32_t dc = dcnt[(size_t)SEGF(s0) * 4];
                 if (d >= SEG_NSP || d >= dc) d = SEG_INVALID;
                 entry[(size_t)SEGF(s0) * 4] = start_ps;
-                for (uint32_t sg = SEGF(s0); sg <= SEGL(s0); sg++) {
-                    dnout[(size_t)sg * 4] = (uint16_t)d;
-                    if (sg > SEGF(s0) && d != SEG_INVALID) entry[(size_t)sg * 4] = rst[(size_t)(sg - 1u) * rstep32 + d];
+                dnout[(size_t)SEGF(s0) * 4] = (uint16_t)d;
+                if (SEGL(s0) > SEGF(s0)) {
+                    /* (a unit: behind its first segment its states have the ids of the second list, rout of the first segment translates) */
+                    const uint32_t dB = d != SEG_INVALID ? (uint32_t)rout[(size_t)SEGF(s0) * rstep32 + d] : (uint32_t)SEG_INVALID;
+                    const bool okB = dB < SEG_NSP;
+                    if (d != SEG_INVALID) entry[(size_t)(SEGF(s0) + 1u) * 4] = rst[(size_t)SEGF(s0) * rstep32 + d];
+                    for (uint32_t sg = SEGF(s0) + 1u; sg <= SEGL(s0); sg++) {
+                        dnout[(size_t)sg * 4] = (uint16_t)(okB ? dB : (uint32_t)SEG_INVALID);
+                        if (sg > SEGF(s0) + 1u && okB) entry[(size_t)sg * 4] = rst[(size_t)(sg - 1u) * rstep32 + dB];
+                    }
                 }
                 /* without an id the unit's first segment is walked by the replay from its entry state; what lies behind it in the unit has no state
                  * to start from: reported as this candidate's first failed decision (an epoch starts there, as behind any failed validation) */
@@ -1727,8 +1856,30 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
                     const uint32_t o = SEGL(sg) * rstep32 + d;
                     dcv[q] = dcnt[SEGF(sg) * 4u];
-                    r[q] = seeded ? 0u : (uint32_t)rout[o];
-                    ps[q] = (useR || seeded) ? rst[o] : SEG_NOSTATE;
+                    if (UNITS && !seeded) { r[q] = (uint32_t)rout[SEGF(sg) * rstep32 + d]; ps[q] = SEG_NOSTATE; }     /* (units: first the id in the unit's second list) */
+                    else {
+                        r[q] = seeded ? 0u : (uint32_t)rout[o];
+                        ps[q] = (useR || seeded) ? rst[o] : SEG_NOSTATE;
+                    }
+                }
+                if (UNITS && !seeded) {
+                    /* the unit's exit index and exit state sit under the id of the SECOND list (a unit of one segment has no second list: rout is the exit index) */
+                    uint32_t r2[SEG_CQ];
+                    PLS_UNROLL
+                    for (int q = 0; q < SEG_CQ; q++) {
+                        const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
+                        const bool one = SEGL(sg) == SEGF(sg), okB = d < dcv[q] && r[q] < SEG_NSP;
+                        const uint32_t o2 = SEGL(sg) * rstep32 + (one ? d : (okB ? r[q] : 0u));
+                        r2[q] = (uint32_t)rout[o2];
+                        ps[q] = useR ? rst[o2] : SEG_NOSTATE;
+                    }
+                    PLS_UNROLL
+                    for (int q = 0; q < SEG_CQ; q++) {
+                        const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;
+                        const bool one = SEGL(sg) == SEGF(sg), okB = d < dcv[q] && r[q] < SEG_NSP;
+                        if (!(one || okB)) { r2[q] = SEG_INVALID; ps[q] = SEG_NOSTATE; }
+                        r[q] = r2[q];
+                    }
                 }
                 if (starter && kb == 0) {
                     if (seeded) {
@@ -1871,18 +2022,24 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     const uint32_t sg = s0 + a + k;
                     if (d == SEG_INVALID) { PLS_ATOMIC_MIN(&idxb[25], k); continue; }
                     dnout[(size_t)SEGF(sg) * 4] = (uint16_t)d;
-                    if (E > 1u) {
-                        /* the unit's inner segments: the same id, entry state = exit state of the segment in front under it */
+                    uint32_t dL = d;                                  /* the id the unit's LAST segment keeps its records under */
+                    if (E > 1u && SEGL(sg) > SEGF(sg)) {
+                        /* the unit's inner segments: the id of the unit's second list (rout of its first segment translates), entry state = exit state of
+                         * the segment in front */
                         const bool have = d < dcnt[(size_t)SEGF(sg) * 4];
+                        const uint32_t dB = have ? (uint32_t)rout[(size_t)SEGF(sg) * rstep32 + d] : (uint32_t)SEG_INVALID;
+                        const bool okB = dB < SEG_NSP;
+                        entry[(size_t)(SEGF(sg) + 1u) * 4] = have ? rst[(size_t)SEGF(sg) * rstep32 + d] : SEG_NOSTATE;
                         for (uint32_t si = SEGF(sg) + 1u; si <= SEGL(sg); si++) {
-                            dnout[(size_t)si * 4] = (uint16_t)d;
-                            entry[(size_t)si * 4] = have ? rst[(size_t)(si - 1u) * rstep32 + d] : SEG_NOSTATE;
+                            dnout[(size_t)si * 4] = (uint16_t)(okB ? dB : (uint32_t)SEG_INVALID);
+                            if (si > SEGF(sg) + 1u) entry[(size_t)si * 4] = okB ? rst[(size_t)(si - 1u) * rstep32 + dB] : SEG_NOSTATE;
                         }
+                        dL = okB ? dB : (uint32_t)SEG_INVALID;
                     }
                     if (k >= ntr) continue;
                     uint32_t ps = SEG_NOSTATE;
                     if (useR) ps = R[(k << SEG_CR_SH) + d];
-                    else if (d < dcnt[(size_t)SEGF(sg) * 4]) ps = rst[(size_t)SEGL(sg) * rstep32 + d];
+                    else if (d < dcnt[(size_t)SEGF(sg) * 4] && dL < SEG_NSP) ps = rst[(size_t)SEGL(sg) * rstep32 + dL];
                     entL[k + 1u] = ps;
                     if (ps != SEG_NOSTATE) entry[(size_t)SEGF(sg + 1u) * 4] = ps;
                 }
