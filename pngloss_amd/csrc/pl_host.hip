@@ -36,7 +36,7 @@
         }                                                                                                        \
     } while (0)
 
-#define SEG_MAX_GROUPS 4
+#define SEG_MAX_GROUPS 8
 struct pngloss_hip_ctx {
     int device = 0;
     /* one device arena, regrown on demand, carved per batch */
@@ -71,8 +71,8 @@ struct pngloss_hip_ctx {
     /* the segment engine's launch loop runs on a helper thread and on a stream of its own (the number of row attempts is decided by the
      * data): the caller's stream waits for the "images finished" word instead of for the host */
     hipStream_t seg_stream = nullptr;
-    hipStream_t seg_gstream[SEG_MAX_GROUPS] = { nullptr, nullptr, nullptr, nullptr };   /* [0] = seg_stream: one stream per GROUP of a batch's images (run_seg_engine) */
-    hipEvent_t ev_seg_gdone[SEG_MAX_GROUPS] = { nullptr, nullptr, nullptr, nullptr };
+    hipStream_t seg_gstream[SEG_MAX_GROUPS] = {};   /* [0] = seg_stream: one stream per GROUP of a batch's images (run_seg_engine) */
+    hipEvent_t ev_seg_gdone[SEG_MAX_GROUPS] = {};
     int seg_groups = 1;
     hipEvent_t ev_prep = nullptr;    /* caller's stream: everything the engine reads is in place */
     hipEvent_t ev_seg_done = nullptr;/* engine's stream: behind the last attempt the launch thread enqueued */
@@ -160,9 +160,9 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
      * for k's inputs, whose kernels sat behind caller j's wait for engine j.  So this thread waits for the inputs, on the host. */
     if (rc == PNGLOSS_SUCCESS && hipEventSynchronize(ctx->ev_prep) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
     const long lookahead = 32;                                  /* attempts queued ahead of the one the device works on */
-    long launched[SEG_MAX_GROUPS] = { 0, 0, 0, 0 };
+    long launched[SEG_MAX_GROUPS] = {};
     auto t_last = std::chrono::steady_clock::now();
-    uint32_t seen[SEG_MAX_GROUPS] = { 0, 0, 0, 0 };
+    uint32_t seen[SEG_MAX_GROUPS] = {};
     int idle = 0;
     for (;;) {
         if (rc != PNGLOSS_SUCCESS) break;
@@ -186,7 +186,7 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
         if (all_done || rc != PNGLOSS_SUCCESS) break;
         if (!any_launched) {
             if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(20)) {
-                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress (attempts %u %u %u %u)\n", seen[0], seen[1], seen[2], seen[3]);
+                std::fprintf(stderr, "pngloss_hip: the segment engine stopped making progress (attempts of the first groups: %u %u %u %u)\n", seen[0], seen[1], seen[2], seen[3]);
                 rc = PNGLOSS_HIP_ERROR;
                 break;
             }
@@ -212,7 +212,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
                    size_t jobs_off, size_t params_off, hipStream_t stream, const uint32_t *d_sel, size_t n_wg, const PlEngineParams &prm)
 {
     const size_t n = list.size();                              /* the images of the batch this engine takes */
-    if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 8 * SEG_MAX_GROUPS > 64 ? 8 * SEG_MAX_GROUPS : 64, hipHostMallocMapped | hipHostMallocCoherent));
     if (!ctx->seg_stream) {
         /* a stream of the HIGHEST priority: streams of one priority share a few hardware queues, and a queue whose head is a caller's
          * wait for the finished word holds up everything behind it -- the engine's attempts must never sit in such a queue (twelve
@@ -233,9 +233,10 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     {
         size_t segs = 0;
         for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
-        /* (measured, profiles/r05_unit_groups.txt: two sequences 1.2x one from 16 frames of 1080p on, three another 2-5 %, FOUR collapse -- 250 ms for 8 frames
-         *  against 113: with the caller's stream they outnumber the hardware queues a process gets.  Two: a second context on the device must still fit) */
-        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = 2;
+        /* (measured, profiles/r05_unit_groups.txt: two sequences 1.2x one from 16 frames of 1080p on, three another 2-6 %, FOUR collapse -- 250 ms for 8 frames
+         *  against 113: with the caller's stream they outnumber the hardware queues a process gets, and the stream that shares a queue with the caller's sits
+         *  behind its wait for the finished word (without that wait four run, six collapse: profiles/r05_validation_in_enum.txt) */
+        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = n >= 12 ? 3 : 2;     /* (round 5, profiles/r05_validation_in_enum.txt: three sequences 16 / 32 / 64 frames 113 / 148 / 242 ms against 121 / 158 / 249 with two) */
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
         ngroups = (int)std::min<size_t>((size_t)ngroups, n);
     }
@@ -399,7 +400,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
              * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
             const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
             auto attempt_us = [&](double wgs, double segs) {
-                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(95.0, 45.0 + 0.015 * wgs);
+                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(95.0, 45.0 + 0.0138 * wgs);       /* (three launch groups: 16 / 32 / 64 frames of 1080p 104 / 136 / 223 us) */
                 return a_us + w_us * wgs;
             };
             auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
