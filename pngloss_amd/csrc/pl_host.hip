@@ -235,8 +235,11 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
         /* (measured, profiles/r05_unit_groups.txt: two sequences 1.2x one from 16 frames of 1080p on, three another 2-6 %, FOUR collapse -- 250 ms for 8 frames
          *  against 113: with the caller's stream they outnumber the hardware queues a process gets, and the stream that shares a queue with the caller's sits
-         *  behind its wait for the finished word (without that wait four run, six collapse: profiles/r05_validation_in_enum.txt) */
-        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = n >= 12 ? 3 : 2;     /* (round 5, profiles/r05_validation_in_enum.txt: three sequences 16 / 32 / 64 frames 113 / 148 / 242 ms against 121 / 158 / 249 with two) */
+         *  behind its wait for the finished word (without that wait four run, six collapse: profiles/r05_validation_in_enum.txt).  THREE looked 6 % faster in a
+         *  process that does nothing else -- and halved every later engine run of bench.py's process, single images included (suite batch 45 -> 14 Mpx/s, 8192 x 8192
+         *  137 -> 71): the hardware queues a third engine stream brings into the process's pool stay there, and from then on an engine stream shares one with a
+         *  waiting stream.  Two it is: a caller with streams of its own must still fit.) */
+        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = 2;
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
         ngroups = (int)std::min<size_t>((size_t)ngroups, n);
     }
@@ -400,7 +403,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
              * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
             const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
             auto attempt_us = [&](double wgs, double segs) {
-                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(95.0, 45.0 + 0.0138 * wgs);       /* (three launch groups: 16 / 32 / 64 frames of 1080p 104 / 136 / 223 us) */
+                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(95.0, 45.0 + 0.015 * wgs);
                 return a_us + w_us * wgs;
             };
             auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
