@@ -240,6 +240,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
          *  137 -> 71): the hardware queues a third engine stream brings into the process's pool stay there, and from then on an engine stream shares one with a
          *  waiting stream.  Two it is: a caller with streams of its own must still fit.) */
         if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = 2;
+        else if (n >= 2) ngroups = 2;                              /* (a small batch: see the shares below) */
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
         ngroups = (int)std::min<size_t>((size_t)ngroups, n);
     }
@@ -257,9 +258,16 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     PL_CHECK(hipHostGetDevicePointer(&d_words, ctx->h_seg_words, 0));
     volatile uint32_t *words = ctx->h_seg_words;
     for (int q = 0; q < 2 * SEG_MAX_GROUPS; q++) words[q] = 0;
-    /* group g = images [gfirst[g], gfirst[g + 1]) of `list` (in the batch's order: equal shares) */
+    /* group g = images [gfirst[g], gfirst[g + 1]) of `list` (tallest first: enqueue): equal shares -- or, in a batch of two groups whose tallest image stands out, that
+     * image alone and the others together.  A group takes as many attempts as its image with the most, and every attempt costs what ALL its images' workgroups
+     * cost: the reference's suite as one batch (configs[2]) spent 71 ms on the 1199 attempts of its tallest image, a screenshot whose candidate none fails in 40 % of
+     * its rows -- at the price of eight images each; the other seven need 625 (profiles/r05_suite_groups.txt). */
     size_t gfirst[SEG_MAX_GROUPS + 1];
     for (int g = 0; g <= ngroups; g++) gfirst[g] = n * (size_t)g / (size_t)ngroups;
+    if (ngroups == 2 && n > 2 && !std::getenv("PNGLOSS_HIP_SEG_GROUPS")) {
+        const uint32_t h0 = ctx->h_jobs[list[0]].height, h1 = ctx->h_jobs[list[1]].height;
+        if ((uint64_t)h0 * 100u > (uint64_t)h1 * 105u) gfirst[1] = 1;
+    }
     auto group_of = [&](size_t i) { int g = 0; while (g + 1 < ngroups && i >= gfirst[g + 1]) g++; return g; };
     ctx->h_sj.assign(n, SegJob{});
     ctx->h_seg_params = params;
@@ -402,8 +410,10 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
              * small workgroups of batches (run_seg_engine): an attempt then takes ~45 us + 0.015 us per workgroup-unit, but not less than ~95 us (the
              * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
             const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
-            auto attempt_us = [&](double wgs, double segs) {
+            auto attempt_us = [&](double wgs, double segs, size_t k) {
                 if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(95.0, 45.0 + 0.015 * wgs);
+                /* (two or more images run as two launch sequences side by side: 4 / 8 / 12 frames of 1080p 58 / 80 / 102 us per attempt, profiles/r05_suite_groups.txt) */
+                if (k >= 2 && !seg_params.seeded) return 35.0 + 0.026 * wgs;
                 return a_us + w_us * wgs;
             };
             auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
@@ -419,7 +429,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 double seg_rows = 0, seg_wgs = 0, seg_segs = 0;
                 auto batch_us = [&](size_t k, double rows, double wgs, double wsum, double segs) {   /* the first k images of `order` on the segment engine */
                     const double wg_us = k < order.size() ? std::max(wg_cost(order[k]), wsum / 256.0) : wsum / 256.0;
-                    return std::max(wg_us, k ? rows * attempt_us(wgs, segs) : 0.0);
+                    return std::max(wg_us, k ? rows * attempt_us(wgs, segs, k) : 0.0);
                 };
                 double best = batch_us(0, 0, 0, wg_sum, 0);
                 size_t best_k = 0;
@@ -444,6 +454,8 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     const bool use_seg = n_seg != 0;
     std::vector<uint32_t> seg_list, wg_list;
     for (size_t i = 0; i < n; i++) (on_seg[i] ? seg_list : wg_list).push_back((uint32_t)i);
+    /* the segment engine's images, tallest first: its launch groups are runs of this list (run_seg_engine), and the tallest image gets a sequence of its own when it stands out */
+    std::stable_sort(seg_list.begin(), seg_list.end(), [&](uint32_t x, uint32_t y) { return images[x].height > images[y].height; });
     std::vector<size_t> seg_offs;
     size_t seg_jobs_off = 0, seg_params_off = 0, sel_off = 0;
     if (use_seg) {

@@ -146,7 +146,8 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_UNIT
 #define SEG_UNIT 3               /* segments per enumeration UNIT when the launcher asks for units (SegParams::unit; batches).  Measured (profiles/r05_unit_groups.txt): 2, 3, 4 within 3 % of each other from 16 frames of 1080p on, 3 best at 32 and 64; 8 loses below 64 frames */
 #endif
-#define SEG_UNIT_MIN_SEGS 320    /* the launcher enumerates in units when the batch's images have more segments than this between them (six frames of 1920 pixels) */
+#define SEG_UNIT_MIN_SEGS 680    /* the launcher enumerates in units when the batch's images have more segments than this between them (twelve frames of 1920 pixels; measured with two
+                                    launch groups, profiles/r05_suite_groups.txt: 8 / 10 / 12 / 16 frames per segment 87 / 99 / 111 / 137 ms, in units 105 / 106 / 108 / 121) */
 #if !defined(SEG_UNC) && SEG_UNIT > 6
 #define SEG_UNC 7                /* (longer units: fewer pairs, so that their pixel records fit the 16 KB the workgroup's shared memory has for them) */
 #endif
