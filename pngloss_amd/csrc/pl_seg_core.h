@@ -1106,7 +1106,13 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
     PLS_SYNC();
     const bool trx = trflag[0] != 0u;
     if (prof) te[1] = PLS_CLOCK();
-    /* -- the seeds, through the run-in -- */
+    /* -- the seeds, through the run-in.  A workgroup of a channel PAIR does it in two stages (round 5): SEG_KA steps from every seed, then only the DISTINCT states
+     *    that are left (a few dozen of the 256 per channel: the seeds differ in the left byte, and the left bytes fall into the bands' phases at once) through the
+     *    rest of the run-in, both channels packed into the first lanes -- two waves instead of eight for most of the run-in's steps.  The distinct states are found
+     *    like the entry set below, in the half of the hash arrays a channel pair leaves unused (channels 2, 3); a state the window has no room for is dropped: a seed
+     *    less, which costs coverage, never correctness.  The entry set is the same SET of states either way. -- */
+    constexpr int SEG_KA = 4;
+    const bool two_stage = NCH == 2 && xs != 0u && nrun > SEG_KA + 2;
     PLS_THREADS(tid, NT) {
         const int lc = tid / SEG_NSP, c = c0 + lc, i = tid % SEG_NSP;
         uint32_t key = SEG_NOKEY;
@@ -1130,13 +1136,70 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
                 }
             }
             if (ok) {
-                const int bad = nrun ? seg_run_fast_f(f, trx, px + 4 + c, 4, nrun, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut)) : 0;
+                const int nst = two_stage ? SEG_KA : nrun;
+                const int bad = nst ? seg_run_fast_f(f, trx, px + 4 + c, 4, nst, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut)) : 0;
                 if (!bad) key = seg_eh_key(st.left, st.cn, st.th);
             }
         }
         keys[tid] = key;
     }
     PLS_SYNC();
+    if (two_stage) {
+        /* the distinct states after SEG_KA steps: list uniq[2 + lc][], count trflag[3 + lc] */
+        PLS_THREADS(tid, NT) {
+            const int lc = tid / SEG_NSP, i = tid % SEG_NSP;
+            const uint32_t key = keys[tid];
+            if (lc < 2 && key != SEG_NOKEY && (i == 0 || keys[tid - 1] != key)) {
+                const uint32_t base = seg_eh_base(key);
+                for (int q = 0; q < SEG_EHW; q++) {
+                    const uint32_t old = PLS_ATOMIC_CAS(&ht[(2 + lc) * SEG_EH_WORDS + base + q], SEG_NOKEY, key);
+                    if (old == SEG_NOKEY) {
+                        const uint32_t d = PLS_ATOMIC_ADD_RET(&trflag[3 + lc], 1u);
+                        if (d < SEG_NSP) uniq[(2 + lc) * SEG_NSP + d] = key;
+                        break;
+                    }
+                    if (old == key) break;
+                }
+            }
+        }
+        PLS_SYNC();
+        /* ... through the rest of the run-in, one lane each */
+        const uint32_t DA0 = trflag[3] < SEG_NSP ? trflag[3] : SEG_NSP, DA1 = trflag[4] < SEG_NSP ? trflag[4] : SEG_NSP;
+        PLS_THREADS(tid, NT) {
+            uint32_t key = SEG_NOKEY;
+            if ((uint32_t)tid < DA0 + DA1) {
+                const int lc = (uint32_t)tid < DA0 ? 0 : 1, c = c0 + lc;
+                const uint32_t i = lc ? (uint32_t)tid - DA0 : (uint32_t)tid;
+                SegState st = seg_eh_state(uniq[(2 + lc) * SEG_NSP + i]);
+                const int bad = seg_run_fast_f(f, trx, px + (1 + SEG_KA) * 4 + c, 4, nrun - SEG_KA, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                if (!bad) key = seg_eh_key(st.left, st.cn, st.th);
+            }
+            keys[tid] = key;
+        }
+        PLS_SYNC();
+        /* -- the entry set (as below), from the packed lanes -- */
+        PLS_THREADS(tid, NT) {
+            if ((uint32_t)tid < DA0 + DA1) {
+                const int c = (uint32_t)tid < DA0 ? 0 : 1;
+                const uint32_t i = c ? (uint32_t)tid - DA0 : (uint32_t)tid;
+                const uint32_t key = keys[tid];
+                if (key != SEG_NOKEY && (i == 0 || keys[tid - 1] != key)) {
+                    const uint32_t base = seg_eh_base(key);
+                    for (int q = 0; q < SEG_EHW; q++) {
+                        const uint32_t old = PLS_ATOMIC_CAS(&ht[c * SEG_EH_WORDS + base + q], SEG_NOKEY, key);
+                        if (old == SEG_NOKEY) {
+                            const uint32_t d = PLS_ATOMIC_ADD_RET(&trflag[1 + c], 1u);
+                            dense[c * SEG_EH_WORDS + base + q] = (uint16_t)(d < SEG_NSP ? d : 0xffffu);
+                            if (d < SEG_NSP) uniq[c * SEG_NSP + d] = key;
+                            break;
+                        }
+                        if (old == key) break;
+                    }
+                }
+            }
+        }
+        PLS_SYNC();
+    } else {
     /* -- the entry set: distinct states, hashed by value (only the first lane of a run of equal neighbours inserts) -- */
     PLS_THREADS(tid, NT) {
         const int c = tid / SEG_NSP, i = tid % SEG_NSP;
@@ -1156,6 +1219,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
         }
     }
     PLS_SYNC();
+    }
     if (prof) te[2] = PLS_CLOCK();
     PLS_THREADS(tid, NT) {
         for (int i = tid; i < NCH * SEG_EH_WORDS; i += NT) {
@@ -1192,7 +1256,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
             te[3] = PLS_CLOCK(); te[4] = te[3];
             for (int q = 0; q < 4; q++) { PLS_ATOMIC_MAX(&j.result[24 + q], (int32_t)(te[q + 1] - te[q])); PLS_ATOMIC_ADD((uint32_t *)&j.result[28 + q], (uint32_t)(te[q + 1] - te[q])); }
             PLS_ATOMIC_ADD((uint32_t *)&j.result[32], 1u);
-            PLS_ATOMIC_ADD((uint32_t *)&j.result[33], trflag[1] + trflag[2] + trflag[3] + trflag[4]);
+            PLS_ATOMIC_ADD((uint32_t *)&j.result[33], two_stage ? 2u * (trflag[1] + trflag[2]) : trflag[1] + trflag[2] + trflag[3] + trflag[4]);
         }
     }
 }
