@@ -420,6 +420,36 @@ def test_segment_engine_batch_of_mixed_images(torch_cuda, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("groups", [None, "1", "2"])
+def test_segment_engine_launch_groups_of_small_and_mixed_batches(torch_cuda, monkeypatch, groups):
+    """Round 5: a batch of two or more images runs as TWO launch sequences on two streams (pl_host.hip:run_seg_engine) -- the tallest image alone when it stands
+    out, equal shares otherwise; the library sorts the segment engine's images by height for that.  Results must not depend on it: the library's own choice,
+    one group and two equal groups (PNGLOSS_HIP_SEG_GROUPS) all give the oracle's bytes, image by image in the caller's order -- heights in every order, ties,
+    a 1x1 image, NULL row_filters, and the same context used for a second batch of another shape."""
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    if groups is not None:
+        monkeypatch.setenv("PNGLOSS_HIP_SEG_GROUPS", groups)
+    ctx = P.HipContext()
+    for specs in ([(300, 40, 0), (200, 90, 1), (64, 48, 4), (700, 25, 5), (33, 77, 3), (1, 1, 1), (512, 90, 2)],      # tallest in the middle, a tie for the tallest
+                  [(260, 30, 2), (180, 64, 0)],                                                                    # two images: one each
+                  [(640, 20, 1), (640, 20, 3), (640, 20, 5)],                                                      # equal heights: equal shares
+                  [(96, 120, 0), (400, 16, 4), (300, 16, 1), (50, 16, 2)]):                                        # one image far taller than the rest
+        imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+        dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+        filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") if i != 1 else None for i, a in enumerate(imgs)]
+        res = ctx.run([(d.data_ptr(), f.data_ptr() if f is not None else 0, a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)], 19, 2,
+                      stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i, (a, d, f, r) in enumerate(zip(imgs, dev, filt, res)):
+            assert ctx.engine_info(i)["engine"] == "segment-parallel"
+            o1, f1 = U.run_port(a, 19, 2, filters=f is not None)
+            assert r["status"] == 0 and np.array_equal(d.cpu().numpy(), o1), (groups, i, specs[i])
+            if f is not None:
+                assert np.array_equal(f.cpu().numpy(), f1), (groups, i, specs[i])
+    ctx.close()
+
+
 def test_segment_engine_strengths_and_bleeds_with_few_and_many_states(monkeypatch):
     """(strength, bleed) pairs from one chain state (s = 0) to the most the lanes hold; widths around the segment (32), group (512)
     and commit-workgroup (1024) sizes; every byte-per-pixel class."""
