@@ -74,6 +74,8 @@ struct pngloss_hip_ctx {
     hipStream_t seg_gstream[SEG_MAX_GROUPS] = {};   /* [0] = seg_stream: one stream per GROUP of a batch's images (run_seg_engine) */
     hipEvent_t ev_seg_gdone[SEG_MAX_GROUPS] = {};
     int seg_groups = 1;
+    bool sync_call = false;          /* the batch under way was started by a SYNCHRONOUS entry point (pngloss_hip_optimize_batch): the caller waits on the host anyway, so the
+                                        caller's stream gets no device-side wait for the engine's finished word (run_seg_engine) */
     hipEvent_t ev_prep = nullptr;    /* caller's stream: everything the engine reads is in place */
     hipEvent_t ev_seg_done = nullptr;/* engine's stream: behind the last attempt the launch thread enqueued */
     std::thread seg_worker;
@@ -336,7 +338,9 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
      * detector of the launch thread is the other net.  (Seen: 1813 attempts for a 63 x 2 image at strength 200, all rows adaptive.) */
     const long max_attempts = (long)std::min<double>(2.0e9, (double)max_h * ((double)params.strength + 1.0) * (2.0 + 2.0 * SEG_MAX_RESTARTS * SEG_NFILT) + 1024.0);
     ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
-    bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct;
+    /* (round 5, measured with tools/gpu_r5_benchlegs.sh: the stream memory operation on the caller's stream is not free -- its queue polls the finished word while
+     *  the engine runs -- : without it the headline frame is 1.4 % faster, the seeded 8192 x 8192 points up to 7 %.  The synchronous entry point has no use for it.) */
+    bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct && !ctx->sync_call;
     if (waiting && stream) {
         /* (a caller's stream of the engine's own priority could share its queue: no wait on that one) */
         int prio = 0;
@@ -813,7 +817,10 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
                                unsigned quantization_strength, long bleed_divider, void *stream,
                                pngloss_hip_result *results)
 {
+    if (!ctx) return PNGLOSS_INVALID_ARGUMENT;
+    ctx->sync_call = true;
     int rc = enqueue(ctx, images, n, nullptr, quantization_strength, bleed_divider, static_cast<hipStream_t>(stream));
+    ctx->sync_call = false;
     if (rc) return rc;
     return finish(ctx, results, n);
 }

@@ -304,8 +304,16 @@ class HipContext:
         return [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols, retried_rows=r.retried_rows, repaired_pixels=r.repaired_pixels) for r in res[:n]]
 
     def run(self, images, strength=19, bleed=2, stream=0):
-        self.enqueue(images, strength, bleed, stream)
-        return self.finish()
+        """pngloss_hip_optimize_batch: the SYNCHRONOUS entry point (enqueue + finish in one call; the library then spares the caller's stream the device-side
+        wait for the engine that the asynchronous entry needs)."""
+        n = len(images)
+        descs = (ImageDesc * max(n, 1))()
+        for i, (p, f, w, h) in enumerate(images):
+            descs[i] = ImageDesc(p, f or None, w, h)
+        res = (Result * max(n, 1))()
+        self._n = n
+        _check(self._lib.pngloss_hip_optimize_batch(self._ctx, descs, n, strength, bleed, stream or None, res), "optimize_batch", partial_ok=True)
+        return [dict(status=r.status, bpp=r.bytes_per_pixel, unique_symbols=r.unique_symbols, retried_rows=r.retried_rows, repaired_pixels=r.repaired_pixels) for r in res[:n]]
 
     def run_host(self, arrays, strength=19, bleed=2, want_filters=True, inplace=False):
         """pngloss_hip_optimize_batch_host on a list of (H, W, 4) uint8 arrays.  Returns (outs, filters, results).
