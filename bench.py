@@ -404,19 +404,20 @@ def run_rank_shares(P, torch, ctx_factory, want):
     return out
 
 
-SAT_FRAMES_PER_RANK, SAT_DISTINCT = 512, 32
+SAT_FRAMES_PER_RANK, SAT_DISTINCT, SAT_BATCH = 512, 32, 512     # (SAT_BATCH: frames per call -- one call: the workgroups of 512 images are dispatched as CUs fall free,
+                                                                  #  so a slow frame no longer holds a whole batch of 256: the frames differ by a third, 272 - 375 ms alone)
 
 
 def run_batch_saturating(P, S, torch, ctx_factory, rank, world, barrier):
-    """512 frames of 1920x1080 PER RANK (4096 in all at N = 8), in device-resident batches of 256: a workload that keeps N GPUs
+    """512 frames of 1920x1080 PER RANK (4096 in all at N = 8), in ONE device-resident batch (SAT_BATCH): a workload that keeps N GPUs
     busy, unlike configs[3] split N ways.  The frames are 32 distinct synthetic ones (indices 0, 1, 255 and 29 more), each
     uploaded once and cloned on the device; the digests of the copies of frames 0, 1 and 255 are checked."""
     idx = [0, 1, 255] + list(range(2, 2 + SAT_DISTINCT - 3))
     base = [torch.from_numpy(P.synth_rgba(BATCH_W, BATCH_H, MODE, i)).cuda() for i in idx]
     ctx = ctx_factory()
     total, eng, recs = 0.0, 0.0, []
-    for part in range(SAT_FRAMES_PER_RANK // 256):
-        dev = [base[k % SAT_DISTINCT].clone() for k in range(256)]
+    for part in range(SAT_FRAMES_PER_RANK // SAT_BATCH):
+        dev = [base[k % SAT_DISTINCT].clone() for k in range(SAT_BATCH)]
         filt = [torch.zeros(BATCH_H, dtype=torch.uint8, device="cuda") for _ in dev]
         desc = [(d.data_ptr(), f.data_ptr(), BATCH_W, BATCH_H) for d, f in zip(dev, filt)]
         barrier()
@@ -687,13 +688,13 @@ def main():
             chk = [r for e in sall for r in e["recs"]]
             nfr = SAT_FRAMES_PER_RANK * world
             line["batch_saturating"] = {"workload": f"{SAT_FRAMES_PER_RANK} synthetic {BATCH_W}x{BATCH_H} RGBA8 frames PER GPU ({nfr} in all), s={STRENGTH} b={BLEED}, "
-                                                    f"device-resident batches of 256; {SAT_DISTINCT} distinct frames cloned on the device",
+                                                    f"device-resident batches of {SAT_BATCH}; {SAT_DISTINCT} distinct frames cloned on the device",
                                         "value": round(nfr * BATCH_W * BATCH_H / st / 1e6, 2), "unit": "Mpixels/s", "seconds": round(st, 4), "scaling": "weak",
                                         "engine_ms_per_rank": [round(e["engine_ms"], 2) for e in sall],
                                         "engine": sall[0].get("engine", {}).get("engine"),
                                         "digests_match_reference": bool(chk) and all(r["ok"] and r["out"] == want[r["frame"]]["out"] and r["filters"] == want[r["frame"]]["filters"] for r in chk),
                                         "note": "configs[3] (256 frames in all) leaves a GPU 256/N images = 256/N busy CUs, so it cannot speed up past N = 1; "
-                                                "this leg gives every GPU two full batches"}
+                                                "this leg gives every GPU 512 frames in one call: two per CU, dispatched as CUs fall free (a frame takes 272 - 375 ms alone, so a call of 256 waits for its slowest)"}
         print(json.dumps(line), flush=True)
     ctx.close()
     if use_dist:

@@ -433,7 +433,12 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 double seg_rows = 0, seg_wgs = 0, seg_segs = 0;
                 auto batch_us = [&](size_t k, double rows, double wgs, double wsum, double segs) {   /* the first k images of `order` on the segment engine */
                     const double wg_us = k < order.size() ? std::max(wg_cost(order[k]), wsum / 256.0) : wsum / 256.0;
-                    return std::max(wg_us, k ? rows * attempt_us(wgs, segs, k) : 0.0);
+                    const double seg_us = k ? rows * attempt_us(wgs, segs, k) : 0.0;
+                    /* side by side only while the other engine leaves the segment engine CUs to run on: its workgroups are persistent and own a CU each (104 KB of
+                     * LDS, every register) -- next to 200 and more of them the segment engine's launches wait until they are through: one after the other
+                     * (measured: 512 frames of 1080p in one call, 130 of them sent to the segment engine by the model of before: 1034 ms against 2 x 375) */
+                    if (n - k > 192) return wg_us + seg_us;
+                    return std::max(wg_us, seg_us);
                 };
                 double best = batch_us(0, 0, 0, wg_sum, 0);
                 size_t best_k = 0;
