@@ -150,6 +150,30 @@ struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
  * still runs behind the engine.  (The images of a mixed batch that the other engine takes run on the caller's stream meanwhile.)
  * (Measured and dropped: the attempts as an executable hipGraph of 16 x (parity 0, parity 1) -- 160 kernel nodes per launch call: the
  * same engine time, and 206 - 246 ms of host CPU per 4096x4096 frame against 79 - 94 ms for the plain launches.) */
+/* The engine's streams are kept for the life of the PROCESS (a free list per device): a context takes its streams from the list and gives them back when it is
+ * destroyed.  Measured (round 5, tools/gpu_r5_benchlegs.sh): streams are mapped onto the process's few hardware queues when they are created; a context that
+ * created fresh streams after an earlier context's three had been destroyed got two streams on ONE queue -- its two launch groups then ran one behind the other
+ * (the reference's suite as one batch: 49 -> 40 Mpx/s in every bench.py run, depending on which leg came before).  Streams that are never destroyed keep their queues. */
+struct SegStreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;       /* (device, stream) */
+    hipError_t take(int device, int prio, hipStream_t *out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == device) { *out = idle[i].second; idle.erase(idle.begin() + (long)i); return hipSuccess; }
+        }
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+    }
+    void give(int device, hipStream_t s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.insert(idle.begin(), std::make_pair(device, s));      /* (first in: the next context takes them in the order this one had them) */
+    }
+};
+SegStreamPool &seg_stream_pool() { static SegStreamPool *p = new SegStreamPool; return *p; }      /* (never destroyed: contexts may outlive static destruction order) */
+
 struct SegGroups { PlSegBatch b[SEG_MAX_GROUPS]; int n = 1; };
 void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
 {
@@ -222,7 +246,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         int least = 0, greatest = 0;
         PL_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         ctx->seg_prio = greatest;
-        PL_CHECK(hipStreamCreateWithPriority(&ctx->seg_stream, hipStreamNonBlocking, greatest));
+        PL_CHECK(seg_stream_pool().take(ctx->device, greatest, &ctx->seg_stream));
         ctx->seg_prio_distinct = greatest != least;
         ctx->seg_gstream[0] = ctx->seg_stream;
     }
@@ -240,14 +264,16 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
          *  behind its wait for the finished word (without that wait four run, six collapse: profiles/r05_validation_in_enum.txt).  THREE looked 6 % faster in a
          *  process that does nothing else -- and halved every later engine run of bench.py's process, single images included (suite batch 45 -> 14 Mpx/s, 8192 x 8192
          *  137 -> 71): the hardware queues a third engine stream brings into the process's pool stay there, and from then on an engine stream shares one with a
-         *  waiting stream.  Two it is: a caller with streams of its own must still fit.) */
-        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = 2;
+         *  waiting stream.  Two it is for the asynchronous entry: a caller with streams of its own must still fit.  The SYNCHRONOUS entry point puts no wait on
+         *  any stream (run_seg_engine below): there three groups are safe -- bench.py's process, every leg after a three-group batch at full speed -- and worth
+         *  6 % at 32 frames, 3 % at 64.) */
+        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = (ctx->sync_call && n >= 12) ? 3 : 2;   /* (three only where no stream of this call holds a wait: the synchronous entry point -- see above) */
         else if (n >= 2) ngroups = 2;                              /* (a small batch: see the shares below) */
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
         ngroups = (int)std::min<size_t>((size_t)ngroups, n);
     }
     for (int g = 1; g < ngroups; g++) {
-        if (!ctx->seg_gstream[g]) PL_CHECK(hipStreamCreateWithPriority(&ctx->seg_gstream[g], hipStreamNonBlocking, ctx->seg_prio));
+        if (!ctx->seg_gstream[g]) PL_CHECK(seg_stream_pool().take(ctx->device, ctx->seg_prio, &ctx->seg_gstream[g]));
         if (!ctx->ev_seg_gdone[g]) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_seg_gdone[g], hipEventDisableTiming));
     }
     ctx->seg_groups = ngroups;
@@ -792,7 +818,7 @@ void pngloss_hip_destroy(pngloss_hip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->seg_worker.joinable()) ctx->seg_worker.join();
     if (ctx->pending) (void)hipEventSynchronize(ctx->ev[3]);
-    for (int g = 0; g < SEG_MAX_GROUPS; g++) if (ctx->seg_gstream[g]) { (void)hipStreamSynchronize(ctx->seg_gstream[g]); (void)hipStreamDestroy(ctx->seg_gstream[g]); }
+    for (int g = SEG_MAX_GROUPS - 1; g >= 0; g--) if (ctx->seg_gstream[g]) { (void)hipStreamSynchronize(ctx->seg_gstream[g]); seg_stream_pool().give(ctx->device, ctx->seg_gstream[g]); }   /* (back to the process's list, [0] first) */
     for (int g = 1; g < SEG_MAX_GROUPS; g++) if (ctx->ev_seg_gdone[g]) (void)hipEventDestroy(ctx->ev_seg_gdone[g]);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_seg_done) (void)hipEventDestroy(ctx->ev_seg_done);
