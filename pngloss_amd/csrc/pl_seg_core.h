@@ -825,9 +825,10 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 + SEG_GRP * SEG_PARTS * 4 * 8 + SEG_GRP * SEG_L * 16 + (SEG_GRP * SEG_L + 3) * 4 + 64)
-#define SEG_SM_POST ((768 + (2 * SEG_VGRP + 1) * 256 + (SEG_VGRP * SEG_L + 2) * 4 + 64 + 512 + 3 * (SEG_VGRP * SEG_L + 2) + 2 * SEG_VGRP * SEG_L + 768 + 32 + 64 + SEG_VGRP * SEG_L + SEG_VGRP * (SEG_L + 1) + 8 * (SEG_VGRP * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands) */
+#define SEG_SM_POST ((768 + (SEG_VGRP + 1) * 256 + (SEG_VGRP * SEG_L + 2) * 4 + 64 + 512 + 2 * (SEG_VGRP * SEG_L + 2) + 2 * SEG_VGRP * SEG_L + 32 + 64 + SEG_VGRP * SEG_L + SEG_VGRP * (SEG_L + 1) + 8 * (SEG_VGRP * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands): 36.9 KB (round 5: 49 KB before -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
 #define SEG_SM_CTLVAL (SEG_SM_CTL > SEG_SM_POST ? SEG_SM_CTL : SEG_SM_POST)   /* the first launch of an attempt carries control and validation workgroups */
-#define SEG_SM_CTL (256 * 4 * 4 + (SEG_TBL_WORDS + 5 * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 4 + (SEG_NFILT + 1) * 256 + 1024) * 4 + 64)   /* (a candidate's tables / a commit workgroup's five tiles, generously) */
+#define SEG_SM_CTL ((8 + 512 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 56 + SEG_NFILT * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 4 + (SEG_NFILT + 1) * 256 + 16) * 4)   /* what a commit workgroup carves out (seg_ctl_commit: split table, control block + sums, decision, five tiles, err1 of both parities, spec): 33.8 KB; a candidate workgroup needs 4 x 256 + SEG_TBL_WORDS words */
+static_assert((1024 + SEG_TBL_WORDS) * 4 <= SEG_SM_CTL, "a candidate workgroup of the control kernel (histograms + table staging) fits the commit workgroups' request");
 
 /* run `n` steps of filter f from pixel record px[0] (stride pstride records per pixel); returns bad > 0 when the lane left the tables */
 template <int F, bool TRX>
@@ -2644,20 +2645,20 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
     const uint32_t grp = seg0 / SEG_GRP, segp = grp * SEG_GRP;  /* the replay group it lies in, and that group's first segment */
     constexpr int NPX = SEG_VGRP * SEG_L;                       /* pixels of a group */
     uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256;
-    uint32_t *cum = H0 + 768;                                  /* [(2 * SEG_VGRP + 1)][256]: bumps in front of each segment of the group */
-    uint32_t *cw = cum + (2 * SEG_VGRP + 1) * 256;             /* (rows SEG_VGRP+1 ..: the bumps of the replay group's segments in front of this half) */                  /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
+    uint32_t *cum = H0 + 768;                                  /* [SEG_VGRP + 1][256]: bumps in front of each segment of the group (staging: row sl + 1 = the bumps OF segment sl) */
+    uint32_t *cw = cum + (SEG_VGRP + 1) * 256;                 /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
     uint32_t *red = cw + (NPX + 2) * 4;                        /* reductions: derr lo/hi, cost, hs[5], fail, lb lo/hi */
     uint32_t *lut = red + 64;                                  /* [512] split table */
     uint32_t *ro = lut + 512;                                  /* [NPX + 1] original row, from pixel xg0 - 1 */
     uint32_t *na = ro + NPX + 2;                               /* [NPX + 1] optimised row above */
-    uint32_t *oa = na + NPX + 2;                               /* [NPX + 1] original row above */
-    uint32_t *e0 = oa + NPX + 2;                               /* [NPX][2] incoming error */
-    uint32_t *rm = e0 + 2 * NPX;                               /* [768] none's bound: largest H0 within reach of a centre value (centre + 256) */
-    uint32_t *wbits = rm + 768;                                /* [8] bitmap of watched bins, [8] pending decisions / slots in use, [9..] bin of each slot */
+    uint32_t *e0 = na + NPX + 2;                               /* [NPX][2] incoming error */
+    uint32_t *wbits = e0 + 2 * NPX;                            /* [8] bitmap of watched bins, [8] pending decisions / slots in use, [9..] bin of each slot */
     uint8_t *slot_of = (uint8_t *)(wbits + 32);                /* [256] slot of a watched bin or 255 */
     uint8_t *pend = slot_of + 256;                             /* [NPX * 4] decision waits for pass 3 */
     uint8_t *binb = pend + NPX * 4;                            /* [SEG_VGRP][SEG_BINB_STRIDE] bin of every decision */
     uint32_t *pcw = (uint32_t *)(binb + SEG_VGRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][SEG_PC_STRIDE] prefix counts of the watched bins */
+    uint32_t *cumx = pcw;                                      /* [SEG_VGRP][256] (staging only, before pcw is written: barriers lie between) the bumps of the replay group's segments in front of this half */
+    static_assert(SEG_WATCH * SEG_PC_STRIDE >= SEG_VGRP * 256, "the staged counts of the segments in front fit where the prefix counts go later");
     uint32_t *btop = pcw + SEG_WATCH * SEG_PC_STRIDE;          /* [2][SEG_NBAND][4] */
     uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
     const uint32_t y = cv.y;
@@ -2711,7 +2712,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
         if (tid <= NPX) { ro[tid] = vro; na[tid] = vna; }
         if (tid >= 512 && tid - 512 < NPX) { e0[2 * (tid - 512)] = ve0a; e0[2 * (tid - 512) + 1] = ve0b; }
         {
-            uint32_t *dst = cum + (sl + 1) * 256 + 4 * q4;
+            uint32_t *dst = (sl < SEG_VGRP ? cum + (sl + 1) * 256 : cumx + (sl - SEG_VGRP) * 256) + 4 * q4;
             dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
         }
     }
@@ -2735,7 +2736,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
             }
             uint32_t add[2 * SEG_VGRP];                                /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
             PLS_UNROLL
-            for (int r = 1; r <= 2 * SEG_VGRP; r++) add[r - 1] = cum[r * 256 + b];
+            for (int r = 1; r <= 2 * SEG_VGRP; r++) add[r - 1] = r <= SEG_VGRP ? cum[r * 256 + b] : cumx[(r - SEG_VGRP - 1) * 256 + b];
             PLS_UNROLL
             for (int r = SEG_VGRP + 1; r <= 2 * SEG_VGRP; r++) before += add[r - 1];
             uint32_t run = before;
