@@ -420,6 +420,38 @@ def test_segment_engine_batch_of_mixed_images(torch_cuda, monkeypatch):
     ctx.close()
 
 
+def test_synchronous_and_asynchronous_entry_points_agree(torch_cuda, monkeypatch):
+    """pngloss_hip_optimize_batch (no device-side wait on the caller's stream, three launch groups for a batch in units) against pngloss_hip_optimize_batch_async +
+    pngloss_hip_finish (stream wait, two groups) on the same inputs: a batch of 14 frames of 1920 x 40 (units: > 680 segments), a mixed small batch and a single
+    image, on a side stream with work enqueued behind the call; both against the oracle; contexts created and destroyed in between (the engine's streams are
+    taken from and returned to the process-wide list)."""
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    st = torch.cuda.Stream()
+    for specs in ([(1920, 40, 0)] * 14, [(300, 40, 0), (200, 90, 1), (64, 48, 4)], [(1536, 24, 5)]):
+        imgs = [P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate(specs)]
+        want = [U.run_port(a, 19, 2) for a in imgs]
+        for mode in ("sync", "async", "sync"):
+            ctx = P.HipContext()
+            dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+            filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") for a in imgs]
+            torch.cuda.synchronize()
+            desc = [(d.data_ptr(), f.data_ptr(), a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)]
+            with torch.cuda.stream(st):
+                if mode == "sync":
+                    res = ctx.run(desc, 19, 2, stream=st.cuda_stream)
+                else:
+                    ctx.enqueue(desc, 19, 2, stream=st.cuda_stream)
+                copies = [d.clone() for d in dev]              # enqueued behind the call on the same stream: must see the optimised pixels
+                if mode == "async":
+                    res = ctx.finish()
+            st.synchronize()
+            for i, (d, f, c, r) in enumerate(zip(dev, filt, copies, res)):
+                assert r["status"] == 0 and np.array_equal(d.cpu().numpy(), want[i][0]) and np.array_equal(f.cpu().numpy(), want[i][1]), (mode, i)
+                assert np.array_equal(c.cpu().numpy(), want[i][0]), ("work behind the call ran ahead of the engine", mode, i)
+            ctx.close()
+
+
 @pytest.mark.parametrize("groups", [None, "1", "2"])
 def test_segment_engine_launch_groups_of_small_and_mixed_batches(torch_cuda, monkeypatch, groups):
     """Round 5: a batch of two or more images runs as TWO launch sequences on two streams (pl_host.hip:run_seg_engine) -- the tallest image alone when it stands
