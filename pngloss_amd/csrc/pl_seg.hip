@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
 
 /* enumeration in UNITS (batches; SegParams::unit = SEG_UNIT): first the filters that look at the left pixel (their workgroups are the long ones: `perb`
  * workgroups of SEG_UNC (unit, channel) pairs per candidate), then none / up -- with their small state set (when it exists) segment by segment, `pers`
- * workgroups of 24 (segment, channel) pairs --, and the five walkers of an epoch's first unit */
+ * workgroups of SEG_UNC_SMALL (unit, channel) pairs --, and the five walkers of an epoch's first unit */
 template <int UNIT>
 __global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers)
 {

@@ -157,7 +157,7 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_UNT
 #define SEG_UNT 512              /* its threads (512 against 1024, 1080p frames: 157.7 against 161.4 ms at 32, 249.2 against 281.4 at 64, 460.6 against 511.3 at 128: the CU starts four workgroups at once instead of two) */
 #endif
-#define SEG_UPOOL 1024           /* ... and the most distinct states its pairs may have between them (one lane each) */
+#define SEG_UPOOL SEG_UNT        /* ... and the most distinct states its pairs may have between them: one LANE each (round 5: it said 1024 for 512-thread workgroups -- states beyond the lanes had no one to walk them) */
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
 #define SEG_VGRP 8                /* segments per VALIDATION workgroup (half a replay group: one decision per thread, twice the CUs) */
 #define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
@@ -1333,15 +1333,20 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCt
  *     pairs as its 1024 lanes hold states for -- and then packs the distinct states of ALL its pairs into its first lanes: ~200 lanes = four
  *     waves that share one copy of the candidate's tables (12.8 KB) instead of one or two half-empty waves per 35 KB workgroup;
  *   - none / up (LANES = 32: their state is (cn, th)) go through the same body, dedupe included: ~3 distinct states per pair instead of 17 lanes,
- *     24 pairs a workgroup.
+ *     twenty pairs a workgroup.
  * The chain kernel composes UNITS (seg_chain_body reads SegParams::unit); replay and validation do not know the difference. */
+#ifndef SEG_UNC_SMALL
 #define SEG_UNC_SMALL (SEG_UNIT <= 3 ? 20 : (SEG_UNIT <= 4 ? 15 : (SEG_UNIT <= 6 ? 10 : 7)))          /* (unit, channel) pairs per workgroup for none / up with their small state set */
+#endif
 #define SEG_UNPX (SEG_UNC_SMALL * (SEG_UNIT * SEG_L + 1))   /* pixel records of a workgroup's pairs */
 /* LDS of the unit enumeration: tables, split table, the pool, the first records of every pair, bookkeeping -- and ONE region that holds the first phase's
- * scratch (hash tables, per-turn lists, keys: 20 KB) and then, for the second phase, the pairs' full pixel records: 40 KB = four workgroups per CU (the
- * first version carved both side by side: 52 KB, three per CU, and the CUs' slots, not their issue, set the kernel's time) */
+ * scratch (hash tables, per-turn lists, keys: 10 KB) and then, for the second phase, the pairs' full pixel records (15.5 KB for the twenty pairs of none / up):
+ * 35.8 KB = four workgroups per CU.  (The first version carved both side by side: 52 KB, three per CU, and the CUs' slots, not their issue, set the kernel's
+ * time; the second was sized for 1024 threads: 39.9 KB.  Sixteen / twelve pairs of none / up = 32.5 / 28.6 KB = FIVE per CU were measured: 464 / 451 Mpx/s
+ * for 32 frames against 465 -- the slots are not what it is short of; the 4 KB less are worth 1.3 %, though: the other launch groups' control, validation and
+ * replay workgroups want 37 - 50 KB next to two or three of these.) */
 #define SEG_UN_K1MAX 4
-#define SEG_UN_SCRATCH (2048 * 4 + 2048 * 2 + 1024 * 4 + SEG_UNT * 4)
+#define SEG_UN_SCRATCH (2 * SEG_UNT * 4 + 2 * SEG_UNT * 2 + SEG_UNT * 4 + SEG_UNT * 4)        /* hash tables (a turn's pairs x twice their lanes), dense ids, the turn's lists, one key a thread */
 #define SEG_UN_PHASE2 (SEG_UNPX * 8 + SEG_UPOOL * 4)      /* the pairs' records and the second list of distinct states (behind the unit's first segment) */
 #define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UPOOL * 4 + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1) * 8 + 512 + (SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2))
 /* set bits among bits [a, b) of a bit array */
@@ -1364,7 +1369,7 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     constexpr int CPR = NT / LANES < NC ? NT / LANES : NC;      /* pairs per turn of the first phase */
     constexpr int ROUNDS = (NC + CPR - 1) / CPR;
     constexpr uint32_t E = UNIT, UL = E * SEG_L, NPX = UL + 1;
-    static_assert(CPR * HT <= 2048 && CPR * LANES <= 1024 && NC <= 24 && NC * (UNIT * SEG_L + 1) <= SEG_UNPX, "hash tables, per-turn lists, pixel records and the bookkeeping words are sized for this");
+    static_assert(CPR * HT <= 2 * SEG_UNT && CPR * LANES <= SEG_UNT && NC <= 24 && NC * (UNIT * SEG_L + 1) <= SEG_UNPX, "hash tables, per-turn lists, pixel records and the bookkeeping words are sized for this");
     const uint32_t W = j.W, bpp = j.bpp, nseg = j.nseg, nunit = (nseg + E - 1) / E, ncombo = nunit * bpp;
     const uint32_t q0 = (uint32_t)grp * NC;
     if (q0 >= ncombo) return;
@@ -1380,9 +1385,9 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
                                                                  [64 + k] the same for the SECOND list (.. [64 + NC] = its total), [96 .. 127] one bit per lane: it represents a state of the second list */
     /* first phase: */
     uint32_t *ht = misc + 128;                                /* [CPR][HT] key or ~0 (this turn) */
-    uint16_t *dense = (uint16_t *)(ht + 2048);                /* [CPR][HT] slot -> dense id */
-    uint32_t *uniqr = (uint32_t *)(dense + 2048);             /* [CPR][LANES] this turn's distinct states by dense id */
-    uint32_t *keys = uniqr + 1024;                            /* [NT] */
+    uint16_t *dense = (uint16_t *)(ht + 2 * SEG_UNT);         /* [CPR][HT] slot -> dense id */
+    uint32_t *uniqr = (uint32_t *)(dense + 2 * SEG_UNT);      /* [CPR][LANES] this turn's distinct states by dense id */
+    uint32_t *keys = uniqr + SEG_UNT;                         /* [NT] */
     /* second phase, in the same place: */
     SegPix *px = (SegPix *)(misc + 128);                      /* [NC][NPX]: all records of a pair */
     uint32_t *pool2 = (uint32_t *)(px + SEG_UNPX);            /* [SEG_UPOOL] the states that are still distinct behind the unit's first segment, at the pairs' places of the first list */
