@@ -74,6 +74,8 @@ struct pngloss_hip_ctx {
     hipStream_t seg_gstream[SEG_MAX_GROUPS] = {};   /* [0] = seg_stream: one stream per GROUP of a batch's images (run_seg_engine) */
     hipEvent_t ev_seg_gdone[SEG_MAX_GROUPS] = {};
     int seg_groups = 1;
+    bool three_groups_ok = false;    /* ... and it is the device-resident synchronous entry point itself: a batch may run as three launch groups (the host-pointer entry points, which the
+                                        multi-device wrapper calls from a thread per context, stay at two: several contexts of one process share its hardware queues) */
     bool sync_call = false;          /* the batch under way was started by a SYNCHRONOUS entry point (pngloss_hip_optimize_batch): the caller waits on the host anyway, so the
                                         caller's stream gets no device-side wait for the engine's finished word (run_seg_engine) */
     hipEvent_t ev_prep = nullptr;    /* caller's stream: everything the engine reads is in place */
@@ -267,7 +269,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
          *  waiting stream.  Two it is for the asynchronous entry: a caller with streams of its own must still fit.  The SYNCHRONOUS entry point puts no wait on
          *  any stream (run_seg_engine below): there three groups are safe -- bench.py's process, every leg after a three-group batch at full speed -- and worth
          *  6 % at 32 frames, 3 % at 64.) */
-        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = (ctx->sync_call && n >= 12) ? 3 : 2;   /* (three only where no stream of this call holds a wait: the synchronous entry point -- see above) */
+        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = (ctx->sync_call && ctx->three_groups_ok && n >= 12) ? 3 : 2;   /* (three only where no stream of this call holds a wait: the synchronous entry point -- see above) */
         else if (n >= 2) ngroups = 2;                              /* (a small batch: see the shares below) */
         if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
         ngroups = (int)std::min<size_t>((size_t)ngroups, n);
@@ -738,7 +740,9 @@ int run_host_image(unsigned char **rows, uint32_t width, uint32_t height, uint32
             ctx->h_progress = nullptr;                     /* no display then; not an error */
         if (ctx->h_progress) *ctx->h_progress = 0;
         ctx->want_progress = verbose && ctx->h_progress;
+        ctx->sync_call = !ctx->want_progress;            /* (the progress display polls while the engine runs: it needs the call back at once; else the host waits anyway) */
         rc = enqueue(ctx, &desc, 1, forced_bpp ? &forced_bpp : nullptr, strength, bleed, nullptr);
+        ctx->sync_call = false;
         ctx->want_progress = false;
         if (rc) break;
         if (verbose && ctx->h_progress) {
@@ -849,9 +853,9 @@ int pngloss_hip_optimize_batch(pngloss_hip_ctx *ctx, const pngloss_hip_image_des
                                pngloss_hip_result *results)
 {
     if (!ctx) return PNGLOSS_INVALID_ARGUMENT;
-    ctx->sync_call = true;
+    ctx->sync_call = true; ctx->three_groups_ok = true;
     int rc = enqueue(ctx, images, n, nullptr, quantization_strength, bleed_divider, static_cast<hipStream_t>(stream));
-    ctx->sync_call = false;
+    ctx->sync_call = false; ctx->three_groups_ok = false;
     if (rc) return rc;
     return finish(ctx, results, n);
 }
@@ -942,7 +946,11 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
     ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
     std::vector<pngloss_hip_result> own_results;
     if (!results) { own_results.resize(n ? n : 1); results = own_results.data(); }
-    if (rc == PNGLOSS_SUCCESS) rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, ctx->copy_stream, emits.data());
+    if (rc == PNGLOSS_SUCCESS) {
+        ctx->sync_call = true;                  /* (finish follows at once: no device-side wait on the copy stream, run_seg_engine) */
+        rc = enqueue(ctx, descs.data(), n, nullptr, quantization_strength, bleed_divider, ctx->copy_stream, emits.data());
+        ctx->sync_call = false;
+    }
     if (rc == PNGLOSS_SUCCESS) rc = finish(ctx, results, n);
     /* a row without an acceptable filter (device status 65, pngloss_image.c:268-271) fails THAT image only: the others of
      * the batch are downloaded and the call reports PNGLOSS_INTERNAL_ABORT with the per-image status in results[] */
