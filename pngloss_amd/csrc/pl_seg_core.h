@@ -2679,6 +2679,25 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
         constexpr int NCW = ((NPX + 2) * 4 + SEG_THREADS - 1) / SEG_THREADS;
         uint32_t vh0 = 0, vrank = 0, vlut = 0, vcw[NCW], vro = 0, vna = 0, vgl = 0, ve0a = 0, ve0b = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (tid < 256) { vh0 = j.H0[par * 256 + tid]; vrank = j.orig_rank[f * 256 + tid]; }
+        /* (round 5) the bumps in front of the group -- validated prefix + the whole replay groups in front -- requested in THIS burst (they need nothing that is staged
+         * here): the prefix pass below had a round trip to device memory of its own for them */
+        uint32_t vbefore = 0;
+        if (tid < 256) {
+            const int b = tid;
+            vbefore = j.base[((size_t)par * SEG_NFILT + f) * 256 + b];
+            uint32_t gv[SEG_NG_BURST];
+            PLS_UNROLL
+            for (int g = 0; g < SEG_NG_BURST; g++) gv[g] = ((uint32_t)g < grp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;   /* (grp < ngrp) */
+            PLS_UNROLL
+            for (int g = 0; g < SEG_NG_BURST; g++) {
+                const bool in = (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
+                vbefore += (in && (uint32_t)g < grp) ? gv[g] : 0u;
+            }
+            for (uint32_t g = SEG_NG_BURST; g < grp && g < ngrp; g++) {           /* (rows beyond 8192 pixels) */
+                const uint32_t v = j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
+                vbefore += g >= fgrp ? v : 0u;
+            }
+        }
         if (tid >= 256 && tid < 768) vlut = P.lut_a[tid - 256];
         PLS_UNROLL
         for (int q = 0; q < NCW; q++) {
@@ -2709,7 +2728,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
                 c0 = sc[0]; c1 = sc[1]; c2 = sc[2]; c3 = sc[3];
             }
         }
-        if (tid < 256) { H0[tid] = vh0; rank[tid] = vrank; }
+        if (tid < 256) { H0[tid] = vh0; rank[tid] = vrank; hiG[tid] = vbefore; }      /* (hiG: parked until the prefix pass has read it; the bounds are written behind that) */
         if (tid < 16) red[tid] = tid == 8 ? SEG_NOFAIL : (tid == 9 ? vgl : 0u);
         if (tid >= 256 && tid < 768) lut[tid - 256] = vlut;
         PLS_UNROLL
@@ -2725,20 +2744,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < 256) {
             const int b = tid;
-            /* (all groups requested at once, the ones that do not count masked out: a loop with the load inside waits for every one) */
-            uint32_t before = j.base[((size_t)par * SEG_NFILT + f) * 256 + b];
-            uint32_t gv[SEG_NG_BURST];
-            PLS_UNROLL
-            for (int g = 0; g < SEG_NG_BURST; g++) gv[g] = ((uint32_t)g < grp) ? j.grpcnt[((size_t)f * ngrp + g) * 256 + b] : 0u;   /* (grp < ngrp) */
-            PLS_UNROLL
-            for (int g = 0; g < SEG_NG_BURST; g++) {
-                const bool in = (uint32_t)g >= fgrp && (uint32_t)g < ngrp;
-                before += (in && (uint32_t)g < grp) ? gv[g] : 0u;
-            }
-            for (uint32_t g = SEG_NG_BURST; g < grp && g < ngrp; g++) {           /* (rows beyond 8192 pixels) */
-                const uint32_t v = j.grpcnt[((size_t)f * ngrp + g) * 256 + b];
-                before += g >= fgrp ? v : 0u;
-            }
+            uint32_t before = hiG[b];                                  /* (base + the replay groups in front: summed by the staging burst) */
             uint32_t add[2 * SEG_VGRP];                                /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
             PLS_UNROLL
             for (int r = 1; r <= 2 * SEG_VGRP; r++) add[r - 1] = r <= SEG_VGRP ? cum[r * 256 + b] : cumx[(r - SEG_VGRP - 1) * 256 + b];
