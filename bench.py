@@ -329,10 +329,13 @@ def run_sweep_8192(P, torch, ctx_factory, golden):
     del base
     torch.cuda.empty_cache()
     return {"workload": "BASELINE.json configs[4]: one 8192x8192 synthetic RGBA8 frame, strength {0,20,40,85} x bleed {1,2,8}, one GPU, point after point",
-            "unit": "Mpixels/s", "points": pts, "min_value": min(p["value"] for p in pts), "all_on_segment_engine": all(p["engine"] == "segment-parallel" for p in pts),
+            "unit": "Mpixels/s", "points": pts, "min_value": min(p["value"] for p in pts), "all_on_segment_engine": all(p["engine"] == "segment-parallel" for p in pts if p["strength"] != 0),
+            "strength_0_engine": sorted({p["engine"] for p in pts if p["strength"] == 0}),
             "all_digests_match_reference": all(p["digests_match_reference"] for p in pts),
             "note": "roofline_frac = 8 B/px * 67.1 Mpx / engine time / 8 TB/s: like the headline, bound by the row-to-row dependency, not by HBM; "
-                    "strengths whose chain-state set exceeds 1024 (85 at bleed 1 and 2, 40 at bleed 1) run the seeded enumeration (DESIGN.md section 4)"}
+                    "strengths whose chain-state set exceeds 1024 (85 at bleed 1 and 2, 40 at bleed 1) run the seeded enumeration (DESIGN.md section 4); "
+                    "strength 0 quantises nothing: its points run the row-statistics engine (pl_rows.hip: one parallel pass for every row's residual counts, one serial pass of "
+                    "decisions; the image is read twice: roofline_frac there is the fraction of HBM peak that 8 B/px would be)"}
 
 
 def run_suite_batch(P, torch, ctx_factory, golden):

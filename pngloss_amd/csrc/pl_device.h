@@ -17,6 +17,7 @@
 
 #define PL_NFILT 5
 #define PL_NSYM 256
+#define PL_ROWSTAT_WORDS (PL_NFILT * PL_NSYM + 8)
 #define PL_ENGINE_THREADS 512   /* 8 waves: five run the candidate chains, all eight the row passes (two waves per SIMD keep 256 VGPRs each) */
 
 /* class flag bits produced by the classify kernel */
@@ -45,7 +46,8 @@ struct PlJob {
     uint32_t emit_pitch;  /* bytes between emitted rows (multiple of 16, >= width*4)                                     */
     uint32_t emit_adaptive_all; /* 1: every row takes libpng's heuristic filter (row_filters == NULL mode), 0: only row 0 */
     uint32_t *progress;   /* null, or a host-visible word that receives the number of finished rows (the -v progress display) */
-    int32_t *result;      /* [64]: [0] status, [1] bpp, [2] unique symbols, [3] retried rows; [20] engine (0 workgroup per image, 3 segment-parallel).
+    uint32_t *rowstat;    /* null, or (strength 0: pl_rows.hip) [height][PL_ROWSTAT_WORDS]: per row the residual counts [5][256] of the five filters and libpng's heuristic sums [5] */
+    int32_t *result;      /* [64]: [0] status, [1] bpp, [2] unique symbols, [3] retried rows; [20] engine (0 workgroup per image, 3 segment-parallel, 4 row statistics = strength 0).
                              Workgroup engine: [4] pixels redone exactly (chain wave 0 = 'up' on band-leader rows), [5] row attempts on the band-leader
                              chains, [6] band rescans, [7] SIMD map, [8..15] chain kilo-cycles / repaired pixels per chain wave, [16..20] light pixels
                              per chain wave (or PL_SEGPROF stamps [16..31]), [21] rows on the round-1 chains by the adaptive choice, [22..23] last
@@ -157,6 +159,7 @@ struct PlEngineParams {
 hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 hipError_t pl_launch_engine(const PlJob *d_jobs, const uint32_t *d_sel, size_t n, PlEngineParams prm, hipStream_t stream);   /* d_sel: n job indices, or null = jobs 0..n-1 */
 int pl_engine_occupancy(void);   /* workgroups of the row engine per CU according to the HIP occupancy query */
+hipError_t pl_launch_rows(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);      /* the row engine of strength 0 (pl_rows.hip) */
 hipError_t pl_launch_finish(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 hipError_t pl_launch_emit(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
 

@@ -98,11 +98,11 @@ namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-    size_t jobs, flags, orig_hist, orig_rank, cand, err0, err1, old_above, final_hist, result, row_ids, out_flags, total;
+    size_t jobs, flags, orig_hist, orig_rank, cand, err0, err1, old_above, final_hist, result, row_ids, out_flags, rowstat, total;
 };
 
 /* per-image workspace: everything the engine keeps outside the image itself */
-WsLayout image_ws(uint32_t width, uint32_t height)
+WsLayout image_ws(uint32_t width, uint32_t height, bool rows_engine = false)
 {
     WsLayout l{};
     size_t o = 0;
@@ -118,6 +118,7 @@ WsLayout image_ws(uint32_t width, uint32_t height)
     l.result = take(sizeof(int32_t) * 64);
     l.row_ids = take(height ? height : 1);
     l.out_flags = take(sizeof(uint32_t));
+    l.rowstat = rows_engine ? take(sizeof(uint32_t) * PL_ROWSTAT_WORDS * (size_t)(height ? height : 1)) : 0;     /* (strength 0: pl_rows.hip) */
     l.total = o;
     return l;
 }
@@ -410,12 +411,20 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     ctx->n_last = 0;
     ctx->split_last = false;                                         /* (only a split host window sets it again: batch_host) */
     /* drop empty images (the reference's loops simply do nothing for them) */
+    /* STRENGTH 0 has a row engine of its own (pl_rows.hip: nothing is quantised, the five candidate rows are the original row, what is left is the filter search):
+     * every image of the batch, unless a test pins another engine.  "rows" pins it (a no-op at other strengths). */
+    bool use_rows = false;
+    {
+        const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();
+        const bool free_choice = !em || std::strcmp(em, "auto") == 0 || std::strcmp(em, "rows") == 0;
+        use_rows = strength == 0 && free_choice && !std::getenv("PNGLOSS_HIP_FORCE_FILTER") && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL");
+    }
     std::vector<size_t> offs;
     size_t total = align_up(sizeof(PlJob) * (n ? n : 1), 256);
     for (size_t i = 0; i < n; i++) {
         if (!images[i].d_rgba && images[i].width && images[i].height) return PNGLOSS_INVALID_ARGUMENT;
         offs.push_back(total);
-        total += image_ws(images[i].width ? images[i].width : 1, images[i].height).total;
+        total += image_ws(images[i].width ? images[i].width : 1, images[i].height, use_rows).total;
     }
     /* Which row engine, IMAGE BY IMAGE: one workgroup for the image (pl_engine: batches, narrow images) or the image spread over the
      * whole GPU (pl_seg: few wide images).  The segment engine takes every strength / bleed pair and rows up to SEG_MAX_WIDTH pixels;
@@ -435,7 +444,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();   /* (the option of the ABI first; the environment variable is the tests' hook) */
         const bool forced = em && std::strcmp(em, "seg") == 0;
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
-        bool seg_ok = n && allowed && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
+        bool seg_ok = n && allowed && !use_rows && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
             const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
             /* round 5: a batch whose images have more than SEG_UNIT_MIN_SEGS segments between them is enumerated in UNITS, in two launch groups, with the
@@ -504,9 +513,10 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     int rc = ensure_ws(ctx, total);
     if (rc) return rc;
     for (size_t i = 0; i < n; i++) {
-        const WsLayout l = image_ws(images[i].width ? images[i].width : 1, images[i].height);
+        const WsLayout l = image_ws(images[i].width ? images[i].width : 1, images[i].height, use_rows);
         char *b = ctx->d_ws + offs[i];
         PlJob j{};
+        j.rowstat = use_rows ? reinterpret_cast<uint32_t *>(b + l.rowstat) : nullptr;
         j.img = static_cast<uint32_t *>(images[i].d_rgba);
         j.row_filters = static_cast<uint8_t *>(images[i].d_row_filters);
         j.width = images[i].width;
@@ -554,7 +564,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
     PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));
-    ctx->last_engine = use_seg ? 3 : 0;
+    ctx->last_engine = use_seg ? 3 : (use_rows ? 4 : 0);
     PL_CHECK(hipEventRecord(ctx->ev[1], stream));
     /* the images of the one-workgroup-per-image engine: all of them, or -- a mixed batch -- those the segment engine did not get; they
      * run on the caller's stream while the segment engine works on its own */
@@ -570,7 +580,8 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         if (const char *k = std::getenv("PNGLOSS_HIP_KIN")) { const int v = std::atoi(k); if (seg_params.seeded && v >= 0 && v <= SEG_KIN) seg_params.kin = v; }   /* experiment: run-in pixels of the seeded enumeration */
         rc = run_seg_engine(ctx, d_jobs, seg_list, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream, d_sel, wg_list.size(), prm);
         if (rc) return rc;
-    } else PL_CHECK(pl_launch_engine(d_jobs, nullptr, n, prm, stream));
+    } else if (use_rows) PL_CHECK(pl_launch_rows(d_jobs, ctx->h_jobs.data(), n, stream));
+    else PL_CHECK(pl_launch_engine(d_jobs, nullptr, n, prm, stream));
     PL_CHECK(hipEventRecord(ctx->ev[2], stream));
     {
         /* (behind this point the segment engine's launch thread may be running: it is joined before an error is returned) */
@@ -1472,6 +1483,7 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
     PL_CHECK(hipMemcpy(r, ctx->h_jobs[index].result, sizeof r, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) info[i] = 0;
     if (r[20] == 3) { info[0] = 3; info[1] = r[5]; info[2] = r[4]; info[3] = r[6]; info[4] = r[7]; info[5] = r[17]; }
+    else if (r[20] == 4) { info[0] = 4; info[1] = r[5]; }
     else { info[0] = 0; info[1] = r[5]; info[2] = r[4]; info[3] = r[21]; }
     return PNGLOSS_SUCCESS;
 }

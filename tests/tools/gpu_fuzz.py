@@ -1,7 +1,7 @@
 """Randomised parity campaign on the GPU box: HIP path (C ABI) vs the CPU oracle over random shapes, contents, strengths
 and bleed dividers, both row_filters modes, plus the device batch API with mixed images.
 usage: gpu_fuzz.py [seconds] [seed] [big]     (big: shapes up to 1500 x 120, so that histogram counts and error rows grow)
-FUZZ_ENGINES=seg,mix,  pins the row engine case by case (segment-parallel, alternating chain kinds, the library's choice)"""
+FUZZ_ENGINES=seg,mix,  pins the row engine case by case (segment-parallel, alternating chain kinds, the library's choice); FUZZ_STRENGTH=s pins the strength"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -46,6 +46,7 @@ def make(rng):
     elif cls == 4: img[..., 3] = np.where(rng.random((h, w)) < 0.4, 0, img[..., 3])
     s = int(rng.choice([0, 1, 2, 5, 7, 8, 15, 16, 19, 20, 23, 24, 31, 32, 40, 47, 48, 63, 64, 85, 100, 127, 200, 255, int(rng.integers(0, 256))]))
     b = int(rng.choice([1, 2, 3, 4, 8, 16, 100, 1000, 32767, int(rng.integers(1, 32768))]))
+    if os.environ.get("FUZZ_STRENGTH"): s = int(os.environ["FUZZ_STRENGTH"])        # (a campaign at one strength: 0 = the row-statistics engine)
     return img, s, b, bool(rng.integers(0, 3))
 
 

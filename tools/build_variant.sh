@@ -13,6 +13,6 @@ for f in pl_seg pl_host; do
 done
 wait
 OBJS=""
-for f in pl_prepost pl_engine pl_pngread pl_inflate pl_emit pl_deflate; do OBJS="$OBJS $S/$f.o"; done
+for f in pl_prepost pl_engine pl_rows pl_pngread pl_inflate pl_emit pl_deflate; do OBJS="$OBJS $S/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ablate_build/libpngloss_hip_$NAME.so $OBJS $B/pl_seg.o $B/pl_host.o
 echo built tools/ablate_build/libpngloss_hip_$NAME.so

@@ -12,6 +12,6 @@ env $GENENV python tools/gen_lead_asm.py > $T/pl_lead_asm.h
 make -C pngloss_amd/csrc -s libpngloss_hip.so
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $DEFS -I include -c $T/pl_engine.hip -o $T/pl_engine.o
 OBJS=""
-for f in pl_prepost pl_seg pl_pngread pl_inflate pl_emit pl_deflate pl_host; do OBJS="$OBJS pngloss_amd/csrc/$f.o"; done
+for f in pl_prepost pl_rows pl_seg pl_pngread pl_inflate pl_emit pl_deflate pl_host; do OBJS="$OBJS pngloss_amd/csrc/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ablate_build/libpngloss_hip_$NAME.so $OBJS $T/pl_engine.o
 echo built tools/ablate_build/libpngloss_hip_$NAME.so
