@@ -287,7 +287,8 @@ void pngloss_hip_pinned_free(void *p);
 
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
- *            (batches).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model (wide images and small batches go to
+ *            (batches), 4 = row statistics (every image of a batch at strength 0, where nothing is quantised and only the filter search of
+ *            pngloss_image.c:201-287 is left: info[1] = rows).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model (wide images and small batches go to
  *            the segment-parallel engine, narrow images and large batches to the other; state sets of up to 1024 chain states, i.e.
  *            most strength / bleed pairs, rows up to 8192 pixels); PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy|mix pins it (test hook).
  *   info[1]  row attempts (engine 3) / rows on the band-leader chains (engine 0)
@@ -304,6 +305,7 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
  *   "seg"     the segment-parallel engine for every image it takes (any strength / bleed; rows up to 2^20 pixels)
  *   "wg"      one workgroup per image (band-leader chains); "lead" / "legacy": its chain variants (diagnostics)
  *   "mix"     alternate the two engines over the images of a batch (diagnostics)
+ *   "rows"    like "auto" (the row-statistics engine takes strength 0 under "auto" and "rows" alike; "seg" / "wg" run strength 0 the long way)
  * The environment variable PNGLOSS_HIP_ENGINE (the tests' hook) is read only while this option is at "auto".
  * Returns PNGLOSS_SUCCESS or PNGLOSS_INVALID_ARGUMENT (unknown name or value).  Results never depend on the engine. */
 int pngloss_hip_set_option(pngloss_hip_ctx *ctx, const char *name, const char *value);

@@ -443,7 +443,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     {
         const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();   /* (the option of the ABI first; the environment variable is the tests' hook) */
         const bool forced = em && std::strcmp(em, "seg") == 0;
-        const bool allowed = !em || forced || std::strcmp(em, "auto") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
+        const bool allowed = !em || forced || std::strcmp(em, "auto") == 0 || std::strcmp(em, "rows") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
         bool seg_ok = n && allowed && !use_rows && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
             const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
@@ -1457,7 +1457,7 @@ int pngloss_hip_set_option(pngloss_hip_ctx *ctx, const char *name, const char *v
     if (!ctx || !name || !value) return PNGLOSS_INVALID_ARGUMENT;
     if (ctx->pending) return PNGLOSS_INVALID_ARGUMENT;
     if (std::strcmp(name, "engine") == 0) {
-        static const char *const known[] = { "auto", "seg", "wg", "lead", "legacy", "mix" };
+        static const char *const known[] = { "auto", "seg", "wg", "lead", "legacy", "mix", "rows" };
         for (const char *k : known)
             if (std::strcmp(value, k) == 0) { ctx->opt_engine = std::strcmp(value, "auto") == 0 ? "" : value; return PNGLOSS_SUCCESS; }
         return PNGLOSS_INVALID_ARGUMENT;
@@ -1488,7 +1488,7 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
     return PNGLOSS_SUCCESS;
 }
 
-const char *pngloss_hip_version(void) { return "pngloss_hip 0.3 (gfx950; row engines: segment-parallel v2 (dense transition tables, checkpoints) + band-leader v2; seam: pngloss_image.h:14-29)"; }
+const char *pngloss_hip_version(void) { return "pngloss_hip 0.4 (gfx950; row engines: segment-parallel v3 (units, launch groups) + band-leader v2 + row statistics (strength 0); seam: pngloss_image.h:14-29)"; }
 
 /* ---- the reference's seam ------------------------------------------------------------------------------- */
 
