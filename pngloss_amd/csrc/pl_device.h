@@ -156,7 +156,7 @@ struct PlEngineParams {
                           rows whose incoming |error| exceeds 8000 use it) */
 };
 
-hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);
+hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream, bool with_hist = true);   /* with_hist = false: no original_frequency pass (the strength-0 engine sums it from its rows' counts) */
 hipError_t pl_launch_engine(const PlJob *d_jobs, const uint32_t *d_sel, size_t n, PlEngineParams prm, hipStream_t stream);   /* d_sel: n job indices, or null = jobs 0..n-1 */
 int pl_engine_occupancy(void);   /* workgroups of the row engine per CU according to the HIP occupancy query */
 hipError_t pl_launch_rows(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream);      /* the row engine of strength 0 (pl_rows.hip) */

@@ -563,7 +563,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     }
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
-    PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream));
+    PL_CHECK(pl_launch_prepare(d_jobs, ctx->h_jobs.data(), n, stream, !use_rows));
     ctx->last_engine = use_seg ? 3 : (use_rows ? 4 : 0);
     PL_CHECK(hipEventRecord(ctx->ev[1], stream));
     /* the images of the one-workgroup-per-image engine: all of them, or -- a mixed batch -- those the segment engine did not get; they

@@ -269,13 +269,14 @@ hipError_t launch_hist(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipSt
 
 } // namespace
 
-hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream)
+hipError_t pl_launch_prepare(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hipStream_t stream, bool with_hist)
 {
     if (!n) return hipSuccess;
     hipError_t e = hipSuccess;
     hipLaunchKernelGGL(pl_init, dim3((unsigned)n), dim3(kThreads), 0, stream, d_jobs);
     hipLaunchKernelGGL(pl_classify, batch_grid(h_jobs, n, 16), dim3(kThreads), 0, stream, d_jobs);
     hipLaunchKernelGGL(pl_repack, batch_grid(h_jobs, n, 8), dim3(kThreads), 0, stream, d_jobs);
+    if (!with_hist) return hipGetLastError();
     {
         e = launch_hist(d_jobs, h_jobs, n, stream);
         if (e != hipSuccess) return e;

@@ -15,9 +15,10 @@
  *   pl_rows_stats    one workgroup per (image, row): the five residual histograms of the row (LDS atomics, four replicas) and the five sums of
  *                    libpng's heuristic -- every row of every image at once, the image read twice (as the row and as the row above): HBM /
  *                    LDS-atomic bound like pl_hist;
- *   pl_rows_decide   one workgroup per image, five waves (a candidate each, four bins a lane), the rows in series: cost of the five candidates
- *                    against the running histogram, winner, histogram += the winner's counts; the next row's counts are requested while this
- *                    row is decided.  ~1 us a row.
+ *   pl_rows_decide   ONE WAVE per image, the rows in series, everything in registers (four bins a lane): cost of the five candidates against the
+ *                    running histogram, winner, histogram += the winner's counts; the next row's counts are requested while this row is decided;
+ *                    the counts of four rows ahead in registers;
+ *                    no shared memory, no barrier.
  *
  * The segment engine takes the same images at strength 0 (its state set has one state; tests pin it with PNGLOSS_HIP_ENGINE=seg): 139 Mpixels/s on
  * an 8192 x 8192 frame against this file's ~4 Gpixels/s (profiles/r05_rows_engine.txt).  Results are the reference's bit for bit either way.
@@ -78,84 +79,116 @@ __global__ __launch_bounds__(kStatThreads) void pl_rows_stats(const PlJob *__res
     if (tid < PL_NFILT) out[PL_NFILT * PL_NSYM + tid] = hsum[tid];
 }
 
-constexpr int kDecideThreads = PL_NFILT * 64;
-
-__global__ __launch_bounds__(kDecideThreads) void pl_rows_decide(const PlJob *__restrict__ jobs)
+/* sum over the wave, the same value in every lane's view as a scalar: four DPP adds inside the 16-lane rows, then the four rows' sums through scalar registers
+ * (no LDS crossbar: __shfl_xor is a ds_bpermute a step, and this kernel is ONE dependent chain) */
+template <int CTRL>
+__device__ __forceinline__ uint32_t rows_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t rows_wave_sum(uint32_t v)
 {
-    __shared__ uint32_t H[PL_NSYM];
-    __shared__ unsigned long long cost[PL_NFILT];
-    __shared__ int win;
+    v += rows_dpp<0x128>(v);        /* row_ror 8, 4, 2, 1: every lane of a 16-lane row holds the row's sum */
+    v += rows_dpp<0x124>(v);
+    v += rows_dpp<0x122>(v);
+    v += rows_dpp<0x121>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+/* ONE wave per image, no shared memory, no barrier: lane l holds bins l, l + 64, l + 128, l + 192 of the running histogram and of the row's five count
+ * vectors in registers (the next row's are requested while this row is decided); every lane takes the (uniform) decision.  A row is one dependent chain of
+ * ~150 instructions: ~0.4 us (the first version -- five waves, a candidate each, three barriers and a shuffle reduction a row -- took 1.4 us a row). */
+__global__ __launch_bounds__(64) void pl_rows_decide(const PlJob *__restrict__ jobs)
+{
     const PlJob j = jobs[blockIdx.x];
     const uint32_t height = j.height;
-    const int tid = (int)threadIdx.x, f = tid >> 6, lane = tid & 63;
+    const int lane = (int)threadIdx.x;
     const uint32_t bpp = pl_job_bpp(j);
-    for (int i = tid; i < PL_NSYM; i += kDecideThreads) H[i] = 0u;
-    __syncthreads();
-    uint32_t status = 0;
-    uint32_t nn[4] = { 0, 0, 0, 0 }, nhs[PL_NFILT] = { 0, 0, 0, 0, 0 };
-    if (height && j.rowstat) {
+    uint32_t H[4] = { 0, 0, 0, 0 }, O[PL_NFILT][4];
+    /* the counts of the next kDepth rows are in registers or on their way: a row's decision takes ~0.4 us, a load from device memory 1 - 2 us */
+    constexpr int kDepth = 4;
+    uint32_t buf[kDepth][PL_NFILT][4], bhs[kDepth][PL_NFILT];
 #pragma unroll
-        for (int q = 0; q < 4; q++) nn[q] = j.rowstat[(size_t)f * PL_NSYM + lane + 64 * q];
-        if (tid == 0) { for (int g = 0; g < PL_NFILT; g++) nhs[g] = j.rowstat[PL_NFILT * PL_NSYM + g]; }
+    for (int f = 0; f < PL_NFILT; f++) { for (int q = 0; q < 4; q++) O[f][q] = 0; }
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) {
+        const bool in = (uint32_t)k < height && j.rowstat;
+        const uint32_t *nx = j.rowstat + (size_t)(in ? k : 0) * PL_ROWSTAT_WORDS;
+#pragma unroll
+        for (int f = 0; f < PL_NFILT; f++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[k][f][q] = in ? nx[(size_t)f * PL_NSYM + lane + 64 * q] : 0u;
+            bhs[k][f] = in ? nx[PL_NFILT * PL_NSYM + f] : 0u;
+        }
     }
-    for (uint32_t y = 0; y < height; y++) {
-        uint32_t n[4], hs[PL_NFILT];
+    uint32_t status = 0;
+    bool done = false;
+    for (uint32_t y0 = 0; y0 < height && !done; y0 += kDepth) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) n[q] = nn[q];
+        for (int k = 0; k < kDepth; k++) {
+            const uint32_t y = y0 + (uint32_t)k;
+            if (y >= height || done) break;
+            uint32_t n[PL_NFILT][4], hs[PL_NFILT];
 #pragma unroll
-        for (int g = 0; g < PL_NFILT; g++) hs[g] = nhs[g];
-        if (y + 1 < height) {                                   /* the next row's counts are on their way while this row is decided */
-            const uint32_t *nx = j.rowstat + (size_t)(y + 1) * PL_ROWSTAT_WORDS;
+            for (int f = 0; f < PL_NFILT; f++) { hs[f] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhs[k][f]); for (int q = 0; q < 4; q++) n[f][q] = buf[k][f][q]; }    /* (every lane loaded the same word: a scalar from here on, and so is the decision) */
+            if (y + kDepth < height) {
+                const uint32_t *nx = j.rowstat + (size_t)(y + kDepth) * PL_ROWSTAT_WORDS;
 #pragma unroll
-            for (int q = 0; q < 4; q++) nn[q] = nx[(size_t)f * PL_NSYM + lane + 64 * q];
-            if (tid == 0) { for (int g = 0; g < PL_NFILT; g++) nhs[g] = nx[PL_NFILT * PL_NSYM + g]; }
-        }
-        /* the row's entropy cost under the histogram after the row (optimize_state.c:326-342) */
-        unsigned long long c = 0;
+                for (int f = 0; f < PL_NFILT; f++) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t h = H[lane + 64 * q] + n[q];
-            c += n[q] ? (unsigned long long)n[q] * (33u + (uint32_t)__builtin_clz(h)) : 0ull;
-        }
-        for (int o2 = 32; o2 > 0; o2 >>= 1) c += __shfl_xor(c, o2, 64);
-        if (lane == 0) cost[f] = c;
-        __syncthreads();
-        if (tid == 0) {
-            const bool adaptive = !j.row_filters || y == 0;         /* pngloss_image.c:210 */
-            int bestg = 0;
-            for (int g = 1; g < PL_NFILT; g++) if (hs[g] < hs[bestg]) bestg = g;
-            unsigned long long best = ~0ull; int w = -1;
-            for (int g = 0; g < PL_NFILT; g++) {
-                const unsigned long long cg = (adaptive && g != bestg) ? ~0ull : cost[g];          /* optimize_state.c:319-324 */
-                if (cg < best) { best = cg; w = g; }                                                /* strict <: pngloss_image.c:257 */
+                    for (int q = 0; q < 4; q++) buf[k][f][q] = nx[(size_t)f * PL_NSYM + lane + 64 * q];
+                    bhs[k][f] = nx[PL_NFILT * PL_NSYM + f];
+                }
             }
-            win = w;
-            if (w >= 0) {
-                if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << w);                       /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
+            /* the row's entropy cost under the histogram after the row (optimize_state.c:326-342); a row's cost fits 32 bits (rows up to 2^20 pixels: 4 * 2^20 * 65) */
+            uint32_t cost[PL_NFILT];
+#pragma unroll
+            for (int f = 0; f < PL_NFILT; f++) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t h = H[q] + n[f][q];
+                    c += n[f][q] * (33u + (uint32_t)__clz((int)h));  /* (n = 0 adds nothing whatever clz says of h = 0) */
+                    O[f][q] += n[f][q];                         /* (original_frequency of the image, optimize_state.c:66-83: the sum of the rows' counts) */
+                }
+                cost[f] = rows_wave_sum(c);
+            }
+            const bool adaptive = !j.row_filters || y == 0;     /* pngloss_image.c:210 */
+            int bestg = 0;
+#pragma unroll
+            for (int g = 1; g < PL_NFILT; g++) if (hs[g] < hs[bestg]) bestg = g;
+            uint64_t best = ~0ull; int w = -1;
+#pragma unroll
+            for (int g = 0; g < PL_NFILT; g++) {
+                const uint64_t cg = (adaptive && g != bestg) ? ~0ull : (uint64_t)cost[g];              /* optimize_state.c:319-324 */
+                if (cg < best) { best = cg; w = g; }                                                    /* strict <: pngloss_image.c:257 */
+            }
+            if (w < 0) { status = 65u; done = true; break; }    /* no acceptable row at strength 0: the reference abort()s (pngloss_image.c:268-271) */
+            switch (w) {                                        /* (w is a scalar: one branch, four additions) */
+            case 0: for (int q = 0; q < 4; q++) H[q] += n[0][q]; break;
+            case 1: for (int q = 0; q < 4; q++) H[q] += n[1][q]; break;
+            case 2: for (int q = 0; q < 4; q++) H[q] += n[2][q]; break;
+            case 3: for (int q = 0; q < 4; q++) H[q] += n[3][q]; break;
+            default: for (int q = 0; q < 4; q++) H[q] += n[4][q]; break;
+            }
+            if (lane == 0) {
+                if (j.row_filters) j.row_filters[y] = (uint8_t)(0x08u << w);                           /* PNG_FILTER_* flags, pngloss_image.c:288-308 */
                 j.row_ids[y] = (uint8_t)w;
                 if (j.progress) __hip_atomic_store(j.progress, y + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        __syncthreads();
-        const int w = win;
-        if (w < 0) { status = 65u; break; }                     /* no acceptable row at strength 0: the reference abort()s (pngloss_image.c:268-271) */
-        if (f == w) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) H[lane + 64 * q] += n[q];
-        }
-        __syncthreads();
     }
-    __syncthreads();
     uint32_t nz = 0;
-    for (int i = tid; i < PL_NSYM; i += kDecideThreads) { j.final_hist[i] = H[i]; nz += H[i] != 0u; }
-    for (int o2 = 32; o2 > 0; o2 >>= 1) nz += __shfl_xor(nz, o2, 64);
-    if (tid < PL_NFILT) cost[tid] = 0ull;
-    __syncthreads();
-    if (lane == 0 && nz) atomicAdd(&cost[0], (unsigned long long)nz);
-    __syncthreads();
-    if (tid == 0) {
-        for (int i = 0; i < 64; i++) j.result[i] = 0;
-        j.result[0] = (int32_t)status; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)cost[0]; j.result[3] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { j.final_hist[lane + 64 * q] = H[q]; nz += H[q] != 0u; }
+#pragma unroll
+    for (int f = 0; f < PL_NFILT; f++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) j.orig_hist[f * PL_NSYM + lane + 64 * q] = O[f][q];                /* (pl_hist is not run for this engine: pngloss_hip_last_histogram reads this) */
+    }
+    nz = rows_wave_sum(nz);
+    if (lane < 64) { j.result[lane] = 0; }
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) {
+        j.result[0] = (int32_t)status; j.result[1] = (int32_t)bpp; j.result[2] = (int32_t)nz; j.result[3] = 0;
         j.result[5] = (int32_t)height;                           /* "row attempts": one per row */
         j.result[20] = 4;                                        /* engine id: row statistics (strength 0) */
     }
@@ -169,6 +202,6 @@ hipError_t pl_launch_rows(const PlJob *d_jobs, const PlJob *h_jobs, size_t n, hi
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) max_h = h_jobs[i].height > max_h ? h_jobs[i].height : max_h;
     if (max_h) hipLaunchKernelGGL(pl_rows_stats, dim3(max_h, (unsigned)n), dim3(kStatThreads), 0, stream, d_jobs);
-    hipLaunchKernelGGL(pl_rows_decide, dim3((unsigned)n), dim3(kDecideThreads), 0, stream, d_jobs);
+    hipLaunchKernelGGL(pl_rows_decide, dim3((unsigned)n), dim3(64), 0, stream, d_jobs);
     return hipGetLastError();
 }
