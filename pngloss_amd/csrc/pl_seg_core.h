@@ -802,7 +802,10 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
     /* run-in: the carried terms must have contracted when the seeds reach the segment -- the larger they can be, the longer it takes.
      * Measured on 8192-pixel rows (a miss costs the chain kernel ~16 us, a run-in pixel ~0.4 us of every enumeration workgroup): s = 85 at
      * bleed 2 and s = 40 at bleed 1 (cmax 12) are fastest with 16 pixels, s = 85 at bleed 1 (cmax 23) with 24 (profiles/r04_seg_coverage.txt) */
-    P.seeded = 1; P.kin = P.cmax <= 12 ? 16 : (P.cmax <= 24 ? 24 : SEG_KIN);
+    /* (round 5: since the run-in runs in two stages -- only the distinct states through most of it -- a longer run-in costs less, and at bleed 1, where the carried
+     *  terms contract slowest, 20 pixels beat 16: s = 40 b = 1 55.8 -> 70.6 Mpixels/s on an 8192-pixel strip (three segments a row walked step by step before);
+     *  s = 85 b = 2, the same bounds at bleed 2, stays fastest at 16: profiles/r05_seeded_runin.txt) */
+    P.seeded = 1; P.kin = P.cmax <= 12 ? (bleed == 1 ? 20 : 16) : (P.cmax <= 24 ? 24 : SEG_KIN);
     P.ns = 0; P.nsp = 64; P.keyn = 0; P.ns_small = 0; P.small_ok = 0; P.idx0_big = P.idx0_small = (uint32_t)SEG_INVALID;
     if (P.cmax > 127 || tmax > 127 || 2 * P.cmax + 1 > SEG_NSP) return false;     /* (s = 255 at bleed 1: cmax 66, tmax 24) */
     int tstep = 1;
