@@ -180,6 +180,17 @@ template __global__ void seg_k_enum_unit<SEG_UNIT>(const SegJob *__restrict__, c
 template __global__ void seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>(const SegJob *__restrict__, const SegParams *__restrict__, int);
 template __global__ void seg_k_replay<SEG_REPLAY_NT_BATCH>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
 
+/* seeded state sets: the dense transitions of the enumerated segments, between the enumeration and the chain (seg_gather_seeded_body); 5 x 4 x nblk workgroups.
+ * (behind the pinned kernels: it joins the code object at its end) */
+__global__ __launch_bounds__(SEG_GT) void seg_k_gather_seeded(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned nblk)
+{
+    (void)P;
+    const SegJob j = sj[blockIdx.y];
+    const unsigned fc = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    if (blk * SEG_GS + 1u >= j.nseg) return;
+    seg_gather_seeded_body(j, seg_view_of(sj + blockIdx.y, par, (int)(fc >> 2)), (int)(fc >> 2), (int)(fc & 3), (int)blk);
+}
+
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 /* the kernels of the engine whose dynamic LDS can exceed 64 KB: opted in per device (pl_lds_optin) */
@@ -279,6 +290,10 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         } else
         if (nt == 512) hipLaunchKernelGGL(seg_k_enum<512>, dim3(blocks, n), dim3(512), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
         else hipLaunchKernelGGL(seg_k_enum<1024>, dim3(blocks, n), dim3(1024), enum_lds, stream, b.d_sj, b.d_params, par, b.max_nseg);
+    }
+    if (b.seeded && b.max_nseg > 1) {
+        const unsigned nblk = (b.max_nseg - 1 + SEG_GS - 1) / SEG_GS;
+        hipLaunchKernelGGL(seg_k_gather_seeded, dim3(SEG_NFILT * 4 * nblk, n), dim3(SEG_GT), 0, stream, b.d_sj, b.d_params, par, nblk);
     }
     if (b.seeded) hipLaunchKernelGGL((seg_k_chain<true, SEG_CHAIN_THREADS, false>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS), SEG_SM_CHAIN(b.max_nseg), stream, b.d_sj, b.d_params, par);
     else if (b.unit > 1) hipLaunchKernelGGL((seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>), dim3(SEG_NFILT * 4 + 1, n), dim3(SEG_CHAIN_THREADS_UNIT), SEG_SM_CHAIN_X((b.max_nseg + b.unit - 1) / b.unit), stream, b.d_sj, b.d_params, par);

@@ -198,6 +198,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
  * it (filters that look at the left pixel), a grid of carried terms (none, up) -- and whatever they have become at the segment's first pixel is
  * the segment's entry set (measured: oracle/seed_study.c -- the reference's own state is in that set in all but 1e-4 .. 1e-3 of the boundaries; the
  * chain kernel walks such a segment step by step).  Entry states are found by value, through a small hash table per segment and channel. */
+#ifndef SEG_KA_SEEDED
+#define SEG_KA_SEEDED 4           /* steps every seed of the seeded enumeration takes before the distinct states go on alone */
+#endif
 #define SEG_KIN 32                /* most run-in pixels of the seeded enumeration (SegParams::kin: 16 .. 32 by the size of the carried terms) */
 #define SEG_EH 512                /* slots of a segment's entry hash (per channel); a key lives in the SEG_EHW slots from its bucket's first */
 #define SEG_EHW 8
@@ -1115,7 +1118,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
      *    rest of the run-in, both channels packed into the first lanes -- two waves instead of eight for most of the run-in's steps.  The distinct states are found
      *    like the entry set below, in the half of the hash arrays a channel pair leaves unused (channels 2, 3); a state the window has no room for is dropped: a seed
      *    less, which costs coverage, never correctness.  The entry set is the same SET of states either way. -- */
-    constexpr int SEG_KA = 4;
+    constexpr int SEG_KA = SEG_KA_SEEDED;
     const bool two_stage = NCH == 2 && xs != 0u && nrun > SEG_KA + 2;
     PLS_THREADS(tid, NT) {
         const int lc = tid / SEG_NSP, c = c0 + lc, i = tid % SEG_NSP;
@@ -1253,8 +1256,7 @@ PLS_HD void seg_enum_seeded_body(const SegJob &j, const SegParams &P, const SegC
                 if (part) j.rck[slot * (SEG_PARTS - 1) + (part - 1)] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
                 bad |= seg_run_fast_f(f, trx, ps + part * SEG_PL * 4, 4, SEG_PL, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
             }
-            j.rout[slot] = (uint16_t)0;
-            j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);
+            j.rst[slot] = bad ? 0xFFFFFFFFu : seg_state_pack(st);             /* (rout of a seeded set: the successor's id, written by seg_gather_seeded_body) */
         }
         if (prof && tid == 0 && !SEG_EXPERIMENT_REPLAY_CLOCKS) {
             te[3] = PLS_CLOCK(); te[4] = te[3];
@@ -1775,6 +1777,57 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
     }
 }
 
+/* ---- GATHER (seeded sets): task (f, c, block of SEG_GS segments) -- the dense transitions, looked up by many workgroups ------------
+ * For every dense id d of segment sg: the id, in segment sg + 1's entry set, of d's exit state (rst -> key -> two 16-byte loads of the entry hash),
+ * left under rout[sg][d] (SEG_INVALID: no such id, no exit state, or the next segment's entry set does not hold it).  This was the head of the chain kernel:
+ * 32 k lookups of two dependent loads on each of its 20 workgroups, 15 us of its 22 (profiles/r05_seeded_runin.txt); on 1280 workgroups of
+ * 256 threads it is one round of loads, and the chain reads two bytes per transition instead. */
+#ifndef SEG_GS
+#define SEG_GS 4
+#endif
+#define SEG_GT 256
+PLS_HD void seg_gather_seeded_body(const SegJob &j, const SegCtlView &cv, int f, int c, int blk)
+{
+    if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
+    const uint32_t W = j.W, nseg = j.nseg, sx = cv.start_x;
+    if (sx >= W) return;
+    const uint32_t first = sx / SEG_L;
+    if (first + 1 >= nseg) return;
+    /* transitions sg -> sg + 1 of the enumerated segments (behind a walked first segment: from the one after it), this block's share */
+    const uint32_t s0 = sx ? first + 1 : 0u, b0 = (uint32_t)blk * SEG_GS;
+    const uint32_t lo = s0 > b0 ? s0 : b0, hi = seg_umin(nseg - 1u, b0 + SEG_GS);
+    if (lo >= hi) return;
+    const SEG_AS_GLB uint32_t *ehash = j.ehash + ((size_t)f * nseg * 4 + c) * SEG_EH_WORDS;    /* + sg * 4 * SEG_EH_WORDS */
+    SEG_AS_GLB uint16_t *rout = j.rout + ((size_t)f * nseg * 4 + c) * SEG_NSP;                 /* + sg * 4 * SEG_NSP */
+    const SEG_AS_GLB uint32_t *rst = j.rst + ((size_t)f * nseg * 4 + c) * SEG_NSP;
+    const SEG_AS_GLB uint32_t *dcnt = j.dcnt + (size_t)f * nseg * 4 + c;                       /* + sg * 4 */
+    const uint32_t rstep32 = 4u * SEG_NSP, estep32 = 4u * SEG_EH_WORDS;
+    PLS_THREADS(tid, SEG_GT) {
+        const uint32_t d = (uint32_t)tid;                       /* (SEG_GT = SEG_NSP: one lane per dense id, its SEG_GS segments in flight together) */
+        uint32_t ps[SEG_GS], key[SEG_GS];
+        bool live[SEG_GS];                                      /* (a lane beyond the segment's distinct states writes SEG_INVALID: the chain reads whole rows) */
+        SegVec16 w0[SEG_GS], w1[SEG_GS];
+        PLS_UNROLL
+        for (int q = 0; q < SEG_GS; q++) {
+            const uint32_t sg = seg_umin(lo + (uint32_t)q, hi - 1u);
+            live[q] = lo + (uint32_t)q < hi && d < dcnt[sg * 4u];
+            ps[q] = live[q] ? rst[sg * rstep32 + d] : 0xFFFFFFFFu;
+        }
+        PLS_UNROLL
+        for (int q = 0; q < SEG_GS; q++) {
+            const uint32_t sg = seg_umin(lo + (uint32_t)q, hi - 1u);
+            key[q] = seg_eh_key_of_packed(ps[q]);
+            const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (sg + 1u) * estep32 + (key[q] == SEG_NOKEY ? 0u : seg_eh_base(key[q])));
+            if (live[q]) { w0[q] = w[0]; w1[q] = w[1]; } else { w0[q] = SegVec16{ 0, 0, 0, 0 }; w1[q] = w0[q]; }
+        }
+        PLS_UNROLL
+        for (int q = 0; q < SEG_GS; q++) {
+            const uint32_t sg = lo + (uint32_t)q;
+            if (sg < hi) rout[sg * rstep32 + d] = (uint16_t)(live[q] ? seg_eh_match(key[q], w0[q], w1[q]) : (uint32_t)SEG_INVALID);
+        }
+    }
+}
+
 /* ---- CHAIN: task (f, c): compose the segments from the epoch's start state ----------------------------------------------
  * The enumeration left, per segment: a way from an entry STATE to its dense id (exhaustive sets: maps, by entry index -- the exit index of
  * segment k IS the entry index of segment k+1; seeded sets: ehash, by value), dense id -> exit index (rout) and exit state (rst).  The chain
@@ -1921,6 +1974,28 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
              * from uniform bases (the whole gather is bound by the instructions 1024 threads issue on one CU, not by memory) */
             const uint32_t d = (uint32_t)tid & (stride - 1), k0 = (uint32_t)tid >> sh, kstep = (uint32_t)CT >> sh;
             uint32_t widest = 0;
+            if (seeded) {
+                /* seeded sets: the gather kernel (seg_gather_seeded_body) left the successor's id of every dense id under rout, SEG_INVALID where there is
+                 * none: eight ids a load, turned into the index of the successor's cell and stored eight at a time */
+                const uint32_t per = stride >> 3;                   /* 16-byte pieces of a table row */
+                for (uint32_t t = (uint32_t)tid; t < ntr * per; t += (uint32_t)CT) {
+                    const uint32_t k = t / per, part = t - k * per, sg = s0 + a + k;
+                    const SegVec16 in = *(const SEG_AS_GLB SegVec16 *)(rout + sg * rstep32 + part * 8u);
+                    const uint32_t nb = (k + 1u) << sh;
+                    uint32_t w[4] = { in.a, in.b, in.c, in.d };
+                    PLS_UNROLL
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t lo = w[q] & 0xFFFFu, hi = w[q] >> 16;
+                        w[q] = (lo < SEG_NSP ? nb + lo : dummy) | ((hi < SEG_NSP ? nb + hi : dummy) << 16);
+                    }
+                    *(SEG_AS_LDS SegVec16 *)(T + (k << sh) + part * 8u) = SegVec16{ w[0], w[1], w[2], w[3] };
+                }
+                for (uint32_t k = (uint32_t)tid; k < ntr; k += (uint32_t)CT) { const uint32_t dc = dcnt[(s0 + a + k) * 4u]; widest = dc > widest ? dc : widest; }
+                if (starter) {
+                    const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (s0 + a) * estep32 + (start_key == SEG_NOKEY ? 0u : start_base));
+                    dfirst = seg_eh_match(start_key, w[0], w[1]);
+                }
+            } else
             for (uint32_t kb = 0; kb < ntr; kb += SEG_CQ * kstep) {
                 /* no branch per item: an item beyond the last transition is clamped onto it and does that one's work once more (same
                  * values to the same places) */
@@ -1932,8 +2007,8 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     dcv[q] = dcnt[SEGF(sg) * 4u];
                     if (UNITS && !seeded) { r[q] = (uint32_t)rout[SEGF(sg) * rstep32 + d]; ps[q] = SEG_NOSTATE; }     /* (units: first the id in the unit's second list) */
                     else {
-                        r[q] = seeded ? 0u : (uint32_t)rout[o];
-                        ps[q] = (useR || seeded) ? rst[o] : SEG_NOSTATE;
+                        r[q] = (uint32_t)rout[o];
+                        ps[q] = useR ? rst[o] : SEG_NOSTATE;
                     }
                 }
                 if (UNITS && !seeded) {
@@ -1956,31 +2031,11 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                     }
                 }
                 if (starter && kb == 0) {
-                    if (seeded) {
-                        const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (s0 + a) * estep32 + (start_key == SEG_NOKEY ? 0u : start_base));
-                        dfirst = seg_eh_match(start_key, w[0], w[1]);
-                    } else if (idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[SEGF(s0 + a) * mstep32 + idx_first];
+                    if (idx_first != SEG_INVALID && (int)idx_first < nstates) dfirst = (uint32_t)maps[SEGF(s0 + a) * mstep32 + idx_first];
                 }
                 /* (the dependent loads in a loop of their own, all of them requested before the first is used: next to their uses, each one
                  * waits for itself) */
-                if (seeded) {
-                    /* (two 16-byte loads per item: half of the items at a time, the registers of a 1024-thread workgroup hold no more) */
-                    PLS_UNROLL
-                    for (int h = 0; h < 2; h++) {
-                        SegVec16 w0[SEG_CQ / 2], w1[SEG_CQ / 2];
-                        uint32_t key[SEG_CQ / 2];
-                        PLS_UNROLL
-                        for (int q = 0; q < SEG_CQ / 2; q++) {
-                            const int qq = h * (SEG_CQ / 2) + q;
-                            const uint32_t k = seg_umin(kb + k0 + (uint32_t)qq * kstep, ntr - 1u), sg = s0 + a + k;
-                            key[q] = seg_eh_key_of_packed(ps[qq]);
-                            const SEG_AS_GLB SegVec16 *w = (const SEG_AS_GLB SegVec16 *)(ehash + (sg + 1u) * estep32 + (key[q] == SEG_NOKEY ? 0u : seg_eh_base(key[q])));
-                            w0[q] = w[0]; w1[q] = w[1];
-                        }
-                        PLS_UNROLL
-                        for (int q = 0; q < SEG_CQ / 2; q++) { const int qq = h * (SEG_CQ / 2) + q; v[qq] = (d < dcv[qq]) ? seg_eh_match(key[q], w0[q], w1[q]) : (uint32_t)SEG_INVALID; }
-                    }
-                } else {
+                {
                     PLS_UNROLL
                     for (int q = 0; q < SEG_CQ; q++) {
                         const uint32_t k = seg_umin(kb + k0 + (uint32_t)q * kstep, ntr - 1u), sg = s0 + a + k;

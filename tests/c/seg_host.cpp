@@ -159,6 +159,10 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
             }
         }
         if (P.unit <= 1) for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
+        if (P.seeded && j.nseg > 1) {   /* the gather kernel of seeded sets: every (filter, channel, block of segments) */
+            const unsigned nblk = (j.nseg - 1 + SEG_GS - 1) / SEG_GS;
+            for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) for (unsigned b = 0; b < nblk; b++) seg_gather_seeded_body(j, seg_ctl_view(j, par, f), f, c, (int)b);
+        }
         {   /* the chain kernel's LDS is sized by the row's segments: the same size here (the sanitizer build sees an overrun) */
             std::vector<unsigned char> csm(P.seeded ? (size_t)SEG_SM_CHAIN(j.nseg) : (size_t)SEG_SM_CHAIN_X(P.unit > 1 ? (j.nseg + P.unit - 1) / P.unit : j.nseg), 0x5A);
             for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) {
