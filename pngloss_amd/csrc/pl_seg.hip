@@ -8,6 +8,7 @@
  *   seg_k_enum    3 x nseg x 2 workgroups of 512 lanes (a channel pair x 256 chain states; 1024 lanes = 4 channels for large batches) for the
  *                 filters that look at the left pixel, 2 x nseg/8 for none / up, 5 first-segment walkers; tables + pixel records in LDS
  *   seg_k_chain   5 x 4 workgroups, a row's dense transition tables (linked: an entry is the index of the next table's entry) and exit states in LDS (up to 149 KB of the CU's 160 KB)
+ *   (seeded state sets only: seg_k_gather_seeded, 5 x 4 x nseg/4 workgroups of 256 lanes between the enumeration and the chain -- the chain's lookups by value)
  *   seg_k_replay  5 x ngrp workgroups: lane = (segment, quarter, channel), 8 steps each from the enumeration's checkpoints
  *   (the exact validation of every decision -- seg_post_body, 5 x 2 ngrp workgroups of 1024 lanes -- rides in seg_k_ctl's launch, one attempt behind)
  *
