@@ -1786,6 +1786,7 @@ PLS_HD void seg_first_body(const SegJob &j, const SegParams &P, const SegCtlView
 #define SEG_GS 4
 #endif
 #define SEG_GT 256
+static_assert(SEG_GT == SEG_NSP && SEG_NSP % 8 == 0, "one lane of the gather kernel per dense id; the chain reads a table row in pieces of eight ids");
 PLS_HD void seg_gather_seeded_body(const SegJob &j, const SegCtlView &cv, int f, int c, int blk)
 {
     if (cv.finished || cv.active != 1 || (uint32_t)c >= j.bpp) return;
