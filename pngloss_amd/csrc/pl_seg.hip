@@ -71,10 +71,11 @@ __global__ SEG_CTL_BOUNDS void seg_k_ctl(const SegJob *__restrict__ sj, const Se
 #if SEG_EXPERIMENT_NO_VAL_CODE
     return;
 #endif
-    /* validation groups are half replay groups: max_ngrp * (SEG_GRP / SEG_VGRP) workgroups per candidate */
-    const unsigned bx = blockIdx.x - nctl, per = max_ngrp * (SEG_GRP / SEG_VGRP), f = bx / per, vg = bx % per;
-    if (vg * SEG_VGRP >= j.nseg) return;
-    seg_post_body(j, *P, seg_view_of(sj + blockIdx.y, seg_k_prev(k), (int)f), seg_k_prev(k), (int)f, (int)vg, seg_smem);
+    /* validation groups are half replay groups (one image) or whole ones (batches in units): max_ngrp * (SEG_GRP / VGRP) workgroups per candidate */
+    constexpr unsigned VGRP = SEG_VGRP_OF(TPARTS);
+    const unsigned bx = blockIdx.x - nctl, per = max_ngrp * (SEG_GRP / VGRP), f = bx / per, vg = bx % per;
+    if (vg * VGRP >= j.nseg) return;
+    seg_post_body<(int)VGRP>(j, *P, seg_view_of(sj + blockIdx.y, seg_k_prev(k), (int)f), seg_k_prev(k), (int)f, (int)vg, seg_smem);
 }
 
 /* NT threads per workgroup: 1024 (four channels of a segment) or 512 (a channel pair), see SEG_ENUM_NT_SMALL_MAX_NSEG */
@@ -204,8 +205,8 @@ hipError_t chain_attr()
     if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_u);
     if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true, SEG_CHAIN_THREADS, false>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
     static std::atomic<unsigned> done_ctl1{ 0 };
-    if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl<SEG_TPARTS>, SEG_SM_CTLVAL, done_ctl);
-    if (e == hipSuccess && SEG_SM_CTLVAL > 65536) e = pl_lds_optin((const void *)seg_k_ctl<1>, SEG_SM_CTLVAL, done_ctl1);
+    if (e == hipSuccess && SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS)) > 65536) e = pl_lds_optin((const void *)seg_k_ctl<SEG_TPARTS>, SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS)), done_ctl);
+    if (e == hipSuccess && SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)) > 65536) e = pl_lds_optin((const void *)seg_k_ctl<1>, SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)), done_ctl1);
     return e;
 }
 static_assert(SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536 && SEG_SM_ENUM_UNIT <= 65536, "these kernels are launched without an LDS opt-in");
@@ -270,9 +271,9 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
     {
         /* (the validation workgroups can be left out at COMPILE time only -- SEG_EXPERIMENT_NO_VAL_CODE, a timing experiment whose results are unvalidated;
          *  the shipped library has no run-time switch that changes what it computes) */
-        const unsigned nctl = SEG_NFILT * b.tparts + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP);
-        if (b.tparts == 1) hipLaunchKernelGGL(seg_k_ctl<1>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
-        else hipLaunchKernelGGL(seg_k_ctl<SEG_TPARTS>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL, stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
+        const unsigned nctl = SEG_NFILT * b.tparts + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP_OF(b.tparts));
+        if (b.tparts == 1) hipLaunchKernelGGL(seg_k_ctl<1>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)), stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
+        else hipLaunchKernelGGL(seg_k_ctl<SEG_TPARTS>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS)), stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
     }
     {
         const bool small_ok = b.small_ok;

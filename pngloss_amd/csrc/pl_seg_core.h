@@ -159,7 +159,10 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #endif
 #define SEG_UPOOL SEG_UNT        /* ... and the most distinct states its pairs may have between them: one LANE each (round 5: it said 1024 for 512-thread workgroups -- states beyond the lanes had no one to walk them) */
 #define SEG_GRP 16               /* segments per group (replay / validation workgroup) */
-#define SEG_VGRP 8                /* segments per VALIDATION workgroup (half a replay group: one decision per thread, twice the CUs) */
+#define SEG_VGRP 8                /* segments per VALIDATION workgroup of ONE image (half a replay group: one decision per thread, twice the CUs) ... */
+#define SEG_VGRP_UNITS 16         /* ... and of batches composed in units (the whole replay group, two decisions per thread: half the workgroups, each with the same staging round trips and barriers --
+                                     what a saturated GPU pays for; measured, 1080p frames in one batch, 8 against 16: 12 / 16 frames 229 / 300 -> 228 / 299 Mpx/s, 32: 469 -> 479, 64: 569 -> 600, 128: 602 -> 648) */
+#define SEG_VGRP_OF(tparts) ((tparts) == 1 ? SEG_VGRP_UNITS : SEG_VGRP)      /* (the launcher asks for one control workgroup per candidate exactly when it composes in units) */
 #define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
 #define SEG_COMMIT_W 256           /* control kernel: pixels per commit workgroup */
 #define SEG_CTL_IMG_OF(P) (SEG_NFILT * (P).tparts)      /* blockIdx.x of the image-wide workgroup; the commit workgroups follow */
@@ -831,8 +834,10 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 + SEG_GRP * SEG_PARTS * 4 * 8 + SEG_GRP * SEG_L * 16 + (SEG_GRP * SEG_L + 3) * 4 + 64)
-#define SEG_SM_POST ((768 + (SEG_VGRP + 1) * 256 + (SEG_VGRP * SEG_L + 2) * 4 + 64 + 512 + 2 * (SEG_VGRP * SEG_L + 2) + 2 * SEG_VGRP * SEG_L + 32 + 64 + SEG_VGRP * SEG_L + SEG_VGRP * (SEG_L + 1) + 8 * (SEG_VGRP * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands): 36.9 KB (round 5: 49 KB before -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
-#define SEG_SM_CTLVAL (SEG_SM_CTL > SEG_SM_POST ? SEG_SM_CTL : SEG_SM_POST)   /* the first launch of an attempt carries control and validation workgroups */
+#define SEG_SM_POST_V(V) ((768 + ((V) + 1) * 256 + ((V) * SEG_L + 2) * 4 + 64 + 512 + 2 * ((V) * SEG_L + 2) + 2 * (V) * SEG_L + 32 + 64 + (V) * SEG_L + (V) * (SEG_L + 1) + 8 * ((V) * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands): 36.9 KB (round 5: 49 KB before -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
+#define SEG_SM_POST SEG_SM_POST_V(SEG_VGRP)
+#define SEG_SM_CTLVAL_V(V) (SEG_SM_CTL > SEG_SM_POST_V(V) ? SEG_SM_CTL : SEG_SM_POST_V(V))
+#define SEG_SM_CTLVAL SEG_SM_CTLVAL_V(SEG_VGRP)   /* the first launch of an attempt carries control and validation workgroups */
 #define SEG_SM_CTL ((8 + 512 + (sizeof(SegCtl) + 7) / 8 * 2 + (sizeof(SegAcc) + 7) / 8 * 2 + 56 + SEG_NFILT * (SEG_COMMIT_W + 4) * 4 + SEG_COMMIT_W * 4 + (SEG_NFILT + 1) * 256 + 16) * 4)   /* what a commit workgroup carves out (seg_ctl_commit: split table, control block + sums, decision, five tiles, err1 of both parities, spec): 33.8 KB; a candidate workgroup needs 4 x 256 + SEG_TBL_WORDS words */
 static_assert((1024 + SEG_TBL_WORDS) * 4 <= SEG_SM_CTL, "a candidate workgroup of the control kernel (histograms + table staging) fits the commit workgroups' request");
 
@@ -2586,18 +2591,19 @@ struct SegVal {
     SegGeo G;
     uint32_t *wbits;
     const uint8_t *slot_of;
-    const uint32_t *pcw;          /* prefix counts of the watched bins, 4 decisions per word: [slot][SEG_PC_STRIDE] */
+    const uint32_t *pcw;          /* prefix counts of the watched bins, 4 decisions per word: [slot][pc_stride] */
+    uint32_t pc_stride;
     uint8_t *binb;                /* bin of every decision, [segment of the group][SEG_BINB_STRIDE bytes] */
     const uint32_t *btop;         /* [2][SEG_NBAND][4]: per band of either sign: largest upper count bound, its bin, second largest */
     const uint32_t *hiG, *loG;    /* [256] frequency of a bin: upper bound (through the group's end), lower bound (at the group's start) */
 };
 #define SEG_BINB_STRIDE (SEG_L * 4 + 4)
 #define SEG_PC_SEG (SEG_L + 1)                   /* words per segment and slot (one pad word: bank spread) */
-#define SEG_PC_STRIDE (SEG_VGRP * SEG_PC_SEG + 8)
+#define SEG_PC_STRIDE_V(V) ((V) * SEG_PC_SEG + 8)
 #define SEG_NBAND 20
-PLS_HD uint32_t seg_pc_get(const uint32_t *pcw, uint32_t slot, int d)
+PLS_HD uint32_t seg_pc_get(const uint32_t *pcw, uint32_t pc_stride, uint32_t slot, int d)
 {
-    const uint32_t w = pcw[(size_t)slot * SEG_PC_STRIDE + (d / (SEG_L * 4)) * SEG_PC_SEG + ((d % (SEG_L * 4)) >> 2)];
+    const uint32_t w = pcw[(size_t)slot * pc_stride + (d / (SEG_L * 4)) * SEG_PC_SEG + ((d % (SEG_L * 4)) >> 2)];
     return (w >> (8 * (d & 3))) & 255u;
 }
 PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
@@ -2656,13 +2662,13 @@ PLS_HD int seg_validate_one(const SegVal &V, int d, int mode)
         if (!have_hv) {
             uint32_t n = 0;
             const uint32_t sv = V.slot_of[bin];
-            if (sv != 255u) n = seg_pc_get(V.pcw, sv, d);
+            if (sv != 255u) n = seg_pc_get(V.pcw, V.pc_stride, sv, d);
             else for (int e = kseg * 4; e < d; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(V.cw[e + 8]) == bin) n++;
             hv_exact = hv_lo + n; have_hv = true;
         }
         uint32_t n = 0;
         const uint32_t su = V.slot_of[ub];
-        if (su != 255u) n = seg_pc_get(V.pcw, su, d);
+        if (su != 255u) n = seg_pc_get(V.pcw, V.pc_stride, su, d);
         else for (int e = kseg * 4; e < d; e++) if ((uint32_t)(e & 3) < bpp && seg_cand_bin(V.cw[e + 8]) == ub) n++;
         const uint32_t hu = V.H0[ub] + cs[ub] + n;
         if (u_wins_ties ? hu >= hv_exact : hu > hv_exact) return 0;
@@ -2698,6 +2704,7 @@ PLS_HD int seg_none_reach(const SegJob &j, const SegParams &P, int s, int M, int
  * front of a decision: validated prefix (base) + whole groups + whole segments (counts written by the replay) + the earlier
  * decisions of its own segment (counted here).  Cheap bound first (counts at the segment's start and end), exact count only when
  * the bound cannot tell. */
+template <int VGRP>
 PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int vg, unsigned char *smem)
 {
     if (cv.finished || cv.active != 1) return;                 /* (candidate none while it is lazy has no row to validate) */
@@ -2705,12 +2712,13 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
     const uint32_t sx = cv.start_x;
     if (sx >= W) return;                                       /* (a row finished serially by the control kernel: exact by construction) */
     const uint32_t first = sx / SEG_L, fgrp = first / SEG_GRP;
-    const uint32_t seg0 = (uint32_t)vg * SEG_VGRP;             /* vg: validation group = SEG_VGRP segments (half a replay group) */
+    const uint32_t seg0 = (uint32_t)vg * VGRP;             /* vg: validation group = VGRP segments (half a replay group, or all of it) */
     const uint32_t grp = seg0 / SEG_GRP, segp = grp * SEG_GRP;  /* the replay group it lies in, and that group's first segment */
-    constexpr int NPX = SEG_VGRP * SEG_L;                       /* pixels of a group */
+    constexpr int NPX = VGRP * SEG_L;                       /* pixels of a group */
+    constexpr int PCS = SEG_PC_STRIDE_V(VGRP);              /* words per slot of the watched bins' prefix counts */
     uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256;
-    uint32_t *cum = H0 + 768;                                  /* [SEG_VGRP + 1][256]: bumps in front of each segment of the group (staging: row sl + 1 = the bumps OF segment sl) */
-    uint32_t *cw = cum + (SEG_VGRP + 1) * 256;                 /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
+    uint32_t *cum = H0 + 768;                                  /* [VGRP + 1][256]: bumps in front of each segment of the group (staging: row sl + 1 = the bumps OF segment sl) */
+    uint32_t *cw = cum + (VGRP + 1) * 256;                 /* [(NPX + 2)][4] candidate words, from pixel xg0 - 2 */
     uint32_t *red = cw + (NPX + 2) * 4;                        /* reductions: derr lo/hi, cost, hs[5], fail, lb lo/hi */
     uint32_t *lut = red + 64;                                  /* [512] split table */
     uint32_t *ro = lut + 512;                                  /* [NPX + 1] original row, from pixel xg0 - 1 */
@@ -2719,11 +2727,13 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
     uint32_t *wbits = e0 + 2 * NPX;                            /* [8] bitmap of watched bins, [8] pending decisions / slots in use, [9..] bin of each slot */
     uint8_t *slot_of = (uint8_t *)(wbits + 32);                /* [256] slot of a watched bin or 255 */
     uint8_t *pend = slot_of + 256;                             /* [NPX * 4] decision waits for pass 3 */
-    uint8_t *binb = pend + NPX * 4;                            /* [SEG_VGRP][SEG_BINB_STRIDE] bin of every decision */
-    uint32_t *pcw = (uint32_t *)(binb + SEG_VGRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][SEG_PC_STRIDE] prefix counts of the watched bins */
-    uint32_t *cumx = pcw;                                      /* [SEG_VGRP][256] (staging only, before pcw is written: barriers lie between) the bumps of the replay group's segments in front of this half */
-    static_assert(SEG_WATCH * SEG_PC_STRIDE >= SEG_VGRP * 256, "the staged counts of the segments in front fit where the prefix counts go later");
-    uint32_t *btop = pcw + SEG_WATCH * SEG_PC_STRIDE;          /* [2][SEG_NBAND][4] */
+    uint8_t *binb = pend + NPX * 4;                            /* [VGRP][SEG_BINB_STRIDE] bin of every decision */
+    uint32_t *pcw = (uint32_t *)(binb + VGRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][PCS] prefix counts of the watched bins */
+    uint32_t *cumx = pcw;                                      /* [VGRP][256] (staging only, before pcw is written: barriers lie between) the bumps of the replay group's segments in front of this half */
+    constexpr int NFR = SEG_GRP - VGRP;                     /* segments of the replay group that can lie in front of this validation group */
+    static_assert(SEG_WATCH * PCS >= NFR * 256, "the staged counts of the segments in front fit where the prefix counts go later");
+    static_assert(VGRP + NFR == SEG_THREADS / 64 && (NFR == 0 || NFR == VGRP), "the staging burst's sixteen rows of lanes: this group's segments, then the ones in front");
+    uint32_t *btop = pcw + SEG_WATCH * PCS;          /* [2][SEG_NBAND][4] */
     uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
     const uint32_t y = cv.y;
     const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
@@ -2779,10 +2789,10 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
         /* bump counts per segment of the group, staged (one 8-byte load per thread), prefix below */
         const int sl = tid >> 6, q4 = tid & 63;
         {
-            /* lanes of rows 0 .. SEG_VGRP-1: this group's segments; rows SEG_VGRP ..: the segments of the same REPLAY group in front of it
+            /* lanes of rows 0 .. VGRP-1: this group's segments; rows VGRP ..: the segments of the same REPLAY group in front of it
              * (the replay's group counts are per SEG_GRP segments: what lies between that group's start and ours is added from these) */
-            const uint32_t sg = sl < SEG_VGRP ? seg0 + (uint32_t)sl : segp + (uint32_t)(sl - SEG_VGRP);
-            if (sg < nseg && sg >= first && sx < W && (sl < SEG_VGRP || sg < seg0)) {
+            const uint32_t sg = sl < VGRP ? seg0 + (uint32_t)sl : segp + (uint32_t)(sl - VGRP);
+            if (sg < nseg && sg >= first && sx < W && (sl < VGRP || sg < seg0)) {
                 const uint16_t *sc = j.segcnt + ((size_t)f * nseg + sg) * 256 + 4 * q4;
                 c0 = sc[0]; c1 = sc[1]; c2 = sc[2]; c3 = sc[3];
             }
@@ -2795,7 +2805,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
         if (tid <= NPX) { ro[tid] = vro; na[tid] = vna; }
         if (tid >= 512 && tid - 512 < NPX) { e0[2 * (tid - 512)] = ve0a; e0[2 * (tid - 512) + 1] = ve0b; }
         {
-            uint32_t *dst = (sl < SEG_VGRP ? cum + (sl + 1) * 256 : cumx + (sl - SEG_VGRP) * 256) + 4 * q4;
+            uint32_t *dst = (sl < VGRP ? cum + (sl + 1) * 256 : cumx + (sl - VGRP) * 256) + 4 * q4;
             dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
         }
     }
@@ -2804,16 +2814,16 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
         if (tid < 256) {
             const int b = tid;
             uint32_t before = hiG[b];                                  /* (base + the replay groups in front: summed by the staging burst) */
-            uint32_t add[2 * SEG_VGRP];                                /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
+            uint32_t add[VGRP + NFR];                              /* (all sixteen rows read first: a read behind a store to the same array waits for it) */
             PLS_UNROLL
-            for (int r = 1; r <= 2 * SEG_VGRP; r++) add[r - 1] = r <= SEG_VGRP ? cum[r * 256 + b] : cumx[(r - SEG_VGRP - 1) * 256 + b];
+            for (int r = 1; r <= VGRP + NFR; r++) add[r - 1] = r <= VGRP ? cum[r * 256 + b] : cumx[(r - VGRP - 1) * 256 + b];
             PLS_UNROLL
-            for (int r = SEG_VGRP + 1; r <= 2 * SEG_VGRP; r++) before += add[r - 1];
+            for (int r = VGRP + 1; r <= VGRP + NFR; r++) before += add[r - 1];
             uint32_t run = before;
             PLS_UNROLL
-            for (int sl = 0; sl <= SEG_VGRP; sl++) {
+            for (int sl = 0; sl <= VGRP; sl++) {
                 cum[sl * 256 + b] = run;
-                if (sl < SEG_VGRP) run += add[sl];
+                if (sl < VGRP) run += add[sl];
             }
         }
     }
@@ -2824,12 +2834,12 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
      *    pass 2 counts, per segment, the bumps of each watched bin in front of every decision; pass 3 settles the rest exactly. -- */
     SegVal V;
     V.cw = cw; V.ro = ro; V.na = na; V.e0 = e0; V.lut = lut; V.H0 = H0; V.rank = rank; V.cum = cum; V.bpp = bpp; V.f = f; V.G = G; V.bleed = P.bleed;
-    V.sx = sx; V.xg0 = xg0; V.W = W; V.wbits = wbits; V.slot_of = slot_of; V.pcw = pcw; V.binb = binb; V.btop = btop; V.hiG = hiG; V.loG = loG;
+    V.sx = sx; V.xg0 = xg0; V.W = W; V.wbits = wbits; V.slot_of = slot_of; V.pcw = pcw; V.pc_stride = PCS; V.binb = binb; V.btop = btop; V.hiG = hiG; V.loG = loG;
     PLS_THREADS(tid, SEG_THREADS) {
         if (tid < 8) wbits[tid] = 0u;
         if (tid == 8) wbits[8] = 0u;                                   /* number of pending decisions */
         if (tid >= 64 && tid < 128) ((uint32_t *)slot_of)[tid - 64] = 0xffffffffu;
-        if (tid >= 256 && tid < 512) { const int b = tid - 256; hiG[b] = H0[b] + cum[SEG_VGRP * 256 + b]; loG[b] = H0[b] + cum[b]; }
+        if (tid >= 256 && tid < 512) { const int b = tid - 256; hiG[b] = H0[b] + cum[VGRP * 256 + b]; loG[b] = H0[b] + cum[b]; }
     }
     PLS_SYNC();
     PLS_THREADS(tid, SEG_THREADS) {
@@ -2869,11 +2879,11 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) {
             const int sl = tid / SEG_WATCH, slot = tid % SEG_WATCH;
-            if (sl < SEG_VGRP && slot < (int)wbits[8]) {
+            if (sl < VGRP && slot < (int)wbits[8]) {
                 /* bumps of the slot's bin in front of every decision of segment sl, four decisions per word in and out */
                 const uint32_t b = wbits[9 + slot];
                 const uint32_t *src = (const uint32_t *)(binb + sl * SEG_BINB_STRIDE);
-                uint32_t *dst = pcw + (size_t)slot * SEG_PC_STRIDE + sl * SEG_PC_SEG;
+                uint32_t *dst = pcw + (size_t)slot * PCS + sl * SEG_PC_SEG;
                 const int e0seg = seg_max(0, ((int)sx - (int)xg0 - sl * SEG_L) * 4);          /* decisions of the segment in front of the epoch do not count */
                 uint32_t run = 0;
                 for (int iw = 0; iw < SEG_L; iw++) {

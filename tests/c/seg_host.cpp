@@ -119,10 +119,11 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     for (;; attempt++) {
         if (attempt > max_attempts) { fprintf(stderr, "seg_host: no progress\n"); return 65; }
         const int par = attempt % 3, kv = (par + 2) % 3;
-        std::vector<unsigned char> cvsm((size_t)SEG_SM_CTLVAL, 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
+        std::vector<unsigned char> cvsm((size_t)(P.tparts == 1 ? SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)) : SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS))), 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
         for (int half = 0; half < 2; half++) {
             if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG_OF(P) + 1 + ncommit; bx++) { if (P.tparts == 1) seg_ctl_body<1>(j, P, par, bx, cvsm.data()); else seg_ctl_body<SEG_TPARTS>(j, P, par, bx, cvsm.data()); } }
-            else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP < j.nseg; vg++) seg_post_body(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
+            else if (P.tparts == 1) { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP_OF(1) < j.nseg; vg++) seg_post_body<SEG_VGRP_OF(1)>(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
+            else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP_OF(SEG_TPARTS) < j.nseg; vg++) seg_post_body<SEG_VGRP_OF(SEG_TPARTS)>(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
         }
         if (j.ctl[par].finished == 2u) break;
         /* the enumeration's workgroups come in two sizes; the product picks by row width, SEG_HOST_ENUM_NT pins one */
