@@ -452,7 +452,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
              * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
             const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
             auto attempt_us = [&](double wgs, double segs, size_t k) {
-                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(100.0, 41.0 + 0.0134 * wgs);   /* (three launch groups: 16 / 32 / 64 / 96 / 128 frames of 1080p 102 / 136 / 222 / 319 / 418 us: the segment engine up to ~100 such frames) */
+                if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(100.0, 28.0 + 0.0124 * wgs);   /* (three launch groups, validation in whole replay groups: 16 / 64 / 96 / 112 / 128 frames of 1080p 102 / 205 / 289 / 333 / 377 us: the segment engine up to 116 such frames -- measured: 112 frames 361 against 372 ms, 120 frames 385 against 372) */
                 /* (two or more images run as two launch sequences side by side: 4 / 8 / 12 frames of 1080p 58 / 80 / 102 us per attempt, profiles/r05_suite_groups.txt) */
                 if (k >= 2 && !seg_params.seeded) return 35.0 + 0.026 * wgs;
                 return a_us + w_us * wgs;
