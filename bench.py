@@ -696,8 +696,8 @@ def main():
                                         "engine_ms_per_rank": [round(e["engine_ms"], 2) for e in sall],
                                         "engine": sall[0].get("engine", {}).get("engine"),
                                         "digests_match_reference": bool(chk) and all(r["ok"] and r["out"] == want[r["frame"]]["out"] and r["filters"] == want[r["frame"]]["filters"] for r in chk),
-                                        "note": "configs[3] (256 frames in all) leaves a GPU 256/N images = 256/N busy CUs, so it cannot speed up past N = 1; "
-                                                "this leg gives every GPU 512 frames in one call: two per CU, dispatched as CUs fall free (a frame takes 272 - 375 ms alone, so a call of 256 waits for its slowest)"}
+                                        "note": "configs[3] (256 frames in all) is a fixed batch: what N GPUs can make of it is batch_rank_share's projected_strong_scaling (a rank's share runs on the segment engine); "
+                                                "this leg is the saturated GPU instead: every GPU gets 512 frames in one call, two per CU, dispatched as CUs fall free (a frame takes 272 - 375 ms alone, so a call of 256 waits for its slowest)"}
         print(json.dumps(line), flush=True)
     ctx.close()
     if use_dist:
