@@ -834,7 +834,10 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
  * dense ids, distinct states, exits, one slot and one key per lane): 35.5 KB at 512 threads = four workgroups per CU, 38.5 KB at 1024 */
 #define SEG_SM_ENUM_NT(nt) (SEG_TBL_WORDS * 4 + (SEG_L + 1) * 4 * 8 + 2048 + 32 + 4 * SEG_HT * 4 + 4 * SEG_HT * 2 + 4 * SEG_NSP * 4 + 4 * SEG_NSP * 2 + (nt) * 2 + (nt) * 4 + 128)
 #define SEG_SM_REPLAY (4096 + SEG_TBL_WORDS * 4 + SEG_GRP * SEG_L * 4 * 8 + SEG_GRP * 256 + SEG_GRP * SEG_PARTS * 4 * 8 + SEG_GRP * SEG_L * 16 + (SEG_GRP * SEG_L + 3) * 4 + 64)
-#define SEG_SM_POST_V(V) ((768 + ((V) + 1) * 256 + ((V) * SEG_L + 2) * 4 + 64 + 512 + 2 * ((V) * SEG_L + 2) + 2 * (V) * SEG_L + 32 + 64 + (V) * SEG_L + (V) * (SEG_L + 1) + 8 * ((V) * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands): 36.9 KB (round 5: 49 KB before -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
+#ifndef SEG_WATCH_OF
+#define SEG_WATCH_OF(V) ((V) > 8 ? 2 : 8)   /* slots of exact prefix counts a validation workgroup has for the bins its undecided decisions name (a bin without a slot is counted by scanning: exact, slower, rare -- 0.01 % of the decisions are undecided at all); two for whole replay groups: with 51 KB instead of 64 a CU takes a third enumeration workgroup next to such a workgroup */
+#endif
+#define SEG_SM_POST_V(V) ((768 + ((V) + 1) * 256 + ((V) * SEG_L + 2) * 4 + 64 + 512 + 2 * ((V) * SEG_L + 2) + 2 * (V) * SEG_L + 32 + 64 + (V) * SEG_L + (V) * (SEG_L + 1) + SEG_WATCH_OF(V) * ((V) * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands): 36.9 KB (round 5: 49 KB before -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
 #define SEG_SM_POST SEG_SM_POST_V(SEG_VGRP)
 #define SEG_SM_CTLVAL_V(V) (SEG_SM_CTL > SEG_SM_POST_V(V) ? SEG_SM_CTL : SEG_SM_POST_V(V))
 #define SEG_SM_CTLVAL SEG_SM_CTLVAL_V(SEG_VGRP)   /* the first launch of an attempt carries control and validation workgroups */
@@ -2715,6 +2718,7 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
     const uint32_t seg0 = (uint32_t)vg * VGRP;             /* vg: validation group = VGRP segments (half a replay group, or all of it) */
     const uint32_t grp = seg0 / SEG_GRP, segp = grp * SEG_GRP;  /* the replay group it lies in, and that group's first segment */
     constexpr int NPX = VGRP * SEG_L;                       /* pixels of a group */
+    constexpr int NW = SEG_WATCH_OF(VGRP);                  /* slots of the watched bins */
     constexpr int PCS = SEG_PC_STRIDE_V(VGRP);              /* words per slot of the watched bins' prefix counts */
     uint32_t *H0 = (uint32_t *)smem, *rank = H0 + 256;
     uint32_t *cum = H0 + 768;                                  /* [VGRP + 1][256]: bumps in front of each segment of the group (staging: row sl + 1 = the bumps OF segment sl) */
@@ -2728,12 +2732,12 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
     uint8_t *slot_of = (uint8_t *)(wbits + 32);                /* [256] slot of a watched bin or 255 */
     uint8_t *pend = slot_of + 256;                             /* [NPX * 4] decision waits for pass 3 */
     uint8_t *binb = pend + NPX * 4;                            /* [VGRP][SEG_BINB_STRIDE] bin of every decision */
-    uint32_t *pcw = (uint32_t *)(binb + VGRP * SEG_BINB_STRIDE);   /* [SEG_WATCH][PCS] prefix counts of the watched bins */
+    uint32_t *pcw = (uint32_t *)(binb + VGRP * SEG_BINB_STRIDE);   /* [NW][PCS] prefix counts of the watched bins */
     uint32_t *cumx = pcw;                                      /* [VGRP][256] (staging only, before pcw is written: barriers lie between) the bumps of the replay group's segments in front of this half */
     constexpr int NFR = SEG_GRP - VGRP;                     /* segments of the replay group that can lie in front of this validation group */
-    static_assert(SEG_WATCH * PCS >= NFR * 256, "the staged counts of the segments in front fit where the prefix counts go later");
+    static_assert(NW * PCS >= NFR * 256, "the staged counts of the segments in front fit where the prefix counts go later");
     static_assert(VGRP + NFR == SEG_THREADS / 64 && (NFR == 0 || NFR == VGRP), "the staging burst's sixteen rows of lanes: this group's segments, then the ones in front");
-    uint32_t *btop = pcw + SEG_WATCH * PCS;          /* [2][SEG_NBAND][4] */
+    uint32_t *btop = pcw + NW * PCS;          /* [2][SEG_NBAND][4] */
     uint32_t *hiG = btop + 2 * SEG_NBAND * 4, *loG = hiG + 256;
     const uint32_t y = cv.y;
     const uint32_t *row = seg_row_orig(j, y), *nab = y ? j.img + (size_t)(y - 1u) * W : nullptr, *e0g = seg_e0(j, y);
@@ -2872,13 +2876,13 @@ PLS_HD void seg_post_body(const SegJob &j, const SegParams &P, const SegCtlView 
             if (tid == 0) {
                 int ns = 0;
                 red[13] = wbits[8];
-                for (int b = 0; b < 256 && ns < SEG_WATCH; b++) if ((wbits[b >> 5] >> (b & 31)) & 1u) { slot_of[b] = (uint8_t)ns; wbits[9 + ns] = (uint32_t)b; ns++; }
+                for (int b = 0; b < 256 && ns < NW; b++) if ((wbits[b >> 5] >> (b & 31)) & 1u) { slot_of[b] = (uint8_t)ns; wbits[9 + ns] = (uint32_t)b; ns++; }
                 wbits[8] = (uint32_t)ns;
             }
         }
         PLS_SYNC();
         PLS_THREADS(tid, SEG_THREADS) {
-            const int sl = tid / SEG_WATCH, slot = tid % SEG_WATCH;
+            const int sl = tid / NW, slot = tid % NW;
             if (sl < VGRP && slot < (int)wbits[8]) {
                 /* bumps of the slot's bin in front of every decision of segment sl, four decisions per word in and out */
                 const uint32_t b = wbits[9 + slot];
