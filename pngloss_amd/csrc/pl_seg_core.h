@@ -837,7 +837,7 @@ inline bool seg_build_params(SegParams &P, int strength, int bleed, bool force_s
 #ifndef SEG_WATCH_OF
 #define SEG_WATCH_OF(V) ((V) > 8 ? 2 : 8)   /* slots of exact prefix counts a validation workgroup has for the bins its undecided decisions name (a bin without a slot is counted by scanning: exact, slower, rare -- 0.01 % of the decisions are undecided at all); two for whole replay groups: with 51 KB instead of 64 a CU takes a third enumeration workgroup next to such a workgroup */
 #endif
-#define SEG_SM_POST_V(V) ((768 + ((V) + 1) * 256 + ((V) * SEG_L + 2) * 4 + 64 + 512 + 2 * ((V) * SEG_L + 2) + 2 * (V) * SEG_L + 32 + 64 + (V) * SEG_L + (V) * (SEG_L + 1) + SEG_WATCH_OF(V) * ((V) * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH = 8 slots, SEG_NBAND = 20 bands): 36.9 KB (round 5: 49 KB before -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
+#define SEG_SM_POST_V(V) ((768 + ((V) + 1) * 256 + ((V) * SEG_L + 2) * 4 + 64 + 512 + 2 * ((V) * SEG_L + 2) + 2 * (V) * SEG_L + 32 + 64 + (V) * SEG_L + (V) * (SEG_L + 1) + SEG_WATCH_OF(V) * ((V) * (SEG_L + 1) + 8) + 2 * 20 * 4 + 512 + 64) * 4)   /* what seg_post_body carves out, in its order (SEG_WATCH_OF(V) slots, SEG_NBAND = 20 bands): 36.9 KB for half replay groups, 51.0 KB for whole ones (round 5: 49 KB before for half groups -- the launch that carries it was short of CUs with that much free next to the enumeration of another launch group) */
 #define SEG_SM_POST SEG_SM_POST_V(SEG_VGRP)
 #define SEG_SM_CTLVAL_V(V) (SEG_SM_CTL > SEG_SM_POST_V(V) ? SEG_SM_CTL : SEG_SM_POST_V(V))
 #define SEG_SM_CTLVAL SEG_SM_CTLVAL_V(SEG_VGRP)   /* the first launch of an attempt carries control and validation workgroups */
@@ -2586,7 +2586,6 @@ PLS_HD void seg_replay_body(const SegJob &j, const SegParams &P, const SegCtlVie
 /* Validation of one decision d = (pixel k of the group) * 4 + channel.  mode 0: with the block bounds only -- returns 1 good, 0 bad,
  * 2 cannot tell (its bins are marked in wbits); mode 1: exactly, with the per-segment prefix counts of the watched bins (pc), or by
  * counting the earlier decisions of the segment for a bin that got no slot. */
-#define SEG_WATCH 8
 struct SegVal {
     const uint32_t *cw, *ro, *na, *e0, *lut, *H0, *rank, *cum;
     uint32_t bpp, sx, xg0, W;
