@@ -519,6 +519,32 @@ def test_segment_engine_launch_groups_of_small_and_mixed_batches(torch_cuda, mon
     ctx.close()
 
 
+def test_engine_choice_on_batches_of_1080p_frames(torch_cuda, monkeypatch):
+    """Which row engine the library picks for n frames of 1920x1080 in one batch (no engine pinned): the segment engine up to ~116 such frames
+    (measured: 112 frames 361 against 372 ms, profiles/r05_engine_crossover.txt), one workgroup per image beyond -- and the bytes do not depend
+    on it: frames 0 and n-1 against the other engine's output of the same frames."""
+    torch = torch_cuda
+    monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
+    base = [P.synth_rgba(1920, 1080, 0, i) for i in range(2)]
+    ref = None
+    for n, want in [(112, "segment-parallel"), (120, "workgroup-per-image")]:
+        ctx = P.HipContext()
+        dev = [torch.from_numpy(base[i % 2].copy()).cuda() for i in range(n)]
+        filt = [torch.zeros(1080, dtype=torch.uint8, device="cuda") for _ in range(n)]
+        res = ctx.run([(d.data_ptr(), f.data_ptr(), 1920, 1080) for d, f in zip(dev, filt)], 19, 2, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert all(r["status"] == 0 for r in res)
+        assert ctx.engine_info(0)["engine"] == want and ctx.engine_info(n - 1)["engine"] == want, (n, ctx.engine_info(0))
+        got = [(dev[i].cpu().numpy(), filt[i].cpu().numpy()) for i in (0, n - 1)]       # frame n-1 is generator frame 1 for both n
+        if ref is None:
+            ref = got
+        else:
+            for (o, f), (o2, f2) in zip(ref, got):
+                assert np.array_equal(o, o2) and np.array_equal(f, f2)
+        ctx.close()
+        del dev, filt
+
+
 def test_segment_engine_strengths_and_bleeds_with_few_and_many_states(monkeypatch):
     """(strength, bleed) pairs from one chain state (s = 0) to the most the lanes hold; widths around the segment (32), group (512)
     and commit-workgroup (1024) sizes; every byte-per-pixel class."""
