@@ -124,8 +124,10 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
 /* enumeration in UNITS (batches; SegParams::unit = SEG_UNIT): first the filters that look at the left pixel (their workgroups are the long ones: `perb`
  * workgroups of SEG_UNC (unit, channel) pairs per candidate), then none / up -- with their small state set (when it exists) segment by segment, `pers`
  * workgroups of SEG_UNC_SMALL (unit, channel) pairs --, and the five walkers of an epoch's first unit */
+/* (the second bound asks for 8 waves per SIMD: the body's 100 SGPRs held it at 7 -- three workgroups of 8 waves per CU where LDS and threads allow four; with 78 + spills to
+ *  vector lanes a batch of more workgroups than slots gains: 96 frames of 1080p 312 -> 301 ms, 128: 403 -> 392; 16 ... 64 frames within +-0.7 %) */
 template <int UNIT>
-__global__ __launch_bounds__(SEG_UNT) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers)
+__global__ __launch_bounds__(SEG_UNT, 8) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
