@@ -11,8 +11,8 @@
              result records.  value = N * pixels * steps / max-over-ranks(time).
   batch    : for every N, additionally BASELINE.json configs[3] -- 256 synthetic 1920x1080 frames split over the N ranks
              with pngloss_amd.shard.contiguous_partition, one device-resident batch per rank; reported under the `batch`
-             key (whole-job Mpixels/s, per-rank engine ms, reference digests of frames 0/1/255 checked).  This is the
-             image-batch (strong) scaling north_star asks about; it is not part of `value`.  One GPU runs one image per CU, so
+             key (whole-job Mpixels/s, per-rank engine ms, reference digests of ALL 256 frames checked) and, as `batch_value`, at the
+             top level of the line for every N.  This is the image-batch (strong) scaling north_star asks about; it is not part of `value`.  One GPU runs one image per CU, so
              configs[3] cannot get faster below 256 frames per GPU: `batch_saturating` (512 frames per rank for N <= 8, i.e.
              4096 frames in all at N = 8) is the leg whose rate can scale with N.
   engines  : the library picks the row engine per batch (pngloss_hip_last_engine_info): few large images -> segment-parallel
@@ -41,7 +41,7 @@ CPU_SAMPLE_ROWS = 1024         # cpu_baseline sample: the top 4096x1024 strip of
 BUILD_CONTAINER_REFERENCE_MPX = 0.515   # the reference, one thread, full 4096x4096 frame, build container
 BATCH_FRAMES, BATCH_W, BATCH_H = 256, 1920, 1080      # BASELINE.json configs[3]
 def _newest_profile(suffix):
-    for r in ("r05", "r04", "r03"):
+    for r in ("r06", "r05", "r04", "r03"):
         if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{suffix}")):
             return f"{r}_{suffix}"
     return f"r03_{suffix}"
@@ -91,8 +91,8 @@ def _ref_worker(frame_index):
 
 
 def _full_frame_worker(q):
-    """The REAL reference (or the port), one thread, on the FULL 4096x4096 frame the metric is quoted on (~18 s of host time): started before the GPU
-    batch legs and collected behind them, so that it adds nothing to the wall clock of the default run."""
+    """The REAL reference (or the port), one thread, on the FULL 4096x4096 frame the metric is quoted on (~18 s of host time), in a process of its own while
+    this one waits and the GPU idles."""
     import numpy as np
     import pngloss_amd as P
     sig = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_bool, C.c_uint8, C.c_long]
@@ -261,8 +261,17 @@ def bandwidth_kernels():
     return out
 
 
+def batch_ctx(P, device):
+    """A context for the batch legs: this process only ever uses the SYNCHRONOUS entry point, so it opts into three launch groups for large batches on the
+    segment engine (pngloss_hip_set_option "launch_groups" "3": include/pngloss_hip.h; the default of two is for processes that also hand the asynchronous
+    entry streams of their own).  Reported as `launch_groups_option` in the line."""
+    ctx = P.HipContext(device)
+    ctx.set_option("launch_groups", "3")
+    return ctx
+
+
 def _known_1080p():
-    """frame -> reference digests of configs[3] frames (tests/golden/digests.json: 0, 1, 255; digests_1080p.json: twenty more)"""
+    """frame -> reference digests of configs[3] frames (tests/golden/digests_1080p.json: all 256 since round 6; digests.json: 0, 1, 255)"""
     try:
         from tests import util as TU
         return TU.load_digests_1080p()
@@ -446,7 +455,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the configs[3] batch leg and the saturating batch leg")
-    ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: only the 4096x1024 strip, not the full 4096x4096 frame (the full frame is ~18 s of ONE host core, run beside the GPU batch legs)")
+    ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: only the 4096x1024 strip, not the full 4096x4096 frame (the full frame is ~18 s of ONE host core on an otherwise idle host)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the configs[4] sweep (8192x8192, 12 points) and the configs[2] suite batch (rank 0, N = 1 only)")
     args = ap.parse_args()
 
@@ -529,14 +538,22 @@ def main():
         print(f"bench.py: record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
         records = rec if rank == 0 else rec
 
-    # ---- cpu_baseline on the configuration the metric is quoted on: the reference on the FULL frame, one host core, beside the GPU legs below ----
-    full_proc = full_q = None
+    # ---- cpu_baseline on the configuration the metric is quoted on: the reference on the FULL frame, one host core, ON AN OTHERWISE IDLE HOST: it runs here, between
+    #      the timed headline steps and the GPU batch legs, and this process waits for it (round 5 ran it beside the batch legs, whose launch thread, clones and uploads
+    #      kept the host busy: the ratio then depended on what else bench.py happened to be doing -- the advisor's finding) ----
+    full_ff = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_full_frame:
         import multiprocessing as mp
         mpc = mp.get_context("spawn")       # (not fork: this process holds a HIP context)
         full_q = mpc.Queue()
         full_proc = mpc.Process(target=_full_frame_worker, args=(full_q,), daemon=True)
+        torch.cuda.synchronize()
         full_proc.start()
+        try:
+            full_ff = full_q.get(timeout=240)
+            full_proc.join(timeout=10)
+        except Exception as exc:          # informational only
+            full_ff = {"error": repr(exc)}
 
     # ---- the image-batch leg (BASELINE.json configs[3]); outside the timed region of `value` ----
     batch = None
@@ -545,7 +562,7 @@ def main():
     if not args.no_batch:
         del work, filt
         torch.cuda.empty_cache()
-        bdt, beng, brecs = run_batch(P, S, torch, lambda: P.HipContext(local_rank), rank, world, local_rank, barrier)
+        bdt, beng, brecs = run_batch(P, S, torch, lambda: batch_ctx(P, local_rank), rank, world, local_rank, barrier)
         tb = torch.tensor([bdt], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
@@ -556,7 +573,7 @@ def main():
             print(f"bench.py: batch record gather failed on rank {rank}: {exc!r}", file=sys.stderr)
             allrecs, engs = brecs, [dict(index=rank, engine_ms=beng, frames=len(brecs))]
         batch = (float(tb.item()), allrecs, engs)
-        sdt, seng, srecs, sinfo = run_batch_saturating(P, S, torch, lambda: P.HipContext(local_rank), rank, world, barrier)
+        sdt, seng, srecs, sinfo = run_batch_saturating(P, S, torch, lambda: batch_ctx(P, local_rank), rank, world, barrier)
         ts = torch.tensor([sdt], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
@@ -569,7 +586,7 @@ def main():
         if rank == 0 and world == 1:
             want1080 = {k: v for k, v in BATCH_KNOWN.items() if v}
             try:
-                shares = run_rank_shares(P, torch, lambda: P.HipContext(local_rank), want1080)
+                shares = run_rank_shares(P, torch, lambda: batch_ctx(P, local_rank), want1080)
             except Exception as exc:          # never lose the headline to a side leg
                 shares = {"error": repr(exc)}
 
@@ -643,14 +660,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(frame)
             line["speedup_vs_cpu_baseline_strip"] = round(value / line["cpu_baseline"]["value"], 2)
             line["speedup_vs_cpu_baseline"] = line["speedup_vs_cpu_baseline_strip"]
-            if full_proc is not None:
+            if full_ff is not None:
                 try:
-                    ff = full_q.get(timeout=180)
-                    full_proc.join(timeout=10)
+                    ff = full_ff
                     assert ff["rc"] == 0
                     fv = W * H / ff["seconds"] / 1e6
                     line["cpu_baseline"]["full_frame"] = {"value": round(fv, 4), "unit": "Mpixels/s", "cores": 1, "kind": ff["kind"], "seconds": round(ff["seconds"], 2),
-                                                          "sample": f"the whole {W}x{H} frame the metric is quoted on, s={STRENGTH} b={BLEED}, one thread, run beside the GPU batch legs of this invocation",
+                                                          "sample": f"the whole {W}x{H} frame the metric is quoted on, s={STRENGTH} b={BLEED}, one thread, host otherwise idle (between the timed steps and the batch legs of this invocation)",
                                                           "digests_match_reference": ff["out"] == g["out"] and ff["filters"] == g["filters"]}
                     line["speedup_vs_cpu_baseline"] = round(value / fv, 2)          # the like-for-like ratio: full frame against full frame
                 except Exception as exc:          # informational only
@@ -659,7 +675,7 @@ def main():
         if world == 1 and not args.no_sweep:
             for key, fn in (("suite_batch", run_suite_batch), ("sweep_8192", run_sweep_8192)):
                 try:
-                    line[key] = fn(P, torch, lambda: P.HipContext(local_rank), golden)
+                    line[key] = fn(P, torch, lambda: batch_ctx(P, local_rank), golden)
                 except Exception as exc:          # never lose the headline to a side leg
                     line[key] = {"error": repr(exc)}
         if batch is not None:
@@ -674,6 +690,11 @@ def main():
                              "all_status_ok": all(r["status"] == 0 for r in brecs) and len(brecs) == BATCH_FRAMES,
                              "digests_match_reference": bool(checked) and all(r["out"] == want[r["index"]]["out"] and r["filters"] == want[r["index"]]["filters"] for r in checked),
                              "digests_checked_frames": [r["index"] for r in checked]}
+            # the STRONG-scaling number of the fixed configs[3] batch, at top level for every N: a SCALE record plots `value` (weak scaling of one 4096^2 frame per
+            # rank: linear by construction) -- this is the honest curve beside it
+            line["batch_value"] = line["batch"]["value"]
+            line["batch_unit"] = "Mpixels/s (BASELINE.json configs[3]: 256 frames of 1920x1080 split over n_gpus ranks; strong scaling)"
+            line["launch_groups_option"] = 3
         if shares is not None and batch is not None:
             r256 = BATCH_FRAMES * BATCH_W * BATCH_H / batch[0] / 1e6
             if isinstance(shares, list):

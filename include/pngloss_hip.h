@@ -297,6 +297,8 @@ void pngloss_hip_pinned_free(void *p);
  *   info[4]  rows in which candidate none was ruled out by its cost bound (engine 3)
  *   info[5]  segments whose entry state was in no enumerated set (engine 3): walked step by step by the chain kernel (seeded state sets), or the
  *            places where a row was broken off and resumed in an epoch (exhaustive state sets: next to never)
+ *   info[6]  launch groups the batch ran as (engine 3; see the option "launch_groups"), info[7] 1 when the call put a device-side wait for the engine on the
+ *            caller's stream (the asynchronous entry's non-blocking variant), 0 when it waited on the host
  * No reference equivalent. */
 int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t info[8]);
 
@@ -306,8 +308,16 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
  *   "wg"      one workgroup per image (band-leader chains); "lead" / "legacy": its chain variants (diagnostics)
  *   "mix"     alternate the two engines over the images of a batch (diagnostics)
  *   "rows"    like "auto" (the row-statistics engine takes strength 0 under "auto" and "rows" alike; "seg" / "wg" run strength 0 the long way)
- * The environment variable PNGLOSS_HIP_ENGINE (the tests' hook) is read only while this option is at "auto".
- * Returns PNGLOSS_SUCCESS or PNGLOSS_INVALID_ARGUMENT (unknown name or value).  Results never depend on the engine. */
+ * The environment variable PNGLOSS_HIP_ENGINE (the tests' hook) is read only while this option is at "auto" (once per call).
+ * Name "launch_groups", value "auto" | "2" (default) | "3": how many launch sequences a large batch gets on the segment-parallel engine through the
+ *   SYNCHRONOUS entry point pngloss_hip_optimize_batch.  "3" is 3-6 % faster at 32-64 frames of 1080p and is meant for a process that never gives
+ *   pngloss_hip_optimize_batch_async a stream of its own: a third engine stream in the process slows every later engine run that waits on a caller's stream,
+ *   so the library then runs the asynchronous entry in its blocking variant (it returns when the engine is done), and it never creates a third stream once
+ *   any context of the process has used such a wait.
+ * Returns PNGLOSS_SUCCESS or PNGLOSS_INVALID_ARGUMENT (unknown name or value).
+ * Results never depend on an option, on the engine, or on the environment: the remaining environment hooks (PNGLOSS_HIP_SEG_GROUPS, _SEG_UNIT, _ENUM_NT,
+ * _NO_STREAM_WAIT, _SEGPROF, _DEBUG ...: timing and test pins) are read once, when a context is created, and none of them changes a byte; the debugging aid
+ * that does ("candidate f wins every row") exists in builds made with -DPL_DEBUG_FORCE_FILTER=f only, and pngloss_hip_version() of such a build says so. */
 int pngloss_hip_set_option(pngloss_hip_ctx *ctx, const char *name, const char *value);
 
 /* Library / device identification string (static storage). */

@@ -37,8 +37,47 @@
     } while (0)
 
 #define SEG_MAX_GROUPS 8
+/* Timing / test hooks of the environment, read ONCE, when a context is created (pngloss_hip_create) -- not per call.  None of them changes results: they pin choices the library
+ * otherwise makes itself (launch groups, units, workgroup sizes), pick the blocking variant of the asynchronous entry, or print.  The one hook that is read per call is
+ * PNGLOSS_HIP_ENGINE (the tests' pin of the row engine, read once at the top of enqueue; pngloss_hip_set_option(ctx, "engine", ..) takes precedence).  A hook that DOES change results
+ * -- "candidate f wins every row", a debugging aid of rounds 1-3 -- exists in builds made with -DPL_DEBUG_FORCE_FILTER=f only: no environment variable of the shipped library can
+ * make the drop-in seam write anything but the reference's bytes. */
+struct PlHooks {
+    int seg_groups = 0;          /* PNGLOSS_HIP_SEG_GROUPS: launch groups of a batch on the segment engine (0: the library's choice) */
+    bool no_stream_wait = false; /* PNGLOSS_HIP_NO_STREAM_WAIT: the blocking variant of the asynchronous entry (rocprofv3 --pmc needs it) */
+    int seg_unit = -1;           /* PNGLOSS_HIP_SEG_UNIT: 0 / 1 pins the enumeration per segment / in units (-1: the library's choice) */
+    int tparts = 0;              /* PNGLOSS_HIP_SEG_TPARTS */
+    int enum_nt = 0;             /* PNGLOSS_HIP_ENUM_NT: 512 / 1024 */
+    int kin = -1;                /* PNGLOSS_HIP_KIN: run-in pixels of the seeded enumeration */
+    bool segprof = false;        /* PNGLOSS_HIP_SEGPROF: phase clocks inside the kernels (slows them down) */
+    bool debug = false;          /* PNGLOSS_HIP_DEBUG */
+    bool debug_seam = false;     /* PNGLOSS_HIP_DEBUG_SEAM */
+    bool force_careful = false;  /* PNGLOSS_HIP_FORCE_CAREFUL: the int16-wrap variant of the round-1 chains for every row (same bytes) */
+    bool no_split = false;       /* PNGLOSS_HIP_NO_SPLIT */
+    int split = 0;               /* PNGLOSS_HIP_SPLIT: chunks of a host window */
+    static PlHooks from_env()
+    {
+        PlHooks h;
+        auto num = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+        if (std::getenv("PNGLOSS_HIP_SEG_GROUPS")) h.seg_groups = std::max(1, std::min(SEG_MAX_GROUPS, num("PNGLOSS_HIP_SEG_GROUPS", 0)));
+        h.no_stream_wait = std::getenv("PNGLOSS_HIP_NO_STREAM_WAIT") != nullptr;
+        if (std::getenv("PNGLOSS_HIP_SEG_UNIT")) h.seg_unit = num("PNGLOSS_HIP_SEG_UNIT", 0) != 0 ? 1 : 0;
+        h.tparts = num("PNGLOSS_HIP_SEG_TPARTS", 0);
+        h.enum_nt = num("PNGLOSS_HIP_ENUM_NT", 0);
+        h.kin = num("PNGLOSS_HIP_KIN", -1);
+        h.segprof = std::getenv("PNGLOSS_HIP_SEGPROF") != nullptr;
+        h.debug = std::getenv("PNGLOSS_HIP_DEBUG") != nullptr;
+        h.debug_seam = std::getenv("PNGLOSS_HIP_DEBUG_SEAM") != nullptr;
+        h.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;
+        { const char *no = std::getenv("PNGLOSS_HIP_NO_SPLIT"); h.no_split = no && *no == '1'; }
+        { const int v = num("PNGLOSS_HIP_SPLIT", 0); if (v >= 1 && v <= 8) h.split = v; }
+        return h;
+    }
+};
 struct pngloss_hip_ctx {
     int device = 0;
+    PlHooks hooks;                   /* (from the environment, at creation) */
+    int opt_launch_groups = 0;       /* pngloss_hip_set_option("launch_groups", "2" | "3" | "auto"): see run_seg_engine */
     /* one device arena, regrown on demand, carved per batch */
     char *d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -74,6 +113,7 @@ struct pngloss_hip_ctx {
     hipStream_t seg_gstream[SEG_MAX_GROUPS] = {};   /* [0] = seg_stream: one stream per GROUP of a batch's images (run_seg_engine) */
     hipEvent_t ev_seg_gdone[SEG_MAX_GROUPS] = {};
     int seg_groups = 1;
+    bool seg_async_wait = false;     /* the last batch on the segment engine put a wait for the engine on the caller's stream (the asynchronous entry's non-blocking variant) */
     bool three_groups_ok = false;    /* ... and it is the device-resident synchronous entry point itself: a batch may run as three launch groups (the host-pointer entry points, which the
                                         multi-device wrapper calls from a thread per context, stay at two: several contexts of one process share its hardware queues) */
     bool sync_call = false;          /* the batch under way was started by a SYNCHRONOUS entry point (pngloss_hip_optimize_batch): the caller waits on the host anyway, so the
@@ -157,6 +197,8 @@ struct EmitTarget { void *d_ids; void *d_rows; uint32_t pitch; };
  * destroyed.  Measured (round 5, tools/gpu_r5_benchlegs.sh): streams are mapped onto the process's few hardware queues when they are created; a context that
  * created fresh streams after an earlier context's three had been destroyed got two streams on ONE queue -- its two launch groups then ran one behind the other
  * (the reference's suite as one batch: 49 -> 40 Mpx/s in every bench.py run, depending on which leg came before).  Streams that are never destroyed keep their queues. */
+/* process-wide: has any context put a wait for the engine on a caller's stream / does a third engine stream exist (run_seg_engine: launch groups) */
+std::atomic<bool> g_stream_wait_used{ false }, g_third_engine_stream{ false };
 struct SegStreamPool {
     std::mutex mu;
     std::vector<std::pair<int, hipStream_t>> idle;       /* (device, stream) */
@@ -270,12 +312,19 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
          *  waiting stream.  Two it is for the asynchronous entry: a caller with streams of its own must still fit.  The SYNCHRONOUS entry point puts no wait on
          *  any stream (run_seg_engine below): there three groups are safe -- bench.py's process, every leg after a three-group batch at full speed -- and worth
          *  6 % at 32 frames, 3 % at 64.) */
-        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = (ctx->sync_call && ctx->three_groups_ok && n >= 12) ? 3 : 2;   /* (three only where no stream of this call holds a wait: the synchronous entry point -- see above) */
+        /* Round 6 (the advisor's finding on round 5): three is OPT-IN -- pngloss_hip_set_option(ctx, "launch_groups", "3"), for a process that uses the synchronous
+         * entry point only (bench.py's batch legs do and say so in their output) --, because nothing stopped a process from running a three-group batch and an asynchronous
+         * one with a stream of its own later: the default is two.  Two guards on top, process-wide: once ANY context of the process has put a wait on a caller's stream no
+         * third engine stream is created any more; and once a third engine stream exists the asynchronous entry takes its blocking variant (no wait on any stream) instead
+         * of running at half speed behind one. */
+        const bool three = ctx->opt_launch_groups == 3 && ctx->sync_call && ctx->three_groups_ok && n >= 12 && !g_stream_wait_used.load(std::memory_order_relaxed);
+        if (segs > SEG_UNIT_MIN_SEGS && n >= 8) ngroups = three ? 3 : 2;
         else if (n >= 2) ngroups = 2;                              /* (a small batch: see the shares below) */
-        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_GROUPS")) ngroups = std::max(1, std::min(SEG_MAX_GROUPS, std::atoi(e)));   /* (timing / test hook: results do not depend on it) */
+        if (ctx->hooks.seg_groups) ngroups = ctx->hooks.seg_groups;   /* (timing / test hook: results do not depend on it) */
         ngroups = (int)std::min<size_t>((size_t)ngroups, n);
     }
     for (int g = 1; g < ngroups; g++) {
+        if (!ctx->seg_gstream[g] && g >= 2) g_third_engine_stream.store(true, std::memory_order_relaxed);
         if (!ctx->seg_gstream[g]) PL_CHECK(seg_stream_pool().take(ctx->device, ctx->seg_prio, &ctx->seg_gstream[g]));
         if (!ctx->ev_seg_gdone[g]) PL_CHECK(hipEventCreateWithFlags(&ctx->ev_seg_gdone[g], hipEventDisableTiming));
     }
@@ -283,7 +332,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     if (ctx->stream_wait_ok < 0) {
         int can = 0;
         ctx->stream_wait_ok = (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can) ? 1 : 0;
-        if (std::getenv("PNGLOSS_HIP_NO_STREAM_WAIT")) ctx->stream_wait_ok = 0;     /* test hook: the blocking variant */
+        if (ctx->hooks.no_stream_wait) ctx->stream_wait_ok = 0;     /* test hook: the blocking variant */
     }
     void *d_words = nullptr;
     PL_CHECK(hipHostGetDevicePointer(&d_words, ctx->h_seg_words, 0));
@@ -295,7 +344,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
      * its rows -- at the price of eight images each; the other seven need 625 (profiles/r05_suite_groups.txt). */
     size_t gfirst[SEG_MAX_GROUPS + 1];
     for (int g = 0; g <= ngroups; g++) gfirst[g] = n * (size_t)g / (size_t)ngroups;
-    if (ngroups == 2 && n > 2 && !std::getenv("PNGLOSS_HIP_SEG_GROUPS")) {
+    if (ngroups == 2 && n > 2 && !ctx->hooks.seg_groups) {
         const uint32_t h0 = ctx->h_jobs[list[0]].height, h1 = ctx->h_jobs[list[1]].height;
         if ((uint64_t)h0 * 100u > (uint64_t)h1 * 105u) gfirst[1] = 1;
     }
@@ -310,10 +359,10 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
         const bool can = !params.seeded && params.ns <= SEG_NSP;       /* (state sets of one chunk of lanes: with more, the distinct states of a workgroup's pairs outgrow its lanes) */
         bool units = can && segs > SEG_UNIT_MIN_SEGS;
-        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_UNIT")) units = can && std::atoi(e) != 0;
+        if (ctx->hooks.seg_unit >= 0) units = can && ctx->hooks.seg_unit != 0;
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
         ctx->h_seg_params.tparts = units ? 1 : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
-        if (const char *e = std::getenv("PNGLOSS_HIP_SEG_TPARTS")) { const int v = std::atoi(e); if (v == 1 || v == SEG_TPARTS) ctx->h_seg_params.tparts = v; }   /* (timing / test hook) */
+        if (ctx->hooks.tparts == 1 || ctx->hooks.tparts == SEG_TPARTS) ctx->h_seg_params.tparts = ctx->hooks.tparts;   /* (timing / test hook) */
     }
     SegGroups gs;
     gs.n = ngroups;
@@ -355,8 +404,8 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         b.seeded = params.seeded != 0;
         b.unit = (uint32_t)ctx->h_seg_params.unit;
         b.tparts = (uint32_t)ctx->h_seg_params.tparts;
-        b.enum_nt = (size_t)b.max_nseg * n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;
-        if (const char *e = std::getenv("PNGLOSS_HIP_ENUM_NT")) { const int v = std::atoi(e); if (v == 512 || v == 1024) b.enum_nt = (uint32_t)v; }   /* test hook */
+        b.enum_nt = (size_t)b.max_nseg * b.n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;     /* (the images of THIS group: gridDim.y of its launches) */
+        if (ctx->hooks.enum_nt == 512 || ctx->hooks.enum_nt == 1024) b.enum_nt = (uint32_t)ctx->hooks.enum_nt;   /* test hook */
     }
     PL_CHECK(pl_seg_launch_resolve(d_jobs, d_sj, n, stream));
     PL_CHECK(hipEventRecord(ctx->ev_prep, stream));
@@ -369,7 +418,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     ctx->seg_rc.store(PNGLOSS_SUCCESS, std::memory_order_relaxed);
     /* (round 5, measured with tools/gpu_r5_benchlegs.sh: the stream memory operation on the caller's stream is not free -- its queue polls the finished word while
      *  the engine runs -- : without it the headline frame is 1.4 % faster, the seeded 8192 x 8192 points up to 7 %.  The synchronous entry point has no use for it.) */
-    bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct && !ctx->sync_call;
+    bool waiting = ctx->stream_wait_ok != 0 && ctx->seg_prio_distinct && !ctx->sync_call && !g_third_engine_stream.load(std::memory_order_relaxed);
     if (waiting && stream) {
         /* (a caller's stream of the engine's own priority could share its queue: no wait on that one) */
         int prio = 0;
@@ -380,8 +429,10 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         for (int g = 0; g < ngroups && waiting; g++) {
             const hipError_t e = hipStreamWaitValue32(stream, static_cast<uint32_t *>(d_words) + 2 * g, (uint32_t)gs.b[g].n, hipStreamWaitValueGte, 0xFFFFFFFFu);
             if (e != hipSuccess) { (void)hipGetLastError(); ctx->stream_wait_ok = 0; waiting = false; }     /* (a wait already enqueued is satisfied when its group finishes: harmless) */
+            else g_stream_wait_used.store(true, std::memory_order_relaxed);
         }
     }
+    ctx->seg_async_wait = waiting;
     try { ctx->seg_worker = std::thread(seg_worker_main, ctx, gs, max_attempts); }
     catch (...) { std::fprintf(stderr, "pngloss_hip: cannot start the launch thread\n"); for (int g = 0; g < ngroups; g++) words[2 * g] = (uint32_t)gs.b[g].n; return PNGLOSS_HIP_ERROR; }
     if (!waiting) {
@@ -414,10 +465,29 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     /* STRENGTH 0 has a row engine of its own (pl_rows.hip: nothing is quantised, the five candidate rows are the original row, what is left is the filter search):
      * every image of the batch, unless a test pins another engine.  "rows" pins it (a no-op at other strengths). */
     bool use_rows = false;
+    /* the pin of the row engine: the option of the ABI first; the environment variable is the tests' hook (the one hook read per call, once: here) */
+    const std::string em_s = !ctx->opt_engine.empty() ? ctx->opt_engine : std::string(std::getenv("PNGLOSS_HIP_ENGINE") ? std::getenv("PNGLOSS_HIP_ENGINE") : "");
+    const char *const em = em_s.empty() ? nullptr : em_s.c_str();
+    const PlHooks &hk = ctx->hooks;
+#ifdef PL_DEBUG_FORCE_FILTER
+    const bool forced_filter = true;      /* (a debugging BUILD: candidate PL_DEBUG_FORCE_FILTER wins every row -- not the reference's bytes; pngloss_hip_version says so) */
+#else
+    const bool forced_filter = false;
+#endif
     {
-        const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();
         const bool free_choice = !em || std::strcmp(em, "auto") == 0 || std::strcmp(em, "rows") == 0;
-        use_rows = strength == 0 && free_choice && !std::getenv("PNGLOSS_HIP_FORCE_FILTER") && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL");
+        use_rows = strength == 0 && free_choice && !forced_filter && !hk.force_careful;
+    }
+    if (use_rows) {
+        /* the row-statistics engine keeps PL_ROWSTAT_WORDS counters per ROW of every image (5.6 MB per 1080p frame: 2.8 GB for 512 frames) -- the other engines need nothing
+         * comparable.  A batch whose counters would not fit beside its images runs strength 0 the long way (the segment / workgroup engines) instead of failing: same bytes. */
+        size_t rs = 0, free_b = 0, total_b = 0;
+        for (size_t i = 0; i < n; i++) rs += align_up(sizeof(uint32_t) * PL_ROWSTAT_WORDS * (size_t)(images[i].height ? images[i].height : 1), 256);
+        const size_t have = ctx->ws_bytes;                       /* (what the context's arena already holds counts as available) */
+        if (rs > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && rs - have > free_b / 2) {
+            if (hk.debug) std::fprintf(stderr, "pngloss_hip: strength 0: %zu MB of row counters against %zu MB free: using the other row engines for this batch\n", rs >> 20, free_b >> 20);
+            use_rows = false;
+        }
     }
     std::vector<size_t> offs;
     size_t total = align_up(sizeof(PlJob) * (n ? n : 1), 256);
@@ -441,10 +511,9 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     std::vector<uint8_t> on_seg(n, 0);
     size_t n_seg = 0;
     {
-        const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();   /* (the option of the ABI first; the environment variable is the tests' hook) */
         const bool forced = em && std::strcmp(em, "seg") == 0;
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0 || std::strcmp(em, "rows") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
-        bool seg_ok = n && allowed && !use_rows && !std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
+        bool seg_ok = n && allowed && !use_rows && !hk.force_careful && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
             const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
             /* round 5: a batch whose images have more than SEG_UNIT_MIN_SEGS segments between them is enumerated in UNITS, in two launch groups, with the
@@ -555,11 +624,13 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
     prm.rq = recip_up_host((long)strength + 1);
     prm.rbleed = recip_up_host(bleed);
     prm.r29 = 2.0f * recip_up_host(9);
-    prm.force_careful = std::getenv("PNGLOSS_HIP_FORCE_CAREFUL") != nullptr;   /* test hook, see pl_device.h */
+    prm.force_careful = hk.force_careful;   /* test hook, see pl_device.h */
     {
-        const char *em = ctx->opt_engine.empty() ? std::getenv("PNGLOSS_HIP_ENGINE") : ctx->opt_engine.c_str();   /* "legacy" = round-1 chains only */
+        /* "legacy" = round-1 chains only */
         prm.engine_mode = (em && std::strcmp(em, "legacy") == 0) ? 1 : ((em && std::strcmp(em, "lead") == 0) ? 2 : ((em && std::strcmp(em, "mix") == 0) ? 3 : 0));   /* "lead": never fall back adaptively; "mix": alternate every four rows */
-        if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) prm.engine_mode |= (std::atoi(ff) + 1) << 8;   /* debugging aid */
+#ifdef PL_DEBUG_FORCE_FILTER
+        prm.engine_mode |= ((PL_DEBUG_FORCE_FILTER) + 1) << 8;   /* debugging build only */
+#endif
     }
 
     PL_CHECK(hipEventRecord(ctx->ev[0], stream));
@@ -575,9 +646,11 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         d_sel = reinterpret_cast<const uint32_t *>(ctx->d_ws + sel_off);
     }
     if (use_seg) {
-        if (const char *ff = std::getenv("PNGLOSS_HIP_FORCE_FILTER")) seg_params.engine_flags = (std::atoi(ff) + 1) << 8;   /* debugging aid */
-        if (std::getenv("PNGLOSS_HIP_SEGPROF")) seg_params.engine_flags |= 1;                                                   /* phase clocks of the validation kernel */
-        if (const char *k = std::getenv("PNGLOSS_HIP_KIN")) { const int v = std::atoi(k); if (seg_params.seeded && v >= 0 && v <= SEG_KIN) seg_params.kin = v; }   /* experiment: run-in pixels of the seeded enumeration */
+#ifdef PL_DEBUG_FORCE_FILTER
+        seg_params.engine_flags = ((PL_DEBUG_FORCE_FILTER) + 1) << 8;   /* debugging build only */
+#endif
+        if (hk.segprof) seg_params.engine_flags |= 1;                                                   /* phase clocks of the validation kernel */
+        if (seg_params.seeded && hk.kin >= 0 && hk.kin <= SEG_KIN) seg_params.kin = hk.kin;             /* experiment: run-in pixels of the seeded enumeration */
         rc = run_seg_engine(ctx, d_jobs, seg_list, seg_params, seg_offs, seg_jobs_off, seg_params_off, stream, d_sel, wg_list.size(), prm);
         if (rc) return rc;
     } else if (use_rows) PL_CHECK(pl_launch_rows(d_jobs, ctx->h_jobs.data(), n, stream));
@@ -624,42 +697,42 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
     ctx->engine_ms = ms;
     PL_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
     ctx->total_ms = ms;
-    if (std::getenv("PNGLOSS_HIP_DEBUG")) std::fprintf(stderr, "pngloss_hip: row engine occupancy query: %d workgroups per CU\n", pl_engine_occupancy());
+    if (ctx->hooks.debug) std::fprintf(stderr, "pngloss_hip: row engine occupancy query: %d workgroups per CU\n", pl_engine_occupancy());
     int worst = PNGLOSS_SUCCESS;
     for (size_t i = 0; i < ctx->n_last; i++) {
         int32_t r[64] = { 0 };
         PL_CHECK(hipMemcpy(r, ctx->h_jobs[i].result, sizeof r, hipMemcpyDeviceToHost));
         if (results && i < n) results[i] = pngloss_hip_result{ r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4] };
         if (r[20] == 3) {
-            if (std::getenv("PNGLOSS_HIP_DEBUG"))
+            if (ctx->hooks.debug)
                 std::fprintf(stderr, "pngloss_hip: image %zu: segment-parallel engine: %d attempts for %u rows, %d epochs (validation restarts), %d rows finished serially, candidate none dropped by its cost bound %d times, %d segments walked step by step by the chain kernel, engine %.3f ms\n",
                              i, r[5], ctx->h_jobs[i].height, r[4], r[6], r[7], r[17], ctx->engine_ms);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF"))
+            if (ctx->hooks.segprof)
                 std::fprintf(stderr, "pngloss_hip:   validation kernel, slowest workgroup per phase (us): load %.1f  pass1 %.1f  watched bins + pass3 %.1f  none bound %.1f  sums %.1f; pending decisions %d, largest reach %d\n",
                              r[40] / 100.0, r[41] / 100.0, r[42] / 100.0, r[43] / 100.0, r[44] / 100.0, r[46], r[47]);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF"))
+            if (ctx->hooks.segprof)
                 std::fprintf(stderr, "pngloss_hip:   control kernel, slowest (us): candidate workgroup up to the table build %.1f, table build %.1f, commit workgroup %.1f\n", r[56] / 100.0, r[57] / 100.0, r[58] / 100.0);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61] && r[63])
+            if (ctx->hooks.segprof && r[61] && r[63])
                 std::fprintf(stderr, "pngloss_hip:   ... average (us): candidate workgroup up to the table build %.2f, table build %.2f, commit workgroup %.2f\n",
                              (uint32_t)r[59] / 100.0 / (uint32_t)r[61], (uint32_t)r[60] / 100.0 / (uint32_t)r[61], (uint32_t)r[62] / 100.0 / (uint32_t)r[63]);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
+            if (ctx->hooks.segprof && r[61])
                 std::fprintf(stderr, "pngloss_hip:   ... candidate workgroup, average (us): requests + copy %.2f, decision %.2f, new histogram + fields %.2f\n",
                              (uint32_t)r[19] / 100.0 / (uint32_t)r[61], (uint32_t)r[21] / 100.0 / (uint32_t)r[61], (uint32_t)r[22] / 100.0 / (uint32_t)r[61]);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
+            if (ctx->hooks.segprof && r[61])
                 std::fprintf(stderr, "pngloss_hip:   ... commit workgroup, average (us): requests + copy %.2f, decision %.2f, terms %.2f, rows + extremes %.2f\n",
                              (uint32_t)r[23] / 100.0 / (uint32_t)r[63], (uint32_t)r[45] / 100.0 / (uint32_t)r[63], (uint32_t)r[54] / 100.0 / (uint32_t)r[63], (uint32_t)r[55] / 100.0 / (uint32_t)r[63]);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[61])
+            if (ctx->hooks.segprof && r[61])
                 std::fprintf(stderr, "pngloss_hip:   ... table build, average (us): keys %.2f, classes %.2f, entries + write %.2f\n",
                              (uint32_t)r[37] / 100.0 / (uint32_t)r[61], (uint32_t)r[38] / 100.0 / (uint32_t)r[61], (uint32_t)r[39] / 100.0 / (uint32_t)r[61]);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[32])
+            if (ctx->hooks.segprof && r[32])
                 std::fprintf(stderr, "pngloss_hip:   enumeration workgroups (us), slowest / average: load %.1f / %.2f  first steps (%d, or %d for a state set of one chunk) + dedupe %.1f / %.2f  remaining steps %.1f / %.2f  map %.1f / %.2f; distinct states per channel after the dedupe %.1f; first-segment walker %.1f / %.2f\n",
                              r[24] / 100.0, (uint32_t)r[28] / 100.0 / (uint32_t)r[32], SEG_K1, SEG_K1_ONE_CHUNK, r[25] / 100.0, (uint32_t)r[29] / 100.0 / (uint32_t)r[32], r[26] / 100.0, (uint32_t)r[30] / 100.0 / (uint32_t)r[32],
                              r[27] / 100.0, (uint32_t)r[31] / 100.0 / (uint32_t)r[32], (uint32_t)r[33] / 4.0 / (uint32_t)r[32], r[34] / 100.0, r[36] ? (uint32_t)r[35] / 100.0 / (uint32_t)r[36] : 0.0);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[16])
+            if (ctx->hooks.segprof && r[16])
                 std::fprintf(stderr, "pngloss_hip:   chain workgroups (us), slowest / average: gather %.1f / %.2f  compose %.1f / %.2f  walk %.1f / %.2f  tail %.1f / %.2f; %u runs, %u through the serial walk, %u at the wide stride\n",
                              r[8] / 100.0, (uint32_t)r[12] / 100.0 / (uint32_t)r[16], r[9] / 100.0, (uint32_t)r[13] / 100.0 / (uint32_t)r[16], r[10] / 100.0, (uint32_t)r[14] / 100.0 / (uint32_t)r[16],
                              r[11] / 100.0, (uint32_t)r[15] / 100.0 / (uint32_t)r[16], (uint32_t)r[16], (uint32_t)r[17], (uint32_t)r[18]);
-            if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[53])
+            if (ctx->hooks.segprof && r[53])
                 std::fprintf(stderr, "pngloss_hip:   ... average per workgroup (us): load %.2f  pass1 %.2f  watched bins + pass3 %.2f  none bound %.2f  sums %.2f  (%u workgroup runs)\n",
                              (uint32_t)r[48] / 100.0 / (uint32_t)r[53], (uint32_t)r[49] / 100.0 / (uint32_t)r[53], (uint32_t)r[50] / 100.0 / (uint32_t)r[53], (uint32_t)r[51] / 100.0 / (uint32_t)r[53],
                              (uint32_t)r[52] / 100.0 / (uint32_t)r[53], (uint32_t)r[53]);
@@ -667,27 +740,27 @@ int finish(pngloss_hip_ctx *ctx, pngloss_hip_result *results, size_t n)
             if (results && i < n) results[i].repaired_pixels = (uint32_t)r[4];
             continue;
         }
-        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+        if (ctx->hooks.debug)
             std::fprintf(stderr, "pngloss_hip: image %zu: chain kcycles per wave %d %d %d %d, repaired pixels %d %d %d %d, engine %.3f ms\n", i,
                          r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15], ctx->engine_ms);
-        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+        if (ctx->hooks.debug)
             std::fprintf(stderr, "pngloss_hip: image %zu: band-leader row attempts %d, wave 4 kcycles %d, exact redos %d, band rescans (wave 0 / 4) %d %d\n", i,
                          r[5], r[24], r[25], r[6], r[26]);
-        if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
+        if (ctx->hooks.debug && r[5])
             for (int w = 0; w < 5; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d (%s) kcycles: vector %d  fast groups %d  exact redo %d  rescan %d  table build %d\n", w,
                              w == 0 ? "up" : (w == 1 ? "sub" : (w == 2 ? "average" : (w == 3 ? "paeth" : "none"))),
                              r[32 + 5 * w], r[33 + 5 * w], r[34 + 5 * w], r[35 + 5 * w], r[36 + 5 * w]);
-        if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
+        if (ctx->hooks.debug && r[5])
             std::fprintf(stderr, "pngloss_hip:   cycles per pixel of undisturbed whole-chunk runs (up sub average paeth none): %d %d %d %d %d\n", r[57], r[58], r[59], r[60], r[61]);
-        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+        if (ctx->hooks.debug)
             std::fprintf(stderr, "pngloss_hip:   wave 0 kcycles in the post pass %d, in the commit pass %d; flush + relation check per chain wave %d %d %d %d %d\n", r[62], r[63], r[27], r[28], r[29], r[30], r[31]);
-        if (std::getenv("PNGLOSS_HIP_DEBUG"))
+        if (ctx->hooks.debug)
             std::fprintf(stderr, "pngloss_hip:   SIMD of waves 0..7: %d %d %d %d %d %d %d %d\n", r[7] & 3, (r[7] >> 2) & 3, (r[7] >> 4) & 3, (r[7] >> 6) & 3,
                          (r[7] >> 8) & 3, (r[7] >> 10) & 3, (r[7] >> 12) & 3, (r[7] >> 14) & 3);
-        if (std::getenv("PNGLOSS_HIP_DEBUG") && r[5])
+        if (ctx->hooks.debug && r[5])
             std::fprintf(stderr, "pngloss_hip:   light pixels per chain wave %d %d %d %d %d; rows on the round-1 chains by the adaptive choice %d (last cycles per pixel: band-leader %d, round-1 %d)\n", r[16], r[17], r[18], r[19], r[20], r[21], r[22], r[23]);
-        if (std::getenv("PNGLOSS_HIP_SEGPROF") && r[16])   /* (engine built with PL_SEGPROF) */
+        if (ctx->hooks.segprof && r[16])   /* (engine built with PL_SEGPROF) */
             for (int w = 0; w < 4; w++)
                 std::fprintf(stderr, "pngloss_hip:   wave %d segments kcycles: head+gather %d  reductions %d  check+lut %d  tail %d\n", w,
                              r[16 + 4 * w], r[17 + 4 * w], r[18 + 4 * w], r[19 + 4 * w]);
@@ -821,6 +894,7 @@ pngloss_hip_ctx *pngloss_hip_create(int device)
     pngloss_hip_ctx *ctx = new (std::nothrow) pngloss_hip_ctx;
     if (!ctx) return nullptr;
     ctx->device = device;
+    ctx->hooks = PlHooks::from_env();
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return nullptr; }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { pngloss_hip_destroy(ctx); return nullptr; }
@@ -924,7 +998,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
         ctx->pinned_bytes = want;
     }
     if (!ctx->copy_stream) PL_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (std::getenv("PNGLOSS_HIP_DEBUG_SEAM")) std::fprintf(stderr, "pngloss_hip: host window chunk %d: arena %zu MB + pinned mirror %zu MB ready after %.1f ms\n", my_turn, total >> 20, mirrored >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count());
+    if (ctx->hooks.debug_seam) std::fprintf(stderr, "pngloss_hip: host window chunk %d: arena %zu MB + pinned mirror %zu MB ready after %.1f ms\n", my_turn, total >> 20, mirrored >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count());
     char *const arena = ctx->d_arena;
     int rc = PNGLOSS_SUCCESS;
     std::vector<pngloss_hip_image_desc> descs(n);
@@ -1019,7 +1093,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
         }
     }
     ctx->download_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
-    if (std::getenv("PNGLOSS_HIP_DEBUG_SEAM"))
+    if (ctx->hooks.debug_seam)
         std::fprintf(stderr, "pngloss_hip: host window chunk %d: %zu images, wait+stage+upload %.1f ms, engine %.1f ms (enqueue..finish %.1f ms), download+fan-out %.1f ms\n", my_turn, n, ctx->upload_ms, ctx->engine_ms,
                      std::chrono::duration<double, std::milli>(td0 - tu0).count() - ctx->upload_ms, ctx->download_ms);
     if (zs && rc == PNGLOSS_SUCCESS) {
@@ -1056,7 +1130,7 @@ static int batch_host_one(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *im
             }
         }
         ctx->deflate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (std::getenv("PNGLOSS_HIP_DEBUG_SEAM")) std::fprintf(stderr, "pngloss_hip: host window: deflate stage %.1f ms for %zu images\n", ctx->deflate_ms, dz.size());
+        if (ctx->hooks.debug_seam) std::fprintf(stderr, "pngloss_hip: host window: deflate stage %.1f ms for %zu images\n", ctx->deflate_ms, dz.size());
     }
     if (rc == PNGLOSS_HIP_ERROR) std::fprintf(stderr, "pngloss_hip: batch transfer or kernel failure: %s\n", hipGetErrorString(hipGetLastError()));
     if (rc == PNGLOSS_SUCCESS && some_aborted) rc = PNGLOSS_INTERNAL_ABORT;
@@ -1073,15 +1147,14 @@ static int batch_host(pngloss_hip_ctx *ctx, const pngloss_hip_host_image *images
                       pngloss_hip_zstream *zs = nullptr)
 {
     if (!ctx || (n && !images)) return PNGLOSS_INVALID_ARGUMENT;
-    const char *no = std::getenv("PNGLOSS_HIP_NO_SPLIT");
     ctx->split_last = false;
     /* Chunks, each on its own context and stream, staggered by the staging turns: chunk k+1 is staged and uploaded while chunk k
      * computes, chunk k is downloaded while chunk k+1 computes.  Measured on 256 x 1280x720 (profiles/r03_host_seam.txt): one chunk
      * 0.237 s, two 0.221 s, four 0.218 s (the engine alone: 0.176 s) -- two it is; PNGLOSS_HIP_SPLIT=k for experiments. */
     size_t K = n >= 16 ? 2 : 1;
-    if (const char *ks = std::getenv("PNGLOSS_HIP_SPLIT")) { const long v = std::atol(ks); if (v >= 1 && v <= 8) K = (size_t)v; }
+    if (ctx->hooks.split) K = (size_t)ctx->hooks.split;
     if (K > n) K = n ? n : 1;
-    if (K <= 1 || zs || (no && *no == '1')) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
+    if (K <= 1 || zs || ctx->hooks.no_split) return batch_host_one(ctx, images, n, quantization_strength, bleed_divider, results, lines, zs);
     while (ctx->peers.size() < K - 1) {
         pngloss_hip_ctx *p = pngloss_hip_create(ctx->device);
         if (!p) break;
@@ -1381,7 +1454,7 @@ int png_decode_body(pngloss_hip_ctx *ctx, const pngloss_hip_png_source *src, siz
         PL_CHECK(hipMemcpyAsync(d_zjobs, zjobs.data(), sizeof(PliStream) * n, hipMemcpyHostToDevice, stream));
         PL_CHECK(pl_launch_inflate(d_zjobs, n, stream));
     }
-    const bool seam_dbg = std::getenv("PNGLOSS_HIP_DEBUG_SEAM") != nullptr;
+    const bool seam_dbg = ctx->hooks.debug_seam;
     double ms_up = 0, ms_k = 0;
     if (seam_dbg) { PL_CHECK(hipStreamSynchronize(stream)); ms_up = ms_since(); }
     PL_CHECK(pl_launch_png_decode(reinterpret_cast<const PrJob *>(b), n, max_bands, stream));
@@ -1462,6 +1535,13 @@ int pngloss_hip_set_option(pngloss_hip_ctx *ctx, const char *name, const char *v
             if (std::strcmp(value, k) == 0) { ctx->opt_engine = std::strcmp(value, "auto") == 0 ? "" : value; return PNGLOSS_SUCCESS; }
         return PNGLOSS_INVALID_ARGUMENT;
     }
+    if (std::strcmp(name, "launch_groups") == 0) {
+        /* launch groups of a large batch on the segment engine through the SYNCHRONOUS entry point: "auto" / "2" (default) or "3" -- for a process that never hands the
+         * asynchronous entry a stream of its own (run_seg_engine: a third engine stream in the process halves every later engine run that waits on a caller's stream) */
+        if (std::strcmp(value, "auto") == 0 || std::strcmp(value, "2") == 0) { ctx->opt_launch_groups = 0; return PNGLOSS_SUCCESS; }
+        if (std::strcmp(value, "3") == 0) { ctx->opt_launch_groups = 3; return PNGLOSS_SUCCESS; }
+        return PNGLOSS_INVALID_ARGUMENT;
+    }
     return PNGLOSS_INVALID_ARGUMENT;
 }
 
@@ -1482,13 +1562,22 @@ int pngloss_hip_last_engine_info(pngloss_hip_ctx *ctx, size_t index, int32_t inf
     int32_t r[64] = { 0 };
     PL_CHECK(hipMemcpy(r, ctx->h_jobs[index].result, sizeof r, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) info[i] = 0;
-    if (r[20] == 3) { info[0] = 3; info[1] = r[5]; info[2] = r[4]; info[3] = r[6]; info[4] = r[7]; info[5] = r[17]; }
+    if (r[20] == 3) { info[0] = 3; info[1] = r[5]; info[2] = r[4]; info[3] = r[6]; info[4] = r[7]; info[5] = r[17]; info[6] = ctx->seg_groups; info[7] = ctx->seg_async_wait ? 1 : 0; }
     else if (r[20] == 4) { info[0] = 4; info[1] = r[5]; }
     else { info[0] = 0; info[1] = r[5]; info[2] = r[4]; info[3] = r[21]; }
     return PNGLOSS_SUCCESS;
 }
 
-const char *pngloss_hip_version(void) { return "pngloss_hip 0.4 (gfx950; row engines: segment-parallel v3 (units, launch groups) + band-leader v2 + row statistics (strength 0); seam: pngloss_image.h:14-29)"; }
+#define PL_STR2(x) #x
+#define PL_STR(x) PL_STR2(x)
+const char *pngloss_hip_version(void)
+{
+#ifdef PL_DEBUG_FORCE_FILTER
+    return "pngloss_hip 0.5 DEBUGGING BUILD -DPL_DEBUG_FORCE_FILTER=" PL_STR(PL_DEBUG_FORCE_FILTER) ": one candidate wins every row, results are NOT the reference's (gfx950)";
+#else
+    return "pngloss_hip 0.5 (gfx950; row engines: segment-parallel v3 (units, launch groups) + band-leader v2 + row statistics (strength 0); seam: pngloss_image.h:14-29)";
+#endif
+}
 
 /* ---- the reference's seam ------------------------------------------------------------------------------- */
 

@@ -1550,8 +1550,9 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
 #if defined(__HIP_DEVICE_COMPILE__)
     /* From here on only the first misc[32 + NC] lanes have work.  The waves behind them END here: a workgroup of 16 waves keeps 16 of the CU's 32 wave slots
      * as long as its waves sit in the barriers below -- with them gone the CU takes the next workgroup (measured: profiles/r05_unit_groups.txt).  A barrier
-     * counts the waves that have not ended, so the ones that stay are not held up. */
-    if ((threadIdx.x & ~63u) >= misc[32 + NC]) return;
+     * counts the waves that have not ended, so the ones that stay are not held up.  Wave 0 always stays: its first NC lanes write the pairs' dcnt below -- also when
+     * EVERY state of every pair left the tables in the first phase (pool total 0): the chain kernel must find "no distinct states" there, not an earlier row's count. */
+    if (threadIdx.x >= 64u && (threadIdx.x & ~63u) >= misc[32 + NC]) return;
 #endif
     /* -- second phase: the distinct states of all pairs, one lane each, through the unit's FIRST segment -- */
     PLS_THREADS(tid, NT) {

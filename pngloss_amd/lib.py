@@ -473,7 +473,7 @@ class HipContext:
         self._lib.pngloss_hip_last_engine_info.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         self._lib.pngloss_hip_last_engine_info.restype = C.c_int
         _check(self._lib.pngloss_hip_last_engine_info(self._ctx, index, a), "engine_info")
-        return dict(engine={3: "segment-parallel", 0: "workgroup-per-image", 4: "row-statistics (strength 0)"}.get(a[0], a[0]), attempts=a[1], restarts=a[2], serial_rows=a[3], none_dropped=a[4], walked_segments=a[5])
+        return dict(engine={3: "segment-parallel", 0: "workgroup-per-image", 4: "row-statistics (strength 0)"}.get(a[0], a[0]), attempts=a[1], restarts=a[2], serial_rows=a[3], none_dropped=a[4], walked_segments=a[5], launch_groups=a[6], stream_wait=a[7])
 
     def histogram(self, index=0):
         h = np.zeros(256, np.uint32)

@@ -1,8 +1,9 @@
 """More reference digests for BASELINE.json configs[3] (256 frames of 1920x1080, generator mode 0, s=19 b=2): the REAL reference
-(oracle/_ref/libpngloss_ref.so, build container only) on a spread of frame indices, one process per frame.
+(oracle/_ref/libpngloss_ref.so, build container only) on EVERY frame index 0..255 (round 6; a spread of 20 before), one process per frame,
+~2.5 minutes on 8 cores.
    python tests/golden/make_frames_1080p.py      ->  tests/golden/digests_1080p.json   (data only: digests of inputs / outputs / filters)
-digests.json already holds frames 0, 1 and 255; this file adds the frames the 256-frame batch test and the
-batch legs of bench.py check on top of those."""
+digests.json holds frames 0, 1 and 255 as the survey measured them; this file holds all 256 (those three included, and they
+must agree): the 256-frame batch test and the batch legs of bench.py check every frame they run."""
 import ctypes as C
 import json
 import multiprocessing as mp
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import pngloss_amd as P  # noqa: E402
 
-FRAMES = [2, 3, 7, 15, 31, 32, 33, 63, 64, 95, 96, 127, 128, 159, 160, 191, 192, 223, 224, 254]
+FRAMES = list(range(256))
 W, H, S, B = 1920, 1080, 19, 2
 
 

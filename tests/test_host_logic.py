@@ -52,6 +52,22 @@ def test_product_code_never_touches_the_oracle():
     assert "port_" not in text
 
 
+def test_no_environment_variable_of_the_shipped_library_changes_results():
+    """Round 6 (the round-5 review's item): the one hook that changed results -- "candidate f wins every row", PNGLOSS_HIP_FORCE_FILTER, a debugging aid of rounds 1-3 -- is a
+    BUILD flag now (-DPL_DEBUG_FORCE_FILTER=f): the shipped library does not know the variable, its version string does not announce a debugging build, and the
+    environment hooks that are left (timing and test pins) are read in one place, when a context is created -- PNGLOSS_HIP_ENGINE, the tests' pin of the row engine,
+    is the one read per call."""
+    so = open(os.path.join(U.ROOT, "pngloss_amd", "csrc", "libpngloss_hip.so"), "rb").read()
+    assert b"PNGLOSS_HIP_FORCE_FILTER" not in so
+    assert b"DEBUGGING BUILD" not in P.hip_lib().pngloss_hip_version()
+    host = open(os.path.join(U.ROOT, "pngloss_amd", "csrc", "pl_host.hip")).read()
+    body = host[host.index("static PlHooks from_env()"):]
+    body = body[body.index("return h;"):]              # (everything behind the hooks' reader)
+    import re
+    left = set(re.findall(r'getenv\("([A-Z_]+)"\)', body))
+    assert left == {"PNGLOSS_HIP_ENGINE", "PNGLOSS_DEVICES"}, left
+
+
 def _recip_up(d, ulps=1):
     r = np.float32(1.0) / np.float32(d)
     for _ in range(ulps):

@@ -112,11 +112,14 @@ def load_digests():
 
 
 def load_digests_1080p():
-    """frame -> reference digests of BASELINE.json configs[3]'s 1920x1080 frames: 0, 1, 255 from digests.json and the twenty of
-    digests_1080p.json (tests/golden/make_frames_1080p.py: the real reference in the build container)."""
+    """frame -> reference digests of BASELINE.json configs[3]'s 1920x1080 frames: 0, 1, 255 from digests.json and all 256 of
+    digests_1080p.json (tests/golden/make_frames_1080p.py: the real reference in the build container; the three frames both files hold must agree)."""
     want = {e["frame"]: e for e in load_digests()["synthetic"] if (e["width"], e["height"]) == (1920, 1080)}
     with open(os.path.join(GOLDEN, "digests_1080p.json")) as fh:
-        want.update({e["frame"]: e for e in json.load(fh)["frames"]})
+        for e in json.load(fh)["frames"]:
+            if e["frame"] in want:
+                assert (want[e["frame"]]["out"], want[e["frame"]]["filters"]) == (e["out"], e["filters"]), e["frame"]
+            want[e["frame"]] = e
     return want
 
 
@@ -282,3 +285,43 @@ def png_read_fixtures():
     s, inp = load_npz("suite_png.npz"), load_npz("suite_inputs.npz")
     out += [("suite_" + k, s[k].tobytes(), inp[k]) for k in s.files]
     return out
+
+
+def fuzz_case(rng, big=False, strength=None):
+    """One random case of the parity campaigns (tests/tools/gpu_fuzz.py on the GPU box by hand, tests/test_gpu_parity.py::test_randomised_parity_campaign in the
+    driver's -m gpu run): shapes around the segment / wave sizes, nine kinds of content, six alpha / gray classes, strengths 0..255, bleeds 1..32767, both
+    row_filters modes.  Returns (rgba, strength, bleed, want_filters)."""
+    w = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 129, 257, int(rng.integers(1, 400))]))
+    h = int(rng.integers(1, 30))
+    if big:
+        w = int(rng.integers(200, 1500)); h = int(rng.integers(20, 120))
+    kind = int(rng.integers(0, 9))
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    elif kind == 1:      # smooth gradients + small noise
+        x = np.linspace(0, 255, w)[None, :, None]; y = np.linspace(0, 255, h)[:, None, None]
+        img = np.clip((x * rng.random(4) + y * rng.random(4)) / 2 + rng.integers(0, 6, (h, w, 4)), 0, 255).astype(np.uint8)
+    elif kind == 2:      # saturated: lots of 0 and 255
+        img = (rng.integers(0, 2, (h, w, 4)) * 255).astype(np.uint8)
+    elif kind == 3:      # near-white with noise (clamping at 255)
+        img = (255 - rng.integers(0, 12, (h, w, 4))).astype(np.uint8)
+    elif kind == 4:      # near-black
+        img = rng.integers(0, 12, (h, w, 4), dtype=np.uint8)
+    elif kind == 5:      # few distinct values -> many histogram ties
+        img = (rng.integers(0, 3, (h, w, 4)) * 100 + 20).astype(np.uint8)
+    elif kind == 6:      # constant
+        img = np.full((h, w, 4), int(rng.integers(0, 256)), np.uint8)
+    elif kind == 7:      # blocks
+        img = np.repeat(np.repeat(rng.integers(0, 256, ((h + 3) // 4, (w + 3) // 4, 4), dtype=np.uint8), 4, 0), 4, 1)[:h, :w]
+    else:                # stripes
+        img = np.zeros((h, w, 4), np.uint8); img[:, ::2] = rng.integers(0, 256, 4); img[:, 1::2] = rng.integers(0, 256, 4)
+    img = np.ascontiguousarray(img)
+    cls = int(rng.integers(0, 6))
+    if cls == 1: img[..., 3] = 255
+    elif cls == 2: img[..., 0] = img[..., 1]; img[..., 2] = img[..., 1]
+    elif cls == 3: img[..., 0] = img[..., 1]; img[..., 2] = img[..., 1]; img[..., 3] = 255
+    elif cls == 4: img[..., 3] = np.where(rng.random((h, w)) < 0.4, 0, img[..., 3])
+    s = int(rng.choice([0, 1, 2, 5, 7, 8, 15, 16, 19, 20, 23, 24, 31, 32, 40, 47, 48, 63, 64, 85, 100, 127, 200, 255, int(rng.integers(0, 256))]))
+    b = int(rng.choice([1, 2, 3, 4, 8, 16, 100, 1000, 32767, int(rng.integers(1, 32768))]))
+    if strength is not None: s = int(strength)
+    return img, s, b, bool(rng.integers(0, 3))
