@@ -49,6 +49,8 @@ struct PlHooks {
     int tparts = 0;              /* PNGLOSS_HIP_SEG_TPARTS */
     int enum_nt = 0;             /* PNGLOSS_HIP_ENUM_NT: 512 / 1024 */
     int kin = -1;                /* PNGLOSS_HIP_KIN: run-in pixels of the seeded enumeration */
+    int seg_seeds = -1;          /* PNGLOSS_HIP_SEG_SEEDS: 0 = units start from every state, as in round 5 (-1 / 1: from seeds where the pair has a seed set) */
+    int seed_kin = -1;           /* PNGLOSS_HIP_SEED_KIN: run-in pixels of the units' seeds (1 .. SEG_SEED_KMAX) */
     bool segprof = false;        /* PNGLOSS_HIP_SEGPROF: phase clocks inside the kernels (slows them down) */
     bool debug = false;          /* PNGLOSS_HIP_DEBUG */
     bool debug_seam = false;     /* PNGLOSS_HIP_DEBUG_SEAM */
@@ -65,6 +67,8 @@ struct PlHooks {
         h.tparts = num("PNGLOSS_HIP_SEG_TPARTS", 0);
         h.enum_nt = num("PNGLOSS_HIP_ENUM_NT", 0);
         h.kin = num("PNGLOSS_HIP_KIN", -1);
+        h.seg_seeds = num("PNGLOSS_HIP_SEG_SEEDS", -1);
+        h.seed_kin = num("PNGLOSS_HIP_SEED_KIN", -1);
         h.segprof = std::getenv("PNGLOSS_HIP_SEGPROF") != nullptr;
         h.debug = std::getenv("PNGLOSS_HIP_DEBUG") != nullptr;
         h.debug_seam = std::getenv("PNGLOSS_HIP_DEBUG_SEAM") != nullptr;
@@ -363,6 +367,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
         ctx->h_seg_params.tparts = units ? 1 : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
         if (ctx->hooks.tparts == 1 || ctx->hooks.tparts == SEG_TPARTS) ctx->h_seg_params.tparts = ctx->hooks.tparts;   /* (timing / test hook) */
+        if (ctx->hooks.seed_kin >= 1 && ctx->hooks.seed_kin <= SEG_SEED_KMAX) ctx->h_seg_params.seed_kin = ctx->hooks.seed_kin;   /* (timing hook) */
     }
     SegGroups gs;
     gs.n = ngroups;
@@ -403,6 +408,8 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         b.small_ok = params.small_ok != 0;
         b.seeded = params.seeded != 0;
         b.unit = (uint32_t)ctx->h_seg_params.unit;
+        /* round 6: units start from seeds with a run-in where the (strength, bleed) pair has a seed set (PNGLOSS_HIP_SEG_SEEDS=0 / 1 pins it for tests and timing; same bytes) */
+        b.seeds = b.unit > 1 && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0;
         b.tparts = (uint32_t)ctx->h_seg_params.tparts;
         b.enum_nt = (size_t)b.max_nseg * b.n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;     /* (the images of THIS group: gridDim.y of its launches) */
         if (ctx->hooks.enum_nt == 512 || ctx->hooks.enum_nt == 1024) b.enum_nt = (uint32_t)ctx->hooks.enum_nt;   /* test hook */

@@ -24,6 +24,7 @@ struct PlSegBatch {
     bool seeded;              /* SegParams::seeded (seg_k_enum_seeded) */
     uint32_t tparts;          /* SegParams::tparts */
     uint32_t unit;            /* SegParams::unit: 1, or SEG_UNIT = enumeration in units (seg_k_enum_unit; batches) */
+    bool seeds;               /* (units only) the units may start from seeds with a run-in instead of from every state (SegParams::seed_n > 0; seg_unit_from_seeds decides per image, candidate and attempt) */
 };
 
 /* fills sj[i].bpp from the class the prepare kernels detected */

@@ -43,6 +43,7 @@ __global__ void seg_k_resolve(const PlJob *jobs, SegJob *sj, unsigned n)
         sj[i].ctl[2].magic = 0u;          /* the image's first attempt (copy 0) finds no attempt behind it: no control block, */
         sj[i].acc[2].failmask = 0u;       /* ... no failed validation */
         for (int k = 0; k < 3; k++) { sj[i].v[k].magic = 0u; sj[i].v[k].finished = 0u; sj[i].v[k].ignore = 0u; sj[i].vfail[k] = 0u; }   /* (the same in the record's own copies) */
+        sj[i].nbreak = 0u;
     }
 }
 
@@ -126,8 +127,10 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
  * workgroups of SEG_UNC_SMALL (unit, channel) pairs --, and the five walkers of an epoch's first unit */
 /* (the second bound asks for 8 waves per SIMD: the body's 100 SGPRs held it at 7 -- three workgroups of 8 waves per CU where LDS and threads allow four; with 78 + spills to
  *  vector lanes a batch of more workgroups than slots gains: 96 frames of 1080p 312 -> 301 ms, 128: 403 -> 392; 16 ... 64 frames within +-0.7 %) */
+/* `seeds` (round 6): the launcher offers the start from seeds (seg_unit_from_seeds decides per image, candidate and attempt); perb is then sized for whichever of the two
+ * bodies needs more workgroups (the exhaustive one: SEG_UNC pairs a workgroup against SEG_UNC_SEEDS) */
 template <int UNIT>
-__global__ __launch_bounds__(SEG_UNT, 8) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers)
+__global__ __launch_bounds__(SEG_UNT, 8) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers, int seeds)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
@@ -140,8 +143,14 @@ __global__ __launch_bounds__(SEG_UNT, 8) void seg_k_enum_unit(const SegJob *__re
     if (blockIdx.x < nb) {
         const unsigned k = blockIdx.x / perb, grp = blockIdx.x % perb;
         const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
+        const SegCtlView cv = seg_view_of(sj + blockIdx.y, par, (int)f);
+        if (seeds && seg_unit_from_seeds(j, *P, cv, (int)f, seeds)) {
+            if (grp * SEG_UNC_SEEDS >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
+            seg_enum_unit_body<SEG_SEED_LANES, SEG_UNIT, SEG_UNC_SEEDS, true>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
+            return;
+        }
         if (grp * SEG_UNC >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
-        seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
+        seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
     } else {
         const unsigned r = blockIdx.x - nb, f = r / pers ? 2u : 0u, grp = r % pers;
         if (grp * SEG_UNC_SMALL >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
@@ -180,7 +189,7 @@ template __global__ void seg_k_enum_seeded<1024>(const SegJob *__restrict__, con
 template __global__ void seg_k_enum<512>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
 template __global__ void seg_k_enum<1024>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
 template __global__ void seg_k_ctl<1>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
-template __global__ void seg_k_enum_unit<SEG_UNIT>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
+template __global__ void seg_k_enum_unit<SEG_UNIT>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned, int);
 template __global__ void seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>(const SegJob *__restrict__, const SegParams *__restrict__, int);
 template __global__ void seg_k_replay<SEG_REPLAY_NT_BATCH>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
 
@@ -283,9 +292,10 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
         const size_t enum_lds = (size_t)SEG_SM_ENUM_NT(nt);
         if (b.unit > 1 && !b.seeded) {
-            const unsigned perb = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
+            const unsigned pairs = ((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4, nc_min = b.seeds && SEG_UNC_SEEDS < SEG_UNC ? SEG_UNC_SEEDS : SEG_UNC;      /* (workgroups for whichever body takes fewer pairs each) */
+            const unsigned perb = (pairs + nc_min - 1) / nc_min, pers = (pairs + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
             const unsigned blocks = (small_ok ? 3 * perb + 2 * pers : SEG_NFILT * perb) + SEG_NFILT;
-            hipLaunchKernelGGL(seg_k_enum_unit<SEG_UNIT>, dim3(blocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers);
+            hipLaunchKernelGGL(seg_k_enum_unit<SEG_UNIT>, dim3(blocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers, b.seeds ? 1 : 0);
         } else
         if (b.seeded) {
             const unsigned sblocks = SEG_NFILT * b.max_nseg * halves + SEG_NFILT;

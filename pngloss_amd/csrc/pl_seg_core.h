@@ -134,6 +134,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_DEBUG_REPAIR
 #define SEG_DEBUG_REPAIR(f, c, sg, est, sid)
 #endif
+#ifndef SEG_DEBUG_BREAK
+#define SEG_DEBUG_BREAK(f, c, sg, est, y)   /* (the CPU harness can list where the chain kernel broke a row off: a unit whose entry state no enumerated state reached) */
+#endif
 #ifndef SEG_DEBUG_STATE
 #define SEG_DEBUG_STATE(f, k, sl, i, ps)   /* (the CPU harness can count the distinct states of a pair at every segment's end: how fast a unit's states keep merging) */
 #endif
@@ -153,6 +156,9 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #endif
 #ifndef SEG_UNC
 #define SEG_UNC 10               /* (unit, channel) pairs per workgroup of the unit enumeration (measured 9 / 10 / 11 / 12: 175.9 / 163.5 / 166.8 / 170.4 ms for 32 frames of 1080p: ~170 distinct states = three waves, and 80 pairs of a 1920-pixel row = 8 workgroups) */
+#endif
+#ifndef SEG_UNC_SEEDS
+#define SEG_UNC_SEEDS 16         /* (unit, channel) pairs per workgroup of the unit enumeration FROM SEEDS (SEG_SEED_LANES lanes a pair: two turns of eight pairs) */
 #endif
 #ifndef SEG_UNT
 #define SEG_UNT 512              /* its threads (512 against 1024, 1080p frames: 157.7 against 161.4 ms at 32, 249.2 against 281.4 at 64, 460.6 against 511.3 at 128: the CU starts four workgroups at once instead of two) */
@@ -205,6 +211,8 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_KA_SEEDED 4           /* steps every seed of the seeded enumeration takes before the distinct states go on alone */
 #endif
 #define SEG_KIN 32                /* most run-in pixels of the seeded enumeration (SegParams::kin: 16 .. 32 by the size of the carried terms) */
+#define SEG_SEED_LANES 64         /* lanes (most seeds) per (unit, channel) pair of the unit enumeration from seeds */
+#define SEG_SEED_KMAX 16          /* most run-in pixels there (SegParams::seed_kin) */
 #define SEG_EH 512                /* slots of a segment's entry hash (per channel); a key lives in the SEG_EHW slots from its bucket's first */
 #define SEG_EHW 8
 #define SEG_EH_WORDS (SEG_EH + SEG_EHW - 4)
@@ -243,6 +251,11 @@ struct SegParams {
     /* control kernel: workgroups that share the build of one candidate's decision tables: SEG_TPARTS (one image: the build is on the critical path of
      * every row), 1 for batches (a quarter of the control workgroups: what a batch pays for is workgroups, not the length of one) */
     int32_t tparts;
+    /* enumeration in units FROM SEEDS (round 6; batches, exhaustive state sets of at most 255 states; seg_enum_unit_body<.., SEEDS = true>): a unit is not started from
+     * every state at its first pixel but from seed_n seeds seed_kin pixels IN FRONT of it -- the states in which nothing was carried into the boundary pixel, one per diff
+     * of that pixel -- and what they have become at the unit's first pixel is its entry set; every other entry index maps to "none".  0: no such set (too many seeds). */
+    int32_t seed_n, seed_kin;
+    uint16_t seed_idx[SEG_SEED_LANES];   /* indices into the exhaustive state list */
 };
 
 /* ---- per-image control block, double buffered by attempt parity ---------------------------------------------------------- */
@@ -323,7 +336,8 @@ struct SegJob {
     uint32_t nseg, ngrp;
     SEG_AS_GLB SegJob *self;             /* where this record lives (device memory): the writers of the fields below */
     SegViewRec v[3];                     /* by attempt % 3 */
-    uint32_t vfail[3], vpad_;            /* bit f: candidate f's row of that attempt failed validation (= SegAcc::failmask) */
+    uint32_t vfail[3];                   /* bit f: candidate f's row of that attempt failed validation (= SegAcc::failmask) */
+    uint32_t nbreak;                     /* rows the chain kernel broke off because a unit's entry state was in no enumerated set (exhaustive state sets; seg_unit_from_seeds reads it) */
 };
 
 /* what belongs to row y (see SegJob) */
@@ -772,6 +786,27 @@ inline bool seg_build_exhaustive(SegParams &P, int strength, int bleed)
             }
         }
         P.ns_small = ok ? n2 : 0; P.small_ok = ok ? 1 : 0;
+    }
+    {
+        /* the seeds of the unit enumeration from seeds: nothing carried into the boundary pixel (carry 0, thr of the pixel before 0), one state per diff of that pixel.
+         * Measured on the reference's own trajectories (oracle/seed_study.c, profiles/r06_seed_study.txt): after a run-in of 8 pixels the true state at a boundary is among
+         * what they have become in all but 0 .. 2e-3 of the boundaries of photographic content; flat regions hold fixed points they miss (the launcher falls back). */
+        int n = 0; bool ok = ns <= 255;
+        for (int delta = -P.dmax; delta <= P.dmax && ok; delta++) {
+            /* one seed per left byte within reach: the diff of the boundary pixel that explains it with the least carried into that pixel (none for |delta| <= s) */
+            const int diff = seg_max(-strength, seg_min(strength, -delta));
+            const SegSplit sp = seg_split_slow(diff, bleed);
+            const int cn = sp.rem, th = sp.h;
+            if (seg_abs(delta) > P.dmax || seg_abs(cn) > P.cmax || seg_abs(th) > P.tmax) continue;
+            const uint16_t idx = P.keylut[((delta + P.dmax) * (2 * P.cmax + 1) + cn + P.cmax) * (2 * P.tmax + 1) + th + P.tmax];
+            if (idx == (uint16_t)SEG_INVALID) continue;
+            bool dup = false;
+            for (int q = 0; q < n; q++) dup |= P.seed_idx[q] == idx;
+            if (dup) continue;
+            if (n >= SEG_SEED_LANES) { ok = false; break; }
+            P.seed_idx[n++] = idx;
+        }
+        P.seed_n = ok ? n : 0; P.seed_kin = 8;
     }
     {
         const SegState z = { 0, 0, 0 };
@@ -1374,7 +1409,11 @@ PLS_HD uint32_t seg_bits_count(const uint32_t *bits, uint32_t a, uint32_t b)
     }
     return n;
 }
-template <int LANES, int UNIT, int NC>
+/* SEEDS (round 6): the first phase does not run every state from the unit's first pixel but P.seed_n seeds from P.seed_kin pixels in front of it; the states they have
+ * become at the unit's first pixel -- encoded relative to the boundary pixel like any exit state -- are the unit's entry set: dense ids in the order of the dedupe, the
+ * pair's entry map holds an id for their indices and "none" everywhere else (a row whose true state is none of them is broken off there by the chain kernel and resumed
+ * in an epoch: costs attempts, never correctness -- the validation is the ground truth either way).  LANES = SEG_SEED_LANES lanes a pair: eight pairs a turn. */
+template <int LANES, int UNIT, int NC, bool SEEDS = false>
 PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtlView &cv, int par, int f, int grp, unsigned char *smem)
 {
     if (cv.finished || cv.active != 1) return;
@@ -1389,18 +1428,24 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     const uint32_t sx = cv.start_x;
     /* an epoch that starts inside the row: the unit that holds its first pixel (and everything in front) is walked by seg_first_body */
     { const uint32_t ql = seg_umin(q0 + NC, ncombo) - 1u; if (sx && (ql / bpp) * UL <= sx) return; }
-    constexpr uint32_t NP1 = SEG_UN_K1MAX + 1;                /* records of a pair the first phase reads: the boundary pixel and SEG_K1 more */
+    constexpr uint32_t NP1 = SEEDS ? SEG_SEED_KMAX + 1 : SEG_UN_K1MAX + 1;   /* records of a pair the first phase reads: the boundary pixel and SEG_K1 more (SEEDS: the pixel in front of the run-in and the run-in) */
     uint32_t *tw = (uint32_t *)smem;
     uint32_t *lut = tw + SEG_TBL_WORDS;
     uint32_t *pool = lut + 512;                               /* [SEG_UPOOL] the distinct states of all pairs, pair behind pair */
-    SegPix *px1 = (SegPix *)(pool + SEG_UPOOL);               /* [NC][NP1]: one channel's first records of a pair, slot 0 = the boundary pixel in front of the unit */
-    uint32_t *misc = (uint32_t *)(px1 + SEG_UNC_SMALL * NP1); /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total),
+    SegPix *px1_std = (SegPix *)(pool + SEG_UPOOL);           /* [NC][NP1]: one channel's first records of a pair, slot 0 = the boundary pixel in front of the unit */
+    uint32_t *misc = (uint32_t *)(px1_std + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1)); /* [0] transparent pixel seen, [8 + kk] distinct states of the turn's pair kk, [32 + k] first pool slot of pair k (.. [32 + NC] = total),
                                                                  [64 + k] the same for the SECOND list (.. [64 + NC] = its total), [96 .. 127] one bit per lane: it represents a state of the second list */
     /* first phase: */
     uint32_t *ht = misc + 128;                                /* [CPR][HT] key or ~0 (this turn) */
     uint16_t *dense = (uint16_t *)(ht + 2 * SEG_UNT);         /* [CPR][HT] slot -> dense id */
     uint32_t *uniqr = (uint32_t *)(dense + 2 * SEG_UNT);      /* [CPR][LANES] this turn's distinct states by dense id */
     uint32_t *keys = uniqr + SEG_UNT;                         /* [NT] */
+    /* SEEDS: the run-in's records and the turn's entry maps, behind the first phase's scratch (the region is as large as the second phase's records) */
+    SegPix *px1 = SEEDS ? (SegPix *)(keys + SEG_UNT) : px1_std;
+    uint16_t *mapl = (uint16_t *)(px1 + NC * NP1);            /* (SEEDS) [CPR][256]: entry index -> dense id of the turn's pairs, staged here and stored coalesced */
+    static_assert(!SEEDS || (SEG_UN_SCRATCH + NC * (int)NP1 * 8 + CPR * 512 <= (SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2)), "the run-in's records and the staged maps fit behind the scratch");
+    static_assert(!SEEDS || LANES == SEG_SEED_LANES, "one lane per seed");
+    const int KR = SEEDS ? seg_min(seg_max(P.seed_kin, 1), SEG_SEED_KMAX) : 0;
     /* second phase, in the same place: */
     SegPix *px = (SegPix *)(misc + 128);                      /* [NC][NPX]: all records of a pair */
     uint32_t *pool2 = (uint32_t *)(px + SEG_UNPX);            /* [SEG_UPOOL] the states that are still distinct behind the unit's first segment, at the pairs' places of the first list */
@@ -1427,8 +1472,8 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
         {
             const uint32_t k = (uint32_t)tid / NP1, pq = (uint32_t)tid % NP1, cq = q0 + k;
             if (k < (uint32_t)NC && cq < ncombo) {
-                const uint32_t u = cq / bpp, c = cq % bpp, x = u * UL + pq - 1u;          /* (pq = 0 in front of the row: wraps beyond W -- a zero record) */
-                if (x < W) vp = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
+                const uint32_t u = cq / bpp, c = cq % bpp, x = SEEDS ? u * UL + pq - 1u - (uint32_t)KR : u * UL + pq - 1u;          /* (pq = 0 in front of the row: wraps beyond W -- a zero record; SEEDS: slot 0 = the pixel in front of the run-in, slot KR = the boundary pixel) */
+                if (x < W && (!SEEDS || pq <= (uint32_t)KR)) vp = seg_pix_load(row, nab, e0g, bpp, x, (int)c);
             }
         }
         PLS_UNROLL
@@ -1439,14 +1484,69 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     PLS_SYNC();
     const bool trx1 = misc[0] != 0u;
     if (prof) te[1] = PLS_CLOCK();
-    const int K1 = seg_k1(nstates);
+    const int K1 = SEEDS ? 0 : seg_k1(nstates);
     /* -- first phase, a turn of CPR pairs at a time: SEG_K1 steps from every state, the dedupe, the pair's entry map (entry index -> dense id) -- */
     for (int r = 0; r < ROUNDS; r++) {
         PLS_THREADS(tid, NT) {
             for (int i = tid; i < CPR * HT; i += NT) ht[i] = 0xffffffffu;
             if (tid < CPR) misc[8 + tid] = 0u;
+            if (SEEDS) for (int i = tid; i < CPR * 128; i += NT) ((uint32_t *)mapl)[i] = 0xffffffffu;
         }
         PLS_SYNC();
+        if (SEEDS) {
+            /* the seeds through the run-in; key = the state at the unit's first pixel | its entry index << 24 (ns <= 255: no key is all ones) */
+            PLS_THREADS(tid, NT) {
+                const int kk = tid / LANES, k = r * CPR + kk, i = tid % LANES;
+                const uint32_t cq = q0 + (uint32_t)k;
+                uint32_t key = 0xffffffffu;
+                if (kk < CPR && k < NC && cq < ncombo && !(sx && (cq / bpp) * UL <= sx)) {
+                    const SegPix *pk = px1 + (size_t)k * NP1;
+                    if (cq / bpp == 0u) { if (i == 0) key = P.idx0_big << 24; }        /* the row's first unit: its one entry state is known (nothing carried, no left pixel) */
+                    else if (i < P.seed_n) {
+                        SegState st;
+                        if (seg_state_decode(P, (int)P.seed_idx[i], pk[0], st)) {
+                            const int bad = seg_run_fast_f(f, trx1, pk + 1, 1, KR, st, SEG_LDS_CU32(tw), SEG_LDS_CU8(tw + 4 * SEG_TN), G, SEG_LDS_CU32(lut));
+                            const uint32_t idx = bad ? (uint32_t)SEG_INVALID : seg_state_encode(P, pk[KR], st);
+                            if (idx != (uint32_t)SEG_INVALID) key = (uint32_t)(st.left & 255) | ((uint32_t)(st.cn & 255) << 8) | ((uint32_t)(st.th & 255) << 16) | (idx << 24);
+                        }
+                    }
+                }
+                keys[tid] = key;
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, NT) {
+                const int kk = tid / LANES, i = tid % LANES;
+                const uint32_t key = keys[tid];
+                if (kk < CPR && key != 0xffffffffu && (i == 0 || keys[tid - 1] != key)) {
+                    uint32_t h = ((key * 0x9E3779B1u) >> 16) & (uint32_t)(HT - 1);
+                    for (int probe = 0; probe < HT; probe++) {
+                        const uint32_t old = PLS_ATOMIC_CAS(&ht[kk * HT + h], 0xffffffffu, key);
+                        if (old == 0xffffffffu) {
+                            const uint32_t d = PLS_ATOMIC_ADD_RET(&misc[8 + kk], 1u);
+                            dense[kk * HT + h] = (uint16_t)d;
+                            uniqr[kk * LANES + d] = key;
+                            mapl[kk * 256 + (key >> 24)] = (uint16_t)d;
+                            break;
+                        }
+                        if (old == key) break;
+                        h = (h + 1) & (uint32_t)(HT - 1);
+                    }
+                }
+            }
+            PLS_SYNC();
+            PLS_THREADS(tid, NT) {
+                /* the turn's entry maps, whole (every index the seeds did not reach: none) */
+                for (int e = tid; e < CPR * 128; e += NT) {
+                    const int kk = e >> 7, w = e & 127, k = r * CPR + kk;
+                    const uint32_t cq = q0 + (uint32_t)k;
+                    if (k < NC && cq < ncombo && !(sx && (cq / bpp) * UL <= sx) && 2 * w < P.nsp) {
+                        const uint32_t u = cq / bpp, c = cq % bpp;
+                        ((SEG_AS_GLB uint32_t *)(j.maps + (((size_t)f * nseg + (size_t)u * E) * 4 + c) * (size_t)P.nsp))[w] = ((const uint32_t *)mapl)[e];
+                    }
+                }
+            }
+            PLS_SYNC();
+        } else
         for (int i0 = 0; i0 < nstates; i0 += LANES) {
             PLS_THREADS(tid, NT) {
                 const int kk = tid / LANES, k = r * CPR + kk, i = i0 + tid % LANES;
@@ -1673,6 +1773,17 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
             }
         }
     }
+}
+
+/* Does candidate f's enumeration of this attempt start its units FROM SEEDS (seg_enum_unit_body<.., SEEDS = true>) -- when the launcher offers it (seeds != 0: a batch
+ * composed in units whose (strength, bleed) pair has a seed set) -- or from every state?  From every state (1) in an EPOCH: a row that was broken off because its true state
+ * sits in a cycle the seeds do not reach (a periodic pattern, a flat region) would be broken off again at the next unit, and again -- two attempts a unit; the exhaustive
+ * start finishes the row in one go; and (2) for the rest of an image whose rows keep breaking (more than one row in sixteen, and eight to begin with): flat, few-coloured
+ * content is full of such fixed points (oracle/seed_study.c on the suite's dice / tux: one boundary in a hundred).  Uniform over the workgroup, deterministic (nbreak is
+ * written by the chain kernels of earlier attempts only), and either way the validation is the ground truth. */
+PLS_HD bool seg_unit_from_seeds(const SegJob &j, const SegParams &P, const SegCtlView &cv, int f, int seeds)
+{
+    return seeds != 0 && P.seed_n > 0 && !seg_is_small(P, f) && cv.start_x == 0u && j.nbreak * 16u <= cv.y + 128u;
 }
 
 /* frozen histogram of candidate f in this attempt: H0 + base[f] */
@@ -2211,7 +2322,9 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                 PLS_THREADS(tid, CT) {
                     if (tid == 0) {
                         SEG_DEBUG_COUNT(2, fb);
+                        SEG_DEBUG_BREAK(f, c, sgb, estb, cv.y);
                         idxb[24]++;
+                        PLS_ATOMIC_ADD(&j.self->nbreak, 1u);
                         dnout[(size_t)sgb * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgb * 4] = estb;
                         const uint32_t xfail = (sgb + 1u) * SEG_L;
                         if ((kqb < ns || E > 1u) && xfail < W) {

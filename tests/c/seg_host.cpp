@@ -23,6 +23,9 @@ static void seg_debug_row(int kind, unsigned failed, int winner, int start_none)
     }
 }
 #define SEG_DEBUG_ROW(kind, failed, winner, start_none) seg_debug_row((kind), (failed), (winner), (start_none))
+#include <cstdio>
+#include <cstdlib>
+#define SEG_DEBUG_BREAK(f, c, sg, est, y) do { if (getenv("SEG_HOST_VERBOSE") && atoi(getenv("SEG_HOST_VERBOSE")) > 1) fprintf(stderr, "seg_host: row %u broken off: candidate %d channel %d segment %u, entry state left %u cn %d th %d\n", (unsigned)(y), (int)(f), (int)(c), (unsigned)(sg), (unsigned)((est) & 255u), (int)(((est) >> 8) & 0xffffu) - 32768, (int)((est) >> 24) - 128); } while (0)
 #include "../../pngloss_amd/csrc/pl_seg_core.h"
 
 #include <cstdio>
@@ -109,6 +112,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     j.rowmm = A.take<int32_t>(4);
     std::vector<unsigned char> smem(160 * 1024, 0x5A);
     const int ncommit = (int)((W + SEG_COMMIT_W - 1) / SEG_COMMIT_W);
+    j.nbreak = 0u;
     j.self = &j; for (int k = 0; k < 3; k++) { j.v[k].magic = 0u; j.v[k].finished = 0u; j.v[k].ignore = 0u; j.vfail[k] = 0u; }
     j.ctl[2].magic = 0u; j.acc[2].failmask = 0u;   /* (seg_k_resolve does this on the device: the first attempt finds no attempt behind it) */
     int attempt = 0;
@@ -135,9 +139,13 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         if (P.unit > 1) {
             /* pl_seg.hip:seg_k_enum_unit: per candidate `per` workgroups of SEG_UNC (unit, channel) pairs, then the five walkers -- with the kernel's LDS size */
             std::vector<unsigned char> usm((size_t)SEG_SM_ENUM_UNIT, 0x5A);
+            const bool seeds = getenv("SEG_HOST_SEEDS") != nullptr && atoi(getenv("SEG_HOST_SEEDS")) && P.seed_n > 0;     /* the first phase from seeds with a run-in (round 6) */
+            if (seeds && getenv("SEG_HOST_SEED_KIN")) P.seed_kin = atoi(getenv("SEG_HOST_SEED_KIN"));
+            const uint32_t perseed = (((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC_SEEDS - 1) / SEG_UNC_SEEDS;
             const uint32_t perb = (((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC - 1) / SEG_UNC, pers = (((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * 4 + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;
             for (int f = 0; f < SEG_NFILT; f++) {
                 if (seg_is_small(P, f)) { for (uint32_t g = 0; g < pers; g++) if (g * SEG_UNC_SMALL < ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) seg_enum_unit_body<SEG_NSS, SEG_UNIT, SEG_UNC_SMALL>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
+                else if (seeds && seg_unit_from_seeds(j, P, seg_ctl_view(j, par, f), f, 1)) { for (uint32_t g = 0; g < perseed; g++) if (g * SEG_UNC_SEEDS < ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) seg_enum_unit_body<SEG_SEED_LANES, SEG_UNIT, SEG_UNC_SEEDS, true>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
                 else { for (uint32_t g = 0; g < perb; g++) if (g * SEG_UNC < ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, P, seg_ctl_view(j, par, f), par, f, (int)g, usm.data()); }
             }
             for (int f = 0; f < SEG_NFILT; f++) seg_first_body<SEG_UNT, true>(j, P, seg_ctl_view(j, par, f), par, f, usm.data());

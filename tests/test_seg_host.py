@@ -211,6 +211,56 @@ def test_seg_engine_enumeration_in_units_matches_oracle(monkeypatch, w, h, mode,
     assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
 
 
+@pytest.mark.parametrize("w,h,mode,s,b", UNIT_CASES + [(1920, 24, 0, 19, 2), (700, 30, 1, 19, 2), (513, 20, 5, 19, 2), (900, 16, 0, 12, 1), (1600, 10, 0, 7, 3), (640, 12, 0, 31, 8)])
+def test_seg_engine_units_from_seeds_match_oracle(monkeypatch, w, h, mode, s, b):
+    """Round 6: the units of a batch start FROM SEEDS -- one per left byte within reach of the data, a run-in of eight pixels in front of the unit -- instead of from every
+    state at the unit's first pixel (seg_enum_unit_body<.., SEEDS = true>; SEG_HOST_SEEDS=1 is what the launcher offers for every (strength, bleed) pair with a seed set).
+    Every class, widths around a unit and around a workgroup's sixteen pairs, rows that need epochs (started exhaustively), the strength retry, transparent pixels in the
+    run-in, pairs whose seeds fall outside 0..255."""
+    monkeypatch.setenv("SEG_HOST_UNIT", "1")
+    monkeypatch.setenv("SEG_HOST_SEEDS", "1")
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+
+
+def test_seg_engine_units_from_seeds_cost_few_attempts_and_a_stuck_row_one_break(monkeypatch):
+    """What a seed set that misses a state costs is attempts, and the count is pinned: on photographic rows the seeds find every entry state (as many attempts as the
+    start from every state, +-2); the 60-row frame of the generator has ONE row whose alpha channel -- a sawtooth of period 32 -- keeps candidate sub in a cycle no seed
+    reaches at ten unit boundaries in a row: the row is broken off ONCE and its epoch starts from every state (seg_unit_from_seeds), so the frame takes 74 attempts
+    against 70 -- not 92, which is what ten breaks cost before epochs started exhaustively."""
+    monkeypatch.setenv("SEG_HOST_UNIT", "1")
+    res = {}
+    for (w, h) in [(1024, 96), (1920, 60)]:
+        img = P.synth_rgba(w, h, 0, 0)
+        want, wf = U.run_port(img, 19, 2)
+        for seeds in ("0", "1"):
+            monkeypatch.setenv("SEG_HOST_SEEDS", seeds)
+            rc, out, f, st = U.run_seg_host(img, 19, 2)
+            assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+            res[(w, seeds)] = int(st[0])
+    assert abs(res[(1024, "1")] - res[(1024, "0")]) <= 2, res
+    assert res[(1920, "1")] <= res[(1920, "0")] + 6, res
+
+
+def test_seg_engine_units_from_seeds_fall_back_on_flat_content(monkeypatch):
+    """Flat, few-coloured content is full of fixed points the seeds do not reach (oracle/seed_study.c on the suite's dice and tux: one unit boundary in a hundred): an image
+    whose rows keep breaking goes back to the start from every state for good (seg_unit_from_seeds: more than eight breaks and one row in sixteen) -- exact either way, and
+    the attempts stay within a quarter of the exhaustive start's."""
+    monkeypatch.setenv("SEG_HOST_UNIT", "1")
+    g = U.load_npz("suite_small.npz")
+    img = np.ascontiguousarray(g["tux/in"])
+    want, wf = g["tux/out"], g["tux/filters"]
+    res = {}
+    for seeds in ("0", "1"):
+        monkeypatch.setenv("SEG_HOST_SEEDS", seeds)
+        rc, out, f, st = U.run_seg_host(img, 19, 2)
+        assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+        res[seeds] = int(st[0])
+    assert res["1"] <= res["0"] * 5 // 4 + 8, res
+
+
 @pytest.mark.parametrize("filters", [True, False])
 def test_seg_engine_units_cost_no_attempts(monkeypatch, filters):
     """the attempt count is what a wrong map, id or entry state would show in (the validation makes the bytes right whatever happens): enumeration in units
