@@ -50,6 +50,7 @@ struct PlHooks {
     int enum_nt = 0;             /* PNGLOSS_HIP_ENUM_NT: 512 / 1024 */
     int kin = -1;                /* PNGLOSS_HIP_KIN: run-in pixels of the seeded enumeration */
     int seg_seeds = -1;          /* PNGLOSS_HIP_SEG_SEEDS: 0 = units start from every state, as in round 5 (-1 / 1: from seeds where the pair has a seed set) */
+    int seg_seeds1 = -1;         /* PNGLOSS_HIP_SEG_SEEDS1: 0 / 1 pins the per-segment enumeration from seeds (seg_k_enum_unit<1>; -1: batches of two or more images) */
     int seed_kin = -1;           /* PNGLOSS_HIP_SEED_KIN: run-in pixels of the units' seeds (1 .. SEG_SEED_KMAX) */
     bool segprof = false;        /* PNGLOSS_HIP_SEGPROF: phase clocks inside the kernels (slows them down) */
     bool debug = false;          /* PNGLOSS_HIP_DEBUG */
@@ -68,6 +69,7 @@ struct PlHooks {
         h.enum_nt = num("PNGLOSS_HIP_ENUM_NT", 0);
         h.kin = num("PNGLOSS_HIP_KIN", -1);
         h.seg_seeds = num("PNGLOSS_HIP_SEG_SEEDS", -1);
+        h.seg_seeds1 = num("PNGLOSS_HIP_SEG_SEEDS1", -1);
         h.seed_kin = num("PNGLOSS_HIP_SEED_KIN", -1);
         h.segprof = std::getenv("PNGLOSS_HIP_SEGPROF") != nullptr;
         h.debug = std::getenv("PNGLOSS_HIP_DEBUG") != nullptr;
@@ -410,6 +412,9 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         b.unit = (uint32_t)ctx->h_seg_params.unit;
         /* round 6: units start from seeds with a run-in where the (strength, bleed) pair has a seed set (PNGLOSS_HIP_SEG_SEEDS=0 / 1 pins it for tests and timing; same bytes) */
         b.seeds = b.unit > 1 && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0;
+        /* ... and a batch of two or more images below that size goes segment by segment from seeds, through the same bodies (seg_k_enum_unit<1>; PNGLOSS_HIP_SEG_SEEDS1=0 / 1 pins it) */
+        if (b.unit == 1 && !params.seeded && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0 && ctx->h_seg_params.ns <= SEG_NSP)
+            b.seeds = ctx->hooks.seg_seeds1 >= 0 ? ctx->hooks.seg_seeds1 != 0 : n >= 2;
         b.tparts = (uint32_t)ctx->h_seg_params.tparts;
         b.enum_nt = (size_t)b.max_nseg * b.n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;     /* (the images of THIS group: gridDim.y of its launches) */
         if (ctx->hooks.enum_nt == 512 || ctx->hooks.enum_nt == 1024) b.enum_nt = (uint32_t)ctx->hooks.enum_nt;   /* test hook */

@@ -128,33 +128,38 @@ __global__ __launch_bounds__(NT) void seg_k_enum_seeded(const SegJob *__restrict
 /* (the second bound asks for 8 waves per SIMD: the body's 100 SGPRs held it at 7 -- three workgroups of 8 waves per CU where LDS and threads allow four; with 78 + spills to
  *  vector lanes a batch of more workgroups than slots gains: 96 frames of 1080p 312 -> 301 ms, 128: 403 -> 392; 16 ... 64 frames within +-0.7 %) */
 /* `seeds` (round 6): the launcher offers the start from seeds (seg_unit_from_seeds decides per image, candidate and attempt); perb is then sized for whichever of the two
- * bodies needs more workgroups (the exhaustive one: SEG_UNC pairs a workgroup against SEG_UNC_SEEDS) */
+ * bodies needs more workgroups (the exhaustive one: SEG_UNC pairs a workgroup against SEG_UNC_SEEDS).
+ * UNIT = SEG_UNIT: batches composed in units.  UNIT = 1 (round 6): the SAME bodies segment by segment -- (segment, channel) pairs, sixteen a workgroup, each started from
+ * seeds eight pixels in front of it -- for small and mid-size batches, whose attempts are bound by the enumeration's dependent path, not by its work: 8 + 32 dependent
+ * steps instead of 8 + 96, a twentieth of the workgroups of seg_k_enum (one per segment and channel pair, every segment from all 253 states). */
 template <int UNIT>
 __global__ __launch_bounds__(SEG_UNT, 8) void seg_k_enum_unit(const SegJob *__restrict__ sj, const SegParams *__restrict__ P, int par, unsigned perb, unsigned pers, int seeds)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     const SegJob j = sj[blockIdx.y];
     const bool small_ok = P->small_ok != 0;
+    constexpr int NCS = SEG_UNC_SMALL_OF(UNIT);
     const unsigned nbig = small_ok ? 3u : 5u, nb = nbig * perb, ns = small_ok ? 2u * pers : 0u;
     if (blockIdx.x >= nb + ns) {
-        seg_first_body<SEG_UNT, true>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - nb - ns)), par, (int)(blockIdx.x - nb - ns), seg_smem);
+        seg_first_body<SEG_UNT, (UNIT > 1)>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)(blockIdx.x - nb - ns)), par, (int)(blockIdx.x - nb - ns), seg_smem);
         return;
     }
+    const unsigned npairs = ((j.nseg + UNIT - 1) / UNIT) * j.bpp;
     if (blockIdx.x < nb) {
         const unsigned k = blockIdx.x / perb, grp = blockIdx.x % perb;
         const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
         const SegCtlView cv = seg_view_of(sj + blockIdx.y, par, (int)f);
         if (seeds && seg_unit_from_seeds(j, *P, cv, (int)f, seeds)) {
-            if (grp * SEG_UNC_SEEDS >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
-            seg_enum_unit_body<SEG_SEED_LANES, SEG_UNIT, SEG_UNC_SEEDS, true>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
+            if (grp * SEG_UNC_SEEDS >= npairs) return;
+            seg_enum_unit_body<SEG_SEED_LANES, UNIT, SEG_UNC_SEEDS, true>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
             return;
         }
-        if (grp * SEG_UNC >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
-        seg_enum_unit_body<SEG_NSP, SEG_UNIT, SEG_UNC>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
+        if (grp * SEG_UNC >= npairs) return;
+        seg_enum_unit_body<SEG_NSP, UNIT, SEG_UNC>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
     } else {
         const unsigned r = blockIdx.x - nb, f = r / pers ? 2u : 0u, grp = r % pers;
-        if (grp * SEG_UNC_SMALL >= ((j.nseg + SEG_UNIT - 1) / SEG_UNIT) * j.bpp) return;
-        seg_enum_unit_body<SEG_NSS, SEG_UNIT, SEG_UNC_SMALL>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
+        if (grp * NCS >= npairs) return;
+        seg_enum_unit_body<SEG_NSS, UNIT, NCS>(j, *P, seg_view_of(sj + blockIdx.y, par, (int)f), par, (int)f, (int)grp, seg_smem);
     }
 }
 
@@ -192,6 +197,9 @@ template __global__ void seg_k_ctl<1>(const SegJob *__restrict__, const SegParam
 template __global__ void seg_k_enum_unit<SEG_UNIT>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned, int);
 template __global__ void seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>(const SegJob *__restrict__, const SegParams *__restrict__, int);
 template __global__ void seg_k_replay<SEG_REPLAY_NT_BATCH>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
+#if SEG_UNIT != 1
+template __global__ void seg_k_enum_unit<1>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned, int);      /* (round 6; behind the pinned kernels) */
+#endif
 
 /* seeded state sets: the dense transitions of the enumerated segments, between the enumeration and the chain (seg_gather_seeded_body); 5 x 4 x nblk workgroups.
  * (behind the pinned kernels: it joins the code object at its end) */
@@ -291,6 +299,13 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const unsigned nt = b.enum_nt, halves = 4 / (nt / SEG_NSP), small_segs = nt / (4 * SEG_NSS);
         const unsigned blocks = (small_ok ? 3 * b.max_nseg * halves + 2 * ((b.max_nseg + small_segs - 1) / small_segs) : SEG_NFILT * b.max_nseg * halves) + SEG_NFILT;
         const size_t enum_lds = (size_t)SEG_SM_ENUM_NT(nt);
+        if (b.unit == 1 && b.seeds && !b.seeded) {
+            /* (round 6) small and mid-size batches: segment by segment, from seeds, through the unit enumeration's bodies */
+            const unsigned pairs = b.max_nseg * 4, nc_min = SEG_UNC_SEEDS < SEG_UNC ? SEG_UNC_SEEDS : SEG_UNC;
+            const unsigned perb = (pairs + nc_min - 1) / nc_min, pers = (pairs + SEG_UNC_SMALL_OF(1) - 1) / SEG_UNC_SMALL_OF(1);
+            const unsigned ublocks = (small_ok ? 3 * perb + 2 * pers : SEG_NFILT * perb) + SEG_NFILT;
+            hipLaunchKernelGGL(seg_k_enum_unit<1>, dim3(ublocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers, 1);
+        } else
         if (b.unit > 1 && !b.seeded) {
             const unsigned pairs = ((b.max_nseg + SEG_UNIT - 1) / SEG_UNIT) * 4, nc_min = b.seeds && SEG_UNC_SEEDS < SEG_UNC ? SEG_UNC_SEEDS : SEG_UNC;      /* (workgroups for whichever body takes fewer pairs each) */
             const unsigned perb = (pairs + nc_min - 1) / nc_min, pers = (pairs + SEG_UNC_SMALL - 1) / SEG_UNC_SMALL;

@@ -1386,6 +1386,7 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCt
 #ifndef SEG_UNC_SMALL
 #define SEG_UNC_SMALL (SEG_UNIT <= 3 ? 20 : (SEG_UNIT <= 4 ? 15 : (SEG_UNIT <= 6 ? 10 : 7)))          /* (unit, channel) pairs per workgroup for none / up with their small state set */
 #endif
+#define SEG_UNC_SMALL_OF(unit) ((unit) == SEG_UNIT ? SEG_UNC_SMALL : (SEG_UNC_SMALL < 20 ? SEG_UNC_SMALL : 20))      /* ... and segment by segment (round 6: seg_k_enum_unit<1>) */
 #define SEG_UNPX (SEG_UNC_SMALL * (SEG_UNIT * SEG_L + 1))   /* pixel records of a workgroup's pairs */
 /* LDS of the unit enumeration: tables, split table, the pool, the first records of every pair, bookkeeping -- and ONE region that holds the first phase's
  * scratch (hash tables, per-turn lists, keys: 10 KB) and then, for the second phase, the pairs' full pixel records (15.5 KB for the twenty pairs of none / up):

@@ -136,6 +136,20 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
         /* the enumeration kernel is launched with exactly SEG_SM_ENUM_NT(nt) bytes of LDS: the bodies get a buffer of that size here, and the
          * sanitizer build (tests/test_seg_host.py) sees any byte they touch beyond it */
         std::vector<unsigned char> esm((size_t)SEG_SM_ENUM_NT(nt), 0x5A);
+        const bool seeds1 = P.unit == 1 && !P.seeded && P.ns <= SEG_NSP && P.seed_n > 0 && getenv("SEG_HOST_SEEDS") != nullptr && atoi(getenv("SEG_HOST_SEEDS")) != 0;
+        if (seeds1) {
+            /* pl_seg.hip:seg_k_enum_unit<1> (round 6: small and mid-size batches): the unit enumeration's bodies segment by segment, started from seeds */
+            if (getenv("SEG_HOST_SEED_KIN")) P.seed_kin = atoi(getenv("SEG_HOST_SEED_KIN"));
+            std::vector<unsigned char> usm((size_t)SEG_SM_ENUM_UNIT, 0x5A);
+            const uint32_t npairs = j.nseg * j.bpp;
+            for (int f = 0; f < SEG_NFILT; f++) {
+                const SegCtlView cv = seg_ctl_view(j, par, f);
+                if (seg_is_small(P, f)) { for (uint32_t g = 0; g * SEG_UNC_SMALL_OF(1) < npairs; g++) seg_enum_unit_body<SEG_NSS, 1, SEG_UNC_SMALL_OF(1)>(j, P, cv, par, f, (int)g, usm.data()); }
+                else if (seg_unit_from_seeds(j, P, cv, f, 1)) { for (uint32_t g = 0; g * SEG_UNC_SEEDS < npairs; g++) seg_enum_unit_body<SEG_SEED_LANES, 1, SEG_UNC_SEEDS, true>(j, P, cv, par, f, (int)g, usm.data()); }
+                else { for (uint32_t g = 0; g * SEG_UNC < npairs; g++) seg_enum_unit_body<SEG_NSP, 1, SEG_UNC>(j, P, cv, par, f, (int)g, usm.data()); }
+            }
+            for (int f = 0; f < SEG_NFILT; f++) seg_first_body<SEG_UNT, false>(j, P, seg_ctl_view(j, par, f), par, f, usm.data());
+        } else
         if (P.unit > 1) {
             /* pl_seg.hip:seg_k_enum_unit: per candidate `per` workgroups of SEG_UNC (unit, channel) pairs, then the five walkers -- with the kernel's LDS size */
             std::vector<unsigned char> usm((size_t)SEG_SM_ENUM_UNIT, 0x5A);
@@ -167,7 +181,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
                 else for (uint32_t sg = 0; sg < j.nseg; sg++) seg_enum_body<1024>(j, P, seg_ctl_view(j, par, f), par, f, (int)sg, 0, esm.data());
             }
         }
-        if (P.unit <= 1) for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
+        if (P.unit <= 1 && !seeds1) for (int f = 0; f < SEG_NFILT; f++) { if (nt == 512) seg_first_body<512, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); else seg_first_body<1024, false>(j, P, seg_ctl_view(j, par, f), par, f, esm.data()); }
         if (P.seeded && j.nseg > 1) {   /* the gather kernel of seeded sets: every (filter, channel, block of segments) */
             const unsigned nblk = (j.nseg - 1 + SEG_GS - 1) / SEG_GS;
             for (int f = 0; f < SEG_NFILT; f++) for (int c = 0; c < 4; c++) for (unsigned b = 0; b < nblk; b++) seg_gather_seeded_body(j, seg_ctl_view(j, par, f), f, c, (int)b);

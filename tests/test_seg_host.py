@@ -225,6 +225,19 @@ def test_seg_engine_units_from_seeds_match_oracle(monkeypatch, w, h, mode, s, b)
     assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
 
 
+@pytest.mark.parametrize("w,h,mode,s,b", [(1024, 24, 0, 19, 2), (700, 30, 1, 19, 2), (513, 20, 5, 19, 2), (385, 20, 2, 19, 2), (289, 20, 3, 19, 2), (193, 20, 4, 19, 2), (95, 7, 0, 19, 2),
+                                          (33, 9, 1, 19, 2), (1600, 10, 0, 7, 3), (900, 16, 0, 12, 1), (640, 12, 0, 31, 8), (2100, 5, 0, 19, 2)])
+def test_seg_engine_segments_from_seeds_match_oracle(monkeypatch, w, h, mode, s, b):
+    """Round 6, small and mid-size batches (pl_seg.hip:seg_k_enum_unit<1>): the unit enumeration's bodies SEGMENT BY SEGMENT -- (segment, channel) pairs, sixteen a
+    workgroup, each started from seeds eight pixels in front of it -- with the per-segment chain, replay and control kernels of one image."""
+    monkeypatch.setenv("SEG_HOST_UNIT", "0")
+    monkeypatch.setenv("SEG_HOST_SEEDS", "1")
+    img = P.synth_rgba(w, h, mode, 0)
+    rc, out, f, st = U.run_seg_host(img, s, b)
+    want, wf = U.run_port(img, s, b)
+    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
+
+
 def test_seg_engine_units_from_seeds_cost_few_attempts_and_a_stuck_row_one_break(monkeypatch):
     """What a seed set that misses a state costs is attempts, and the count is pinned: on photographic rows the seeds find every entry state (as many attempts as the
     start from every state, +-2); the 60-row frame of the generator has ONE row whose alpha channel -- a sawtooth of period 32 -- keeps candidate sub in a cycle no seed
