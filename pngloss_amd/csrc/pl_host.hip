@@ -357,6 +357,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     auto group_of = [&](size_t i) { int g = 0; while (g + 1 < ngroups && i >= gfirst[g + 1]) g++; return g; };
     ctx->h_sj.assign(n, SegJob{});
     ctx->h_seg_params = params;
+    size_t seg_total = 0;
     {
         /* Enumeration in UNITS of SEG_UNIT segments (seg_enum_unit_body): less than half the instructions per row, a dependent path SEG_UNIT times as long.
          * It pays when the batch is what keeps the GPU busy, not the latency of one row: from a handful of images on.  Results do not depend on it (the
@@ -364,7 +365,9 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         size_t segs = 0;
         for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
         const bool can = !params.seeded && params.ns <= SEG_NSP;       /* (state sets of one chunk of lanes: with more, the distinct states of a workgroup's pairs outgrow its lanes) */
-        bool units = can && segs > SEG_UNIT_MIN_SEGS;
+        const bool have_seeds = can && params.seed_n > 0 && ctx->hooks.seg_seeds != 0;
+        bool units = can && segs > (have_seeds ? (size_t)SEG_UNIT_MIN_SEGS_SEEDS : (size_t)SEG_UNIT_MIN_SEGS);     /* (with seeds the per-segment enumeration stays ahead up to sixteen 1080p frames: pl_seg_core.h) */
+        seg_total = segs;
         if (ctx->hooks.seg_unit >= 0) units = can && ctx->hooks.seg_unit != 0;
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
         ctx->h_seg_params.tparts = units ? 1 : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
@@ -414,7 +417,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         b.seeds = b.unit > 1 && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0;
         /* ... and a batch of two or more images below that size goes segment by segment from seeds, through the same bodies (seg_k_enum_unit<1>; PNGLOSS_HIP_SEG_SEEDS1=0 / 1 pins it) */
         if (b.unit == 1 && !params.seeded && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0 && ctx->h_seg_params.ns <= SEG_NSP)
-            b.seeds = ctx->hooks.seg_seeds1 >= 0 ? ctx->hooks.seg_seeds1 != 0 : n >= 2;
+            b.seeds = ctx->hooks.seg_seeds1 >= 0 ? ctx->hooks.seg_seeds1 != 0 : (n >= 2 && seg_total >= SEG_SEEDS1_MIN_SEGS);
         b.tparts = (uint32_t)ctx->h_seg_params.tparts;
         b.enum_nt = (size_t)b.max_nseg * b.n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;     /* (the images of THIS group: gridDim.y of its launches) */
         if (ctx->hooks.enum_nt == 512 || ctx->hooks.enum_nt == 1024) b.enum_nt = (uint32_t)ctx->hooks.enum_nt;   /* test hook */
@@ -533,6 +536,11 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
              * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
             const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
             auto attempt_us = [&](double wgs, double segs, size_t k) {
+                const bool have_seeds = can_units && seg_params.seed_n > 0 && hk.seg_seeds != 0;
+                /* round 6, from seeds (per row of the tallest image, epochs included; 1080p frames, profiles/r06_seeds.txt): units 24 / 32 / 64 / 128 frames 105 / 114 / 168 / 301 us,
+                 * segment by segment 6 / 11 / 16 frames 61 / 76 / 90 us -- 128 frames 325 ms against 373 on the other engine, the crossover near 148 */
+                if (have_seeds && segs > SEG_UNIT_MIN_SEGS_SEEDS) return std::max(100.0, 35.0 + 0.00945 * wgs);
+                if (have_seeds && k >= 2 && segs >= SEG_SEEDS1_MIN_SEGS) return 43.0 + 0.0134 * wgs;
                 if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(100.0, 28.0 + 0.0124 * wgs);   /* (three launch groups, validation in whole replay groups: 16 / 64 / 96 / 112 / 128 frames of 1080p 102 / 205 / 289 / 333 / 377 us: the segment engine up to 116 such frames -- measured: 112 frames 361 against 372 ms, 120 frames 385 against 372) */
                 /* (two or more images run as two launch sequences side by side: 4 / 8 / 12 frames of 1080p 58 / 80 / 102 us per attempt, profiles/r05_suite_groups.txt) */
                 if (k >= 2 && !seg_params.seeded) return 35.0 + 0.026 * wgs;

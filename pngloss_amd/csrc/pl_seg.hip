@@ -150,8 +150,8 @@ __global__ __launch_bounds__(SEG_UNT, 8) void seg_k_enum_unit(const SegJob *__re
         const unsigned f = small_ok ? (k == 0 ? 1u : (k == 1 ? 3u : 4u)) : k;
         const SegCtlView cv = seg_view_of(sj + blockIdx.y, par, (int)f);
         if (seeds && seg_unit_from_seeds(j, *P, cv, (int)f, seeds)) {
-            if (grp * SEG_UNC_SEEDS >= npairs) return;
-            seg_enum_unit_body<SEG_SEED_LANES, UNIT, SEG_UNC_SEEDS, true>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
+            if (grp * SEG_UNC_SEEDS_OF(UNIT) >= npairs) return;
+            seg_enum_unit_body<SEG_SEED_LANES, UNIT, SEG_UNC_SEEDS_OF(UNIT), true>(j, *P, cv, par, (int)f, (int)grp, seg_smem);
             return;
         }
         if (grp * SEG_UNC >= npairs) return;
@@ -301,7 +301,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         const size_t enum_lds = (size_t)SEG_SM_ENUM_NT(nt);
         if (b.unit == 1 && b.seeds && !b.seeded) {
             /* (round 6) small and mid-size batches: segment by segment, from seeds, through the unit enumeration's bodies */
-            const unsigned pairs = b.max_nseg * 4, nc_min = SEG_UNC_SEEDS < SEG_UNC ? SEG_UNC_SEEDS : SEG_UNC;
+            const unsigned pairs = b.max_nseg * 4, nc_min = SEG_UNC_SEEDS1 < SEG_UNC ? SEG_UNC_SEEDS1 : SEG_UNC;
             const unsigned perb = (pairs + nc_min - 1) / nc_min, pers = (pairs + SEG_UNC_SMALL_OF(1) - 1) / SEG_UNC_SMALL_OF(1);
             const unsigned ublocks = (small_ok ? 3 * perb + 2 * pers : SEG_NFILT * perb) + SEG_NFILT;
             hipLaunchKernelGGL(seg_k_enum_unit<1>, dim3(ublocks, n), dim3(SEG_UNT), (size_t)SEG_SM_ENUM_UNIT, stream, b.d_sj, b.d_params, par, perb, pers, 1);

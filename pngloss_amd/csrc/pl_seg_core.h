@@ -151,6 +151,13 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #endif
 #define SEG_UNIT_MIN_SEGS 680    /* the launcher enumerates in units when the batch's images have more segments than this between them (twelve frames of 1920 pixels; measured with two
                                     launch groups, profiles/r05_suite_groups.txt: 8 / 10 / 12 / 16 frames per segment 87 / 99 / 111 / 137 ms, in units 105 / 106 / 108 / 121) */
+/* round 6, batches whose (strength, bleed) pair has a seed set (SegParams::seed_n): between SEG_SEEDS1_MIN_SEGS and SEG_UNIT_MIN_SEGS_SEEDS segments they are enumerated
+ * segment by segment from seeds (seg_k_enum_unit<1>), beyond in units from seeds, below like one image (seg_k_enum: every segment from every state -- the shortest dependent
+ * path).  Measured, 1080p frames of 60 segments, ms per batch, [from every state per segment | per segment from seeds | units from seeds]: 2 frames 48.9 | 53.6 | -,
+ * 4: 60.7 | 60.7 | 92, 6: 73.1 | 65.4 | -, 8: 86.3 | 74.9 | 95.7, 11: 106 | 81.8 | 97.5, 12: - | 83.7 | 100.9, 16: - | 97.5 | 103.2, 20: - | 114 | ~108, 24: - | 132 | 113.8, 32: - | 166 | 123.5;
+ * the reference's suite as one batch (182 segments, flat content whose fixed points the seeds miss): 59.4 | 66.8 | - (profiles/r06_seeds.txt). */
+#define SEG_SEEDS1_MIN_SEGS 330
+#define SEG_UNIT_MIN_SEGS_SEEDS 1000
 #if !defined(SEG_UNC) && SEG_UNIT > 6
 #define SEG_UNC 7                /* (longer units: fewer pairs, so that their pixel records fit the 16 KB the workgroup's shared memory has for them) */
 #endif
@@ -160,6 +167,11 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #ifndef SEG_UNC_SEEDS
 #define SEG_UNC_SEEDS 16         /* (unit, channel) pairs per workgroup of the unit enumeration FROM SEEDS (SEG_SEED_LANES lanes a pair: two turns of eight pairs) */
 #endif
+#ifndef SEG_UNC_SEEDS1
+#define SEG_UNC_SEEDS1 8         /* ... and segment by segment (seg_k_enum_unit<1>): ONE turn of eight pairs -- what those batches pay for is the dependent path (measured, 1080p frames,
+                                    8 against 16 pairs: 2 / 6 / 11 / 16 frames 53.6 / 65.4 / 81.8 / 97.5 against 59.5 / 72.7 / 86.5 / 98.5 ms; 24 / 32: 132 / 166 against 128 / 160) */
+#endif
+#define SEG_UNC_SEEDS_OF(unit) ((unit) == 1 ? SEG_UNC_SEEDS1 : SEG_UNC_SEEDS)
 #ifndef SEG_UNT
 #define SEG_UNT 512              /* its threads (512 against 1024, 1080p frames: 157.7 against 161.4 ms at 32, 249.2 against 281.4 at 64, 460.6 against 511.3 at 128: the CU starts four workgroups at once instead of two) */
 #endif

@@ -145,7 +145,7 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
             for (int f = 0; f < SEG_NFILT; f++) {
                 const SegCtlView cv = seg_ctl_view(j, par, f);
                 if (seg_is_small(P, f)) { for (uint32_t g = 0; g * SEG_UNC_SMALL_OF(1) < npairs; g++) seg_enum_unit_body<SEG_NSS, 1, SEG_UNC_SMALL_OF(1)>(j, P, cv, par, f, (int)g, usm.data()); }
-                else if (seg_unit_from_seeds(j, P, cv, f, 1)) { for (uint32_t g = 0; g * SEG_UNC_SEEDS < npairs; g++) seg_enum_unit_body<SEG_SEED_LANES, 1, SEG_UNC_SEEDS, true>(j, P, cv, par, f, (int)g, usm.data()); }
+                else if (seg_unit_from_seeds(j, P, cv, f, 1)) { for (uint32_t g = 0; g * SEG_UNC_SEEDS1 < npairs; g++) seg_enum_unit_body<SEG_SEED_LANES, 1, SEG_UNC_SEEDS1, true>(j, P, cv, par, f, (int)g, usm.data()); }
                 else { for (uint32_t g = 0; g * SEG_UNC < npairs; g++) seg_enum_unit_body<SEG_NSP, 1, SEG_UNC>(j, P, cv, par, f, (int)g, usm.data()); }
             }
             for (int f = 0; f < SEG_NFILT; f++) seg_first_body<SEG_UNT, false>(j, P, seg_ctl_view(j, par, f), par, f, usm.data());

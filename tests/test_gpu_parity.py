@@ -520,14 +520,14 @@ def test_segment_engine_launch_groups_of_small_and_mixed_batches(torch_cuda, mon
 
 
 def test_engine_choice_on_batches_of_1080p_frames(torch_cuda, monkeypatch):
-    """Which row engine the library picks for n frames of 1920x1080 in one batch (no engine pinned): the segment engine up to ~116 such frames
-    (measured: 112 frames 361 against 372 ms, profiles/r05_engine_crossover.txt), one workgroup per image beyond -- and the bytes do not depend
+    """Which row engine the library picks for n frames of 1920x1080 in one batch (no engine pinned): the segment engine up to ~148 such frames
+    (round 6, units from seeds: 128 frames 325 ms against 373; round 5: 116), one workgroup per image beyond -- and the bytes do not depend
     on it: frames 0 and n-1 against the other engine's output of the same frames."""
     torch = torch_cuda
     monkeypatch.delenv("PNGLOSS_HIP_ENGINE", raising=False)
     base = [P.synth_rgba(1920, 1080, 0, i) for i in range(2)]
     ref = None
-    for n, want in [(112, "segment-parallel"), (120, "workgroup-per-image")]:
+    for n, want in [(136, "segment-parallel"), (164, "workgroup-per-image")]:
         ctx = P.HipContext()
         dev = [torch.from_numpy(base[i % 2].copy()).cuda() for i in range(n)]
         filt = [torch.zeros(1080, dtype=torch.uint8, device="cuda") for _ in range(n)]
