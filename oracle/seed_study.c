@@ -8,7 +8,11 @@
  * the start of the row, as the engine does:
  *   miss(K)   boundaries whose TRUE state is not among the states the seeds reach after K steps
  *   sets(K)   distinct states the seeds reach (how many lanes run on, how wide the dense tables must be)
- * usage: seed_study W H mode strength bleed [L]        (FS_FILE=raw rgba file instead of the generator)
+ * usage: seed_study W H mode strength bleed [L]        (FS_FILE=raw rgba file instead of the generator; KSET=a,b,c,d the four run-in lengths; ROWSTEP=n every n-th row;
+ *        VARIANT=0 seeds without carried terms, 1 (default) with the carried terms of the diff that explains the left byte, 2 / 3 a second / third family per diff -- the steady
+ *        state of flat regions; SHOWMISS=k lists the first misses at the k-th run-in length).
+ * Round 6 (profiles/r06_seed_study.txt): the same question for EXHAUSTIVE state sets (s = 19 b = 2): may the units of a batch start from ~47 seeds eight pixels in front of them
+ * instead of from all 253 states?  Photographic content: no miss in 10^4 .. 10^5 boundaries; flat regions hold fixed points the seeds miss (the engine falls back).
  */
 #include "pngloss_port.c"
 
@@ -16,7 +20,7 @@ extern void pngloss_synth_rgba(unsigned char *rgba, uint32_t width, uint32_t hei
 
 typedef struct { int left, cn, th; } cstate;
 #define NK 4
-static const int KS[NK] = { 8, 16, 24, 32 };
+static int KS[NK] = { 8, 16, 24, 32 };
 static unsigned long long n_bound[F_COUNT], n_miss[F_COUNT][NK], n_sets[F_COUNT][NK], max_set[F_COUNT][NK], n_seedless[F_COUNT], n_dirty[F_COUNT][NK];
 static int VARIANT = 1, CMAX, TMAX;
 static int ROWSTEP = 1;
@@ -146,6 +150,21 @@ static void study_row(const engine *e, uint32_t y, int f, unsigned s, long bleed
                             for (int cn = -CMAX; cn <= CMAX; cn++) for (int th = -(TMAX / tstep) * tstep; th <= TMAX; th += tstep) seeds[n++] = (cstate){ 0, cn, th };
                         }
                     }
+                    else if (VARIANT >= 2) {
+                        /* by the diff d of the boundary pixel: nothing carried in (fresh); the same diff in the pixels before (steady: flat regions sit in such fixed points);
+                         * VARIANT 3: also diff d before with diff 0 two before, ... */
+                        for (int d = -(int)s; d <= (int)s; d++) {
+                            int p[5]; port_sierra_split(d, bleed, p);
+                            const int fam = VARIANT == 2 ? 2 : VARIANT;
+                            for (int k = 0; k < fam; k++) {
+                                const int carry = k == 0 ? 0 : (k == 1 ? p[4] + p[1] : p[4]);
+                                const int thp = k == 0 ? 0 : (k == 1 ? p[1] : 0);
+                                const int l = centre + carry - d;
+                                if (l < 0 || l > 255) continue;
+                                seeds[n++] = (cstate){ l, p[4] + thp, p[1] };
+                            }
+                        }
+                    }
                     else for (int l = 0; l <= 255; l++) {
                         if (VARIANT == 0) { if (abs(l - centre) <= dmax) seeds[n++] = (cstate){ l, 0, 0 }; }
                         else {
@@ -158,6 +177,7 @@ static void study_row(const engine *e, uint32_t y, int f, unsigned s, long bleed
                     }
                 }
                 if (!n) n_seedless[f]++;
+                { static int once; if (!once && n > 1) { once = 1; fprintf(stderr, "seeds per boundary: %d\n", n); } }
                 for (int i = 0; i < n; i++)
                     for (uint32_t x = x0; x < b; x++) fstep(e, y, f, s, bleed, e->hist, x, c, &seeds[i]);
                 qsort(seeds, (size_t)n, sizeof(cstate), cmp_state);
@@ -167,6 +187,14 @@ static void study_row(const engine *e, uint32_t y, int f, unsigned s, long bleed
                     if (!cmp_state(&seeds[i], &truth)) hit = 1;
                 }
                 if (!hit) n_miss[f][ki]++;
+                if (!hit && getenv("SHOWMISS") && ki == atoi(getenv("SHOWMISS")) && n_miss[f][ki] <= 40) {
+                    const int cb = orig[(size_t)(b - 1) * bpp + c] + e->E0[(size_t)(b - 1) * 4 + pl];
+                    printf("MISS f=%d y=%u b=%u c=%u truth: dleft=%d cn=%d th=%d | reached:", f, y, b, c, truth.left - cb, truth.cn, truth.th);
+                    for (int i = 0; i < n; i++) if (i == 0 || cmp_state(&seeds[i], &seeds[i - 1])) printf(" (%d,%d,%d)", seeds[i].left - cb, seeds[i].cn, seeds[i].th);
+                    printf("  orig:");
+                    for (uint32_t x = b - 6; x < b; x++) printf(" %d", orig[(size_t)x * bpp + c]);
+                    printf("\n");
+                }
                 n_sets[f][ki] += (unsigned long long)u;
                 if ((unsigned long long)u > max_set[f][ki]) max_set[f][ki] = (unsigned long long)u;
             }
@@ -183,6 +211,7 @@ int main(int argc, char **argv)
     const long bleed = atol(argv[5]);
     if (argc > 6) SEGL = atoi(argv[6]);
     if (getenv("ROWSTEP")) ROWSTEP = atoi(getenv("ROWSTEP"));
+    if (getenv("KSET")) sscanf(getenv("KSET"), "%d,%d,%d,%d", &KS[0], &KS[1], &KS[2], &KS[3]);
     unsigned char *rgba = malloc((size_t)W * H * 4);
     if (getenv("FS_FILE")) { FILE *fp = fopen(getenv("FS_FILE"), "rb"); if (!fp || fread(rgba, 4, (size_t)W * H, fp) != (size_t)W * H) { fprintf(stderr, "cannot read %s\n", getenv("FS_FILE")); return 1; } fclose(fp); }
     else pngloss_synth_rgba(rgba, W, H, mode, 0);
