@@ -1409,7 +1409,9 @@ PLS_HD void seg_enum_small_body(const SegJob &j, const SegParams &P, const SegCt
 #define SEG_UN_K1MAX 4
 #define SEG_UN_SCRATCH (2 * SEG_UNT * 4 + 2 * SEG_UNT * 2 + SEG_UNT * 4 + SEG_UNT * 4)        /* hash tables (a turn's pairs x twice their lanes), dense ids, the turn's lists, one key a thread */
 #define SEG_UN_PHASE2 (SEG_UNPX * 8 + SEG_UPOOL * 4)      /* the pairs' records and the second list of distinct states (behind the unit's first segment) */
-#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UPOOL * 4 + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1) * 8 + 512 + (SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2))
+#define SEG_UN_SEEDX (SEG_UN_SCRATCH + (SEG_UNC_SEEDS > SEG_UNC_SEEDS1 ? SEG_UNC_SEEDS : SEG_UNC_SEEDS1) * (SEG_SEED_KMAX + 1) * 8 + (SEG_UNT / SEG_SEED_LANES) * 512)   /* (from seeds: the run-in's records and a turn's staged entry maps behind the scratch) */
+#define SEG_UN_REGION ((SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2) > SEG_UN_SEEDX ? (SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2) : SEG_UN_SEEDX)
+#define SEG_SM_ENUM_UNIT (SEG_TBL_WORDS * 4 + 2048 + SEG_UPOOL * 4 + SEG_UNC_SMALL * (SEG_UN_K1MAX + 1) * 8 + 512 + SEG_UN_REGION)
 /* set bits among bits [a, b) of a bit array */
 PLS_HD uint32_t seg_bits_count(const uint32_t *bits, uint32_t a, uint32_t b)
 {
@@ -1456,7 +1458,7 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     /* SEEDS: the run-in's records and the turn's entry maps, behind the first phase's scratch (the region is as large as the second phase's records) */
     SegPix *px1 = SEEDS ? (SegPix *)(keys + SEG_UNT) : px1_std;
     uint16_t *mapl = (uint16_t *)(px1 + NC * NP1);            /* (SEEDS) [CPR][256]: entry index -> dense id of the turn's pairs, staged here and stored coalesced */
-    static_assert(!SEEDS || (SEG_UN_SCRATCH + NC * (int)NP1 * 8 + CPR * 512 <= (SEG_UN_SCRATCH > SEG_UN_PHASE2 ? SEG_UN_SCRATCH : SEG_UN_PHASE2)), "the run-in's records and the staged maps fit behind the scratch");
+    static_assert(!SEEDS || (SEG_UN_SCRATCH + NC * (int)NP1 * 8 + CPR * 512 <= SEG_UN_REGION), "the run-in's records and the staged maps fit behind the scratch");
     static_assert(!SEEDS || LANES == SEG_SEED_LANES, "one lane per seed");
     const int KR = SEEDS ? seg_min(seg_max(P.seed_kin, 1), SEG_SEED_KMAX) : 0;
     /* second phase, in the same place: */

@@ -953,6 +953,39 @@ def test_engine_option_of_the_abi_pins_the_row_engine(torch_cuda, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("hooks", [dict(PNGLOSS_HIP_SEG_UNIT="1"), dict(PNGLOSS_HIP_SEG_UNIT="0", PNGLOSS_HIP_SEG_SEEDS1="1"), dict(PNGLOSS_HIP_SEG_UNIT="1", PNGLOSS_HIP_SEG_SEEDS="0"), dict()],
+                         ids=["units-from-seeds", "segments-from-seeds", "units-from-every-state", "library-choice"])
+def test_segment_engine_batches_from_seeds_match_the_oracle(torch_cuda, monkeypatch, hooks):
+    """Round 6: the enumeration of a batch starts FROM SEEDS with a run-in (pl_seg_core.h: seg_enum_unit_body<.., SEEDS>) -- in units (large batches) or segment by segment
+    (small and mid-size ones, seg_k_enum_unit<1>) -- instead of from every state.  Mixed batches pinned to each path, the round-5 path and the library's own choice:
+    photographic frames, noise, transparency, gray classes, and FLAT few-coloured content (the suite's tux and dice, whose fixed points the seeds miss: those images fall
+    back to the start from every state, seg_unit_from_seeds) -- every image against the CPU oracle, another strength / bleed pair with a seed set, NULL row_filters."""
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    for k, v in hooks.items():
+        monkeypatch.setenv(k, v)
+    g = U.load_npz("suite_small.npz")
+    suite = U.load_npz("suite_inputs.npz")
+    sets = [([P.synth_rgba(w, h, m, i) for i, (w, h, m) in enumerate([(1920, 28, 0), (1920, 28, 0), (1600, 24, 1), (1280, 30, 5), (1024, 26, 2), (900, 20, 3), (800, 22, 4), (1920, 18, 0),
+                                                                      (700, 28, 0), (641, 19, 1), (1919, 21, 0), (97, 30, 0), (33, 9, 5), (1, 5, 1)])], 19, 2),
+            ([np.ascontiguousarray(g["tux/in"]), np.ascontiguousarray(suite["dice"][:160]), np.ascontiguousarray(suite["lena"][:120]), P.synth_rgba(1920, 60, 0, 0),
+              P.synth_rgba(1920, 40, 0, 7), np.ascontiguousarray(suite["ssr"][:100]), P.synth_rgba(1500, 50, 5, 3), P.synth_rgba(1200, 64, 0, 9)], 19, 2),
+            ([P.synth_rgba(w, h, m, 3 + i) for i, (w, h, m) in enumerate([(1700, 20, 0), (1400, 24, 1), (1300, 16, 5), (1920, 22, 0), (960, 30, 2), (1100, 18, 4), (1800, 12, 0), (640, 25, 3)])], 12, 1)]
+    ctx = P.HipContext()
+    for imgs, s, b in sets:
+        dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]
+        filt = [torch.zeros(a.shape[0], dtype=torch.uint8, device="cuda") if i != 2 else None for i, a in enumerate(imgs)]
+        res = ctx.run([(d.data_ptr(), f.data_ptr() if f is not None else 0, a.shape[1], a.shape[0]) for d, f, a in zip(dev, filt, imgs)], s, b)
+        torch.cuda.synchronize()
+        for i, (a, d, f, r) in enumerate(zip(imgs, dev, filt, res)):
+            assert ctx.engine_info(i)["engine"] == "segment-parallel"
+            o1, f1 = U.run_port(a, s, b, filters=f is not None)
+            assert r["status"] == 0 and np.array_equal(d.cpu().numpy(), o1), (hooks, i, a.shape, s, b)
+            if f is not None:
+                assert np.array_equal(f.cpu().numpy(), f1), (hooks, i, a.shape, s, b)
+    ctx.close()
+
+
 CAMPAIGN = [("seg", 5000, 100, 601), ("wg", 5000, 100, 602), ("", 5000, 100, 603), ("lead", 1500, 30, 604), ("mix", 1500, 30, 605)]
 
 
