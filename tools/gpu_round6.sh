@@ -122,8 +122,9 @@ if has fuzz; then
 fi
 if has batch; then
   # batches: a kernel timeline of 32 frames of 1080p (two launch groups), n-frame curves on the segment engine, small and mixed batches in one process
-  bash tools/gpu_r5_timeline.sh 32 ${TAG}
-  { echo "# $STAMP"; cat $OUT/${TAG}_timeline_32.txt; } > $OUT/${TAG}_batch_timeline_32.txt; rm -f $OUT/${TAG}_timeline_32.txt
+  TAG=${TAG}_tl HEAD=${HEAD:-unknown} bash tools/gpu_r6_timeline.sh 32 64
+  for n in 32 64; do mv $OUT/${TAG}_tl_timeline_$n.txt $OUT/${TAG}_batch_timeline_$n.txt; done; rm -f $OUT/${TAG}_tl_prof.log
+  { echo "# $STAMP"; echo "# the first n frames of configs[3] as one batch through the synchronous entry point, three launch groups opted in (python tests/tools/gpu_rank_share.py; wall ms, best of 2; $BOX)"; for eng in seg wg; do echo "## PNGLOSS_HIP_ENGINE=$eng"; PNGLOSS_HIP_ENGINE=$eng python tests/tools/gpu_rank_share.py 1 2 4 6 8 11 16 24 32 48 64 96 128 2>&1 | grep -v amdgpu.ids; done; echo "## the library's choice"; python tests/tools/gpu_rank_share.py 128 144 160 192 256 2>&1 | grep -v amdgpu.ids; } > $OUT/${TAG}_rank_shares.txt
   { echo "# $STAMP"; echo "# n frames of 1920x1080 (generator mode 0, s=19 b=2) in one device-resident batch, engine ms (best of 2) from the library's events: tests/tools/gpu_seg_batch.py ($BOX)"; python tests/tools/gpu_seg_batch.py 1920 1080 1 2 4 8 16 32 64 128 256 2>&1 | grep -v amdgpu.ids; } > $OUT/${TAG}_batch_curve.txt
   { echo "# $STAMP"; echo "# python tests/tools/gpu_small_batches.py 3 ($BOX)"; python tests/tools/gpu_small_batches.py 3 2>&1 | grep -v amdgpu.ids; } > $OUT/${TAG}_small_batches.txt
 fi
