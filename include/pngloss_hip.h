@@ -288,7 +288,8 @@ void pngloss_hip_pinned_free(void *p);
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
  *            (batches), 4 = row statistics (every image of a batch at strength 0, where nothing is quantised and only the filter search of
- *            pngloss_image.c:201-287 is left: info[1] = rows).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model (wide images and small batches go to
+ *            pngloss_image.c:201-287 is left: info[1] = rows).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model -- calibrated once per device and process on a
+ *            small synthetic frame (the first batch of two or more images pays ~30 ms for it; PNGLOSS_HIP_CALIB=0 keeps the reference box's constants) -- (wide images and small batches go to
  *            the segment-parallel engine, narrow images and large batches to the other; state sets of up to 1024 chain states, i.e.
  *            most strength / bleed pairs, rows up to 8192 pixels); PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy|mix pins it (test hook).
  *   info[1]  row attempts (engine 3) / rows on the band-leader chains (engine 0)
@@ -296,7 +297,8 @@ void pngloss_hip_pinned_free(void *p);
  *   info[3]  rows finished serially (engine 3) / rows on the round-1 chains by the adaptive choice (engine 0)
  *   info[4]  rows in which candidate none was ruled out by its cost bound (engine 3)
  *   info[5]  segments whose entry state was in no enumerated set (engine 3): walked step by step by the chain kernel (seeded state sets), or the
- *            places where a row was broken off and resumed in an epoch (exhaustive state sets: next to never)
+ *            places where a row was broken off and resumed in an epoch (exhaustive state sets: next to never from every state; a batch whose units or segments start from
+ *            seeds -- round 6 -- breaks a row off where no seed reached its state and finishes it from every state)
  *   info[6]  launch groups the batch ran as (engine 3; see the option "launch_groups"), info[7] 1 when the call put a device-side wait for the engine on the
  *            caller's stream (the asynchronous entry's non-blocking variant), 0 when it waited on the host
  * No reference equivalent. */

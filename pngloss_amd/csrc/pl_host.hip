@@ -14,6 +14,8 @@
 #include "pl_seg.h"
 
 #include <chrono>
+#include <pthread.h>
+#include <sched.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +53,8 @@ struct PlHooks {
     int kin = -1;                /* PNGLOSS_HIP_KIN: run-in pixels of the seeded enumeration */
     int seg_seeds = -1;          /* PNGLOSS_HIP_SEG_SEEDS: 0 = units start from every state, as in round 5 (-1 / 1: from seeds where the pair has a seed set) */
     int seg_seeds1 = -1;         /* PNGLOSS_HIP_SEG_SEEDS1: 0 / 1 pins the per-segment enumeration from seeds (seg_k_enum_unit<1>; -1: batches of two or more images) */
+    int pin = -1;                /* PNGLOSS_HIP_PIN: 0 = the launch thread is not pinned to a CPU (-1 / 1: pinned when the affinity set has room, run_seg_engine) */
+    int calib = -1;              /* PNGLOSS_HIP_CALIB: 0 = the cost model that picks the row engine of a batch is not calibrated on this device (engine_calib) */
     int seed_kin = -1;           /* PNGLOSS_HIP_SEED_KIN: run-in pixels of the units' seeds (1 .. SEG_SEED_KMAX) */
     bool segprof = false;        /* PNGLOSS_HIP_SEGPROF: phase clocks inside the kernels (slows them down) */
     bool debug = false;          /* PNGLOSS_HIP_DEBUG */
@@ -70,6 +74,8 @@ struct PlHooks {
         h.kin = num("PNGLOSS_HIP_KIN", -1);
         h.seg_seeds = num("PNGLOSS_HIP_SEG_SEEDS", -1);
         h.seg_seeds1 = num("PNGLOSS_HIP_SEG_SEEDS1", -1);
+        h.pin = num("PNGLOSS_HIP_PIN", -1);
+        h.calib = num("PNGLOSS_HIP_CALIB", -1);
         h.seed_kin = num("PNGLOSS_HIP_SEED_KIN", -1);
         h.segprof = std::getenv("PNGLOSS_HIP_SEGPROF") != nullptr;
         h.debug = std::getenv("PNGLOSS_HIP_DEBUG") != nullptr;
@@ -83,6 +89,7 @@ struct PlHooks {
 struct pngloss_hip_ctx {
     int device = 0;
     PlHooks hooks;                   /* (from the environment, at creation) */
+    int pin_slot = 0;                /* which pair of CPUs of the affinity set this context's launch thread is pinned into: max(device, contexts created before it in the process) */
     int opt_launch_groups = 0;       /* pngloss_hip_set_option("launch_groups", "2" | "3" | "auto"): see run_seg_engine */
     /* one device arena, regrown on demand, carved per batch */
     char *d_ws = nullptr;
@@ -232,6 +239,25 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
     volatile uint32_t *words = ctx->h_seg_words;
     int rc = PNGLOSS_SUCCESS;
     if (hipSetDevice(ctx->device) != hipSuccess) rc = PNGLOSS_HIP_ERROR;
+    /* Round 6: the launch thread has a CPU of its own.  It must issue four launches every 45 - 100 us for as long as the engine runs; on a node every rank (or every context of
+     * pngloss_hip_multi) has one, next to the threads that stage images.  CPU (2 * slot + 1) of the process's affinity set, slot = the context's device ordinal or its serial
+     * number in the process, whichever is larger: eight ranks with one device each and eight contexts of one process get eight different CPUs; skipped when the set is too
+     * small for that, or with PNGLOSS_HIP_PIN=0.  (Measured on one box, eight contexts on one device: profiles/r06_host_side.txt: no measurable difference with 256 CPUs visible and a quota of 16 -- 181.56 against 181.62 ms for the headline frame, 1730 - 1751 against 1742 - 1796 ms for configs[3] on eight contexts of one device; all of it on TWO CPUs: 1938 ms.) */
+    if (ctx->hooks.pin != 0) {
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+            std::vector<int> cpus;
+            for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+            const size_t want = (size_t)(2 * ctx->pin_slot + 1);
+            if (cpus.size() >= 4 && want < cpus.size()) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[want], &one);
+                (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);       /* (a refusal is not an error: the thread stays where the scheduler puts it) */
+            }
+        }
+    }
     /* The engine's streams never wait for another stream ON THE DEVICE: streams share a few hardware queues, a queue is served in order,
      * and the callers' streams hold waits for the finished words -- with twelve contexts, engine j's attempts sat behind engine k's wait
      * for k's inputs, whose kernels sat behind caller j's wait for engine j.  So this thread waits for the inputs, on the host. */
@@ -459,6 +485,65 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     return PNGLOSS_SUCCESS;
 }
 
+/* ---- the cost model that picks a batch's row engine, calibrated per device ---------------------------------------------------------
+ * Its constants were fitted on one kind of box (MI355X, 256 CUs, performance level "auto").  Round 6 (the review's item): the first batch of two or more images whose engine is
+ * the library's to choose runs a small synthetic image (1024 x 32, photographic) three times on each engine through a context of its own -- ~30 ms, once per device and
+ * process -- and compares with what the reference box takes for it; the model's per-attempt floor and per-pixel cost are scaled by the ratios, its per-workgroup slope and its
+ * "one image per CU" terms by the device's CU count.  A dead band of 15 % around the reference ratio keeps the choice deterministic on boxes of the reference kind (the run
+ * varies by a few per cent); PNGLOSS_HIP_CALIB=0 skips it.  pngloss_hip_last_engine_info does not change: it reports what ran. */
+struct EngineCalib { double seg = 1.0, wg = 1.0, cus = 256.0; double seg_ms = 0, wg_ms = 0; bool done = false; };
+constexpr double CALIB_REF_SEG_MS = 2.40, CALIB_REF_WG_MS = 5.97;      /* (the reference box, profiles/r06_host_side.txt: min of three runs of the 1024 x 32 image, five processes: 2.39 .. 2.42 and 5.94 .. 6.04 ms) */
+std::mutex g_calib_mu;
+EngineCalib g_calib[32];
+thread_local bool t_calibrating = false;
+EngineCalib engine_calib(int device, bool debug)
+{
+    std::lock_guard<std::mutex> lk(g_calib_mu);
+    EngineCalib &c = g_calib[device & 31];
+    if (c.done || t_calibrating) return c;
+    c.done = true;                                       /* (whatever happens below: once) */
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c.cus = (double)cus;
+    t_calibrating = true;
+    pngloss_hip_ctx *tmp = pngloss_hip_create(device);
+    const uint32_t w = 1024, h = 32;
+    std::vector<uint32_t> img((size_t)w * h);
+    uint32_t lcg = 12345u;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            const uint32_t r = std::min(255u, x * 255u / w + ((lcg >> 8) & 7u)), g = std::min(255u, y * 255u / h + ((lcg >> 12) & 7u)), b = std::min(255u, (x + y) * 255u / (w + h) + ((lcg >> 16) & 7u));
+            img[(size_t)y * w + x] = r | (g << 8) | (b << 16) | ((255u - ((x ^ y) & 31u)) << 24);
+        }
+    void *d_img = nullptr, *d_f = nullptr;
+    bool ok = tmp && hipMalloc(&d_img, img.size() * 4) == hipSuccess && hipMalloc(&d_f, h) == hipSuccess;
+    double ms[2] = { 0, 0 };
+    for (int e = 0; e < 2 && ok; e++) {
+        ok = pngloss_hip_set_option(tmp, "engine", e == 0 ? "seg" : "wg") == PNGLOSS_SUCCESS;
+        double best = 1e30;
+        for (int rep = 0; rep < 3 && ok; rep++) {
+            ok = hipMemcpy(d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+            pngloss_hip_image_desc desc{ d_img, d_f, w, h };
+            pngloss_hip_result res{};
+            if (ok) ok = pngloss_hip_optimize_batch(tmp, &desc, 1, 19, 2, nullptr, &res) == PNGLOSS_SUCCESS && res.status == 0;
+            if (ok) best = std::min(best, pngloss_hip_last_engine_ms(tmp));
+        }
+        ms[e] = best;
+    }
+    if (d_img) (void)hipFree(d_img);
+    if (d_f) (void)hipFree(d_f);
+    if (tmp) pngloss_hip_destroy(tmp);
+    t_calibrating = false;
+    if (ok && ms[0] > 0 && ms[1] > 0) {
+        c.seg_ms = ms[0]; c.wg_ms = ms[1];
+        const double rs = ms[0] / CALIB_REF_SEG_MS, rw = ms[1] / CALIB_REF_WG_MS, ratio = rs / rw;
+        if (ratio < 0.85 || ratio > 1.0 / 0.85) { c.seg = std::min(2.0, std::max(0.5, rs)); c.wg = std::min(2.0, std::max(0.5, rw)); }
+    }
+    if (debug) std::fprintf(stderr, "pngloss_hip: engine calibration on device %d: %g CUs, 1024x32 frame: segment engine %.3f ms (reference %.2f), workgroup engine %.3f ms (reference %.2f) -> cost model scales %.2f / %.2f\n",
+                            device, c.cus, ms[0], CALIB_REF_SEG_MS, ms[1], CALIB_REF_WG_MS, c.seg, c.wg);
+    return c;
+}
+
 int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n, const uint32_t *forced_bpp,
             unsigned strength, long bleed, hipStream_t stream, const EmitTarget *emits = nullptr)
 {
@@ -530,12 +615,15 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         const bool allowed = !em || forced || std::strcmp(em, "auto") == 0 || std::strcmp(em, "rows") == 0;       /* "wg" / "lead" / "legacy": the one-workgroup-per-image engine */
         bool seg_ok = n && allowed && !use_rows && !hk.force_careful && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
+            EngineCalib cal;
+            if (!em && n >= 2 && hk.calib != 0 && !t_calibrating) cal = engine_calib(ctx->device, hk.debug);     /* (once per device and process; a pinned engine, one image or PNGLOSS_HIP_CALIB=0: the reference box's constants) */
+            const double cu_scale = 256.0 / cal.cus;
             const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
             /* round 5: a batch whose images have more than SEG_UNIT_MIN_SEGS segments between them is enumerated in UNITS, in two launch groups, with the
              * small workgroups of batches (run_seg_engine): an attempt then takes ~45 us + 0.015 us per workgroup-unit, but not less than ~95 us (the
              * dependent steps of a unit): 1080p frames 16 / 32 / 64 = 102 / 150 / 261 us measured (profiles/r05_unit_groups.txt) */
             const bool can_units = !seg_params.seeded && seg_params.ns <= SEG_NSP;
-            auto attempt_us = [&](double wgs, double segs, size_t k) {
+            auto attempt_us_ref = [&](double wgs, double segs, size_t k) {
                 const bool have_seeds = can_units && seg_params.seed_n > 0 && hk.seg_seeds != 0;
                 /* round 6, from seeds (per row of the tallest image, epochs included; 1080p frames, profiles/r06_seeds.txt): units 24 / 32 / 64 / 128 frames 105 / 114 / 168 / 301 us,
                  * segment by segment 6 / 11 / 16 frames 61 / 76 / 90 us -- 128 frames 325 ms against 373 on the other engine, the crossover near 148 */
@@ -546,7 +634,8 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 if (k >= 2 && !seg_params.seeded) return 35.0 + 0.026 * wgs;
                 return a_us + w_us * wgs;
             };
-            auto wg_cost = [&](size_t i) { return 0.18 * (double)images[i].width * (double)images[i].height; };
+            auto attempt_us = [&](double wgs, double segs, size_t k) { return cal.seg * attempt_us_ref(wgs * cu_scale, segs, k); };      /* (fewer CUs: every workgroup weighs more) */
+            auto wg_cost = [&](size_t i) { return cal.wg * 0.18 * (double)images[i].width * (double)images[i].height; };
             std::vector<size_t> order;
             for (size_t i = 0; i < n; i++)
                 if (images[i].width && images[i].height && images[i].width <= SEG_MAX_WIDTH) order.push_back(i);
@@ -558,12 +647,12 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 for (size_t i = 0; i < n; i++) wg_sum += wg_cost(i);
                 double seg_rows = 0, seg_wgs = 0, seg_segs = 0;
                 auto batch_us = [&](size_t k, double rows, double wgs, double wsum, double segs) {   /* the first k images of `order` on the segment engine */
-                    const double wg_us = k < order.size() ? std::max(wg_cost(order[k]), wsum / 256.0) : wsum / 256.0;
+                    const double wg_us = k < order.size() ? std::max(wg_cost(order[k]), wsum / cal.cus) : wsum / cal.cus;
                     const double seg_us = k ? rows * attempt_us(wgs, segs, k) : 0.0;
                     /* side by side only while the other engine leaves the segment engine CUs to run on: its workgroups are persistent and own a CU each (104 KB of
                      * LDS, every register) -- next to 200 and more of them the segment engine's launches wait until they are through: one after the other
                      * (measured: 512 frames of 1080p in one call, 130 of them sent to the segment engine by the model of before: 1034 ms against 2 x 375) */
-                    if (n - k > 192) return wg_us + seg_us;
+                    if ((double)(n - k) > 0.75 * cal.cus) return wg_us + seg_us;
                     return std::max(wg_us, seg_us);
                 };
                 double best = batch_us(0, 0, 0, wg_sum, 0);
@@ -915,6 +1004,7 @@ pngloss_hip_ctx *pngloss_hip_create(int device)
     if (!ctx) return nullptr;
     ctx->device = device;
     ctx->hooks = PlHooks::from_env();
+    { static std::atomic<int> serial{ 0 }; ctx->pin_slot = std::max(device, serial.fetch_add(1)); }
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return nullptr; }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { pngloss_hip_destroy(ctx); return nullptr; }

@@ -784,6 +784,38 @@ def test_three_launch_groups_are_opt_in_and_do_not_slow_a_later_asynchronous_bat
     assert g_default == 2 and g_three == 3 and w_after == 0, (g_default, g_three, w_after)     # three groups on request; the asynchronous entry then waits on the host
 
 
+def test_engine_cost_model_is_calibrated_once_per_process_and_pins_nothing(tmp_path):
+    """Round 6: the first batch of two or more images whose engine is the library's to choose times a small synthetic frame on both row engines (a context of its own, ~30 ms,
+    once per device and process) and scales the cost model by what it finds against the reference box (pl_host.hip:engine_calib; PNGLOSS_HIP_CALIB=0 skips it).  On a box of the
+    reference kind the ratio lies inside the dead band: scales 1.00 / 1.00, so the choice is the documented one; the bytes never depend on it.  One process: calibration line
+    printed once (PNGLOSS_HIP_DEBUG=1), both batches equal to the oracle; a second process with PNGLOSS_HIP_CALIB=0 prints none."""
+    script = tmp_path / "calib.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import pngloss_amd as P\n"
+        "from tests import util as U\n"
+        "for rnd in range(2):\n"
+        "    ctx = P.HipContext()\n"
+        "    imgs = [P.synth_rgba(640, 40, m, rnd) for m in (0, 1, 5)]\n"
+        "    dev = [torch.from_numpy(a.copy()).cuda() for a in imgs]; flt = [torch.zeros(40, dtype=torch.uint8, device='cuda') for _ in imgs]\n"
+        "    res = ctx.run([(d.data_ptr(), f.data_ptr(), 640, 40) for d, f in zip(dev, flt)], 19, 2); torch.cuda.synchronize()\n"
+        "    for a, d, f, r in zip(imgs, dev, flt, res):\n"
+        "        o, of = U.run_port(a, 19, 2)\n"
+        "        assert r['status'] == 0 and np.array_equal(d.cpu().numpy(), o) and np.array_equal(f.cpu().numpy(), of)\n"
+        "    ctx.close()\n"
+        "print('calib ok')\n" % U.ROOT)
+    env = dict(os.environ, PNGLOSS_HIP_DEBUG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PNGLOSS_HIP_ENGINE", None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "calib ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stderr.splitlines() if "engine calibration" in ln]
+    assert len(lines) == 1, lines
+    assert "256 CUs" in lines[0] and lines[0].rstrip().endswith("cost model scales 1.00 / 1.00"), lines[0]
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(env, PNGLOSS_HIP_CALIB="0"))
+    assert r.returncode == 0 and "calib ok" in r.stdout and "engine calibration" not in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_segment_engine_from_two_contexts_and_two_ranks_at_once(torch_cuda, monkeypatch, tmp_path):
     """What one box can show of a node: the SEGMENT engine (pinned) from two contexts of the C host at once (device list "0,0": two launch
     threads, two engine streams, two 150 KB chain kernels interleaved on one device), and from two processes (gloo ranks, one HipContext
