@@ -281,6 +281,11 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
                 rc = PNGLOSS_HIP_ERROR;
                 break;
             }
+            /* a group whose rows keep breaking off -- its images hold fixed points and cycles the seeds do not reach (flat content; real photographs break in ~5 % of their rows,
+             * the generator's frames in 0.3 %) -- goes back to the start from every state for the rest of the batch: more than one image-row in 25, sixteen to begin with (the
+             * device-side rule, seg_unit_from_seeds, does the same image by image inside the kernel; this one changes the KERNEL -- for small batches seg_k_enum instead of
+             * seg_k_enum_unit<1> with its slow exhaustive path).  Results do not depend on it; the count lags the launches by the look-ahead. */
+            if (gs.b[g].seeds && (uint64_t)words[2 * SEG_MAX_GROUPS + g] * 25u > (uint64_t)at * gs.b[g].n + 400u) gs.b[g].seeds = false;
             const hipError_t e = pl_seg_launch_attempt(gs.b[g], (int)launched[g], ctx->seg_gstream[g]);
             if (e != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(e)); rc = PNGLOSS_HIP_ERROR; break; }
             launched[g]++;
@@ -315,7 +320,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
                    size_t jobs_off, size_t params_off, hipStream_t stream, const uint32_t *d_sel, size_t n_wg, const PlEngineParams &prm)
 {
     const size_t n = list.size();                              /* the images of the batch this engine takes */
-    if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 8 * SEG_MAX_GROUPS > 64 ? 8 * SEG_MAX_GROUPS : 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (!ctx->h_seg_words) PL_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_words), 16 * SEG_MAX_GROUPS, hipHostMallocMapped | hipHostMallocCoherent));
     if (!ctx->seg_stream) {
         /* a stream of the HIGHEST priority: streams of one priority share a few hardware queues, and a queue whose head is a caller's
          * wait for the finished word holds up everything behind it -- the engine's attempts must never sit in such a queue (twelve
@@ -369,7 +374,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     void *d_words = nullptr;
     PL_CHECK(hipHostGetDevicePointer(&d_words, ctx->h_seg_words, 0));
     volatile uint32_t *words = ctx->h_seg_words;
-    for (int q = 0; q < 2 * SEG_MAX_GROUPS; q++) words[q] = 0;
+    for (int q = 0; q < 4 * SEG_MAX_GROUPS; q++) words[q] = 0;       /* ([2g], [2g + 1]: see seg_worker_main; [2 * SEG_MAX_GROUPS + g]: rows of group g the chain kernel broke off) */
     /* group g = images [gfirst[g], gfirst[g + 1]) of `list` (tallest first: enqueue): equal shares -- or, in a batch of two groups whose tallest image stands out, that
      * image alone and the others together.  A group takes as many attempts as its image with the most, and every attempt costs what ALL its images' workgroups
      * cost: the reference's suite as one batch (configs[2]) spent 71 ms on the 1199 attempts of its tallest image, a screenshot whose candidate none fails in 40 % of
@@ -413,6 +418,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         s.orig_rank = pj.orig_rank; s.cand = reinterpret_cast<uint32_t *>(pj.cand);
         s.err0 = reinterpret_cast<uint32_t *>(base + l.err0); s.err1 = reinterpret_cast<uint32_t *>(base + l.err1); s.rowcopy = reinterpret_cast<uint32_t *>(base + l.rowcopy);
         s.final_hist = pj.final_hist; s.result = pj.result; s.progress = pj.progress;
+        s.break_word = static_cast<uint32_t *>(d_words) + 2 * SEG_MAX_GROUPS + group_of(i);
         { const int g = group_of(i); s.done_counter = static_cast<uint32_t *>(d_words) + 2 * g; s.attempt_word = i == gfirst[g] ? static_cast<uint32_t *>(d_words) + 2 * g + 1 : nullptr; }
         s.ctl = reinterpret_cast<SegCtl *>(base + l.ctl); s.base = reinterpret_cast<uint32_t *>(base + l.base);
         s.H0 = reinterpret_cast<uint32_t *>(base + l.h0); s.acc = reinterpret_cast<SegAcc *>(base + l.acc);
@@ -443,7 +449,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         b.seeds = b.unit > 1 && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0;
         /* ... and a batch of two or more images below that size goes segment by segment from seeds, through the same bodies (seg_k_enum_unit<1>; PNGLOSS_HIP_SEG_SEEDS1=0 / 1 pins it) */
         if (b.unit == 1 && !params.seeded && ctx->h_seg_params.seed_n > 0 && ctx->hooks.seg_seeds != 0 && ctx->h_seg_params.ns <= SEG_NSP)
-            b.seeds = ctx->hooks.seg_seeds1 >= 0 ? ctx->hooks.seg_seeds1 != 0 : (n >= 2 && seg_total >= SEG_SEEDS1_MIN_SEGS);
+            b.seeds = ctx->hooks.seg_seeds1 >= 0 ? ctx->hooks.seg_seeds1 != 0 : (n >= 2 && seg_total >= SEG_SEEDS1_MIN_SEGS && seg_total >= (size_t)SEG_SEEDS1_MIN_SEGS_PER_IMAGE * n);
         b.tparts = (uint32_t)ctx->h_seg_params.tparts;
         b.enum_nt = (size_t)b.max_nseg * b.n <= SEG_ENUM_NT_SMALL_MAX_NSEG ? 512u : 1024u;     /* (the images of THIS group: gridDim.y of its launches) */
         if (ctx->hooks.enum_nt == 512 || ctx->hooks.enum_nt == 1024) b.enum_nt = (uint32_t)ctx->hooks.enum_nt;   /* test hook */
@@ -628,7 +634,7 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 /* round 6, from seeds (per row of the tallest image, epochs included; 1080p frames, profiles/r06_seeds.txt): units 24 / 32 / 64 / 128 frames 105 / 114 / 168 / 301 us,
                  * segment by segment 6 / 11 / 16 frames 61 / 76 / 90 us -- 128 frames 325 ms against 373 on the other engine, the crossover near 148 */
                 if (have_seeds && segs > SEG_UNIT_MIN_SEGS_SEEDS) return std::max(100.0, 35.0 + 0.00945 * wgs);
-                if (have_seeds && k >= 2 && segs >= SEG_SEEDS1_MIN_SEGS) return 43.0 + 0.0134 * wgs;
+                if (have_seeds && k >= 2 && segs >= SEG_SEEDS1_MIN_SEGS && segs >= (double)SEG_SEEDS1_MIN_SEGS_PER_IMAGE * (double)k) return 43.0 + 0.0134 * wgs;
                 if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(100.0, 28.0 + 0.0124 * wgs);   /* (three launch groups, validation in whole replay groups: 16 / 64 / 96 / 112 / 128 frames of 1080p 102 / 205 / 289 / 333 / 377 us: the segment engine up to 116 such frames -- measured: 112 frames 361 against 372 ms, 120 frames 385 against 372) */
                 /* (two or more images run as two launch sequences side by side: 4 / 8 / 12 frames of 1080p 58 / 80 / 102 us per attempt, profiles/r05_suite_groups.txt) */
                 if (k >= 2 && !seg_params.seeded) return 35.0 + 0.026 * wgs;

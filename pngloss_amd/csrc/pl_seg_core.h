@@ -157,6 +157,8 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
  * 4: 60.7 | 60.7 | 92, 6: 73.1 | 65.4 | -, 8: 86.3 | 74.9 | 95.7, 11: 106 | 81.8 | 97.5, 12: - | 83.7 | 100.9, 16: - | 97.5 | 103.2, 20: - | 114 | ~108, 24: - | 132 | 113.8, 32: - | 166 | 123.5;
  * the reference's suite as one batch (182 segments, flat content whose fixed points the seeds miss): 59.4 | 66.8 | - (profiles/r06_seeds.txt). */
 #define SEG_SEEDS1_MIN_SEGS 330
+#define SEG_SEEDS1_MIN_SEGS_PER_IMAGE 32    /* ... of images a thousand pixels wide on average: batches of NARROW images keep the start from every state (measured on the suite's photographs, 512 .. 768 pixels wide:
+                                               20 of them -- 392 segments -- 39.4 ms from every state, 47.4 segment by segment from seeds; 40: 61.6 / 57.8; profiles/r06_photo_batch.txt) */
 #define SEG_UNIT_MIN_SEGS_SEEDS 1000
 #if !defined(SEG_UNC) && SEG_UNIT > 6
 #define SEG_UNC 7                /* (longer units: fewer pairs, so that their pixel records fit the 16 KB the workgroup's shared memory has for them) */
@@ -327,6 +329,8 @@ struct SegJob {
     SEG_AS_GLB uint32_t *progress;       /* or null: host-visible word that receives the number of finished rows (-v display) */
     SEG_AS_GLB uint32_t *done_counter;   /* or null: host-visible word, +1 when this image is finished (the host stops enqueueing attempts) */
     SEG_AS_GLB uint32_t *attempt_word;   /* or null: host-visible word that receives the number of the attempt being started (launch throttle) */
+    SEG_AS_GLB uint32_t *break_word;     /* or null: host-visible word of the image's launch group, +1 for every row the chain kernel breaks off (the launch thread takes a group whose rows keep breaking
+                                            off the start from seeds: pl_host.hip:seg_worker_main) */
     SEG_AS_GLB SegCtl *ctl;              /* [3]: by attempt % 3, like base, H0, acc */
     SEG_AS_GLB uint32_t *base;           /* [3][5][256] bumps of the validated prefix [0, start_x) */
     SEG_AS_GLB uint32_t *H0;             /* [3][256] committed histogram */
@@ -2340,6 +2344,7 @@ PLS_HD void seg_chain_body(const SegJob &j, const SegParams &P, const SegCtlView
                         SEG_DEBUG_BREAK(f, c, sgb, estb, cv.y);
                         idxb[24]++;
                         PLS_ATOMIC_ADD(&j.self->nbreak, 1u);
+                        if (j.break_word) PLS_HOST_VISIBLE_ADD(j.break_word, 1u);
                         dnout[(size_t)sgb * 4] = (uint16_t)SEG_INVALID; entry[(size_t)sgb * 4] = estb;
                         const uint32_t xfail = (sgb + 1u) * SEG_L;
                         if ((kqb < ns || E > 1u) && xfail < W) {
