@@ -1077,6 +1077,42 @@ def test_randomised_parity_campaign(torch_cuda, monkeypatch, engine, n_small, n_
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("pin,seed", [(dict(PNGLOSS_HIP_SEG_UNIT="0", PNGLOSS_HIP_SEG_SEEDS1="1"), 611), (dict(PNGLOSS_HIP_SEG_UNIT="1"), 612)], ids=["segments-from-seeds", "units-from-seeds"])
+def test_randomised_parity_campaign_on_the_seeds_paths(torch_cuda, monkeypatch, pin, seed):
+    """The campaign's random cases through the enumeration FROM SEEDS (round 6), which the library itself only picks for batches of wide images: pinned here for every case --
+    single images and device batches of five mixed ones; strengths whose state set has no seed set run their usual path -- 3000 small and 60 large cases per pin against the
+    CPU oracle.  (Random content is what the seeds like least: noise, stripes, constant and saturated images are full of cycles they miss; the rows break, finish from every
+    state, images fall back -- and every byte must still be the reference's.)"""
+    import concurrent.futures as cf
+    torch = torch_cuda
+    monkeypatch.setenv("PNGLOSS_HIP_ENGINE", "seg")
+    for k, v in pin.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(seed)
+    cases = [U.fuzz_case(rng, False) for _ in range(3000)] + [U.fuzz_case(rng, True) for _ in range(60)]
+    U.port()
+    ctx = P.HipContext()
+    bad = []
+    with cf.ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as pool:
+        i = 0
+        while i < len(cases):
+            nb = 5 if i % 4 == 3 else 1
+            items = cases[i:i + nb]
+            s0, b0 = items[0][1], items[0][2]
+            futs = [pool.submit(U._run_rows, U.port().port_optimize_with_rows, it[0], s0, b0, True) for it in items]
+            dev = [torch.from_numpy(it[0].copy()).cuda() for it in items]
+            flt = [torch.zeros(it[0].shape[0], dtype=torch.uint8, device="cuda") for it in items]
+            res = ctx.run([(d.data_ptr(), f.data_ptr(), it[0].shape[1], it[0].shape[0]) for d, f, it in zip(dev, flt, items)], s0, b0)
+            torch.cuda.synchronize()
+            for k, (d, f, fu) in enumerate(zip(dev, flt, futs)):
+                o1, f1 = fu.result()
+                if res[k]["status"] != 0 or not (np.array_equal(o1, d.cpu().numpy()) and np.array_equal(f1, f.cpu().numpy())):
+                    bad.append((seed, i + k, items[k][0].shape, s0, b0))
+            i += len(items)
+    ctx.close()
+    assert not bad, bad[:10]
+
+
 def _configs3_frames(indices):
     return [P.synth_rgba(1920, 1080, 0, i) for i in indices]
 
