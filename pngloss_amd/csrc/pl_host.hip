@@ -401,8 +401,8 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         seg_total = segs;
         if (ctx->hooks.seg_unit >= 0) units = can && ctx->hooks.seg_unit != 0;
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
-        ctx->h_seg_params.tparts = units ? 1 : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
-        if (ctx->hooks.tparts == 1 || ctx->hooks.tparts == SEG_TPARTS) ctx->h_seg_params.tparts = ctx->hooks.tparts;   /* (timing / test hook) */
+        ctx->h_seg_params.tparts = units ? SEG_TPARTS_BATCH : SEG_TPARTS;     /* (batches: one control workgroup per candidate) */
+        if (ctx->hooks.tparts == 1 || ctx->hooks.tparts == SEG_TPARTS) ctx->h_seg_params.tparts = ctx->hooks.tparts == 1 ? SEG_TPARTS_BATCH : SEG_TPARTS;   /* (timing / test hook) */
         if (ctx->hooks.seed_kin >= 1 && ctx->hooks.seed_kin <= SEG_SEED_KMAX) ctx->h_seg_params.seed_kin = ctx->hooks.seed_kin;   /* (timing hook) */
     }
     SegGroups gs;

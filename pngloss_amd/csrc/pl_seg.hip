@@ -193,7 +193,7 @@ template __global__ void seg_k_enum_seeded<512>(const SegJob *__restrict__, cons
 template __global__ void seg_k_enum_seeded<1024>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
 template __global__ void seg_k_enum<512>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
 template __global__ void seg_k_enum<1024>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
-template __global__ void seg_k_ctl<1>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
+template __global__ void seg_k_ctl<SEG_TPARTS_BATCH>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned);
 template __global__ void seg_k_enum_unit<SEG_UNIT>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned, unsigned, int);
 template __global__ void seg_k_chain<false, SEG_CHAIN_THREADS_UNIT, true>(const SegJob *__restrict__, const SegParams *__restrict__, int);
 template __global__ void seg_k_replay<SEG_REPLAY_NT_BATCH>(const SegJob *__restrict__, const SegParams *__restrict__, int, unsigned);
@@ -225,7 +225,7 @@ hipError_t chain_attr()
     if (e == hipSuccess) e = pl_lds_optin((const void *)seg_k_chain<true, SEG_CHAIN_THREADS, false>, SEG_SM_CHAIN(SEG_CHAIN_CAP + 1), done_chain_s);
     static std::atomic<unsigned> done_ctl1{ 0 };
     if (e == hipSuccess && SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS)) > 65536) e = pl_lds_optin((const void *)seg_k_ctl<SEG_TPARTS>, SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS)), done_ctl);
-    if (e == hipSuccess && SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)) > 65536) e = pl_lds_optin((const void *)seg_k_ctl<1>, SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)), done_ctl1);
+    if (e == hipSuccess && SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS_BATCH)) > 65536) e = pl_lds_optin((const void *)seg_k_ctl<SEG_TPARTS_BATCH>, SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS_BATCH)), done_ctl1);
     return e;
 }
 static_assert(SEG_SM_REPLAY <= 65536 && SEG_SM_ENUM_NT(1024) <= 65536 && SEG_SM_ENUM_SEEDED(1024) <= 65536 && SEG_SM_ENUM_UNIT <= 65536, "these kernels are launched without an LDS opt-in");
@@ -291,7 +291,7 @@ hipError_t pl_seg_launch_attempt(const PlSegBatch &b, int attempt, hipStream_t s
         /* (the validation workgroups can be left out at COMPILE time only -- SEG_EXPERIMENT_NO_VAL_CODE, a timing experiment whose results are unvalidated;
          *  the shipped library has no run-time switch that changes what it computes) */
         const unsigned nctl = SEG_NFILT * b.tparts + 1 + b.max_ncommit, nval = SEG_EXPERIMENT_NO_VAL_CODE ? 0u : SEG_NFILT * b.max_ngrp * (SEG_GRP / SEG_VGRP_OF(b.tparts));
-        if (b.tparts == 1) hipLaunchKernelGGL(seg_k_ctl<1>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)), stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
+        if (b.tparts == SEG_TPARTS_BATCH) hipLaunchKernelGGL(seg_k_ctl<SEG_TPARTS_BATCH>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS_BATCH)), stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
         else hipLaunchKernelGGL(seg_k_ctl<SEG_TPARTS>, dim3(nctl + nval, n), dim3(SEG_THREADS), SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS)), stream, b.d_sj, b.d_params, par, nctl, b.max_ngrp);
     }
     {

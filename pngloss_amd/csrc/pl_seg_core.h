@@ -182,7 +182,10 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #define SEG_VGRP 8                /* segments per VALIDATION workgroup of ONE image (half a replay group: one decision per thread, twice the CUs) ... */
 #define SEG_VGRP_UNITS 16         /* ... and of batches composed in units (the whole replay group, two decisions per thread: half the workgroups, each with the same staging round trips and barriers --
                                      what a saturated GPU pays for; measured, 1080p frames in one batch, 8 against 16: 12 / 16 frames 229 / 300 -> 228 / 299 Mpx/s, 32: 469 -> 479, 64: 569 -> 600, 128: 602 -> 648) */
-#define SEG_VGRP_OF(tparts) ((tparts) == 1 ? SEG_VGRP_UNITS : SEG_VGRP)      /* (the launcher asks for one control workgroup per candidate exactly when it composes in units) */
+#ifndef SEG_TPARTS_BATCH
+#define SEG_TPARTS_BATCH 1        /* control workgroups per candidate for batches composed in units (SegParams::tparts there; SEG_TPARTS = 4 for one image) */
+#endif
+#define SEG_VGRP_OF(tparts) ((tparts) == SEG_TPARTS_BATCH ? SEG_VGRP_UNITS : SEG_VGRP)      /* (the launcher asks for one control workgroup per candidate exactly when it composes in units) */
 #define SEG_TPARTS 4              /* control kernel: workgroups that share the build of one candidate's decision tables */
 #define SEG_COMMIT_W 256           /* control kernel: pixels per commit workgroup */
 #define SEG_CTL_IMG_OF(P) (SEG_NFILT * (P).tparts)      /* blockIdx.x of the image-wide workgroup; the commit workgroups follow */

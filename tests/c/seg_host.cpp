@@ -59,8 +59,8 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     if (!seg_build_params(P, (int)strength, (int)bleed, getenv("SEG_HOST_SEEDED") != nullptr)) return 64;
     if (getenv("SEG_HOST_FORCE_FILTER")) P.engine_flags = (atoi(getenv("SEG_HOST_FORCE_FILTER")) + 1) << 8;
     if (getenv("SEG_HOST_FLAGS")) P.engine_flags |= atoi(getenv("SEG_HOST_FLAGS")) & 0xfe;   /* test hooks of the chain kernel (2: slow path, 4: wide stride) */
-    if (getenv("SEG_HOST_UNIT") && atoi(getenv("SEG_HOST_UNIT")) && !P.seeded && (P.ns <= SEG_NSP || atoi(getenv("SEG_HOST_UNIT")) > 1)) { P.unit = SEG_UNIT; P.tparts = 1; }
-    if (getenv("SEG_HOST_TPARTS")) P.tparts = atoi(getenv("SEG_HOST_TPARTS")) == 1 ? 1 : SEG_TPARTS;   /* enumeration in units, as the launcher asks for batches (seg_enum_unit_body) */
+    if (getenv("SEG_HOST_UNIT") && atoi(getenv("SEG_HOST_UNIT")) && !P.seeded && (P.ns <= SEG_NSP || atoi(getenv("SEG_HOST_UNIT")) > 1)) { P.unit = SEG_UNIT; P.tparts = SEG_TPARTS_BATCH; }
+    if (getenv("SEG_HOST_TPARTS")) P.tparts = atoi(getenv("SEG_HOST_TPARTS")) == 1 ? SEG_TPARTS_BATCH : SEG_TPARTS;   /* enumeration in units, as the launcher asks for batches (seg_enum_unit_body) */
     /* classify + pack into slots (what pl_classify / pl_repack do on the device) */
     bool gray = true, opaque = true;
     for (size_t i = 0; i < (size_t)W * H; i++) { const unsigned char *p = rgba + 4 * i; gray &= p[0] == p[1] && p[1] == p[2]; opaque &= p[3] == 255; }
@@ -123,10 +123,10 @@ extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, un
     for (;; attempt++) {
         if (attempt > max_attempts) { fprintf(stderr, "seg_host: no progress\n"); return 65; }
         const int par = attempt % 3, kv = (par + 2) % 3;
-        std::vector<unsigned char> cvsm((size_t)(P.tparts == 1 ? SEG_SM_CTLVAL_V(SEG_VGRP_OF(1)) : SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS))), 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
+        std::vector<unsigned char> cvsm((size_t)(P.tparts == SEG_TPARTS_BATCH ? SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS_BATCH)) : SEG_SM_CTLVAL_V(SEG_VGRP_OF(SEG_TPARTS))), 0x5A);       /* (the launch's LDS request: the sanitizer build sees an overrun) */
         for (int half = 0; half < 2; half++) {
-            if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG_OF(P) + 1 + ncommit; bx++) { if (P.tparts == 1) seg_ctl_body<1>(j, P, par, bx, cvsm.data()); else seg_ctl_body<SEG_TPARTS>(j, P, par, bx, cvsm.data()); } }
-            else if (P.tparts == 1) { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP_OF(1) < j.nseg; vg++) seg_post_body<SEG_VGRP_OF(1)>(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
+            if ((half == 0) != val_first) { for (int bx = 0; bx < SEG_CTL_IMG_OF(P) + 1 + ncommit; bx++) { if (P.tparts == SEG_TPARTS_BATCH) seg_ctl_body<SEG_TPARTS_BATCH>(j, P, par, bx, cvsm.data()); else seg_ctl_body<SEG_TPARTS>(j, P, par, bx, cvsm.data()); } }
+            else if (P.tparts == SEG_TPARTS_BATCH) { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP_OF(SEG_TPARTS_BATCH) < j.nseg; vg++) seg_post_body<SEG_VGRP_OF(SEG_TPARTS_BATCH)>(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
             else { for (int f = 0; f < SEG_NFILT; f++) for (uint32_t vg = 0; vg * SEG_VGRP_OF(SEG_TPARTS) < j.nseg; vg++) seg_post_body<SEG_VGRP_OF(SEG_TPARTS)>(j, P, seg_ctl_view(j, kv, f), kv, f, (int)vg, cvsm.data()); }
         }
         if (j.ctl[par].finished == 2u) break;
