@@ -405,7 +405,7 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         if (ctx->hooks.tparts == 1 || ctx->hooks.tparts == SEG_TPARTS) ctx->h_seg_params.tparts = ctx->hooks.tparts == 1 ? SEG_TPARTS_BATCH : SEG_TPARTS;   /* (timing / test hook) */
         if (ctx->hooks.seed_kin >= 1 && ctx->hooks.seed_kin <= SEG_SEED_KMAX) ctx->h_seg_params.seed_kin = ctx->hooks.seed_kin;   /* (timing hook) */
     }
-    SegGroups gs;
+    SegGroups gs{};                     /* (value-initialised: the per-group maxima below start from zero) */
     gs.n = ngroups;
     uint32_t max_h = 0;
     for (size_t i = 0; i < n; i++) {
