@@ -288,8 +288,8 @@ void pngloss_hip_pinned_free(void *p);
 /* What the row engine did for image `index` of the last finished batch (diagnostics; bench.py reports it):
  *   info[0]  engine: 3 = segment-parallel (the image spread over the whole GPU: few large images, latency), 0 = one workgroup per image
  *            (batches), 4 = row statistics (every image of a batch at strength 0, where nothing is quantised and only the filter search of
- *            pngloss_image.c:201-287 is left: info[1] = rows).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model -- calibrated once per device and process on a
- *            small synthetic frame (the first batch of two or more images pays ~30 ms for it; PNGLOSS_HIP_CALIB=0 keeps the reference box's constants) -- (wide images and small batches go to
+ *            pngloss_image.c:201-287 is left: info[1] = rows).  Chosen per batch by pngloss_hip_optimize_batch_async from a cost model -- fitted on the reference kind of box, scaled by the device's CU count;
+ *            PNGLOSS_HIP_CALIB=1 also calibrates it once per device and process on a small synthetic frame (~30 ms; off by default: the probe is sensitive to the clock governor) -- (wide images and small batches go to
  *            the segment-parallel engine, narrow images and large batches to the other; state sets of up to 1024 chain states, i.e.
  *            most strength / bleed pairs, rows up to 8192 pixels); PNGLOSS_HIP_ENGINE=seg|wg|lead|legacy|mix pins it (test hook).
  *   info[1]  row attempts (engine 3) / rows on the band-leader chains (engine 0)

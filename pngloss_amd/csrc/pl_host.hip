@@ -54,7 +54,7 @@ struct PlHooks {
     int seg_seeds = -1;          /* PNGLOSS_HIP_SEG_SEEDS: 0 = units start from every state, as in round 5 (-1 / 1: from seeds where the pair has a seed set) */
     int seg_seeds1 = -1;         /* PNGLOSS_HIP_SEG_SEEDS1: 0 / 1 pins the per-segment enumeration from seeds (seg_k_enum_unit<1>; -1: batches of two or more images) */
     int pin = -1;                /* PNGLOSS_HIP_PIN: 0 = the launch thread is not pinned to a CPU (-1 / 1: pinned when the affinity set has room, run_seg_engine) */
-    int calib = -1;              /* PNGLOSS_HIP_CALIB: 0 = the cost model that picks the row engine of a batch is not calibrated on this device (engine_calib) */
+    int calib = -1;              /* PNGLOSS_HIP_CALIB: 1 = the cost model that picks the row engine of a batch is calibrated on this device by a probe (engine_calib; off by default: see enqueue) */
     int seed_kin = -1;           /* PNGLOSS_HIP_SEED_KIN: run-in pixels of the units' seeds (1 .. SEG_SEED_KMAX) */
     bool segprof = false;        /* PNGLOSS_HIP_SEGPROF: phase clocks inside the kernels (slows them down) */
     bool debug = false;          /* PNGLOSS_HIP_DEBUG */
@@ -622,7 +622,12 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
         bool seg_ok = n && allowed && !use_rows && !hk.force_careful && pl_seg_supported(nullptr, 0, strength, bleed, &seg_params);
         if (seg_ok) {
             EngineCalib cal;
-            if (!em && n >= 2 && hk.calib != 0 && !t_calibrating) cal = engine_calib(ctx->device, hk.debug);     /* (once per device and process; a pinned engine, one image or PNGLOSS_HIP_CALIB=0: the reference box's constants) */
+            /* OPT-IN (PNGLOSS_HIP_CALIB=1) since it was measured inside bench.py: the probe is 2 - 6 ms of GPU work, and what it finds depends on what the process did before it
+             * (the clock governor follows the load: after the headline's steps the probe read the segment engine 1.3x slower against the other one than in a fresh process, the
+             * model sent 128 frames of 1080p to the wrong engine and the 256-frame batch lost 16 %: profiles/r06_host_side.txt).  A wrong calibration costs more than the constants
+             * of the reference box cost on a box of another kind; the CU count (deterministic) is always taken from the device. */
+            if (!em && n >= 2 && hk.calib > 0 && !t_calibrating) cal = engine_calib(ctx->device, hk.debug);
+            else { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) cal.cus = (double)cus; }
             const double cu_scale = 256.0 / cal.cus;
             const double a_us = seg_params.seeded ? 82.0 : 38.0, w_us = seg_params.seeded ? 0.05 : 0.032;   /* (round 4: an attempt is four launches: 49.5 us at 4096 pixels = 424 workgroups in these units, 46 at 1920, 69 at 8192) */
             /* round 5: a batch whose images have more than SEG_UNIT_MIN_SEGS segments between them is enumerated in UNITS, in two launch groups, with the

@@ -784,11 +784,11 @@ def test_three_launch_groups_are_opt_in_and_do_not_slow_a_later_asynchronous_bat
     assert g_default == 2 and g_three == 3 and w_after == 0, (g_default, g_three, w_after)     # three groups on request; the asynchronous entry then waits on the host
 
 
-def test_engine_cost_model_is_calibrated_once_per_process_and_pins_nothing(tmp_path):
-    """Round 6: the first batch of two or more images whose engine is the library's to choose times a small synthetic frame on both row engines (a context of its own, ~30 ms,
-    once per device and process) and scales the cost model by what it finds against the reference box (pl_host.hip:engine_calib; PNGLOSS_HIP_CALIB=0 skips it).  On a box of the
-    reference kind the ratio lies inside the dead band: scales 1.00 / 1.00, so the choice is the documented one; the bytes never depend on it.  One process: calibration line
-    printed once (PNGLOSS_HIP_DEBUG=1), both batches equal to the oracle; a second process with PNGLOSS_HIP_CALIB=0 prints none."""
+def test_engine_cost_model_calibration_is_opt_in_and_changes_no_bytes(tmp_path):
+    """Round 6: with PNGLOSS_HIP_CALIB=1 the first batch of two or more images whose engine is the library's to choose times a small synthetic frame on both row engines (a
+    context of its own, ~30 ms, once per device and process) and scales the cost model by what it finds against the reference box (pl_host.hip:engine_calib).  It is OFF by
+    default: measured inside bench.py, a probe of a few milliseconds reads the clock governor's mood as much as the box (profiles/r06_host_side.txt).  One process with the
+    switch: the calibration line is printed once (PNGLOSS_HIP_DEBUG=1), both batches equal the oracle whatever it found; a process without it prints none."""
     script = tmp_path / "calib.py"
     script.write_text(
         "import sys, numpy as np, torch\n"
@@ -807,12 +807,12 @@ def test_engine_cost_model_is_calibrated_once_per_process_and_pins_nothing(tmp_p
         "print('calib ok')\n" % U.ROOT)
     env = dict(os.environ, PNGLOSS_HIP_DEBUG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("PNGLOSS_HIP_ENGINE", None)
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    env.pop("PNGLOSS_HIP_CALIB", None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(env, PNGLOSS_HIP_CALIB="1"))
     assert r.returncode == 0 and "calib ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [ln for ln in r.stderr.splitlines() if "engine calibration" in ln]
-    assert len(lines) == 1, lines
-    assert "256 CUs" in lines[0] and lines[0].rstrip().endswith("cost model scales 1.00 / 1.00"), lines[0]
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(env, PNGLOSS_HIP_CALIB="0"))
+    assert len(lines) == 1 and "256 CUs" in lines[0] and "cost model scales" in lines[0], lines
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "calib ok" in r.stdout and "engine calibration" not in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
 
 
