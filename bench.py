@@ -269,8 +269,8 @@ def batch_ctx(P, device):
     ctx.set_option("launch_groups", "3")
     global _CALIB_WARMED
     if not _CALIB_WARMED:
-        # the library calibrates its engine cost model on the first batch of two or more images of a process (~30 ms, once per device: pl_host.hip:engine_calib): a warm-up,
-        # like the headline's --warmup steps -- two tiny frames here, so that no timed leg carries it
+        # one-time costs of a process's first batch (the engine's streams and launch thread; with PNGLOSS_HIP_CALIB=1 also the ~30 ms probe that calibrates the engine cost
+        # model, pl_host.hip:engine_calib): a warm-up, like the headline's --warmup steps -- two tiny frames here, so that no timed leg carries them
         import torch
         tiny = [torch.from_numpy(P.synth_rgba(96, 8, 0, i)).cuda() for i in range(2)]
         ctx.run([(t.data_ptr(), 0, 96, 8) for t in tiny], STRENGTH, BLEED)
