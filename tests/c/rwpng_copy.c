@@ -1,6 +1,6 @@
 /* tests/c/rwpng_copy.c -- test driver for the rwpng surface: decode a PNG to RGBA8 and write it back with a given
  * per-row filter policy, WITHOUT touching the pixels.  Compiled twice by tests/test_cli_host.py: against our
- * pngloss_amd/cli/rwpng.c and (where /root/reference exists) against the reference's rwpng.c; both must emit the same
+ * pngloss_amd/cli/png_bridge.c (the rwpng.h surface) and (where /root/reference exists) against the reference's rwpng.c; both must emit the same
  * bytes.   usage: rwpng_copy in.png out.png policy strip      policy: -1 = NULL filters, 0..4 = that filter on every row,
  * 5 = rows cycle none,sub,up,avg,paeth */
 #include <stdio.h>

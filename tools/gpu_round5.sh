@@ -122,7 +122,7 @@ if has fuzz; then
 fi
 if has batch; then
   # batches: a kernel timeline of 32 frames of 1080p (two launch groups), n-frame curves on the segment engine, small and mixed batches in one process
-  bash tools/gpu_r5_timeline.sh 32 ${TAG}
+  bash tools/archive_r5/gpu_r5_timeline.sh 32 ${TAG}
   { echo "# $STAMP"; cat $OUT/${TAG}_timeline_32.txt; } > $OUT/${TAG}_batch_timeline_32.txt; rm -f $OUT/${TAG}_timeline_32.txt
   { echo "# $STAMP"; echo "# n frames of 1920x1080 (generator mode 0, s=19 b=2) in one device-resident batch, engine ms (best of 2) from the library's events: tests/tools/gpu_seg_batch.py ($BOX)"; python tests/tools/gpu_seg_batch.py 1920 1080 1 2 4 8 16 32 64 128 256 2>&1 | grep -v amdgpu.ids; } > $OUT/${TAG}_batch_curve.txt
   { echo "# $STAMP"; echo "# python tests/tools/gpu_small_batches.py 3 ($BOX)"; python tests/tools/gpu_small_batches.py 3 2>&1 | grep -v amdgpu.ids; } > $OUT/${TAG}_small_batches.txt
