@@ -156,6 +156,14 @@ def test_seg_engine_bodies_clean_under_asan_and_ubsan(tmp_path):
         "    rc = lib.seg_host_optimize(out.ctypes.data, w, h, f.ctypes.data, s, b, st.ctypes.data)\n"
         "    want, wf = U.run_port(img, s, b)\n"
         "    assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf), (w, h, m, s, b)\n"
+        "import os\n"
+        "for unit in ('1', '0'):\n"      # round 6: the enumeration FROM SEEDS, in units and segment by segment (its run-in records and staged maps live behind the first phase's scratch)
+        "    os.environ['SEG_HOST_UNIT'] = unit; os.environ['SEG_HOST_SEEDS'] = '1'\n"
+        "    for (w, h, m, s, b) in [(700, 10, 0, 19, 2), (1920, 6, 0, 19, 2), (333, 7, 3, 19, 2), (33, 5, 5, 7, 3), (513, 8, 5, 19, 2), (2100, 3, 1, 12, 1), (8192, 2, 0, 19, 2)]:\n"
+        "        img = P.synth_rgba(w, h, m, 0); out = img.copy(); f = np.zeros(h, np.uint8); st = np.zeros(8, np.uint32)\n"
+        "        rc = lib.seg_host_optimize(out.ctypes.data, w, h, f.ctypes.data, s, b, st.ctypes.data)\n"
+        "        want, wf = U.run_port(img, s, b)\n"
+        "        assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf), ('seeds', unit, w, h, m, s, b)\n"
         "print('sanitized ok')\n") % (U.ROOT, str(so))
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
