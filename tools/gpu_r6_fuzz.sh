@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 { echo "# $(python -c 'import pngloss_amd as P; print("source_digest=" + P.source_digest())') head=${HEAD:-unknown}"
   echo "# randomised parity campaign against the CPU oracle (tests/tools/gpu_fuzz.py: random shapes, contents, strengths 0..255, bleeds 1..32767, both row_filters modes, device batches of 5 mixed images)"
-  for seed in 61 62; do
+  for seed in ${FUZZ_SEEDS:-61 62}; do
     echo "## FUZZ_ENGINES=seg,,seg,mix  python tests/tools/gpu_fuzz.py 150 $seed"; FUZZ_ENGINES=seg,,seg,mix timeout 400 python tests/tools/gpu_fuzz.py 150 $seed 2>&1 | grep -v amdgpu.ids | tail -3
     echo "## FUZZ_ENGINES=seg,  python tests/tools/gpu_fuzz.py 120 $seed big"; FUZZ_ENGINES=seg, timeout 400 python tests/tools/gpu_fuzz.py 120 $seed big 2>&1 | grep -v amdgpu.ids | tail -3
     echo "## segments from seeds pinned (PNGLOSS_HIP_SEG_UNIT=0 PNGLOSS_HIP_SEG_SEEDS1=1)  FUZZ_ENGINES=seg python tests/tools/gpu_fuzz.py 150 $seed"; PNGLOSS_HIP_SEG_UNIT=0 PNGLOSS_HIP_SEG_SEEDS1=1 FUZZ_ENGINES=seg timeout 400 python tests/tools/gpu_fuzz.py 150 $seed 2>&1 | grep -v amdgpu.ids | tail -3
