@@ -397,7 +397,10 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
         for (size_t i = 0; i < n; i++) segs += (ctx->h_jobs[list[i]].width + SEG_L - 1) / SEG_L;
         const bool can = !params.seeded && params.ns <= SEG_NSP;       /* (state sets of one chunk of lanes: with more, the distinct states of a workgroup's pairs outgrow its lanes) */
         const bool have_seeds = can && params.seed_n > 0 && ctx->hooks.seg_seeds != 0;
-        bool units = can && segs > (have_seeds ? (size_t)SEG_UNIT_MIN_SEGS_SEEDS : (size_t)SEG_UNIT_MIN_SEGS);     /* (with seeds the per-segment enumeration stays ahead up to sixteen 1080p frames: pl_seg_core.h) */
+        /* (with seeds the per-segment enumeration stays ahead up to sixteen 1080p frames: pl_seg_core.h -- where it applies: batches of NARROW images, which it does not take, go to units from
+         *  the round-5 size on: 40 photographs of 512 .. 768 pixels, 784 segments, 54.8 ms in units against 62.4 per segment from every state) */
+        const bool seeds1_fit = have_seeds && n >= 2 && segs >= SEG_SEEDS1_MIN_SEGS && segs >= (size_t)SEG_SEEDS1_MIN_SEGS_PER_IMAGE * n;
+        bool units = can && segs > (seeds1_fit ? (size_t)SEG_UNIT_MIN_SEGS_SEEDS : (size_t)SEG_UNIT_MIN_SEGS);
         seg_total = segs;
         if (ctx->hooks.seg_unit >= 0) units = can && ctx->hooks.seg_unit != 0;
         ctx->h_seg_params.unit = units ? SEG_UNIT : 1;
@@ -638,8 +641,9 @@ int enqueue(pngloss_hip_ctx *ctx, const pngloss_hip_image_desc *images, size_t n
                 const bool have_seeds = can_units && seg_params.seed_n > 0 && hk.seg_seeds != 0;
                 /* round 6, from seeds (per row of the tallest image, epochs included; 1080p frames, profiles/r06_seeds.txt): units 24 / 32 / 64 / 128 frames 105 / 114 / 168 / 301 us,
                  * segment by segment 6 / 11 / 16 frames 61 / 76 / 90 us -- 128 frames 325 ms against 373 on the other engine, the crossover near 148 */
-                if (have_seeds && segs > SEG_UNIT_MIN_SEGS_SEEDS) return std::max(100.0, 35.0 + 0.00945 * wgs);
-                if (have_seeds && k >= 2 && segs >= SEG_SEEDS1_MIN_SEGS && segs >= (double)SEG_SEEDS1_MIN_SEGS_PER_IMAGE * (double)k) return 43.0 + 0.0134 * wgs;
+                const bool seeds1_fit = have_seeds && k >= 2 && segs >= SEG_SEEDS1_MIN_SEGS && segs >= (double)SEG_SEEDS1_MIN_SEGS_PER_IMAGE * (double)k;
+                if (have_seeds && segs > (seeds1_fit ? SEG_UNIT_MIN_SEGS_SEEDS : SEG_UNIT_MIN_SEGS)) return std::max(100.0, 35.0 + 0.00945 * wgs);
+                if (seeds1_fit) return 43.0 + 0.0134 * wgs;
                 if (can_units && segs > SEG_UNIT_MIN_SEGS) return std::max(100.0, 28.0 + 0.0124 * wgs);   /* (three launch groups, validation in whole replay groups: 16 / 64 / 96 / 112 / 128 frames of 1080p 102 / 205 / 289 / 333 / 377 us: the segment engine up to 116 such frames -- measured: 112 frames 361 against 372 ms, 120 frames 385 against 372) */
                 /* (two or more images run as two launch sequences side by side: 4 / 8 / 12 frames of 1080p 58 / 80 / 102 us per attempt, profiles/r05_suite_groups.txt) */
                 if (k >= 2 && !seg_params.seeded) return 35.0 + 0.026 * wgs;

@@ -229,6 +229,7 @@ typedef SEG_AS_LDS uint16_t *seg_lds_u16;
 #endif
 #define SEG_KIN 32                /* most run-in pixels of the seeded enumeration (SegParams::kin: 16 .. 32 by the size of the carried terms) */
 #define SEG_SEED_LANES 64         /* lanes (most seeds) per (unit, channel) pair of the unit enumeration from seeds */
+#define SEG_SEED_LONG_AFTER 2u      /* rows an image has had broken off before its run-ins get half as long again */
 #define SEG_SEED_KMAX 16          /* most run-in pixels there (SegParams::seed_kin) */
 #define SEG_EH 512                /* slots of a segment's entry hash (per channel); a key lives in the SEG_EHW slots from its bucket's first */
 #define SEG_EHW 8
@@ -1467,7 +1468,10 @@ PLS_HD void seg_enum_unit_body(const SegJob &j, const SegParams &P, const SegCtl
     uint16_t *mapl = (uint16_t *)(px1 + NC * NP1);            /* (SEEDS) [CPR][256]: entry index -> dense id of the turn's pairs, staged here and stored coalesced */
     static_assert(!SEEDS || (SEG_UN_SCRATCH + NC * (int)NP1 * 8 + CPR * 512 <= SEG_UN_REGION), "the run-in's records and the staged maps fit behind the scratch");
     static_assert(!SEEDS || LANES == SEG_SEED_LANES, "one lane per seed");
-    const int KR = SEEDS ? seg_min(seg_max(P.seed_kin, 1), SEG_SEED_KMAX) : 0;
+    /* the run-in: P.seed_kin pixels (8) -- and half as many again for an image that has had rows broken off (SegJob::nbreak): real photographs lose the true state at a boundary in
+     * ~1e-3 of the cases after 8 pixels and a quarter of that after 12 (oracle/seed_study.c on the suite's lena: sub 17 -> 4 of 23 040, paeth 5 -> 2), the generator's frames next to never
+     * either way, and the longer run-in costs every workgroup 1 - 3 % */
+    const int KR = SEEDS ? seg_min(seg_max(j.nbreak >= SEG_SEED_LONG_AFTER ? P.seed_kin + P.seed_kin / 2 : P.seed_kin, 1), SEG_SEED_KMAX) : 0;
     /* second phase, in the same place: */
     SegPix *px = (SegPix *)(misc + 128);                      /* [NC][NPX]: all records of a pair */
     uint32_t *pool2 = (uint32_t *)(px + SEG_UNPX);            /* [SEG_UPOOL] the states that are still distinct behind the unit's first segment, at the pairs' places of the first list */
