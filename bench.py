@@ -528,8 +528,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     engine_ms = []
+    step_wall_ms = []
     for i in range(args.warmup, nrun):
+        ts = time.perf_counter()
         e, _ = step(i)
+        step_wall_ms.append((time.perf_counter() - ts) * 1e3)
         engine_ms.append(e)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -618,7 +621,7 @@ def main():
         line = {
             "metric": "Mpixels/s (filter+quantise path), 4096x4096 RGBA8 s=19; bit-exact vs ref",
             "value": round(value, 4), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "step_ms_rank0": [round(v, 2) for v in step_wall_ms], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: one 4096x4096 synthetic RGBA8 frame per GPU "
                                    "(Appendix B generator mode 0, frame=rank), strength 19, bleed 2, "
