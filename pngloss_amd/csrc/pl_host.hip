@@ -1700,7 +1700,7 @@ const char *pngloss_hip_version(void)
 #ifdef PL_DEBUG_FORCE_FILTER
     return "pngloss_hip 0.5 DEBUGGING BUILD -DPL_DEBUG_FORCE_FILTER=" PL_STR(PL_DEBUG_FORCE_FILTER) ": one candidate wins every row, results are NOT the reference's (gfx950)";
 #else
-    return "pngloss_hip 0.5 (gfx950; row engines: segment-parallel v3 (units, launch groups) + band-leader v2 + row statistics (strength 0); seam: pngloss_image.h:14-29)";
+    return "pngloss_hip 0.5 (gfx950; row engines: segment-parallel v4 (units and segments from seeds, launch groups) + band-leader v2 + row statistics (strength 0); seam: pngloss_image.h:14-29)";
 #endif
 }
 
