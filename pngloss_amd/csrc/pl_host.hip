@@ -494,12 +494,12 @@ int run_seg_engine(pngloss_hip_ctx *ctx, const PlJob *d_jobs, const std::vector<
     return PNGLOSS_SUCCESS;
 }
 
-/* ---- the cost model that picks a batch's row engine, calibrated per device ---------------------------------------------------------
- * Its constants were fitted on one kind of box (MI355X, 256 CUs, performance level "auto").  Round 6 (the review's item): the first batch of two or more images whose engine is
- * the library's to choose runs a small synthetic image (1024 x 32, photographic) three times on each engine through a context of its own -- ~30 ms, once per device and
- * process -- and compares with what the reference box takes for it; the model's per-attempt floor and per-pixel cost are scaled by the ratios, its per-workgroup slope and its
- * "one image per CU" terms by the device's CU count.  A dead band of 15 % around the reference ratio keeps the choice deterministic on boxes of the reference kind (the run
- * varies by a few per cent); PNGLOSS_HIP_CALIB=0 skips it.  pngloss_hip_last_engine_info does not change: it reports what ran. */
+/* ---- the cost model that picks a batch's row engine: an OPTIONAL calibration per device (PNGLOSS_HIP_CALIB=1) ------------------------------
+ * Its constants were fitted on one kind of box (MI355X, 256 CUs, performance level "auto").  Round 6 (the review's item): with the switch, the first batch of two or more images
+ * whose engine is the library's to choose runs a small synthetic image (1024 x 32, photographic) three times on each engine through a context of its own -- ~30 ms, once per
+ * device and process -- and compares with what the reference box takes for it; the model's per-attempt floor and per-pixel cost are scaled by the ratios (dead band 15 %).
+ * OFF by default (enqueue says why: a probe that short reads the clock governor).  What is always taken from the device is its CU count: the model's per-workgroup slope and its
+ * "one image per CU" terms.  pngloss_hip_last_engine_info does not change: it reports what ran. */
 struct EngineCalib { double seg = 1.0, wg = 1.0, cus = 256.0; double seg_ms = 0, wg_ms = 0; bool done = false; };
 constexpr double CALIB_REF_SEG_MS = 2.40, CALIB_REF_WG_MS = 5.97;      /* (the reference box, profiles/r06_host_side.txt: min of three runs of the 1024 x 32 image, five processes: 2.39 .. 2.42 and 5.94 .. 6.04 ms) */
 std::mutex g_calib_mu;

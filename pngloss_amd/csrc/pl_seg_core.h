@@ -17,6 +17,10 @@
  *                                 1024 states in chunks of 256 lanes); the trajectories merge within a few pixels, so after 4 steps
  *                                 the distinct states (a few dozen) are given dense ids and only they run on.  Out: entry state ->
  *                                 dense id, dense id -> exit state, dense id -> state at every quarter of the segment (checkpoints);
+ *                                 BATCHES enumerate in units of three segments (seg_enum_unit_body), and since round 6 a unit -- or, for small batches, a
+ *                                 segment -- is not started from every state but from SEEDS with a run-in of eight pixels (one per left byte within reach of
+ *                                 the data): what they have become at its first pixel is its entry set; a row whose true state none of them reached is
+ *                                 broken off there by the chain and finishes from every state (costs attempts, never bytes: see VALIDATE);
  *   CHAIN      (seg_chain_body)   the dense transition tables of consecutive segments are composed from the row's true start
  *                                 state: one table lookup per segment instead of 32 dependent pixel steps -- this is where the
  *                                 serial chain of W steps shrinks;
@@ -33,7 +37,7 @@
  *   CONTROL    (seg_ctl_body)     winner (strict <, pngloss_image.c:257), strength retry (:266-274), commit (:277-308),
  *                                 decision tables of the next row.
  *
- * One "attempt" = these five kernels; all state lives in device memory, so the host only enqueues attempts (no data-dependent
+ * One "attempt" = these steps, four launches since round 4 (the validation rides in the control kernel's launch, one attempt behind); all state lives in device memory, so the host only enqueues attempts (no data-dependent
  * host control flow, no in-kernel grid barrier: a kernel boundary is the cheapest grid-wide sync on this machine).
  *
  * This header is compiled twice: by hipcc into the kernels of pl_seg.hip, and by g++ into tests/c/seg_host.cpp, which runs the
