@@ -52,6 +52,20 @@ extern "C" int seg_host_describe(unsigned strength, long bleed, int32_t *out)
     return ok ? 0 : 64;
 }
 
+/* the seed set of the unit enumeration from seeds (round 6): out = { seed_n, seed_kin, ns, dmax }, states[i] = (delta, cn, th) of seed i */
+extern "C" int seg_host_seeds(unsigned strength, long bleed, int32_t *out, int32_t *states)
+{
+    static SegParams P;
+    if (!seg_build_params(P, (int)strength, (int)bleed)) return 64;
+    out[0] = P.seed_n; out[1] = P.seed_kin; out[2] = P.ns; out[3] = P.dmax;
+    for (int i = 0; i < P.seed_n; i++) {
+        if (P.seed_idx[i] >= P.ns) return 65;
+        const uint32_t w = P.st_pack[P.seed_idx[i]];
+        states[3 * i] = (int)(w & 255u) - 128; states[3 * i + 1] = (int)((w >> 8) & 255u) - 128; states[3 * i + 2] = (int)((w >> 16) & 255u) - 128;
+    }
+    return 0;
+}
+
 extern "C" int seg_host_optimize(unsigned char *rgba, uint32_t W, uint32_t H, unsigned char *row_filters, unsigned strength, long bleed, uint32_t *stats)
 {
     if (!W || !H) return 0;

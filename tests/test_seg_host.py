@@ -246,6 +246,33 @@ def test_seg_engine_segments_from_seeds_match_oracle(monkeypatch, w, h, mode, s,
     assert rc == 0 and np.array_equal(out, want) and np.array_equal(f, wf)
 
 
+def test_seed_sets_of_the_unit_enumeration():
+    """The seeds a unit starts from (pl_seg_core.h:seg_build_exhaustive, round 6): one member of the exhaustive state list per left byte within reach of the data (delta = -dmax ..
+    dmax, each once), with the carried terms of the diff that explains it when as little as possible was carried into the boundary pixel -- for |delta| <= s exactly the split of
+    -delta (optimize_state.c:445-467: rem, threes).  s = 19 b = 2: 47 of 253 states; no seed set where the reach does not fit 64 lanes, the set has more than 255 states, or it is seeded anyway."""
+    import ctypes as C
+    lib = U.seg_host_lib()
+    lib.seg_host_seeds.argtypes = [C.c_uint, C.c_long, C.c_void_p, C.c_void_p]
+    lib.seg_host_seeds.restype = C.c_int
+
+    def seeds(s, b):
+        out = np.zeros(4, np.int32); st = np.zeros(3 * 64, np.int32)
+        assert lib.seg_host_seeds(s, b, out.ctypes.data, st.ctypes.data) == 0
+        return [int(v) for v in out], st.reshape(64, 3)[: out[0]]
+
+    (n, kin, ns, dmax), st = seeds(19, 2)
+    assert (n, kin, ns, dmax) == (47, 8, 253, 23)
+    assert sorted(int(d) for d in st[:, 0]) == list(range(-23, 24))
+    for delta, cn, th in st:
+        if abs(delta) <= 19:
+            d = int(-delta) // 2 if -delta >= 0 else -(int(delta) // 2)          # truncating division by the bleed divider
+            t = int(d / 16); d -= 4 * t; h = int(d / 8); d -= 2 * h; f = int(d * 2 / 9); d -= 2 * f; v = int(d / 2); d -= v
+            assert (cn, th) == (d, h), (delta, cn, th)
+    for (s, b), want in {(7, 3): True, (12, 1): True, (31, 8): True, (20, 2): False, (40, 2): False, (40, 8): False, (85, 1): False, (20, 1): True}.items():
+        (n, kin, ns, dmax), _ = seeds(s, b)
+        assert (n > 0) == (want and 2 * dmax + 1 <= 64 and 0 < ns <= 255), (s, b, n, ns, dmax)
+
+
 def test_seg_engine_units_from_seeds_cost_few_attempts_and_a_stuck_row_one_break(monkeypatch):
     """What a seed set that misses a state costs is attempts, and the count is pinned: on photographic rows the seeds find every entry state (as many attempts as the
     start from every state, +-2); the 60-row frame of the generator has ONE row whose alpha channel -- a sawtooth of period 32 -- keeps candidate sub in a cycle no seed
