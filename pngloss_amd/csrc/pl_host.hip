@@ -267,6 +267,7 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
     auto t_last = std::chrono::steady_clock::now();
     uint32_t seen[SEG_MAX_GROUPS] = {};
     int idle = 0;
+    long lead_sum = 0, lead_n = 0, lead_min = 1 << 30, lead_low = 0;
     for (;;) {
         if (rc != PNGLOSS_SUCCESS) break;
         bool all_done = true, any_launched = false;
@@ -286,6 +287,7 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
              * device-side rule, seg_unit_from_seeds, does the same image by image inside the kernel; this one changes the KERNEL -- for small batches seg_k_enum instead of
              * seg_k_enum_unit<1> with its slow exhaustive path).  Results do not depend on it; the count lags the launches by the look-ahead. */
             if (gs.b[g].seeds && (uint64_t)words[2 * SEG_MAX_GROUPS + g] * 25u > (uint64_t)at * gs.b[g].n + 400u) gs.b[g].seeds = false;
+            if (launched[g] >= 64) { const long lead = launched[g] - (long)at; lead_sum += lead; lead_n++; if (lead < lead_min) lead_min = lead; if (lead <= 2) lead_low++; }   /* (PNGLOSS_HIP_DEBUG: how far ahead of the device the launches run) */
             const hipError_t e = pl_seg_launch_attempt(gs.b[g], (int)launched[g], ctx->seg_gstream[g]);
             if (e != hipSuccess) { std::fprintf(stderr, "pngloss_hip: launching a row attempt failed: %s\n", hipGetErrorString(e)); rc = PNGLOSS_HIP_ERROR; break; }
             launched[g]++;
@@ -310,6 +312,9 @@ void seg_worker_main(pngloss_hip_ctx *ctx, SegGroups gs, long max_attempts)
         for (int g = 0; g < gs.n; g++) words[2 * g] = (uint32_t)gs.b[g].n;
         for (int g = 0; g < gs.n; g++) (void)hipStreamSynchronize(ctx->seg_gstream[g]);
     }
+    if (ctx->hooks.debug && lead_n)
+        std::fprintf(stderr, "pngloss_hip: launch thread: %d group(s), %ld launches of an attempt; attempts queued ahead of the device when launching: average %.1f, least %ld, at most two ahead in %ld launches (look-ahead %ld)\n",
+                     gs.n, lead_n, (double)lead_sum / (double)lead_n, lead_min, lead_low, lookahead);
     long mx = 0;
     for (int g = 0; g < gs.n; g++) mx = std::max(mx, launched[g]);
     ctx->seg_attempts = mx;
