@@ -133,3 +133,24 @@ def test_inflater_match_whose_destination_wraps_onto_its_source(dist):
     z, want = _far_match_stream(dist)
     rc, out = run(z, len(want))
     assert rc == 0 and out == want
+
+
+def test_inflater_takes_every_path():
+    """The decoder's counters (tests/c/inflate_host.cpp: PLI_STAT): a photograph-like stream goes through rounds of several sets, runs of literals, plain matches and codes longer
+    than the direct tables; long matches and matches at the window's end take the general path (the cases above) -- and every one of them equals zlib."""
+    lib = inflate_lib()
+    lib.inflate_host_stats.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(5)
+    # a skewed alphabet (codes from 2 to 15 bits) with repeats: literals, matches, long codes
+    vals = np.minimum(255, rng.geometric(0.06, 400000)).astype(np.uint8)
+    data = bytearray(vals.tobytes())
+    for i in range(0, len(data) - 4000, 3000):
+        data[i + 1000:i + 1000 + 40] = data[i:i + 40]
+    data = bytes(data)
+    st = (C.c_ulonglong * 8)()
+    lib.inflate_host_stats(st)
+    rc, out = run(_z(data, level=6), len(data))
+    assert rc == 0 and out == data
+    lib.inflate_host_stats(st)
+    rounds, sets, lits, matches, mbytes, longs, runs = [int(v) for v in st[:7]]
+    assert rounds > 1000 and sets > 2 * rounds and lits > 100000 and matches > 50 and mbytes >= 40 * 50 and longs > 100 and runs > 1000, list(st)

@@ -20,7 +20,15 @@ def make(rng):
 t0 = time.time(); n = 0; bad = 0
 ctx = P.HipContext()
 import torch
+# FUZZ_WATCHDOG=seconds: a case that takes longer than that gets its number and every thread's Python stack printed, and the process ends (a hang then names its case and the call it sits in)
+WATCHDOG = float(os.environ.get("FUZZ_WATCHDOG", "0"))
+if WATCHDOG:
+    import faulthandler
 while time.time() - t0 < budget:
+    if WATCHDOG:
+        faulthandler.cancel_dump_traceback_later()
+        with open("gpurun_out/fuzz_current_case.txt", "w") as fh: fh.write(f"{n} seed {sys.argv[2] if len(sys.argv) > 2 else 1234} t={time.time() - t0:.1f}\n")
+        faulthandler.dump_traceback_later(WATCHDOG, exit=True)
     # the row engine is pinned case by case (the variable is read per call): by default every other case the band-leader chains (no
     # adaptive fallback to the round-1 chains on slow rows); FUZZ_ENGINES="seg,mix," cycles through the named ones ("" = the library's choice)
     engines = os.environ.get("FUZZ_ENGINES", ",lead").split(",")
@@ -53,5 +61,6 @@ while time.time() - t0 < budget:
             np.save(f"gpurun_out/fuzz_fail_{n}.npy", img)
             print("MISMATCH", n, img.shape, s, b, filt, int((o1 != o2).sum()), flush=True)
     n += 1
+if WATCHDOG: faulthandler.cancel_dump_traceback_later()
 print(f"fuzz: {n} cases in {time.time() - t0:.0f} s, {bad} mismatches")
 sys.exit(1 if bad else 0)
