@@ -2,8 +2,8 @@
  * pl_inflate.hip -- the inflate of a window's PNG files on the device: one wave per zlib stream (pl_inflate_core.h has the decoder and says
  * what it replaces: zlib under libpng's png_read_image, /root/reference/src/rwpng.c:179-400).  The streams of a window are independent,
  * so the serial bit stream of one file costs latency, not throughput: ~10 MB/s of scanlines for a lone wave on photographs, 30 - 40 on flat content (round 6: rounds of speculative
- * look-ups by all lanes, the chain followed in scalar registers; 3.3 MB/s before; profiles/r06_inflate.txt), 62 KB of shared memory a stream (32 KB window, 16 KB staged input,
- * tables) = two streams per CU, 512 in flight on the device: 4.4 GB/s of scanlines in aggregate.
+ * look-ups by all lanes, the chain followed in scalar registers; 3.3 MB/s before; profiles/r06_inflate.txt), 50 KB of shared memory a stream (32 KB window, 4 KB staged input,
+ * tables) = three streams per CU, 768 in flight on the device: 8 GB/s of scanlines in aggregate.
  */
 #include "pl_inflate.h"
 

@@ -13,7 +13,7 @@
  *               written when the next reader of the window comes up (settle); everything else -- longer codes, long matches, the block's end, whatever is wrong -- takes a
  *               general path that also words the errors.  What a lone wave pays for is dependent steps and taken branches (~10 cycles an instruction as measured), not
  *               arithmetic: the layout of that loop was measured (profiles/r06_inflate.txt).
- *   all lanes   input staging (the compressed bytes come through a 16 KB buffer in shared memory), table construction (a symbol a lane), stored blocks, and the way out:
+ *   all lanes   input staging (the compressed bytes come through a 4 KB buffer in shared memory), table construction (a symbol a lane), stored blocks, and the way out:
  *               the 32 KB window lives in shared memory and leaves for device memory in 4 KB pieces, 64 bytes a lane, with the piece's share of the Adler-32 (RFC 1950)
  *               computed on the way.
  *   lane 0      block headers (a dynamic block's code lengths), the zlib header and trailer.
@@ -76,7 +76,10 @@ static inline uint32_t pli_brev32_host(uint32_t v) { uint32_t r = 0; for (int i 
 #endif
 #define PLI_WIN 32768u            /* the window (RFC 1951: distances up to 32768) */
 #define PLI_PIECE 4096u           /* what leaves the window at a time */
-#define PLI_IN 16384u             /* staged input */
+#ifndef PLI_IN
+#define PLI_IN 4096u              /* staged input (4 KB against 16: 50 KB of shared memory a stream instead of 62 = THREE streams a CU; one stream alone 10.0 MB/s either way, 768 files
+                                     of 1280x720 in one call 452 ms against 813: profiles/r06_inflate.txt) */
+#endif
 #ifndef PLI_LBITS
 #define PLI_LBITS 11             /* (10 against 11, the suite's files one stream at a time: 9.1 / 9.4 / 8.7 / 14.6 MB/s against 9.2 / 9.5 / 9.5 / 15.9 for barbara / lena / ssr / tenko: profiles/r06_inflate.txt) */
 #endif

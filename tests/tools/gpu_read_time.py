@@ -27,8 +27,11 @@ def png_of(img):
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
 
 
-frames = [P.synth_rgba(W, H, 0, i) for i in range(n)]
+# READ_DISTINCT=k: only k distinct files, repeated (the aggregate of many streams without compressing hundreds of frames first)
+distinct = min(n, int(os.environ.get("READ_DISTINCT", n)))
+frames = [P.synth_rgba(W, H, 0, i) for i in range(distinct)]
 files = [png_of(f) for f in frames]
+files = [files[i % distinct] for i in range(n)]
 zbytes = sum(len(L.parse_png(f)["zstream"]) for f in files[:1]) * n
 ctx = P.HipContext()
 ctx.png_decode_device(files[:2])                      # runtime, code objects

@@ -7,8 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 { echo "# $(python -c 'import pngloss_amd as P; print("source_digest=" + P.source_digest())') head=${HEAD:-unknown}"
   echo "## python -m pytest tests/test_png_read.py -m gpu -q"; timeout 900 python -m pytest tests/test_png_read.py -m gpu -q 2>&1 | tail -3
-  for n in ${INFL_N:-1 32 256 512}; do
-    echo "## python tests/tools/gpu_read_time.py $n 1280 720 16"; timeout 600 python tests/tools/gpu_read_time.py $n 1280 720 16 2>&1 | grep -v amdgpu.ids | tail -4
+  for n in ${INFL_N:-1 32 256 512 768}; do
+    echo "## READ_DISTINCT=32 python tests/tools/gpu_read_time.py $n 1280 720 16"; READ_DISTINCT=32 timeout 600 python tests/tools/gpu_read_time.py $n 1280 720 16 2>&1 | grep -v amdgpu.ids | tail -4
   done
   echo "## python tests/tools/gpu_inflate_suite.py"; timeout 600 python tests/tools/gpu_inflate_suite.py 2>&1 | grep -v amdgpu.ids | tail -14
   echo "## one 4096x4096 file"; timeout 600 python tests/tools/gpu_read_time.py 1 4096 4096 16 2>&1 | grep -v amdgpu.ids | tail -2
