@@ -250,3 +250,25 @@ def test_device_inflate_match_whose_destination_wraps_onto_its_source():
         want = np.stack([g, g, g, np.full_like(g, 255)], axis=2)
         assert np.array_equal(_device_bytes(fr[0][0], w * h * 4).reshape(h, w, 4), want), dist
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_inflate_more_streams_than_the_device_holds():
+    """900 streams in one call: three a CU are in flight (768 on 256 CUs), the others follow as workgroups end.  The 78 fixture files over and over, their scanlines compressed
+    again at levels 1 / 6 / 9 in turn (other block structures, other code sets), every frame against the real reference reader's pixels."""
+    import zlib
+    fx = U.png_read_fixtures()
+    n = 900
+    files, zs, want = [], [], []
+    cache = {}
+    for i in range(n):
+        k, lvl = i % len(fx), (1, 6, 9)[(i // len(fx)) % 3]
+        if (k, lvl) not in cache:
+            cache[(k, lvl)] = zlib.compress(L.parse_png(fx[k][1])["scanlines"], lvl)
+        files.append(fx[k][1]); zs.append(cache[(k, lvl)]); want.append(fx[k][2])
+    ctx = P.HipContext()
+    fr, st, rc = ctx.png_decode_device_z(files, zstreams=zs)
+    assert rc == 0 and not any(st) and len(fr) == n
+    for i, ((ptr, w, h), wn) in enumerate(zip(fr, want)):
+        assert np.array_equal(_device_bytes(ptr, w * h * 4).reshape(h, w, 4), wn), (i, fx[i % len(fx)][0])
+    ctx.close()
