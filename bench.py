@@ -460,6 +460,70 @@ def run_batch_saturating(P, S, torch, ctx_factory, rank, world, barrier):
     return total, eng, recs, info
 
 
+def run_read_side(P, torch, device):
+    """SURVEY.md section 8 (f.2), the read side's inflate on the device (pngloss_hip_png_decode_batch_device_z, pl_inflate_core.h: one wave per zlib stream, three streams a CU):
+    one 1280x720 RGBA file alone = MB/s of scanlines per stream; 768 such files in one call = the aggregate.  The files are made here (generator mode 0, PNG filter `sub` on every
+    row, zlib level 6; 8 distinct ones, repeated); both times have the same call WITHOUT the inflate (scanlines up + inverse filters + expansion) taken off; the first and the last
+    frame are read back and compared with the generator's pixels.  Informational: not the headline, not a baseline."""
+    import ctypes as C
+    import struct
+    import zlib
+    import numpy as np
+    from pngloss_amd import lib as L
+    W, H, DISTINCT, N = 1280, 720, 8, 768
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+
+    frames = [P.synth_rgba(W, H, 0, i) for i in range(DISTINCT)]
+    parsed = []
+    for img in frames:
+        rows = img.reshape(H, W * 4).astype(np.int16)
+        sub = rows.copy(); sub[:, 4:] -= rows[:, :-4]
+        raw = np.concatenate([np.full((H, 1), 1, np.uint8), (sub & 255).astype(np.uint8)], axis=1).tobytes()
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+        parsed.append(L.parse_png(png))
+    lib = P.hip_lib()
+    lib.pngloss_hip_png_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(L.PngSource), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+    lib.pngloss_hip_png_decode_batch_device_z.argtypes = [C.c_void_p, C.POINTER(L.PngZSource), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+    hip = C.CDLL([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0])
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    ctx = P.HipContext(device)
+    out = {"workload": f"the device inflate (read side, SURVEY 8 f.2): {W}x{H} RGBA PNG files (generator mode 0, filter sub, zlib level 6; {DISTINCT} distinct), one alone and {N} in one call, "
+                       "file bytes -> RGBA8 frames in device memory; times are the call with the inflate minus the same call from inflated scanlines", "unit_per_stream": "MB/s of scanlines",
+           "unit_aggregate": "GB/s of scanlines"}
+    try:
+        ok = True
+        for n in (1, N):
+            src = (L.PngSource * n)(); zsrc = (L.PngZSource * n)()
+            for i in range(n):
+                p = parsed[i % DISTINCT]
+                src[i] = L.PngSource(p["scanlines"], W, H, 6, 8, None, 0, None, 0, None)
+                zsrc[i] = L.PngZSource(p["zstream"], len(p["zstream"]), W, H, 6, 8, None, 0, None, 0)
+            ptrs = (C.c_void_p * n)(); st = (C.c_int * n)()
+            best_d = best_z = 1e9
+            for rep in range(2):
+                t0 = time.perf_counter(); rc1 = lib.pngloss_hip_png_decode_batch_device(ctx._ctx, src, n, ptrs, st, None)
+                t1 = time.perf_counter(); rc2 = lib.pngloss_hip_png_decode_batch_device_z(ctx._ctx, zsrc, n, ptrs, st, None)
+                t2 = time.perf_counter()
+                ok = ok and rc1 == 0 and rc2 == 0 and not any(st[i] for i in range(n))
+                best_d = min(best_d, t1 - t0); best_z = min(best_z, t2 - t1)
+            for i in (0, n - 1):                       # (the frames of the last call: the one with the inflate)
+                got = np.zeros(W * H * 4, np.uint8)
+                ok = ok and hip.hipMemcpy(got.ctypes.data, ptrs[i], got.size, 2) == 0 and np.array_equal(got.reshape(H, W, 4), frames[i % DISTINCT])
+            infl = max(1e-9, best_z - best_d)
+            scan = H * (W * 4 + 1)
+            if n == 1:
+                out["per_stream"] = round(scan / 1e6 / infl, 2); out["one_file_ms"] = round(infl * 1e3, 1)
+            else:
+                out["aggregate"] = round(n * scan / 1e9 / infl, 2); out["files"] = n; out["call_ms"] = round(best_z * 1e3, 1); out["call_without_inflate_ms"] = round(best_d * 1e3, 1)
+        out["frames_match_the_generator"] = bool(ok)
+    finally:
+        ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -693,6 +757,10 @@ def main():
                     line[key] = fn(P, torch, lambda: batch_ctx(P, local_rank), golden)
                 except Exception as exc:          # never lose the headline to a side leg
                     line[key] = {"error": repr(exc)}
+            try:
+                line["read_side"] = run_read_side(P, torch, local_rank)
+            except Exception as exc:
+                line["read_side"] = {"error": repr(exc)}
         if batch is not None:
             bt, brecs, engs = batch
             want = {e["frame"]: e for e in golden["synthetic"] if (e["width"], e["height"]) == (BATCH_W, BATCH_H)}
