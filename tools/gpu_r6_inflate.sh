@@ -13,7 +13,7 @@ cd $R
   echo "## python tests/tools/gpu_inflate_suite.py"; timeout 600 python tests/tools/gpu_inflate_suite.py 2>&1 | grep -v amdgpu.ids | tail -14
   echo "## one 4096x4096 file"; timeout 600 python tests/tools/gpu_read_time.py 1 4096 4096 16 2>&1 | grep -v amdgpu.ids | tail -2
   echo "## rocprofv3 --kernel-trace --stats -- python tests/tools/gpu_read_time.py 32 1280 720 16"
-  rm -rf $OUT/infl_prof; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/infl_prof -o infl -- python tests/tools/gpu_read_time.py 32 1280 720 16 > /dev/null 2>&1
+  rm -rf $OUT/infl_prof; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/infl_prof -o infl -- python tests/tools/gpu_read_time.py 32 1280 720 16 > /dev/null 2>&1
   python - <<'P'
 import csv, glob, os
 for f in glob.glob(os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/infl_prof/**/*kernel_stats.csv", recursive=True):
